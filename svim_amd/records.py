@@ -1,0 +1,493 @@
+"""Alignment records: a pysam-free stand-in for the accessors SVIM's COLLECT step uses.
+
+SVIM reads alignments through pysam (htslib).  pysam is not part of this image, and the hot
+path only needs a handful of record accessors, so this module provides
+
+* ``AlignedSegment``  - duck type with the pysam attribute names COLLECT touches
+  (reference call sites: src/svim/SVIM_COLLECT.py:47,50,72-90,108,113,143-145,
+  src/svim/SVIM_intra.py:37-39,47, src/svim/SVIM_inter.py:30-46,85,91);
+* ``AlignmentFile``   - SAM text / BAM (BGZF) reader exposing ``fetch(until_eof=True)``,
+  ``getrname``/``get_reference_name``, ``get_tid``, ``references``, ``header`` as used at
+  src/svim/SVIM_COLLECT.py:11,79,133 and src/svim/svim:91-104.
+
+The derived coordinates follow htslib/pysam semantics:
+``reference_end = pos + sum(len of M,D,N,=,X)`` (at least pos+1), ``query_alignment_start`` =
+leading soft clips (hard clips skipped), ``query_alignment_end = l_qseq - trailing soft clips``
+(walking back to, but not including, CIGAR element 0; when there is no sequence it is
+M+I+=+X plus the leading soft clip), ``infer_read_length = sum(M,I,S,=,X,H)``.
+"""
+import gzip
+import io
+import struct
+import zlib
+
+CIGAR_OPS = "MIDNSHP=XB"
+_CIGAR_CODE = {c: i for i, c in enumerate(CIGAR_OPS)}
+BAM_NIBBLE = "=ACMGRSVTWYHKDBN"
+_NIBBLE_CODE = {c: i for i, c in enumerate(BAM_NIBBLE)}
+
+BAM_CMATCH, BAM_CINS, BAM_CDEL, BAM_CREF_SKIP, BAM_CSOFT_CLIP, BAM_CHARD_CLIP, BAM_CPAD, BAM_CEQUAL, BAM_CDIFF, BAM_CBACK = range(10)
+
+
+def parse_cigar_string(cigar):
+    """'10S5M' -> [(4, 10), (0, 5)].  '*' or '' -> []."""
+    if cigar is None or cigar == "*" or cigar == "":
+        return []
+    out = []
+    num = 0
+    have = False
+    for ch in cigar:
+        if "0" <= ch <= "9":
+            num = num * 10 + (ord(ch) - 48)
+            have = True
+        else:
+            if not have or ch not in _CIGAR_CODE:
+                raise ValueError("invalid CIGAR string: %r" % (cigar,))
+            out.append((_CIGAR_CODE[ch], num))
+            num = 0
+            have = False
+    if have:
+        raise ValueError("invalid CIGAR string: %r" % (cigar,))
+    return out
+
+
+def cigar_to_string(tuples):
+    if not tuples:
+        return None
+    return "".join("%d%s" % (l, CIGAR_OPS[op]) for op, l in tuples)
+
+
+class AlignedSegment(object):
+    """Mutable alignment record with pysam's attribute names.
+
+    It can be filled attribute by attribute exactly as
+    src/svim/SVIM_COLLECT.py:72-90 fills a ``pysam.AlignedSegment()``.
+    """
+    __slots__ = ("query_name", "flag", "reference_id", "reference_start", "_mapq", "_cigar",
+                 "_seq", "query_qualities", "next_reference_id", "next_reference_start",
+                 "template_length", "_tags", "_packed_cigar")
+
+    def __init__(self, header=None):
+        self.query_name = None
+        self.flag = 0
+        self.reference_id = -1
+        self.reference_start = -1
+        self._mapq = 0
+        self._cigar = []
+        self._seq = None
+        self.query_qualities = None
+        self.next_reference_id = -1
+        self.next_reference_start = -1
+        self.template_length = 0
+        self._tags = {}
+        self._packed_cigar = None
+
+    # --- plain fields ---------------------------------------------------------------------
+    @property
+    def mapping_quality(self):
+        return self._mapq
+
+    @mapping_quality.setter
+    def mapping_quality(self, value):
+        # pysam stores MAPQ in a uint8 and raises OverflowError beyond it
+        # (handled at src/svim/SVIM_COLLECT.py:81-84)
+        if value < 0 or value > 255:
+            raise OverflowError("value too large to convert to uint8_t")
+        self._mapq = int(value)
+
+    @property
+    def cigartuples(self):
+        return list(self._cigar) if self._cigar else None
+
+    @cigartuples.setter
+    def cigartuples(self, value):
+        self._cigar = [(int(o), int(l)) for o, l in value] if value else []
+        self._packed_cigar = None
+
+    @property
+    def cigarstring(self):
+        return cigar_to_string(self._cigar)
+
+    @cigarstring.setter
+    def cigarstring(self, value):
+        self._cigar = parse_cigar_string(value)
+        self._packed_cigar = None
+
+    @property
+    def query_sequence(self):
+        return self._seq
+
+    @query_sequence.setter
+    def query_sequence(self, value):
+        if value is None or value == "*" or value == "":
+            self._seq = None
+        else:
+            self._seq = value
+
+    @property
+    def query_length(self):
+        return 0 if self._seq is None else len(self._seq)
+
+    # --- flags ----------------------------------------------------------------------------
+    @property
+    def is_unmapped(self):
+        return bool(self.flag & 0x4)
+
+    @property
+    def is_reverse(self):
+        return bool(self.flag & 0x10)
+
+    @property
+    def is_secondary(self):
+        return bool(self.flag & 0x100)
+
+    @property
+    def is_supplementary(self):
+        return bool(self.flag & 0x800)
+
+    # --- derived coordinates (htslib semantics) -------------------------------------------
+    @property
+    def reference_end(self):
+        if self.is_unmapped or not self._cigar:
+            return None
+        rlen = 0
+        for op, l in self._cigar:
+            if op in (0, 2, 3, 7, 8):
+                rlen += l
+        if rlen == 0:
+            rlen = 1
+        return self.reference_start + rlen
+
+    @property
+    def query_alignment_start(self):
+        start = 0
+        for op, l in self._cigar:
+            if op == BAM_CHARD_CLIP:
+                continue
+            elif op == BAM_CSOFT_CLIP:
+                start += l
+            else:
+                break
+        return start
+
+    @property
+    def query_alignment_end(self):
+        end = self.query_length
+        cig = self._cigar
+        if end == 0:
+            for op, l in cig:
+                if op in (0, 1, 7, 8) or (op == BAM_CSOFT_CLIP and end == 0):
+                    end += l
+        else:
+            for k in range(len(cig) - 1, 0, -1):
+                op, l = cig[k]
+                if op == BAM_CHARD_CLIP:
+                    continue
+                elif op == BAM_CSOFT_CLIP:
+                    end -= l
+                else:
+                    break
+        return end
+
+    def infer_read_length(self):
+        if not self._cigar:
+            return None
+        total = 0
+        for op, l in self._cigar:
+            if op in (0, 1, 4, 5, 7, 8):
+                total += l
+        return total if total > 0 else None
+
+    def get_cigar_stats(self):
+        bases = [0] * 11
+        blocks = [0] * 11
+        for op, l in self._cigar:
+            bases[op] += l
+            blocks[op] += 1
+        if "NM" in self._tags:
+            bases[10] = self._tags["NM"]
+            blocks[10] = 1
+        return bases, blocks
+
+    # --- tags -----------------------------------------------------------------------------
+    def get_tag(self, name):
+        return self._tags[name]          # KeyError when absent, like pysam
+
+    def has_tag(self, name):
+        return name in self._tags
+
+    def set_tag(self, name, value, value_type=None):
+        self._tags[name] = value
+
+    def set_tags(self, tags):
+        self._tags = {}
+        for t in tags:
+            self._tags[t[0]] = t[1]
+
+    def get_tags(self):
+        return list(self._tags.items())
+
+    def __repr__(self):
+        return "<AlignedSegment %s flag=%d tid=%d pos=%d mapq=%d cigar=%s>" % (
+            self.query_name, self.flag, self.reference_id, self.reference_start, self._mapq,
+            (self.cigarstring or "*")[:40])
+
+
+def _parse_sam_tag(field, tags):
+    name, typ, val = field.split(":", 2)
+    if typ == "i":
+        tags[name] = int(val)
+    elif typ == "f":
+        tags[name] = float(val)
+    else:
+        tags[name] = val
+
+
+def parse_sam_line(line, name_to_tid):
+    f = line.rstrip("\n").split("\t")
+    a = AlignedSegment()
+    a.query_name = f[0]
+    a.flag = int(f[1])
+    a.reference_id = name_to_tid.get(f[2], -1)
+    a.reference_start = int(f[3]) - 1
+    a._mapq = int(f[4])
+    a.cigarstring = f[5]
+    a.next_reference_id = a.reference_id if f[6] == "=" else name_to_tid.get(f[6], -1)
+    a.next_reference_start = int(f[7]) - 1
+    a.template_length = int(f[8])
+    a.query_sequence = f[9]
+    a.query_qualities = None if f[10] == "*" else f[10]
+    tags = {}
+    for t in f[11:]:
+        if t:
+            _parse_sam_tag(t, tags)
+    a._tags = tags
+    return a
+
+
+def _read_bgzf(path):
+    """Inflate a BGZF (or plain gzip) file completely; returns bytes."""
+    with gzip.open(path, "rb") as fh:       # BGZF is a series of gzip members
+        return fh.read()
+
+
+def _decode_bam_aux(buf, p, end, tags):
+    while p < end:
+        name = buf[p:p + 2].decode("ascii")
+        typ = chr(buf[p + 2])
+        p += 3
+        if typ == "A":
+            tags[name] = chr(buf[p]); p += 1
+        elif typ == "c":
+            tags[name] = struct.unpack_from("<b", buf, p)[0]; p += 1
+        elif typ == "C":
+            tags[name] = buf[p]; p += 1
+        elif typ == "s":
+            tags[name] = struct.unpack_from("<h", buf, p)[0]; p += 2
+        elif typ == "S":
+            tags[name] = struct.unpack_from("<H", buf, p)[0]; p += 2
+        elif typ == "i":
+            tags[name] = struct.unpack_from("<i", buf, p)[0]; p += 4
+        elif typ == "I":
+            tags[name] = struct.unpack_from("<I", buf, p)[0]; p += 4
+        elif typ == "f":
+            tags[name] = struct.unpack_from("<f", buf, p)[0]; p += 4
+        elif typ in "ZH":
+            q = buf.index(b"\0", p)
+            tags[name] = buf[p:q].decode("ascii"); p = q + 1
+        elif typ == "B":
+            sub = chr(buf[p]); n = struct.unpack_from("<I", buf, p + 1)[0]; p += 5
+            fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
+            size = struct.calcsize(fmt)
+            tags[name] = list(struct.unpack_from("<%d%s" % (n, fmt), buf, p)); p += n * size
+            tags["__B_" + name] = sub
+        else:
+            raise ValueError("unknown BAM aux type %r" % typ)
+    return p
+
+
+class AlignmentFile(object):
+    """Minimal reader for SAM text and BAM files with the pysam calls COLLECT makes."""
+
+    def __init__(self, path=None, mode=None, text=None):
+        self.filename = path
+        self.references = []
+        self.lengths = []
+        self.header = {}
+        self._records = None
+        self._sam_lines = None
+        self._bam = None
+        if text is not None:
+            self._init_sam(text)
+        else:
+            with open(path, "rb") as fh:
+                magic = fh.read(4)
+            if magic[:2] == b"\x1f\x8b":
+                data = _read_bgzf(path)
+                if data[:4] == b"BAM\1":
+                    self._init_bam(data)
+                else:
+                    self._init_sam(data.decode("ascii"))
+            else:
+                with open(path, "r") as fh:
+                    self._init_sam(fh.read())
+        self._name_to_tid = {n: i for i, n in enumerate(self.references)}
+
+    # -- header --
+    def _parse_header_text(self, lines):
+        hdr = {}
+        for line in lines:
+            if not line.startswith("@") or len(line) < 3:
+                continue
+            kind = line[1:3]
+            if kind == "CO":
+                hdr.setdefault("CO", []).append(line[4:])
+                continue
+            d = {}
+            for fld in line.rstrip("\n").split("\t")[1:]:
+                if len(fld) >= 3 and fld[2] == ":":
+                    d[fld[:2]] = fld[3:]
+            if kind == "HD":
+                hdr["HD"] = d
+            else:
+                hdr.setdefault(kind, []).append(d)
+        return hdr
+
+    def _init_sam(self, text):
+        lines = text.split("\n")
+        head = [l for l in lines if l.startswith("@")]
+        self.header = self._parse_header_text(head)
+        for sq in self.header.get("SQ", []):
+            self.references.append(sq["SN"])
+            self.lengths.append(int(sq.get("LN", 0)))
+        self._sam_lines = [l for l in lines if l and not l.startswith("@")]
+
+    def _init_bam(self, data):
+        l_text = struct.unpack_from("<i", data, 4)[0]
+        text = data[8:8 + l_text].split(b"\0", 1)[0].decode("ascii", "replace")
+        self.header = self._parse_header_text(text.split("\n"))
+        p = 8 + l_text
+        n_ref = struct.unpack_from("<i", data, p)[0]
+        p += 4
+        for _ in range(n_ref):
+            l_name = struct.unpack_from("<i", data, p)[0]
+            p += 4
+            self.references.append(data[p:p + l_name - 1].decode("ascii"))
+            p += l_name
+            self.lengths.append(struct.unpack_from("<i", data, p)[0])
+            p += 4
+        self._bam = (data, p)
+
+    # -- pysam API --
+    def getrname(self, tid):
+        if tid < 0 or tid >= len(self.references):
+            raise ValueError("reference_id %i out of range 0<=tid<%i" % (tid, len(self.references)))
+        return self.references[tid]
+
+    get_reference_name = getrname
+
+    def get_tid(self, name):
+        return self._name_to_tid.get(name, -1)
+
+    gettid = get_tid
+
+    def fetch(self, contig=None, start=None, stop=None, until_eof=True):
+        if contig is not None:
+            raise NotImplementedError("random access fetch is outside the COLLECT+CLUSTER path")
+        if self._sam_lines is not None:
+            for line in self._sam_lines:
+                yield parse_sam_line(line, self._name_to_tid)
+        else:
+            for rec in self._iter_bam():
+                yield rec
+
+    def _iter_bam(self):
+        data, p = self._bam
+        n = len(data)
+        while p + 4 <= n:
+            block_size = struct.unpack_from("<i", data, p)[0]
+            p += 4
+            end = p + block_size
+            (tid, pos, l_read_name, mapq, _bin, n_cigar, flag, l_seq, ntid, npos, tlen) = \
+                struct.unpack_from("<iiBBHHHiiii", data, p)
+            q = p + 32
+            a = AlignedSegment()
+            a.query_name = data[q:q + l_read_name - 1].decode("ascii")
+            q += l_read_name
+            cig = struct.unpack_from("<%dI" % n_cigar, data, q)
+            q += 4 * n_cigar
+            a._cigar = [(c & 0xF, c >> 4) for c in cig]
+            if l_seq:
+                sb = data[q:q + (l_seq + 1) // 2]
+                s = "".join(BAM_NIBBLE[b >> 4] + BAM_NIBBLE[b & 0xF] for b in sb)
+                a._seq = s[:l_seq]
+            q += (l_seq + 1) // 2
+            q += l_seq      # qualities: not on the path
+            a.flag, a.reference_id, a.reference_start, a._mapq = flag, tid, pos, mapq
+            a.next_reference_id, a.next_reference_start, a.template_length = ntid, npos, tlen
+            tags = {}
+            _decode_bam_aux(data, q, end, tags)
+            # long CIGARs (> 65535 ops) live in the CG:B,I tag with a placeholder kSmN CIGAR
+            if "CG" in tags and n_cigar == 2 and a._cigar[0] == (4, l_seq) and a._cigar[1][0] == 3:
+                a._cigar = [(c & 0xF, c >> 4) for c in tags.pop("CG")]
+                tags.pop("__B_CG", None)
+            a._tags = {k: v for k, v in tags.items() if not k.startswith("__B_")}
+            p = end
+            yield a
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def write_bam(path, references, lengths, records, sort_order="coordinate"):
+    """Write records (AlignedSegment) to a BAM file (BGZF, 64 KiB blocks).  Used by the synthetic
+    data generator and tests; not on the measured path."""
+    out = io.BytesIO()
+    text = "@HD\tVN:1.6\tSO:%s\n" % sort_order + "".join(
+        "@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(references, lengths))
+    tb = text.encode("ascii")
+    out.write(b"BAM\1" + struct.pack("<i", len(tb)) + tb + struct.pack("<i", len(references)))
+    for n, l in zip(references, lengths):
+        nb = n.encode("ascii") + b"\0"
+        out.write(struct.pack("<i", len(nb)) + nb + struct.pack("<i", l))
+    for a in records:
+        name = a.query_name.encode("ascii") + b"\0"
+        cig = a._cigar
+        seq = a._seq or ""
+        l_seq = len(seq)
+        aux = b""
+        if len(cig) > 65535:
+            aux += b"CGBI" + struct.pack("<I", len(cig)) + struct.pack("<%dI" % len(cig), *[(l << 4) | o for o, l in cig])
+            rlen = sum(l for o, l in cig if o in (0, 2, 3, 7, 8))
+            cig = [(4, l_seq), (3, rlen)]
+        for k, v in a._tags.items():
+            if isinstance(v, int):
+                aux += k.encode("ascii") + b"i" + struct.pack("<i", v)
+            elif isinstance(v, float):
+                aux += k.encode("ascii") + b"f" + struct.pack("<f", v)
+            else:
+                aux += k.encode("ascii") + b"Z" + str(v).encode("ascii") + b"\0"
+        codes = [_NIBBLE_CODE.get(c, 15) for c in seq.upper()]
+        if l_seq & 1:
+            codes.append(0)
+        sb = bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
+        core = struct.pack("<iiBBHHHiiii", a.reference_id, a.reference_start, len(name), a._mapq, 4680,
+                           len(cig), a.flag, l_seq, a.next_reference_id, a.next_reference_start, a.template_length)
+        body = core + name + struct.pack("<%dI" % len(cig), *[(l << 4) | o for o, l in cig]) + sb + b"\xff" * l_seq + aux
+        out.write(struct.pack("<i", len(body)) + body)
+    raw = out.getvalue()
+    with open(path, "wb") as fh:
+        for i in range(0, len(raw), 0xff00):
+            chunk = raw[i:i + 0xff00]
+            comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+            cd = comp.compress(chunk) + comp.flush()
+            bsize = len(cd) + 25
+            fh.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + cd +
+                     struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+        fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))

@@ -1,0 +1,512 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference).  The reference is pure Python; it is
+imported from /root/reference/src with two third-party modules stubbed:
+
+* ``pysam``  -> ``AlignedSegment`` = svim_amd.records.AlignedSegment (htslib coordinate rules),
+               ``FastaFile`` = plain-text FASTA slicer with end clipping;
+* ``edlib``  -> ``align(a, b)["editDistance"]`` = unit-cost global Levenshtein distance (unique value).
+
+scipy (linkage / fcluster), random (MT19937 seed/sample) and statistics (mean/stdev) are the real
+modules of this container (CPython 3.10.12, scipy 1.15.3); their versions are recorded in every file.
+
+Outputs are DATA ONLY: inputs (SAM text, signature rows, condensed matrices) and the reference's
+outputs for them.  No reference source is copied.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import gzip
+import json
+import os
+import random
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference/src")
+
+from svim_amd import records, synth   # noqa: E402
+
+
+# ------------------------------------------------------------------ stubs
+def levenshtein(a, b):
+    """Unit-cost global edit distance (Myers/Hyyro bit-vector on Python ints)."""
+    if len(a) < len(b):
+        a, b = b, a
+    m = len(b)
+    if m == 0:
+        return len(a)
+    peq = {}
+    for i, c in enumerate(b):
+        peq[c] = peq.get(c, 0) | (1 << i)
+    mask = (1 << m) - 1
+    high = 1 << (m - 1)
+    pv, mv, score = mask, 0, m
+    for c in a:
+        eq = peq.get(c, 0)
+        xv = eq | mv
+        xh = ((((eq & pv) + pv) ^ pv) | eq) & mask
+        ph = (mv | ~(xh | pv)) & mask
+        mh = pv & xh
+        if ph & high:
+            score += 1
+        elif mh & high:
+            score -= 1
+        ph = ((ph << 1) | 1) & mask
+        mh = (mh << 1) & mask
+        pv = (mh | ~(xv | ph)) & mask
+        mv = ph & xv
+    return score
+
+
+def levenshtein_dp(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i] + [0] * len(b)
+        for j, cb in enumerate(b, 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb))
+        prev = cur
+    return prev[-1]
+
+
+class FastaFile(object):
+    def __init__(self, path):
+        self.seqs = {}
+        name = None
+        opener = gzip.open if path.endswith(".gz") else open
+        with opener(path, "rt") as fh:
+            for line in fh:
+                line = line.rstrip("\n")
+                if line.startswith(">"):
+                    name = line[1:].split()[0]
+                    self.seqs[name] = []
+                elif name is not None:
+                    self.seqs[name].append(line)
+        self.seqs = {k: "".join(v) for k, v in self.seqs.items()}
+
+    def fetch(self, contig, start, end):
+        return self.seqs[contig][start:end]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+pysam_stub = types.ModuleType("pysam")
+pysam_stub.AlignedSegment = records.AlignedSegment
+pysam_stub.FastaFile = FastaFile
+pysam_stub.AlignmentFile = records.AlignmentFile
+sys.modules["pysam"] = pysam_stub
+edlib_stub = types.ModuleType("edlib")
+edlib_stub.align = lambda a, b, **kw: {"editDistance": levenshtein(a, b)}
+sys.modules["edlib"] = edlib_stub
+
+import numpy as np                                   # noqa: E402
+import scipy                                         # noqa: E402
+from scipy.cluster.hierarchy import linkage, fcluster   # noqa: E402
+from svim import SVIM_intra, SVIM_inter, SVIM_COLLECT, SVIM_CLUSTER, SVIM_clustering, SVSignature  # noqa: E402
+
+VERSIONS = {"python": sys.version.split()[0], "scipy": scipy.__version__, "numpy": np.__version__,
+            "reference": "eldariont/svim v2.0.0 (/root/reference)"}
+
+
+def options(**kw):
+    o = types.SimpleNamespace(min_mapq=20, min_sv_size=40, max_sv_size=100000, segment_gap_tolerance=10,
+                              segment_overlap_tolerance=5, partition_max_distance=1000,
+                              position_distance_normalizer=900, edit_distance_normalizer=1.0,
+                              cluster_max_distance=0.5, all_bnds=False, genome=os.path.join(HERE, "ref.fa.gz"))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def opt_dict(o):
+    d = dict(vars(o))
+    d["genome"] = os.path.basename(d["genome"])
+    return d
+
+
+# ------------------------------------------------------------------ serialisation
+def sig_row(s):
+    t = s.type
+    if t in ("DEL",):
+        return [t, s.contig, s.start, s.end, s.signature, s.read]
+    if t == "INS":
+        return [t, s.contig, s.start, s.end, s.signature, s.read, s.sequence]
+    if t == "INV":
+        return [t, s.contig, s.start, s.end, s.signature, s.read, s.direction]
+    if t == "DUP_TAN":
+        return [t, s.contig, s.start, s.end, s.signature, s.read, s.copies, bool(s.fully_covered)]
+    if t == "DUP_INT":
+        return [t, s.contig1, s.start, s.end, s.signature, s.read, s.contig2, s.pos]
+    if t == "BND":
+        return [t, s.contig1, s.pos1, s.direction1, s.contig2, s.pos2, s.direction2, s.signature, s.read]
+    raise ValueError(t)
+
+
+def row_sig(r):
+    t = r[0]
+    S = SVSignature
+    if t == "DEL":
+        return S.SignatureDeletion(r[1], r[2], r[3], r[4], r[5])
+    if t == "INS":
+        return S.SignatureInsertion(r[1], r[2], r[3], r[4], r[5], r[6])
+    if t == "INV":
+        return S.SignatureInversion(r[1], r[2], r[3], r[4], r[5], r[6])
+    if t == "DUP_TAN":
+        return S.SignatureDuplicationTandem(r[1], r[2], r[3], r[6], r[7], r[4], r[5])
+    if t == "DUP_INT":
+        return S.SignatureInsertionFrom(r[1], r[2], r[3], r[6], r[7], r[4], r[5])
+    if t == "BND":
+        return S.SignatureTranslocation(r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8])
+    raise ValueError(t)
+
+
+def cluster_rows(clusters6, sigs):
+    idx = {id(s): i for i, s in enumerate(sigs)}
+    out = []
+    for k, lst in enumerate(clusters6):
+        rows = []
+        for c in lst:
+            members = [idx[id(m)] for m in c.members]
+            if k < 3:
+                rows.append([c.contig, c.start, c.end, c.score, c.size, c.std_span, c.std_pos, members])
+            else:
+                row = [c.source_contig, c.source_start, c.source_end, c.dest_contig, c.dest_start, c.dest_end,
+                       c.score, c.size, c.std_span, c.std_pos, members]
+                if c.type == "BND":
+                    row += [c.direction1, c.direction2]
+                rows.append(row)
+        out.append(rows)
+    return out
+
+
+def dump(name, obj):
+    obj["versions"] = VERSIONS
+    path = os.path.join(HERE, name)
+    with gzip.GzipFile(path, "wb", mtime=0) if name.endswith(".gz") else open(path, "wb") as fh:
+        fh.write(json.dumps(obj, separators=(",", ":")).encode("ascii"))
+    print("wrote", name, os.path.getsize(path), "bytes")
+
+
+# ------------------------------------------------------------------ G1: analyze_cigar_indel
+def gen_intra():
+    rng = random.Random(101)
+    cases = []
+    # the reference's own four known-answer vectors (src/tests/test_intra.py:9-22)
+    kat = [
+        ([(5, 10), (4, 20), (0, 10), (7, 10), (8, 5), (0, 5), (1, 50), (0, 30), (4, 25), (5, 15)], 30),
+        ([(5, 10), (4, 20), (0, 30), (2, 50), (0, 30), (4, 25), (5, 15)], 30),
+        ([(5, 10), (4, 20), (0, 30), (2, 40), (1, 50), (0, 30), (4, 25), (5, 15)], 30),
+        ([(5, 10), (4, 20), (0, 30), (1, 40), (2, 50), (0, 30), (4, 25), (5, 15)], 30),
+    ]
+    for tuples, ml in kat:
+        cases.append({"tuples": tuples, "min_length": ml,
+                      "expect": [list(x) for x in SVIM_intra.analyze_cigar_indel(tuples, ml)]})
+    for _ in range(1200):
+        n = rng.choice((0, 1, 2, 5, 20, 64, 65, 200, 257, 700))
+        ml = rng.choice((1, 30, 40, 41))
+        tuples = []
+        for _ in range(n):
+            op = rng.choice((0, 0, 0, 1, 1, 2, 2, 3, 4, 5, 6, 7, 8, 9))
+            ln = rng.choice((1, 2, 5, 29, 30, 39, 40, 41, 100, 5000, rng.randint(1, 60)))
+            tuples.append((op, ln))
+        cases.append({"tuples": tuples, "min_length": ml,
+                      "expect": [list(x) for x in SVIM_intra.analyze_cigar_indel(tuples, ml)]})
+    dump("g1_cigar_indel.json.gz", {"cases": cases,
+                                    "source": "svim.SVIM_intra.analyze_cigar_indel (src/svim/SVIM_intra.py:8-30)"})
+
+
+# ------------------------------------------------------------------ G2/G3: COLLECT
+def run_collect(sam_text, opts, mode):
+    bam = records.AlignmentFile(text=sam_text)
+    fn = SVIM_COLLECT.analyze_alignment_file_coordsorted if mode == "coordinate" else \
+        SVIM_COLLECT.analyze_alignment_file_querysorted
+    sigs, bnds = fn(bam, opts)
+    return sigs, bnds
+
+
+def gen_collect(refs, references, lengths):
+    # chimeric_read.sam is a data file of the reference's own test-suite (src/tests/chimeric_read.sam)
+    with open("/root/reference/src/tests/chimeric_read.sam") as fh:
+        chim = fh.read()
+    with open(os.path.join(HERE, "chimeric_read.sam"), "w") as fh:
+        fh.write(chim)
+    bam = records.AlignmentFile(text=chim)
+    alns = list(bam.fetch(until_eof=True))
+    rebuilt = SVIM_COLLECT.retrieve_other_alignments(alns[0], bam)
+    sa_table = [[a.cigarstring, a.reference_id, a.reference_start, a.reference_end, a.flag, a.mapping_quality,
+                 a.query_alignment_start, a.query_alignment_end, a.infer_read_length()] for a in rebuilt]
+    direct = [[a.cigarstring, a.reference_id, a.reference_start, a.reference_end, a.flag, a.mapping_quality,
+               a.query_alignment_start, a.query_alignment_end, a.infer_read_length()] for a in alns[1:]]
+    cases = []
+    for all_bnds in (False, True):
+        for mode in ("coordinate", "queryname"):
+            o = options(all_bnds=all_bnds)
+            sigs, bnds = run_collect(chim, o, mode)
+            cases.append({"name": "chimeric", "sam_file": "chimeric_read.sam", "mode": mode, "options": opt_dict(o),
+                          "signatures": [sig_row(s) for s in sigs], "bnds": [sig_row(s) for s in bnds]})
+    dump("g3_satag.json", {"sa_rebuilt": sa_table, "supplementary_records": direct,
+                           "source": "svim.SVIM_COLLECT.retrieve_other_alignments on src/tests/chimeric_read.sam "
+                                     "(expected values of src/tests/test_satag.py:21-34)"})
+
+    fuzz_sets = [
+        ("fuzzA", dict(seed=11, n_reads=170, max_sv_size=100000), dict()),
+        ("fuzzB", dict(seed=12, n_reads=170, max_sv_size=20000), dict(max_sv_size=20000, min_sv_size=30,
+                                                                       segment_gap_tolerance=15,
+                                                                       segment_overlap_tolerance=8)),
+        ("fuzzC", dict(seed=13, n_reads=140, max_sv_size=100000), dict(min_mapq=5)),
+    ]
+    stats = {}
+    for name, gen_kw, opt_kw in fuzz_sets:
+        recs = synth.fuzz_split_reads(references=references, lengths=lengths, **gen_kw)
+        for mode in ("coordinate", "queryname"):
+            if mode == "coordinate":
+                ordered = synth.coordinate_sort(recs)
+            else:
+                ordered = recs          # generator emits read by read: query-name grouped
+            text = synth.sam_text(references, lengths, ordered, sort_order=mode)
+            for all_bnds in (False, True):
+                o = options(all_bnds=all_bnds, **opt_kw)
+                sigs, bnds = run_collect(text, o, mode)
+                for s in sigs:
+                    stats[(s.type, s.signature)] = stats.get((s.type, s.signature), 0) + 1
+                cases.append({"name": name, "sam": text if not all_bnds else None, "mode": mode,
+                              "options": opt_dict(o), "signatures": [sig_row(s) for s in sigs],
+                              "bnds": [sig_row(s) for s in bnds]})
+    # planted DEL/INS/INV reads: realistic C1-like slice
+    recs = synth.planted_reads(21, 500, refs, references, lengths, n_sites=30, types=("DEL", "INS", "INV"))
+    text = synth.sam_text(references, lengths, synth.coordinate_sort(recs))
+    for all_bnds in (False, True):
+        o = options(all_bnds=all_bnds)
+        sigs, bnds = run_collect(text, o, "coordinate")
+        for s in sigs:
+            stats[(s.type, s.signature)] = stats.get((s.type, s.signature), 0) + 1
+        cases.append({"name": "planted", "sam": text if not all_bnds else None, "mode": "coordinate",
+                      "options": opt_dict(o), "signatures": [sig_row(s) for s in sigs],
+                      "bnds": [sig_row(s) for s in bnds]})
+    print("collect branch coverage:", sorted(stats.items()))
+    dump("g2_collect.json.gz", {"cases": cases, "references": references, "lengths": lengths,
+                                "source": "svim.SVIM_COLLECT.analyze_alignment_file_{coord,query}sorted "
+                                          "(src/svim/SVIM_COLLECT.py:96-167) on synthetic SAM"})
+    return cases
+
+
+# ------------------------------------------------------------------ G4-G7: CLUSTER
+def synth_signature_rows(seed, refs, references, lengths):
+    """Direct signature lists that stress partition sizes (1,2,3,50,100,101,1045,1046,5000), same-read
+    duplicates, exact ties, distances straddling 0.5, multi-contig string order, all six types."""
+    rng = random.Random(seed)
+    rows = []
+    rid = [0]
+
+    def read():
+        rid[0] += 1
+        return "r%d" % rid[0]
+
+    def blob(typ, contig, center, n, span, jit_pos, jit_span, reads=None):
+        for k in range(n):
+            c = center + rng.randint(-jit_pos, jit_pos)
+            sp = max(1, span + rng.randint(-jit_span, jit_span))
+            st = max(0, c - sp // 2)
+            rd = reads[k % len(reads)] if reads else read()
+            src = rng.choice(("cigar", "suppl"))
+            if typ == "DEL":
+                rows.append(["DEL", contig, st, st + sp, src, rd])
+            elif typ == "INS":
+                base = blob.ins_seq.setdefault((contig, center), synth.random_seq(rng, span + jit_span + 5))
+                seq = "".join(ch if rng.random() > 0.04 else rng.choice("ACGT") for ch in base[:sp])
+                rows.append(["INS", contig, st, st + sp, src, rd, seq])
+            elif typ == "INV":
+                rows.append(["INV", contig, st, st + sp, "suppl", rd,
+                             rng.choice(("left_fwd", "left_rev", "right_fwd", "right_rev"))])
+            elif typ == "DUP_TAN":
+                rows.append(["DUP_TAN", contig, st, st + sp, "suppl", rd, rng.randint(1, 4), rng.random() < 0.5])
+            elif typ == "DUP_INT":
+                c2 = rng.choice(references)
+                rows.append(["DUP_INT", contig, st, st + sp, "suppl", rd, c2,
+                             (center * 7) % 40000 + rng.randint(-jit_pos, jit_pos) + 500])
+            elif typ == "BND":
+                c2 = rng.choice(references)
+                d1, d2 = rng.choice((("fwd", "fwd"), ("fwd", "rev"), ("rev", "rev"), ("rev", "fwd"), ("fwd", "fwd")))
+                rows.append(["BND", contig, c, d1, c2, (center * 3) % 30000 + 200 + rng.randint(-jit_pos, jit_pos), d2,
+                             "suppl", rd])
+    blob.ins_seq = {}
+    sizes = [1, 2, 3, 7, 50, 100, 101, 150]
+    for typ in ("DEL", "INS", "INV", "DUP_TAN", "DUP_INT", "BND"):
+        pos = 5000
+        for contig in references:
+            for n in sizes:
+                if typ == "INS" and n > 60:
+                    n = 60 if n == 100 else (101 if n == 101 else 40)
+                span = rng.choice((60, 200, 800))
+                if typ == "INS":
+                    span = rng.choice((50, 120, 300))
+                blob(typ, contig, pos, n, span, rng.choice((0, 5, 60, 300)), rng.choice((0, 3, 30)))
+                # same-read duplicates + exact ties
+                rd = read()
+                blob(typ, contig, pos + 3, 3, span, 0, 0, reads=[rd])
+                pos += rng.choice((900, 1500, 2500, 4000))
+                if pos > min(lengths) - 3000:
+                    pos = 5000 + rng.randint(0, 500)
+    # very large DEL partitions: both random.sample code paths and RNG carry-over between partitions
+    for n, center in ((1045, 20000), (1046, 40000), (3000, 60000)):
+        blob("DEL", references[0], center, n, 300, 400, 100)
+    rng.shuffle(rows)
+    return rows
+
+
+def gen_cluster(collect_cases, refs, references, lengths):
+    cases = []
+    # (i) cluster what COLLECT produced
+    for c in collect_cases:
+        if c["options"]["all_bnds"] or c["name"] == "chimeric":
+            continue
+        for kw in (dict(), dict(partition_max_distance=5000, cluster_max_distance=0.7,
+                                position_distance_normalizer=450, edit_distance_normalizer=1.5)):
+            if kw and c["mode"] != "coordinate":
+                continue
+            o = options(**{**{k: v for k, v in c["options"].items() if k != "genome"}, **kw})
+            sigs = [row_sig(r) for r in c["signatures"]]
+            res = SVIM_CLUSTER.cluster_sv_signatures(sigs, o)
+            cases.append({"name": "from_collect:%s:%s" % (c["name"], c["mode"]), "options": opt_dict(o),
+                          "signatures": c["signatures"], "clusters": cluster_rows(res, sigs)})
+    # (ii) direct stress lists
+    for seed, kw in ((31, dict()), (32, dict(partition_max_distance=300)), (33, dict(cluster_max_distance=0.3))):
+        rows = synth_signature_rows(seed, refs, references, lengths)
+        o = options(**kw)
+        sigs = [row_sig(r) for r in rows]
+        rows = [sig_row(s) for s in sigs]           # BND rows in canonical (post-constructor) form
+        res = SVIM_CLUSTER.cluster_sv_signatures(sigs, o)
+        cases.append({"name": "stress%d" % seed, "options": opt_dict(o), "signatures": rows,
+                      "clusters": cluster_rows(res, sigs)})
+        print("stress", seed, "n_sig", len(rows), "clusters", [len(x) for x in res])
+    # form_partitions boundaries (G4)
+    parts = []
+    for case in cases[-3:]:
+        sigs = [row_sig(r) for r in case["signatures"]]
+        idx = {id(s): i for i, s in enumerate(sigs)}
+        for typ in ("DEL", "INS", "INV", "DUP_TAN", "BND", "DUP_INT"):
+            sub = [s for s in sigs if s.type == typ]
+            p = SVIM_clustering.form_partitions(sub, case["options"]["partition_max_distance"])
+            parts.append({"case": case["name"], "type": typ, "partitions": [[idx[id(s)] for s in q] for q in p]})
+    dump("g4_partitions.json.gz", {"partitions": parts,
+                                   "source": "svim.SVIM_clustering.form_partitions (src/svim/SVIM_clustering.py:17-29)"})
+    dump("g5_cluster.json.gz", {"cases": cases, "references": references, "lengths": lengths,
+                                "source": "svim.SVIM_CLUSTER.cluster_sv_signatures (src/svim/SVIM_CLUSTER.py:7-26)"})
+    # G6: span_position_distance bit patterns
+    import struct
+    pairs = []
+    ref = FastaFile(os.path.join(HERE, "ref.fa.gz"))
+    rows = cases[-3]["signatures"]
+    sigs = [row_sig(r) for r in rows]
+    rng = random.Random(5)
+    by_type = {}
+    for i, s in enumerate(sigs):
+        by_type.setdefault(s.type, []).append(i)
+    for typ, ids in by_type.items():
+        for _ in range(150):
+            i, j = rng.sample(ids, 2)
+            if typ == "INS" and (abs(sigs[i].start - sigs[j].start) > 3000 or sigs[i].contig != sigs[j].contig):
+                continue
+            d = SVIM_clustering.span_position_distance(sigs[i], sigs[j], typ, ref, 900, 1.0, 0.5)
+            pairs.append([i, j, struct.pack("<d", float(d)).hex()])
+    dump("g6_distance.json.gz", {"signatures": rows, "pairs": pairs, "params": [900, 1.0, 0.5],
+                                 "source": "svim.SVIM_clustering.span_position_distance (src/svim/SVIM_clustering.py:47-96)"})
+
+
+# ------------------------------------------------------------------ linkage / rng / edit distance
+def gen_linkage():
+    rng = random.Random(77)
+    cases = []
+    for it in range(240):
+        n = rng.choice((2, 3, 4, 5, 8, 13, 30, 64, 65, 100))
+        pts = [(rng.randint(0, 40) * rng.choice((1, 1, 25)), rng.choice((50, 60, 100, 400))) for _ in range(n)]
+        if it % 3 == 0:
+            pts = [pts[rng.randrange(max(1, n // 3))] for _ in range(n)]       # many exact duplicates
+        reads = [rng.randrange(max(2, n // 2)) for _ in range(n)]
+        d = []
+        for i in range(n - 1):
+            for j in range(i + 1, n):
+                if it % 2 and reads[i] == reads[j]:
+                    d.append(99999)
+                else:
+                    (c1, s1), (c2, s2) = pts[i], pts[j]
+                    d.append(abs(c1 - c2) / 900 + abs(s1 - s2) / max(s1, s2))
+        Z = linkage(np.array(d), method="average")
+        t = rng.choice((0.5, 0.5, 0.3, 0.0, 1.0))
+        lab = [int(x) for x in fcluster(Z, t, criterion="distance")]
+        cases.append({"n": n, "d": [float(x).hex() for x in d], "t": t,
+                      "Z": [[float(v).hex() for v in row] for row in Z], "labels": lab})
+    dump("g_linkage.json.gz", {"cases": cases,
+                               "source": "scipy.cluster.hierarchy.linkage(method='average') + fcluster(criterion="
+                                         "'distance') as called at src/svim/SVIM_clustering.py:170-171"})
+
+
+def gen_rng():
+    out = {"getrandbits": {}, "samples": []}
+    for k in (7, 8, 10, 11, 13, 32):
+        random.seed(1524)
+        out["getrandbits"][str(k)] = [random.getrandbits(k) for _ in range(2000)]
+    random.seed(1524)
+    for n in (101, 150, 1045, 1046, 5000, 77777, 128, 100000, 101):
+        out["samples"].append({"n": n, "idx": random.sample(range(n), 100)})
+    dump("g8_rng.json.gz", {"rng": out, "source": "random.seed(1524); random.sample(partition, 100) as at "
+                                                  "src/svim/SVIM_clustering.py:129,133 (sequential, one seed)"})
+
+
+def gen_edit():
+    rng = random.Random(9)
+    cases = []
+    for _ in range(300):
+        la = rng.choice((0, 1, 5, 31, 32, 33, 63, 64, 65, 100, 200, 400))
+        a = synth.random_seq(rng, la)
+        mode = rng.random()
+        if mode < 0.5:
+            b = list(a)
+            for _ in range(rng.randint(0, max(1, la // 6))):
+                r = rng.random()
+                p = rng.randrange(len(b) + 1)
+                if r < 0.33 and b:
+                    b[min(p, len(b) - 1)] = rng.choice("ACGTN")
+                elif r < 0.66 and b:
+                    del b[min(p, len(b) - 1)]
+                else:
+                    b.insert(p, rng.choice("ACGT"))
+            b = "".join(b)
+        else:
+            b = synth.random_seq(rng, rng.choice((0, 3, 64, 130, 333)))
+        d = levenshtein_dp(a, b)
+        assert d == levenshtein(a, b) == levenshtein(b, a)
+        cases.append([a, b, d])
+    dump("g_editdistance.json.gz", {"cases": cases,
+                                    "source": "textbook O(nm) Levenshtein DP: the value edlib.align(a,b)['editDistance'] "
+                                              "returns at src/svim/SVIM_clustering.py:45 (edlib not installed; unique by mathematics)"})
+
+
+def main():
+    contigs = [("chr1", 180000), ("chr2", 60000), ("chr10", 60000)]   # tid order != Python string order
+    refs = synth.make_reference(1, contigs)
+    references = [c[0] for c in contigs]
+    lengths = [c[1] for c in contigs]
+    fa = os.path.join(HERE, "ref.fa")
+    synth.write_fasta(fa, refs)
+    with open(fa, "rb") as f_in, gzip.GzipFile(fa + ".gz", "wb", mtime=0) as f_out:
+        f_out.write(f_in.read())
+    os.remove(fa)
+    gen_intra()
+    collect_cases = gen_collect(refs, references, lengths)
+    gen_cluster(collect_cases, refs, references, lengths)
+    gen_linkage()
+    gen_rng()
+    gen_edit()
+
+
+if __name__ == "__main__":
+    main()
