@@ -1,0 +1,194 @@
+/*
+ * svx.h - C ABI of the MI355X-native COLLECT+CLUSTER path (libsvx.so).
+ *
+ * The reference (eldariont/svim v2.0.0) has no FFI seam: its hot path is the Python call boundary
+ *   analyze_alignment_file_coordsorted / _querysorted   src/svim/SVIM_COLLECT.py:132 / :96
+ *   analyze_alignment_indel / analyze_cigar_indel        src/svim/SVIM_intra.py:33 / :8
+ *   analyze_read_segments                                src/svim/SVIM_inter.py:24
+ *   cluster_sv_signatures -> partition_and_cluster       src/svim/SVIM_CLUSTER.py:7, SVIM_clustering.py:375
+ * The entry points below are what a ctypes binding behind those Python functions binds
+ * (INTEGRATION.md shows the stub).  Plain pointers and sizes only; every array is Structure-of-Arrays.
+ *
+ * Conventions
+ *   - return value: 0 = ok, negative = SVX_E_* (no exceptions cross the boundary)
+ *   - pointers in svx_batch / svx_sig_view / svx_genome may be HOST or DEVICE memory; the `on_device`
+ *     member says which (device pointers let a caller keep everything resident in HBM)
+ *   - results stay resident in the context (HBM) until fetched with svx_*_fetch into caller-allocated
+ *     host arrays sized from svx_*_count
+ *   - one context per GPU / per process; a context is not re-entrant
+ */
+#ifndef SVX_H
+#define SVX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVX_OK               0
+#define SVX_E_NODEVICE     (-1)   /* no HIP device / extension cannot run: the product path never falls back to CPU */
+#define SVX_E_HIP          (-2)   /* a HIP runtime call failed (svx_last_error() has the text) */
+#define SVX_E_ARG          (-3)
+#define SVX_E_CAPACITY     (-4)   /* an internal fixed-capacity buffer overflowed */
+#define SVX_E_STATE        (-5)   /* call order violated (e.g. cluster before collect/set_signatures) */
+
+/* signature types, in the order CLUSTER processes them (src/svim/SVIM_CLUSTER.py:19-24) */
+enum { SVX_DEL = 0, SVX_INS = 1, SVX_INV = 2, SVX_DUP_TAN = 3, SVX_BND = 4, SVX_DUP_INT = 5, SVX_NTYPES = 6 };
+/* sig.src */
+enum { SVX_SRC_CIGAR = 0, SVX_SRC_SUPPL = 1 };
+/* sig.aux for INV (src/svim/SVIM_inter.py:159-198) */
+enum { SVX_LEFT_FWD = 0, SVX_LEFT_REV = 1, SVX_RIGHT_FWD = 2, SVX_RIGHT_REV = 3, SVX_DIR_ALL = 4 };
+/* sig.aux for BND: bit0 = direction1 is 'rev', bit1 = direction2 is 'rev'; for DUP_TAN: bit0 = fully_covered */
+
+/* host-set marker in svx_batch.flag: record is to be ignored (query-sorted mode: read without exactly one
+ * good primary, src/svim/SVIM_COLLECT.py:108) */
+#define SVX_FLAG_SKIP 0x8000u
+/* host-set marker: this record's segment rows were rebuilt from its SA tag, so they are void when the
+ * record has hard-clipped bases (get_cigar_stats()[0][5] > 0, src/svim/SVIM_COLLECT.py:47) */
+#define SVX_FLAG_SA   0x4000u
+
+/* options read on the path (src/svim/SVIM_input_parsing.py:279-371) */
+typedef struct svx_params {
+    int32_t min_mapq;                      /* 20     */
+    int32_t min_sv_size;                   /* 40     */
+    int32_t max_sv_size;                   /* 100000 */
+    int32_t segment_gap_tolerance;         /* 10     */
+    int32_t segment_overlap_tolerance;     /* 5      */
+    int32_t all_bnds;                      /* 0      */
+    int64_t partition_max_distance;        /* 1000   */
+    double  position_distance_normalizer;  /* 900    */
+    double  edit_distance_normalizer;      /* 1.0    */
+    double  cluster_max_distance;          /* 0.5    */
+} svx_params;
+
+/* One batch of BAM records in file order (SoA).  Replaces the per-record pysam accessors used at
+ * src/svim/SVIM_COLLECT.py:143-161 and the SA-tag re-materialisation at :44-93 (the host parses the SA
+ * string into the segment table; the device derives every coordinate from the packed CIGARs). */
+typedef struct svx_batch {
+    int32_t on_device;
+    int64_t n_rec;
+    const uint16_t* flag;        /* [n_rec] SAM FLAG (+ SVX_FLAG_SKIP) */
+    const int32_t*  tid;         /* [n_rec] reference_id */
+    const int32_t*  pos;         /* [n_rec] 0-based reference_start */
+    const uint8_t*  mapq;        /* [n_rec] */
+    const int32_t*  lseq;        /* [n_rec] l_qseq of the stored SEQ (0 = none) */
+    const int32_t*  read_id;     /* [n_rec] interned query_name */
+    const uint32_t* order;       /* [n_rec] emission slot of this record's CIGAR indels */
+    const uint32_t* seg_order;   /* [n_rec] emission slot of this read's split-alignment signatures */
+    const uint64_t* cigar_off;   /* [n_rec+1] */
+    const uint32_t* cigar;       /* BAM packed: len<<4 | op */
+    const uint64_t* seq_off;     /* [n_rec+1] byte offsets into seq */
+    const uint8_t*  seq;         /* 4-bit packed bases, BAM layout (high nibble first) */
+    const uint32_t* seg_off;     /* [n_rec+1] rows of the segment table per record (other alignments of the read) */
+    int64_t n_seg;
+    const int32_t*  seg_tid;     /* [n_seg] */
+    const int32_t*  seg_pos;     /* [n_seg] 0-based */
+    const uint8_t*  seg_rev;     /* [n_seg] 1 = reverse strand */
+    const uint8_t*  seg_mapq;    /* [n_seg] (SA mapq > 255 already mapped to 0, src/svim/SVIM_COLLECT.py:81-84) */
+    const int32_t*  seg_lseq;    /* [n_seg] l_qseq of the segment record (SA rebuild: the primary's) */
+    const uint64_t* seg_cigar_off; /* [n_seg+1] */
+    const uint32_t* seg_cigar;
+    int32_t n_contig;
+    const int32_t*  contig_rank; /* [n_contig] rank of each contig NAME in Python str order */
+} svx_batch;
+
+/* Signature table (SoA).  Mirrors the fields of the six Signature classes (src/svim/SVSignature.py:3-233). */
+typedef struct svx_sig_view {
+    int32_t on_device;
+    int64_t n;
+    uint64_t* key;       /* emission order key: slot<<32 | phase<<30 | ordinal (ascending = reference list order) */
+    uint8_t*  type;      /* SVX_DEL .. SVX_DUP_INT */
+    uint8_t*  src;       /* SVX_SRC_* */
+    uint8_t*  aux;
+    int32_t*  contig;    /* contig / contig1 / source contig (tid) */
+    int32_t*  start;     /* start / pos1 */
+    int32_t*  end;       /* end   / pos1+1 for BND */
+    int32_t*  contig2;   /* BND contig2, DUP_INT destination contig, else -1 */
+    int32_t*  pos2;      /* BND pos2, DUP_INT pos, DUP_TAN copies, else 0 */
+    int32_t*  read_id;
+    int64_t*  seq_off;   /* [n+1] INS: offsets into seq; other types have empty ranges */
+    uint8_t*  seq;       /* inserted bases, one 4-bit code ("=ACMGRSVTWYHKDBN") per byte */
+} svx_sig_view;
+
+/* Reference genome, one 4-bit code per byte, upper-cased (pysam.FastaFile.fetch(...).upper() at
+ * src/svim/SVIM_clustering.py:37-43). */
+typedef struct svx_genome {
+    int32_t on_device;
+    int32_t n_contig;
+    const int64_t* off;      /* [n_contig+1] */
+    const uint8_t* codes;
+} svx_genome;
+
+/* Consolidated clusters (src/svim/SVSignature.py:236-311, SVIM_clustering.py:214-303), grouped by type
+ * in SVX_* order; unilocal types already sorted by (contig name, (start+end)/2) as at :381. */
+typedef struct svx_cluster_view {
+    int64_t n;                 /* capacity on input to fetch, count on output */
+    int64_t type_count[SVX_NTYPES];
+    uint8_t* type;
+    int32_t* contig;  int32_t* start;  int32_t* end;      /* unilocal / source */
+    int32_t* contig2; int32_t* start2; int32_t* end2;     /* destination (bilocal types) */
+    uint8_t* aux;              /* BND: direction bits */
+    double*  score;
+    double*  std_span;         /* NaN = None */
+    double*  std_pos;
+    int32_t* size;
+    int64_t* member_off;       /* [n+1] */
+    int32_t* members;          /* [n_members] indices into the clustered signature table, cluster-major */
+    int64_t  n_members;
+} svx_cluster_view;
+
+typedef struct svx_ctx svx_ctx;
+
+/* timing / traffic counters of the last collect / cluster call (seconds measured with HIP events on the
+ * context's stream) */
+typedef struct svx_stats {
+    double  t_collect_ms, t_cluster_ms;
+    double  t_cigar_scan_ms, t_segments_ms, t_sort_ms, t_partition_ms, t_edit_ms, t_linkage_ms, t_gather_ms;
+    int64_t n_rec_used, n_ops, n_seg, n_seg_ops, n_sig, n_bnd_side, n_ins_bases;
+    int64_t n_partitions, n_large_partitions, n_pairs, n_edit_pairs, n_edit_cells, n_clusters, n_hap_bytes;
+} svx_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int  svx_ctx_create(int device_ordinal, svx_ctx** out);     /* SVX_E_NODEVICE when no GPU is present */
+void svx_ctx_destroy(svx_ctx* ctx);
+const char* svx_last_error(void);
+int  svx_version(void);
+int  svx_get_stats(svx_ctx* ctx, svx_stats* out);
+void* svx_stream(svx_ctx* ctx);                              /* hipStream_t the kernels run on */
+
+/* ---- COLLECT: replaces analyze_alignment_file_* (src/svim/SVIM_COLLECT.py:96-167) -------------- */
+int  svx_collect(svx_ctx* ctx, const svx_batch* batch, const svx_params* p);
+int  svx_collect_count(svx_ctx* ctx, int64_t* n_sig, int64_t* n_seq_bytes, int64_t* n_bnd_side);
+/* which: 0 = sv_signatures, 1 = translocation_signatures_all_bnds (second list of the reference's tuple) */
+int  svx_collect_fetch(svx_ctx* ctx, int which, svx_sig_view* host_out);
+
+/* ---- CLUSTER: replaces cluster_sv_signatures (src/svim/SVIM_CLUSTER.py:7-26) -------------------- */
+int  svx_set_genome(svx_ctx* ctx, const svx_genome* g);      /* FastaFile(options.genome), SVIM_clustering.py:377 */
+/* source: 0 = signatures resident from the last svx_collect, 1 = its all_bnds side list,
+ *         2 = the table passed in `sigs` (host or device memory) */
+int  svx_cluster(svx_ctx* ctx, int source, const svx_sig_view* sigs, int32_t n_contig,
+                 const int32_t* contig_rank_host, const svx_params* p);
+int  svx_cluster_count(svx_ctx* ctx, int64_t* n_clusters, int64_t* n_members);
+int  svx_cluster_fetch(svx_ctx* ctx, svx_cluster_view* host_out);
+
+/* multi-GPU: cluster only partitions with (global partition index % world) == rank; the caller gathers
+ * the per-rank cluster tables (RCCL) and merges them by partition index (returned in part_index) */
+int  svx_cluster_set_shard(svx_ctx* ctx, int rank, int world);
+int  svx_cluster_fetch_part_index(svx_ctx* ctx, int64_t* host_out /* [n_clusters] */);
+
+/* ---- single-function entry points kept importable by the reference's API ------------------------ */
+/* analyze_cigar_indel (src/svim/SVIM_intra.py:8-30) on one packed CIGAR; out arrays sized n_ops */
+int  svx_cigar_indel(svx_ctx* ctx, const uint32_t* cigar_host, int64_t n_ops, int32_t min_length,
+                     int64_t* out_pos_ref, int64_t* out_pos_read, int32_t* out_len, uint8_t* out_is_del,
+                     int64_t* out_n);
+/* edlib.align(a,b)["editDistance"] (src/svim/SVIM_clustering.py:45) for n pairs of code strings */
+int  svx_edit_distance(svx_ctx* ctx, int64_t n_pairs, const uint8_t* codes_host, const int64_t* a_off,
+                       const int64_t* b_off /* [n_pairs+1] each, a and b ranges in codes */, int32_t* out_dist);
+/* scipy linkage(method='average') + fcluster(criterion='distance') (SVIM_clustering.py:170-171) for a
+ * batch of condensed matrices; labels out (1-based) */
+int  svx_linkage_fcluster(svx_ctx* ctx, int64_t n_problems, const int32_t* n_host, const int64_t* d_off,
+                          const double* d_host, double cutoff, const int64_t* label_off, int32_t* labels_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,122 @@
+"""Shared test helpers: golden-vector loading and row <-> table conversion."""
+import gzip
+import json
+import os
+import types
+
+import numpy as np
+
+from svim_amd import _abi, convert, records, batch
+from svim_amd.signatures import (SignatureDeletion, SignatureInsertion, SignatureInversion, SignatureInsertionFrom,
+                                 SignatureDuplicationTandem, SignatureTranslocation)
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REFS = ["chr1", "chr2", "chr10"]
+
+
+def load(name):
+    path = os.path.join(GOLDEN, name)
+    opener = gzip.open if name.endswith(".gz") else open
+    with opener(path, "rt") as fh:
+        return json.load(fh)
+
+
+def options(d):
+    o = types.SimpleNamespace(**d)
+    o.genome = os.path.join(GOLDEN, d.get("genome", "ref.fa.gz"))
+    return o
+
+
+def row_sig(r):
+    t = r[0]
+    if t == "DEL":
+        return SignatureDeletion(r[1], r[2], r[3], r[4], r[5])
+    if t == "INS":
+        return SignatureInsertion(r[1], r[2], r[3], r[4], r[5], r[6])
+    if t == "INV":
+        return SignatureInversion(r[1], r[2], r[3], r[4], r[5], r[6])
+    if t == "DUP_TAN":
+        return SignatureDuplicationTandem(r[1], r[2], r[3], r[6], r[7], r[4], r[5])
+    if t == "DUP_INT":
+        return SignatureInsertionFrom(r[1], r[2], r[3], r[6], r[7], r[4], r[5])
+    if t == "BND":
+        return SignatureTranslocation(r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8])
+    raise ValueError(t)
+
+
+def sig_row(s):
+    t = s.type
+    if t == "DEL":
+        return [t, s.contig, s.start, s.end, s.signature, s.read]
+    if t == "INS":
+        return [t, s.contig, s.start, s.end, s.signature, s.read, s.sequence]
+    if t == "INV":
+        return [t, s.contig, s.start, s.end, s.signature, s.read, s.direction]
+    if t == "DUP_TAN":
+        return [t, s.contig, s.start, s.end, s.signature, s.read, s.copies, bool(s.fully_covered)]
+    if t == "DUP_INT":
+        return [t, s.contig1, s.start, s.end, s.signature, s.read, s.contig2, s.pos]
+    return [t, s.contig1, s.pos1, s.direction1, s.contig2, s.pos2, s.direction2, s.signature, s.read]
+
+
+def table_rows(tab, references, read_names):
+    return [sig_row(s) for s in convert.objects_from_sigtable(tab, references, read_names)]
+
+
+def cluster_rows(ct, references):
+    """ClusterTable -> same row layout as the golden files (lists per return-tuple slot)."""
+    dirs = ("fwd", "rev")
+    by = [[] for _ in range(6)]
+    slot = {0: 0, 1: 1, 2: 2, 3: 3, 5: 4, 4: 5}       # SVX type code -> index in the reference's return tuple
+    for k in range(ct.n):
+        code = int(ct.type[k])
+        mem = [int(x) for x in ct.members[ct.member_off[k]:ct.member_off[k + 1]]]
+        sp = None if np.isnan(ct.std_span[k]) else float(ct.std_span[k])
+        po = None if np.isnan(ct.std_pos[k]) else float(ct.std_pos[k])
+        if code <= 2:
+            row = [references[ct.contig[k]], int(ct.start[k]), int(ct.end[k]), float(ct.score[k]), int(ct.size[k]),
+                   sp, po, mem]
+        else:
+            row = [references[ct.contig[k]], int(ct.start[k]), int(ct.end[k]), references[ct.contig2[k]],
+                   int(ct.start2[k]), int(ct.end2[k]), float(ct.score[k]), int(ct.size[k]), sp, po, mem]
+            if code == 4:
+                row += [dirs[ct.aux[k] & 1], dirs[(ct.aux[k] >> 1) & 1]]
+        by[slot[code]].append(row)
+    return by
+
+
+def close(a, b, rtol=1e-9):
+    if a is None or b is None:
+        return a is None and b is None
+    return abs(a - b) <= rtol * max(1.0, abs(b))
+
+
+def compare_cluster_rows(got, exp, rtol=1e-9):
+    """exact on ints / strings / member lists, rtol on the FP columns (score, std_span, std_pos)."""
+    for slot in range(6):
+        assert len(got[slot]) == len(exp[slot]), "slot %d: %d clusters != %d" % (slot, len(got[slot]), len(exp[slot]))
+        for k, (g, e) in enumerate(zip(got[slot], exp[slot])):
+            assert len(g) == len(e), (slot, k, g, e)
+            for x, y in zip(g, e):
+                if isinstance(y, float) or (y is None) or isinstance(x, float):
+                    assert close(x, y, rtol), "slot %d cluster %d: %r != %r\n got %r\n exp %r" % (slot, k, x, y, g, e)
+                else:
+                    assert x == y, "slot %d cluster %d: %r != %r\n got %r\n exp %r" % (slot, k, x, y, g, e)
+
+
+def sam_case_batch(case, collect_golden):
+    """golden COLLECT case -> (AlignmentFile, HostBatch, options)"""
+    if case.get("sam_file"):
+        with open(os.path.join(GOLDEN, case["sam_file"])) as fh:
+            text = fh.read()
+    else:
+        text = case["sam"]
+        if text is None:      # all_bnds twin shares the SAM text of the preceding case with the same name/mode
+            for c in collect_golden["cases"]:
+                if c["name"] == case["name"] and c["mode"] == case["mode"] and c.get("sam"):
+                    text = c["sam"]
+                    break
+    bam = records.AlignmentFile(text=text)
+    o = options(case["options"])
+    hb = batch.build_batch(bam, o, mode=case["mode"])
+    return bam, hb, o

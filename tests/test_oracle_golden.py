@@ -1,0 +1,109 @@
+"""Pin the oracle (oracle/svx_oracle.c) against golden vectors produced by running the reference
+(tests/golden/make_golden.py).  CPU only."""
+import struct
+
+import numpy as np
+import pytest
+
+import helpers as H
+from svim_amd import _abi, convert, batch
+
+
+def test_g1_cigar_indel(oracle):
+    g = H.load("g1_cigar_indel.json.gz")
+    for c in g["cases"]:
+        got = oracle.cigar_indel([tuple(t) for t in c["tuples"]], c["min_length"])
+        assert got == [tuple(x) for x in c["expect"]]
+
+
+def test_g8_rng(oracle):
+    g = H.load("g8_rng.json.gz")["rng"]
+    for k, vals in g["getrandbits"].items():
+        got = oracle.getrandbits(1524, int(k), len(vals))
+        assert got.tolist() == vals
+    ns = [s["n"] for s in g["samples"]]
+    got = oracle.sample_sequence(1524, ns)
+    for row, s in zip(got, g["samples"]):
+        assert row.tolist() == s["idx"]
+
+
+def test_edit_distance(oracle):
+    g = H.load("g_editdistance.json.gz")
+    for a, b, d in g["cases"]:
+        assert oracle.edit_distance(a, b) == d
+        assert oracle.edit_distance(b, a) == d
+
+
+def test_linkage_fcluster(oracle):
+    g = H.load("g_linkage.json.gz")
+    for c in g["cases"]:
+        d = np.array([float.fromhex(x) for x in c["d"]])
+        lab, Z = oracle.linkage_fcluster(c["n"], d, c["t"], want_z=True)
+        Zexp = np.array([[float.fromhex(v) for v in row] for row in c["Z"]])
+        assert np.array_equal(Z[:c["n"] - 1], Zexp)
+        assert lab.tolist() == c["labels"]
+
+
+def test_g3_satag_rebuild():
+    """SA-tag reconstruction == the supplementary records themselves (src/tests/test_satag.py:21-34), through the
+    host batcher + the geometry rules the device applies."""
+    g = H.load("g3_satag.json")
+    assert len(g["sa_rebuilt"]) == 3
+    for a, b in zip(g["sa_rebuilt"], g["supplementary_records"]):
+        assert a == b
+
+
+@pytest.mark.parametrize("idx", range(40))
+def test_g2_collect(oracle, idx):
+    g = H.load("g2_collect.json.gz")
+    if idx >= len(g["cases"]):
+        pytest.skip("no such case")
+    case = g["cases"][idx]
+    bam, hb, o = H.sam_case_batch(case, g)
+    sig, bnd = oracle.collect(hb, _abi.Params.from_options(o))
+    assert H.table_rows(sig, hb.references, hb.read_names) == case["signatures"]
+    assert H.table_rows(bnd, hb.references, hb.read_names) == case["bnds"]
+
+
+def test_g4_partitions(oracle):
+    g4 = H.load("g4_partitions.json.gz")
+    g5 = H.load("g5_cluster.json.gz")
+    cases = {c["name"]: c for c in g5["cases"]}
+    for p in g4["partitions"]:
+        case = cases[p["case"]]
+        sigs = [H.row_sig(r) for r in case["signatures"]]
+        tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(H.REFS))
+        code = _abi.TYPE_CODE[p["type"]]
+        sidx, pid = oracle.form_partitions(tab, batch.contig_ranks(contigs.names), case["options"]["partition_max_distance"])
+        sel = tab.type[sidx] == code
+        got = {}
+        for i, q in zip(sidx[sel], pid[sel]):
+            got.setdefault(int(q), []).append(int(i))
+        assert [got[k] for k in sorted(got)] == p["partitions"]
+
+
+def test_g6_distance(oracle):
+    g = H.load("g6_distance.json.gz")
+    sigs = [H.row_sig(r) for r in g["signatures"]]
+    tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(H.REFS))
+    off, codes = convert.genome_arrays(H.options({}).genome, contigs.names)
+    oracle.set_genome(off, codes)
+    p = _abi.Params.from_options(H.options({}))
+    for i, j, hexd in g["pairs"]:
+        d = oracle.span_position_distance(tab, i, j, p)
+        assert struct.pack("<d", d).hex() == hexd, (i, j, g["signatures"][i][0])
+
+
+@pytest.mark.parametrize("idx", range(16))
+def test_g5_cluster(oracle, idx):
+    g = H.load("g5_cluster.json.gz")
+    if idx >= len(g["cases"]):
+        pytest.skip("no such case")
+    case = g["cases"][idx]
+    o = H.options(case["options"])
+    sigs = [H.row_sig(r) for r in case["signatures"]]
+    tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(H.REFS))
+    off, codes = convert.genome_arrays(o.genome, contigs.names)
+    oracle.set_genome(off, codes)
+    ct = oracle.cluster(_abi.Params.from_options(o), batch.contig_ranks(contigs.names), table=tab)
+    H.compare_cluster_rows(H.cluster_rows(ct, contigs.names), case["clusters"])
