@@ -1,0 +1,193 @@
+"""ctypes binding of svim_amd/libsvx.so (the C ABI declared in include/svx.h).
+
+There is no CPU fallback: if the HIP library is missing, or no MI355X is visible, every entry point of the
+package raises (SvxError) instead of silently computing somewhere else.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _abi
+from ._abi import ClusterTable, SigTable, ptr
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsvx.so")
+_LIB = None
+_ENGINES = {}
+
+SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream",
+           "svx_collect", "svx_collect_count", "svx_collect_fetch", "svx_set_genome", "svx_cluster",
+           "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_shard", "svx_cluster_fetch_part_index",
+           "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster"]
+
+
+class SvxError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "clean"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(_HERE, "csrc")])
+    return _LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIB_PATH):
+            raise SvxError("svim_amd/libsvx.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C svim_amd/csrc`); the GPU path has no CPU fallback")
+        L = C.CDLL(_LIB_PATH)
+        L.svx_last_error.restype = C.c_char_p
+        L.svx_stream.restype = C.c_void_p
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().svx_last_error().decode("utf-8", "replace")
+        raise SvxError("%s failed: %s (%s)" % (what, _abi.ERRORS.get(rc, rc), msg))
+
+
+class Engine(object):
+    """One libsvx context on one GPU."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.ctx = C.c_void_p()
+        _check(self.L.svx_ctx_create(C.c_int(device), C.byref(self.ctx)), "svx_ctx_create")
+        self.device = device
+        self._keep = []
+
+    def close(self):
+        if self.ctx:
+            self.L.svx_ctx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- COLLECT ----
+    def collect(self, hb, params, fetch=True):
+        b = hb.struct() if hasattr(hb, "struct") else hb
+        _check(self.L.svx_collect(self.ctx, C.byref(b), C.byref(params)), "svx_collect")
+        if not fetch:
+            return None
+        return self.fetch_signatures(0), self.fetch_signatures(1)
+
+    def collect_counts(self):
+        n, ns, nb = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(self.L.svx_collect_count(self.ctx, C.byref(n), C.byref(ns), C.byref(nb)), "svx_collect_count")
+        return n.value, ns.value, nb.value
+
+    def fetch_signatures(self, which):
+        n, ns, nb = self.collect_counts()
+        t = SigTable(n if which == 0 else nb, ns if which == 0 else 0)
+        v = t.view()
+        _check(self.L.svx_collect_fetch(self.ctx, which, C.byref(v)), "svx_collect_fetch")
+        return t
+
+    # ---- CLUSTER ----
+    def set_genome(self, off, codes, on_device=False):
+        g = _abi.Genome(1 if on_device else 0, len(off) - 1 if not on_device else int(off.shape[0]) - 1, ptr(off), ptr(codes))
+        self._keep = [off, codes]
+        _check(self.L.svx_set_genome(self.ctx, C.byref(g)), "svx_set_genome")
+
+    def cluster(self, params, contig_rank, table=None, source=2, shard=None, fetch=True):
+        if shard is not None:
+            _check(self.L.svx_cluster_set_shard(self.ctx, shard[0], shard[1]), "svx_cluster_set_shard")
+        v = table.view() if (table is not None and hasattr(table, "view")) else (table if table is not None else _abi.SigView())
+        rank = np.ascontiguousarray(contig_rank, dtype=np.int32)
+        _check(self.L.svx_cluster(self.ctx, source, C.byref(v), len(rank), ptr(rank), C.byref(params)), "svx_cluster")
+        if not fetch:
+            return None
+        return self.fetch_clusters()
+
+    def fetch_clusters(self):
+        n, nm = C.c_int64(), C.c_int64()
+        _check(self.L.svx_cluster_count(self.ctx, C.byref(n), C.byref(nm)), "svx_cluster_count")
+        ct = ClusterTable(n.value, nm.value)
+        cv = ct.view()
+        _check(self.L.svx_cluster_fetch(self.ctx, C.byref(cv)), "svx_cluster_fetch")
+        ct.finish(cv)
+        pi = np.zeros(max(1, n.value), dtype=np.int64)
+        _check(self.L.svx_cluster_fetch_part_index(self.ctx, ptr(pi)), "svx_cluster_fetch_part_index")
+        ct.part_index = pi[:n.value]
+        return ct
+
+    def stats(self):
+        s = _abi.Stats()
+        _check(self.L.svx_get_stats(self.ctx, C.byref(s)), "svx_get_stats")
+        return s.as_dict()
+
+    def stream(self):
+        return self.L.svx_stream(self.ctx)
+
+    # ---- single-function entry points ----
+    def cigar_indel(self, tuples, min_length):
+        c = np.array([(l << 4) | op for op, l in tuples] or [0], dtype=np.uint32)
+        n = len(tuples)
+        o_ref = np.zeros(max(1, n), dtype=np.int64)
+        o_read = np.zeros(max(1, n), dtype=np.int64)
+        o_len = np.zeros(max(1, n), dtype=np.int32)
+        o_del = np.zeros(max(1, n), dtype=np.uint8)
+        m = C.c_int64()
+        _check(self.L.svx_cigar_indel(self.ctx, ptr(c), C.c_int64(n), C.c_int32(min_length), ptr(o_ref), ptr(o_read),
+                                      ptr(o_len), ptr(o_del), C.byref(m)), "svx_cigar_indel")
+        return [(int(o_ref[i]), int(o_read[i]), int(o_len[i]), "DEL" if o_del[i] else "INS") for i in range(m.value)]
+
+    def edit_distances(self, pairs):
+        """pairs: list of (a, b) strings -> list of unit-cost global edit distances."""
+        chunks, a_off, b_off = [], [0], [0]
+        pos = 0
+        # layout: all a strings, then all b strings; a_off/b_off index into the same code array
+        for a, _ in pairs:
+            c = _abi.encode_bases(a)
+            chunks.append(c)
+            pos += c.size
+            a_off.append(pos)
+        b_off = [pos]
+        for _, b in pairs:
+            c = _abi.encode_bases(b)
+            chunks.append(c)
+            pos += c.size
+            b_off.append(pos)
+        codes = np.concatenate(chunks + [np.zeros(1, np.uint8)])
+        a_off = np.array(a_off, dtype=np.int64)
+        b_off = np.array(b_off, dtype=np.int64)
+        out = np.zeros(max(1, len(pairs)), dtype=np.int32)
+        _check(self.L.svx_edit_distance(self.ctx, C.c_int64(len(pairs)), ptr(codes), ptr(a_off), ptr(b_off), ptr(out)),
+               "svx_edit_distance")
+        return [int(x) for x in out[:len(pairs)]]
+
+    def linkage_fcluster(self, problems, cutoff):
+        """problems: list of (n, condensed distance array) -> list of label arrays (1-based, scipy numbering)."""
+        ns = np.array([p[0] for p in problems], dtype=np.int32)
+        d_off = np.zeros(len(problems) + 1, dtype=np.int64)
+        l_off = np.zeros(len(problems) + 1, dtype=np.int64)
+        for i, (n, d) in enumerate(problems):
+            d_off[i + 1] = d_off[i] + n * (n - 1) // 2
+            l_off[i + 1] = l_off[i] + n
+        d = np.concatenate([np.asarray(p[1], dtype=np.float64).ravel() for p in problems] + [np.zeros(1)])
+        lab = np.zeros(max(1, int(l_off[-1])), dtype=np.int32)
+        _check(self.L.svx_linkage_fcluster(self.ctx, C.c_int64(len(problems)), ptr(ns), ptr(d_off), ptr(d), C.c_double(cutoff),
+                                           ptr(l_off), ptr(lab)), "svx_linkage_fcluster")
+        return [lab[l_off[i]:l_off[i + 1]].copy() for i in range(len(problems))]
+
+
+def engine(device=None):
+    """Process-wide engine for `device` (default: LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    e = _ENGINES.get(device)
+    if e is None:
+        e = _ENGINES[device] = Engine(device)
+    return e

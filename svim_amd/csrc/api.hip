@@ -1,0 +1,282 @@
+// api.hip - the extern "C" boundary of libsvx.so (include/svx.h).
+#include "common.hpp"
+
+thread_local std::string g_svx_err;
+
+int svx_fail(int code, const char* what, const char* file, int line, hipError_t e) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed at %s:%d%s%s", what, file, line, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+    g_svx_err = buf;
+    return code;
+}
+
+extern "C" const char* svx_last_error(void) { return g_svx_err.c_str(); }
+extern "C" int svx_version(void) { return 100; }
+
+extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || device_ordinal >= ndev)
+        return svx_fail(SVX_E_NODEVICE, "no HIP device available (libsvx has no CPU fallback)", __FILE__, __LINE__, e);
+    HIPCHK(hipSetDevice(device_ordinal));
+    svx_ctx* c = new svx_ctx();
+    c->device = device_ordinal;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& ev : c->ev) HIPCHK(hipEventCreate(&ev));
+    memset(&c->stats, 0, sizeof c->stats);
+    *out = c;
+    return SVX_OK;
+}
+
+extern "C" void svx_ctx_destroy(svx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& b : c->batch_bufs) b.release();
+    c->sig.release(); c->bnd.release(); c->raw_sig.release(); c->raw_bnd.release();
+    DevBuf* bufs[] = {&c->counters, &c->rec_geom, &c->seg_geom, &c->seg_ws, &c->tmp0, &c->tmp1, &c->tmp2, &c->tmp3, &c->tmp4, &c->tmp5, &c->sort_tmp,
+                      &c->g_off, &c->g_codes, &c->c_rank, &c->k_hi, &c->k_lo, &c->k_idx, &c->k_hi2, &c->k_lo2, &c->k_idx2, &c->part_flag, &c->part_id,
+                      &c->part_start, &c->part_meta, &c->samp_idx, &c->large_list, &c->pair_off, &c->ed, &c->work, &c->stage, &c->stage_members, &c->labels,
+                      &c->clu.type, &c->clu.contig, &c->clu.start, &c->clu.end, &c->clu.contig2, &c->clu.start2, &c->clu.end2, &c->clu.aux, &c->clu.score,
+                      &c->clu.std_span, &c->clu.std_pos, &c->clu.size, &c->clu.member_off, &c->clu.members, &c->clu.part_index};
+    for (auto* b : bufs) b->release();
+    for (auto& b : c->user_sig) b.release();
+    for (auto& ev : c->ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void* svx_stream(svx_ctx* c) { return (void*)c->stream; }
+extern "C" int svx_get_stats(svx_ctx* c, svx_stats* out) { *out = c->stats; return SVX_OK; }
+
+static int upload(svx_ctx* c, DevBuf& d, const void* host, size_t bytes, size_t pad = 64) {
+    SVXCHK(d.reserve(bytes + pad));
+    if (bytes) HIPCHK(hipMemcpyAsync(d.p, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return SVX_OK;
+}
+
+// ---- COLLECT -----------------------------------------------------------------------------------------------
+extern "C" int svx_collect(svx_ctx* c, const svx_batch* b, const svx_params* p) {
+    if (!c || !b || !p) return svx_fail(SVX_E_ARG, "null argument", __FILE__, __LINE__, hipSuccess);
+    HIPCHK(hipSetDevice(c->device));
+    svx_batch d = *b;
+    if (!b->on_device) {
+        // host batch: read the array extents from the offset tables and stage everything in HBM
+        const size_t n = (size_t)b->n_rec, ns = (size_t)b->n_seg;
+        const size_t n_ops = n ? (size_t)b->cigar_off[n] : 0, n_seq = n ? (size_t)b->seq_off[n] : 0;
+        const size_t n_sops = ns ? (size_t)b->seg_cigar_off[ns] : 0;
+        if (c->batch_bufs.size() < 21) c->batch_bufs.resize(21);
+        auto& B = c->batch_bufs;
+        SVXCHK(upload(c, B[0], b->flag, n * 2)); d.flag = B[0].as<uint16_t>();
+        SVXCHK(upload(c, B[1], b->tid, n * 4)); d.tid = B[1].as<int32_t>();
+        SVXCHK(upload(c, B[2], b->pos, n * 4)); d.pos = B[2].as<int32_t>();
+        SVXCHK(upload(c, B[3], b->mapq, n)); d.mapq = B[3].as<uint8_t>();
+        SVXCHK(upload(c, B[4], b->lseq, n * 4)); d.lseq = B[4].as<int32_t>();
+        SVXCHK(upload(c, B[5], b->read_id, n * 4)); d.read_id = B[5].as<int32_t>();
+        SVXCHK(upload(c, B[6], b->order, n * 4)); d.order = B[6].as<uint32_t>();
+        SVXCHK(upload(c, B[7], b->seg_order, n * 4)); d.seg_order = B[7].as<uint32_t>();
+        SVXCHK(upload(c, B[8], b->cigar_off, (n + 1) * 8)); d.cigar_off = B[8].as<uint64_t>();
+        SVXCHK(upload(c, B[9], b->cigar, n_ops * 4)); d.cigar = B[9].as<uint32_t>();
+        SVXCHK(upload(c, B[10], b->seq_off, (n + 1) * 8)); d.seq_off = B[10].as<uint64_t>();
+        SVXCHK(upload(c, B[11], b->seq, n_seq)); d.seq = B[11].as<uint8_t>();
+        SVXCHK(upload(c, B[12], b->seg_off, (n + 1) * 4)); d.seg_off = B[12].as<uint32_t>();
+        SVXCHK(upload(c, B[13], b->seg_tid, ns * 4)); d.seg_tid = B[13].as<int32_t>();
+        SVXCHK(upload(c, B[14], b->seg_pos, ns * 4)); d.seg_pos = B[14].as<int32_t>();
+        SVXCHK(upload(c, B[15], b->seg_rev, ns)); d.seg_rev = B[15].as<uint8_t>();
+        SVXCHK(upload(c, B[16], b->seg_mapq, ns)); d.seg_mapq = B[16].as<uint8_t>();
+        SVXCHK(upload(c, B[17], b->seg_lseq, ns * 4)); d.seg_lseq = B[17].as<int32_t>();
+        SVXCHK(upload(c, B[18], b->seg_cigar_off, (ns + 1) * 8)); d.seg_cigar_off = B[18].as<uint64_t>();
+        SVXCHK(upload(c, B[19], b->seg_cigar, n_sops * 4)); d.seg_cigar = B[19].as<uint32_t>();
+        SVXCHK(upload(c, B[20], b->contig_rank, (size_t)b->n_contig * 4)); d.contig_rank = B[20].as<int32_t>();
+        d.on_device = 1;
+    }
+    return svx_collect_impl(c, &d, p);
+}
+
+extern "C" int svx_collect_count(svx_ctx* c, int64_t* n_sig, int64_t* n_seq, int64_t* n_bnd) {
+    if (n_sig) *n_sig = c->sig.n;
+    if (n_seq) *n_seq = c->sig.n_seq;
+    if (n_bnd) *n_bnd = c->bnd.n;
+    return SVX_OK;
+}
+
+extern "C" int svx_collect_fetch(svx_ctx* c, int which, svx_sig_view* o) {
+    HIPCHK(hipSetDevice(c->device));
+    DevSigs& s = which ? c->bnd : c->sig;
+    const size_t n = (size_t)s.n;
+    hipStream_t st = c->stream;
+#define D2H(dst, buf, bytes) do { if ((bytes) && (dst)) HIPCHK(hipMemcpyAsync((dst), (buf).p, (bytes), hipMemcpyDeviceToHost, st)); } while (0)
+    D2H(o->key, s.key, n * 8); D2H(o->type, s.type, n); D2H(o->src, s.src, n); D2H(o->aux, s.aux, n);
+    D2H(o->contig, s.contig, n * 4); D2H(o->start, s.start, n * 4); D2H(o->end, s.end, n * 4); D2H(o->contig2, s.contig2, n * 4);
+    D2H(o->pos2, s.pos2, n * 4); D2H(o->read_id, s.read_id, n * 4);
+    if (o->seq_off) HIPCHK(hipMemcpyAsync(o->seq_off, s.seq_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    D2H(o->seq, s.seq, (size_t)s.n_seq);
+#undef D2H
+    HIPCHK(hipStreamSynchronize(st));
+    o->n = s.n;
+    return SVX_OK;
+}
+
+// ---- genome --------------------------------------------------------------------------------------------------
+extern "C" int svx_set_genome(svx_ctx* c, const svx_genome* g) {
+    HIPCHK(hipSetDevice(c->device));
+    c->g_n = g->n_contig;
+    if (g->on_device) {
+        c->g_off_p = g->off; c->g_codes_p = g->codes; c->g_borrowed = true;
+        return SVX_OK;
+    }
+    const size_t n = (size_t)g->n_contig;
+    const size_t tot = (size_t)g->off[n];
+    SVXCHK(upload(c, c->g_off, g->off, (n + 1) * 8));
+    SVXCHK(upload(c, c->g_codes, g->codes, tot));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->g_off_p = c->g_off.as<int64_t>(); c->g_codes_p = c->g_codes.as<uint8_t>(); c->g_borrowed = false;
+    return SVX_OK;
+}
+
+// ---- CLUSTER -------------------------------------------------------------------------------------------------
+extern "C" int svx_cluster(svx_ctx* c, int source, const svx_sig_view* sigs, int32_t n_contig, const int32_t* contig_rank_host, const svx_params* p) {
+    if (!c || !p || !contig_rank_host) return svx_fail(SVX_E_ARG, "null argument", __FILE__, __LINE__, hipSuccess);
+    HIPCHK(hipSetDevice(c->device));
+    SVXCHK(upload(c, c->c_rank, contig_rank_host, (size_t)n_contig * 4));
+    ClusterIn in;
+    if (source == 0 || source == 1) {
+        DevSigs& s = source ? c->bnd : c->sig;
+        in.n = s.n; in.type = s.type.as<uint8_t>(); in.aux = s.aux.as<uint8_t>(); in.contig = s.contig.as<int32_t>(); in.start = s.start.as<int32_t>();
+        in.end = s.end.as<int32_t>(); in.contig2 = s.contig2.as<int32_t>(); in.pos2 = s.pos2.as<int32_t>(); in.read_id = s.read_id.as<int32_t>();
+        in.seq_off = s.seq_off.as<int64_t>(); in.seq = s.seq.as<uint8_t>();
+        if (s.n > 0 && !s.seq_off.p) return svx_fail(SVX_E_STATE, "no resident signatures: run svx_collect first", __FILE__, __LINE__, hipSuccess);
+    } else if (source == 2) {
+        if (!sigs) return svx_fail(SVX_E_ARG, "source 2 needs a signature table", __FILE__, __LINE__, hipSuccess);
+        in.n = sigs->n;
+        if (sigs->on_device) {
+            in.type = sigs->type; in.aux = sigs->aux; in.contig = sigs->contig; in.start = sigs->start; in.end = sigs->end; in.contig2 = sigs->contig2;
+            in.pos2 = sigs->pos2; in.read_id = sigs->read_id; in.seq_off = sigs->seq_off; in.seq = sigs->seq;
+        } else {
+            const size_t n = (size_t)sigs->n;
+            const size_t nseq = n ? (size_t)sigs->seq_off[n] : 0;
+            auto& U = c->user_sig;
+            SVXCHK(upload(c, U[0], sigs->type, n)); in.type = U[0].as<uint8_t>();
+            SVXCHK(upload(c, U[1], sigs->aux, n)); in.aux = U[1].as<uint8_t>();
+            SVXCHK(upload(c, U[2], sigs->contig, n * 4)); in.contig = U[2].as<int32_t>();
+            SVXCHK(upload(c, U[3], sigs->start, n * 4)); in.start = U[3].as<int32_t>();
+            SVXCHK(upload(c, U[4], sigs->end, n * 4)); in.end = U[4].as<int32_t>();
+            SVXCHK(upload(c, U[5], sigs->contig2, n * 4)); in.contig2 = U[5].as<int32_t>();
+            SVXCHK(upload(c, U[6], sigs->pos2, n * 4)); in.pos2 = U[6].as<int32_t>();
+            SVXCHK(upload(c, U[7], sigs->read_id, n * 4)); in.read_id = U[7].as<int32_t>();
+            SVXCHK(upload(c, U[8], sigs->seq_off, (n + 1) * 8)); in.seq_off = U[8].as<int64_t>();
+            SVXCHK(upload(c, U[9], sigs->seq, nseq)); in.seq = U[9].as<uint8_t>();
+        }
+    } else return svx_fail(SVX_E_ARG, "source must be 0, 1 or 2", __FILE__, __LINE__, hipSuccess);
+    return svx_cluster_impl(c, in, n_contig, c->c_rank.as<int32_t>(), p);
+}
+
+extern "C" int svx_cluster_set_shard(svx_ctx* c, int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) return svx_fail(SVX_E_ARG, "bad shard", __FILE__, __LINE__, hipSuccess);
+    c->shard_rank = rank; c->shard_world = world;
+    return SVX_OK;
+}
+
+extern "C" int svx_cluster_count(svx_ctx* c, int64_t* n_clusters, int64_t* n_members) {
+    if (n_clusters) *n_clusters = c->clu.n;
+    if (n_members) *n_members = c->clu.n_members;
+    return SVX_OK;
+}
+
+extern "C" int svx_cluster_fetch(svx_ctx* c, svx_cluster_view* o) {
+    HIPCHK(hipSetDevice(c->device));
+    DevClusters& v = c->clu;
+    const size_t n = (size_t)v.n;
+    hipStream_t st = c->stream;
+#define D2H(dst, buf, bytes) do { if ((bytes) && (dst)) HIPCHK(hipMemcpyAsync((dst), (buf).p, (bytes), hipMemcpyDeviceToHost, st)); } while (0)
+    D2H(o->type, v.type, n); D2H(o->aux, v.aux, n); D2H(o->contig, v.contig, n * 4); D2H(o->start, v.start, n * 4); D2H(o->end, v.end, n * 4);
+    D2H(o->contig2, v.contig2, n * 4); D2H(o->start2, v.start2, n * 4); D2H(o->end2, v.end2, n * 4); D2H(o->score, v.score, n * 8);
+    D2H(o->std_span, v.std_span, n * 8); D2H(o->std_pos, v.std_pos, n * 8); D2H(o->size, v.size, n * 4);
+    if (o->member_off) { if (n) HIPCHK(hipMemcpyAsync(o->member_off, v.member_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, st)); else o->member_off[0] = 0; }
+    D2H(o->members, v.members, (size_t)v.n_members * 4);
+#undef D2H
+    HIPCHK(hipStreamSynchronize(st));
+    o->n = v.n; o->n_members = v.n_members;
+    for (int t = 0; t < SVX_NTYPES; t++) o->type_count[t] = v.type_count[t];
+    return SVX_OK;
+}
+
+extern "C" int svx_cluster_fetch_part_index(svx_ctx* c, int64_t* host_out) {
+    HIPCHK(hipSetDevice(c->device));
+    if (c->clu.n) HIPCHK(hipMemcpyAsync(host_out, c->clu.part_index.p, (size_t)c->clu.n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SVX_OK;
+}
+
+// ---- single-function entry points ------------------------------------------------------------------------------
+extern "C" int svx_cigar_indel(svx_ctx* c, const uint32_t* cigar_host, int64_t n_ops, int32_t min_length, int64_t* out_pos_ref,
+                               int64_t* out_pos_read, int32_t* out_len, uint8_t* out_is_del, int64_t* out_n) {
+    // analyze_cigar_indel on ONE alignment: a one-record batch through the same scan kernel (positions relative to the
+    // alignment start; sequence length "infinite" so that pos_read comes back unclipped)
+    HIPCHK(hipSetDevice(c->device));
+    uint16_t flag = 0; int32_t tid = 0, pos = 0, lseq = 0x7fffffff, rid = 0, rank0 = 0; uint8_t mapq = 255; uint32_t order = 0, sorder = 1, seg_off[2] = {0, 0};
+    uint64_t coff[2] = {0, (uint64_t)n_ops}, soff[2] = {0, 0}, scoff[1] = {0};
+    uint8_t seq = 0; uint32_t zero = 0;
+    svx_batch b; memset(&b, 0, sizeof b);
+    b.on_device = 0; b.n_rec = 1; b.flag = &flag; b.tid = &tid; b.pos = &pos; b.mapq = &mapq; b.lseq = &lseq; b.read_id = &rid; b.order = &order;
+    b.seg_order = &sorder; b.cigar_off = coff; b.cigar = n_ops ? cigar_host : &zero; b.seq_off = soff; b.seq = &seq; b.seg_off = seg_off; b.n_seg = 0;
+    b.seg_tid = &tid; b.seg_pos = &pos; b.seg_rev = &seq; b.seg_mapq = &seq; b.seg_lseq = &lseq; b.seg_cigar_off = scoff; b.seg_cigar = &zero;
+    b.n_contig = 1; b.contig_rank = &rank0;
+    svx_params p; memset(&p, 0, sizeof p);
+    p.min_mapq = 0; p.min_sv_size = min_length; p.max_sv_size = 0x7fffffff; p.partition_max_distance = 1000; p.position_distance_normalizer = 900;
+    p.edit_distance_normalizer = 1; p.cluster_max_distance = 0.5;
+    // sequences are not wanted here: keep the gather from touching `seq` by clearing lseq afterwards is not possible, so run the
+    // scan with lseq = INT_MAX and ignore the gathered bases (qlen is clipped only by that bound; seq_off[1] = 0 keeps reads in range)
+    c->no_seq_gather = true;
+    const int rc = svx_collect(c, &b, &p);
+    c->no_seq_gather = false;
+    SVXCHK(rc);
+    const int64_t n = c->sig.n;
+    std::vector<int32_t> start((size_t)n + 1), qpos((size_t)n + 1), end((size_t)n + 1); std::vector<uint8_t> type((size_t)n + 1);
+    if (n) {
+        HIPCHK(hipMemcpy(start.data(), c->sig.start.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(end.data(), c->sig.end.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(qpos.data(), c->sig.qpos.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(type.data(), c->sig.type.p, (size_t)n, hipMemcpyDeviceToHost));
+    }
+    for (int64_t i = 0; i < n; i++) {
+        out_pos_ref[i] = start[i]; out_len[i] = end[i] - start[i]; out_is_del[i] = type[i] == SVX_DEL;
+        out_pos_read[i] = qpos[i];
+    }
+    *out_n = n;
+    return SVX_OK;
+}
+
+extern "C" int svx_edit_distance(svx_ctx* c, int64_t n_pairs, const uint8_t* codes_host, const int64_t* a_off, const int64_t* b_off, int32_t* out_dist) {
+    HIPCHK(hipSetDevice(c->device));
+    if (n_pairs <= 0) return SVX_OK;
+    int64_t tot = 0;
+    for (int64_t i = 0; i <= n_pairs; i++) { if (a_off[i] > tot) tot = a_off[i]; if (b_off[i] > tot) tot = b_off[i]; }
+    SVXCHK(upload(c, c->tmp0, codes_host, (size_t)tot));
+    SVXCHK(upload(c, c->tmp1, a_off, (size_t)(n_pairs + 1) * 8));
+    SVXCHK(upload(c, c->tmp2, b_off, (size_t)(n_pairs + 1) * 8));
+    SVXCHK(c->tmp3.reserve((size_t)n_pairs * 4));
+    SVXCHK(svx_edit_distance_pairs(c, n_pairs, c->tmp0.as<uint8_t>(), c->tmp1.as<int64_t>(), c->tmp2.as<int64_t>(), c->tmp3.as<int32_t>()));
+    HIPCHK(hipMemcpyAsync(out_dist, c->tmp3.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SVX_OK;
+}
+
+extern "C" int svx_linkage_fcluster(svx_ctx* c, int64_t n_problems, const int32_t* n_host, const int64_t* d_off, const double* d_host, double cutoff,
+                                    const int64_t* label_off, int32_t* labels_out) {
+    HIPCHK(hipSetDevice(c->device));
+    if (n_problems <= 0) return SVX_OK;
+    for (int64_t i = 0; i < n_problems; i++)
+        if (n_host[i] < 1 || n_host[i] > 100) return svx_fail(SVX_E_ARG, "linkage problems must have 1..100 observations", __FILE__, __LINE__, hipSuccess);
+    const int64_t nd = d_off[n_problems], nl = label_off[n_problems];
+    SVXCHK(upload(c, c->tmp0, n_host, (size_t)n_problems * 4));
+    SVXCHK(upload(c, c->tmp1, d_off, (size_t)(n_problems + 1) * 8));
+    SVXCHK(upload(c, c->tmp2, d_host, (size_t)nd * 8));
+    SVXCHK(upload(c, c->tmp3, label_off, (size_t)(n_problems + 1) * 8));
+    SVXCHK(c->tmp4.reserve((size_t)nl * 4 + 16));
+    SVXCHK(svx_linkage_batch(c, n_problems, c->tmp0.as<int32_t>(), c->tmp1.as<int64_t>(), c->tmp2.as<double>(), cutoff, c->tmp3.as<int64_t>(),
+                             c->tmp4.as<int32_t>()));
+    HIPCHK(hipMemcpyAsync(labels_out, c->tmp4.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SVX_OK;
+}

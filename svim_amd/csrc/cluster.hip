@@ -1,0 +1,858 @@
+// cluster.hip - CLUSTER on the GPU: partition -> sample -> pairwise distance -> average linkage -> flat cut ->
+// consolidate.
+//
+// Reference being replaced (eldariont/svim v2.0.0):
+//   cluster_sv_signatures                      src/svim/SVIM_CLUSTER.py:7-26
+//   partition_and_cluster / form_partitions    src/svim/SVIM_clustering.py:375-385 / :17-29
+//   clusters_from_partitions                   :122-180  (seed(1524), sample(...,100), same-read dedupe, 99999 rule)
+//   span_position_distance                     :47-96
+//   scipy linkage('average') + fcluster('distance')   call sites :170-171 (nn_chain / label / cluster_dist)
+//   consolidate_clusters_unilocal/_bilocal, calculate_score   :183-303
+//   random.sample / MT19937                    CPython Lib/random.py, Modules/_randommodule.c
+//
+// Layout: signatures stay in their SoA table; one 64-bit + one 32-bit radix key order them exactly like
+// sorted(key=get_key) (stable, contig names compared through their precomputed string rank).  One wavefront
+// owns one partition (<= 100 sampled signatures): member records, the condensed FP64 distance matrix
+// (<= 4950 doubles = 39.6 KB) and the whole dendrogram live in LDS; nothing is re-read from HBM.
+// FP64 throughout with the reference's operation order (-ffp-contract=off), so labels are bit-exact.
+#include "common.hpp"
+
+int svx_launch_edit_pairs(svx_ctx* c, int64_t n_work, const void* work_dev, const ClusterIn& in, int32_t* ed_dev,
+                          unsigned long long* cells_dev);
+
+struct EditWork { uint32_t a, b; long long slot; };
+
+#define MAXN 100
+
+// ---------------------------------------------------------------------------------------------------------
+// sort keys (get_key): hi = type | rank1 | rank2, lo = biased coordinate
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_make_keys(ClusterIn in, const int32_t* rank, uint64_t* hi, uint64_t* lo, uint32_t* idx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.n) return;
+    const int t = in.type[i];
+    uint64_t r1, r2 = 0; int32_t coord;
+    if (t == SVX_INS) { r1 = (uint64_t)rank[in.contig[i]]; coord = in.start[i]; }
+    else if (t == SVX_DUP_INT) { r1 = (uint64_t)rank[in.contig2[i]]; r2 = (uint64_t)rank[in.contig[i]]; coord = in.pos2[i]; }
+    else if (t == SVX_BND) { r1 = (uint64_t)rank[in.contig[i]]; coord = in.start[i]; }
+    else { r1 = (uint64_t)rank[in.contig[i]]; coord = in.end[i]; }
+    hi[i] = ((uint64_t)t << 56) | (r1 << 28) | r2;
+    lo[i] = (uint64_t)((uint32_t)coord ^ 0x80000000u);
+    idx[i] = (uint32_t)i;
+}
+
+__global__ void k_iota_u32c(uint32_t* v, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+
+__global__ void k_gather_u64(const uint64_t* src, const uint32_t* idx, uint64_t* dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+// new-partition flags in sorted order (form_partitions: gap to the PREVIOUS element only)
+__global__ void k_part_flags(ClusterIn in, const uint64_t* hi_sorted, const uint32_t* sidx, long long max_distance, int64_t* flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > in.n) return;
+    if (i == in.n) { flag[i] = 0; return; }
+    int f = 1;
+    if (i > 0 && hi_sorted[i] == hi_sorted[i - 1]) {          // same type and same contig(s)
+        const uint32_t a = sidx[i - 1], b = sidx[i];
+        const int t = in.type[b];
+        long long d;
+        if (t == SVX_INS) d = (long long)in.start[b] - in.start[a];
+        else if (t == SVX_DUP_INT) d = (long long)in.pos2[b] - in.pos2[a];
+        else d = (long long)in.start[b] - in.end[a];
+        if (d < 0) d = 0;
+        f = d > max_distance;
+    }
+    flag[i] = f;
+}
+
+// part_start[pid] = first sorted position of partition pid
+__global__ void k_part_starts(const int64_t* flag, const int64_t* pid_excl, long long n, int64_t* part_start, long long n_part) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { part_start[n_part] = n; return; }
+    if (flag[i]) part_start[pid_excl[i]] = i;
+}
+
+// per-partition derived sizes: ns = min(size, 100); large flag; INS pair slots
+__global__ void k_part_sizes(const int64_t* part_start, long long n_part, const uint8_t* type, const uint32_t* sidx, int rank_, int world,
+                             int64_t* ns, int64_t* large, int64_t* pairs) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n_part) return;
+    if (p == n_part) { ns[p] = 0; large[p] = 0; pairs[p] = 0; return; }
+    const long long size = part_start[p + 1] - part_start[p];
+    const long long m = size > MAXN ? MAXN : size;
+    ns[p] = m;
+    large[p] = size > MAXN;
+    const bool mine = (p % world) == rank_;
+    pairs[p] = (mine && type[sidx[part_start[p]]] == SVX_INS) ? m * (m - 1) / 2 : 0;
+}
+
+__global__ void k_large_list(const int64_t* large, const int64_t* large_excl, long long n_part, int32_t* list) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_part && large[p]) list[large_excl[p]] = (int32_t)p;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// random.sample(partition, 100) for every partition > 100, one wave per signature type (the RNG is re-seeded per
+// type and carried across that type's partitions: SVIM_clustering.py:129-134)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+
+struct MtStream {
+    uint32_t* s;          // LDS state, 624 words
+    uint32_t buf;         // lane i: tempered word base+i
+    int base, pos, lim;   // uniform
+    __device__ void twist() {
+        const int lane = lane_id();
+        // three dependency phases; inside a phase every lane reads before any lane of the same instruction writes
+        for (int k0 = 0; k0 < 227; k0 += 64) { const int k = k0 + lane; uint32_t v = 0; const bool ok = k < 227;
+            if (ok) { const uint32_t y = (s[k] & 0x80000000u) | (s[k + 1] & 0x7fffffffu); v = s[k + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+            __syncthreads(); if (ok) s[k] = v; __syncthreads(); }
+        for (int k0 = 227; k0 < 454; k0 += 64) { const int k = k0 + lane; uint32_t v = 0; const bool ok = k < 454;
+            if (ok) { const uint32_t y = (s[k] & 0x80000000u) | (s[k + 1] & 0x7fffffffu); v = s[k - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+            __syncthreads(); if (ok) s[k] = v; __syncthreads(); }
+        for (int k0 = 454; k0 < 623; k0 += 64) { const int k = k0 + lane; uint32_t v = 0; const bool ok = k < 623;
+            if (ok) { const uint32_t y = (s[k] & 0x80000000u) | (s[k + 1] & 0x7fffffffu); v = s[k - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+            __syncthreads(); if (ok) s[k] = v; __syncthreads(); }
+        if (lane == 0) { const uint32_t y = (s[623] & 0x80000000u) | (s[0] & 0x7fffffffu); s[623] = s[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+        __syncthreads();
+    }
+    __device__ uint32_t next() {
+        if (pos == lim) {
+            base += 64;
+            if (base >= 624) { twist(); base = 0; }
+            const int k = base + lane_id();
+            buf = (k < 624) ? mt_temper(s[k]) : 0u;
+            lim = (624 - base) < 64 ? (624 - base) : 64;
+            pos = 0;
+        }
+        const uint32_t w = (uint32_t)__shfl((int)buf, pos, 64);
+        pos++;
+        return w;
+    }
+    __device__ uint32_t randbelow(uint32_t n) {      // Random._randbelow_with_getrandbits
+        const int k = 32 - __clz((int)n);
+        uint32_t r = next() >> (32 - k);
+        while (r >= n) r = next() >> (32 - k);
+        return r;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_sample(const int32_t* large_list, long long n_large, const int64_t* part_start, const uint32_t* sidx,
+                                               const uint8_t* type, const int64_t* large_excl, const uint32_t* mt_init, int32_t* sample_idx) {
+    __shared__ uint32_t s[624];
+    const int t = blockIdx.x, lane = lane_id();
+    // range of large partitions whose type is t (types are non-decreasing along the sorted order)
+    long long lo = 0, hi = n_large;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((int)type[sidx[part_start[large_list[mid]]]] < t) lo = mid + 1; else hi = mid; }
+    const long long begin = lo;
+    hi = n_large;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((int)type[sidx[part_start[large_list[mid]]]] <= t) lo = mid + 1; else hi = mid; }
+    const long long end = lo;
+    if (begin == end) return;
+    for (int i = lane; i < 624; i += 64) s[i] = mt_init[i];
+    __syncthreads();
+    MtStream mt; mt.s = s; mt.buf = 0; mt.base = 624; mt.pos = 0; mt.lim = 0;      // first next() twists (index == 624 after seeding)
+    for (long long q = begin; q < end; q++) {
+        const int p = large_list[q];
+        const uint32_t n = (uint32_t)(part_start[p + 1] - part_start[p]);
+        // per-step records kept in registers: lane l holds steps l (a) and 64+l (b)
+        uint32_t pos_a = 0, val_a = 0, res_a = 0, pos_b = 0, val_b = 0, res_b = 0;
+        if (n <= 1045) {
+            // pool method: result[i] = pool[j]; pool[j] = pool[n-i-1]; the pool is virtual (identity + <= 100 overrides)
+            for (int i = 0; i < 100; i++) {
+                const uint32_t j = mt.randbelow(n - (uint32_t)i);
+                const uint32_t tail = n - (uint32_t)i - 1u;
+                uint32_t vj = j, vt = tail;
+                // latest override wins: steps 64.. first, then 0..63
+                unsigned long long mb = __ballot(lane < i - 64 && pos_b == j), ma = __ballot(lane < i && lane < 64 && pos_a == j);
+                if (mb) vj = (uint32_t)__shfl((int)val_b, 63 - __clzll((long long)mb), 64);
+                else if (ma) vj = (uint32_t)__shfl((int)val_a, 63 - __clzll((long long)ma), 64);
+                mb = __ballot(lane < i - 64 && pos_b == tail); ma = __ballot(lane < i && lane < 64 && pos_a == tail);
+                if (mb) vt = (uint32_t)__shfl((int)val_b, 63 - __clzll((long long)mb), 64);
+                else if (ma) vt = (uint32_t)__shfl((int)val_a, 63 - __clzll((long long)ma), 64);
+                if (i < 64) { if (lane == i) { pos_a = j; val_a = vt; res_a = vj; } }
+                else if (lane == i - 64) { pos_b = j; val_b = vt; res_b = vj; }
+            }
+        } else {
+            // set method: draw until unseen
+            for (int i = 0; i < 100; i++) {
+                uint32_t j;
+                for (;;) {
+                    j = mt.randbelow(n);
+                    const unsigned long long seen = __ballot((lane < i && res_a == j) || (lane < i - 64 && res_b == j));
+                    if (!seen) break;
+                }
+                if (i < 64) { if (lane == i) res_a = j; }
+                else if (lane == i - 64) res_b = j;
+            }
+        }
+        int32_t* out = sample_idx + large_excl[p] * 100;
+        out[lane] = (int32_t)res_a;
+        if (lane < 36) out[64 + lane] = (int32_t)res_b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// distances
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long floordiv2(long long x) { return (x >= 0) ? x / 2 : -((-x + 1) / 2); }
+__device__ __forceinline__ long long labs64(long long x) { return x < 0 ? -x : x; }
+
+struct Member { int start, end, pos2, read, aux, gidx, c2, pad; };
+
+// span_position_distance (SVIM_clustering.py:47-96); ed = haplotype edit distance for INS pairs that need it
+__device__ __forceinline__ double span_position_distance(int t, const Member& a, const Member& b, const svx_params& p, int ed) {
+    if (t == SVX_BND) {
+        const long long d1 = labs64((long long)a.start - b.start), d2 = labs64((long long)a.pos2 - b.pos2);
+        return (a.aux == b.aux) ? (double)(d1 + d2) / 3000.0 : 99999.0;
+    }
+    const long long span1 = (long long)a.end - a.start, span2 = (long long)b.end - b.start;
+    const long long mx = span1 > span2 ? span1 : span2;
+    if (t == SVX_INS) {
+        const double pd = (double)labs64((long long)a.start - b.start) / p.position_distance_normalizer;
+        if (pd > 2 * p.cluster_max_distance) return pd + (double)labs64(span1 - span2) / (double)mx;
+        return pd + (double)ed / (double)mx / p.edit_distance_normalizer;
+    }
+    const long long c1 = floordiv2((long long)a.start + a.end), c2 = floordiv2((long long)b.start + b.end);
+    const double pd = (double)labs64(c1 - c2) / p.position_distance_normalizer;
+    const double sd = (double)labs64(span1 - span2) / (double)mx;
+    if (t == SVX_DUP_INT) {
+        const double pdd = (double)labs64((long long)a.pos2 - b.pos2) / p.position_distance_normalizer;
+        return pd + pdd + sd;
+    }
+    return pd + sd;
+}
+
+__device__ __forceinline__ bool ins_needs_edit(const Member& a, const Member& b, const svx_params& p) {
+    const double pd = (double)labs64((long long)a.start - b.start) / p.position_distance_normalizer;
+    return !(pd > 2 * p.cluster_max_distance);
+}
+
+__device__ __forceinline__ int cidx(int n, int i, int j) { if (i > j) { const int t = i; i = j; j = t; } return n * i - i * (i + 1) / 2 + (j - i - 1); }
+
+// sampled member q of partition p -> global signature index
+__device__ __forceinline__ uint32_t member_gidx(long long pstart, long long size, int q, const uint32_t* sidx, const int32_t* sample_idx,
+                                                const int64_t* large_excl, long long p) {
+    if (size > MAXN) return sidx[pstart + sample_idx[large_excl[p] * 100 + q]];
+    return sidx[pstart + q];
+}
+
+// enumerate the INS pairs that need an edit distance (one wave per INS partition of this shard)
+__global__ __launch_bounds__(64) void k_ins_pairs(long long n_part, const int64_t* part_start, const uint32_t* sidx, const int32_t* sample_idx,
+                                                  const int64_t* large_excl, const int64_t* pair_cnt, const int64_t* pair_off, ClusterIn in,
+                                                  svx_params p, EditWork* work, unsigned long long* n_work, long long work_cap) {
+    const long long pt = blockIdx.x;
+    if (pt >= n_part || pair_cnt[pt] == 0) return;
+    __shared__ int m_start[MAXN]; __shared__ uint32_t m_g[MAXN];
+    const long long ps = part_start[pt], size = part_start[pt + 1] - ps;
+    const int ns = size > MAXN ? MAXN : (int)size;
+    for (int q = lane_id(); q < ns; q += 64) { const uint32_t g = member_gidx(ps, size, q, sidx, sample_idx, large_excl, pt); m_g[q] = g; m_start[q] = in.start[g]; }
+    __syncthreads();
+    const int npairs = ns * (ns - 1) / 2;
+    const long long base = pair_off[pt];
+    for (int k = lane_id(); k < npairs; k += 64) {
+        // invert the condensed index
+        int i = 0, rem = k;
+        while (rem >= ns - 1 - i) { rem -= ns - 1 - i; i++; }
+        const int j = i + 1 + rem;
+        const double pd = (double)labs64((long long)m_start[i] - m_start[j]) / p.position_distance_normalizer;
+        if (!(pd > 2 * p.cluster_max_distance)) {
+            const unsigned long long w = atomicAdd(n_work, 1ull);
+            if ((long long)w < work_cap) { EditWork e; e.a = m_g[i]; e.b = m_g[j]; e.slot = base + k; work[w] = e; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// nn-chain average linkage + flat cut, entirely in LDS (scipy _hierarchy.nn_chain / label / cluster_dist)
+// ---------------------------------------------------------------------------------------------------------
+struct LinkLds {
+    double* D;        // condensed distances, n(n-1)/2
+    double* Zh;       // merge heights [n-1] (unsorted), reused as sorted heights
+    double* MD;       // max height below [n-1]
+    int* Zx; int* Zy; // merge members (unsorted)
+    int* size; int* chain;
+    int* ord;         // merge order after the stable sort
+    int* L; int* Rr;  // relabelled children per sorted row
+    int* parent;      // union-find [2n-1]
+    int* stack; int* visited; int* labels;
+};
+
+// returns number of flat clusters; labels[0..n) in 1..ncl.  All 64 lanes must call.
+__device__ int linkage_fcluster_lds(int n, const LinkLds& w, double cutoff) {
+    const int lane = lane_id();
+    if (n == 1) { if (lane == 0) w.labels[0] = 1; __syncthreads(); return 1; }
+    for (int i = lane; i < n; i += 64) w.size[i] = 1;
+    __syncthreads();
+    int chain_len = 0;
+    int y = 0;
+    for (int k = 0; k < n - 1; k++) {
+        int x; double cur;
+        if (chain_len == 0) {
+            // first live cluster
+            const unsigned long long b0 = __ballot(lane < n && w.size[lane] > 0);
+            int first;
+            if (b0) first = __ffsll((long long)b0) - 1;
+            else { const unsigned long long b1 = __ballot(lane + 64 < n && w.size[lane + 64] > 0); first = 64 + __ffsll((long long)b1) - 1; }
+            if (lane == 0) w.chain[0] = first;
+            chain_len = 1;
+            __syncthreads();
+        }
+        for (;;) {
+            x = w.chain[chain_len - 1];
+            if (chain_len > 1) { y = w.chain[chain_len - 2]; cur = w.D[cidx(n, x, y)]; }
+            else cur = __builtin_inf();
+            // nearest live neighbour of x: strict '<' scanning i upward => lowest index wins ties, previous element kept on ties
+            const int i0 = lane, i1 = lane + 64;
+            const bool v0 = i0 < n && i0 != x && w.size[i0] > 0, v1 = i1 < n && i1 != x && w.size[i1] > 0;
+            const double d0 = v0 ? w.D[cidx(n, x, i0)] : __builtin_inf();
+            const double d1 = v1 ? w.D[cidx(n, x, i1)] : __builtin_inf();
+            double m = d0 < d1 ? d0 : d1;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { const double t = __shfl_xor(m, o, 64); m = t < m ? t : m; }
+            if (m < cur) {
+                cur = m;
+                const unsigned long long b0 = __ballot(v0 && d0 == m);
+                if (b0) y = __ffsll((long long)b0) - 1;
+                else { const unsigned long long b1 = __ballot(v1 && d1 == m); y = 64 + __ffsll((long long)b1) - 1; }
+            }
+            if (chain_len > 1 && y == w.chain[chain_len - 2]) break;
+            __syncthreads();
+            if (lane == 0) w.chain[chain_len] = y;
+            chain_len++;
+            __syncthreads();
+        }
+        chain_len -= 2;
+        if (x > y) { const int t = x; x = y; y = t; }
+        const int nx = w.size[x], ny = w.size[y];
+        __syncthreads();
+        if (lane == 0) { w.Zx[k] = x; w.Zy[k] = y; w.Zh[k] = cur; w.size[x] = 0; w.size[y] = nx + ny; }
+        // Lance-Williams update for average linkage, same expression as scipy
+        for (int i = lane; i < n; i += 64) {
+            if (i == y || i == x) continue;
+            if (w.size[i] == 0) continue;
+            const int iy = cidx(n, i, y);
+            w.D[iy] = ((double)nx * w.D[cidx(n, i, x)] + (double)ny * w.D[iy]) / (double)(nx + ny);
+        }
+        __syncthreads();
+    }
+    const int nm = n - 1;
+    // stable sort of merges by height: rank = #{h_j < h_i} + #{h_j == h_i, j < i}
+    for (int i = lane; i < nm; i += 64) {
+        const double h = w.Zh[i]; int r = 0;
+        for (int j = 0; j < nm; j++) { const double hj = w.Zh[j]; r += (hj < h) || (hj == h && j < i); }
+        w.ord[r] = i;
+    }
+    for (int i = lane; i < 2 * n - 1; i += 64) { w.parent[i] = i; w.visited[i] = 0; }
+    __syncthreads();
+    // union-find relabel in sorted order + max-height-below (serial, <= 99 rows)
+    if (lane == 0) {
+        for (int r = 0; r < nm; r++) {
+            const int src = w.ord[r];
+            int a = w.Zx[src], b = w.Zy[src];
+            while (w.parent[a] != a) a = w.parent[a];
+            while (w.parent[b] != b) b = w.parent[b];
+            const int l = a < b ? a : b, rr = a < b ? b : a;
+            w.L[r] = l; w.Rr[r] = rr;
+            w.parent[a] = n + r; w.parent[b] = n + r;
+            double m = w.Zh[src];
+            if (l >= n && w.MD[l - n] > m) m = w.MD[l - n];
+            if (rr >= n && w.MD[rr - n] > m) m = w.MD[rr - n];
+            w.MD[r] = m;
+        }
+        // cluster_monocrit: DFS from the root, left child first
+        int k = 0, ncl = 0, leader = -1;
+        w.stack[0] = 2 * n - 2;
+        while (k >= 0) {
+            const int root = w.stack[k] - n;
+            const int lc = w.L[root], rc = w.Rr[root];
+            if (leader == -1 && w.MD[root] <= cutoff) { leader = root; ncl++; }
+            if (lc >= n && !w.visited[lc]) { w.visited[lc] = 1; w.stack[++k] = lc; continue; }
+            if (rc >= n && !w.visited[rc]) { w.visited[rc] = 1; w.stack[++k] = rc; continue; }
+            if (lc < n) { if (leader == -1) ncl++; w.labels[lc] = ncl; }
+            if (rc < n) { if (leader == -1) ncl++; w.labels[rc] = ncl; }
+            if (leader == root) leader = -1;
+            k--;
+        }
+        w.stack[0] = ncl;
+    }
+    __syncthreads();
+    return w.stack[0];
+}
+
+__device__ __forceinline__ LinkLds carve_link(char*& sm, int nmax) {
+    LinkLds w;
+    const int np = nmax * (nmax - 1) / 2;
+    w.D = reinterpret_cast<double*>(sm); sm += sizeof(double) * (size_t)(np > 0 ? np : 1);
+    w.Zh = reinterpret_cast<double*>(sm); sm += sizeof(double) * nmax;
+    w.MD = reinterpret_cast<double*>(sm); sm += sizeof(double) * nmax;
+    int* ip = reinterpret_cast<int*>(sm);
+    w.Zx = ip; ip += nmax; w.Zy = ip; ip += nmax; w.size = ip; ip += nmax; w.chain = ip; ip += nmax; w.ord = ip; ip += nmax;
+    w.L = ip; ip += nmax; w.Rr = ip; ip += nmax; w.parent = ip; ip += 2 * nmax; w.stack = ip; ip += nmax; w.visited = ip; ip += 2 * nmax;
+    w.labels = ip; ip += nmax;
+    sm = reinterpret_cast<char*>(ip);
+    return w;
+}
+static size_t link_lds_bytes(int nmax) {
+    const int np = nmax * (nmax - 1) / 2;
+    return sizeof(double) * (size_t)(np > 0 ? np : 1) + 2 * sizeof(double) * nmax + sizeof(int) * 13 * (size_t)nmax + 16;
+}
+
+// utility / test entry: batch of condensed matrices -> flat labels
+__global__ __launch_bounds__(64) void k_linkage_batch(long long n_problems, const int32_t* ns, const int64_t* d_off, const double* d, double cutoff,
+                                                      const int64_t* label_off, int32_t* labels) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long q = blockIdx.x;
+    if (q >= n_problems) return;
+    const int n = ns[q];
+    char* sm = smem;
+    LinkLds w = carve_link(sm, MAXN);
+    const int np = n * (n - 1) / 2;
+    for (int i = lane_id(); i < np; i += 64) w.D[i] = d[d_off[q] + i];
+    __syncthreads();
+    linkage_fcluster_lds(n, w, cutoff);
+    for (int i = lane_id(); i < n; i += 64) labels[label_off[q] + i] = w.labels[i];
+}
+
+int svx_linkage_batch(svx_ctx* c, int64_t n_problems, const int32_t* n_dev, const int64_t* d_off_dev, const double* d_dev, double cutoff,
+                      const int64_t* label_off_dev, int32_t* labels_dev) {
+    if (n_problems <= 0) return SVX_OK;
+    const size_t lds = link_lds_bytes(MAXN);
+    k_linkage_batch<<<(unsigned)n_problems, 64, lds, c->stream>>>(n_problems, n_dev, d_off_dev, d_dev, cutoff, label_off_dev, labels_dev);
+    HIPCHK(hipGetLastError());
+    return SVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-partition clustering + consolidation
+// ---------------------------------------------------------------------------------------------------------
+struct Stage {          // staging records, indexed by samp_base[p] + label-1
+    uint8_t* type; uint8_t* aux; int32_t* contig; int32_t* start; int32_t* end; int32_t* contig2; int32_t* start2; int32_t* end2;
+    double* score; double* std_span; double* std_pos; int32_t* size; int32_t* mem_local;   // offset of the member list inside the partition
+    int32_t* members;   // [samp_total] global signature indices, partition-major then cluster-major
+};
+
+__device__ __forceinline__ double stdev_seq(const double* x, int n) {          // FP64 restatement, same op order as the oracle
+    double s = 0;
+    for (int i = 0; i < n; i++) s += x[i];
+    const double c = s / (double)n;
+    double ss = 0, sd = 0;
+    for (int i = 0; i < n; i++) { const double d = x[i] - c; ss += d * d; sd += d; }
+    ss -= sd * sd / (double)n;
+    if (ss < 0) ss = 0;
+    return sqrt(ss / (double)(n - 1));
+}
+
+__device__ __forceinline__ double calc_score(int num, bool has, double std_span, double std_pos, double span) {
+    double sds = 0, pds = 0;
+    if (has) { const double a = std_span / span; sds = 1 - (a < 1 ? a : 1); const double b = std_pos / span; pds = 1 - (b < 1 ? b : 1); }
+    return (double)num + sds * ((double)num / 8) + pds * ((double)num / 8);
+}
+
+// consolidate the members with label `lab` (in index order); executed by ONE lane
+__device__ void consolidate_one(int t, int contig, const Member* mem, const int* labels, int nm, int lab, double* xs, double* xp,
+                                const Stage& st, long long slot, long long mbase, int moff) {
+    long long ss = 0, se = 0, ds = 0; int n = 0; long long maxc = 0; int cnt[5] = {0, 0, 0, 0, 0}; int aux0 = 0, contig2 = -1;
+    for (int i = 0; i < nm; i++) if (labels[i] == lab) {
+        const Member& m = mem[i];
+        if (n == 0) { aux0 = m.aux; contig2 = m.c2; }
+        ss += m.start; se += m.end; ds += m.pos2; if (m.pos2 > maxc) maxc = m.pos2;
+        if (t == SVX_INV && m.aux >= 0 && m.aux < 5) cnt[m.aux]++;
+        xs[n] = (double)((long long)m.end - m.start); xp[n] = (double)((long long)m.end + m.start) / 2.0;
+        st.members[mbase + moff + n] = m.gidx;
+        n++;
+    }
+    const double avg_s = (double)ss / (double)n, avg_e = (double)se / (double)n;
+    const bool has = n > 1;
+    double std_span = __builtin_nan(""), std_pos = __builtin_nan("");
+    if (has) { std_span = stdev_seq(xs, n); std_pos = stdev_seq(xp, n); }
+    const int start = (int)rint(avg_s), end = (int)rint(avg_e);      // round-half-even, like int(round(x))
+    int num = n < 80 ? n : 80;
+    if (t == SVX_INV) { const int left = cnt[0] + cnt[1], right = cnt[2] + cnt[3]; const int valid = (left < right ? left : right) + cnt[4]; num = valid < 80 ? valid : 80; }
+    int c2 = -1, s2 = 0, e2 = 0, aux = 0; double score, o_span = std_span, o_pos = std_pos;
+    if (t <= SVX_INV) score = calc_score(num, has, std_span, std_pos, avg_e - avg_s);
+    else if (t == SVX_DUP_TAN) {
+        score = calc_score(num, has, std_span, std_pos, avg_e - avg_s);
+        c2 = contig; s2 = end; e2 = (int)((long long)end + maxc * ((long long)end - start));
+    } else if (t == SVX_DUP_INT) {
+        const double davg_s = (double)ds / (double)n, davg_e = (double)(ds + (se - ss)) / (double)n;
+        const double span = ((avg_e - avg_s) + (davg_e - davg_s)) / 2.0;
+        c2 = contig2; s2 = (int)rint(davg_s); e2 = (int)rint(davg_e);
+        if (has) {
+            // destination span == source span; destination centre = pos + span/2
+            int q = 0;
+            for (int i = 0; i < nm; i++) if (labels[i] == lab) { const Member& m = mem[i]; xp[q++] = (double)((long long)m.pos2 + ((long long)m.end - m.start) + m.pos2) / 2.0; }
+            const double dsp = stdev_seq(xs, n), dpo = stdev_seq(xp, n);
+            o_span = (std_span + dsp) / 2.0; o_pos = (std_pos + dpo) / 2.0;
+            score = calc_score(num, true, o_span, o_pos, span);
+        } else score = calc_score(num, false, 0, 0, span);
+    } else {    // BND
+        const double davg_s = (double)ds / (double)n, davg_e = (double)(ds + n) / (double)n;
+        c2 = contig2; s2 = (int)rint(davg_s); e2 = (int)rint(davg_e); aux = aux0;
+        if (has) {
+            int q = 0;
+            for (int i = 0; i < nm; i++) if (labels[i] == lab) { const Member& m = mem[i]; xp[q++] = (double)((long long)m.pos2 + 1 + m.pos2) / 2.0; }
+            const double dpo = stdev_seq(xp, n);
+            o_span = std_pos; o_pos = dpo;
+            score = calc_score(num, true, std_pos, dpo, 500.0);
+        } else score = calc_score(num, false, 0, 0, 500.0);
+    }
+    st.type[slot] = (uint8_t)t; st.aux[slot] = (uint8_t)aux; st.contig[slot] = contig; st.start[slot] = start; st.end[slot] = end;
+    st.contig2[slot] = c2; st.start2[slot] = s2; st.end2[slot] = e2; st.score[slot] = score; st.std_span[slot] = o_span; st.std_pos[slot] = o_pos;
+    st.size[slot] = n; st.mem_local[slot] = moff;
+}
+
+__global__ __launch_bounds__(64) void k_cluster(long long n_part, const int64_t* part_start, const uint32_t* sidx, const int32_t* sample_idx,
+                                                const int64_t* large_excl, const int64_t* samp_base, const int64_t* pair_off, const int32_t* ed,
+                                                ClusterIn in, svx_params p, int rank_, int world, Stage st, int32_t* ncl_out, int32_t* nmem_out,
+                                                unsigned long long* n_pairs_stat) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long pt = blockIdx.x;
+    if (pt >= n_part) return;
+    const int lane = lane_id();
+    if ((pt % world) != rank_) { if (lane == 0) { ncl_out[pt] = 0; nmem_out[pt] = 0; } return; }
+    char* sm = smem;
+    LinkLds w = carve_link(sm, MAXN);
+    Member* mem = reinterpret_cast<Member*>(sm); sm += sizeof(Member) * MAXN;      // survivors after dedupe
+    Member* all = reinterpret_cast<Member*>(sm); sm += sizeof(Member) * MAXN;      // the sample
+    int* dup = reinterpret_cast<int*>(sm); sm += sizeof(int) * MAXN;
+    int* orig = reinterpret_cast<int*>(sm); sm += sizeof(int) * MAXN;
+    int* cl_off = reinterpret_cast<int*>(sm); sm += sizeof(int) * (MAXN + 2);
+    double* xs = reinterpret_cast<double*>(sm); sm += sizeof(double) * MAXN * 2;    // per-lane scratch is carved below
+
+    const long long ps = part_start[pt], size = part_start[pt + 1] - ps;
+    const int ns = size > MAXN ? MAXN : (int)size;
+    const long long sbase = samp_base[pt];
+    const uint32_t g0 = member_gidx(ps, size, 0, sidx, sample_idx, large_excl, pt);
+    const int t = in.type[g0];
+    const int contig = in.contig[g0];
+    for (int q = lane; q < ns; q += 64) {
+        const uint32_t g = member_gidx(ps, size, q, sidx, sample_idx, large_excl, pt);
+        Member m; m.start = in.start[g]; m.end = in.end[g]; m.pos2 = in.pos2[g]; m.read = in.read_id[g]; m.aux = in.aux[g]; m.gidx = (int)g; m.c2 = in.contig2[g]; m.pad = 0;
+        all[q] = m; dup[q] = 0;
+    }
+    __syncthreads();
+    const long long pbase = pair_off[pt];
+    // same-read duplicates (SVIM_clustering.py:141-151): j is dropped when ANY earlier i of the same read is within the cut
+    if (t != SVX_INV && ns > 1) {
+        const int npairs = ns * (ns - 1) / 2;
+        for (int k = lane; k < npairs; k += 64) {
+            int i = 0, rem = k;
+            while (rem >= ns - 1 - i) { rem -= ns - 1 - i; i++; }
+            const int j = i + 1 + rem;
+            if (all[i].read == all[j].read) {
+                const int e = (t == SVX_INS && ins_needs_edit(all[i], all[j], p)) ? ed[pbase + k] : 0;
+                if (span_position_distance(t, all[i], all[j], p, e) <= p.cluster_max_distance) dup[j] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    // order-preserving compaction of the survivors
+    int nm;
+    {
+        const int f0 = (lane < ns && !dup[lane]) ? 1 : 0, f1 = (lane + 64 < ns && !dup[lane + 64]) ? 1 : 0;
+        const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+        const int c0 = __popcll(b0);
+        if (f0) { const int d = __popcll(b0 & lanemask_lt()); mem[d] = all[lane]; orig[d] = lane; }
+        if (f1) { const int d = c0 + __popcll(b1 & lanemask_lt()); mem[d] = all[lane + 64]; orig[d] = lane + 64; }
+        nm = c0 + __popcll(b1);
+    }
+    __syncthreads();
+    int ncl;
+    if (nm == 1) { if (lane == 0) w.labels[0] = 1; ncl = 1; __syncthreads(); }
+    else {
+        const int npairs = nm * (nm - 1) / 2;
+        for (int k = lane; k < npairs; k += 64) {
+            int i = 0, rem = k;
+            while (rem >= nm - 1 - i) { rem -= nm - 1 - i; i++; }
+            const int j = i + 1 + rem;
+            double d;
+            if (t != SVX_INV && mem[i].read == mem[j].read) d = 99999.0;
+            else {
+                const int e = (t == SVX_INS && ins_needs_edit(mem[i], mem[j], p)) ? ed[pbase + cidx(ns, orig[i], orig[j])] : 0;
+                d = span_position_distance(t, mem[i], mem[j], p, e);
+            }
+            w.D[k] = d;
+        }
+        if (lane == 0) atomicAdd(n_pairs_stat, (unsigned long long)npairs);
+        __syncthreads();
+        ncl = linkage_fcluster_lds(nm, w, p.cluster_max_distance);
+    }
+    // member-list offsets per label (members of a cluster stay in index order)
+    if (lane == 0) {
+        for (int l = 0; l <= ncl; l++) cl_off[l] = 0;
+        for (int i = 0; i < nm; i++) cl_off[w.labels[i]]++;
+        int acc = 0;
+        for (int l = 1; l <= ncl; l++) { const int c = cl_off[l]; cl_off[l] = acc; acc += c; }
+        ncl_out[pt] = ncl; nmem_out[pt] = nm;
+    }
+    __syncthreads();
+    // one lane per cluster; its FP64 scratch (2 x size doubles) is carved from the D region, which is dead now
+    double* scratch = w.D;
+    for (int l = lane + 1; l <= ncl; l += 64) {
+        const int moff = cl_off[l];
+        double* mxs = (nm <= 1) ? xs : scratch + 2 * moff;
+        const int csz = ((l < ncl) ? cl_off[l + 1] : nm) - moff;
+        consolidate_one(t, contig, mem, w.labels, nm, l, mxs, mxs + csz, st, sbase + (l - 1), sbase, moff);
+    }
+}
+
+// copy staged clusters of partition p to their final dense position
+__global__ __launch_bounds__(64) void k_finalize(long long n_part, const int64_t* samp_base, const int32_t* ncl, const int64_t* clu_off,
+                                                 const int64_t* mem_off, Stage st, uint8_t* o_type, uint8_t* o_aux, int32_t* o_contig, int32_t* o_start,
+                                                 int32_t* o_end, int32_t* o_contig2, int32_t* o_start2, int32_t* o_end2, double* o_score, double* o_span,
+                                                 double* o_pos, int32_t* o_size, int64_t* o_moff, int64_t* o_part, uint64_t* o_key, const int32_t* rank) {
+    const long long pt = blockIdx.x;
+    if (pt >= n_part) return;
+    const int n = ncl[pt];
+    const long long sb = samp_base[pt], cb = clu_off[pt], mb = mem_off[pt];
+    for (int k = lane_id(); k < n; k += 64) {
+        const long long s = sb + k, d = cb + k;
+        const int t = st.type[s];
+        o_type[d] = st.type[s]; o_aux[d] = st.aux[s]; o_contig[d] = st.contig[s]; o_start[d] = st.start[s]; o_end[d] = st.end[s];
+        o_contig2[d] = st.contig2[s]; o_start2[d] = st.start2[s]; o_end2[d] = st.end2[s]; o_score[d] = st.score[s]; o_span[d] = st.std_span[s];
+        o_pos[d] = st.std_pos[s]; o_size[d] = st.size[s]; o_moff[d] = mb + st.mem_local[s]; o_part[d] = pt;
+        // final order: type-major; unilocal types by (contig name rank, start+end) (SVIM_clustering.py:381), bilocal types keep partition order
+        uint64_t key = (uint64_t)t << 60;
+        if (t <= SVX_INV) key |= ((uint64_t)rank[st.contig[s]] << 34) | (uint64_t)((long long)st.start[s] + st.end[s] + (1ll << 32));
+        o_key[d] = key;
+    }
+}
+
+__global__ void k_copy_members(long long n_part, const int64_t* samp_base, const int32_t* nmem, const int64_t* mem_off, const int32_t* src, int32_t* dst) {
+    const long long pt = blockIdx.x;
+    if (pt >= n_part) return;
+    const int n = nmem[pt];
+    for (int k = threadIdx.x; k < n; k += blockDim.x) dst[mem_off[pt] + k] = src[samp_base[pt] + k];
+}
+
+// apply the final stable ordering
+__global__ void k_permute_clusters(long long n, const uint32_t* perm, const uint8_t* i_type, const uint8_t* i_aux, const int32_t* i_contig,
+                                   const int32_t* i_start, const int32_t* i_end, const int32_t* i_contig2, const int32_t* i_start2, const int32_t* i_end2,
+                                   const double* i_score, const double* i_span, const double* i_pos, const int32_t* i_size, const int64_t* i_moff,
+                                   const int64_t* i_part, uint8_t* o_type, uint8_t* o_aux, int32_t* o_contig, int32_t* o_start, int32_t* o_end,
+                                   int32_t* o_contig2, int32_t* o_start2, int32_t* o_end2, double* o_score, double* o_span, double* o_pos, int32_t* o_size,
+                                   int64_t* o_src_moff, int64_t* o_part) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { o_size[n] = 0; return; }
+    const uint32_t s = perm[i];
+    o_type[i] = i_type[s]; o_aux[i] = i_aux[s]; o_contig[i] = i_contig[s]; o_start[i] = i_start[s]; o_end[i] = i_end[s]; o_contig2[i] = i_contig2[s];
+    o_start2[i] = i_start2[s]; o_end2[i] = i_end2[s]; o_score[i] = i_score[s]; o_span[i] = i_span[s]; o_pos[i] = i_pos[s]; o_size[i] = i_size[s];
+    o_src_moff[i] = i_moff[s]; o_part[i] = i_part[s];
+}
+
+__global__ void k_gather_members(long long n, const int32_t* size, const int64_t* src_moff, const int64_t* dst_moff, const int32_t* src, int32_t* dst) {
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int m = size[i];
+    for (int k = lane_id(); k < m; k += 64) dst[dst_moff[i] + k] = src[src_moff[i] + k];
+}
+
+__global__ void k_type_counts(long long n, const uint8_t* type, unsigned long long* counts) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&counts[type[i]], 1ull);
+}
+
+// MT19937 state after random.seed(1524): init_by_array([1524]) (constant of the path; generated once on the host)
+static void mt_seed_state(uint32_t key0, uint32_t* s) {
+    s[0] = 19650218u;
+    for (int i = 1; i < 624; i++) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + (uint32_t)i;
+    int i = 1;
+    for (int k = 624; k; k--) {
+        s[i] = (s[i] ^ ((s[i - 1] ^ (s[i - 1] >> 30)) * 1664525u)) + key0 + 0u;
+        i++;
+        if (i >= 624) { s[0] = s[623]; i = 1; }
+    }
+    for (int k = 623; k; k--) {
+        s[i] = (s[i] ^ ((s[i - 1] ^ (s[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        i++;
+        if (i >= 624) { s[0] = s[623]; i = 1; }
+    }
+    s[0] = 0x80000000u;
+}
+
+#define GRID(n, t) (unsigned)(((n) + (t) - 1) / (t))
+
+int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const int32_t* rank, const svx_params* pp) {
+    hipStream_t st = c->stream;
+    const svx_params p = *pp;
+    const int64_t n = in.n;
+    DevClusters& out = c->clu;
+    out.n = 0; out.n_members = 0;
+    for (int t = 0; t < SVX_NTYPES; t++) out.type_count[t] = 0;
+    svx_stats& S = c->stats;
+    S.n_partitions = S.n_large_partitions = S.n_pairs = S.n_edit_pairs = S.n_edit_cells = S.n_clusters = S.n_hap_bytes = 0;
+    S.t_cluster_ms = S.t_partition_ms = S.t_edit_ms = S.t_linkage_ms = 0;
+    if (n == 0) return SVX_OK;
+    if (n >= (1ll << 31)) return svx_fail(SVX_E_ARG, "more than 2^31 signatures in one call", __FILE__, __LINE__, hipSuccess);
+    const int T = 256;
+    HIPCHK(hipEventRecord(c->ev[8], st));
+    // ---- sort by (type, contig ranks, coordinate), stable w.r.t. list order --------------------------------------
+    SVXCHK(c->k_hi.reserve((size_t)n * 8)); SVXCHK(c->k_lo.reserve((size_t)n * 8)); SVXCHK(c->k_idx.reserve((size_t)n * 4));
+    SVXCHK(c->k_hi2.reserve((size_t)n * 8)); SVXCHK(c->k_lo2.reserve((size_t)n * 8)); SVXCHK(c->k_idx2.reserve((size_t)n * 4));
+    k_make_keys<<<GRID(n, T), T, 0, st>>>(in, rank, c->k_hi.as<uint64_t>(), c->k_lo.as<uint64_t>(), c->k_idx.as<uint32_t>());
+    SVXCHK(svx_sort_pairs_u64(c, c->k_lo.as<uint64_t>(), c->k_lo2.as<uint64_t>(), c->k_idx.as<uint32_t>(), c->k_idx2.as<uint32_t>(), n, 0, 32));
+    k_gather_u64<<<GRID(n, T), T, 0, st>>>(c->k_hi.as<uint64_t>(), c->k_idx2.as<uint32_t>(), c->k_hi2.as<uint64_t>(), n);
+    SVXCHK(svx_sort_pairs_u64(c, c->k_hi2.as<uint64_t>(), c->k_hi.as<uint64_t>(), c->k_idx2.as<uint32_t>(), c->k_idx.as<uint32_t>(), n, 0, 64));
+    const uint64_t* hi_sorted = c->k_hi.as<uint64_t>();
+    const uint32_t* sidx = c->k_idx.as<uint32_t>();
+    // ---- partitions ------------------------------------------------------------------------------------------------
+    SVXCHK(c->part_flag.reserve((size_t)(n + 1) * 8)); SVXCHK(c->part_id.reserve((size_t)(n + 1) * 8));
+    k_part_flags<<<GRID(n + 1, T), T, 0, st>>>(in, hi_sorted, sidx, p.partition_max_distance, c->part_flag.as<int64_t>());
+    SVXCHK(svx_exclusive_scan_i64(c, c->part_flag.as<int64_t>(), c->part_id.as<int64_t>(), n + 1));
+    int64_t n_part = 0;
+    HIPCHK(hipMemcpyAsync(&n_part, c->part_id.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    SVXCHK(c->part_start.reserve((size_t)(n_part + 1) * 8));
+    k_part_starts<<<GRID(n + 1, T), T, 0, st>>>(c->part_flag.as<int64_t>(), c->part_id.as<int64_t>(), n, c->part_start.as<int64_t>(), n_part);
+    // per-partition sizes -> sample base, large-partition slots, INS pair slots (5 arrays of n_part+1 int64 in part_meta)
+    const size_t PM = (size_t)(n_part + 1);
+    SVXCHK(c->part_meta.reserve(PM * 8 * 8));
+    int64_t* ns_a = c->part_meta.as<int64_t>(); int64_t* large_a = ns_a + PM; int64_t* pairs_a = large_a + PM;
+    int64_t* samp_base = pairs_a + PM; int64_t* large_excl = samp_base + PM; int64_t* pair_off = large_excl + PM;
+    int64_t* clu_off = pair_off + PM; int64_t* mem_off = clu_off + PM;
+    k_part_sizes<<<GRID(n_part + 1, T), T, 0, st>>>(c->part_start.as<int64_t>(), n_part, in.type, sidx, c->shard_rank, c->shard_world, ns_a, large_a, pairs_a);
+    SVXCHK(svx_exclusive_scan_i64(c, ns_a, samp_base, n_part + 1));
+    SVXCHK(svx_exclusive_scan_i64(c, large_a, large_excl, n_part + 1));
+    SVXCHK(svx_exclusive_scan_i64(c, pairs_a, pair_off, n_part + 1));
+    int64_t totals[3];
+    HIPCHK(hipMemcpyAsync(&totals[0], samp_base + n_part, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&totals[1], large_excl + n_part, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&totals[2], pair_off + n_part, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int64_t samp_total = totals[0], n_large = totals[1], pair_total = totals[2];
+    // ---- sampling ----------------------------------------------------------------------------------------------------
+    SVXCHK(c->samp_idx.reserve((size_t)(n_large + 1) * 100 * 4));
+    if (n_large > 0) {
+        SVXCHK(c->large_list.reserve((size_t)n_large * 4 + 624 * 4));
+        uint32_t* mt_dev = reinterpret_cast<uint32_t*>(c->large_list.as<int32_t>() + n_large);
+        uint32_t mt_host[624];
+        mt_seed_state(1524u, mt_host);
+        HIPCHK(hipMemcpyAsync(mt_dev, mt_host, sizeof mt_host, hipMemcpyHostToDevice, st));
+        k_large_list<<<GRID(n_part, T), T, 0, st>>>(large_a, large_excl, n_part, c->large_list.as<int32_t>());
+        k_sample<<<SVX_NTYPES, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl, mt_dev,
+                                           c->samp_idx.as<int32_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));       // mt_host is a stack buffer
+    }
+    HIPCHK(hipEventRecord(c->ev[9], st));
+    // ---- INS haplotype edit distances -----------------------------------------------------------------------------
+    SVXCHK(c->ed.reserve((size_t)(pair_total + 1) * 4));
+    SVXCHK(c->counters.reserve(16 * 8));
+    unsigned long long* cnt = c->counters.as<unsigned long long>();
+    HIPCHK(hipMemsetAsync(cnt, 0, 16 * 8, st));
+    unsigned long long h_cnt[16] = {0};
+    if (pair_total > 0) {
+        if (!c->g_off_p) return svx_fail(SVX_E_STATE, "svx_set_genome must precede clustering of insertions", __FILE__, __LINE__, hipSuccess);
+        SVXCHK(c->work.reserve((size_t)pair_total * sizeof(EditWork)));
+        k_ins_pairs<<<(unsigned)n_part, 64, 0, st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl, pairs_a, pair_off, in, p,
+                                                    c->work.as<EditWork>(), cnt + 8, pair_total);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_cnt, cnt, 16 * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const int64_t n_work = (int64_t)h_cnt[8];
+        SVXCHK(svx_launch_edit_pairs(c, n_work, c->work.p, in, c->ed.as<int32_t>(), cnt + 9));
+        S.n_edit_pairs = n_work;
+    }
+    HIPCHK(hipEventRecord(c->ev[10], st));
+    // ---- per-partition clustering into the staging area ---------------------------------------------------------
+    const size_t SN = (size_t)(samp_total + 1);
+    SVXCHK(c->stage.reserve(SN * (2 + 4 * 7 + 8 * 3) + 64));
+    Stage stg;
+    {
+        char* b = c->stage.as<char>();
+        stg.score = reinterpret_cast<double*>(b); b += SN * 8; stg.std_span = reinterpret_cast<double*>(b); b += SN * 8;
+        stg.std_pos = reinterpret_cast<double*>(b); b += SN * 8;
+        stg.contig = reinterpret_cast<int32_t*>(b); b += SN * 4; stg.start = reinterpret_cast<int32_t*>(b); b += SN * 4;
+        stg.end = reinterpret_cast<int32_t*>(b); b += SN * 4; stg.contig2 = reinterpret_cast<int32_t*>(b); b += SN * 4;
+        stg.start2 = reinterpret_cast<int32_t*>(b); b += SN * 4; stg.end2 = reinterpret_cast<int32_t*>(b); b += SN * 4;
+        stg.size = reinterpret_cast<int32_t*>(b); b += SN * 4;
+        stg.type = reinterpret_cast<uint8_t*>(b); b += SN; stg.aux = reinterpret_cast<uint8_t*>(b); b += SN;
+    }
+    SVXCHK(c->stage_members.reserve(SN * 4 * 2));
+    stg.members = c->stage_members.as<int32_t>(); stg.mem_local = stg.members + SN;
+    SVXCHK(c->labels.reserve(PM * 4 * 2));
+    int32_t* ncl_a = c->labels.as<int32_t>(); int32_t* nmem_a = ncl_a + PM;
+    HIPCHK(hipMemsetAsync(ncl_a, 0, PM * 8, st));
+    const size_t lds = link_lds_bytes(MAXN) + sizeof(Member) * MAXN * 2 + sizeof(int) * (3 * MAXN + 2) + sizeof(double) * MAXN * 2 + 64;
+    k_cluster<<<(unsigned)n_part, 64, lds, st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl, samp_base, pair_off,
+                                                c->ed.as<int32_t>(), in, p, c->shard_rank, c->shard_world, stg, ncl_a, nmem_a, cnt + 10);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[11], st));
+    // ---- dense output ------------------------------------------------------------------------------------------------
+    SVXCHK(svx_exclusive_scan_i32_to_i64(c, ncl_a, clu_off, n_part + 1));
+    SVXCHK(svx_exclusive_scan_i32_to_i64(c, nmem_a, mem_off, n_part + 1));
+    int64_t tot2[2];
+    HIPCHK(hipMemcpyAsync(&tot2[0], clu_off + n_part, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&tot2[1], mem_off + n_part, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_cnt, cnt, 16 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int64_t ncl = tot2[0], nmem = tot2[1];
+    const size_t CN = (size_t)(ncl + 1);
+    // unsorted dense copy lives in tmp buffers, final tables in c->clu
+    SVXCHK(c->tmp0.reserve(CN * (2 + 4 * 7 + 8 * 5 + 8) + 64));
+    char* b = c->tmp0.as<char>();
+    double* u_score = reinterpret_cast<double*>(b); b += CN * 8; double* u_span = reinterpret_cast<double*>(b); b += CN * 8;
+    double* u_pos = reinterpret_cast<double*>(b); b += CN * 8; int64_t* u_moff = reinterpret_cast<int64_t*>(b); b += CN * 8;
+    int64_t* u_part = reinterpret_cast<int64_t*>(b); b += CN * 8; uint64_t* u_key = reinterpret_cast<uint64_t*>(b); b += CN * 8;
+    int32_t* u_contig = reinterpret_cast<int32_t*>(b); b += CN * 4; int32_t* u_start = reinterpret_cast<int32_t*>(b); b += CN * 4;
+    int32_t* u_end = reinterpret_cast<int32_t*>(b); b += CN * 4; int32_t* u_contig2 = reinterpret_cast<int32_t*>(b); b += CN * 4;
+    int32_t* u_start2 = reinterpret_cast<int32_t*>(b); b += CN * 4; int32_t* u_end2 = reinterpret_cast<int32_t*>(b); b += CN * 4;
+    int32_t* u_size = reinterpret_cast<int32_t*>(b); b += CN * 4;
+    uint8_t* u_type = reinterpret_cast<uint8_t*>(b); b += CN; uint8_t* u_aux = reinterpret_cast<uint8_t*>(b); b += CN;
+    SVXCHK(c->tmp1.reserve((size_t)(nmem + 1) * 4));
+    int32_t* u_members = c->tmp1.as<int32_t>();
+    k_finalize<<<(unsigned)n_part, 64, 0, st>>>(n_part, samp_base, ncl_a, clu_off, mem_off, stg, u_type, u_aux, u_contig, u_start, u_end, u_contig2, u_start2,
+                                               u_end2, u_score, u_span, u_pos, u_size, u_moff, u_part, u_key, rank);
+    k_copy_members<<<(unsigned)n_part, 64, 0, st>>>(n_part, samp_base, nmem_a, mem_off, stg.members, u_members);
+    HIPCHK(hipGetLastError());
+    // final stable order
+    SVXCHK(out.type.reserve(CN)); SVXCHK(out.aux.reserve(CN)); SVXCHK(out.contig.reserve(CN * 4)); SVXCHK(out.start.reserve(CN * 4));
+    SVXCHK(out.end.reserve(CN * 4)); SVXCHK(out.contig2.reserve(CN * 4)); SVXCHK(out.start2.reserve(CN * 4)); SVXCHK(out.end2.reserve(CN * 4));
+    SVXCHK(out.score.reserve(CN * 8)); SVXCHK(out.std_span.reserve(CN * 8)); SVXCHK(out.std_pos.reserve(CN * 8)); SVXCHK(out.size.reserve(CN * 4));
+    SVXCHK(out.member_off.reserve((CN + 1) * 8)); SVXCHK(out.members.reserve((size_t)(nmem + 1) * 4)); SVXCHK(out.part_index.reserve(CN * 8));
+    if (ncl > 0) {
+        SVXCHK(c->tmp2.reserve(CN * 8 + CN * 4 * 2 + CN * 8));
+        uint64_t* key2 = c->tmp2.as<uint64_t>(); uint32_t* perm0 = reinterpret_cast<uint32_t*>(key2 + CN); uint32_t* perm = perm0 + CN;
+        int64_t* src_moff = reinterpret_cast<int64_t*>(perm + CN);
+        k_iota_u32c<<<GRID(ncl, T), T, 0, st>>>(perm0, ncl);
+        SVXCHK(svx_sort_pairs_u64(c, u_key, key2, perm0, perm, ncl, 0, 64));
+        k_permute_clusters<<<GRID(ncl + 1, T), T, 0, st>>>(ncl, perm, u_type, u_aux, u_contig, u_start, u_end, u_contig2, u_start2, u_end2, u_score, u_span,
+                                                          u_pos, u_size, u_moff, u_part, out.type.as<uint8_t>(), out.aux.as<uint8_t>(),
+                                                          out.contig.as<int32_t>(), out.start.as<int32_t>(), out.end.as<int32_t>(),
+                                                          out.contig2.as<int32_t>(), out.start2.as<int32_t>(), out.end2.as<int32_t>(),
+                                                          out.score.as<double>(), out.std_span.as<double>(), out.std_pos.as<double>(),
+                                                          out.size.as<int32_t>(), src_moff, out.part_index.as<int64_t>());
+        SVXCHK(svx_exclusive_scan_i32_to_i64(c, out.size.as<int32_t>(), out.member_off.as<int64_t>(), ncl + 1));
+        k_gather_members<<<GRID(ncl, 4), 256, 0, st>>>(ncl, out.size.as<int32_t>(), src_moff, out.member_off.as<int64_t>(), u_members, out.members.as<int32_t>());
+        unsigned long long* tc = cnt + 0;
+        HIPCHK(hipMemsetAsync(tc, 0, 6 * 8, st));
+        k_type_counts<<<GRID(ncl, T), T, 0, st>>>(ncl, out.type.as<uint8_t>(), tc);
+        unsigned long long h_tc[6];
+        HIPCHK(hipMemcpyAsync(h_tc, tc, 6 * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int t = 0; t < SVX_NTYPES; t++) out.type_count[t] = (int64_t)h_tc[t];
+    } else {
+        HIPCHK(hipMemsetAsync(out.member_off.p, 0, 16, st));
+    }
+    out.n = ncl; out.n_members = nmem;
+    HIPCHK(hipEventRecord(c->ev[12], st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[8], c->ev[9])); S.t_partition_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[9], c->ev[10])); S.t_edit_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[10], c->ev[11])); S.t_linkage_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[8], c->ev[12])); S.t_cluster_ms = ms;
+    S.n_partitions = n_part; S.n_large_partitions = n_large; S.n_pairs = (int64_t)h_cnt[10]; S.n_edit_cells = (int64_t)h_cnt[9]; S.n_clusters = ncl;
+    return SVX_OK;
+}

@@ -1,0 +1,509 @@
+// collect.hip - COLLECT on the GPU: CIGAR scan (signature emission + alignment geometry), split-read
+// segment analysis, ordering and inserted-sequence gather.
+//
+// Reference being replaced (eldariont/svim v2.0.0):
+//   analyze_alignment_file_coordsorted / _querysorted   src/svim/SVIM_COLLECT.py:96-167
+//   analyze_cigar_indel / analyze_alignment_indel        src/svim/SVIM_intra.py:8-51
+//   analyze_read_segments, is_similar                    src/svim/SVIM_inter.py:11-302
+//   pysam accessors reference_end / query_alignment_start,end / infer_read_length (htslib rules)
+//
+// Kernel 1 (k_cigar_scan) is the HBM-bound kernel of the path: one 64-lane wavefront per alignment streams
+// the packed CIGAR words with 16-byte loads per lane (1 KiB per wave-instruction, fully coalesced), keeps the
+// running (ref, read) cursors as lane-local partial sums and only falls into the cross-lane prefix scan for
+// the rare chunks that actually emit a signature.  No LDS, no MFMA (integer / indexing workload).
+#include "common.hpp"
+
+enum { CNT_SIG = 0, CNT_BND = 1, CNT_USED = 2, CNT_OPS = 3, CNT_SEGOPS = 4, CNT_INS_BASES = 5 };
+
+#define KEY(slot, phase, ord) (((uint64_t)(slot) << 32) | ((uint64_t)(phase) << 30) | (uint64_t)(ord))
+
+struct EmitTarget {
+    SigPtrs p;
+    int64_t cap;
+    unsigned long long* counter;
+};
+
+__device__ __forceinline__ void write_sig(const EmitTarget& t, long long i, uint64_t key, int type, int src, int aux, int contig,
+                                          long long start, long long end, int contig2, long long pos2, int read_id, int rec,
+                                          int qpos, int qlen) {
+    if (i >= t.cap) return;           // counted but not stored: host grows the buffers and reruns
+    t.p.key[i] = key; t.p.type[i] = (uint8_t)type; t.p.src[i] = (uint8_t)src; t.p.aux[i] = (uint8_t)aux;
+    t.p.contig[i] = contig; t.p.start[i] = (int)start; t.p.end[i] = (int)end; t.p.contig2[i] = contig2;
+    t.p.pos2[i] = (int)pos2; t.p.read_id[i] = read_id; t.p.rec[i] = rec; t.p.qpos[i] = qpos; t.p.qlen[i] = qlen;
+}
+
+// Python slice semantics seq[a:b] on a sequence of length len
+__device__ __forceinline__ void py_slice(long long a, long long b, long long len, int& lo, int& n) {
+    if (a < 0) { a += len; if (a < 0) a = 0; } else if (a > len) a = len;
+    if (b < 0) { b += len; if (b < 0) b = 0; } else if (b > len) b = len;
+    if (b < a) b = a;
+    lo = (int)a; n = (int)(b - a);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Kernel 1: CIGAR scan.  Work item w < n_rec: BAM record w; w >= n_rec: segment-table row w - n_rec.
+// geometry record = {ref_len, query_alignment_start, query_alignment_end, infer_read_length, hard_clipped}
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cigar_scan(svx_batch b, svx_params p, EmitTarget sig, EmitTarget bnd,
+                                                    unsigned long long* counters, int* rec_geom, int* seg_geom,
+                                                    unsigned long long total_ops, unsigned long long total_seg_ops) {
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    const bool is_rec = w < b.n_rec;
+    if (!is_rec && w - b.n_rec >= b.n_seg) return;
+    const uint32_t* cig;
+    unsigned long long off0, off1, tot;
+    int lseq, need_indel = 0, need_geom = 1;
+    long long r = w, s = w - b.n_rec;
+    int* geom_out;
+    if (is_rec) {
+        unsigned f = b.flag[r];
+        if ((f & SVX_FLAG_USED_MASK) || (int)b.mapq[r] < p.min_mapq) return;
+        need_indel = 1;
+        need_geom = !(f & 2048u) && (b.seg_off[r + 1] > b.seg_off[r]);
+        cig = b.cigar; off0 = b.cigar_off[r]; off1 = b.cigar_off[r + 1]; tot = total_ops; lseq = b.lseq[r];
+        geom_out = rec_geom + 5 * r;
+        if (lane == 0) { atomicAdd(&counters[CNT_USED], 1ull); atomicAdd(&counters[CNT_OPS], off1 - off0); }
+    } else {
+        cig = b.seg_cigar; off0 = b.seg_cigar_off[s]; off1 = b.seg_cigar_off[s + 1]; tot = total_seg_ops; lseq = b.seg_lseq[s];
+        geom_out = seg_geom + 5 * s;
+        if (lane == 0) atomicAdd(&counters[CNT_SEGOPS], off1 - off0);
+    }
+    const int min_len = p.min_sv_size;
+    int acc_ref = 0, acc_read = 0, acc_n = 0, acc_h = 0, acc_s = 0;
+    const unsigned long long a0 = off0 & ~3ull;
+    for (unsigned long long k0 = a0; k0 < off1; k0 += 256) {
+        const unsigned long long k = k0 + (unsigned long long)lane * 4;
+        uint32_t v[4] = {15u, 15u, 15u, 15u};                  // op 15 / len 0 = no-op
+        if (k < off1) {
+            if (k + 4 <= tot) {
+                const uint4 q = *reinterpret_cast<const uint4*>(cig + k);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+                for (int j = 0; j < 4; j++) if (k + j < tot) v[j] = cig[k + j];
+            }
+        }
+        int pre_ref[4], pre_read[4], len[4], opc[4];
+        int t_ref = 0, t_read = 0;
+        bool any_emit = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool valid = (k + j >= off0) && (k + j < off1);
+            const int op = valid ? (int)(v[j] & 15u) : 15;
+            const int l = valid ? (int)(v[j] >> 4) : 0;
+            opc[j] = op; len[j] = l;
+            pre_ref[j] = t_ref; pre_read[j] = t_read;
+            t_ref += ((0x185 >> op) & 1) ? l : 0;              // M D = X advance the reference cursor (N does not)
+            t_read += ((0x193 >> op) & 1) ? l : 0;             // M I S = X advance the read cursor
+            any_emit |= need_indel && (op == 1 || op == 2) && l >= min_len;
+            if (need_geom) {
+                acc_n += (op == 3) ? l : 0;
+                acc_h += (op == 5) ? l : 0;
+                acc_s += (op == 4) ? l : 0;
+            }
+        }
+        if (__any(any_emit)) {
+            // rare path: exact cursor positions = wave-wide sum of everything before this chunk + exclusive scan inside it
+            const long long base_ref = wave_sum_i64(acc_ref), base_read = wave_sum_i64(acc_read);
+            const long long ex_ref = wave_incl_scan_i64(t_ref) - t_ref, ex_read = wave_incl_scan_i64(t_read) - t_read;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool e = need_indel && (opc[j] == 1 || opc[j] == 2) && len[j] >= min_len;
+                const unsigned long long m = __ballot(e);
+                if (!m) continue;
+                const unsigned long long md = __ballot(e && opc[j] == 2);
+                long long sbase = 0, bbase = 0;
+                if (lane == 0) {
+                    sbase = (long long)atomicAdd(sig.counter, (unsigned long long)__popcll(m));
+                    if (p.all_bnds && md) bbase = (long long)atomicAdd(bnd.counter, (unsigned long long)__popcll(md));
+                }
+                sbase = __shfl(sbase, 0, 64); bbase = __shfl(bbase, 0, 64);
+                if (e) {
+                    const long long pos_ref = base_ref + ex_ref + pre_ref[j], pos_read = base_read + ex_read + pre_read[j];
+                    const long long rs = b.pos[r];
+                    const uint64_t key = KEY(b.order[r], 0, (k + j) - off0);
+                    const long long slot = sbase + __popcll(m & lanemask_lt());
+                    if (opc[j] == 1) {
+                        int qpos, qlen;
+                        py_slice(pos_read, pos_read + len[j], lseq, qpos, qlen);
+                        write_sig(sig, slot, key, SVX_INS, SVX_SRC_CIGAR, 0, b.tid[r], rs + pos_ref, rs + pos_ref + len[j], -1, 0,
+                                  b.read_id[r], (int)r, qpos, qlen);
+                    } else {
+                        write_sig(sig, slot, key, SVX_DEL, SVX_SRC_CIGAR, 0, b.tid[r], rs + pos_ref, rs + pos_ref + len[j], -1, 0,
+                                  b.read_id[r], -1, 0, 0);
+                        if (p.all_bnds)
+                            write_sig(bnd, bbase + __popcll(md & lanemask_lt()), key, SVX_BND, SVX_SRC_CIGAR, 0, b.tid[r], rs + pos_ref,
+                                      rs + pos_ref + 1, b.tid[r], rs + pos_ref + len[j], b.read_id[r], -1, 0, 0);
+                    }
+                }
+            }
+        }
+        acc_ref += t_ref; acc_read += t_read;
+    }
+    if (!need_geom) return;
+    const long long sum_ref = wave_sum_i64(acc_ref), sum_read = wave_sum_i64(acc_read);
+    const long long sum_n = wave_sum_i64(acc_n), sum_h = wave_sum_i64(acc_h), sum_s = wave_sum_i64(acc_s);
+    if (lane == 0) {
+        const long long n = (long long)(off1 - off0);
+        const uint32_t* c = cig + off0;
+        long long qstart = 0;
+        for (long long i = 0; i < n; i++) {                     // leading clips: hard skipped, soft summed
+            const int op = c[i] & 15;
+            if (op == 5) continue;
+            if (op == 4) qstart += c[i] >> 4; else break;
+        }
+        long long qend;
+        if (lseq == 0) {
+            // no stored sequence: M+I+=+X, plus a soft clip met while the running total is still zero
+            qend = sum_read - sum_s;
+            for (long long i = 0; i < n; i++) {
+                const int op = c[i] & 15; const long long l = c[i] >> 4;
+                if (l == 0) continue;
+                if (op == 4) { qend += l; break; }
+                if (op == 0 || op == 1 || op == 7 || op == 8) break;
+            }
+        } else {
+            qend = lseq;
+            for (long long i = n - 1; i >= 1; i--) {            // element 0 is never inspected (pysam getQueryEnd)
+                const int op = c[i] & 15;
+                if (op == 5) continue;
+                if (op == 4) qend -= c[i] >> 4; else break;
+            }
+        }
+        long long ref_len = sum_ref + sum_n;
+        if (ref_len == 0) ref_len = 1;                          // bam_endpos never returns pos itself
+        geom_out[0] = (int)ref_len; geom_out[1] = (int)qstart; geom_out[2] = (int)qend;
+        geom_out[3] = (n > 0) ? (int)(sum_read + sum_h) : 0; geom_out[4] = (int)sum_h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Kernel 2: split-read analysis, one lane per primary record that owns segment-table rows.
+// ------------------------------------------------------------------------------------------------------
+struct ASeg { int qs, qe, rs, re, tid, rev; };
+struct TDup { int chr, s, e, full, fwd, pad; };
+struct Trn { int d1, d2, c1, p1, c2, p2; };
+
+__device__ __forceinline__ bool is_similar_d(int chr1, double s1, double e1, int chr2, double s2, double e2, double thr) {
+    const double span1 = e1 - s1, span2 = e2 - s2;
+    const double c1 = floor((s1 + e1) / 2.0), c2 = floor((s2 + e2) / 2.0);
+    const double pd = fabs(c1 - c2) / 900.0;
+    const double mx = span1 > span2 ? span1 : span2;
+    const double sd = fabs(span1 - span2) / mx;
+    return chr1 == chr2 && pd + sd < thr;
+}
+
+__device__ __forceinline__ void push_bnd(const EmitTarget& t, uint64_t key, const int* rank, int c1, long long p1, int rev1, int c2,
+                                         long long p2, int rev2, int read_id) {
+    const long long i = (long long)atomicAdd(t.counter, 1ull);
+    const bool keep = (rank[c1] < rank[c2]) || (c1 == c2 && p1 < p2);
+    if (keep) write_sig(t, i, key, SVX_BND, SVX_SRC_SUPPL, (rev1 ? 1 : 0) | (rev2 ? 2 : 0), c1, p1, p1 + 1, c2, p2, read_id, -1, 0, 0);
+    else      write_sig(t, i, key, SVX_BND, SVX_SRC_SUPPL, (rev2 ? 0 : 1) | (rev1 ? 0 : 2), c2, p2, p2 + 1, c1, p1, read_id, -1, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_segments(svx_batch b, svx_params p, EmitTarget sig, EmitTarget bnd, const int* rec_geom,
+                                                  const int* seg_geom, ASeg* ws_al, TDup* ws_td, Trn* ws_tr) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= b.n_rec) return;
+    const unsigned f = b.flag[r];
+    if ((f & SVX_FLAG_USED_MASK) || (f & 2048u) || (int)b.mapq[r] < p.min_mapq) return;
+    long long s0 = b.seg_off[r], s1 = b.seg_off[r + 1];
+    if (s1 <= s0) return;                                       // a single alignment has no adjacent pair
+    const int* pg = rec_geom + 5 * r;
+    if ((f & SVX_FLAG_SA) && pg[4] > 0) return;                 // hard-clipped primary: SA rebuild void (SVIM_COLLECT.py:47)
+    ASeg* al = ws_al + s0 + r; TDup* td = ws_td + s0 + r; Trn* tr = ws_tr + s0 + r;
+    int na = 0;
+    for (long long k = -1; k < s1 - s0; k++) {
+        const int* g; int rev, tid; long long pos;
+        if (k < 0) { g = pg; rev = (f & 16u) != 0; tid = b.tid[r]; pos = b.pos[r]; }
+        else {
+            const long long s = s0 + k;
+            if ((int)b.seg_mapq[s] < p.min_mapq) continue;       // good_suppl_alns (SVIM_COLLECT.py:113,154)
+            g = seg_geom + 5 * s; rev = b.seg_rev[s]; tid = b.seg_tid[s]; pos = b.seg_pos[s];
+        }
+        ASeg a;
+        if (rev) {
+            if (g[3] <= 0) continue;                             // infer_read_length() is None
+            a.qs = g[3] - g[2]; a.qe = g[3] - g[1];
+        } else { a.qs = g[1]; a.qe = g[2]; }
+        a.tid = tid; a.rs = (int)pos; a.re = (int)(pos + g[0]); a.rev = rev;
+        // stable insertion by (q_start, q_end)
+        int j = na - 1;
+        while (j >= 0 && (al[j].qs > a.qs || (al[j].qs == a.qs && al[j].qe > a.qe))) { al[j + 1] = al[j]; j--; }
+        al[j + 1] = a; na++;
+    }
+    int ntd = 0, ntr = 0;
+    const int* rank = b.contig_rank;
+    const uint32_t slot = b.seg_order[r];
+    const int rid = b.read_id[r];
+    const long long MIN = p.min_sv_size, MAX = p.max_sv_size, GAP = p.segment_gap_tolerance, OVL = p.segment_overlap_tolerance;
+    const long long prim_len = b.lseq[r], prim_infer = pg[3];
+#define SIG(TYPE_, AUX_, C_, S_, E_) do { const long long i_ = (long long)atomicAdd(sig.counter, 1ull); \
+        write_sig(sig, i_, KEY(slot, 1, idx), TYPE_, SVX_SRC_SUPPL, AUX_, C_, S_, E_, -1, 0, rid, -1, 0, 0); } while (0)
+#define BND_MAIN(C1_, P1_, R1_, C2_, P2_, R2_) do { push_bnd(sig, KEY(slot, 1, idx), rank, C1_, P1_, R1_, C2_, P2_, R2_, rid); \
+        Trn t_; t_.d1 = R1_; t_.d2 = R2_; t_.c1 = C1_; t_.p1 = (int)(P1_); t_.c2 = C2_; t_.p2 = (int)(P2_); tr[ntr++] = t_; } while (0)
+#define BND_SIDE(C1_, P1_, R1_, C2_, P2_, R2_) do { if (p.all_bnds) push_bnd(bnd, KEY(slot, 1, idx), rank, C1_, P1_, R1_, C2_, P2_, R2_, rid); } while (0)
+#define TDUP(C_, S_, E_, FU_, FW_) do { TDup t_; t_.chr = C_; t_.s = (int)(S_); t_.e = (int)(E_); t_.full = FU_; t_.fwd = FW_; t_.pad = 0; td[ntd++] = t_; } while (0)
+    for (int idx = 0; idx + 1 < na; idx++) {
+        const ASeg cu = al[idx], nx = al[idx + 1];
+        const long long dr = (long long)nx.qs - cu.qe;
+        if (cu.tid == nx.tid) {
+            const int chr = cu.tid;
+            if (cu.rev == nx.rev) {
+                const long long dref = cu.rev ? (long long)cu.rs - nx.re : (long long)nx.rs - cu.re;
+                if (dr >= -OVL) {
+                    if (dref >= -OVL) {
+                        const long long dev = dr - dref;
+                        if (dev >= MIN) {                                            // INS candidate (SVIM_inter.py:80-94)
+                            if (dref <= GAP) {
+                                const long long st = cu.rev ? cu.rs : cu.re;
+                                const long long a = cu.rev ? prim_infer - nx.qs : cu.qe;
+                                int qpos = 0, qlen = 0;
+                                if (prim_len > 0) py_slice(a, a + dev, prim_len, qpos, qlen);
+                                const long long i_ = (long long)atomicAdd(sig.counter, 1ull);
+                                write_sig(sig, i_, KEY(slot, 1, idx), SVX_INS, SVX_SRC_SUPPL, 0, chr, st, st + dev, -1, 0, rid, (int)r, qpos, qlen);
+                            }
+                        } else if (-MAX <= dev && dev <= -MIN) {                     // DEL candidate (:96-106)
+                            if (dr <= GAP) {
+                                const long long st = cu.rev ? nx.re : cu.re;
+                                SIG(SVX_DEL, 0, chr, st, st - dev);
+                                BND_SIDE(chr, st - 1, 0, chr, st - dev, 0);
+                            }
+                        } else if (dev < -MAX) {                                     // very large DEL or TRANS (:108-116)
+                            if (dr <= GAP) {
+                                if (!cu.rev) BND_MAIN(chr, (long long)cu.re - 1, 0, chr, (long long)nx.rs, 0);
+                                else         BND_MAIN(chr, (long long)cu.rs, 1, chr, (long long)nx.re - 1, 1);
+                            }
+                        }
+                    } else if (dref <= -MIN) {                                       // overlap on the reference (:118-150)
+                        if (!cu.rev) {
+                            if (nx.re > cu.rs) { TDUP(chr, nx.rs, cu.re, 1, 1); BND_SIDE(chr, (long long)cu.re - 1, 0, chr, (long long)nx.rs, 0); }
+                            else if (dref >= -MAX) { TDUP(chr, nx.rs, cu.re, 0, 1); BND_SIDE(chr, (long long)cu.re - 1, 0, chr, (long long)nx.rs, 0); }
+                            else BND_MAIN(chr, (long long)cu.re - 1, 0, chr, (long long)nx.rs, 0);
+                        } else {
+                            if (nx.rs < cu.re) { TDUP(chr, cu.rs, nx.re, 1, 0); BND_SIDE(chr, (long long)cu.rs, 1, chr, (long long)nx.re - 1, 1); }
+                            else if (dref >= -MAX) { TDUP(chr, cu.rs, nx.re, 0, 0); BND_SIDE(chr, (long long)cu.rs, 1, chr, (long long)nx.re - 1, 1); }
+                            else BND_MAIN(chr, (long long)cu.rs, 1, chr, (long long)nx.re - 1, 1);
+                        }
+                    }
+                }
+            } else if (!cu.rev && nx.rev) {                                          // normal -> reverse (:154-178)
+                if (-OVL <= dr && dr <= GAP) {
+                    if ((long long)nx.rs - cu.re >= -OVL) {
+                        const long long sz = (long long)nx.re - cu.re;
+                        if (MIN <= sz && sz <= MAX) { SIG(SVX_INV, SVX_LEFT_FWD, chr, cu.re, nx.re); BND_SIDE(chr, (long long)cu.re - 1, 0, chr, (long long)nx.re - 1, 1); }
+                        else if (sz > MAX) BND_MAIN(chr, (long long)cu.re - 1, 0, chr, (long long)nx.re - 1, 1);
+                    } else if ((long long)cu.rs - nx.re >= -OVL) {
+                        const long long sz = (long long)cu.re - nx.re;
+                        if (MIN <= sz && sz <= MAX) { SIG(SVX_INV, SVX_LEFT_REV, chr, nx.re, cu.re); BND_SIDE(chr, (long long)cu.re - 1, 0, chr, (long long)nx.re - 1, 1); }
+                        else if (sz > MAX) BND_MAIN(chr, (long long)cu.re - 1, 0, chr, (long long)nx.re - 1, 1);
+                    }
+                }
+            } else {                                                                 // reverse -> normal (:180-204)
+                if (-OVL <= dr && dr <= GAP) {
+                    if ((long long)nx.rs - cu.re >= -OVL) {
+                        const long long sz = (long long)nx.rs - cu.rs;
+                        if (MIN <= sz && sz <= MAX) { SIG(SVX_INV, SVX_RIGHT_FWD, chr, cu.rs, nx.rs); BND_SIDE(chr, (long long)cu.rs, 1, chr, (long long)nx.rs, 0); }
+                        else if (sz > MAX) BND_MAIN(chr, (long long)cu.rs, 1, chr, (long long)nx.rs, 0);
+                    } else if ((long long)cu.rs - nx.re >= -OVL) {
+                        const long long sz = (long long)cu.rs - nx.rs;
+                        if (MIN <= sz && sz <= MAX) { SIG(SVX_INV, SVX_RIGHT_REV, chr, nx.rs, cu.rs); BND_SIDE(chr, (long long)cu.rs, 1, chr, (long long)nx.rs, 0); }
+                        else if (sz > MAX) BND_MAIN(chr, (long long)cu.rs, 1, chr, (long long)nx.rs, 0);
+                    }
+                }
+            }
+        } else if (dr >= -OVL && dr <= GAP) {                                        // different chromosomes (:206-240)
+            if (cu.rev == nx.rev) {
+                if (!cu.rev) BND_MAIN(cu.tid, (long long)cu.re - 1, 0, nx.tid, (long long)nx.rs, 0);
+                else         BND_MAIN(cu.tid, (long long)cu.rs, 1, nx.tid, (long long)nx.re - 1, 1);
+            } else {
+                if (!cu.rev) BND_MAIN(cu.tid, (long long)cu.re - 1, 0, nx.tid, (long long)nx.re - 1, 1);
+                else         BND_MAIN(cu.tid, (long long)cu.rs, 1, nx.tid, (long long)nx.rs, 0);
+            }
+        }
+    }
+#undef SIG
+#undef BND_MAIN
+#undef BND_SIDE
+#undef TDUP
+    // tandem-duplication runs (:242-272); current_direction is deliberately never refreshed (reference quirk)
+    if (ntd > 0) {
+        int cur_chr = td[0].chr; long long sum_s = td[0].s, sum_e = td[0].e, cnt = 1; int any_full = td[0].full;
+        const int cur_dir = td[0].fwd; unsigned ord = 0;
+        for (int k = 1; k <= ntd; k++) {
+            bool merge = false;
+            if (k < ntd) {
+                const double ms = (double)sum_s / (double)cnt, me = (double)sum_e / (double)cnt;
+                merge = is_similar_d(cur_chr, ms, me, td[k].chr, (double)td[k].s, (double)td[k].e, 0.3) && cur_dir == td[k].fwd;
+            }
+            if (merge) { sum_s += td[k].s; sum_e += td[k].e; cnt++; any_full |= td[k].full; }
+            else {
+                const long long i_ = (long long)atomicAdd(sig.counter, 1ull);
+                write_sig(sig, i_, KEY(slot, 2, ord), SVX_DUP_TAN, SVX_SRC_SUPPL, any_full ? 1 : 0, cur_chr, sum_s / cnt, sum_e / cnt, -1, cnt,
+                          rid, -1, 0, 0);
+                ord++;
+                if (k < ntd) { cur_chr = td[k].chr; sum_s = td[k].s; sum_e = td[k].e; cnt = 1; any_full = td[k].full; }
+            }
+        }
+    }
+    // insertions with detected origin (:274-300)
+    for (int ti = 0; ti < ntr; ti++) {
+        const Trn t = tr[ti];
+        for (int bi = 0; bi < ti; bi++) {
+            const Trn q = tr[bi];
+            if (q.d1 == t.d2 && q.d2 == t.d1 &&
+                is_similar_d(q.c1, (double)q.p1, (double)q.p1 + 1.0, t.c2, (double)t.p2, (double)t.p2 + 1.0, 0.1) && q.c2 == t.c1 && q.d2 == q.d1) {
+                const uint64_t key = KEY(slot, 3, (uint64_t)ti * (uint64_t)ntr + (uint64_t)bi);
+                if (q.d1 == 0) {
+                    const long long sz = (long long)t.p1 - q.p2 + 1;
+                    if (MIN <= sz && sz <= MAX) {
+                        const long long i_ = (long long)atomicAdd(sig.counter, 1ull);
+                        write_sig(sig, i_, key, SVX_DUP_INT, SVX_SRC_SUPPL, 0, q.c2, q.p2, (long long)t.p1 + 1, q.c1, ((long long)q.p1 + 1 + t.p2) / 2, rid, -1, 0, 0);
+                    }
+                } else {
+                    const long long sz = (long long)q.p2 - t.p1;
+                    if (MIN <= sz && sz <= MAX) {
+                        const long long i_ = (long long)atomicAdd(sig.counter, 1ull);
+                        write_sig(sig, i_, key, SVX_DUP_INT, SVX_SRC_SUPPL, 0, q.c2, t.p1, (long long)q.p2 + 1, q.c1, ((long long)q.p1 + t.p2 + 1) / 2, rid, -1, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Ordering + gather
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_iota_u32(uint32_t* v, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+
+__global__ void k_permute_sigs(SigPtrs in, SigPtrs out, const uint32_t* idx, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { out.qlen[n] = 0; return; }                    // sentinel so that the scan yields the total
+    const uint32_t s = idx[i];
+    out.type[i] = in.type[s]; out.src[i] = in.src[s]; out.aux[i] = in.aux[s]; out.contig[i] = in.contig[s];
+    out.start[i] = in.start[s]; out.end[i] = in.end[s]; out.contig2[i] = in.contig2[s]; out.pos2[i] = in.pos2[s];
+    out.read_id[i] = in.read_id[s]; out.rec[i] = in.rec[s]; out.qpos[i] = in.qpos[s]; out.qlen[i] = in.qlen[s];
+}
+
+// one wave per signature: unpack qlen 4-bit bases of the owning record into one code per byte
+__global__ __launch_bounds__(256) void k_gather_seq(SigPtrs s, long long n, const int64_t* seq_off, uint8_t* seq_out,
+                                                    const uint64_t* rec_seq_off, const uint8_t* rec_seq) {
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int len = s.qlen[i];
+    if (len <= 0) return;
+    const uint8_t* src = rec_seq + rec_seq_off[s.rec[i]];
+    uint8_t* dst = seq_out + seq_off[i];
+    const int q0 = s.qpos[i];
+    for (int k = lane_id(); k < len; k += 64) {
+        const int q = q0 + k;
+        const uint8_t by = src[q >> 1];
+        dst[k] = (q & 1) ? (by & 15) : (by >> 4);
+    }
+}
+
+static int order_and_store(svx_ctx* c, DevSigs& raw, DevSigs& out, int64_t n) {
+    hipStream_t st = c->stream;
+    SVXCHK(out.reserve(n + 1));
+    out.n = n;
+    if (n == 0) return SVX_OK;
+    SVXCHK(c->tmp0.reserve((size_t)n * 4));
+    SVXCHK(c->tmp1.reserve((size_t)n * 4));
+    const int T = 256;
+    k_iota_u32<<<(unsigned)((n + T - 1) / T), T, 0, st>>>(c->tmp0.as<uint32_t>(), n);
+    SVXCHK(svx_sort_pairs_u64(c, raw.key.as<uint64_t>(), out.key.as<uint64_t>(), c->tmp0.as<uint32_t>(), c->tmp1.as<uint32_t>(), n, 0, 64));
+    k_permute_sigs<<<(unsigned)((n + 1 + T - 1) / T), T, 0, st>>>(sig_ptrs(raw), sig_ptrs(out), c->tmp1.as<uint32_t>(), n);
+    HIPCHK(hipGetLastError());
+    return SVX_OK;
+}
+
+int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
+    hipStream_t st = c->stream;
+    const svx_batch& b = *bd;
+    SVXCHK(c->counters.reserve(16 * 8));
+    SVXCHK(c->rec_geom.reserve((size_t)(b.n_rec + 1) * 5 * 4));
+    SVXCHK(c->seg_geom.reserve((size_t)(b.n_seg + 1) * 5 * 4));
+    const size_t ws_n = (size_t)(b.n_seg + b.n_rec + 1);
+    SVXCHK(c->seg_ws.reserve(ws_n * (sizeof(ASeg) + sizeof(TDup) + sizeof(Trn))));
+    ASeg* ws_al = c->seg_ws.as<ASeg>();
+    TDup* ws_td = reinterpret_cast<TDup*>(ws_al + ws_n);
+    Trn* ws_tr = reinterpret_cast<Trn*>(ws_td + ws_n);
+    // total op counts (needed to bound the 16-byte loads at the very end of the arrays)
+    uint64_t tot_ops = 0, tot_seg_ops = 0;
+    HIPCHK(hipMemcpyAsync(&tot_ops, b.cigar_off + b.n_rec, 8, hipMemcpyDeviceToHost, st));
+    if (b.n_seg > 0) HIPCHK(hipMemcpyAsync(&tot_seg_ops, b.seg_cigar_off + b.n_seg, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int64_t cap_sig = c->raw_sig.cap > 0 ? c->raw_sig.cap : 0, cap_bnd = c->raw_bnd.cap > 0 ? c->raw_bnd.cap : 0;
+    int64_t want_sig = (int64_t)(tot_ops / 256) + 4 * b.n_seg + 4096;
+    if (cap_sig < want_sig) cap_sig = want_sig;
+    if (cap_bnd < 1024) cap_bnd = 1024;
+    if (p->all_bnds && cap_bnd < want_sig) cap_bnd = want_sig;
+    unsigned long long h_cnt[16];
+    for (int attempt = 0; attempt < 3; attempt++) {
+        SVXCHK(c->raw_sig.reserve(cap_sig));
+        SVXCHK(c->raw_bnd.reserve(cap_bnd));
+        HIPCHK(hipMemsetAsync(c->counters.p, 0, 16 * 8, st));
+        EmitTarget ts{sig_ptrs(c->raw_sig), c->raw_sig.cap, c->counters.as<unsigned long long>() + CNT_SIG};
+        EmitTarget tb{sig_ptrs(c->raw_bnd), c->raw_bnd.cap, c->counters.as<unsigned long long>() + CNT_BND};
+        HIPCHK(hipEventRecord(c->ev[0], st));
+        const long long items = b.n_rec + b.n_seg;
+        if (items > 0) {
+            k_cigar_scan<<<(unsigned)((items + 3) / 4), 256, 0, st>>>(b, *p, ts, tb, c->counters.as<unsigned long long>(),
+                                                                     c->rec_geom.as<int>(), c->seg_geom.as<int>(), tot_ops, tot_seg_ops);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(c->ev[1], st));
+        if (b.n_rec > 0 && b.n_seg > 0) {
+            k_segments<<<(unsigned)((b.n_rec + 255) / 256), 256, 0, st>>>(b, *p, ts, tb, c->rec_geom.as<int>(), c->seg_geom.as<int>(), ws_al, ws_td, ws_tr);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(c->ev[2], st));
+        HIPCHK(hipMemcpyAsync(h_cnt, c->counters.p, 16 * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if ((int64_t)h_cnt[CNT_SIG] <= c->raw_sig.cap && (int64_t)h_cnt[CNT_BND] <= c->raw_bnd.cap) break;
+        if (attempt == 2) return svx_fail(SVX_E_CAPACITY, "signature buffers", __FILE__, __LINE__, hipSuccess);
+        cap_sig = (int64_t)h_cnt[CNT_SIG] + 1024; cap_bnd = (int64_t)h_cnt[CNT_BND] + 1024;
+    }
+    const int64_t n_sig = (int64_t)h_cnt[CNT_SIG], n_bnd = (int64_t)h_cnt[CNT_BND];
+    SVXCHK(order_and_store(c, c->raw_sig, c->sig, n_sig));
+    SVXCHK(order_and_store(c, c->raw_bnd, c->bnd, n_bnd));
+    HIPCHK(hipEventRecord(c->ev[3], st));
+    // inserted sequences of the main list
+    SVXCHK(c->sig.seq_off.reserve((size_t)(n_sig + 2) * 8));
+    int64_t n_seq = 0;
+    if (n_sig > 0 && !c->no_seq_gather) {
+        SVXCHK(svx_exclusive_scan_i32_to_i64(c, c->sig.qlen.as<int32_t>(), c->sig.seq_off.as<int64_t>(), n_sig + 1));
+        HIPCHK(hipMemcpyAsync(&n_seq, c->sig.seq_off.as<int64_t>() + n_sig, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        SVXCHK(c->sig.seq.reserve((size_t)n_seq + 16));
+        k_gather_seq<<<(unsigned)((n_sig + 3) / 4), 256, 0, st>>>(sig_ptrs(c->sig), n_sig, c->sig.seq_off.as<int64_t>(), c->sig.seq.as<uint8_t>(),
+                                                                 b.seq_off, b.seq);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemsetAsync(c->sig.seq_off.p, 0, (size_t)(n_sig + 2) * 8, st));
+        SVXCHK(c->sig.seq.reserve(16));
+    }
+    c->sig.n_seq = n_seq;
+    // the side list carries no sequences
+    SVXCHK(c->bnd.seq_off.reserve((size_t)(n_bnd + 2) * 8));
+    HIPCHK(hipMemsetAsync(c->bnd.seq_off.p, 0, (size_t)(n_bnd + 2) * 8, st));
+    SVXCHK(c->bnd.seq.reserve(16));
+    c->bnd.n_seq = 0;
+    HIPCHK(hipEventRecord(c->ev[4], st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms;
+    svx_stats& s = c->stats;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); s.t_cigar_scan_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); s.t_segments_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); s.t_sort_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); s.t_gather_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[4])); s.t_collect_ms = ms;
+    s.n_rec_used = (int64_t)h_cnt[CNT_USED]; s.n_ops = (int64_t)h_cnt[CNT_OPS]; s.n_seg = b.n_seg; s.n_seg_ops = (int64_t)h_cnt[CNT_SEGOPS];
+    s.n_sig = n_sig; s.n_bnd_side = n_bnd; s.n_ins_bases = n_seq;
+    return SVX_OK;
+}

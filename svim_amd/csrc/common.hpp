@@ -1,0 +1,174 @@
+// common.hpp - context, device buffers and wave helpers shared by the libsvx translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/svx.h"
+
+#define SVX_FLAG_USED_MASK (SVX_FLAG_SKIP | 4u | 256u)
+
+extern thread_local std::string g_svx_err;
+int svx_fail(int code, const char* what, const char* file, int line, hipError_t e);
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return svx_fail(SVX_E_HIP, #expr, __FILE__, __LINE__, e_);               \
+    } while (0)
+#define SVXCHK(expr)                                                                                   \
+    do {                                                                                               \
+        int rc_ = (expr);                                                                              \
+        if (rc_ != SVX_OK) return rc_;                                                                 \
+    } while (0)
+
+// Growable device allocation (never shrinks; contents are NOT preserved on growth unless asked).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
+        if (bytes <= cap) return SVX_OK;
+        size_t ncap = bytes + bytes / 8 + 256;
+        void* np = nullptr;
+        HIPCHK(hipMalloc(&np, ncap));
+        if (keep && p && cap) {
+            HIPCHK(hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        if (p) (void)hipFree(p);
+        p = np;
+        cap = ncap;
+        return SVX_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Device-resident signature table (SoA); `cap` entries allocated.
+struct DevSigs {
+    int64_t n = 0, cap = 0;
+    DevBuf key, type, src, aux, contig, start, end, contig2, pos2, read_id, rec, qpos, qlen;
+    DevBuf seq_off, seq;          // filled by the gather step (per-signature inserted bases)
+    int64_t n_seq = 0;
+    int reserve(int64_t c) {
+        if (c <= cap) return SVX_OK;
+        SVXCHK(key.reserve(c * 8)); SVXCHK(type.reserve(c)); SVXCHK(src.reserve(c)); SVXCHK(aux.reserve(c));
+        SVXCHK(contig.reserve(c * 4)); SVXCHK(start.reserve(c * 4)); SVXCHK(end.reserve(c * 4));
+        SVXCHK(contig2.reserve(c * 4)); SVXCHK(pos2.reserve(c * 4)); SVXCHK(read_id.reserve(c * 4));
+        SVXCHK(rec.reserve(c * 4)); SVXCHK(qpos.reserve(c * 4)); SVXCHK(qlen.reserve(c * 4));
+        cap = c;
+        return SVX_OK;
+    }
+    void release() {
+        DevBuf* all[] = {&key, &type, &src, &aux, &contig, &start, &end, &contig2, &pos2, &read_id, &rec, &qpos, &qlen, &seq_off, &seq};
+        for (auto* b : all) b->release();
+        n = cap = 0;
+    }
+};
+
+// Raw pointer view of a signature table used by kernels.
+struct SigPtrs {
+    uint64_t* key; uint8_t* type; uint8_t* src; uint8_t* aux;
+    int32_t *contig, *start, *end, *contig2, *pos2, *read_id, *rec, *qpos, *qlen;
+};
+inline SigPtrs sig_ptrs(const DevSigs& d) {
+    SigPtrs p;
+    p.key = d.key.as<uint64_t>(); p.type = d.type.as<uint8_t>(); p.src = d.src.as<uint8_t>(); p.aux = d.aux.as<uint8_t>();
+    p.contig = d.contig.as<int32_t>(); p.start = d.start.as<int32_t>(); p.end = d.end.as<int32_t>();
+    p.contig2 = d.contig2.as<int32_t>(); p.pos2 = d.pos2.as<int32_t>(); p.read_id = d.read_id.as<int32_t>();
+    p.rec = d.rec.as<int32_t>(); p.qpos = d.qpos.as<int32_t>(); p.qlen = d.qlen.as<int32_t>();
+    return p;
+}
+
+// Read-only view of the clustering input (device pointers).
+struct ClusterIn {
+    int64_t n;
+    const uint8_t* type; const uint8_t* aux;
+    const int32_t *contig, *start, *end, *contig2, *pos2, *read_id;
+    const int64_t* seq_off; const uint8_t* seq;
+};
+
+struct DevClusters {
+    int64_t n = 0, n_members = 0, cap = 0;
+    int64_t type_count[SVX_NTYPES] = {0, 0, 0, 0, 0, 0};
+    DevBuf type, contig, start, end, contig2, start2, end2, aux, score, std_span, std_pos, size, member_off, members, part_index;
+};
+
+struct svx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[16];
+    // device copies of a host-resident batch
+    std::vector<DevBuf> batch_bufs;
+    // COLLECT results
+    DevSigs sig, bnd;               // sorted by key
+    DevSigs raw_sig, raw_bnd;       // unordered emission buffers
+    DevBuf counters;                // device counters (uint64 x 16)
+    DevBuf rec_geom, seg_geom;      // int32 x 5 per record / per segment row
+    DevBuf seg_ws;                  // segment analysis workspace
+    DevBuf tmp0, tmp1, tmp2, tmp3, tmp4, tmp5, sort_tmp;
+    // genome
+    DevBuf g_off, g_codes; int32_t g_n = 0; bool g_borrowed = false; const int64_t* g_off_p = nullptr; const uint8_t* g_codes_p = nullptr;
+    // CLUSTER workspace + results
+    DevBuf user_sig[12]; DevBuf c_rank;
+    DevBuf k_hi, k_lo, k_idx, k_hi2, k_lo2, k_idx2, part_flag, part_id, part_start, part_meta, samp_idx, large_list;
+    DevBuf pair_off, ed, work, stage, stage_members, labels;
+    DevClusters clu;
+    int shard_rank = 0, shard_world = 1;
+    bool no_seq_gather = false;   // svx_cigar_indel hook: positions only
+    svx_stats stats;
+    int64_t last_cluster_source_n = 0;
+};
+
+// ---- primitives (prims.hip) ---------------------------------------------------------------------------
+int svx_sort_pairs_u64(svx_ctx* c, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                       int64_t n, int begin_bit, int end_bit);
+int svx_exclusive_scan_i64(svx_ctx* c, const int64_t* in, int64_t* out, int64_t n);   // out[n] NOT written
+int svx_exclusive_scan_i32_to_i64(svx_ctx* c, const int32_t* in, int64_t* out, int64_t n);
+
+// ---- stage entry points ------------------------------------------------------------------------------------
+int svx_collect_impl(svx_ctx* c, const svx_batch* b_dev, const svx_params* p);
+int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const int32_t* rank_dev, const svx_params* p);
+int svx_edit_distance_pairs(svx_ctx* c, int64_t n_pairs, const uint8_t* codes_dev, const int64_t* a_off_dev, const int64_t* b_off_dev, int32_t* out_dev);
+int svx_linkage_batch(svx_ctx* c, int64_t n_problems, const int32_t* n_dev, const int64_t* d_off_dev, const double* d_dev, double cutoff,
+                      const int64_t* label_off_dev, int32_t* labels_dev);
+
+// ---- device helpers --------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive scan across the 64 lanes
+__device__ __forceinline__ long long wave_incl_scan_i64(long long v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        long long t = __shfl_up(v, o, 64);
+        if (lane_id() >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o, 64);
+        if (lane_id() >= o) v += t;
+    }
+    return v;
+}
+#endif

@@ -1,0 +1,147 @@
+"""Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in CPU tests).
+
+Sharding (DESIGN.md "Multi-GPU"):
+  * COLLECT shards the record batch by contiguous record ranges - records are independent;
+  * the per-rank signature tables are all-gathered (rank-major = file order) so that every rank sees the
+    complete list: sort + partition + the sequential random.sample stream (which is carried across partitions
+    of a type) are recomputed redundantly - they are cheap - and each rank clusters only the partitions with
+    index % world == rank (the quadratic work);
+  * one gather of the fixed-width cluster records to rank 0, merged by partition index.
+"""
+import numpy as np
+
+from . import _abi
+from ._abi import CLU_DTYPES, ClusterTable, SIG_DTYPES, SigTable
+
+
+def merge_cluster_tables(parts, contig_rank):
+    """Merge per-shard ClusterTables (each carrying part_index) into the single-GPU result: clusters ordered by
+    type, then - unilocal types - by (contig name rank, start+end) with ties in partition order, - bilocal types -
+    in partition order (src/svim/SVIM_clustering.py:381,383)."""
+    parts = [p for p in parts if p.n > 0]
+    n = sum(p.n for p in parts)
+    nm = sum(p.n_members for p in parts)
+    out = ClusterTable(n, nm)
+    if n == 0:
+        return out
+    cat = {k: np.concatenate([getattr(p, k)[:p.n] for p in parts]) for k in CLU_DTYPES}
+    part_index = np.concatenate([p.part_index[:p.n] for p in parts])
+    src_off, base = [], 0
+    for p in parts:
+        src_off.append(p.member_off[:p.n] + base)
+        base += p.n_members
+    src_off = np.concatenate(src_off)
+    members = np.concatenate([p.members[:p.n_members] for p in parts])
+    rank = np.asarray(contig_rank)
+    t = cat["type"].astype(np.int64)
+    uni = t <= 2
+    k1 = np.where(uni, rank[cat["contig"]].astype(np.int64), 0)
+    k2 = np.where(uni, cat["start"].astype(np.int64) + cat["end"].astype(np.int64), 0)
+    # within one shard the device order is already final; across shards ties are broken by partition index, and
+    # clusters of one partition always come from the same shard in label order (kept by the stable sort)
+    order = np.lexsort((np.arange(n), part_index, k2, k1, t))
+    for k in CLU_DTYPES:
+        setattr(out, k, cat[k][order])
+    out.part_index = part_index[order]
+    sizes = out.size.astype(np.int64)
+    out.member_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(sizes, out=out.member_off[1:])
+    mem = np.zeros(max(1, nm), dtype=np.int32)
+    so = src_off[order]
+    for i in range(n):
+        mem[out.member_off[i]:out.member_off[i + 1]] = members[so[i]:so[i] + sizes[i]]
+    out.members = mem[:nm]
+    out.n, out.n_members = n, nm
+    out.type_count = [int((out.type == k).sum()) for k in range(6)]
+    return out
+
+
+def concat_sig_tables(tables):
+    """Rank-major concatenation of signature tables (= file order when records were sharded contiguously)."""
+    n = sum(t.n for t in tables)
+    nseq = sum(int(t.seq_off[t.n]) for t in tables)
+    out = SigTable(n, nseq)
+    pos, spos = 0, 0
+    for t in tables:
+        for k in SIG_DTYPES:
+            getattr(out, k)[pos:pos + t.n] = getattr(t, k)[:t.n]
+        m = int(t.seq_off[t.n])
+        out.seq_off[pos:pos + t.n + 1] = t.seq_off[:t.n + 1] + spos
+        out.seq[spos:spos + m] = t.seq[:m]
+        pos += t.n
+        spos += m
+    out.key[:] = np.arange(n, dtype=np.uint64)       # list position is the order from here on
+    return out
+
+
+def _pack_sig(t):
+    cols = [getattr(t, k)[:t.n].view(np.uint8).reshape(-1) for k in SIG_DTYPES]
+    head = np.array([t.n, int(t.seq_off[t.n])], dtype=np.int64).view(np.uint8)
+    return np.concatenate([head] + cols + [t.seq_off[:t.n + 1].view(np.uint8), t.seq[:int(t.seq_off[t.n])]])
+
+
+def _unpack_sig(buf):
+    n, nseq = (int(x) for x in buf[:16].view(np.int64))
+    t = SigTable(n, nseq)
+    p = 16
+    for k, dt in SIG_DTYPES.items():
+        nb = n * np.dtype(dt).itemsize
+        setattr(t, k, buf[p:p + nb].view(dt).copy())
+        p += nb
+    t.seq_off = buf[p:p + (n + 1) * 8].view(np.int64).copy()
+    p += (n + 1) * 8
+    t.seq = buf[p:p + nseq].copy() if nseq else np.zeros(1, dtype=np.uint8)
+    return t
+
+
+def _pack_clu(c):
+    head = np.array([c.n, c.n_members], dtype=np.int64).view(np.uint8)
+    cols = [getattr(c, k)[:c.n].view(np.uint8).reshape(-1) for k in CLU_DTYPES]
+    return np.concatenate([head] + cols + [c.member_off[:c.n + 1].view(np.uint8), c.members[:c.n_members].view(np.uint8),
+                                           np.asarray(c.part_index[:c.n], dtype=np.int64).view(np.uint8)])
+
+
+def _unpack_clu(buf):
+    n, nm = (int(x) for x in buf[:16].view(np.int64))
+    c = ClusterTable(n, nm)
+    p = 16
+    for k, dt in CLU_DTYPES.items():
+        nb = n * np.dtype(dt).itemsize
+        setattr(c, k, buf[p:p + nb].view(dt).copy())
+        p += nb
+    c.member_off = buf[p:p + (n + 1) * 8].view(np.int64).copy()
+    p += (n + 1) * 8
+    c.members = buf[p:p + nm * 4].view(np.int32).copy()
+    p += nm * 4
+    c.part_index = buf[p:p + n * 8].view(np.int64).copy()
+    return c
+
+
+def all_gather_bytes(arr, device=None):
+    """all_gather of variable-length uint8 arrays through torch.distributed (padded to the max length)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    dev = device if device is not None else "cpu"
+    n = torch.tensor([arr.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes + [1])
+    buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    if arr.size:
+        buf[:arr.size] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    outs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return [o[:s].cpu().numpy() for o, s in zip(outs, sizes)]
+
+
+def all_gather_signatures(table, device=None):
+    """Every rank ends up with the rank-major concatenation of all ranks' signature tables."""
+    return concat_sig_tables([_unpack_sig(b) for b in all_gather_bytes(_pack_sig(table), device)])
+
+
+def gather_clusters(ct, contig_rank, device=None):
+    """Final candidate gather: merged ClusterTable (identical on every rank; rank 0 is the consumer)."""
+    return merge_cluster_tables([_unpack_clu(b) for b in all_gather_bytes(_pack_clu(ct), device)], contig_rank)

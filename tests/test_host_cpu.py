@@ -1,0 +1,176 @@
+"""CPU tests: host logic (records, batcher, object layer, multi-GPU merge) and the C ABI surface.
+No compute call is made on the product library here (it has no CPU path)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers as H
+from svim_amd import _abi, _lib, batch, convert, records, synth
+from svim_amd.SVSignature import SignatureDeletion, SignatureInsertion
+
+
+def test_abi_library_exports_every_declared_symbol():
+    _lib.build()
+    assert os.path.exists(_lib._LIB_PATH)
+    L = ctypes.CDLL(_lib._LIB_PATH)
+    header = open(os.path.join(os.path.dirname(_lib._HERE), "include", "svx.h")).read()
+    declared = sorted(set(re.findall(r"\b(svx_[a-z_]+)\s*\(", header)))
+    assert set(declared) == set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.SvxError):
+        _lib.Engine(0)
+    import svim_amd
+    with pytest.raises(_lib.SvxError):
+        svim_amd.analyze_cigar_indel([(0, 10)], 5)
+
+
+def test_signature_accessors_like_reference_tests():
+    # src/tests/test_Signature.py:7-29
+    d = SignatureDeletion("chr1", 100, 300, "cigar", "read1")
+    assert d.get_source() == ("chr1", 100, 300)
+    assert d.get_key() == ("DEL", "chr1", 300)
+    d2 = SignatureDeletion("chr1", 450, 500, "cigar", "read2")
+    d3 = SignatureDeletion("chr1", 150, 200, "cigar", "read3")
+    d4 = SignatureDeletion("chr2", 350, 400, "cigar", "read3")
+    ins = SignatureInsertion("chr1", 150, 200, "cigar", "read2", "ACGT")
+    assert d.downstream_distance_to(d2) == 150
+    assert d.downstream_distance_to(d3) == 0
+    assert d.downstream_distance_to(d4) == float("inf")
+    assert d.downstream_distance_to(ins) == float("inf")
+    assert d.as_string() == "chr1\t100\t300\tDEL;cigar\tread1"
+    assert d.as_string(":") == "chr1:100:300:DEL;cigar:read1"
+
+
+def test_is_similar_like_reference_tests():
+    # src/tests/test_inter.py:7-11
+    from svim_amd.SVIM_inter import is_similar
+    assert not is_similar("chrI", 0, 100, "chrII", 0, 100)
+    assert is_similar("chrI", 0, 100, "chrI", 0, 100)
+    assert is_similar("chrI", 0, 100, "chrI", 10, 90)
+    assert not is_similar("chrI", 100, 105, "chrI", 21, 100)
+
+
+def test_object_strings_match_reference_golden():
+    """as_string / get_key / partition gaps of our classes on every golden signature row."""
+    g = H.load("g5_cluster.json.gz")
+    rows = g["cases"][-1]["signatures"]
+    for r in rows[:3000]:
+        s = H.row_sig(r)
+        assert H.sig_row(s) == r
+        assert isinstance(s.as_string(), str) and s.get_key()[0] == r[0]
+
+
+def test_form_partitions_host_helper_matches_golden():
+    from svim_amd.SVIM_clustering import form_partitions
+    g4 = H.load("g4_partitions.json.gz")
+    g5 = H.load("g5_cluster.json.gz")
+    cases = {c["name"]: c for c in g5["cases"]}
+    p = g4["partitions"][0]
+    case = cases[p["case"]]
+    sigs = [H.row_sig(r) for r in case["signatures"]]
+    idx = {id(s): i for i, s in enumerate(sigs)}
+    sub = [s for s in sigs if s.type == p["type"]]
+    got = [[idx[id(s)] for s in q] for q in form_partitions(sub, case["options"]["partition_max_distance"])]
+    assert got == p["partitions"]
+
+
+def test_satag_reconstruction_like_reference_test():
+    # src/tests/test_satag.py:16-34 replayed on our record model
+    from svim_amd.SVIM_COLLECT import retrieve_other_alignments
+    bam = records.AlignmentFile(os.path.join(H.GOLDEN, "chimeric_read.sam"))
+    alns = list(bam.fetch(until_eof=True))
+    assert len(alns) == 4
+    sup = retrieve_other_alignments(alns[0], bam)
+    assert len(sup) == 3
+    for a, b in zip(sup, alns[1:]):
+        assert a.cigarstring == b.cigarstring and a.reference_id == b.reference_id
+        assert a.reference_start == b.reference_start and a.reference_end == b.reference_end
+        assert a.flag == b.flag and a.mapping_quality == b.mapping_quality
+        assert a.query_name == b.query_name
+        assert a.query_alignment_start == b.query_alignment_start and a.query_alignment_end == b.query_alignment_end
+
+
+def test_bam_roundtrip_and_iterator(tmp_path):
+    # src/tests/test_Collect.py:252-268 shape: 10 primary-only + 10 primary+supplementary reads, grouped by name
+    from svim_amd.SVIM_COLLECT import bam_iterator
+    refs, lens = ["chr1", "chr2"], [300000, 200000]
+    recs = synth.fuzz_split_reads(5, 30, refs, lens)
+    path = str(tmp_path / "t.bam")
+    records.write_bam(path, refs, lens, recs, sort_order="queryname")
+    bam = records.AlignmentFile(path)
+    back = list(bam.fetch(until_eof=True))
+    assert len(back) == len(recs)
+    for a, b in zip(recs, back):
+        assert (a.query_name, a.flag, a.reference_id, a.reference_start, a.mapping_quality) == \
+               (b.query_name, b.flag, b.reference_id, b.reference_start, b.mapping_quality)
+        assert a.cigartuples == b.cigartuples and a.query_sequence == b.query_sequence
+        assert a.get_tags() == b.get_tags()
+    assert bam.header["HD"]["SO"] == "queryname"
+    groups = list(bam_iterator(bam))
+    assert len(groups) == 30 and all(len(set(x.query_name for x in p + s + q)) == 1 for p, s, q in groups)
+
+
+def test_batch_builder_layout():
+    refs, lens = ["chr1", "chr2", "chr10"], [180000, 60000, 60000]
+    recs = synth.coordinate_sort(synth.fuzz_split_reads(9, 40, refs, lens))
+    bam = records.AlignmentFile(text=synth.sam_text(refs, lens, recs))
+    hb = batch.build_batch(bam, H.options({"min_mapq": 20}), mode="coordinate")
+    A = hb.arrays
+    assert hb.n_rec == len(recs)
+    assert A["cigar_off"][-1] == sum(len(a.cigartuples or []) for a in recs)
+    assert list(A["contig_rank"]) == [0, 2, 1]          # 'chr1' < 'chr10' < 'chr2'
+    for i, a in enumerate(recs):
+        lo, hi = int(A["cigar_off"][i]), int(A["cigar_off"][i + 1])
+        assert [(int(c) & 15, int(c) >> 4) for c in A["cigar"][lo:hi]] == (a.cigartuples or [])
+        if a.query_sequence:
+            packed = A["seq"][int(A["seq_off"][i]):int(A["seq_off"][i + 1])]
+            s = "".join(_abi.NIBBLE[b >> 4] + _abi.NIBBLE[b & 15] for b in packed)[:len(a.query_sequence)]
+            assert s == a.query_sequence
+    # segment rows only for usable primaries carrying an SA tag
+    for i, a in enumerate(recs):
+        nseg = int(A["seg_off"][i + 1]) - int(A["seg_off"][i])
+        usable = not (a.flag & (4 | 256 | 2048)) and a.mapping_quality >= 20 and a.has_tag("SA")
+        assert (nseg > 0) == usable
+
+
+def test_table_object_roundtrip():
+    g = H.load("g5_cluster.json.gz")
+    rows = g["cases"][0]["signatures"]
+    sigs = [H.row_sig(r) for r in rows]
+    tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(H.REFS))
+    back = convert.objects_from_sigtable(tab, contigs.names, reads.names)
+    assert [H.sig_row(s) for s in back] == rows
+    with pytest.raises(TypeError):
+        convert.sigtable_from_objects([SignatureDeletion("chr1", 10.5, 20.5, "cigar", "r")])
+    with pytest.raises(ValueError):
+        convert.sigtable_from_objects([SignatureInsertion("chr1", 10, 20, "cigar", "r", "ACGU")])
+
+
+def test_shard_merge_equals_unsharded(oracle):
+    """Multi-GPU decomposition checked with the oracle as the stand-in compute engine."""
+    from svim_amd.distributed import merge_cluster_tables
+    g = H.load("g5_cluster.json.gz")
+    case = g["cases"][-1]
+    o = H.options(case["options"])
+    sigs = [H.row_sig(r) for r in case["signatures"]]
+    tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(H.REFS))
+    off, codes = convert.genome_arrays(o.genome, contigs.names)
+    oracle.set_genome(off, codes)
+    rank = batch.contig_ranks(contigs.names)
+    p = _abi.Params.from_options(o)
+    full = oracle.cluster(p, rank, table=tab, shard=(0, 1))
+    for world in (2, 3):
+        parts = [oracle.cluster(p, rank, table=tab, shard=(r, world)) for r in range(world)]
+        merged = merge_cluster_tables(parts, rank)
+        assert merged.first_difference(full) is None
+    oracle.cluster(p, rank, table=tab, shard=(0, 1))
