@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_cigar_scan(svx_batch b, svx_params p, E
                                   b.read_id[r], (int)r, qpos, qlen);
                     } else {
                         write_sig(sig, slot, key, SVX_DEL, SVX_SRC_CIGAR, 0, b.tid[r], rs + pos_ref, rs + pos_ref + len[j], -1, 0,
-                                  b.read_id[r], -1, 0, 0);
+                                  b.read_id[r], -1, (int)pos_read, 0);        // qpos kept for the analyze_cigar_indel entry point
                         if (p.all_bnds)
                             write_sig(bnd, bbase + __popcll(md & lanemask_lt()), key, SVX_BND, SVX_SRC_CIGAR, 0, b.tid[r], rs + pos_ref,
                                       rs + pos_ref + 1, b.tid[r], rs + pos_ref + len[j], b.read_id[r], -1, 0, 0);
