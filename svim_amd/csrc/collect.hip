@@ -63,11 +63,9 @@ __global__ __launch_bounds__(256) void k_cigar_scan(svx_batch b, svx_params p, E
         need_geom = !(f & 2048u) && (b.seg_off[r + 1] > b.seg_off[r]);
         cig = b.cigar; off0 = b.cigar_off[r]; off1 = b.cigar_off[r + 1]; tot = total_ops; lseq = b.lseq[r];
         geom_out = rec_geom + 5 * r;
-        if (lane == 0) { atomicAdd(&counters[CNT_USED], 1ull); atomicAdd(&counters[CNT_OPS], off1 - off0); }
     } else {
         cig = b.seg_cigar; off0 = b.seg_cigar_off[s]; off1 = b.seg_cigar_off[s + 1]; tot = total_seg_ops; lseq = b.seg_lseq[s];
         geom_out = seg_geom + 5 * s;
-        if (lane == 0) atomicAdd(&counters[CNT_SEGOPS], off1 - off0);
     }
     const int min_len = p.min_sv_size;
     int acc_ref = 0, acc_read = 0, acc_n = 0, acc_h = 0, acc_s = 0;
@@ -175,6 +173,22 @@ __global__ __launch_bounds__(256) void k_cigar_scan(svx_batch b, svx_params p, E
         geom_out[0] = (int)ref_len; geom_out[1] = (int)qstart; geom_out[2] = (int)qend;
         geom_out[3] = (n > 0) ? (int)(sum_read + sum_h) : 0; geom_out[4] = (int)sum_h;
     }
+}
+
+// bookkeeping for the metric (reads passing the filter, their CIGAR ops): one thread per record, one atomic pair per
+// block - kept out of the scan kernel, where a per-wave atomic on one address serialises the whole launch
+__global__ __launch_bounds__(256) void k_count_used(svx_batch b, svx_params p, unsigned long long* counters) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long used = 0, ops = 0;
+    if (r < b.n_rec) {
+        const unsigned f = b.flag[r];
+        if (!(f & SVX_FLAG_USED_MASK) && (int)b.mapq[r] >= p.min_mapq) { used = 1; ops = b.cigar_off[r + 1] - b.cigar_off[r]; }
+    }
+    used = (unsigned long long)wave_sum_i64((long long)used); ops = (unsigned long long)wave_sum_i64((long long)ops);
+    __shared__ unsigned long long su[4], so[4];
+    if (lane_id() == 0) { su[threadIdx.x >> 6] = used; so[threadIdx.x >> 6] = ops; }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicAdd(&counters[CNT_USED], su[0] + su[1] + su[2] + su[3]); atomicAdd(&counters[CNT_OPS], so[0] + so[1] + so[2] + so[3]); }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -463,6 +477,7 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(c->ev[2], st));
+        if (b.n_rec > 0) k_count_used<<<(unsigned)((b.n_rec + 255) / 256), 256, 0, st>>>(b, *p, c->counters.as<unsigned long long>());
         HIPCHK(hipMemcpyAsync(h_cnt, c->counters.p, 16 * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if ((int64_t)h_cnt[CNT_SIG] <= c->raw_sig.cap && (int64_t)h_cnt[CNT_BND] <= c->raw_bnd.cap) break;
@@ -503,7 +518,7 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
     HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); s.t_sort_ms = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); s.t_gather_ms = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[4])); s.t_collect_ms = ms;
-    s.n_rec_used = (int64_t)h_cnt[CNT_USED]; s.n_ops = (int64_t)h_cnt[CNT_OPS]; s.n_seg = b.n_seg; s.n_seg_ops = (int64_t)h_cnt[CNT_SEGOPS];
+    s.n_rec_used = (int64_t)h_cnt[CNT_USED]; s.n_ops = (int64_t)h_cnt[CNT_OPS]; s.n_seg = b.n_seg; s.n_seg_ops = (int64_t)tot_seg_ops;
     s.n_sig = n_sig; s.n_bnd_side = n_bnd; s.n_ins_bases = n_seq;
     return SVX_OK;
 }
