@@ -99,8 +99,13 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
     eng = _lib.Engine(local_rank)
-    g_off = torch.tensor([0, genome.numel()], dtype=torch.int64, device=dev)
-    eng.set_genome(g_off, genome, on_device=True)
+    if world > 1:
+        from svim_amd import distributed as D
+        g_off, g_all = D.all_gather_genomes(genome, dev)
+        eng.set_genome(g_off, g_all, on_device=True)
+    else:
+        g_off = torch.tensor([0, genome.numel()], dtype=torch.int64, device=dev)
+        eng.set_genome(g_off, genome, on_device=True)
     rank_arr = np.zeros(1, dtype=np.int32)
     bstruct = batch.struct()
 

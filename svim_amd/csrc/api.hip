@@ -1,5 +1,6 @@
 // api.hip - the extern "C" boundary of libsvx.so (include/svx.h).
 #include "common.hpp"
+#include <cstdlib>
 
 thread_local std::string g_svx_err;
 
@@ -21,9 +22,11 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
     HIPCHK(hipSetDevice(device_ordinal));
     svx_ctx* c = new svx_ctx();
     c->device = device_ordinal;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount; }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& ev : c->ev) HIPCHK(hipEventCreate(&ev));
     memset(&c->stats, 0, sizeof c->stats);
+    { const char* e = getenv("SVX_EDIT_FORCE_FULL"); c->edit_force_full = e && e[0] == '1'; }
     *out = c;
     return SVX_OK;
 }
@@ -34,9 +37,9 @@ extern "C" void svx_ctx_destroy(svx_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->batch_bufs) b.release();
     c->sig.release(); c->bnd.release(); c->raw_sig.release(); c->raw_bnd.release();
-    DevBuf* bufs[] = {&c->counters, &c->rec_geom, &c->seg_geom, &c->seg_ws, &c->tmp0, &c->tmp1, &c->tmp2, &c->tmp3, &c->tmp4, &c->tmp5, &c->sort_tmp,
+    DevBuf* bufs[] = {&c->counters, &c->raw_indel, &c->shard_cnt, &c->rec_geom, &c->seg_geom, &c->seg_ws, &c->tmp0, &c->tmp1, &c->tmp2, &c->tmp3, &c->tmp4, &c->tmp5, &c->sort_tmp,
                       &c->g_off, &c->g_codes, &c->c_rank, &c->k_hi, &c->k_lo, &c->k_idx, &c->k_hi2, &c->k_lo2, &c->k_idx2, &c->part_flag, &c->part_id,
-                      &c->part_start, &c->part_meta, &c->samp_idx, &c->large_list, &c->pair_off, &c->ed, &c->work, &c->stage, &c->stage_members, &c->labels,
+                      &c->part_start, &c->part_meta, &c->samp_idx, &c->large_list, &c->samp_stream, &c->cell_shards, &c->pair_off, &c->ed, &c->work, &c->stage, &c->stage_members, &c->labels, &c->e_words, &c->e_off, &c->e_scratch, &c->e_desc, &c->e_key, &c->e_val, &c->e_slot, &c->e_fail, &c->e_big_list, &c->e_big_state, &c->e_big_off,
                       &c->clu.type, &c->clu.contig, &c->clu.start, &c->clu.end, &c->clu.contig2, &c->clu.start2, &c->clu.end2, &c->clu.aux, &c->clu.score,
                       &c->clu.std_span, &c->clu.std_pos, &c->clu.size, &c->clu.member_off, &c->clu.members, &c->clu.part_index};
     for (auto* b : bufs) b->release();
@@ -105,13 +108,15 @@ extern "C" int svx_collect_fetch(svx_ctx* c, int which, svx_sig_view* o) {
     DevSigs& s = which ? c->bnd : c->sig;
     const size_t n = (size_t)s.n;
     hipStream_t st = c->stream;
-#define D2H(dst, buf, bytes) do { if ((bytes) && (dst)) HIPCHK(hipMemcpyAsync((dst), (buf).p, (bytes), hipMemcpyDeviceToHost, st)); } while (0)
-    D2H(o->key, s.key, n * 8); D2H(o->type, s.type, n); D2H(o->src, s.src, n); D2H(o->aux, s.aux, n);
-    D2H(o->contig, s.contig, n * 4); D2H(o->start, s.start, n * 4); D2H(o->end, s.end, n * 4); D2H(o->contig2, s.contig2, n * 4);
-    D2H(o->pos2, s.pos2, n * 4); D2H(o->read_id, s.read_id, n * 4);
-    if (o->seq_off) HIPCHK(hipMemcpyAsync(o->seq_off, s.seq_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
-    D2H(o->seq, s.seq, (size_t)s.n_seq);
-#undef D2H
+    // o->on_device: the caller's arrays live in HBM (e.g. torch tensors feeding an RCCL all-gather) -> device-to-device copies
+    const hipMemcpyKind kind = o->on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+#define CPY(dst, buf, bytes) do { if ((bytes) && (dst)) HIPCHK(hipMemcpyAsync((dst), (buf).p, (bytes), kind, st)); } while (0)
+    CPY(o->key, s.key, n * 8); CPY(o->type, s.type, n); CPY(o->src, s.src, n); CPY(o->aux, s.aux, n);
+    CPY(o->contig, s.contig, n * 4); CPY(o->start, s.start, n * 4); CPY(o->end, s.end, n * 4); CPY(o->contig2, s.contig2, n * 4);
+    CPY(o->pos2, s.pos2, n * 4); CPY(o->read_id, s.read_id, n * 4);
+    if (o->seq_off) HIPCHK(hipMemcpyAsync(o->seq_off, s.seq_off.p, (n + 1) * 8, kind, st));
+    CPY(o->seq, s.seq, (size_t)s.n_seq);
+#undef CPY
     HIPCHK(hipStreamSynchronize(st));
     o->n = s.n;
     return SVX_OK;

@@ -106,10 +106,16 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
+// MT19937 word source for one signature type.  The tempered words are also appended to a global stream so that the
+// per-partition sampling (phase B) can run in parallel once phase A has fixed where each partition starts reading.
 struct MtStream {
-    uint32_t* s;          // LDS state, 624 words
-    uint32_t buf;         // lane i: tempered word base+i
-    int base, pos, lim;   // uniform
+    uint32_t* s;            // LDS state, 624 words
+    uint32_t* stream;       // global copy of every tempered word, in generation order
+    long long cap;          // capacity of `stream` (words)
+    long long gen;          // words generated so far (multiple of 624)
+    uint32_t buf;           // lane i: tempered word base+i of the current 624-block
+    int base, pos, lim;     // uniform cursor inside the block
+    int overflow;
     __device__ void twist() {
         const int lane = lane_id();
         // three dependency phases; inside a phase every lane reads before any lane of the same instruction writes
@@ -124,7 +130,11 @@ struct MtStream {
             __syncthreads(); if (ok) s[k] = v; __syncthreads(); }
         if (lane == 0) { const uint32_t y = (s[623] & 0x80000000u) | (s[0] & 0x7fffffffu); s[623] = s[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
         __syncthreads();
+        if (gen + 624 <= cap) { for (int k = lane; k < 624; k += 64) stream[gen + k] = mt_temper(s[k]); }
+        else overflow = 1;
+        gen += 624;
     }
+    __device__ long long position() const { return gen - 624 + base + pos; }      // global index of the next word
     __device__ uint32_t next() {
         if (pos == lim) {
             base += 64;
@@ -134,7 +144,7 @@ struct MtStream {
             lim = (624 - base) < 64 ? (624 - base) : 64;
             pos = 0;
         }
-        const uint32_t w = (uint32_t)__shfl((int)buf, pos, 64);
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)buf, pos);
         pos++;
         return w;
     }
@@ -146,8 +156,12 @@ struct MtStream {
     }
 };
 
-__global__ __launch_bounds__(64) void k_sample(const int32_t* large_list, long long n_large, const int64_t* part_start, const uint32_t* sidx,
-                                               const uint8_t* type, const int64_t* large_excl, const uint32_t* mt_init, int32_t* sample_idx) {
+// Phase A: one wave per type walks that type's large partitions IN ORDER and only decides how many words each one
+// consumes (pool method, n <= 1045: acceptance does not depend on the sampled values).  Partitions above 1045 use the
+// set method, whose rejections depend on the values drawn: they are sampled right here.
+__global__ __launch_bounds__(64) void k_sample_scan(const int32_t* large_list, long long n_large, const int64_t* part_start, const uint32_t* sidx,
+                                                    const uint8_t* type, const int64_t* large_excl, const uint32_t* mt_init, uint32_t* stream,
+                                                    long long cap_per_type, long long* samp_start, int32_t* sample_idx, int* err) {
     __shared__ uint32_t s[624];
     const int t = blockIdx.x, lane = lane_id();
     // range of large partitions whose type is t (types are non-decreasing along the sorted order)
@@ -160,30 +174,19 @@ __global__ __launch_bounds__(64) void k_sample(const int32_t* large_list, long l
     if (begin == end) return;
     for (int i = lane; i < 624; i += 64) s[i] = mt_init[i];
     __syncthreads();
-    MtStream mt; mt.s = s; mt.buf = 0; mt.base = 624; mt.pos = 0; mt.lim = 0;      // first next() twists (index == 624 after seeding)
+    MtStream mt; mt.s = s; mt.stream = stream + (long long)t * cap_per_type; mt.cap = cap_per_type; mt.gen = 0; mt.buf = 0;
+    mt.base = 624; mt.pos = 0; mt.lim = 0; mt.overflow = 0;                       // first next() twists (index == 624 after seeding)
     for (long long q = begin; q < end; q++) {
         const int p = large_list[q];
         const uint32_t n = (uint32_t)(part_start[p + 1] - part_start[p]);
-        // per-step records kept in registers: lane l holds steps l (a) and 64+l (b)
-        uint32_t pos_a = 0, val_a = 0, res_a = 0, pos_b = 0, val_b = 0, res_b = 0;
         if (n <= 1045) {
-            // pool method: result[i] = pool[j]; pool[j] = pool[n-i-1]; the pool is virtual (identity + <= 100 overrides)
-            for (int i = 0; i < 100; i++) {
-                const uint32_t j = mt.randbelow(n - (uint32_t)i);
-                const uint32_t tail = n - (uint32_t)i - 1u;
-                uint32_t vj = j, vt = tail;
-                // latest override wins: steps 64.. first, then 0..63
-                unsigned long long mb = __ballot(lane < i - 64 && pos_b == j), ma = __ballot(lane < i && lane < 64 && pos_a == j);
-                if (mb) vj = (uint32_t)__shfl((int)val_b, 63 - __clzll((long long)mb), 64);
-                else if (ma) vj = (uint32_t)__shfl((int)val_a, 63 - __clzll((long long)ma), 64);
-                mb = __ballot(lane < i - 64 && pos_b == tail); ma = __ballot(lane < i && lane < 64 && pos_a == tail);
-                if (mb) vt = (uint32_t)__shfl((int)val_b, 63 - __clzll((long long)mb), 64);
-                else if (ma) vt = (uint32_t)__shfl((int)val_a, 63 - __clzll((long long)ma), 64);
-                if (i < 64) { if (lane == i) { pos_a = j; val_a = vt; res_a = vj; } }
-                else if (lane == i - 64) { pos_b = j; val_b = vt; res_b = vj; }
-            }
+            // before the very first twist position() has no block to refer to: generate it now
+            if (mt.gen == 0) { mt.twist(); mt.base = 0; mt.lim = 0; mt.pos = 0; const int k = lane; mt.buf = mt_temper(s[k]); mt.lim = 64; }
+            if (lane == 0) samp_start[q] = mt.position();
+            for (int i = 0; i < 100; i++) (void)mt.randbelow(n - (uint32_t)i);
         } else {
-            // set method: draw until unseen
+            if (lane == 0) samp_start[q] = -1;
+            uint32_t res_a = 0, res_b = 0;
             for (int i = 0; i < 100; i++) {
                 uint32_t j;
                 for (;;) {
@@ -194,11 +197,58 @@ __global__ __launch_bounds__(64) void k_sample(const int32_t* large_list, long l
                 if (i < 64) { if (lane == i) res_a = j; }
                 else if (lane == i - 64) res_b = j;
             }
+            int32_t* out = sample_idx + large_excl[p] * 100;
+            out[lane] = (int32_t)res_a;
+            if (lane < 36) out[64 + lane] = (int32_t)res_b;
         }
-        int32_t* out = sample_idx + large_excl[p] * 100;
-        out[lane] = (int32_t)res_a;
-        if (lane < 36) out[64 + lane] = (int32_t)res_b;
     }
+    if (mt.overflow && lane == 0) *err = 1;
+}
+
+// Phase B: one wave per pool-method partition replays random.sample from its slice of the word stream.
+__global__ __launch_bounds__(64) void k_sample_apply(const int32_t* large_list, long long n_large, const int64_t* part_start, const uint32_t* sidx,
+                                                     const uint8_t* type, const int64_t* large_excl, const uint32_t* stream, long long cap_per_type,
+                                                     const long long* samp_start, int32_t* sample_idx) {
+    const long long q = blockIdx.x;
+    if (q >= n_large) return;
+    const long long st = samp_start[q];
+    if (st < 0) return;
+    const int lane = lane_id();
+    const int p = large_list[q];
+    const int t = type[sidx[part_start[p]]];
+    const uint32_t* strm = stream + (long long)t * cap_per_type;
+    const uint32_t n = (uint32_t)(part_start[p + 1] - part_start[p]);
+    long long chunk = st;                   // words [chunk, chunk+64) sit in `buf`
+    uint32_t buf = (chunk + lane < cap_per_type) ? strm[chunk + lane] : 0u;
+    int pos = 0;
+    // per-step records kept in registers: lane l holds steps l (a) and 64+l (b)
+    uint32_t pos_a = 0, val_a = 0, res_a = 0, pos_b = 0, val_b = 0, res_b = 0;
+    // pool method: result[i] = pool[j]; pool[j] = pool[n-i-1]; the pool is virtual (identity + <= 100 overrides)
+    for (int i = 0; i < 100; i++) {
+        const uint32_t bound = n - (uint32_t)i;
+        const int k = 32 - __clz((int)bound);
+        uint32_t j;
+        for (;;) {
+            if (pos == 64) { chunk += 64; buf = (chunk + lane < cap_per_type) ? strm[chunk + lane] : 0u; pos = 0; }
+            j = (uint32_t)__builtin_amdgcn_readlane((int)buf, pos) >> (32 - k);
+            pos++;
+            if (j < bound) break;
+        }
+        const uint32_t tail = bound - 1u;
+        uint32_t vj = j, vt = tail;
+        // latest override wins: steps 64.. first, then 0..63
+        unsigned long long mb = __ballot(lane < i - 64 && pos_b == j), ma = __ballot(lane < i && pos_a == j);
+        if (mb) vj = (uint32_t)__shfl((int)val_b, 63 - __clzll((long long)mb), 64);
+        else if (ma) vj = (uint32_t)__shfl((int)val_a, 63 - __clzll((long long)ma), 64);
+        mb = __ballot(lane < i - 64 && pos_b == tail); ma = __ballot(lane < i && pos_a == tail);
+        if (mb) vt = (uint32_t)__shfl((int)val_b, 63 - __clzll((long long)mb), 64);
+        else if (ma) vt = (uint32_t)__shfl((int)val_a, 63 - __clzll((long long)ma), 64);
+        if (i < 64) { if (lane == i) { pos_a = j; val_a = vt; res_a = vj; } }
+        else if (lane == i - 64) { pos_b = j; val_b = vt; res_b = vj; }
+    }
+    int32_t* out = sample_idx + large_excl[p] * 100;
+    out[lane] = (int32_t)res_a;
+    if (lane < 36) out[64 + lane] = (int32_t)res_b;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -731,26 +781,41 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     HIPCHK(hipMemcpyAsync(&totals[2], pair_off + n_part, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const int64_t samp_total = totals[0], n_large = totals[1], pair_total = totals[2];
+    SVXCHK(c->counters.reserve(16 * 8));
+    unsigned long long* cnt = c->counters.as<unsigned long long>();
+    HIPCHK(hipMemsetAsync(cnt, 0, 16 * 8, st));
     // ---- sampling ----------------------------------------------------------------------------------------------------
     SVXCHK(c->samp_idx.reserve((size_t)(n_large + 1) * 100 * 4));
     if (n_large > 0) {
-        SVXCHK(c->large_list.reserve((size_t)n_large * 4 + 624 * 4));
-        uint32_t* mt_dev = reinterpret_cast<uint32_t*>(c->large_list.as<int32_t>() + n_large);
+        SVXCHK(c->large_list.reserve((size_t)n_large * 4 + 624 * 4 + 64));
+        uint32_t* mt_dev = reinterpret_cast<uint32_t*>(c->large_list.as<int32_t>() + ((n_large + 1) & ~1ll));
         uint32_t mt_host[624];
         mt_seed_state(1524u, mt_host);
         HIPCHK(hipMemcpyAsync(mt_dev, mt_host, sizeof mt_host, hipMemcpyHostToDevice, st));
         k_large_list<<<GRID(n_part, T), T, 0, st>>>(large_a, large_excl, n_part, c->large_list.as<int32_t>());
-        k_sample<<<SVX_NTYPES, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl, mt_dev,
-                                           c->samp_idx.as<int32_t>());
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st));       // mt_host is a stack buffer
+        long long cap = n_large * 512 + 4 * 624;                       // expected use: <= ~200 words per partition
+        for (int attempt = 0; attempt < 6; attempt++) {
+            SVXCHK(c->samp_stream.reserve((size_t)cap * SVX_NTYPES * 4 + (size_t)n_large * 8 + 64));
+            uint32_t* stream = c->samp_stream.as<uint32_t>();
+            long long* samp_start = reinterpret_cast<long long*>(stream + cap * SVX_NTYPES);
+            int* err = reinterpret_cast<int*>(cnt + 15);
+            HIPCHK(hipMemsetAsync(err, 0, 8, st));
+            k_sample_scan<<<SVX_NTYPES, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl, mt_dev,
+                                                    stream, cap, samp_start, c->samp_idx.as<int32_t>(), err);
+            k_sample_apply<<<(unsigned)n_large, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
+                                                            stream, cap, samp_start, c->samp_idx.as<int32_t>());
+            HIPCHK(hipGetLastError());
+            int h_err = 0;
+            HIPCHK(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));       // also covers mt_host (stack buffer)
+            if (!h_err) break;
+            if (attempt == 5) return svx_fail(SVX_E_CAPACITY, "random word stream", __FILE__, __LINE__, hipSuccess);
+            cap *= 4;
+        }
     }
     HIPCHK(hipEventRecord(c->ev[9], st));
     // ---- INS haplotype edit distances -----------------------------------------------------------------------------
     SVXCHK(c->ed.reserve((size_t)(pair_total + 1) * 4));
-    SVXCHK(c->counters.reserve(16 * 8));
-    unsigned long long* cnt = c->counters.as<unsigned long long>();
-    HIPCHK(hipMemsetAsync(cnt, 0, 16 * 8, st));
     unsigned long long h_cnt[16] = {0};
     if (pair_total > 0) {
         if (!c->g_off_p) return svx_fail(SVX_E_STATE, "svx_set_genome must precede clustering of insertions", __FILE__, __LINE__, hipSuccess);
@@ -761,7 +826,9 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
         HIPCHK(hipMemcpyAsync(h_cnt, cnt, 16 * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         const int64_t n_work = (int64_t)h_cnt[8];
-        SVXCHK(svx_launch_edit_pairs(c, n_work, c->work.p, in, c->ed.as<int32_t>(), cnt + 9));
+        SVXCHK(c->cell_shards.reserve(1024 * 8));
+        HIPCHK(hipMemsetAsync(c->cell_shards.p, 0, 1024 * 8, st));
+        SVXCHK(svx_launch_edit_pairs(c, n_work, c->work.p, in, c->ed.as<int32_t>(), c->cell_shards.as<unsigned long long>()));
         S.n_edit_pairs = n_work;
     }
     HIPCHK(hipEventRecord(c->ev[10], st));
@@ -853,6 +920,13 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     HIPCHK(hipEventElapsedTime(&ms, c->ev[9], c->ev[10])); S.t_edit_ms = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[10], c->ev[11])); S.t_linkage_ms = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[8], c->ev[12])); S.t_cluster_ms = ms;
-    S.n_partitions = n_part; S.n_large_partitions = n_large; S.n_pairs = (int64_t)h_cnt[10]; S.n_edit_cells = (int64_t)h_cnt[9]; S.n_clusters = ncl;
+    S.n_partitions = n_part; S.n_large_partitions = n_large; S.n_pairs = (int64_t)h_cnt[10]; S.n_clusters = ncl;
+    if (pair_total > 0 && c->cell_shards.p) {
+        unsigned long long h_cells[1024];
+        HIPCHK(hipMemcpy(h_cells, c->cell_shards.p, sizeof h_cells, hipMemcpyDeviceToHost));
+        unsigned long long tot = 0;
+        for (int i = 0; i < 1024; i++) tot += h_cells[i];
+        S.n_edit_cells = (int64_t)tot;
+    }
     return SVX_OK;
 }

@@ -13,7 +13,8 @@
 // the rare chunks that actually emit a signature.  No LDS, no MFMA (integer / indexing workload).
 #include "common.hpp"
 
-enum { CNT_SIG = 0, CNT_BND = 1, CNT_USED = 2, CNT_OPS = 3, CNT_SEGOPS = 4, CNT_INS_BASES = 5 };
+enum { CNT_SIG = 0, CNT_BND = 1, CNT_USED = 2, CNT_OPS = 3, CNT_SEGOPS = 4, CNT_INS_BASES = 5, CNT_RAW = 6, CNT_OVERFLOW = 7 };
+#define RAW_SHARDS 1024      /* a single allocation counter would serialise the launch (~12 ns per same-address atomic) */
 
 #define KEY(slot, phase, ord) (((uint64_t)(slot) << 32) | ((uint64_t)(phase) << 30) | (uint64_t)(ord))
 
@@ -32,6 +33,11 @@ __device__ __forceinline__ void write_sig(const EmitTarget& t, long long i, uint
     t.p.pos2[i] = (int)pos2; t.p.read_id[i] = read_id; t.p.rec[i] = rec; t.p.qpos[i] = qpos; t.p.qlen[i] = qlen;
 }
 
+// What the scan kernel emits for an indel: the heavy signature-table write happens in k_emit_indels, so that the
+// streaming loop keeps a small register footprint.
+struct RawIndel { uint32_t item; uint32_t opidx; int pos_ref; int pos_read; int len_op; };     // len_op = len<<1 | is_del
+struct RawTarget { RawIndel* raw; long long shard_cap; unsigned long long* shard_counter; };     // RAW_SHARDS regions of shard_cap records
+
 // Python slice semantics seq[a:b] on a sequence of length len
 __device__ __forceinline__ void py_slice(long long a, long long b, long long len, int& lo, int& n) {
     if (a < 0) { a += len; if (a < 0) a = 0; } else if (a > len) a = len;
@@ -43,107 +49,131 @@ __device__ __forceinline__ void py_slice(long long a, long long b, long long len
 // ------------------------------------------------------------------------------------------------------
 // Kernel 1: CIGAR scan.  Work item w < n_rec: BAM record w; w >= n_rec: segment-table row w - n_rec.
 // geometry record = {ref_len, query_alignment_start, query_alignment_end, infer_read_length, hard_clipped}
+//
+// Persistent waves: the grid is sized to the chip (waves = CUs x resident waves), every wave walks items
+// w, w + n_waves, ... so the cost of the per-item metadata fetch and of uneven read lengths is spread out.
+// Inside an item the wave streams 1 KiB per load instruction (16 B per lane) with the next chunk's load issued
+// before the current chunk is decoded (two loads in flight per wave).
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cigar_scan(svx_batch b, svx_params p, EmitTarget sig, EmitTarget bnd,
-                                                    unsigned long long* counters, int* rec_geom, int* seg_geom,
-                                                    unsigned long long total_ops, unsigned long long total_seg_ops) {
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+#define MASK_REF 0x185      /* M D = X advance the reference cursor (N does not: reference quirk) */
+#define MASK_READ 0x193     /* M I S = X advance the read cursor */
+
+__device__ __forceinline__ int op_sel(int mask, int op, int l) { return l & -((mask >> op) & 1); }
+
+struct ItemMeta { unsigned long long off0, off1; int lseq; unsigned flag; int mapq; int has_seg; };
+
+__device__ __forceinline__ ItemMeta load_meta(const svx_batch& b, long long w) {
+    ItemMeta m;
+    if (w < b.n_rec) {
+        m.off0 = b.cigar_off[w]; m.off1 = b.cigar_off[w + 1]; m.lseq = b.lseq[w]; m.flag = b.flag[w]; m.mapq = b.mapq[w];
+        m.has_seg = b.seg_off[w + 1] > b.seg_off[w];
+    } else {
+        const long long s = w - b.n_rec;
+        m.off0 = b.seg_cigar_off[s]; m.off1 = b.seg_cigar_off[s + 1]; m.lseq = b.seg_lseq[s]; m.flag = 0; m.mapq = 255; m.has_seg = 1;
+    }
+    return m;
+}
+
+__device__ __forceinline__ uint4 load_chunk(const uint32_t* cig, unsigned long long k, unsigned long long off1, unsigned long long tot) {
+    uint4 q = make_uint4(15u, 15u, 15u, 15u);            // op 15 / len 0 = no-op
+    if (k < off1) {
+        if (k + 4 <= tot) q = *reinterpret_cast<const uint4*>(cig + k);
+        else {
+            if (k < tot) q.x = cig[k];
+            if (k + 1 < tot) q.y = cig[k + 1];
+            if (k + 2 < tot) q.z = cig[k + 2];
+        }
+    }
+    return q;
+}
+
+template <bool GEOM>
+__device__ __forceinline__ void scan_item(const svx_batch& b, const svx_params& p, const RawTarget& out, long long w,
+                                          const ItemMeta& mt, bool need_indel, int* geom_out, unsigned long long total_ops,
+                                          unsigned long long total_seg_ops, int shard) {
     const int lane = lane_id();
     const bool is_rec = w < b.n_rec;
-    if (!is_rec && w - b.n_rec >= b.n_seg) return;
-    const uint32_t* cig;
-    unsigned long long off0, off1, tot;
-    int lseq, need_indel = 0, need_geom = 1;
-    long long r = w, s = w - b.n_rec;
-    int* geom_out;
-    if (is_rec) {
-        unsigned f = b.flag[r];
-        if ((f & SVX_FLAG_USED_MASK) || (int)b.mapq[r] < p.min_mapq) return;
-        need_indel = 1;
-        need_geom = !(f & 2048u) && (b.seg_off[r + 1] > b.seg_off[r]);
-        cig = b.cigar; off0 = b.cigar_off[r]; off1 = b.cigar_off[r + 1]; tot = total_ops; lseq = b.lseq[r];
-        geom_out = rec_geom + 5 * r;
-    } else {
-        cig = b.seg_cigar; off0 = b.seg_cigar_off[s]; off1 = b.seg_cigar_off[s + 1]; tot = total_seg_ops; lseq = b.seg_lseq[s];
-        geom_out = seg_geom + 5 * s;
-    }
+    const uint32_t* cig = is_rec ? b.cigar : b.seg_cigar;
+    const unsigned long long tot = is_rec ? total_ops : total_seg_ops;
+    const unsigned long long off0 = mt.off0, off1 = mt.off1;
     const int min_len = p.min_sv_size;
     int acc_ref = 0, acc_read = 0, acc_n = 0, acc_h = 0, acc_s = 0;
     const unsigned long long a0 = off0 & ~3ull;
-    for (unsigned long long k0 = a0; k0 < off1; k0 += 256) {
+    // NU consecutive 1 KiB chunks per trip: the loads of the next trip are all issued before the current one is decoded,
+    // so a wave keeps NU KiB in flight (memory-level parallelism is what this kernel lives on)
+    constexpr int NU = 4;
+    uint4 nx[NU];
+#pragma unroll
+    for (int u = 0; u < NU; u++) nx[u] = load_chunk(cig, a0 + 256ull * u + (unsigned long long)lane * 4, off1, tot);
+    for (unsigned long long kb = a0; kb < off1; kb += 256ull * NU) {
+        uint4 cu[NU];
+#pragma unroll
+        for (int u = 0; u < NU; u++) cu[u] = nx[u];
+#pragma unroll
+        for (int u = 0; u < NU; u++) nx[u] = load_chunk(cig, kb + 256ull * (NU + u) + (unsigned long long)lane * 4, off1, tot);
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+        const unsigned long long k0 = kb + 256ull * u;
+        if (k0 >= off1) break;
         const unsigned long long k = k0 + (unsigned long long)lane * 4;
-        uint32_t v[4] = {15u, 15u, 15u, 15u};                  // op 15 / len 0 = no-op
-        if (k < off1) {
-            if (k + 4 <= tot) {
-                const uint4 q = *reinterpret_cast<const uint4*>(cig + k);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            } else {
-                for (int j = 0; j < 4; j++) if (k + j < tot) v[j] = cig[k + j];
-            }
+        uint4 q = cu[u];
+        // mask the elements outside [off0, off1) (only the first and the last chunk of an item can have any)
+        if (k0 < off0 || k0 + 256 > off1) {
+            if (k < off0 || k >= off1) q.x = 15u;
+            if (k + 1 < off0 || k + 1 >= off1) q.y = 15u;
+            if (k + 2 < off0 || k + 2 >= off1) q.z = 15u;
+            if (k + 3 < off0 || k + 3 >= off1) q.w = 15u;
         }
-        int pre_ref[4], pre_read[4], len[4], opc[4];
+        const uint32_t v[4] = {q.x, q.y, q.z, q.w};
         int t_ref = 0, t_read = 0;
         bool any_emit = false;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const bool valid = (k + j >= off0) && (k + j < off1);
-            const int op = valid ? (int)(v[j] & 15u) : 15;
-            const int l = valid ? (int)(v[j] >> 4) : 0;
-            opc[j] = op; len[j] = l;
-            pre_ref[j] = t_ref; pre_read[j] = t_read;
-            t_ref += ((0x185 >> op) & 1) ? l : 0;              // M D = X advance the reference cursor (N does not)
-            t_read += ((0x193 >> op) & 1) ? l : 0;             // M I S = X advance the read cursor
-            any_emit |= need_indel && (op == 1 || op == 2) && l >= min_len;
-            if (need_geom) {
+            const int op = (int)(v[j] & 15u), l = (int)(v[j] >> 4);
+            t_ref += op_sel(MASK_REF, op, l);
+            t_read += op_sel(MASK_READ, op, l);
+            any_emit |= ((unsigned)(op - 1) < 2u) && l >= min_len;
+            if (GEOM) {
                 acc_n += (op == 3) ? l : 0;
                 acc_h += (op == 5) ? l : 0;
                 acc_s += (op == 4) ? l : 0;
             }
         }
-        if (__any(any_emit)) {
+        if (need_indel && __any(any_emit)) {
             // rare path: exact cursor positions = wave-wide sum of everything before this chunk + exclusive scan inside it
-            const long long base_ref = wave_sum_i64(acc_ref), base_read = wave_sum_i64(acc_read);
-            const long long ex_ref = wave_incl_scan_i64(t_ref) - t_ref, ex_read = wave_incl_scan_i64(t_read) - t_read;
+            const int base_ref = wave_sum_i32(acc_ref), base_read = wave_sum_i32(acc_read);
+            const int ex_ref = wave_incl_scan_i32(t_ref) - t_ref, ex_read = wave_incl_scan_i32(t_read) - t_read;
+            int pr = 0, pq = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool e = need_indel && (opc[j] == 1 || opc[j] == 2) && len[j] >= min_len;
+                const int op = (int)(v[j] & 15u), l = (int)(v[j] >> 4);
+                const bool e = ((unsigned)(op - 1) < 2u) && l >= min_len;
                 const unsigned long long m = __ballot(e);
-                if (!m) continue;
-                const unsigned long long md = __ballot(e && opc[j] == 2);
-                long long sbase = 0, bbase = 0;
-                if (lane == 0) {
-                    sbase = (long long)atomicAdd(sig.counter, (unsigned long long)__popcll(m));
-                    if (p.all_bnds && md) bbase = (long long)atomicAdd(bnd.counter, (unsigned long long)__popcll(md));
-                }
-                sbase = __shfl(sbase, 0, 64); bbase = __shfl(bbase, 0, 64);
-                if (e) {
-                    const long long pos_ref = base_ref + ex_ref + pre_ref[j], pos_read = base_read + ex_read + pre_read[j];
-                    const long long rs = b.pos[r];
-                    const uint64_t key = KEY(b.order[r], 0, (k + j) - off0);
+                if (m) {
+                    long long sbase = 0;
+                    if (lane == 0) sbase = (long long)atomicAdd(out.shard_counter + shard, (unsigned long long)__popcll(m));
+                    sbase = __shfl(sbase, 0, 64);
                     const long long slot = sbase + __popcll(m & lanemask_lt());
-                    if (opc[j] == 1) {
-                        int qpos, qlen;
-                        py_slice(pos_read, pos_read + len[j], lseq, qpos, qlen);
-                        write_sig(sig, slot, key, SVX_INS, SVX_SRC_CIGAR, 0, b.tid[r], rs + pos_ref, rs + pos_ref + len[j], -1, 0,
-                                  b.read_id[r], (int)r, qpos, qlen);
-                    } else {
-                        write_sig(sig, slot, key, SVX_DEL, SVX_SRC_CIGAR, 0, b.tid[r], rs + pos_ref, rs + pos_ref + len[j], -1, 0,
-                                  b.read_id[r], -1, (int)pos_read, 0);        // qpos kept for the analyze_cigar_indel entry point
-                        if (p.all_bnds)
-                            write_sig(bnd, bbase + __popcll(md & lanemask_lt()), key, SVX_BND, SVX_SRC_CIGAR, 0, b.tid[r], rs + pos_ref,
-                                      rs + pos_ref + 1, b.tid[r], rs + pos_ref + len[j], b.read_id[r], -1, 0, 0);
+                    if (e && slot < out.shard_cap) {
+                        RawIndel ri;
+                        ri.item = (uint32_t)w; ri.opidx = (uint32_t)((k + j) - off0);
+                        ri.pos_ref = base_ref + ex_ref + pr; ri.pos_read = base_read + ex_read + pq; ri.len_op = (l << 1) | (op == 2);
+                        out.raw[(long long)shard * out.shard_cap + slot] = ri;
                     }
                 }
+                pr += op_sel(MASK_REF, op, l); pq += op_sel(MASK_READ, op, l);
             }
         }
         acc_ref += t_ref; acc_read += t_read;
+        }
     }
-    if (!need_geom) return;
-    const long long sum_ref = wave_sum_i64(acc_ref), sum_read = wave_sum_i64(acc_read);
-    const long long sum_n = wave_sum_i64(acc_n), sum_h = wave_sum_i64(acc_h), sum_s = wave_sum_i64(acc_s);
+    if (!GEOM) return;
+    const long long sum_ref = wave_sum_i32(acc_ref), sum_read = wave_sum_i32(acc_read);
+    const long long sum_n = wave_sum_i32(acc_n), sum_h = wave_sum_i32(acc_h), sum_s = wave_sum_i32(acc_s);
     if (lane == 0) {
         const long long n = (long long)(off1 - off0);
         const uint32_t* c = cig + off0;
+        const int lseq = mt.lseq;
         long long qstart = 0;
         for (long long i = 0; i < n; i++) {                     // leading clips: hard skipped, soft summed
             const int op = c[i] & 15;
@@ -172,6 +202,70 @@ __global__ __launch_bounds__(256) void k_cigar_scan(svx_batch b, svx_params p, E
         if (ref_len == 0) ref_len = 1;                          // bam_endpos never returns pos itself
         geom_out[0] = (int)ref_len; geom_out[1] = (int)qstart; geom_out[2] = (int)qend;
         geom_out[3] = (n > 0) ? (int)(sum_read + sum_h) : 0; geom_out[4] = (int)sum_h;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cigar_scan(svx_batch b, svx_params p, RawTarget out, int* rec_geom, int* seg_geom,
+                                                    unsigned long long total_ops, unsigned long long total_seg_ops) {
+    const long long n_items = b.n_rec + b.n_seg;
+    const long long n_waves = (long long)gridDim.x * 4;
+    // the wave index is uniform: keep it (and everything derived from it: metadata, base pointers) in scalar registers
+    long long w = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (w >= n_items) return;
+    const int shard = (int)(w & (RAW_SHARDS - 1));
+    ItemMeta nm = load_meta(b, w);
+    for (; w < n_items; w += n_waves) {
+        const ItemMeta mt = nm;
+        if (w + n_waves < n_items) nm = load_meta(b, w + n_waves);        // prefetch the next item's metadata
+        const bool is_rec = w < b.n_rec;
+        if (is_rec && ((mt.flag & SVX_FLAG_USED_MASK) || mt.mapq < p.min_mapq)) continue;
+        const bool need_geom = is_rec ? (!(mt.flag & 2048u) && mt.has_seg) : true;
+        int* geom_out = is_rec ? rec_geom + 5 * w : seg_geom + 5 * (w - b.n_rec);
+        if (need_geom) scan_item<true>(b, p, out, w, mt, is_rec, geom_out, total_ops, total_seg_ops, shard);
+        else scan_item<false>(b, p, out, w, mt, is_rec, geom_out, total_ops, total_seg_ops, shard);
+    }
+}
+
+// exclusive prefix of the per-shard counts -> dense signature slots; also freezes the total in CNT_SIG / CNT_RAW
+__global__ __launch_bounds__(RAW_SHARDS) void k_shard_prefix(const unsigned long long* shard_counter, long long shard_cap, long long* prefix,
+                                                             unsigned long long* counters) {
+    __shared__ long long s[RAW_SHARDS];
+    const int t = threadIdx.x;
+    unsigned long long c = shard_counter[t];
+    if ((long long)c > shard_cap) { atomicAdd(&counters[CNT_OVERFLOW], c - (unsigned long long)shard_cap); }
+    s[t] = (long long)c;
+    __syncthreads();
+    for (int o = 1; o < RAW_SHARDS; o <<= 1) { const long long v = (t >= o) ? s[t - o] : 0; __syncthreads(); s[t] += v; __syncthreads(); }
+    prefix[t + 1] = s[t];
+    if (t == 0) prefix[0] = 0;
+    if (t == RAW_SHARDS - 1) { counters[CNT_SIG] = (unsigned long long)s[t]; counters[CNT_RAW] = (unsigned long long)s[t]; }
+}
+
+// raw indel i of shard g -> signature table slot prefix[g] + i (analyze_alignment_indel, src/svim/SVIM_intra.py:33-51)
+__global__ __launch_bounds__(256) void k_emit_indels(svx_batch b, svx_params p, const RawIndel* raw, const unsigned long long* shard_counter,
+                                                     long long shard_cap, const long long* prefix, EmitTarget sig, EmitTarget bnd) {
+    const int g = blockIdx.y;
+    const long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long cnt = (long long)shard_counter[g];
+    if (cnt > shard_cap) cnt = shard_cap;
+    if (li >= cnt) return;
+    const long long i = prefix[g] + li;
+    const RawIndel ri = raw[(long long)g * shard_cap + li];
+    const long long r = ri.item;
+    const int l = ri.len_op >> 1;
+    const long long rs = b.pos[r];
+    const uint64_t key = KEY(b.order[r], 0, ri.opidx);
+    if (ri.len_op & 1) {
+        write_sig(sig, i, key, SVX_DEL, SVX_SRC_CIGAR, 0, b.tid[r], rs + ri.pos_ref, rs + ri.pos_ref + l, -1, 0, b.read_id[r], -1, ri.pos_read, 0);
+        if (p.all_bnds) {
+            const long long bi = (long long)atomicAdd(bnd.counter, 1ull);
+            write_sig(bnd, bi, key, SVX_BND, SVX_SRC_CIGAR, 0, b.tid[r], rs + ri.pos_ref, rs + ri.pos_ref + 1, b.tid[r], rs + ri.pos_ref + l, b.read_id[r],
+                      -1, 0, 0);
+        }
+    } else {
+        int qpos, qlen;
+        py_slice(ri.pos_read, (long long)ri.pos_read + l, b.lseq[r], qpos, qlen);
+        write_sig(sig, i, key, SVX_INS, SVX_SRC_CIGAR, 0, b.tid[r], rs + ri.pos_ref, rs + ri.pos_ref + l, -1, 0, b.read_id[r], (int)r, qpos, qlen);
     }
 }
 
@@ -467,8 +561,29 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
         HIPCHK(hipEventRecord(c->ev[0], st));
         const long long items = b.n_rec + b.n_seg;
         if (items > 0) {
-            k_cigar_scan<<<(unsigned)((items + 3) / 4), 256, 0, st>>>(b, *p, ts, tb, c->counters.as<unsigned long long>(),
-                                                                     c->rec_geom.as<int>(), c->seg_geom.as<int>(), tot_ops, tot_seg_ops);
+            long long blocks = (items + 3) / 4;
+            static int per_cu = 0;                                         // resident 256-thread blocks per CU for this kernel
+            if (!per_cu) {
+                int occ = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_cigar_scan, 256, 0) != hipSuccess || occ < 1) occ = 4;
+                per_cu = occ > 6 ? 6 : occ;                                // > 96 SGPRs: the hardware admits one block fewer than the API says
+            }
+            const long long max_blocks = (long long)c->n_cu * per_cu;
+            if (blocks > max_blocks) blocks = max_blocks;
+            const long long shard_cap = (c->raw_sig.cap + RAW_SHARDS - 1) / RAW_SHARDS;
+            SVXCHK(c->raw_indel.reserve((size_t)shard_cap * RAW_SHARDS * sizeof(RawIndel)));
+            SVXCHK(c->shard_cnt.reserve((size_t)RAW_SHARDS * 8 + (size_t)(RAW_SHARDS + 1) * 8));
+            unsigned long long* shard_counter = c->shard_cnt.as<unsigned long long>();
+            long long* shard_prefix = reinterpret_cast<long long*>(shard_counter + RAW_SHARDS);
+            HIPCHK(hipMemsetAsync(shard_counter, 0, RAW_SHARDS * 8, st));
+            RawTarget rt{c->raw_indel.as<RawIndel>(), shard_cap, shard_counter};
+            k_cigar_scan<<<(unsigned)blocks, 256, 0, st>>>(b, *p, rt, c->rec_geom.as<int>(), c->seg_geom.as<int>(), tot_ops, tot_seg_ops);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev[5], st));
+            // dense slots for the raw records; the total becomes the start of the segment kernel's allocations
+            k_shard_prefix<<<1, RAW_SHARDS, 0, st>>>(shard_counter, shard_cap, shard_prefix, c->counters.as<unsigned long long>());
+            k_emit_indels<<<dim3((unsigned)((shard_cap + 255) / 256), RAW_SHARDS), 256, 0, st>>>(b, *p, c->raw_indel.as<RawIndel>(), shard_counter, shard_cap,
+                                                                                              shard_prefix, ts, tb);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(c->ev[1], st));
@@ -480,9 +595,10 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
         if (b.n_rec > 0) k_count_used<<<(unsigned)((b.n_rec + 255) / 256), 256, 0, st>>>(b, *p, c->counters.as<unsigned long long>());
         HIPCHK(hipMemcpyAsync(h_cnt, c->counters.p, 16 * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if ((int64_t)h_cnt[CNT_SIG] <= c->raw_sig.cap && (int64_t)h_cnt[CNT_BND] <= c->raw_bnd.cap) break;
+        if ((int64_t)h_cnt[CNT_SIG] <= c->raw_sig.cap && (int64_t)h_cnt[CNT_BND] <= c->raw_bnd.cap && h_cnt[CNT_OVERFLOW] == 0) break;
         if (attempt == 2) return svx_fail(SVX_E_CAPACITY, "signature buffers", __FILE__, __LINE__, hipSuccess);
-        cap_sig = (int64_t)h_cnt[CNT_SIG] + 1024; cap_bnd = (int64_t)h_cnt[CNT_BND] + 1024;
+        cap_sig = 2 * ((int64_t)h_cnt[CNT_SIG] + (int64_t)h_cnt[CNT_OVERFLOW]) + 64 * RAW_SHARDS; cap_bnd = (int64_t)h_cnt[CNT_BND] + 1024;
+        if (cap_sig < 4 * c->raw_sig.cap && h_cnt[CNT_OVERFLOW]) cap_sig = 4 * c->raw_sig.cap;     // shard imbalance: grow generously
     }
     const int64_t n_sig = (int64_t)h_cnt[CNT_SIG], n_bnd = (int64_t)h_cnt[CNT_BND];
     SVXCHK(order_and_store(c, c->raw_sig, c->sig, n_sig));
@@ -513,7 +629,7 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
     HIPCHK(hipStreamSynchronize(st));
     float ms;
     svx_stats& s = c->stats;
-    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); s.t_cigar_scan_ms = ms;
+    if (b.n_rec + b.n_seg > 0) { HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[5])); s.t_cigar_scan_ms = ms; } else s.t_cigar_scan_ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); s.t_segments_ms = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); s.t_sort_ms = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); s.t_gather_ms = ms;

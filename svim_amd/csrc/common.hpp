@@ -102,6 +102,7 @@ struct DevClusters {
 
 struct svx_ctx {
     int device = 0;
+    int n_cu = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev[16];
     // device copies of a host-resident batch
@@ -110,6 +111,8 @@ struct svx_ctx {
     DevSigs sig, bnd;               // sorted by key
     DevSigs raw_sig, raw_bnd;       // unordered emission buffers
     DevBuf counters;                // device counters (uint64 x 16)
+    DevBuf shard_cnt;               // per-shard allocation counters + prefix of the raw indel buffer
+    DevBuf raw_indel;               // RawIndel records written by the scan kernel
     DevBuf rec_geom, seg_geom;      // int32 x 5 per record / per segment row
     DevBuf seg_ws;                  // segment analysis workspace
     DevBuf tmp0, tmp1, tmp2, tmp3, tmp4, tmp5, sort_tmp;
@@ -117,10 +120,13 @@ struct svx_ctx {
     DevBuf g_off, g_codes; int32_t g_n = 0; bool g_borrowed = false; const int64_t* g_off_p = nullptr; const uint8_t* g_codes_p = nullptr;
     // CLUSTER workspace + results
     DevBuf user_sig[12]; DevBuf c_rank;
-    DevBuf k_hi, k_lo, k_idx, k_hi2, k_lo2, k_idx2, part_flag, part_id, part_start, part_meta, samp_idx, large_list;
+    DevBuf k_hi, k_lo, k_idx, k_hi2, k_lo2, k_idx2, part_flag, part_id, part_start, part_meta, samp_idx, large_list, samp_stream;
+    DevBuf cell_shards;
     DevBuf pair_off, ed, work, stage, stage_members, labels;
+    DevBuf e_words, e_off, e_scratch, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off;     // edit-distance pipeline
     DevClusters clu;
     int shard_rank = 0, shard_world = 1;
+    bool edit_force_full = false;  // debugging aid (env SVX_EDIT_FORCE_FULL=1): every pair through the full-matrix kernel
     bool no_seq_gather = false;   // svx_cigar_indel hook: positions only
     svx_stats stats;
     int64_t last_cluster_source_n = 0;

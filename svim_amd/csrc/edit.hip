@@ -2,15 +2,26 @@
 //
 // Replaces compute_haplotype_edit_distance (src/svim/SVIM_clustering.py:32-45): the reference builds
 //   hap_k = ref[ws:start_k] + inserted_k + ref[start_k:we]   (window = min/max start -+ 100, clipped to the contig)
-// as Python strings with four FASTA fetches per pair and calls edlib.align(h1, h2)["editDistance"].  Here the
-// haplotypes are never materialised: a `Hap` is a virtual concatenation of three byte ranges living in HBM
-// (genome codes + the signature's inserted bases), the common prefix/suffix is stripped wave-parallel, and the
-// remaining core is solved exactly with Myers/Hyyro bit-vector DP laid out as a 64-lane systolic array:
-//   lane l owns R consecutive 32-row blocks of the shorter string (bit-sliced into 4 planes, 4-bit alphabet),
-//   at step t it processes text column t-l, receives (symbol, horizontal delta) from lane l-1 through a single
-//   DPP wave shift and hands its own to lane l+1.  Text symbols are fetched 64 at a time (one coalesced load,
-//   prefetched a chunk ahead) and broadcast with v_readlane.  No LDS, no MFMA: integer ALU bound.
+// as Python strings with four FASTA fetches per pair and calls edlib.align(h1, h2)["editDistance"].
+//
+// Pipeline (all exact):
+//   1. k_pair_words / scan      size the scratch that will hold every pair's two trimmed cores
+//   2. k_edit_prep (wave/pair)  a `Hap` is a virtual concatenation of three byte ranges in HBM (genome codes + the
+//                               signature's inserted bases); the common prefix/suffix is stripped wave-parallel and the
+//                               two cores are written 4-bit packed (8 symbols per 32-bit word), plus a Hamming-style
+//                               upper bound of the distance
+//   3. k_edit_band<Q> (LANE/pair) Ukkonen band of 32*Q diagonals around the main corridor, Myers/Hyyro bit-vector
+//                               recurrence in band-relative coordinates (the window slides one row per column), all
+//                               state in registers: Q words each of Pv, Mv and the 4 bit-planes of the pattern window.
+//                               The result d is exact iff floor((d-(n-m))/2) <= band margin; otherwise d is only an
+//                               upper bound and the pair is retried with the band that bound guarantees
+//   4. k_edit_full (wave/pair)  pairs whose band would exceed 512 diagonals: full matrix as a 64-lane systolic array
+//                               (lane l owns R 32-row blocks, column t-l at step t, carries handed down with one DPP
+//                               wave shift); cores longer than 16384 rows keep their block state in a scratch area
+// No LDS, no MFMA: integer-ALU bound (reported as cell updates/s).
 #include "common.hpp"
+
+struct EditWork { uint32_t a, b; long long slot; };
 
 struct Hap {
     const uint8_t* p0; const uint8_t* p1; const uint8_t* p2;
@@ -21,6 +32,12 @@ struct Hap {
         if (i < n1) return p1[i];
         return p2[i - n1];
     }
+};
+
+// 4-bit packed string: symbol i = (w[i>>3] >> 4*(i&7)) & 15
+struct Packed {
+    const uint32_t* w;
+    __device__ __forceinline__ uint32_t at(int i) const { return (w[i >> 3] >> ((i & 7) << 2)) & 15u; }
 };
 
 __device__ __forceinline__ void hap_fetch(const int64_t* g_off, const uint8_t* g_codes, int contig, long long a, long long b,
@@ -47,7 +64,275 @@ __device__ __forceinline__ Hap plain_hap(const uint8_t* s, int n) {
     Hap h; h.p0 = s; h.n0 = 0; h.p1 = s; h.n1 = n; h.p2 = s; h.n2 = 0; h.len = n; return h;
 }
 
-// one 32-row block, one text column
+// where the two strings of a work item come from
+struct PairSource {
+    int plain;                       // 1: codes + a_off/b_off ; 0: signature pairs
+    const uint8_t* codes; const int64_t* a_off; const int64_t* b_off;
+    const EditWork* work; ClusterIn in; const int64_t* g_off; const uint8_t* g_codes;
+    __device__ __forceinline__ void haps(long long w, Hap& A, Hap& B) const {
+        if (plain) {
+            A = plain_hap(codes + a_off[w], (int)(a_off[w + 1] - a_off[w]));
+            B = plain_hap(codes + b_off[w], (int)(b_off[w + 1] - b_off[w]));
+        } else {
+            const EditWork wk = work[w];
+            const long long s1 = in.start[wk.a], s2 = in.start[wk.b];
+            const long long ws = (s1 < s2 ? s1 : s2) - 100, we = (s1 > s2 ? s1 : s2) + 100;
+            A = make_hap(g_off, g_codes, in.contig[wk.a], s1, in.seq + in.seq_off[wk.a], (int)(in.seq_off[wk.a + 1] - in.seq_off[wk.a]), ws, we);
+            B = make_hap(g_off, g_codes, in.contig[wk.b], s2, in.seq + in.seq_off[wk.b], (int)(in.seq_off[wk.b + 1] - in.seq_off[wk.b]), ws, we);
+        }
+    }
+    __device__ __forceinline__ long long slot(long long w) const { return plain ? w : work[w].slot; }
+};
+
+// per-pair descriptor after trimming
+struct PairDesc {
+    unsigned long long pat;     // word offset of the shorter core in the scratch
+    unsigned long long txt;     // word offset of the longer core
+    int m, n;                   // core lengths, m <= n
+    int ub;                     // upper bound of the distance known so far
+    int cls;                    // next class to try: 0..4 = band of 32<<cls diagonals, 5 = full matrix
+};
+
+#define CLS_FULL 5
+#define MIN_MARGIN 16
+
+__device__ __forceinline__ int band_class_for(int need_w) {      // smallest class whose window keeps the needed margin after dmax is aligned to 7 (mod 8)
+    const int w = need_w + 14;
+    if (w <= 32) return 0;
+    if (w <= 64) return 1;
+    if (w <= 128) return 2;
+    if (w <= 256) return 3;
+    if (w <= 512) return 4;
+    return CLS_FULL;
+}
+// window that guarantees exactness when the true distance is <= ub
+__device__ __forceinline__ int need_window(int m, int n, int ub) {
+    int x = (ub - (n - m)) / 2;
+    if (x < 0) x = 0;
+    return (n - m) + 2 * x + 1;
+}
+
+// ---- 1. scratch sizing --------------------------------------------------------------------------------------
+__global__ void k_pair_words(long long n_work, PairSource src, int64_t* words) {
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > n_work) return;
+    if (w == n_work) { words[w] = 0; return; }
+    Hap A, B;
+    src.haps(w, A, B);
+    words[w] = (A.len + 7) / 8 + (B.len + 7) / 8 + 2;
+}
+
+// ---- 2. trim + pack ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource src, const int64_t* word_off, uint32_t* scratch, PairDesc* desc,
+                                                   uint64_t* sort_key, uint32_t* sort_val, int32_t* ed, unsigned long long* cells, int force_full) {
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_work) return;
+    const int lane = lane_id();
+    Hap A, B;
+    src.haps(w, A, B);
+    const int la = A.len, lb = B.len;
+    const int mn = la < lb ? la : lb;
+    int pre = 0;
+    while (pre < mn) {
+        const int i = pre + lane;
+        const bool diff = (i >= mn) || (A.at(i) != B.at(i));
+        const unsigned long long d = __ballot(diff);
+        if (d) { pre += __ffsll((long long)d) - 1; break; }
+        pre += 64;
+    }
+    if (pre > mn) pre = mn;
+    int suf = 0;
+    const int lim = mn - pre;
+    while (suf < lim) {
+        const int i = suf + lane;
+        const bool diff = (i >= lim) || (A.at(la - 1 - i) != B.at(lb - 1 - i));
+        const unsigned long long d = __ballot(diff);
+        if (d) { suf += __ffsll((long long)d) - 1; break; }
+        suf += 64;
+    }
+    if (suf > lim) suf = lim;
+    const int ca = la - pre - suf, cb = lb - pre - suf;
+    PairDesc pd;
+    const bool a_short = ca <= cb;
+    const Hap& P = a_short ? A : B;
+    const Hap& T = a_short ? B : A;
+    pd.m = a_short ? ca : cb; pd.n = a_short ? cb : ca;
+    pd.pat = (unsigned long long)word_off[w];
+    pd.txt = pd.pat + (unsigned long long)((pd.m + 7) / 8) + 1ull;
+    if (pd.m == 0) {                                   // one core is empty: the distance is the other's length
+        if (lane == 0) { ed[src.slot(w)] = pd.n; pd.ub = pd.n; pd.cls = -1; desc[w] = pd; sort_key[w] = 0xffull << 32; sort_val[w] = (uint32_t)w; }
+        return;
+    }
+    // pack the cores, count mismatches of the two trivial alignments (left- / right-justified) and look for code 0
+    uint32_t* pw = scratch + pd.pat; uint32_t* tw = scratch + pd.txt;
+    int ham_l = 0, ham_r = 0, zero = 0;
+    for (int base = 0; base < pd.n; base += 512) {     // 64 lanes x 8 symbols
+        const int i0 = base + lane * 8;
+        uint32_t wt = 0, wp = 0;
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + k;
+            if (i < pd.n) {
+                const uint32_t ct = T.at(pre + i);
+                wt |= ct << (4 * k); zero |= (ct == 0);
+                if (i < pd.m) {
+                    const uint32_t cp = P.at(pre + i);
+                    wp |= cp << (4 * k); zero |= (cp == 0);
+                    ham_l += (cp != ct);
+                    ham_r += (P.at(pre + i) != T.at(pre + (pd.n - pd.m) + i));
+                }
+            }
+        }
+        if (i0 < pd.n) tw[i0 >> 3] = wt;
+        if (i0 < pd.m) pw[i0 >> 3] = wp;
+    }
+    ham_l = wave_sum_i32(ham_l); ham_r = wave_sum_i32(ham_r);
+    zero = __any(zero);
+    if (lane == 0) {
+        const int ub = (ham_l < ham_r ? ham_l : ham_r) + (pd.n - pd.m);
+        pd.ub = ub;
+        int cls;
+        if (zero || force_full) cls = CLS_FULL;                       // symbol '=' (code 0) is the band kernel's "never matches" filler
+        else {
+            const int guaranteed = band_class_for(need_window(pd.m, pd.n, ub));
+            const int spec = band_class_for((pd.n - pd.m) + 2 * MIN_MARGIN + 1);
+            cls = guaranteed < spec ? guaranteed : spec;
+        }
+        pd.cls = cls;
+        desc[w] = pd;
+        sort_key[w] = ((unsigned long long)cls << 32) | (unsigned long long)(pd.n > 0xffffff ? 0xffffff : pd.n);
+        sort_val[w] = (uint32_t)w;
+        if (cells) atomicAdd(cells + (w & 1023), (unsigned long long)pd.m * (unsigned long long)pd.n);      // 1024 shards: no same-address pile-up
+    }
+}
+
+// ---- 3. banded lane-per-pair kernel -----------------------------------------------------------------------------
+// Window of W = 32*Q bits; bit b of column j <-> row (j - dmax) + b.  dmax = 7 (mod 8) so that the row entering at the
+// bottom of the window and the text symbol of the column sit at the same nibble phase of their packed words.
+template <int Q>
+__global__ __launch_bounds__(256) void k_edit_band(long long count, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
+                                                   const long long* slot_of, int32_t* ed, unsigned long long* n_fail, uint32_t* fail_list,
+                                                   uint64_t* fail_key) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < count;
+    uint32_t widx = 0;
+    PairDesc pd; pd.m = 0; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
+    if (live) { widx = list[t]; pd = desc[widx]; }
+    const int W = 32 * Q;
+    const int m = pd.m, n = live ? pd.n : 0;
+    // largest dmax <= (n-m) + floor((W-1-(n-m))/2) with dmax = 7 (mod 8)
+    int a0 = (W - 1 - (n - m)) / 2;
+    int dmax = (n - m) + a0;
+    dmax -= ((dmax - 7) & 7);
+    const int margin = dmax - (n - m);                 // top margin; bottom margin W-1-dmax >= margin
+    const int a_bot = W - 1 - dmax;                    // multiple of 8
+    const uint32_t* pat = scratch + pd.pat;
+    const uint32_t* txt = scratch + pd.txt;
+    uint32_t pv[Q], mv[Q], p0[Q], p1[Q], p2[Q], p3[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int lo = 32 * q, nvirt = dmax + 1;        // rows <= 0 : vertical delta -1
+        uint32_t mlow;
+        if (nvirt >= lo + 32) mlow = 0xffffffffu; else if (nvirt <= lo) mlow = 0u; else mlow = (1u << (nvirt - lo)) - 1u;
+        mv[q] = mlow; pv[q] = ~mlow;
+        p0[q] = p1[q] = p2[q] = p3[q] = 0u;
+    }
+    const int pat_words = (m + 7) >> 3;
+    // pre-roll: rows 1..a_bot enter the window (a_bot/8 whole words)
+    for (int wi = 0; wi < (a_bot >> 3); wi++) {
+        const uint32_t word = (live && wi < pat_words) ? pat[wi] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int row = wi * 8 + k + 1;
+            const uint32_t c = (row <= m) ? ((word >> (4 * k)) & 15u) : 0u;
+#pragma unroll
+            for (int q = 0; q < Q - 1; q++) {
+                p0[q] = __builtin_amdgcn_alignbit(p0[q + 1], p0[q], 1); p1[q] = __builtin_amdgcn_alignbit(p1[q + 1], p1[q], 1);
+                p2[q] = __builtin_amdgcn_alignbit(p2[q + 1], p2[q], 1); p3[q] = __builtin_amdgcn_alignbit(p3[q + 1], p3[q], 1);
+            }
+            p0[Q - 1] = (p0[Q - 1] >> 1) | ((c & 1u) << 31); p1[Q - 1] = (p1[Q - 1] >> 1) | (((c >> 1) & 1u) << 31);
+            p2[Q - 1] = (p2[Q - 1] >> 1) | (((c >> 2) & 1u) << 31); p3[Q - 1] = (p3[Q - 1] >> 1) | (((c >> 3) & 1u) << 31);
+        }
+    }
+    int S = dmax;
+    // uniform trip count: the longest text in the wave
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
+    const int txt_words = (n + 7) >> 3;
+    const int pbase = a_bot >> 3;                        // pattern word holding row j + a_bot for j = 8*jb+1..
+    uint32_t tw_next = (live && txt_words > 0) ? txt[0] : 0u;
+    uint32_t pw_next = (live && pbase < pat_words) ? pat[pbase] : 0u;
+    for (int jb = 0; jb * 8 < nmax; jb++) {
+        const uint32_t tw = tw_next, pw = pw_next;
+        tw_next = (live && jb + 1 < txt_words) ? txt[jb + 1] : 0u;
+        pw_next = (live && pbase + jb + 1 < pat_words) ? pat[pbase + jb + 1] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = jb * 8 + k + 1;
+            if (j <= n) {
+                const uint32_t c = (tw >> (4 * k)) & 15u;
+                const uint32_t pc = (j + a_bot <= m) ? ((pw >> (4 * k)) & 15u) : 0u;
+                // slide the window one row down
+#pragma unroll
+                for (int q = 0; q < Q - 1; q++) {
+                    pv[q] = __builtin_amdgcn_alignbit(pv[q + 1], pv[q], 1); mv[q] = __builtin_amdgcn_alignbit(mv[q + 1], mv[q], 1);
+                    p0[q] = __builtin_amdgcn_alignbit(p0[q + 1], p0[q], 1); p1[q] = __builtin_amdgcn_alignbit(p1[q + 1], p1[q], 1);
+                    p2[q] = __builtin_amdgcn_alignbit(p2[q + 1], p2[q], 1); p3[q] = __builtin_amdgcn_alignbit(p3[q + 1], p3[q], 1);
+                }
+                pv[Q - 1] = (pv[Q - 1] >> 1) | 0x80000000u; mv[Q - 1] >>= 1;
+                p0[Q - 1] = (p0[Q - 1] >> 1) | ((pc & 1u) << 31); p1[Q - 1] = (p1[Q - 1] >> 1) | (((pc >> 1) & 1u) << 31);
+                p2[Q - 1] = (p2[Q - 1] >> 1) | (((pc >> 2) & 1u) << 31); p3[Q - 1] = (p3[Q - 1] >> 1) | (((pc >> 3) & 1u) << 31);
+                S += (int)(pv[0] & 1u) - (int)(mv[0] & 1u);
+                const uint32_t n0 = (c & 1u) - 1u, n1 = ((c >> 1) & 1u) - 1u, n2 = ((c >> 2) & 1u) - 1u, n3 = ((c >> 3) & 1u) - 1u;
+                uint32_t carry = 0, ph_in = 1u, mh_in = 0u;
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const uint32_t eq = (p0[q] ^ n0) & (p1[q] ^ n1) & (p2[q] ^ n2) & (p3[q] ^ n3);
+                    const uint32_t PV = pv[q], MV = mv[q];
+                    const uint32_t xv = eq | MV;
+                    const unsigned long long sum = (unsigned long long)(eq & PV) + (unsigned long long)PV + (unsigned long long)carry;
+                    carry = (uint32_t)(sum >> 32);
+                    const uint32_t xh = (((uint32_t)sum) ^ PV) | eq;
+                    uint32_t ph = MV | ~(xh | PV);
+                    uint32_t mh = PV & xh;
+                    if (q == 0) S += (int)(ph & 1u) - (int)(mh & 1u);
+                    const uint32_t ph_out = ph >> 31, mh_out = mh >> 31;
+                    ph = (ph << 1) | ph_in; mh = (mh << 1) | mh_in;
+                    ph_in = ph_out; mh_in = mh_out;
+                    pv[q] = mh | ~(xv | ph);
+                    mv[q] = ph & xv;
+                }
+            }
+        }
+    }
+    if (!live) return;
+    // D[m][n] = D[top][n] + vertical deltas of rows top+1..m  (bits 1..margin)
+    int d = S;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int lo = 32 * q;                           // bits lo..lo+31 ; wanted bits 1..margin
+        int hi_bit = margin - lo;                        // number of wanted bits in this word counted from bit 0 of the word, inclusive of bit 'margin'
+        uint32_t mask;
+        if (hi_bit >= 31) mask = 0xffffffffu; else if (hi_bit < 0) mask = 0u; else mask = (2u << hi_bit) - 1u;
+        if (q == 0) mask &= ~1u;
+        d += __popc(pv[q] & mask) - __popc(mv[q] & mask);
+    }
+    const int x = (d - (n - m)) >> 1;                    // floor: d >= n-m always
+    if (margin >= 0 && x >= 0 && x <= margin) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
+    else {
+        // d is a valid alignment cost, hence an upper bound: the band it guarantees succeeds next time
+        const int ub = d < pd.ub ? d : pd.ub;
+        int cls = band_class_for(need_window(m, n, ub));
+        if (cls <= pd.cls) cls = pd.cls + 1;             // never retry the same width (can only differ by the alignment slack)
+        if (cls > 4) cls = CLS_FULL;
+        desc[widx].ub = ub; desc[widx].cls = cls;
+        const unsigned long long i = atomicAdd(n_fail, 1ull);
+        fail_list[i] = widx;
+        fail_key[i] = ((unsigned long long)cls << 32) | (unsigned long long)(n > 0xffffff ? 0xffffff : n);
+    }
+}
+
+// ---- 4. full-matrix systolic kernel ----------------------------------------------------------------------------
 __device__ __forceinline__ void myers_block(uint32_t eq, uint32_t& pv, uint32_t& mv, uint32_t& hp, uint32_t& hm, uint32_t topmask) {
     const uint32_t xv = eq | mv;
     eq |= hm;
@@ -67,10 +352,10 @@ __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
 }
 
-// Exact distance between the cores pat (length m >= 1, the shorter) and txt (length n >= m); whole wave cooperates.
+// Exact distance between pat (length m >= 1, the shorter) and txt (length n >= m); whole wave cooperates.
 // R = 32-row blocks per lane held in registers (m <= 64*32*R).
 template <int R>
-__device__ int systolic_distance(const Hap& pat, int poff, int m, const Hap& txt, int toff, int n) {
+__device__ int systolic_distance(const Packed& pat, int m, const Packed& txt, int n) {
     const int lane = lane_id();
     const int nb = (m + 31) >> 5;
     uint32_t pl[R][4], vm[R], pv[R], mv[R], top[R];
@@ -83,7 +368,7 @@ __device__ int systolic_distance(const Hap& pat, int poff, int m, const Hap& txt
             for (int i = 0; i < 32; i++) {
                 const int row = row0 + i;
                 if (row < m) {
-                    const uint32_t c = pat.at(poff + row);
+                    const uint32_t c = pat.at(row);
                     a0 |= (c & 1u) << i; a1 |= ((c >> 1) & 1u) << i; a2 |= ((c >> 2) & 1u) << i; a3 |= ((c >> 3) & 1u) << i;
                     v |= 1u << i;
                 }
@@ -99,11 +384,11 @@ __device__ int systolic_distance(const Hap& pat, int poff, int m, const Hap& txt
     int score = m;
     const int steps = n + lanes_used - 1;
     uint32_t out = 0;
-    uint32_t tc_next = (lane < n) ? txt.at(toff + lane) : 0u;
+    uint32_t tc_next = (lane < n) ? txt.at(lane) : 0u;
     for (int t0 = 0; t0 < steps; t0 += 64) {
         const uint32_t tc = tc_next;
         const int nxt = t0 + 64 + lane;
-        tc_next = (nxt < n) ? txt.at(toff + nxt) : 0u;
+        tc_next = (nxt < n) ? txt.at(nxt) : 0u;
 #pragma unroll 4
         for (int j = 0; j < 64; j++) {
             const int t = t0 + j;
@@ -132,12 +417,11 @@ __device__ int systolic_distance(const Hap& pat, int poff, int m, const Hap& txt
     return __shfl(score, last_lane, 64);
 }
 
-// Fallback for cores longer than 64*32*8 rows: same systolic schedule, block state in a global scratch area.
-__device__ int systolic_distance_big(const Hap& pat, int poff, int m, const Hap& txt, int toff, int n, uint32_t* scratch) {
+// cores longer than 64*32*8 rows: same systolic schedule, block state in a global scratch area (7 words per block)
+__device__ int systolic_distance_big(const Packed& pat, int m, const Packed& txt, int n, uint32_t* state) {
     const int lane = lane_id();
     const int nb = (m + 31) >> 5;
     const int R = (nb + 63) / 64;
-    // scratch layout per block: pl0..pl3, vm, pv, mv  (7 words), block-major
     for (int r = 0; r < R; r++) {
         const int blk = lane * R + r;
         if (blk >= nb) break;
@@ -146,12 +430,12 @@ __device__ int systolic_distance_big(const Hap& pat, int poff, int m, const Hap&
         for (int i = 0; i < 32; i++) {
             const int row = row0 + i;
             if (row < m) {
-                const uint32_t c = pat.at(poff + row);
+                const uint32_t c = pat.at(row);
                 a0 |= (c & 1u) << i; a1 |= ((c >> 1) & 1u) << i; a2 |= ((c >> 2) & 1u) << i; a3 |= ((c >> 3) & 1u) << i;
                 v |= 1u << i;
             }
         }
-        uint32_t* s = scratch + (size_t)blk * 7;
+        uint32_t* s = state + (size_t)blk * 7;
         s[0] = a0; s[1] = a1; s[2] = a2; s[3] = a3; s[4] = v; s[5] = 0xffffffffu; s[6] = 0u;
     }
     const int lanes_used = (nb + R - 1) / R;
@@ -159,11 +443,11 @@ __device__ int systolic_distance_big(const Hap& pat, int poff, int m, const Hap&
     int score = m;
     const int steps = n + lanes_used - 1;
     uint32_t out = 0;
-    uint32_t tc_next = (lane < n) ? txt.at(toff + lane) : 0u;
+    uint32_t tc_next = (lane < n) ? txt.at(lane) : 0u;
     for (int t0 = 0; t0 < steps; t0 += 64) {
         const uint32_t tc = tc_next;
         const int nxt = t0 + 64 + lane;
-        tc_next = (nxt < n) ? txt.at(toff + nxt) : 0u;
+        tc_next = (nxt < n) ? txt.at(nxt) : 0u;
         for (int j = 0; j < 64; j++) {
             const int t = t0 + j;
             if (t >= steps) break;
@@ -177,7 +461,7 @@ __device__ int systolic_distance_big(const Hap& pat, int poff, int m, const Hap&
                 for (int r = 0; r < R; r++) {
                     const int blk = lane * R + r;
                     if (blk >= nb) break;
-                    uint32_t* s = scratch + (size_t)blk * 7;
+                    uint32_t* s = state + (size_t)blk * 7;
                     const uint32_t eq = (s[0] ^ n0) & (s[1] ^ n1) & (s[2] ^ n2) & (s[3] ^ n3) & s[4];
                     uint32_t pv = s[5], mv = s[6];
                     const uint32_t top = (blk == nb - 1) ? (1u << ((m - 1) & 31)) : 0x80000000u;
@@ -194,153 +478,157 @@ __device__ int systolic_distance_big(const Hap& pat, int poff, int m, const Hap&
     return __shfl(score, last_lane, 64);
 }
 
-#define SVX_EDIT_BIG (-2)      // returned by edit_core when the pair needs the scratch-backed path
-
-// Whole-wave edit distance of two virtual strings.  cells: (optional) DP-cell count for statistics.
-__device__ int edit_core(const Hap& A, const Hap& B, uint32_t* big_scratch, unsigned long long* cells, int* big_m = nullptr) {
-    const int lane = lane_id();
-    const int la = A.len, lb = B.len;
-    const int mn = la < lb ? la : lb;
-    // common prefix
-    int pre = 0;
-    while (pre < mn) {
-        const int i = pre + lane;
-        const bool diff = (i >= mn) || (A.at(i) != B.at(i));
-        const unsigned long long d = __ballot(diff);
-        if (d) { pre += __ffsll((long long)d) - 1; break; }
-        pre += 64;
-    }
-    if (pre > mn) pre = mn;
-    // common suffix (not overlapping the prefix)
-    int suf = 0;
-    const int lim = mn - pre;
-    while (suf < lim) {
-        const int i = suf + lane;
-        const bool diff = (i >= lim) || (A.at(la - 1 - i) != B.at(lb - 1 - i));
-        const unsigned long long d = __ballot(diff);
-        if (d) { suf += __ffsll((long long)d) - 1; break; }
-        suf += 64;
-    }
-    if (suf > lim) suf = lim;
-    const int ca = la - pre - suf, cb = lb - pre - suf;
-    if (ca == 0 || cb == 0) return ca + cb;
-    const bool a_short = ca <= cb;
-    const Hap& pat = a_short ? A : B;
-    const Hap& txt = a_short ? B : A;
-    const int m = a_short ? ca : cb, n = a_short ? cb : ca;
-    if (cells && lane == 0) atomicAdd(cells, (unsigned long long)m * (unsigned long long)n);
-    const int nb = (m + 31) >> 5;
-    if (nb <= 64) return systolic_distance<1>(pat, pre, m, txt, pre, n);
-    if (nb <= 128) return systolic_distance<2>(pat, pre, m, txt, pre, n);
-    if (nb <= 256) return systolic_distance<4>(pat, pre, m, txt, pre, n);
-    if (nb <= 512) return systolic_distance<8>(pat, pre, m, txt, pre, n);
-    if (!big_scratch) { if (big_m) *big_m = m; return SVX_EDIT_BIG; }
-    return systolic_distance_big(pat, pre, m, txt, pre, n, big_scratch);
+// one wave per pair of the FULL class; pairs with more than 16384 rows are deferred to k_edit_full_big
+__global__ __launch_bounds__(256) void k_edit_full(long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
+                                                   const long long* slot_of, int32_t* ed, unsigned long long* n_big, uint32_t* big_list) {
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= count) return;
+    const uint32_t widx = list[t];
+    const PairDesc pd = desc[widx];
+    Packed P{scratch + pd.pat}, T{scratch + pd.txt};
+    const int nb = (pd.m + 31) >> 5;
+    int d;
+    if (nb <= 64) d = systolic_distance<1>(P, pd.m, T, pd.n);
+    else if (nb <= 128) d = systolic_distance<2>(P, pd.m, T, pd.n);
+    else if (nb <= 256) d = systolic_distance<4>(P, pd.m, T, pd.n);
+    else if (nb <= 512) d = systolic_distance<8>(P, pd.m, T, pd.n);
+    else { if (lane_id() == 0) { const unsigned long long i = atomicAdd(n_big, 1ull); big_list[i] = widx; } return; }
+    if (lane_id() == 0) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
 }
 
-// ---- kernels -------------------------------------------------------------------------------------------
-
-// plain string pairs (svx_edit_distance test/utility entry point)
-__global__ __launch_bounds__(256) void k_edit_plain(long long n_pairs, const uint8_t* codes, const int64_t* a_off, const int64_t* b_off,
-                                                    int32_t* out, uint32_t* scratch, long long scratch_words_per_wave) {
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= n_pairs) return;
-    const Hap A = plain_hap(codes + a_off[w], (int)(a_off[w + 1] - a_off[w]));
-    const Hap B = plain_hap(codes + b_off[w], (int)(b_off[w + 1] - b_off[w]));
-    const int d = edit_core(A, B, scratch ? scratch + (size_t)w * scratch_words_per_wave : nullptr, nullptr);
-    if (lane_id() == 0) out[w] = d;
-}
-
-// insertion-signature pairs: work item = (global signature index a, b, output slot)
-struct EditWork { uint32_t a, b; long long slot; };
-
-__global__ __launch_bounds__(256) void k_edit_pairs(long long n_work, const EditWork* work, ClusterIn in, const int64_t* g_off,
-                                                    const uint8_t* g_codes, int32_t* ed, unsigned long long* cells,
-                                                    unsigned long long* big_count, uint2* big_list) {
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= n_work) return;
-    const EditWork wk = work[w];
-    const long long s1 = in.start[wk.a], s2 = in.start[wk.b];
-    const long long ws = (s1 < s2 ? s1 : s2) - 100, we = (s1 > s2 ? s1 : s2) + 100;
-    const Hap A = make_hap(g_off, g_codes, in.contig[wk.a], s1, in.seq + in.seq_off[wk.a], (int)(in.seq_off[wk.a + 1] - in.seq_off[wk.a]), ws, we);
-    const Hap B = make_hap(g_off, g_codes, in.contig[wk.b], s2, in.seq + in.seq_off[wk.b], (int)(in.seq_off[wk.b + 1] - in.seq_off[wk.b]), ws, we);
-    int big_m = 0;
-    const int d = edit_core(A, B, nullptr, cells, &big_m);
-    if (lane_id() == 0) {
-        if (d == SVX_EDIT_BIG) { const unsigned long long i = atomicAdd(big_count, 1ull); big_list[i] = make_uint2((uint32_t)w, (uint32_t)big_m); }
-        else ed[wk.slot] = d;
-    }
-}
-
-// second pass for the (rare) pairs whose shorter core exceeds 16384 symbols
-__global__ __launch_bounds__(64) void k_edit_pairs_big(long long n_big, const uint2* big_list, const long long* scratch_off, const EditWork* work,
-                                                       ClusterIn in, const int64_t* g_off, const uint8_t* g_codes, int32_t* ed, uint32_t* scratch) {
+__global__ __launch_bounds__(64) void k_edit_full_big(long long count, const uint32_t* big_list, const long long* state_off, const uint32_t* scratch,
+                                                      const PairDesc* desc, const long long* slot_of, int32_t* ed, uint32_t* state) {
     const long long q = blockIdx.x;
-    if (q >= n_big) return;
-    const EditWork wk = work[big_list[q].x];
-    const long long s1 = in.start[wk.a], s2 = in.start[wk.b];
-    const long long ws = (s1 < s2 ? s1 : s2) - 100, we = (s1 > s2 ? s1 : s2) + 100;
-    const Hap A = make_hap(g_off, g_codes, in.contig[wk.a], s1, in.seq + in.seq_off[wk.a], (int)(in.seq_off[wk.a + 1] - in.seq_off[wk.a]), ws, we);
-    const Hap B = make_hap(g_off, g_codes, in.contig[wk.b], s2, in.seq + in.seq_off[wk.b], (int)(in.seq_off[wk.b + 1] - in.seq_off[wk.b]), ws, we);
-    const int d = edit_core(A, B, scratch + scratch_off[q], nullptr);
-    if (lane_id() == 0) ed[wk.slot] = d;
+    if (q >= count) return;
+    const uint32_t widx = big_list[q];
+    const PairDesc pd = desc[widx];
+    Packed P{scratch + pd.pat}, T{scratch + pd.txt};
+    const int d = systolic_distance_big(P, pd.m, T, pd.n, state + state_off[q]);
+    if (lane_id() == 0) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
+}
+
+__global__ void k_slots(long long n_work, PairSource src, long long* slot_of) {
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < n_work) slot_of[w] = src.slot(w);
+}
+
+// class boundaries in the sorted key array: first index whose class >= c, for c = 0..6
+__global__ void k_class_bounds(const uint64_t* keys, long long n, long long* bounds) {
+    const int c = threadIdx.x;
+    if (c > 6) return;
+    long long lo = 0, hi = n;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)(keys[mid] >> 32) < c) lo = mid + 1; else hi = mid; }
+    bounds[c] = lo;
+}
+
+// ---- host orchestration -----------------------------------------------------------------------------------------
+static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src, int32_t* ed_dev, unsigned long long* cells_dev) {
+    if (n_work <= 0) return SVX_OK;
+    if (n_work >= (1ll << 32)) return svx_fail(SVX_E_ARG, "more than 2^32 edit-distance pairs in one call", __FILE__, __LINE__, hipSuccess);
+    hipStream_t st = c->stream;
+    const int T = 256;
+    // 1. scratch sizing
+    SVXCHK(c->e_words.reserve((size_t)(n_work + 1) * 8));
+    SVXCHK(c->e_off.reserve((size_t)(n_work + 1) * 8));
+    k_pair_words<<<(unsigned)((n_work + 1 + T - 1) / T), T, 0, st>>>(n_work, src, c->e_words.as<int64_t>());
+    SVXCHK(svx_exclusive_scan_i64(c, c->e_words.as<int64_t>(), c->e_off.as<int64_t>(), n_work + 1));
+    int64_t total_words = 0;
+    HIPCHK(hipMemcpyAsync(&total_words, c->e_off.as<int64_t>() + n_work, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    SVXCHK(c->e_scratch.reserve((size_t)(total_words + 64) * 4));
+    SVXCHK(c->e_desc.reserve((size_t)n_work * sizeof(PairDesc)));
+    SVXCHK(c->e_key.reserve((size_t)n_work * 8 * 2)); SVXCHK(c->e_val.reserve((size_t)n_work * 4 * 2));
+    SVXCHK(c->e_slot.reserve((size_t)n_work * 8));
+    SVXCHK(c->e_fail.reserve((size_t)n_work * (4 + 8) + 256 + 64));
+    uint64_t* key_a = c->e_key.as<uint64_t>(); uint64_t* key_b = key_a + n_work;
+    uint32_t* val_a = c->e_val.as<uint32_t>(); uint32_t* val_b = val_a + n_work;
+    long long* slot_of = c->e_slot.as<long long>();
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(c->e_fail.as<char>());           // [0] fails, [1] big, [8..15] bounds
+    uint32_t* fail_list = reinterpret_cast<uint32_t*>(cnt + 32);
+    uint64_t* fail_key = reinterpret_cast<uint64_t*>(fail_list + ((n_work + 1) & ~1ll));
+    PairDesc* desc = c->e_desc.as<PairDesc>();
+    uint32_t* scratch = c->e_scratch.as<uint32_t>();
+    // 2. trim + pack + classify
+    k_slots<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, src, slot_of);
+    k_edit_prep<<<(unsigned)((n_work + 3) / 4), 256, 0, st>>>(n_work, src, c->e_off.as<int64_t>(), scratch, desc, key_a, val_a, ed_dev, cells_dev, c->edit_force_full ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    long long pending = n_work;
+    const uint64_t* keys_in = key_a; const uint32_t* vals_in = val_a;
+    for (int round = 0; round < 4 && pending > 0; round++) {
+        // 3. group by class (and by text length inside a class, so that the 64 pairs of a wave finish together)
+        SVXCHK(svx_sort_pairs_u64(c, keys_in, key_b, vals_in, val_b, pending, 0, 40));
+        k_class_bounds<<<1, 64, 0, st>>>(key_b, pending, reinterpret_cast<long long*>(cnt + 8));
+        HIPCHK(hipMemsetAsync(cnt, 0, 16, st));
+        long long bounds[7];
+        HIPCHK(hipMemcpyAsync(bounds, cnt + 8, 7 * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int cls = 0; cls <= 4; cls++) {
+            const long long lo = bounds[cls], cn = bounds[cls + 1] - lo;
+            if (cn <= 0) continue;
+            const unsigned grid = (unsigned)((cn + T - 1) / T);
+            switch (cls) {
+                case 0: k_edit_band<1><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+                case 1: k_edit_band<2><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+                case 2: k_edit_band<4><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+                case 3: k_edit_band<8><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+                default: k_edit_band<16><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+            }
+            HIPCHK(hipGetLastError());
+        }
+        {   // full-matrix class
+            const long long lo = bounds[5], cn = bounds[6] - lo;
+            if (cn > 0) {
+                SVXCHK(c->e_big_list.reserve((size_t)cn * 4 + 64));
+                k_edit_full<<<(unsigned)((cn + 3) / 4), 256, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
+                HIPCHK(hipGetLastError());
+            }
+        }
+        unsigned long long h[2];
+        HIPCHK(hipMemcpyAsync(h, cnt, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h[1]) {
+            // rare: shorter core > 16384 symbols.  Size the block-state scratch exactly from the core lengths.
+            const long long nbig = (long long)h[1];
+            std::vector<uint32_t> items((size_t)nbig);
+            HIPCHK(hipMemcpyAsync(items.data(), c->e_big_list.p, (size_t)nbig * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            std::vector<PairDesc> pd((size_t)nbig);
+            for (long long i = 0; i < nbig; i++) HIPCHK(hipMemcpyAsync(&pd[(size_t)i], desc + items[(size_t)i], sizeof(PairDesc), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            std::vector<long long> off((size_t)nbig + 1, 0);
+            for (long long i = 0; i < nbig; i++) off[(size_t)i + 1] = off[(size_t)i] + (((long long)pd[(size_t)i].m + 31) / 32) * 7;
+            SVXCHK(c->e_big_state.reserve((size_t)off[(size_t)nbig] * 4 + 16));
+            SVXCHK(c->e_big_off.reserve((size_t)(nbig + 1) * 8));
+            HIPCHK(hipMemcpyAsync(c->e_big_off.p, off.data(), (size_t)(nbig + 1) * 8, hipMemcpyHostToDevice, st));
+            k_edit_full_big<<<(unsigned)nbig, 64, 0, st>>>(nbig, c->e_big_list.as<uint32_t>(), c->e_big_off.as<long long>(), scratch, desc, slot_of, ed_dev,
+                                                          c->e_big_state.as<uint32_t>());
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        pending = (long long)h[0];
+        if (pending > 0) {
+            // retry list becomes the next round's input (copied, because the sort ping-pongs between key_a/key_b)
+            HIPCHK(hipMemcpyAsync(key_a, fail_key, (size_t)pending * 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(val_a, fail_list, (size_t)pending * 4, hipMemcpyDeviceToDevice, st));
+            keys_in = key_a; vals_in = val_a;
+        }
+        c->stats.n_hap_bytes += (round == 0) ? total_words * 4 : 0;
+    }
+    if (pending > 0) return svx_fail(SVX_E_STATE, "edit-distance retry loop did not converge", __FILE__, __LINE__, hipSuccess);
+    return SVX_OK;
 }
 
 int svx_edit_distance_pairs(svx_ctx* c, int64_t n_pairs, const uint8_t* codes_dev, const int64_t* a_off_dev, const int64_t* b_off_dev,
                             int32_t* out_dev) {
-    if (n_pairs <= 0) return SVX_OK;
-    // utility path: always provide scratch large enough for the longest string (sizes are read back once)
-    std::vector<int64_t> ha((size_t)n_pairs + 1), hb((size_t)n_pairs + 1);
-    HIPCHK(hipMemcpyAsync(ha.data(), a_off_dev, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(hb.data(), b_off_dev, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    int64_t mx = 0;
-    for (int64_t i = 0; i < n_pairs; i++) {
-        const int64_t la = ha[i + 1] - ha[i], lb = hb[i + 1] - hb[i];
-        const int64_t m = la < lb ? la : lb;
-        if (m > mx) mx = m;
-    }
-    uint32_t* scratch = nullptr;
-    long long words = 0;
-    if (mx > 64 * 32 * 8) {
-        words = ((mx + 31) / 32) * 7;
-        SVXCHK(c->tmp5.reserve((size_t)n_pairs * (size_t)words * 4));
-        scratch = c->tmp5.as<uint32_t>();
-    }
-    k_edit_plain<<<(unsigned)((n_pairs + 3) / 4), 256, 0, c->stream>>>(n_pairs, codes_dev, a_off_dev, b_off_dev, out_dev, scratch, words);
-    HIPCHK(hipGetLastError());
-    return SVX_OK;
+    PairSource src; memset(&src, 0, sizeof src);
+    src.plain = 1; src.codes = codes_dev; src.a_off = a_off_dev; src.b_off = b_off_dev;
+    return run_edit_pipeline(c, n_pairs, src, out_dev, nullptr);
 }
 
 // used by cluster.hip
 int svx_launch_edit_pairs(svx_ctx* c, int64_t n_work, const void* work_dev, const ClusterIn& in, int32_t* ed_dev,
                           unsigned long long* cells_dev) {
-    if (n_work <= 0) return SVX_OK;
-    hipStream_t st = c->stream;
-    SVXCHK(c->tmp4.reserve(16 + (size_t)n_work * 8));
-    unsigned long long* big_count = c->tmp4.as<unsigned long long>();
-    uint2* big_list = reinterpret_cast<uint2*>(big_count + 2);
-    HIPCHK(hipMemsetAsync(big_count, 0, 16, st));
-    k_edit_pairs<<<(unsigned)((n_work + 3) / 4), 256, 0, st>>>(n_work, (const EditWork*)work_dev, in, c->g_off_p, c->g_codes_p, ed_dev, cells_dev,
-                                                              big_count, big_list);
-    HIPCHK(hipGetLastError());
-    unsigned long long nbig = 0;
-    HIPCHK(hipMemcpyAsync(&nbig, big_count, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (nbig) {
-        // rare: shorter core > 16384 symbols.  Size the block-state scratch exactly from the recorded core lengths.
-        std::vector<uint2> items((size_t)nbig);
-        HIPCHK(hipMemcpyAsync(items.data(), big_list, (size_t)nbig * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        std::vector<long long> off((size_t)nbig + 1, 0);
-        for (size_t i = 0; i < (size_t)nbig; i++) off[i + 1] = off[i] + (((long long)items[i].y + 31) / 32) * 7;
-        SVXCHK(c->tmp5.reserve((size_t)off[nbig] * 4 + 16));
-        SVXCHK(c->tmp3.reserve((size_t)(nbig + 1) * 8));
-        HIPCHK(hipMemcpyAsync(c->tmp3.p, off.data(), (size_t)(nbig + 1) * 8, hipMemcpyHostToDevice, st));
-        k_edit_pairs_big<<<(unsigned)nbig, 64, 0, st>>>((long long)nbig, big_list, c->tmp3.as<long long>(), (const EditWork*)work_dev, in, c->g_off_p,
-                                                       c->g_codes_p, ed_dev, c->tmp5.as<uint32_t>());
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st));
-    }
-    return SVX_OK;
+    PairSource src; memset(&src, 0, sizeof src);
+    src.plain = 0; src.work = (const EditWork*)work_dev; src.in = in; src.g_off = c->g_off_p; src.g_codes = c->g_codes_p;
+    return run_edit_pipeline(c, n_work, src, ed_dev, cells_dev);
 }

@@ -145,3 +145,82 @@ def all_gather_signatures(table, device=None):
 def gather_clusters(ct, contig_rank, device=None):
     """Final candidate gather: merged ClusterTable (identical on every rank; rank 0 is the consumer)."""
     return merge_cluster_tables([_unpack_clu(b) for b in all_gather_bytes(_pack_clu(ct), device)], contig_rank)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device-resident multi-GPU step (bench.py --gpus N): everything stays in HBM, the exchange is RCCL over xGMI
+# ---------------------------------------------------------------------------------------------------------------------
+_DEV_COLS = (("type", "uint8"), ("src", "uint8"), ("aux", "uint8"), ("contig", "int32"), ("start", "int32"), ("end", "int32"),
+             ("contig2", "int32"), ("pos2", "int32"), ("read_id", "int32"))
+
+
+def _all_gather_var(t, counts, dist, torch):
+    """all-gather of 1-D device tensors with per-rank lengths `counts` -> concatenation in rank order."""
+    mx = max(max(counts), 1)
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[:t.numel()] = t
+    out = torch.empty(mx * len(counts), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * mx:r * mx + c] for r, c in enumerate(counts)])
+
+
+def device_pipeline_step(eng, params, rank, world, dev, read_id_stride=1 << 26):
+    """COLLECT already ran on this rank's records (results resident in its context).  Exchange the signature tables,
+    cluster the partitions this rank owns, gather the cluster tables.  Returns the merged ClusterTable on rank 0.
+
+    Each rank's batch lives on its own contig: contig id := rank, read ids are made globally unique by a per-rank stride."""
+    import torch
+    import torch.distributed as dist
+    n, nseq, _ = eng.collect_counts()
+    cnt = torch.tensor([n, nseq], dtype=torch.int64, device=dev)
+    allc = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(allc, cnt)
+    ns = [int(c[0].item()) for c in allc]
+    nq = [int(c[1].item()) for c in allc]
+    cols = {k: torch.empty(max(1, n), dtype=getattr(torch, dt), device=dev) for k, dt in _DEV_COLS}
+    key = torch.empty(max(1, n), dtype=torch.int64, device=dev)
+    seq_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    seq = torch.empty(max(1, nseq), dtype=torch.uint8, device=dev)
+    v = _abi.SigView()
+    v.on_device, v.n = 1, n
+    v.key = _abi.ptr(key)
+    for k, _ in _DEV_COLS:
+        setattr(v, k, _abi.ptr(cols[k]))
+    v.seq_off, v.seq = _abi.ptr(seq_off), _abi.ptr(seq)
+    import ctypes as C
+    from ._lib import _check
+    _check(eng.L.svx_collect_fetch(eng.ctx, 0, C.byref(v)), "svx_collect_fetch")
+    cols["contig"] = cols["contig"] + rank                       # this rank's contig
+    cols["contig2"] = torch.where(cols["contig2"] >= 0, cols["contig2"] + rank, cols["contig2"])
+    cols["read_id"] = cols["read_id"] + rank * read_id_stride
+    g = {k: _all_gather_var(cols[k][:n], ns, dist, torch) for k, _ in _DEV_COLS}
+    lens = (seq_off[1:] - seq_off[:-1])
+    g_len = _all_gather_var(lens, ns, dist, torch)
+    g_seq = _all_gather_var(seq[:nseq], nq, dist, torch)
+    N = sum(ns)
+    g_off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(g_len, 0, out=g_off[1:])
+    gv = _abi.SigView()
+    gv.on_device, gv.n = 1, N
+    for k, _ in _DEV_COLS:
+        setattr(gv, k, _abi.ptr(g[k] if g[k].numel() else torch.zeros(1, dtype=g[k].dtype, device=dev)))
+    gv.seq_off, gv.seq = _abi.ptr(g_off), _abi.ptr(g_seq if g_seq.numel() else torch.zeros(1, dtype=torch.uint8, device=dev))
+    contig_rank = np.arange(world, dtype=np.int32)
+    ct = eng.cluster(params, contig_rank, table=gv, source=2, shard=(rank, world))
+    return gather_clusters(ct, contig_rank, device=dev)
+
+
+def all_gather_genomes(genome, dev):
+    """Every rank ends up with the concatenation of all ranks' contigs (+ offsets): the equivalent of loading the same
+    reference FASTA on every GPU.  Untimed setup."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    n = torch.tensor([genome.numel()], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    full = _all_gather_var(genome, sizes, dist, torch)
+    off = torch.zeros(world + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(torch.tensor(sizes, dtype=torch.int64, device=dev), 0)
+    return off, full

@@ -62,6 +62,44 @@ def test_edit_distance_long_vs_oracle(eng, oracle):
     assert got == exp
 
 
+def test_edit_distance_banded_classes_vs_oracle(eng, oracle):
+    """Similar pairs with substitutions AND indels at several divergences / lengths / length differences: drives every
+    band class (32..512 diagonals), the failed-band retry and the full-matrix fallback; also the '=' symbol (code 0)."""
+    rng = random.Random(11)
+    pairs = []
+    for it in range(700):
+        la = rng.choice((10, 40, 90, 200, 400, 800, 1500, 3000))
+        a = synth.random_seq(rng, la)
+        b = list(a)
+        div = rng.choice((0.0, 0.01, 0.03, 0.08, 0.2, 0.5))
+        for _ in range(int(div * la) + rng.choice((0, 0, 1, 5))):
+            if not b:
+                break
+            p = rng.randrange(len(b))
+            r = rng.random()
+            if r < 0.4:
+                b[p] = rng.choice("ACGTN")
+            elif r < 0.7:
+                del b[p]
+            else:
+                b.insert(p, rng.choice("ACGT"))
+        b = "".join(b)
+        r = rng.random()
+        if r < 0.15:
+            b = b + synth.random_seq(rng, rng.choice((5, 40, 300)))      # length difference
+        elif r < 0.25:
+            b = synth.random_seq(rng, rng.choice((7, 33, 250))) + b
+        if it % 97 == 0:
+            a = a[:len(a) // 2] + "=" + a[len(a) // 2:]
+        if rng.random() < 0.5:
+            a, b = b, a
+        pairs.append((a, b))
+    got = eng.edit_distances(pairs)
+    exp = [oracle.edit_distance(a, b) for a, b in pairs]
+    bad = [(i, g, e, len(pairs[i][0]), len(pairs[i][1])) for i, (g, e) in enumerate(zip(got, exp)) if g != e]
+    assert not bad, bad[:10]
+
+
 def test_linkage_golden(eng):
     g = H.load("g_linkage.json.gz")
     by_t = {}
