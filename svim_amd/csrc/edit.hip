@@ -94,7 +94,13 @@ struct PairDesc {
 };
 
 #define CLS_FULL 5
+#define CLS_LANE0 6           /* 6..10: whole pattern (<= 32<<k rows) in one lane, full matrix, never fails */
+#define N_CLASSES 11
 #define MIN_MARGIN 16
+
+// secondary sort key: pairs that share a wave should cost the same (full-matrix class: rows first, then text length)
+__device__ __forceinline__ unsigned long long work_key(int cls, int m, int n);
+__device__ __forceinline__ int lane_class_for(int m) { return m <= 32 ? 0 : m <= 64 ? 1 : m <= 128 ? 2 : m <= 256 ? 3 : 4; }
 
 __device__ __forceinline__ int band_class_for(int need_w) {      // smallest class whose window keeps the needed margin after dmax is aligned to 7 (mod 8)
     const int w = need_w + 14;
@@ -110,6 +116,12 @@ __device__ __forceinline__ int need_window(int m, int n, int ub) {
     int x = (ub - (n - m)) / 2;
     if (x < 0) x = 0;
     return (n - m) + 2 * x + 1;
+}
+
+__device__ __forceinline__ unsigned long long work_key(int cls, int m, int n) {
+    const unsigned long long nn = (unsigned long long)(n > 0x3ffff ? 0x3ffff : n);
+    if (cls == CLS_FULL) return ((unsigned long long)(m > 0x3fff ? 0x3fff : m) << 18) | nn;       // systolic: rows decide the lane count
+    return nn;
 }
 
 // ---- 1. scratch sizing --------------------------------------------------------------------------------------
@@ -191,15 +203,23 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
         const int ub = (ham_l < ham_r ? ham_l : ham_r) + (pd.n - pd.m);
         pd.ub = ub;
         int cls;
-        if (zero || force_full) cls = CLS_FULL;                       // symbol '=' (code 0) is the band kernel's "never matches" filler
+        if (force_full) cls = CLS_FULL;
+        else if (zero) cls = (pd.m <= 512) ? CLS_LANE0 + lane_class_for(pd.m) : CLS_FULL;                       // symbol '=' (code 0) is the band kernel's "never matches" filler
         else {
+            // `guaranteed` cannot fail (the trivial alignments bound the distance); when that bound is useless (position jitter
+            // shifts the two cores against each other) start from a band sized for ~12 % divergence and widen on failure.
             const int guaranteed = band_class_for(need_window(pd.m, pd.n, ub));
-            const int spec = band_class_for((pd.n - pd.m) + 2 * MIN_MARGIN + 1);
-            cls = guaranteed < spec ? guaranteed : spec;
+            int guess = 2 * MIN_MARGIN;
+            if (pd.m / 8 > guess) guess = pd.m / 8;
+            int spec = band_class_for((pd.n - pd.m) + guess + 1);
+            if (spec > 4 && band_class_for((pd.n - pd.m) + 2 * MIN_MARGIN + 1) <= 4) spec = 4;      // widest band before giving up on banding
+            cls = guaranteed <= spec ? guaranteed : spec;
+            // short patterns: the whole column fits one lane (k_edit_lane), nothing to speculate about
+            if (cls > 0 && pd.m <= 512 && lane_class_for(pd.m) <= cls) cls = CLS_LANE0 + lane_class_for(pd.m);
         }
         pd.cls = cls;
         desc[w] = pd;
-        sort_key[w] = ((unsigned long long)cls << 32) | (unsigned long long)(pd.n > 0xffffff ? 0xffffff : pd.n);
+        sort_key[w] = ((unsigned long long)cls << 32) | work_key(cls, pd.m, pd.n);
         sort_val[w] = (uint32_t)w;
         if (cells) atomicAdd(cells + (w & 1023), (unsigned long long)pd.m * (unsigned long long)pd.n);      // 1024 shards: no same-address pile-up
     }
@@ -322,14 +342,90 @@ __global__ __launch_bounds__(256) void k_edit_band(long long count, const uint32
     else {
         // d is a valid alignment cost, hence an upper bound: the band it guarantees succeeds next time
         const int ub = d < pd.ub ? d : pd.ub;
-        int cls = band_class_for(need_window(m, n, ub));
-        if (cls <= pd.cls) cls = pd.cls + 1;             // never retry the same width (can only differ by the alignment slack)
+        int cls = band_class_for(need_window(m, n, ub));   // cannot fail, but d from a too-narrow band can be a gross over-estimate:
+        if (cls > pd.cls + 1) cls = pd.cls + 1;            // widen geometrically instead
+        if (cls <= pd.cls) cls = pd.cls + 1;               // never retry the same width (can only differ by the alignment slack)
         if (cls > 4) cls = CLS_FULL;
+        if (m <= 512 && lane_class_for(m) <= cls) cls = CLS_LANE0 + lane_class_for(m);
         desc[widx].ub = ub; desc[widx].cls = cls;
         const unsigned long long i = atomicAdd(n_fail, 1ull);
         fail_list[i] = widx;
-        fail_key[i] = ((unsigned long long)cls << 32) | (unsigned long long)(n > 0xffffff ? 0xffffff : n);
+        fail_key[i] = ((unsigned long long)cls << 32) | work_key(cls, m, n);
     }
+}
+
+// ---- 3b. whole pattern in one lane (m <= 32*Q), full matrix: plain multi-word Myers, 64 pairs per wave ----------
+template <int Q>
+__global__ __launch_bounds__(256) void k_edit_lane(long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
+                                                   const long long* slot_of, int32_t* ed) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < count;
+    uint32_t widx = 0;
+    PairDesc pd; pd.m = 1; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
+    if (live) { widx = list[t]; pd = desc[widx]; }
+    const int m = pd.m, n = live ? pd.n : 0;
+    const uint32_t* pat = scratch + pd.pat;
+    const uint32_t* txt = scratch + pd.txt;
+    uint32_t pv[Q], mv[Q], p0[Q], p1[Q], p2[Q], p3[Q], vm[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+        for (int wq = 0; wq < 4; wq++) {                 // 4 packed words = 32 rows
+            const int row0 = q * 32 + wq * 8;
+            const uint32_t word = (live && row0 < m) ? pat[(row0 >> 3)] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t c = (word >> (4 * k)) & 15u;
+                const int b = wq * 8 + k;
+                a0 |= (c & 1u) << b; a1 |= ((c >> 1) & 1u) << b; a2 |= ((c >> 2) & 1u) << b; a3 |= ((c >> 3) & 1u) << b;
+            }
+        }
+        const int rows = m - q * 32;
+        vm[q] = rows >= 32 ? 0xffffffffu : (rows <= 0 ? 0u : ((1u << rows) - 1u));
+        p0[q] = a0; p1[q] = a1; p2[q] = a2; p3[q] = a3;
+        pv[q] = 0xffffffffu; mv[q] = 0u;
+    }
+    const int lastq = (m - 1) >> 5;
+    const uint32_t topbit = 1u << ((m - 1) & 31);
+    int score = m;
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
+    const int txt_words = (n + 7) >> 3;
+    uint32_t tw_next = (live && txt_words > 0) ? txt[0] : 0u;
+    for (int jb = 0; jb * 8 < nmax; jb++) {
+        const uint32_t tw = tw_next;
+        tw_next = (live && jb + 1 < txt_words) ? txt[jb + 1] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = jb * 8 + k + 1;
+            if (j <= n) {
+                const uint32_t c = (tw >> (4 * k)) & 15u;
+                const uint32_t n0 = (c & 1u) - 1u, n1 = ((c >> 1) & 1u) - 1u, n2 = ((c >> 2) & 1u) - 1u, n3 = ((c >> 3) & 1u) - 1u;
+                uint32_t carry = 0, ph_in = 1u, mh_in = 0u;           // first row: horizontal delta +1
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const uint32_t eq = (p0[q] ^ n0) & (p1[q] ^ n1) & (p2[q] ^ n2) & (p3[q] ^ n3) & vm[q];
+                    const uint32_t PV = pv[q], MV = mv[q];
+                    const uint32_t xv = eq | MV;
+                    // the Q words form ONE wide bit-vector: a single adder carry chain, shifts cross the word borders
+                    const unsigned long long sum = (unsigned long long)(eq & PV) + (unsigned long long)PV + (unsigned long long)carry;
+                    carry = (uint32_t)(sum >> 32);
+                    const uint32_t xh = (((uint32_t)sum) ^ PV) | eq;
+                    uint32_t ph = MV | ~(xh | PV);
+                    uint32_t mh = PV & xh;
+                    if (q == lastq) score += (int)((ph & topbit) != 0) - (int)((mh & topbit) != 0);
+                    const uint32_t ph_out = ph >> 31, mh_out = mh >> 31;
+                    ph = (ph << 1) | ph_in; mh = (mh << 1) | mh_in;
+                    ph_in = ph_out; mh_in = mh_out;
+                    pv[q] = mh | ~(xv | ph);
+                    mv[q] = ph & xv;
+                }
+            }
+        }
+    }
+    if (live) ed[slot_of ? slot_of[widx] : (long long)widx] = score;
 }
 
 // ---- 4. full-matrix systolic kernel ----------------------------------------------------------------------------
@@ -512,10 +608,10 @@ __global__ void k_slots(long long n_work, PairSource src, long long* slot_of) {
     if (w < n_work) slot_of[w] = src.slot(w);
 }
 
-// class boundaries in the sorted key array: first index whose class >= c, for c = 0..6
+// class boundaries in the sorted key array: first index whose class >= c, for c = 0..N_CLASSES
 __global__ void k_class_bounds(const uint64_t* keys, long long n, long long* bounds) {
     const int c = threadIdx.x;
-    if (c > 6) return;
+    if (c > N_CLASSES) return;
     long long lo = 0, hi = n;
     while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)(keys[mid] >> 32) < c) lo = mid + 1; else hi = mid; }
     bounds[c] = lo;
@@ -554,13 +650,13 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     HIPCHK(hipGetLastError());
     long long pending = n_work;
     const uint64_t* keys_in = key_a; const uint32_t* vals_in = val_a;
-    for (int round = 0; round < 4 && pending > 0; round++) {
+    for (int round = 0; round < 8 && pending > 0; round++) {
         // 3. group by class (and by text length inside a class, so that the 64 pairs of a wave finish together)
         SVXCHK(svx_sort_pairs_u64(c, keys_in, key_b, vals_in, val_b, pending, 0, 40));
         k_class_bounds<<<1, 64, 0, st>>>(key_b, pending, reinterpret_cast<long long*>(cnt + 8));
         HIPCHK(hipMemsetAsync(cnt, 0, 16, st));
-        long long bounds[7];
-        HIPCHK(hipMemcpyAsync(bounds, cnt + 8, 7 * 8, hipMemcpyDeviceToHost, st));
+        long long bounds[N_CLASSES + 1];
+        HIPCHK(hipMemcpyAsync(bounds, cnt + 8, (N_CLASSES + 1) * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         for (int cls = 0; cls <= 4; cls++) {
             const long long lo = bounds[cls], cn = bounds[cls + 1] - lo;
@@ -572,6 +668,19 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                 case 2: k_edit_band<4><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
                 case 3: k_edit_band<8><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
                 default: k_edit_band<16><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+            }
+            HIPCHK(hipGetLastError());
+        }
+        for (int lc = 0; lc <= 4; lc++) {                      // whole-pattern-in-a-lane classes
+            const long long lo = bounds[CLS_LANE0 + lc], cn = bounds[CLS_LANE0 + lc + 1] - lo;
+            if (cn <= 0) continue;
+            const unsigned grid = (unsigned)((cn + T - 1) / T);
+            switch (lc) {
+                case 0: k_edit_lane<1><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
+                case 1: k_edit_lane<2><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
+                case 2: k_edit_lane<4><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
+                case 3: k_edit_lane<8><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
+                default: k_edit_lane<16><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
             }
             HIPCHK(hipGetLastError());
         }
