@@ -156,8 +156,18 @@ def main():
     scan_s = st["t_cigar_scan_ms"] * 1e-3
     scan_bytes = 32 * st["n_rec_used"] + 4 * st["n_ops"] + 16 * st["n_seg"] + 4 * st["n_seg_ops"] + 32 * st["n_sig"]
     achieved = scan_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+    # HBM traffic of that kernel from the PMC counters (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction):
+    # measured once for the default workload and committed under profiles/; null for any other workload
+    traffic = None
+    try:
+        with open(os.path.join(REPO, "profiles", "traffic_k_cigar_scan.json")) as fh:
+            tj = json.load(fh)
+        if tj.get("workload_cigar_ops") == meta["n_ops"]:
+            traffic = tj["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        traffic = None
     roofline = {"kernel": "k_cigar_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": None,
+                "frac": achieved / 8000.0, "traffic": traffic,
                 "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": st["t_cigar_scan_ms"]}
     kernels = {
         "k_cigar_scan_ms": st["t_cigar_scan_ms"], "k_segments_ms": st["t_segments_ms"], "collect_order_ms": st["t_sort_ms"],
