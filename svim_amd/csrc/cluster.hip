@@ -148,6 +148,51 @@ struct MtStream {
         pos++;
         return w;
     }
+    __device__ void refill() {
+        base += 64;
+        if (base >= 624) { twist(); base = 0; }
+        const int k = base + lane_id();
+        buf = (k < 624) ? mt_temper(s[k]) : 0u;
+        lim = (624 - base) < 64 ? (624 - base) : 64;
+        pos = 0;
+    }
+    // Consume exactly the words random.sample(range(n), 100) consumes with the pool method (n <= 1045) WITHOUT producing
+    // the sample: draw i accepts a word iff word >> (32-k) < n-i.  64 words are classified at once; the only coupling
+    // between lanes is the number of earlier accepts, resolved by a short monotone fix-point on ballots.
+    __device__ void skip_pool_sample(uint32_t n) {
+        const int lane = lane_id();
+        int i = 0;
+        while (i < 100) {
+            if (pos == lim) refill();
+            const uint32_t bound = n - (uint32_t)i;
+            const int k = 32 - __clz((int)bound);
+            // k stays valid while the bound has the same bit length: at most `cap` accepts in this round
+            const int cap = (int)(bound - (1u << (k - 1))) + 1;
+            int need = 100 - i;
+            if (cap < need) need = cap;
+            const bool valid = lane >= pos && lane < lim;
+            const unsigned long long V = __ballot(valid);
+            const uint32_t r = buf >> (32 - k);
+            unsigned long long A = __ballot(valid && r + (uint32_t)__popcll(V & lanemask_lt()) < bound);    // accepted whatever happened before
+            unsigned long long R = __ballot(valid && r >= bound);                                          // rejected whatever happened before
+            unsigned long long U = V & ~A & ~R;
+            while (U) {
+                const uint32_t a_lo = (uint32_t)__popcll(A & lanemask_lt()), a_hi = (uint32_t)__popcll((A | U) & lanemask_lt());
+                const bool inU = (U >> lane) & 1ull;
+                // signed: the upper estimate a_hi may exceed a small bound (then the word cannot be accepted)
+                const unsigned long long nA = __ballot(inU && (int)r < (int)bound - (int)a_hi), nR = __ballot(inU && (int)r >= (int)bound - (int)a_lo);
+                A |= nA; R |= nR; U &= ~(nA | nR);
+            }
+            const int c = __popcll(A);
+            if (c < need) { i += c; pos = lim; }
+            else {
+                const bool inA = (A >> lane) & 1ull;
+                const unsigned long long hit = __ballot(inA && (int)__popcll(A & lanemask_lt()) + 1 == need);
+                pos = __ffsll((long long)hit);           // one past the lane holding the need-th accepted word
+                i += need;
+            }
+        }
+    }
     __device__ uint32_t randbelow(uint32_t n) {      // Random._randbelow_with_getrandbits
         const int k = 32 - __clz((int)n);
         uint32_t r = next() >> (32 - k);
@@ -183,7 +228,7 @@ __global__ __launch_bounds__(64) void k_sample_scan(const int32_t* large_list, l
             // before the very first twist position() has no block to refer to: generate it now
             if (mt.gen == 0) { mt.twist(); mt.base = 0; mt.lim = 0; mt.pos = 0; const int k = lane; mt.buf = mt_temper(s[k]); mt.lim = 64; }
             if (lane == 0) samp_start[q] = mt.position();
-            for (int i = 0; i < 100; i++) (void)mt.randbelow(n - (uint32_t)i);
+            mt.skip_pool_sample(n);
         } else {
             if (lane == 0) samp_start[q] = -1;
             uint32_t res_a = 0, res_b = 0;

@@ -175,9 +175,9 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
         if (lane == 0) { ed[src.slot(w)] = pd.n; pd.ub = pd.n; pd.cls = -1; desc[w] = pd; sort_key[w] = 0xffull << 32; sort_val[w] = (uint32_t)w; }
         return;
     }
-    // pack the cores, count mismatches of the two trivial alignments (left- / right-justified) and look for code 0
+    // pack the cores, count mismatches of the trivial left-justified alignment and look for code 0
     uint32_t* pw = scratch + pd.pat; uint32_t* tw = scratch + pd.txt;
-    int ham_l = 0, ham_r = 0, zero = 0;
+    int ham_l = 0, zero = 0;
     for (int base = 0; base < pd.n; base += 512) {     // 64 lanes x 8 symbols
         const int i0 = base + lane * 8;
         uint32_t wt = 0, wp = 0;
@@ -190,17 +190,16 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
                     const uint32_t cp = P.at(pre + i);
                     wp |= cp << (4 * k); zero |= (cp == 0);
                     ham_l += (cp != ct);
-                    ham_r += (P.at(pre + i) != T.at(pre + (pd.n - pd.m) + i));
                 }
             }
         }
         if (i0 < pd.n) tw[i0 >> 3] = wt;
         if (i0 < pd.m) pw[i0 >> 3] = wp;
     }
-    ham_l = wave_sum_i32(ham_l); ham_r = wave_sum_i32(ham_r);
+    ham_l = wave_sum_i32(ham_l);
     zero = __any(zero);
     if (lane == 0) {
-        const int ub = (ham_l < ham_r ? ham_l : ham_r) + (pd.n - pd.m);
+        const int ub = ham_l + (pd.n - pd.m);
         pd.ub = ub;
         int cls;
         if (force_full) cls = CLS_FULL;

@@ -145,6 +145,40 @@ def test_cluster_golden_and_oracle(eng, oracle, idx):
     assert np.array_equal(ct.part_index, oc.part_index)
 
 
+def test_sampling_many_partition_sizes_vs_oracle(eng, oracle):
+    """random.sample replay: partitions of every size 101..190, around 256/512/1024 and the pool/set switch (1045/1046),
+    several per type so that the RNG stream is carried across them."""
+    rng = random.Random(5)
+    sizes = list(range(101, 191)) + [250, 255, 256, 257, 300, 511, 512, 513, 700, 1023, 1024, 1025, 1044, 1045, 1046, 1047, 2000]
+    rng.shuffle(sizes)
+    rows = []
+    pos = 10000
+    rid = 0
+    for n in sizes:
+        typ = rng.choice(("DEL", "DEL", "INV", "DUP_TAN"))
+        span = rng.choice((80, 300))
+        for k in range(n):
+            rid += 1
+            st = pos + rng.randint(-150, 150)
+            sp = span + rng.randint(-20, 20)
+            if typ == "DEL":
+                rows.append(["DEL", "chr1", st, st + sp, "cigar", "r%d" % rid])
+            elif typ == "INV":
+                rows.append(["INV", "chr1", st, st + sp, "suppl", "r%d" % rid, rng.choice(("left_fwd", "right_rev"))])
+            else:
+                rows.append(["DUP_TAN", "chr1", st, st + sp, "suppl", "r%d" % rid, 2, True])
+        pos += 5000
+    rng.shuffle(rows)
+    sigs = [H.row_sig(r) for r in rows]
+    tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(H.REFS))
+    rank = batch.contig_ranks(contigs.names)
+    p = _abi.Params.from_options(H.options({"partition_max_distance": 1000, "cluster_max_distance": 0.5, "position_distance_normalizer": 900,
+                                            "edit_distance_normalizer": 1.0}))
+    ct = eng.cluster(p, rank, table=tab)
+    oc = oracle.cluster(p, rank, table=tab)
+    assert ct.n == oc.n and ct.first_difference(oc, rtol=1e-12) is None
+
+
 def _planted_case(seed, n_reads, n_sites):
     contigs = [("chr1", 180000), ("chr2", 60000), ("chr10", 60000)]
     refs = synth.make_reference(1, contigs)
