@@ -87,8 +87,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
-    if world > 1:
+    # SVX_BENCH_FORCE_DIST=1 exercises the multi-GPU code path (RCCL exchange + sharded clustering) with any world size
+    use_dist = world > 1 or os.environ.get("SVX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from svim_amd import _abi, _lib, devsynth
@@ -99,7 +103,7 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
     eng = _lib.Engine(local_rank)
-    if world > 1:
+    if use_dist:
         from svim_amd import distributed as D
         g_off, g_all = D.all_gather_genomes(genome, dev)
         eng.set_genome(g_off, g_all, on_device=True)
@@ -111,7 +115,7 @@ def main():
 
     def step():
         eng.collect(bstruct, p, fetch=False)
-        if world > 1:
+        if use_dist:
             from svim_amd import distributed as D
             D.device_pipeline_step(eng, p, rank, world, dev)
         else:
@@ -119,7 +123,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -135,7 +139,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     st = eng.stats()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -145,7 +149,7 @@ def main():
     else:
         tot_used, tot_sig, tot_ops = st["n_rec_used"], st["n_sig"], st["n_ops"]
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
     ms_per_step = 1e3 * elapsed / args.steps
@@ -196,7 +200,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(batch, genome, p)
         out["speedup_vs_cpu_port"] = reads_per_s / world / out["cpu_baseline"]["value"]
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -47,11 +47,10 @@ def merge_cluster_tables(parts, contig_rank):
     sizes = out.size.astype(np.int64)
     out.member_off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(sizes, out=out.member_off[1:])
-    mem = np.zeros(max(1, nm), dtype=np.int32)
     so = src_off[order]
-    for i in range(n):
-        mem[out.member_off[i]:out.member_off[i + 1]] = members[so[i]:so[i] + sizes[i]]
-    out.members = mem[:nm]
+    # member j of output cluster i comes from members[so[i] + j]: one vectorised gather
+    src_idx = np.repeat(so - out.member_off[:-1], sizes) + np.arange(nm, dtype=np.int64)
+    out.members = members[src_idx].astype(np.int32) if nm else np.zeros(0, dtype=np.int32)
     out.n, out.n_members = n, nm
     out.type_count = [int((out.type == k).sum()) for k in range(6)]
     return out

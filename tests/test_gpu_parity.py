@@ -251,3 +251,44 @@ def test_dropin_api_matches_reference_golden(eng):
     # the reference's own known-answer vectors (src/tests/test_intra.py:9-22) through the drop-in name
     assert svim_amd.analyze_cigar_indel([(5, 10), (4, 20), (0, 30), (2, 40), (1, 50), (0, 30), (4, 25), (5, 15)], 30) == \
         [(30, 50, 40, "DEL"), (70, 50, 50, "INS")]
+
+
+def test_device_pipeline_step_single_rank(eng, oracle):
+    """bench.py's multi-GPU step (device-to-device fetch, RCCL all-gather of the signature tables, sharded clustering,
+    cluster gather) with a process group of one rank must reproduce the plain single-GPU result."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from svim_amd import devsynth
+    from svim_amd.distributed import device_pipeline_step
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = "cuda:0"
+        b, genome, meta = devsynth.make_batch(n_reads=6000, n50=8000, contig_len=4_000_000, n_sites=80, seed=9, device=dev)
+        o = H.options({"min_mapq": 20, "min_sv_size": 40, "max_sv_size": 100000, "segment_gap_tolerance": 10, "segment_overlap_tolerance": 5,
+                       "partition_max_distance": 1000, "position_distance_normalizer": 900, "edit_distance_normalizer": 1.0,
+                       "cluster_max_distance": 0.5, "all_bnds": False})
+        p = _abi.Params.from_options(o)
+        eng.set_genome(torch.tensor([0, genome.numel()], dtype=torch.int64, device=dev), genome, on_device=True)
+        eng.collect(b.struct(), p, fetch=False)
+        direct = eng.cluster(p, np.zeros(1, np.int32), source=0)
+        eng.collect(b.struct(), p, fetch=False)
+        merged = device_pipeline_step(eng, p, 0, 1, dev)
+        assert merged.n > 50
+        assert merged.first_difference(direct) is None
+        # and the device-generated batch agrees with the oracle (device pointers in, host tables out)
+        g = genome.cpu().numpy()
+        oracle.set_genome(np.array([0, g.size], dtype=np.int64), g)
+        hb = b.slice_records(0, b.n_rec)
+        osig, _ = oracle.collect(hb, p)
+        oc = oracle.cluster(p, np.zeros(1, np.int32), source=0)
+        assert eng.fetch_signatures(0).first_difference(osig) is None
+        assert direct.first_difference(oc, rtol=1e-12) is None
+    finally:
+        dist.destroy_process_group()
