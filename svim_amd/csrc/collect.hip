@@ -12,9 +12,11 @@
 // running (ref, read) cursors as lane-local partial sums and only falls into the cross-lane prefix scan for
 // the rare chunks that actually emit a signature.  No LDS, no MFMA (integer / indexing workload).
 #include "common.hpp"
+#include <cstdlib>
 
 enum { CNT_SIG = 0, CNT_BND = 1, CNT_USED = 2, CNT_OPS = 3, CNT_SEGOPS = 4, CNT_INS_BASES = 5, CNT_RAW = 6, CNT_OVERFLOW = 7 };
-#define RAW_SHARDS 1024      /* a single allocation counter would serialise the launch (~12 ns per same-address atomic) */
+#define RAW_SHARDS 8192      /* one private raw-output region per persistent wave: no allocation atomics at all in the scan
+                                (a single global counter serialised the launch at ~12 ns per same-address atomic) */
 
 #define KEY(slot, phase, ord) (((uint64_t)(slot) << 32) | ((uint64_t)(phase) << 30) | (uint64_t)(ord))
 
@@ -55,14 +57,25 @@ __device__ __forceinline__ void py_slice(long long a, long long b, long long len
 // Inside an item the wave streams 1 KiB per load instruction (16 B per lane) with the next chunk's load issued
 // before the current chunk is decoded (two loads in flight per wave).
 // ------------------------------------------------------------------------------------------------------
+#ifndef SVX_SCAN_NU
+#define SVX_SCAN_NU 2
+#endif
 #define MASK_REF 0x185      /* M D = X advance the reference cursor (N does not: reference quirk) */
 #define MASK_READ 0x193     /* M I S = X advance the read cursor */
 
 __device__ __forceinline__ int op_sel(int mask, int op, int l) { return l & -((mask >> op) & 1); }
 
+// only what the scan touches: fewer live SGPRs -> more resident blocks per CU (MI355X admits 8 blocks only up to 80 SGPRs)
+struct ScanArgs {
+    long long n_rec, n_seg;
+    const uint16_t* flag; const uint8_t* mapq; const int32_t* lseq; const uint32_t* seg_off; const uint64_t* cigar_off; const uint32_t* cigar;
+    const int32_t* seg_lseq; const uint64_t* seg_cigar_off; const uint32_t* seg_cigar;
+    int min_mapq, min_sv_size;
+};
+
 struct ItemMeta { unsigned long long off0, off1; int lseq; unsigned flag; int mapq; int has_seg; };
 
-__device__ __forceinline__ ItemMeta load_meta(const svx_batch& b, long long w) {
+__device__ __forceinline__ ItemMeta load_meta(const ScanArgs& b, long long w) {
     ItemMeta m;
     if (w < b.n_rec) {
         m.off0 = b.cigar_off[w]; m.off1 = b.cigar_off[w + 1]; m.lseq = b.lseq[w]; m.flag = b.flag[w]; m.mapq = b.mapq[w];
@@ -88,29 +101,41 @@ __device__ __forceinline__ uint4 load_chunk(const uint32_t* cig, unsigned long l
 }
 
 template <bool GEOM>
-__device__ __forceinline__ void scan_item(const svx_batch& b, const svx_params& p, const RawTarget& out, long long w,
+__device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& out, long long w,
                                           const ItemMeta& mt, bool need_indel, int* geom_out, unsigned long long total_ops,
-                                          unsigned long long total_seg_ops, int shard) {
+                                          unsigned long long total_seg_ops, int shard, int& n_out, uint4 (&nx)[SVX_SCAN_NU], bool has_next,
+                                          long long wn, const ItemMeta& mtn) {
     const int lane = lane_id();
     const bool is_rec = w < b.n_rec;
     const uint32_t* cig = is_rec ? b.cigar : b.seg_cigar;
     const unsigned long long tot = is_rec ? total_ops : total_seg_ops;
     const unsigned long long off0 = mt.off0, off1 = mt.off1;
-    const int min_len = p.min_sv_size;
+    // the item after this one: its first trip is requested while this item's last trip is decoded
+    const bool n_is_rec = wn < b.n_rec;
+    const uint32_t* cig_n = n_is_rec ? b.cigar : b.seg_cigar;
+    const unsigned long long tot_n = n_is_rec ? total_ops : total_seg_ops;
+    const unsigned long long a0_n = mtn.off0 & ~3ull, off1_n = has_next ? mtn.off1 : 0ull;
+    const int min_len = b.min_sv_size;
     int acc_ref = 0, acc_read = 0, acc_n = 0, acc_h = 0, acc_s = 0;
     const unsigned long long a0 = off0 & ~3ull;
     // NU consecutive 1 KiB chunks per trip: the loads of the next trip are all issued before the current one is decoded,
     // so a wave keeps NU KiB in flight (memory-level parallelism is what this kernel lives on)
-    constexpr int NU = 4;
-    uint4 nx[NU];
+    constexpr int NU = SVX_SCAN_NU;
+    if (off1 <= a0) {                                  // empty CIGAR: nothing to decode, just keep the pipeline primed
 #pragma unroll
-    for (int u = 0; u < NU; u++) nx[u] = load_chunk(cig, a0 + 256ull * u + (unsigned long long)lane * 4, off1, tot);
+        for (int u = 0; u < NU; u++) nx[u] = load_chunk(cig_n, a0_n + 256ull * u + (unsigned long long)lane * 4, off1_n, tot_n);
+    }
     for (unsigned long long kb = a0; kb < off1; kb += 256ull * NU) {
         uint4 cu[NU];
 #pragma unroll
         for (int u = 0; u < NU; u++) cu[u] = nx[u];
+        if (kb + 256ull * NU < off1) {
 #pragma unroll
-        for (int u = 0; u < NU; u++) nx[u] = load_chunk(cig, kb + 256ull * (NU + u) + (unsigned long long)lane * 4, off1, tot);
+            for (int u = 0; u < NU; u++) nx[u] = load_chunk(cig, kb + 256ull * (NU + u) + (unsigned long long)lane * 4, off1, tot);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NU; u++) nx[u] = load_chunk(cig_n, a0_n + 256ull * u + (unsigned long long)lane * 4, off1_n, tot_n);
+        }
 #pragma unroll
         for (int u = 0; u < NU; u++) {
         const unsigned long long k0 = kb + 256ull * u;
@@ -150,16 +175,14 @@ __device__ __forceinline__ void scan_item(const svx_batch& b, const svx_params& 
                 const bool e = ((unsigned)(op - 1) < 2u) && l >= min_len;
                 const unsigned long long m = __ballot(e);
                 if (m) {
-                    long long sbase = 0;
-                    if (lane == 0) sbase = (long long)atomicAdd(out.shard_counter + shard, (unsigned long long)__popcll(m));
-                    sbase = __shfl(sbase, 0, 64);
-                    const long long slot = sbase + __popcll(m & lanemask_lt());
+                    const long long slot = (long long)n_out + __popcll(m & lanemask_lt());
                     if (e && slot < out.shard_cap) {
                         RawIndel ri;
                         ri.item = (uint32_t)w; ri.opidx = (uint32_t)((k + j) - off0);
                         ri.pos_ref = base_ref + ex_ref + pr; ri.pos_read = base_read + ex_read + pq; ri.len_op = (l << 1) | (op == 2);
                         out.raw[(long long)shard * out.shard_cap + slot] = ri;
                     }
+                    n_out += __popcll(m);
                 }
                 pr += op_sel(MASK_REF, op, l); pq += op_sel(MASK_READ, op, l);
             }
@@ -205,40 +228,74 @@ __device__ __forceinline__ void scan_item(const svx_batch& b, const svx_params& 
     }
 }
 
-__global__ __launch_bounds__(256) void k_cigar_scan(svx_batch b, svx_params p, RawTarget out, int* rec_geom, int* seg_geom,
-                                                    unsigned long long total_ops, unsigned long long total_seg_ops) {
+__global__ __launch_bounds__(256) void k_cigar_scan(ScanArgs b, RawTarget out, int* rec_geom, int* seg_geom,
+                                                    unsigned long long total_ops, unsigned long long total_seg_ops, int map_mode) {
     const long long n_items = b.n_rec + b.n_seg;
     const long long n_waves = (long long)gridDim.x * 4;
     // the wave index is uniform: keep it (and everything derived from it: metadata, base pointers) in scalar registers
-    long long w = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (w >= n_items) return;
-    const int shard = (int)(w & (RAW_SHARDS - 1));
-    ItemMeta nm = load_meta(b, w);
-    for (; w < n_items; w += n_waves) {
-        const ItemMeta mt = nm;
-        if (w + n_waves < n_items) nm = load_meta(b, w + n_waves);        // prefetch the next item's metadata
+    const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int shard = (int)wave;                   // grid is capped at RAW_SHARDS waves
+    int n_out = 0;                                 // records this wave has emitted (uniform)
+    // map_mode 0: wave walks items wave, wave+W, ... ; 1: wave owns a contiguous run of items (sequential DRAM stream per wave)
+    long long w, w_end, w_step;
+    if (map_mode == 0) { w = wave; w_end = n_items; w_step = n_waves; }
+    else { const long long per = (n_items + n_waves - 1) / n_waves; w = wave * per; w_end = w + per < n_items ? w + per : n_items; w_step = 1; }
+    // first used item of this wave
+    ItemMeta mt;
+    for (;; w += w_step) {
+        if (w >= w_end) return;
+        mt = load_meta(b, w);
+        if (!(w < b.n_rec && ((mt.flag & SVX_FLAG_USED_MASK) || mt.mapq < b.min_mapq))) break;
+    }
+    uint4 nx[SVX_SCAN_NU];
+    {
         const bool is_rec = w < b.n_rec;
-        if (is_rec && ((mt.flag & SVX_FLAG_USED_MASK) || mt.mapq < p.min_mapq)) continue;
+        const uint32_t* cig = is_rec ? b.cigar : b.seg_cigar;
+        const unsigned long long tot = is_rec ? total_ops : total_seg_ops;
+#pragma unroll
+        for (int u = 0; u < SVX_SCAN_NU; u++) nx[u] = load_chunk(cig, (mt.off0 & ~3ull) + 256ull * u + (unsigned long long)lane_id() * 4, mt.off1, tot);
+    }
+    for (;;) {
+        // next used item (its metadata comes through the scalar cache)
+        long long wn = w + w_step;
+        ItemMeta mtn = mt;
+        bool has_next = false;
+        for (; wn < w_end; wn += w_step) {
+            mtn = load_meta(b, wn);
+            if (!(wn < b.n_rec && ((mtn.flag & SVX_FLAG_USED_MASK) || mtn.mapq < b.min_mapq))) { has_next = true; break; }
+        }
+        const bool is_rec = w < b.n_rec;
         const bool need_geom = is_rec ? (!(mt.flag & 2048u) && mt.has_seg) : true;
         int* geom_out = is_rec ? rec_geom + 5 * w : seg_geom + 5 * (w - b.n_rec);
-        if (need_geom) scan_item<true>(b, p, out, w, mt, is_rec, geom_out, total_ops, total_seg_ops, shard);
-        else scan_item<false>(b, p, out, w, mt, is_rec, geom_out, total_ops, total_seg_ops, shard);
+        if (need_geom) scan_item<true>(b, out, w, mt, is_rec, geom_out, total_ops, total_seg_ops, shard, n_out, nx, has_next, wn, mtn);
+        else scan_item<false>(b, out, w, mt, is_rec, geom_out, total_ops, total_seg_ops, shard, n_out, nx, has_next, wn, mtn);
+        if (!has_next) break;
+        w = wn; mt = mtn;
     }
+    if (lane_id() == 0) out.shard_counter[shard] = (unsigned long long)n_out;
 }
 
 // exclusive prefix of the per-shard counts -> dense signature slots; also freezes the total in CNT_SIG / CNT_RAW
-__global__ __launch_bounds__(RAW_SHARDS) void k_shard_prefix(const unsigned long long* shard_counter, long long shard_cap, long long* prefix,
-                                                             unsigned long long* counters) {
-    __shared__ long long s[RAW_SHARDS];
+__global__ __launch_bounds__(1024) void k_shard_prefix(const unsigned long long* shard_counter, long long shard_cap, long long* prefix,
+                                                       unsigned long long* counters) {
+    __shared__ long long s[1024];
     const int t = threadIdx.x;
-    unsigned long long c = shard_counter[t];
-    if ((long long)c > shard_cap) { atomicAdd(&counters[CNT_OVERFLOW], c - (unsigned long long)shard_cap); }
-    s[t] = (long long)c;
+    constexpr int PER = RAW_SHARDS / 1024;
+    long long loc[PER]; long long sum = 0; unsigned long long over = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        unsigned long long c = shard_counter[t * PER + k];
+        if ((long long)c > shard_cap) { over += c - (unsigned long long)shard_cap; c = (unsigned long long)shard_cap; }
+        loc[k] = sum; sum += (long long)c;
+    }
+    if (over) atomicAdd(&counters[CNT_OVERFLOW], over);
+    s[t] = sum;
     __syncthreads();
-    for (int o = 1; o < RAW_SHARDS; o <<= 1) { const long long v = (t >= o) ? s[t - o] : 0; __syncthreads(); s[t] += v; __syncthreads(); }
-    prefix[t + 1] = s[t];
-    if (t == 0) prefix[0] = 0;
-    if (t == RAW_SHARDS - 1) { counters[CNT_SIG] = (unsigned long long)s[t]; counters[CNT_RAW] = (unsigned long long)s[t]; }
+    for (int o = 1; o < 1024; o <<= 1) { const long long v = (t >= o) ? s[t - o] : 0; __syncthreads(); s[t] += v; __syncthreads(); }
+    const long long base = s[t] - sum;
+#pragma unroll
+    for (int k = 0; k < PER; k++) prefix[t * PER + k] = base + loc[k];
+    if (t == 1023) { prefix[RAW_SHARDS] = s[t]; counters[CNT_SIG] = (unsigned long long)s[t]; counters[CNT_RAW] = (unsigned long long)s[t]; }
 }
 
 // raw indel i of shard g -> signature table slot prefix[g] + i (analyze_alignment_indel, src/svim/SVIM_intra.py:33-51)
@@ -547,7 +604,7 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
     if (b.n_seg > 0) HIPCHK(hipMemcpyAsync(&tot_seg_ops, b.seg_cigar_off + b.n_seg, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     int64_t cap_sig = c->raw_sig.cap > 0 ? c->raw_sig.cap : 0, cap_bnd = c->raw_bnd.cap > 0 ? c->raw_bnd.cap : 0;
-    int64_t want_sig = (int64_t)(tot_ops / 256) + 4 * b.n_seg + 4096;
+    int64_t want_sig = (int64_t)(tot_ops / 256) + 4 * b.n_seg + 16 * (int64_t)RAW_SHARDS;      // >= 16 raw slots per wave-private region
     if (cap_sig < want_sig) cap_sig = want_sig;
     if (cap_bnd < 1024) cap_bnd = 1024;
     if (p->all_bnds && cap_bnd < want_sig) cap_bnd = want_sig;
@@ -562,13 +619,15 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
         const long long items = b.n_rec + b.n_seg;
         if (items > 0) {
             long long blocks = (items + 3) / 4;
-            static int per_cu = 0;                                         // resident 256-thread blocks per CU for this kernel
+            static int per_cu = 0, scan_map = 0;                           // resident 256-thread blocks per CU for this kernel
+            { const char* e = getenv("SVX_SCAN_MAP"); if (e) scan_map = atoi(e); const char* f = getenv("SVX_SCAN_BLOCKS"); if (f) per_cu = atoi(f); }
             if (!per_cu) {
                 int occ = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_cigar_scan, 256, 0) != hipSuccess || occ < 1) occ = 4;
                 per_cu = occ > 6 ? 6 : occ;                                // > 96 SGPRs: the hardware admits one block fewer than the API says
             }
-            const long long max_blocks = (long long)c->n_cu * per_cu;
+            long long max_blocks = (long long)c->n_cu * per_cu;
+            if (max_blocks > RAW_SHARDS / 4) max_blocks = RAW_SHARDS / 4;
             if (blocks > max_blocks) blocks = max_blocks;
             const long long shard_cap = (c->raw_sig.cap + RAW_SHARDS - 1) / RAW_SHARDS;
             SVXCHK(c->raw_indel.reserve((size_t)shard_cap * RAW_SHARDS * sizeof(RawIndel)));
@@ -577,11 +636,12 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
             long long* shard_prefix = reinterpret_cast<long long*>(shard_counter + RAW_SHARDS);
             HIPCHK(hipMemsetAsync(shard_counter, 0, RAW_SHARDS * 8, st));
             RawTarget rt{c->raw_indel.as<RawIndel>(), shard_cap, shard_counter};
-            k_cigar_scan<<<(unsigned)blocks, 256, 0, st>>>(b, *p, rt, c->rec_geom.as<int>(), c->seg_geom.as<int>(), tot_ops, tot_seg_ops);
+            ScanArgs sa{b.n_rec, b.n_seg, b.flag, b.mapq, b.lseq, b.seg_off, b.cigar_off, b.cigar, b.seg_lseq, b.seg_cigar_off, b.seg_cigar, p->min_mapq, p->min_sv_size};
+            k_cigar_scan<<<(unsigned)blocks, 256, 0, st>>>(sa, rt, c->rec_geom.as<int>(), c->seg_geom.as<int>(), tot_ops, tot_seg_ops, scan_map);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev[5], st));
             // dense slots for the raw records; the total becomes the start of the segment kernel's allocations
-            k_shard_prefix<<<1, RAW_SHARDS, 0, st>>>(shard_counter, shard_cap, shard_prefix, c->counters.as<unsigned long long>());
+            k_shard_prefix<<<1, 1024, 0, st>>>(shard_counter, shard_cap, shard_prefix, c->counters.as<unsigned long long>());
             k_emit_indels<<<dim3((unsigned)((shard_cap + 255) / 256), RAW_SHARDS), 256, 0, st>>>(b, *p, c->raw_indel.as<RawIndel>(), shard_counter, shard_cap,
                                                                                               shard_prefix, ts, tb);
             HIPCHK(hipGetLastError());
@@ -597,7 +657,7 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
         HIPCHK(hipStreamSynchronize(st));
         if ((int64_t)h_cnt[CNT_SIG] <= c->raw_sig.cap && (int64_t)h_cnt[CNT_BND] <= c->raw_bnd.cap && h_cnt[CNT_OVERFLOW] == 0) break;
         if (attempt == 2) return svx_fail(SVX_E_CAPACITY, "signature buffers", __FILE__, __LINE__, hipSuccess);
-        cap_sig = 2 * ((int64_t)h_cnt[CNT_SIG] + (int64_t)h_cnt[CNT_OVERFLOW]) + 64 * RAW_SHARDS; cap_bnd = (int64_t)h_cnt[CNT_BND] + 1024;
+        cap_sig = 2 * ((int64_t)h_cnt[CNT_SIG] + (int64_t)h_cnt[CNT_OVERFLOW]) + 64 * (int64_t)RAW_SHARDS; cap_bnd = (int64_t)h_cnt[CNT_BND] + 1024;
         if (cap_sig < 4 * c->raw_sig.cap && h_cnt[CNT_OVERFLOW]) cap_sig = 4 * c->raw_sig.cap;     // shard imbalance: grow generously
     }
     const int64_t n_sig = (int64_t)h_cnt[CNT_SIG], n_bnd = (int64_t)h_cnt[CNT_BND];
