@@ -188,6 +188,18 @@ int  svx_edit_distance(svx_ctx* ctx, int64_t n_pairs, const uint8_t* codes_host,
 int  svx_linkage_fcluster(svx_ctx* ctx, int64_t n_problems, const int32_t* n_host, const int64_t* d_off,
                           const double* d_host, double cutoff, const int64_t* label_off, int32_t* labels_out);
 
+/* ---- native BAM front-end (host side) --------------------------------------------------
+ * Replaces pysam.AlignmentFile(bam).fetch(until_eof=True) + the per-record accessors + the SA-tag string handling of
+ * src/svim/SVIM_COLLECT.py:8-41,44-85,133 for BAM inputs: multi-threaded BGZF inflate, records decoded straight into
+ * a record batch whose host arrays are owned by the handle and stay valid until the next read or close.  mode 0 = coordinate-sorted rules
+ * (:132-167), 1 = query-name-sorted rules (:96-129; a read's group is never split across batches). */
+typedef struct svx_bam svx_bam;
+int  svx_bam_open(const char* path, int n_threads /* 0 = auto */, svx_bam** out);
+void svx_bam_close(svx_bam* h);
+int  svx_bam_header(svx_bam* h, int32_t* n_ref, const char** names_nul_separated, const int32_t** lengths, const char** sort_order);
+int  svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int min_mapq, svx_batch* out, int64_t* n_out);
+int  svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** nul_separated, int64_t* blob_len);
+
 #ifdef __cplusplus
 }
 #endif

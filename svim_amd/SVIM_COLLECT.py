@@ -56,7 +56,46 @@ def _open(bam):
     return records.AlignmentFile(bam) if isinstance(bam, str) else bam
 
 
+def _is_bam_path(bam):
+    if not isinstance(bam, str):
+        return False
+    try:
+        import gzip
+        with gzip.open(bam, "rb") as fh:
+            return fh.read(4) == b"BAM\1"
+    except OSError:
+        return False
+
+
+def _run_native(path, options, mode, batch_records=2000000):
+    """BAM path: native reader (svim_amd/csrc/bamio.cpp) -> batches of svx_batch -> svx_collect, tables concatenated in
+    file order."""
+    from .bamio import NativeBam
+    from .distributed import concat_sig_tables
+    bam = NativeBam(path)
+    eng = _lib.engine()
+    p = _abi.Params.from_options(options)
+    sigs, bnds, n_rec = [], [], 0
+    while True:
+        b, n = bam.read_batch(batch_records, int(getattr(options, "min_mapq", 20)), mode)
+        if n == 0:
+            break
+        n_rec += n
+        logging.info("Processed read {0}".format(n_rec))
+        s, t = eng.collect(b, p)
+        sigs.append(s)
+        bnds.append(t)
+    names = bam.read_names()
+    refs = bam.references
+    sig = concat_sig_tables(sigs) if sigs else _abi.SigTable(0)
+    bnd = concat_sig_tables(bnds) if bnds else _abi.SigTable(0)
+    bam.close()
+    return convert.objects_from_sigtable(sig, refs, names), convert.objects_from_sigtable(bnd, refs, names)
+
+
 def _run(bam, options, mode):
+    if _is_bam_path(bam):
+        return _run_native(bam, options, mode)
     bam = _open(bam)
     hb = batch.build_batch(bam, options, mode=mode)
     logging.info("Processed read {0}".format(hb.n_rec))

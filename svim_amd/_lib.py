@@ -20,7 +20,8 @@ _ENGINES = {}
 SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream",
            "svx_collect", "svx_collect_count", "svx_collect_fetch", "svx_set_genome", "svx_cluster",
            "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_shard", "svx_cluster_fetch_part_index",
-           "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster"]
+           "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster",
+           "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names"]
 
 
 class SvxError(RuntimeError):

@@ -1,0 +1,96 @@
+"""ctypes wrapper of the native BAM front-end (svim_amd/csrc/bamio.cpp): BGZF inflate + record decode into the record
+batch, on the host, without pysam.  Needs only libsvx.so - no GPU - so it is usable (and tested) on CPU."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import SvxError, lib
+
+
+class NativeBam(object):
+    """BAM reader with the handful of pysam.AlignmentFile members SVIM's COLLECT driver uses (references, lengths,
+    get_tid/getrname, header['HD']['SO']) plus read_batch(), which yields ready-made svx_batch structs."""
+
+    def __init__(self, path, threads=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.svx_bam_open(path.encode(), C.c_int(threads), C.byref(self.h))
+        if rc != 0:
+            raise SvxError("svx_bam_open(%r) failed: %s" % (path, self.L.svx_last_error().decode()))
+        n = C.c_int32()
+        names, lens, so = C.c_char_p(), C.POINTER(C.c_int32)(), C.c_char_p()
+        blob = C.c_void_p()
+        self.L.svx_bam_header(self.h, C.byref(n), C.byref(blob), C.byref(lens), C.byref(so))
+        # names: NUL separated, n of them
+        out, p = [], blob.value
+        for _ in range(n.value):
+            s = C.string_at(p)
+            out.append(s.decode("ascii"))
+            p += len(s) + 1
+        self.references = out
+        self.lengths = [lens[i] for i in range(n.value)]
+        self.sort_order = (so.value or b"").decode("ascii")
+        self.header = {"HD": {"SO": self.sort_order}} if self.sort_order else {}
+        self._tid = {r: i for i, r in enumerate(self.references)}
+        self.filename = path
+
+    def get_tid(self, name):
+        return self._tid.get(name, -1)
+
+    def getrname(self, tid):
+        return self.references[tid]
+
+    get_reference_name = getrname
+
+    def read_batch(self, max_records, min_mapq, mode="coordinate"):
+        """-> (svx_batch struct with host pointers owned by the reader, n_records); n_records == 0 at EOF."""
+        b = _abi.Batch()
+        n = C.c_int64()
+        rc = self.L.svx_bam_read_batch(self.h, C.c_int64(max_records), C.c_int(0 if mode == "coordinate" else 1), C.c_int(min_mapq),
+                                       C.byref(b), C.byref(n))
+        if rc != 0:
+            raise SvxError("svx_bam_read_batch failed: %s" % self.L.svx_last_error().decode())
+        return b, n.value
+
+    def batch_arrays(self, b):
+        """numpy copies of a batch returned by read_batch (tests / inspection)."""
+        n, ns = b.n_rec, b.n_seg
+
+        def arr(ptr, count, dt):
+            if count == 0:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * np.dtype(dt).itemsize,)).view(dt).copy()
+        A = {}
+        for k in ("flag", "tid", "pos", "mapq", "lseq", "read_id", "order", "seg_order"):
+            A[k] = arr(getattr(b, k), n, _abi.BATCH_DTYPES[k])
+        A["cigar_off"] = arr(b.cigar_off, n + 1, np.uint64)
+        A["cigar"] = arr(b.cigar, int(A["cigar_off"][-1]) if n else 0, np.uint32)
+        A["seq_off"] = arr(b.seq_off, n + 1, np.uint64)
+        A["seq"] = arr(b.seq, int(A["seq_off"][-1]) if n else 0, np.uint8)
+        A["seg_off"] = arr(b.seg_off, n + 1, np.uint32)
+        for k in ("seg_tid", "seg_pos", "seg_rev", "seg_mapq", "seg_lseq"):
+            A[k] = arr(getattr(b, k), ns, _abi.BATCH_DTYPES[k])
+        A["seg_cigar_off"] = arr(b.seg_cigar_off, ns + 1, np.uint64)
+        A["seg_cigar"] = arr(b.seg_cigar, int(A["seg_cigar_off"][-1]) if ns else 0, np.uint32)
+        A["contig_rank"] = arr(b.contig_rank, b.n_contig, np.int32)
+        return A
+
+    def read_names(self):
+        n, blob, ln = C.c_int64(), C.c_void_p(), C.c_int64()
+        self.L.svx_bam_read_names(self.h, C.byref(n), C.byref(blob), C.byref(ln))
+        if n.value == 0:
+            return []
+        raw = C.string_at(blob, ln.value)
+        return raw[:-1].decode("ascii").split("\0")
+
+    def close(self):
+        if self.h:
+            self.L.svx_bam_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,385 @@
+// bamio.cpp - native BAM front-end: BGZF inflate (multi-threaded) + BAM record decode straight into the
+// Structure-of-Arrays record batch of include/svx.h (host memory).
+//
+// Replaces, for BAM inputs, what the reference gets from pysam/htslib on the COLLECT path:
+//   pysam.AlignmentFile(bam).fetch(until_eof=True)        src/svim/SVIM_COLLECT.py:133, src/svim/svim:91
+//   record accessors + SA tag string                      src/svim/SVIM_COLLECT.py:47-85,143-145
+//   bam_iterator query-name grouping                      src/svim/SVIM_COLLECT.py:8-41,108,113
+// Host code (string / inflate work); the numeric work on the arrays built here happens on the GPU (collect.hip).
+// SURVEY.md section 8(f) row 1.
+#include <zlib.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+#include "../../include/svx.h"
+
+extern thread_local std::string g_svx_err;
+static int bam_fail(int code, const std::string& what) { g_svx_err = what; return code; }
+
+struct svx_bam {
+    FILE* f = nullptr;
+    std::string path, sort_order, names_blob;
+    std::vector<std::string> ref_names;
+    std::vector<int32_t> ref_len, contig_rank;
+    std::unordered_map<std::string, int32_t> tid_of, read_id_of;
+    std::string read_names_blob;          // NUL-separated, id order
+    std::vector<uint64_t> read_name_off;
+    // uncompressed stream window
+    std::vector<uint8_t> buf; size_t pos = 0; bool file_eof = false;
+    int n_threads = 8;
+    // batch arrays
+    std::vector<uint16_t> flag; std::vector<int32_t> tid, bpos, lseq, read_id; std::vector<uint8_t> mapq;
+    std::vector<uint32_t> order, seg_order, seg_off, cigar, seg_cigar;
+    std::vector<uint64_t> cigar_off, seq_off, seg_cigar_off;
+    std::vector<uint8_t> seq, seg_rev, seg_mapq;
+    std::vector<int32_t> seg_tid, seg_pos, seg_lseq;
+    // per-record SA strings of the current batch (offset, length into sa_blob; length 0 = none)
+    std::string sa_blob; std::vector<uint64_t> sa_at; std::vector<uint32_t> sa_len;
+    std::vector<uint32_t> name_id_tmp;
+    int64_t total_records = 0;
+};
+
+// ---- BGZF ------------------------------------------------------------------------------------------------------------------
+struct RawBlock { std::vector<uint8_t> comp; uint32_t isize; size_t out_at; };
+
+static bool read_block(svx_bam* h, RawBlock& b) {
+    uint8_t hd[18];
+    size_t n = fread(hd, 1, 18, h->f);
+    if (n == 0) return false;
+    if (n != 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4)) throw std::string("not a BGZF block");
+    const unsigned xlen = hd[10] | (hd[11] << 8);
+    // the BC subfield is first in every BAM writer we know; be tolerant and scan the extra field
+    std::vector<uint8_t> extra(xlen);
+    memcpy(extra.data(), hd + 12, std::min<size_t>(6, xlen));
+    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, h->f) != xlen - 6) throw std::string("truncated BGZF extra field");
+    int bsize = -1;
+    for (size_t p = 0; p + 4 <= xlen;) {
+        const unsigned slen = extra[p + 2] | (extra[p + 3] << 8);
+        if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2) bsize = extra[p + 4] | (extra[p + 5] << 8);
+        p += 4 + slen;
+    }
+    if (bsize < 0) throw std::string("BGZF block without BC subfield");
+    const size_t clen = (size_t)bsize + 1 - 12 - xlen - 8;
+    b.comp.resize(clen + 8);
+    if (fread(b.comp.data(), 1, clen + 8, h->f) != clen + 8) throw std::string("truncated BGZF block");
+    b.isize = b.comp[clen + 4] | (b.comp[clen + 5] << 8) | (b.comp[clen + 6] << 16) | ((uint32_t)b.comp[clen + 7] << 24);
+    b.comp.resize(clen);
+    return true;
+}
+
+static void inflate_block(const RawBlock& b, uint8_t* out) {
+    if (b.isize == 0) return;
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) throw std::string("inflateInit2 failed");
+    zs.next_in = const_cast<Bytef*>(b.comp.data()); zs.avail_in = (uInt)b.comp.size();
+    zs.next_out = out; zs.avail_out = b.isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.avail_out != 0) throw std::string("BGZF inflate failed");
+}
+
+// make at least `need` bytes available from h->pos (false at clean EOF with nothing left)
+static bool ensure(svx_bam* h, size_t need) {
+    while (h->buf.size() - h->pos < need) {
+        if (h->file_eof) return false;
+        if (h->pos > (64u << 20)) { h->buf.erase(h->buf.begin(), h->buf.begin() + (long)h->pos); h->pos = 0; }
+        std::vector<RawBlock> blocks;
+        size_t total = 0;
+        while (blocks.size() < 1024 && total < (48u << 20)) {
+            RawBlock b;
+            if (!read_block(h, b)) { h->file_eof = true; break; }
+            b.out_at = total; total += b.isize;
+            blocks.push_back(std::move(b));
+        }
+        const size_t base = h->buf.size();
+        h->buf.resize(base + total);
+        const int T = std::max(1, std::min<int>(h->n_threads, (int)blocks.size()));
+        std::vector<std::thread> th;
+        std::vector<std::string> errs((size_t)T);
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                try { for (size_t i = (size_t)t; i < blocks.size(); i += (size_t)T) inflate_block(blocks[i], h->buf.data() + base + blocks[i].out_at); }
+                catch (const std::string& e) { errs[(size_t)t] = e; }
+            });
+        for (auto& x : th) x.join();
+        for (auto& e : errs) if (!e.empty()) throw e;
+        if (blocks.empty()) break;
+    }
+    return h->buf.size() - h->pos >= need;
+}
+
+static inline uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out) {
+    svx_bam* h = new svx_bam();
+    h->path = path;
+    h->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    h->f = fopen(path, "rb");
+    if (!h->f) { delete h; return bam_fail(SVX_E_ARG, std::string("cannot open ") + path); }
+    try {
+        if (!ensure(h, 12) || memcmp(h->buf.data(), "BAM\1", 4) != 0) throw std::string("not a BAM file");
+        const uint32_t l_text = rd32(h->buf.data() + 4);
+        if (!ensure(h, 12 + l_text)) throw std::string("truncated BAM header");
+        std::string text((const char*)h->buf.data() + 8, l_text);
+        h->pos = 8 + l_text;
+        // @HD SO:
+        const size_t hd = text.find("@HD");
+        if (hd != std::string::npos) {
+            const size_t eol = text.find('\n', hd);
+            const std::string line = text.substr(hd, eol == std::string::npos ? std::string::npos : eol - hd);
+            const size_t so = line.find("\tSO:");
+            if (so != std::string::npos) { size_t e = line.find('\t', so + 4); h->sort_order = line.substr(so + 4, e == std::string::npos ? std::string::npos : e - so - 4); }
+        }
+        const uint32_t n_ref = rd32(h->buf.data() + h->pos); h->pos += 4;
+        for (uint32_t i = 0; i < n_ref; i++) {
+            if (!ensure(h, 4)) throw std::string("truncated BAM reference list");
+            const uint32_t l_name = rd32(h->buf.data() + h->pos); h->pos += 4;
+            if (!ensure(h, l_name + 4)) throw std::string("truncated BAM reference list");
+            std::string nm((const char*)h->buf.data() + h->pos, l_name ? l_name - 1 : 0); h->pos += l_name;
+            h->ref_len.push_back((int32_t)rd32(h->buf.data() + h->pos)); h->pos += 4;
+            h->tid_of.emplace(nm, (int32_t)i);
+            h->names_blob += nm; h->names_blob.push_back('\0');
+            h->ref_names.push_back(std::move(nm));
+        }
+        // rank of each contig NAME in Python str order (bytewise for ASCII names)
+        std::vector<int32_t> idx(n_ref);
+        for (uint32_t i = 0; i < n_ref; i++) idx[i] = (int32_t)i;
+        std::sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return h->ref_names[(size_t)a] < h->ref_names[(size_t)b]; });
+        h->contig_rank.assign(n_ref ? n_ref : 1, 0);
+        for (uint32_t r = 0; r < n_ref; r++) h->contig_rank[(size_t)idx[r]] = (int32_t)r;
+    } catch (const std::string& e) { fclose(h->f); delete h; return bam_fail(SVX_E_ARG, e); }
+    *out = h;
+    return SVX_OK;
+}
+
+extern "C" void svx_bam_close(svx_bam* h) {
+    if (!h) return;
+    if (h->f) fclose(h->f);
+    delete h;
+}
+
+extern "C" int svx_bam_header(svx_bam* h, int32_t* n_ref, const char** names_blob, const int32_t** lengths, const char** sort_order) {
+    *n_ref = (int32_t)h->ref_names.size(); *names_blob = h->names_blob.c_str(); *lengths = h->ref_len.data(); *sort_order = h->sort_order.c_str();
+    return SVX_OK;
+}
+
+static bool parse_int(const char* s, size_t n, long long& v) {
+    if (n == 0) return false;
+    size_t i = 0; bool neg = false;
+    if (s[0] == '-' || s[0] == '+') { neg = s[0] == '-'; i = 1; if (n == 1) return false; }
+    long long x = 0;
+    for (; i < n; i++) { if (s[i] < '0' || s[i] > '9') return false; x = x * 10 + (s[i] - '0'); if (x > (1ll << 40)) return false; }
+    v = neg ? -x : x;
+    return true;
+}
+
+// SA tag -> segment rows (src/svim/SVIM_COLLECT.py:55-85): 6-field check, pos-1, strand, mapq overflow -> 0
+static int append_sa(svx_bam* h, const char* sa, size_t len, int32_t primary_lseq) {
+    size_t p = 0;
+    while (p < len) {
+        size_t e = p; while (e < len && sa[e] != ';') e++;
+        if (e > p) {
+            size_t fs[7]; int nf = 0; fs[0] = p;
+            for (size_t i = p; i < e; i++) if (sa[i] == ',') { if (nf < 6) fs[++nf] = i + 1; else { nf++; } }
+            if (nf == 5) {
+                fs[6] = e + 1;
+                auto fld = [&](int k, const char*& s, size_t& n) { s = sa + fs[k]; n = fs[k + 1] - 1 - fs[k]; };
+                const char* s; size_t n; long long pos, mq, nm;
+                fld(0, s, n); const std::string rname(s, n);
+                fld(1, s, n); if (!parse_int(s, n, pos)) return bam_fail(SVX_E_ARG, "malformed SA tag (position)");
+                fld(2, s, n); const bool rev = !(n == 1 && s[0] == '+');
+                const char* cs; size_t cn; fld(3, cs, cn);
+                fld(4, s, n); if (!parse_int(s, n, mq)) return bam_fail(SVX_E_ARG, "malformed SA tag (mapq)");
+                fld(5, s, n); if (!parse_int(s, n, nm)) return bam_fail(SVX_E_ARG, "malformed SA tag (NM)");
+                if (mq < 0 || mq > 255) mq = 0;
+                auto it = h->tid_of.find(rname);
+                h->seg_tid.push_back(it == h->tid_of.end() ? -1 : it->second);
+                h->seg_pos.push_back((int32_t)(pos - 1)); h->seg_rev.push_back(rev ? 1 : 0); h->seg_mapq.push_back((uint8_t)mq);
+                h->seg_lseq.push_back(primary_lseq);
+                long long num = 0; bool have = false;
+                if (!(cn == 1 && cs[0] == '*')) {
+                    for (size_t i = 0; i < cn; i++) {
+                        const char ch = cs[i];
+                        if (ch >= '0' && ch <= '9') { num = num * 10 + (ch - '0'); have = true; }
+                        else {
+                            const char* ops = "MIDNSHP=XB"; const char* q = strchr(ops, ch);
+                            if (!q || !have) return bam_fail(SVX_E_ARG, "malformed CIGAR in SA tag");
+                            h->seg_cigar.push_back((uint32_t)(num << 4) | (uint32_t)(q - ops)); num = 0; have = false;
+                        }
+                    }
+                    if (have) return bam_fail(SVX_E_ARG, "malformed CIGAR in SA tag");
+                }
+                h->seg_cigar_off.push_back(h->seg_cigar.size());
+            } else {
+                fprintf(stderr, "WARNING: SA tag does not consist of 6 fields. This could be a sign of invalid characters "
+                                "(e.g. commas or semicolons) in a chromosome name of the reference genome.\n");
+            }
+        }
+        p = e + 1;
+    }
+    return SVX_OK;
+}
+
+// next record -> appended to the batch arrays; returns 1 = ok, 0 = EOF
+static int parse_record(svx_bam* h) {
+    if (!ensure(h, 4)) return 0;
+    const uint32_t bs = rd32(h->buf.data() + h->pos);
+    if (!ensure(h, 4 + (size_t)bs)) throw std::string("truncated BAM record");
+    const uint8_t* r = h->buf.data() + h->pos + 4;
+    const uint8_t* end = r + bs;
+    h->pos += 4 + (size_t)bs;
+    const int32_t tid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
+    const unsigned l_name = r[8], mq = r[9];
+    unsigned n_cig = rd16(r + 12); const unsigned flag = rd16(r + 14);
+    const uint32_t l_seq = rd32(r + 16);
+    const uint8_t* q = r + 32;
+    const std::string name((const char*)q, l_name ? l_name - 1 : 0);
+    q += l_name;
+    const uint8_t* cig = q; q += 4 * (size_t)n_cig;
+    const uint8_t* sq = q; q += (l_seq + 1) / 2;
+    q += l_seq;
+    // aux: SA (Z) and CG (B,I)
+    const char* sa = nullptr; size_t sa_n = 0; const uint8_t* cg = nullptr; uint32_t cg_n = 0;
+    while (q + 3 <= end) {
+        const char t0 = (char)q[0], t1 = (char)q[1], ty = (char)q[2]; q += 3;
+        size_t sz = 0;
+        switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': { const uint8_t* z = (const uint8_t*)memchr(q, 0, (size_t)(end - q)); if (!z) throw std::string("unterminated aux string");
+                if (t0 == 'S' && t1 == 'A' && ty == 'Z') { sa = (const char*)q; sa_n = (size_t)(z - q); } sz = (size_t)(z - q) + 1; break; }
+            case 'B': { const char sub = (char)q[0]; const uint32_t cnt = rd32(q + 1); const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                if (t0 == 'C' && t1 == 'G' && sub == 'I') { cg = q + 5; cg_n = cnt; } sz = 5 + es * cnt; break; }
+            default: throw std::string("unknown BAM aux type");
+        }
+        q += sz;
+    }
+    // long CIGARs (> 65535 ops) live in CG:B,I behind a <l_seq>S<ref_len>N placeholder
+    if (cg && n_cig == 2 && (rd32(cig) & 15) == 4 && (rd32(cig) >> 4) == l_seq && (rd32(cig + 4) & 15) == 3) { cig = cg; n_cig = cg_n; }
+    auto it = h->read_id_of.find(name);
+    int32_t rid;
+    if (it == h->read_id_of.end()) {
+        rid = (int32_t)h->read_name_off.size();
+        h->read_id_of.emplace(name, rid);
+        h->read_name_off.push_back(h->read_names_blob.size());
+        h->read_names_blob += name; h->read_names_blob.push_back('\0');
+    } else rid = it->second;
+    h->flag.push_back((uint16_t)(flag & 0x0fff)); h->tid.push_back(tid); h->bpos.push_back(pos); h->mapq.push_back((uint8_t)mq);
+    h->lseq.push_back((int32_t)l_seq); h->read_id.push_back(rid);
+    const size_t c0 = h->cigar.size();
+    h->cigar.resize(c0 + n_cig);
+    for (unsigned i = 0; i < n_cig; i++) h->cigar[c0 + i] = rd32(cig + 4 * (size_t)i);
+    h->cigar_off.push_back(h->cigar.size());
+    h->seq.insert(h->seq.end(), sq, sq + (l_seq + 1) / 2);
+    h->seq_off.push_back(h->seq.size());
+    h->sa_at.push_back(h->sa_blob.size()); h->sa_len.push_back((uint32_t)sa_n);
+    if (sa_n) h->sa_blob.append(sa, sa_n);
+    return 1;
+}
+
+static void clear_batch(svx_bam* h) {
+    h->flag.clear(); h->tid.clear(); h->bpos.clear(); h->mapq.clear(); h->lseq.clear(); h->read_id.clear(); h->order.clear(); h->seg_order.clear();
+    h->seg_off.clear(); h->cigar.clear(); h->seg_cigar.clear(); h->cigar_off.assign(1, 0); h->seq_off.assign(1, 0); h->seg_cigar_off.assign(1, 0);
+    h->seq.clear(); h->seg_rev.clear(); h->seg_mapq.clear(); h->seg_tid.clear(); h->seg_pos.clear(); h->seg_lseq.clear();
+    h->sa_blob.clear(); h->sa_at.clear(); h->sa_len.clear();
+}
+
+// Read up to max_records records (query-name mode: never splits a read's group) and lay them out as an svx_batch whose
+// arrays stay valid until the next call.  *n_out = 0 at end of file.  mode 0 = coordinate-sorted rules
+// (src/svim/SVIM_COLLECT.py:132-167), 1 = query-name-sorted rules (:96-129).
+extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int min_mapq, svx_batch* out, int64_t* n_out) {
+    try {
+        clear_batch(h);
+        int64_t n = 0;
+        while (n < max_records) { if (!parse_record(h)) break; n++; }
+        if (mode == 1 && n == max_records) {
+            // finish the current read group: keep reading while the name does not change (peek = parse, names are interned)
+            for (;;) {
+                const size_t save_pos = h->pos;
+                if (!ensure(h, 4)) break;
+                const uint32_t bs = rd32(h->buf.data() + h->pos);
+                if (!ensure(h, 4 + (size_t)bs)) throw std::string("truncated BAM record");
+                const uint8_t* r = h->buf.data() + h->pos + 4;
+                const std::string name((const char*)r + 32, r[8] ? r[8] - 1 : 0);
+                auto it = h->read_id_of.find(name);
+                if (it == h->read_id_of.end() || it->second != h->read_id[(size_t)n - 1]) { h->pos = save_pos; break; }
+                parse_record(h); n++;
+            }
+        }
+        *n_out = n;
+        h->order.assign((size_t)n, 0); h->seg_order.assign((size_t)n, 0); h->seg_off.assign((size_t)n + 1, 0);
+        if (mode == 0) {
+            for (int64_t i = 0; i < n; i++) {
+                h->order[(size_t)i] = (uint32_t)(2 * i); h->seg_order[(size_t)i] = (uint32_t)(2 * i + 1);
+                h->seg_off[(size_t)i] = (uint32_t)h->seg_tid.size();
+                const unsigned f = h->flag[(size_t)i];
+                if ((f & (4u | 256u | 2048u)) || (int)h->mapq[(size_t)i] < min_mapq || !h->sa_len[(size_t)i]) continue;
+                h->flag[(size_t)i] |= SVX_FLAG_SA;
+                const int rc = append_sa(h, h->sa_blob.data() + h->sa_at[(size_t)i], h->sa_len[(size_t)i], h->lseq[(size_t)i]);
+                if (rc != SVX_OK) return rc;
+            }
+            h->seg_off[(size_t)n] = (uint32_t)h->seg_tid.size();
+        } else {
+            uint32_t slot = 0;
+            int64_t i = 0;
+            while (i < n) {
+                int64_t j = i;
+                while (j < n && h->read_id[(size_t)j] == h->read_id[(size_t)i]) j++;
+                std::vector<int64_t> prim, sup;
+                for (int64_t k = i; k < j; k++) { const unsigned f = h->flag[(size_t)k]; if (f & 256u) continue; if (f & 2048u) sup.push_back(k); else prim.push_back(k); }
+                const bool ok = prim.size() == 1 && !(h->flag[(size_t)prim[0]] & 4u) && (int)h->mapq[(size_t)prim[0]] >= min_mapq;
+                for (int64_t k = i; k < j; k++) { h->flag[(size_t)k] |= SVX_FLAG_SKIP; h->seg_off[(size_t)k] = (uint32_t)h->seg_tid.size(); }
+                if (ok) {
+                    const int64_t p = prim[0];
+                    // segment rows belong to the primary: the offsets of the records after it inside the group move past them
+                    std::vector<int64_t> good;
+                    for (int64_t k : sup) if (!(h->flag[(size_t)k] & 4u) && (int)h->mapq[(size_t)k] >= min_mapq) good.push_back(k);
+                    h->flag[(size_t)p] &= (uint16_t)~SVX_FLAG_SKIP;
+                    h->order[(size_t)p] = slot;
+                    for (int64_t k = i; k <= p; k++) h->seg_off[(size_t)k] = (uint32_t)h->seg_tid.size();
+                    for (size_t qn = 0; qn < good.size(); qn++) {
+                        const int64_t k = good[qn];
+                        h->flag[(size_t)k] &= (uint16_t)~SVX_FLAG_SKIP;
+                        h->order[(size_t)k] = slot + 1 + (uint32_t)qn;
+                        h->seg_tid.push_back(h->tid[(size_t)k]); h->seg_pos.push_back(h->bpos[(size_t)k]);
+                        h->seg_rev.push_back((h->flag[(size_t)k] & 16u) ? 1 : 0); h->seg_mapq.push_back(h->mapq[(size_t)k]);
+                        h->seg_lseq.push_back(h->lseq[(size_t)k]);
+                        for (uint64_t c = h->cigar_off[(size_t)k]; c < h->cigar_off[(size_t)k + 1]; c++) h->seg_cigar.push_back(h->cigar[(size_t)c]);
+                        h->seg_cigar_off.push_back(h->seg_cigar.size());
+                    }
+                    for (int64_t k = p + 1; k < j; k++) h->seg_off[(size_t)k] = (uint32_t)h->seg_tid.size();
+                    h->seg_order[(size_t)p] = slot + 1 + (uint32_t)good.size();
+                    slot += (uint32_t)good.size() + 2;
+                }
+                i = j;
+            }
+            h->seg_off[(size_t)n] = (uint32_t)h->seg_tid.size();
+        }
+        // never hand out null pointers for empty arrays
+        auto pad = [](auto& v) { if (v.empty()) v.resize(1); };
+        pad(h->cigar); pad(h->seq); pad(h->seg_tid); pad(h->seg_pos); pad(h->seg_rev); pad(h->seg_mapq); pad(h->seg_lseq); pad(h->seg_cigar);
+        pad(h->flag); pad(h->tid); pad(h->bpos); pad(h->mapq); pad(h->lseq); pad(h->read_id); pad(h->order); pad(h->seg_order);
+        memset(out, 0, sizeof *out);
+        out->on_device = 0; out->n_rec = n; out->flag = h->flag.data(); out->tid = h->tid.data(); out->pos = h->bpos.data(); out->mapq = h->mapq.data();
+        out->lseq = h->lseq.data(); out->read_id = h->read_id.data(); out->order = h->order.data(); out->seg_order = h->seg_order.data();
+        out->cigar_off = h->cigar_off.data(); out->cigar = h->cigar.data(); out->seq_off = h->seq_off.data(); out->seq = h->seq.data();
+        out->seg_off = h->seg_off.data(); out->n_seg = (int64_t)h->seg_cigar_off.size() - 1; out->seg_tid = h->seg_tid.data(); out->seg_pos = h->seg_pos.data();
+        out->seg_rev = h->seg_rev.data(); out->seg_mapq = h->seg_mapq.data(); out->seg_lseq = h->seg_lseq.data(); out->seg_cigar_off = h->seg_cigar_off.data();
+        out->seg_cigar = h->seg_cigar.data(); out->n_contig = (int32_t)h->ref_names.size(); out->contig_rank = h->contig_rank.data();
+        h->total_records += n;
+    } catch (const std::string& e) { return bam_fail(SVX_E_ARG, e); }
+    return SVX_OK;
+}
+
+// read names interned so far: NUL-separated blob in id order
+extern "C" int svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** blob, int64_t* blob_len) {
+    *n_names = (int64_t)h->read_name_off.size(); *blob = h->read_names_blob.data(); *blob_len = (int64_t)h->read_names_blob.size();
+    return SVX_OK;
+}

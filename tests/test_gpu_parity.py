@@ -292,3 +292,25 @@ def test_device_pipeline_step_single_rank(eng, oracle):
         assert direct.first_difference(oc, rtol=1e-12) is None
     finally:
         dist.destroy_process_group()
+
+
+def test_bam_path_native_reader_route(eng, tmp_path):
+    """analyze_alignment_file_*(path_to_bam, options): C++ BAM front-end -> batches -> svx_collect must return the same
+    objects as the Python-reader route on the same records (both sort modes, several batches)."""
+    import svim_amd
+    from svim_amd import SVIM_COLLECT
+    g = H.load("g2_collect.json.gz")
+    for mode, fn in (("coordinate", svim_amd.analyze_alignment_file_coordsorted), ("queryname", svim_amd.analyze_alignment_file_querysorted)):
+        case = [c for c in g["cases"] if c["name"] == "fuzzB" and c["mode"] == mode and c["options"]["all_bnds"]][0]
+        text = [c for c in g["cases"] if c["name"] == "fuzzB" and c["mode"] == mode and c.get("sam")][0]["sam"]
+        bam = records.AlignmentFile(text=text)
+        recs = list(bam.fetch(until_eof=True))
+        path = str(tmp_path / ("%s.bam" % mode))
+        records.write_bam(path, bam.references, bam.lengths, recs, sort_order=mode)
+        o = H.options(case["options"])
+        sigs, bnds = fn(path, o)
+        assert [H.sig_row(s) for s in sigs] == case["signatures"]
+        assert [H.sig_row(s) for s in bnds] == case["bnds"]
+        sigs2, bnds2 = SVIM_COLLECT._run_native(path, o, mode, batch_records=41)
+        assert [H.sig_row(s) for s in sigs2] == case["signatures"]
+        assert [H.sig_row(s) for s in bnds2] == case["bnds"]

@@ -174,3 +174,54 @@ def test_shard_merge_equals_unsharded(oracle):
         merged = merge_cluster_tables(parts, rank)
         assert merged.first_difference(full) is None
     oracle.cluster(p, rank, table=tab, shard=(0, 1))
+
+
+@pytest.mark.parametrize("mode", ["coordinate", "queryname"])
+def test_native_bam_reader_matches_python_batcher(tmp_path, mode):
+    """The C++ BAM front-end (BGZF inflate + record decode + SA / grouping rules) builds the same record batch as the
+    Python reader + batcher, field by field; also when the file is consumed in several batches."""
+    from svim_amd.bamio import NativeBam
+    refs, lens = ["chr1", "chr2", "chr10"], [180000, 60000, 60000]
+    recs = synth.fuzz_split_reads(21, 120, refs, lens)
+    recs += synth.planted_reads(22, 60, synth.make_reference(1, list(zip(refs, lens))), refs, lens, n_sites=10)
+    if mode == "coordinate":
+        recs = synth.coordinate_sort(recs)
+    else:
+        # keep each read's records together
+        order = {}
+        for a in recs:
+            order.setdefault(a.query_name, len(order))
+        recs = sorted(recs, key=lambda a: order[a.query_name])
+    path = str(tmp_path / "t.bam")
+    records.write_bam(path, refs, lens, recs, sort_order=mode)
+    o = H.options({"min_mapq": 20})
+    hb = batch.build_batch(records.AlignmentFile(path), o, mode=mode)
+    nb = NativeBam(path, threads=3)
+    assert nb.references == refs and nb.lengths == lens and nb.sort_order == mode
+    b, n = nb.read_batch(1 << 30, 20, mode)
+    assert n == hb.n_rec and b.n_seg == hb.n_seg
+    A = nb.batch_arrays(b)
+    for k in _abi.BATCH_DTYPES:
+        exp = hb.arrays[k]
+        got = A[k]
+        assert np.array_equal(got, exp[:got.size]), k
+    assert nb.read_names() == hb.read_names
+    b2, n2 = nb.read_batch(10, 20, mode)
+    assert n2 == 0
+    nb.close()
+    # several batches: concatenation of the per-batch records is the file
+    nb = NativeBam(path, threads=2)
+    tot, flags = 0, []
+    while True:
+        b, n = nb.read_batch(37, 20, mode)
+        if n == 0:
+            break
+        A = nb.batch_arrays(b)
+        flags.append(A["flag"] & 0x0fff)
+        tot += n
+        if mode == "queryname":        # a read is never split across batches
+            ids = A["read_id"]
+            assert len(set(ids.tolist())) == len([1 for i in range(len(ids)) if i == 0 or ids[i] != ids[i - 1]])
+    assert tot == hb.n_rec
+    assert np.array_equal(np.concatenate(flags), hb.arrays["flag"] & 0x0fff)
+    nb.close()
