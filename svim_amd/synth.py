@@ -17,7 +17,7 @@ def revcomp(s):
 
 
 def random_seq(rng, n):
-    return "".join(rng.choice("ACGT") for _ in range(n))
+    return "".join(rng.choices("ACGT", k=n))
 
 
 def make_reference(seed, contigs):
@@ -25,7 +25,7 @@ def make_reference(seed, contigs):
     rng = random.Random(seed)
     out = {}
     for name, length in contigs:
-        s = [rng.choice("ACGT") for _ in range(length)]
+        s = rng.choices("ACGT", k=length)
         # sprinkle lower-case and N to exercise .upper() / non-ACGT symbols
         for _ in range(max(1, length // 20000)):
             p = rng.randrange(0, max(1, length - 50))

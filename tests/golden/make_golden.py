@@ -490,6 +490,38 @@ def gen_edit():
                                               "returns at src/svim/SVIM_clustering.py:45 (edlib not installed; unique by mathematics)"})
 
 
+def gen_c1():
+    """BASELINE.json configs[0]: 10k-read synthetic 1-contig input, DEL/INS only, through the reference's CPU path
+    (analyze_alignment_file_coordsorted + cluster_sv_signatures), timed.  The reads are regenerated from the seed by the
+    tests (svim_amd.synth is deterministic); only the reference's outputs are stored."""
+    import time
+    contigs = [("chr1", 2000000)]
+    refs = synth.make_reference(7, contigs)
+    recs = synth.coordinate_sort(synth.planted_reads(8, 10000, refs, ["chr1"], [2000000], n_sites=300, types=("DEL", "INS"),
+                                                     read_len=(1000, 6000)))
+    fa = os.path.join(HERE, "_c1.fa")
+    synth.write_fasta(fa, refs, lower_every=0)
+    text = synth.sam_text(["chr1"], [2000000], recs)
+    o = options(genome=fa)
+    bam = records.AlignmentFile(text=text)
+    t0 = time.perf_counter()
+    sigs, bnds = SVIM_COLLECT.analyze_alignment_file_coordsorted(bam, o)
+    t1 = time.perf_counter()
+    res = SVIM_CLUSTER.cluster_sv_signatures(sigs, o)
+    t2 = time.perf_counter()
+    os.remove(fa)
+    n_ops = sum(len(a.cigartuples) for a in recs)
+    print("C1: %d records, %d ops, %d signatures, collect %.2fs cluster %.2fs" % (len(recs), n_ops, len(sigs), t1 - t0, t2 - t1))
+    dump("g_c1.json.gz", {"generator": "synth.planted_reads(8, 10000, make_reference(7, [('chr1', 2000000)]), ['chr1'], [2000000], n_sites=300, "
+                                       "types=('DEL','INS'), read_len=(1000,6000)) coordinate-sorted",
+                          "n_records": len(recs), "n_ops": n_ops, "options": opt_dict(options()),
+                          "signatures": [sig_row(s) for s in sigs], "clusters": cluster_rows(res, sigs),
+                          "reference_seconds": {"collect": t1 - t0, "cluster": t2 - t1,
+                                                "note": "reference Python functions in the build container, 1 core, pysam/edlib stubbed "
+                                                        "(edlib = pure-Python bit-vector Levenshtein, so cluster time is an upper bound)"},
+                          "source": "svim.SVIM_COLLECT.analyze_alignment_file_coordsorted + svim.SVIM_CLUSTER.cluster_sv_signatures"})
+
+
 def main():
     contigs = [("chr1", 180000), ("chr2", 60000), ("chr10", 60000)]   # tid order != Python string order
     refs = synth.make_reference(1, contigs)
@@ -506,6 +538,7 @@ def main():
     gen_linkage()
     gen_rng()
     gen_edit()
+    gen_c1()
 
 
 if __name__ == "__main__":

@@ -120,3 +120,19 @@ def sam_case_batch(case, collect_golden):
     o = options(case["options"])
     hb = batch.build_batch(bam, o, mode=case["mode"])
     return bam, hb, o
+
+
+_C1 = {}
+
+
+def c1_case():
+    """BASELINE.json configs[0] input regenerated from its seed (cached per process): (golden, refs, recs)."""
+    if not _C1:
+        from svim_amd import synth
+        g = load("g_c1.json.gz")
+        refs = synth.make_reference(7, [("chr1", 2000000)])
+        recs = synth.coordinate_sort(synth.planted_reads(8, 10000, refs, ["chr1"], [2000000], n_sites=300, types=("DEL", "INS"),
+                                                         read_len=(1000, 6000)))
+        assert len(recs) == g["n_records"] and sum(len(a.cigartuples) for a in recs) == g["n_ops"]
+        _C1.update(g=g, refs=refs, recs=recs)
+    return _C1["g"], _C1["refs"], _C1["recs"]

@@ -314,3 +314,30 @@ def test_bam_path_native_reader_route(eng, tmp_path):
         sigs2, bnds2 = SVIM_COLLECT._run_native(path, o, mode, batch_records=41)
         assert [H.sig_row(s) for s in sigs2] == case["signatures"]
         assert [H.sig_row(s) for s in bnds2] == case["bnds"]
+
+
+def test_c1_config0_through_bam_file(eng, tmp_path):
+    """BASELINE.json configs[0] end to end through the drop-in entry points: BAM file on disk -> native reader ->
+    analyze_alignment_file_coordsorted -> cluster_sv_signatures (genome from a FASTA file) == the reference's output."""
+    import svim_amd
+    g, refs, recs = H.c1_case()
+    path = str(tmp_path / "c1.bam")
+    records.write_bam(path, ["chr1"], [2000000], recs)
+    fa = str(tmp_path / "c1.fa")
+    synth.write_fasta(fa, refs)
+    o = H.options(g["options"])
+    o.genome = fa
+    sigs, bnds = svim_amd.analyze_alignment_file_coordsorted(path, o)
+    assert [H.sig_row(s) for s in sigs] == g["signatures"]
+    res = svim_amd.cluster_sv_signatures(sigs, o)
+    idx = {id(s): i for i, s in enumerate(sigs)}
+    got = []
+    for k, lst in enumerate(res):
+        rows = []
+        for c in lst:
+            mem = [idx[id(m)] for m in c.members]
+            rows.append([c.contig, c.start, c.end, c.score, c.size, c.std_span, c.std_pos, mem] if k < 3 else
+                        [c.source_contig, c.source_start, c.source_end, c.dest_contig, c.dest_start, c.dest_end, c.score, c.size, c.std_span,
+                         c.std_pos, mem])
+        got.append(rows)
+    H.compare_cluster_rows(got, g["clusters"])

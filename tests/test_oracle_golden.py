@@ -107,3 +107,20 @@ def test_g5_cluster(oracle, idx):
     oracle.set_genome(off, codes)
     ct = oracle.cluster(_abi.Params.from_options(o), batch.contig_ranks(contigs.names), table=tab)
     H.compare_cluster_rows(H.cluster_rows(ct, contigs.names), case["clusters"])
+
+
+def test_c1_config0_end_to_end(oracle):
+    """BASELINE.json configs[0] (10k-read synthetic 1-contig input, DEL/INS only): the oracle reproduces what the
+    reference's CPU path returned for COLLECT and CLUSTER."""
+    from svim_amd import synth
+    g, refs, recs = H.c1_case()
+    bam = H.records.AlignmentFile(text=synth.sam_text(["chr1"], [2000000], recs))
+    o = H.options(g["options"])
+    hb = batch.build_batch(bam, o, mode="coordinate")
+    p = _abi.Params.from_options(o)
+    sig, bnd = oracle.collect(hb, p)
+    assert H.table_rows(sig, hb.references, hb.read_names) == g["signatures"]
+    off, codes = convert.genome_arrays(refs, ["chr1"])
+    oracle.set_genome(off, codes)
+    ct = oracle.cluster(p, hb.contig_rank, source=0)
+    H.compare_cluster_rows(H.cluster_rows(ct, ["chr1"]), g["clusters"])
