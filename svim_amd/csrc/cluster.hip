@@ -606,6 +606,9 @@ __device__ void consolidate_one(int t, int contig, const Member* mem, const int*
     st.size[slot] = n; st.mem_local[slot] = moff;
 }
 
+// CAP = LDS capacity class: partitions with at most CAP sampled members (and more than LO) are handled by this instantiation;
+// the small class needs 1/4 of the LDS, so 3-4x more partitions are resident per CU
+template <int CAP, int LO>
 __global__ __launch_bounds__(64) void k_cluster(long long n_part, const int64_t* part_start, const uint32_t* sidx, const int32_t* sample_idx,
                                                 const int64_t* large_excl, const int64_t* samp_base, const int64_t* pair_off, const int32_t* ed,
                                                 ClusterIn in, svx_params p, int rank_, int world, Stage st, int32_t* ncl_out, int32_t* nmem_out,
@@ -614,18 +617,19 @@ __global__ __launch_bounds__(64) void k_cluster(long long n_part, const int64_t*
     const long long pt = blockIdx.x;
     if (pt >= n_part) return;
     const int lane = lane_id();
-    if ((pt % world) != rank_) { if (lane == 0) { ncl_out[pt] = 0; nmem_out[pt] = 0; } return; }
-    char* sm = smem;
-    LinkLds w = carve_link(sm, MAXN);
-    Member* mem = reinterpret_cast<Member*>(sm); sm += sizeof(Member) * MAXN;      // survivors after dedupe
-    Member* all = reinterpret_cast<Member*>(sm); sm += sizeof(Member) * MAXN;      // the sample
-    int* dup = reinterpret_cast<int*>(sm); sm += sizeof(int) * MAXN;
-    int* orig = reinterpret_cast<int*>(sm); sm += sizeof(int) * MAXN;
-    int* cl_off = reinterpret_cast<int*>(sm); sm += sizeof(int) * (MAXN + 2);
-    double* xs = reinterpret_cast<double*>(sm); sm += sizeof(double) * MAXN * 2;    // per-lane scratch is carved below
-
+    if ((pt % world) != rank_) { if (lane == 0 && LO == 0) { ncl_out[pt] = 0; nmem_out[pt] = 0; } return; }
     const long long ps = part_start[pt], size = part_start[pt + 1] - ps;
     const int ns = size > MAXN ? MAXN : (int)size;
+    if (ns > CAP || ns <= LO) return;                                               // the other size class owns this partition
+    char* sm = smem;
+    LinkLds w = carve_link(sm, CAP);
+    Member* mem = reinterpret_cast<Member*>(sm); sm += sizeof(Member) * CAP;       // survivors after dedupe
+    Member* all = reinterpret_cast<Member*>(sm); sm += sizeof(Member) * CAP;       // the sample
+    int* dup = reinterpret_cast<int*>(sm); sm += sizeof(int) * CAP;
+    int* orig = reinterpret_cast<int*>(sm); sm += sizeof(int) * CAP;
+    int* cl_off = reinterpret_cast<int*>(sm); sm += sizeof(int) * (CAP + 2);
+    double* xs = reinterpret_cast<double*>(sm); sm += sizeof(double) * CAP * 2;     // per-lane scratch is carved below
+
     const long long sbase = samp_base[pt];
     const uint32_t g0 = member_gidx(ps, size, 0, sidx, sample_idx, large_excl, pt);
     const int t = in.type[g0];
@@ -753,9 +757,16 @@ __global__ void k_gather_members(long long n, const int32_t* size, const int64_t
     for (int k = lane_id(); k < m; k += 64) dst[dst_moff[i] + k] = src[src_moff[i] + k];
 }
 
+// clusters are sorted by type: count[t] = lower_bound(t+1) - lower_bound(t)
 __global__ void k_type_counts(long long n, const uint8_t* type, unsigned long long* counts) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&counts[type[i]], 1ull);
+    const int t = threadIdx.x;
+    if (t >= SVX_NTYPES) return;
+    long long lo = 0, hi = n;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((int)type[mid] < t) lo = mid + 1; else hi = mid; }
+    const long long a = lo;
+    hi = n;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((int)type[mid] <= t) lo = mid + 1; else hi = mid; }
+    counts[t] = (unsigned long long)(lo - a);
 }
 
 // MT19937 state after random.seed(1524): init_by_array([1524]) (constant of the path; generated once on the host)
@@ -896,9 +907,14 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     SVXCHK(c->labels.reserve(PM * 4 * 2));
     int32_t* ncl_a = c->labels.as<int32_t>(); int32_t* nmem_a = ncl_a + PM;
     HIPCHK(hipMemsetAsync(ncl_a, 0, PM * 8, st));
-    const size_t lds = link_lds_bytes(MAXN) + sizeof(Member) * MAXN * 2 + sizeof(int) * (3 * MAXN + 2) + sizeof(double) * MAXN * 2 + 64;
-    k_cluster<<<(unsigned)n_part, 64, lds, st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl, samp_base, pair_off,
-                                                c->ed.as<int32_t>(), in, p, c->shard_rank, c->shard_world, stg, ncl_a, nmem_a, cnt + 10);
+    constexpr int SMALL = 48;
+    auto cluster_lds = [](int cap) { return link_lds_bytes(cap) + sizeof(Member) * cap * 2 + sizeof(int) * (3 * cap + 2) + sizeof(double) * cap * 2 + 64; };
+    k_cluster<SMALL, 0><<<(unsigned)n_part, 64, cluster_lds(SMALL), st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
+                                                                      samp_base, pair_off, c->ed.as<int32_t>(), in, p, c->shard_rank, c->shard_world, stg,
+                                                                      ncl_a, nmem_a, cnt + 10);
+    k_cluster<MAXN, SMALL><<<(unsigned)n_part, 64, cluster_lds(MAXN), st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
+                                                                        samp_base, pair_off, c->ed.as<int32_t>(), in, p, c->shard_rank, c->shard_world, stg,
+                                                                        ncl_a, nmem_a, cnt + 10);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[11], st));
     // ---- dense output ------------------------------------------------------------------------------------------------
@@ -949,7 +965,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
         k_gather_members<<<GRID(ncl, 4), 256, 0, st>>>(ncl, out.size.as<int32_t>(), src_moff, out.member_off.as<int64_t>(), u_members, out.members.as<int32_t>());
         unsigned long long* tc = cnt + 0;
         HIPCHK(hipMemsetAsync(tc, 0, 6 * 8, st));
-        k_type_counts<<<GRID(ncl, T), T, 0, st>>>(ncl, out.type.as<uint8_t>(), tc);
+        k_type_counts<<<1, 64, 0, st>>>(ncl, out.type.as<uint8_t>(), tc);
         unsigned long long h_tc[6];
         HIPCHK(hipMemcpyAsync(h_tc, tc, 6 * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));

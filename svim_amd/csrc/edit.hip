@@ -32,6 +32,27 @@ struct Hap {
         if (i < n1) return p1[i];
         return p2[i - n1];
     }
+    // symbols i..i+7 as one 4-bit packed word (symbols at or beyond `lim` read as 0): one unaligned 8-byte load when the run
+    // lies inside a single piece, byte loads across a piece border
+    __device__ __forceinline__ uint32_t pack8(int i, int lim) const {
+        const int cnt = lim - i >= 8 ? 8 : (lim - i);
+        if (cnt <= 0) return 0u;
+        const uint8_t* q = nullptr;
+        if (i + cnt <= n0) q = p0 + i;
+        else if (i >= n0 && i + cnt <= n0 + n1) q = p1 + (i - n0);
+        else if (i >= n0 + n1) q = p2 + (i - n0 - n1);
+        if (q && cnt == 8) {
+            unsigned long long x;
+            __builtin_memcpy(&x, q, 8);
+            x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+            x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+            x = (x | (x >> 16));
+            return (uint32_t)x;
+        }
+        uint32_t w = 0;
+        for (int k = 0; k < cnt; k++) w |= at(i + k) << (4 * k);
+        return w;
+    }
 };
 
 // 4-bit packed string: symbol i = (w[i>>3] >> 4*(i&7)) & 15
@@ -180,21 +201,23 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     int ham_l = 0, zero = 0;
     for (int base = 0; base < pd.n; base += 512) {     // 64 lanes x 8 symbols
         const int i0 = base + lane * 8;
-        uint32_t wt = 0, wp = 0;
-        for (int k = 0; k < 8; k++) {
-            const int i = i0 + k;
-            if (i < pd.n) {
-                const uint32_t ct = T.at(pre + i);
-                wt |= ct << (4 * k); zero |= (ct == 0);
-                if (i < pd.m) {
-                    const uint32_t cp = P.at(pre + i);
-                    wp |= cp << (4 * k); zero |= (cp == 0);
-                    ham_l += (cp != ct);
-                }
+        if (i0 < pd.n) {
+            const uint32_t wt = T.pack8(pre + i0, pre + pd.n);
+            tw[i0 >> 3] = wt;
+            const int vt = pd.n - i0 >= 8 ? 8 : pd.n - i0;
+            const uint32_t nzt = (wt | (wt >> 1) | (wt >> 2) | (wt >> 3)) & 0x11111111u;
+            zero |= (__popc(nzt) < vt);
+            if (i0 < pd.m) {
+                const uint32_t wp = P.pack8(pre + i0, pre + pd.m);
+                pw[i0 >> 3] = wp;
+                const int vp = pd.m - i0 >= 8 ? 8 : pd.m - i0;
+                const uint32_t nzp = (wp | (wp >> 1) | (wp >> 2) | (wp >> 3)) & 0x11111111u;
+                zero |= (__popc(nzp) < vp);
+                const uint32_t vmask = vp >= 8 ? 0xffffffffu : ((1u << (4 * vp)) - 1u);
+                const uint32_t x = (wp ^ wt) & vmask;
+                ham_l += __popc((x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u);
             }
         }
-        if (i0 < pd.n) tw[i0 >> 3] = wt;
-        if (i0 < pd.m) pw[i0 >> 3] = wp;
     }
     ham_l = wave_sum_i32(ham_l);
     zero = __any(zero);
