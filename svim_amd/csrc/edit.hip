@@ -116,11 +116,14 @@ struct PairDesc {
 
 #define CLS_FULL 5
 #define CLS_LANE0 6           /* 6..10: whole pattern (<= 32<<k rows) in one lane, full matrix, never fails */
-#define N_CLASSES 11
+#define CLS_WIDE0 11          /* 11..13: full matrix, 2/4/8 lanes per pair with 512 rows each (m <= 1024 / 2048 / 4096) */
+#define N_CLASSES 14
 #define MIN_MARGIN 16
 
 // secondary sort key: pairs that share a wave should cost the same (full-matrix class: rows first, then text length)
 __device__ __forceinline__ unsigned long long work_key(int cls, int m, int n);
+// class of a pair that needs the full matrix
+__device__ __forceinline__ int full_class_for(int m);
 __device__ __forceinline__ int lane_class_for(int m) { return m <= 32 ? 0 : m <= 64 ? 1 : m <= 128 ? 2 : m <= 256 ? 3 : 4; }
 
 __device__ __forceinline__ int band_class_for(int need_w) {      // smallest class whose window keeps the needed margin after dmax is aligned to 7 (mod 8)
@@ -143,6 +146,14 @@ __device__ __forceinline__ unsigned long long work_key(int cls, int m, int n) {
     const unsigned long long nn = (unsigned long long)(n > 0x3ffff ? 0x3ffff : n);
     if (cls == CLS_FULL) return ((unsigned long long)(m > 0x3fff ? 0x3fff : m) << 18) | nn;       // systolic: rows decide the lane count
     return nn;
+}
+
+__device__ __forceinline__ int full_class_for(int m) {
+    if (m <= 512) return CLS_LANE0 + lane_class_for(m);
+    if (m <= 1024) return CLS_WIDE0;
+    if (m <= 2048) return CLS_WIDE0 + 1;
+    if (m <= 4096) return CLS_WIDE0 + 2;
+    return CLS_FULL;
 }
 
 // ---- 1. scratch sizing --------------------------------------------------------------------------------------
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
         pd.ub = ub;
         int cls;
         if (force_full) cls = CLS_FULL;
-        else if (zero) cls = (pd.m <= 512) ? CLS_LANE0 + lane_class_for(pd.m) : CLS_FULL;                       // symbol '=' (code 0) is the band kernel's "never matches" filler
+        else if (zero) cls = full_class_for(pd.m);                       // symbol '=' (code 0) is the band kernel's "never matches" filler
         else {
             // `guaranteed` cannot fail (the trivial alignments bound the distance); when that bound is useless (position jitter
             // shifts the two cores against each other) start from a band sized for ~12 % divergence and widen on failure.
@@ -238,6 +249,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
             cls = guaranteed <= spec ? guaranteed : spec;
             // short patterns: the whole column fits one lane (k_edit_lane), nothing to speculate about
             if (cls > 0 && pd.m <= 512 && lane_class_for(pd.m) <= cls) cls = CLS_LANE0 + lane_class_for(pd.m);
+            else if (cls == CLS_FULL) cls = full_class_for(pd.m);
         }
         pd.cls = cls;
         desc[w] = pd;
@@ -369,11 +381,17 @@ __global__ __launch_bounds__(256) void k_edit_band(long long count, const uint32
         if (cls <= pd.cls) cls = pd.cls + 1;               // never retry the same width (can only differ by the alignment slack)
         if (cls > 4) cls = CLS_FULL;
         if (m <= 512 && lane_class_for(m) <= cls) cls = CLS_LANE0 + lane_class_for(m);
+        else if (cls == CLS_FULL) cls = full_class_for(m);
         desc[widx].ub = ub; desc[widx].cls = cls;
         const unsigned long long i = atomicAdd(n_fail, 1ull);
         fail_list[i] = widx;
         fail_key[i] = ((unsigned long long)cls << 32) | work_key(cls, m, n);
     }
+}
+
+__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
+    // lane l receives lane l-1's value, lane 0 receives 0 (gfx9 DPP control wave_shr:1)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
 }
 
 // ---- 3b. whole pattern in one lane (m <= 32*Q), full matrix: plain multi-word Myers, 64 pairs per wave ----------
@@ -450,6 +468,97 @@ __global__ __launch_bounds__(256) void k_edit_lane(long long count, const uint32
     if (live) ed[slot_of ? slot_of[widx] : (long long)widx] = score;
 }
 
+// ---- 3c. full matrix, G lanes per pair, 512 rows (16 words) per lane --------------------------------------------------------
+// The m-row column is ONE wide bit-vector spread over G lanes; lane g of a group works on text column t-g at step t and hands
+// (symbol, adder carry, shifted-out plus/minus bits) to lane g+1 through a DPP wave shift.  64/G pairs share a wave, every
+// lane carries 16 words of state, so the per-step overhead is amortised over 512 cells (the 1-block-per-lane systolic kernel
+// pays it per 32 cells).
+template <int G>
+__global__ __launch_bounds__(256) void k_edit_wide(long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
+                                                   const long long* slot_of, int32_t* ed) {
+    constexpr int Q = 16;
+    const int lane = lane_id();
+    const int gl = lane & (G - 1);
+    const long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const bool live = t < count;
+    uint32_t widx = 0;
+    PairDesc pd; pd.m = 1; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
+    if (live) { widx = list[t]; pd = desc[widx]; }
+    const int m = pd.m, n = live ? pd.n : 0;
+    const uint32_t* pat = scratch + pd.pat;
+    const uint32_t* txt = scratch + pd.txt;
+    const int row_base = gl * 512;
+    const int rows = m - row_base;                           // rows of this lane that exist (<= 0: lane unused)
+    uint32_t pv[Q], mv[Q], p0[Q], p1[Q], p2[Q], p3[Q], vm[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+        for (int wq = 0; wq < 4; wq++) {
+            const int row0 = row_base + q * 32 + wq * 8;
+            const uint32_t word = (live && row0 < m) ? pat[row0 >> 3] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t c = (word >> (4 * k)) & 15u;
+                const int b = wq * 8 + k;
+                a0 |= (c & 1u) << b; a1 |= ((c >> 1) & 1u) << b; a2 |= ((c >> 2) & 1u) << b; a3 |= ((c >> 3) & 1u) << b;
+            }
+        }
+        const int rq = rows - q * 32;
+        vm[q] = rq >= 32 ? 0xffffffffu : (rq <= 0 ? 0u : ((1u << rq) - 1u));
+        p0[q] = a0; p1[q] = a1; p2[q] = a2; p3[q] = a3;
+        pv[q] = 0xffffffffu; mv[q] = 0u;
+    }
+    const int lanes_used = live ? (m + 511) / 512 : 0;
+    const bool has_last = rows > 0 && rows <= 512;           // this lane holds row m
+    const int lastq = has_last ? ((rows - 1) >> 5) : -1;
+    const uint32_t topbit = has_last ? (1u << ((rows - 1) & 31)) : 0u;
+    int score = m;
+    int steps = live ? n + lanes_used - 1 : 0, smax = steps;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(smax, o, 64); smax = v > smax ? v : smax; }
+    const int txt_words = (n + 7) >> 3;
+    const bool feeder = live && gl == 0;
+    uint32_t tw_next = (feeder && txt_words > 0) ? txt[0] : 0u;
+    uint32_t out = 0;
+    for (int jb = 0; jb * 8 < smax; jb++) {
+        const uint32_t tw = tw_next;
+        tw_next = (feeder && jb + 1 < txt_words) ? txt[jb + 1] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int st = jb * 8 + k;                       // step; the group's first lane is at text column st
+            uint32_t in = dpp_wave_shr1(out);
+            if (gl == 0) in = (st < n) ? (((tw >> (4 * k)) & 15u) | 0x20u | 0x80u) : 0u;      // top row: plus bit 1, no carry
+            if ((in & 0x80u) && gl < lanes_used) {
+                const uint32_t c = in & 15u;
+                const uint32_t n0 = (c & 1u) - 1u, n1 = ((c >> 1) & 1u) - 1u, n2 = ((c >> 2) & 1u) - 1u, n3 = ((c >> 3) & 1u) - 1u;
+                uint32_t carry = (in >> 4) & 1u, ph_in = (in >> 5) & 1u, mh_in = (in >> 6) & 1u;
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const uint32_t eq = (p0[q] ^ n0) & (p1[q] ^ n1) & (p2[q] ^ n2) & (p3[q] ^ n3) & vm[q];
+                    const uint32_t PV = pv[q], MV = mv[q];
+                    const uint32_t xv = eq | MV;
+                    const unsigned long long sum = (unsigned long long)(eq & PV) + (unsigned long long)PV + (unsigned long long)carry;
+                    carry = (uint32_t)(sum >> 32);
+                    const uint32_t xh = (((uint32_t)sum) ^ PV) | eq;
+                    uint32_t ph = MV | ~(xh | PV);
+                    uint32_t mh = PV & xh;
+                    if (q == lastq) score += (int)((ph & topbit) != 0) - (int)((mh & topbit) != 0);
+                    const uint32_t ph_out = ph >> 31, mh_out = mh >> 31;
+                    ph = (ph << 1) | ph_in; mh = (mh << 1) | mh_in;
+                    ph_in = ph_out; mh_in = mh_out;
+                    pv[q] = mh | ~(xv | ph);
+                    mv[q] = ph & xv;
+                }
+                out = c | (carry << 4) | (ph_in << 5) | (mh_in << 6) | 0x80u;
+            } else {
+                out = 0;
+            }
+        }
+    }
+    if (live && has_last) ed[slot_of ? slot_of[widx] : (long long)widx] = score;
+}
+
 // ---- 4. full-matrix systolic kernel ----------------------------------------------------------------------------
 __device__ __forceinline__ void myers_block(uint32_t eq, uint32_t& pv, uint32_t& mv, uint32_t& hp, uint32_t& hm, uint32_t topmask) {
     const uint32_t xv = eq | mv;
@@ -463,11 +572,6 @@ __device__ __forceinline__ void myers_block(uint32_t eq, uint32_t& pv, uint32_t&
     pv = mh | ~(xv | ph);
     mv = ph & xv;
     hp = hpo; hm = hmo;
-}
-
-__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
-    // lane l receives lane l-1's value, lane 0 receives 0 (gfx9 DPP control wave_shr:1)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
 }
 
 // Exact distance between pat (length m >= 1, the shorter) and txt (length n >= m); whole wave cooperates.
@@ -703,6 +807,18 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                 case 2: k_edit_lane<4><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
                 case 3: k_edit_lane<8><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
                 default: k_edit_lane<16><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
+            }
+            HIPCHK(hipGetLastError());
+        }
+        for (int wc = 0; wc < 3; wc++) {                       // G lanes per pair, full matrix
+            const long long lo = bounds[CLS_WIDE0 + wc], cn = bounds[CLS_WIDE0 + wc + 1] - lo;
+            if (cn <= 0) continue;
+            const int G = 2 << wc;
+            const unsigned grid = (unsigned)((cn * G + T - 1) / T);
+            switch (wc) {
+                case 0: k_edit_wide<2><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
+                case 1: k_edit_wide<4><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
+                default: k_edit_wide<8><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
             }
             HIPCHK(hipGetLastError());
         }

@@ -177,6 +177,17 @@ def make_batch(n_reads=10000, n50=20000, contig_len=250_000_000, n_sites=None, s
         planted_site.append(ss)
     planted_unit = torch.cat(planted_unit) if planted_unit else torch.zeros(0, dtype=i64, device=dev)
     planted_site = torch.cat(planted_site) if planted_site else torch.zeros(0, dtype=i64, device=dev)
+    if planted_unit.numel():
+        # a unit planted in two passes keeps the LAST site (its length/op were overwritten in pass order); without this the
+        # sequence overwrite below would scatter two different site sequences to the same bytes (order-undefined on a GPU)
+        ordk = torch.arange(planted_unit.numel(), device=dev)
+        key = planted_unit * (planted_unit.numel() + 1) + ordk
+        srt = torch.argsort(key)
+        pu_s = planted_unit[srt]
+        last = torch.ones_like(pu_s, dtype=torch.bool)
+        last[:-1] = pu_s[:-1] != pu_s[1:]
+        keep = srt[last]
+        planted_unit, planted_site = planted_unit[keep], planted_site[keep]
     # ---- per-read totals ------------------------------------------------------------------------------------
     ref_c = m_len.to(i64) + torch.where(ind_op == 2, ind_len, 0).to(i64) + torch.where(ind_op == 0, ind_len, 0).to(i64)
     qry_c = m_len.to(i64) + torch.where(ind_op == 1, ind_len, 0).to(i64) + torch.where(ind_op == 0, ind_len, 0).to(i64)

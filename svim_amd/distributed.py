@@ -205,6 +205,8 @@ def device_pipeline_step(eng, params, rank, world, dev, read_id_stride=1 << 26):
         setattr(gv, k, _abi.ptr(g[k] if g[k].numel() else torch.zeros(1, dtype=g[k].dtype, device=dev)))
     gv.seq_off, gv.seq = _abi.ptr(g_off), _abi.ptr(g_seq if g_seq.numel() else torch.zeros(1, dtype=torch.uint8, device=dev))
     contig_rank = np.arange(world, dtype=np.int32)
+    # the gathered tensors were produced on torch's / RCCL's streams; libsvx runs on its own non-blocking stream
+    torch.cuda.synchronize()
     ct = eng.cluster(params, contig_rank, table=gv, source=2, shard=(rank, world))
     return gather_clusters(ct, contig_rank, device=dev)
 
@@ -222,4 +224,5 @@ def all_gather_genomes(genome, dev):
     full = _all_gather_var(genome, sizes, dist, torch)
     off = torch.zeros(world + 1, dtype=torch.int64, device=dev)
     off[1:] = torch.cumsum(torch.tensor(sizes, dtype=torch.int64, device=dev), 0)
+    torch.cuda.synchronize()          # consumers run on another stream
     return off, full
