@@ -32,7 +32,7 @@ def options():
                                  edit_distance_normalizer=1.0, cluster_max_distance=0.5, all_bnds=False)
 
 
-def cpu_baseline(batch, genome, params, budget_s=20.0):
+def cpu_baseline(batch, genome, params, eng=None, budget_s=20.0):
     """The oracle (single-threaded C restatement of the reference algorithm, kind 'port') on a bounded, contiguous
     slice of the same batch (contiguous in coordinate order = full local coverage, so per-partition work is
     representative)."""
@@ -56,7 +56,14 @@ def cpu_baseline(batch, genome, params, budget_s=20.0):
             break
         n = min(batch.n_rec, n * 4)
     t = best["t_collect"] + best["t_cluster"]
-    return {"value": best["used"] / t, "unit": "reads/s", "cores": 1, "kind": "port",
+    parity = None
+    if eng is not None:
+        # the same slice through the HIP path (host batch this time): the bench line carries its own parity evidence
+        gs, _ = eng.collect(hb, params)
+        gc = eng.cluster(params, np.zeros(1, np.int32), source=0)
+        parity = {"records": best["n_rec"], "signatures_identical": gs.first_difference(sig) is None,
+                  "clusters_identical": gc.first_difference(ct, rtol=1e-12) is None}
+    return {"parity_vs_gpu_on_sample": parity, "value": best["used"] / t, "unit": "reads/s", "cores": 1, "kind": "port",
             "sample": "first %d records of the same batch (coordinate order): %d reads used, %d signatures, %d clusters; "
                       "collect %.2f s + cluster %.2f s on 1 host core (of %d)" % (
                           best["n_rec"], best["used"], best["n_sig"], best["n_clusters"], best["t_collect"], best["t_cluster"],
@@ -197,7 +204,7 @@ def main():
         "roofline": roofline, "kernels": kernels, "synth_seconds": t_gen,
     }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(batch, genome, p)
+        out["cpu_baseline"] = cpu_baseline(batch, genome, p, eng)
         out["speedup_vs_cpu_port"] = reads_per_s / world / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     if use_dist:

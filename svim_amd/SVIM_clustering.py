@@ -83,3 +83,60 @@ def calculate_score(cluster, std_span, std_pos, span, type):
     else:
         n = min(80, len(cluster))
     return n + sds * (n / 8) + pds * (n / 8)
+
+
+def span_position_distance_intdup_candidates(signature1, signature2, position_distance_normalizer):
+    """src/svim/SVIM_clustering.py:110-119 (host scalar, same operation order)."""
+    (_, s1, e1), (_, s2, e2) = signature1.get_source(), signature2.get_source()
+    span1, span2 = e1 - s1, e2 - s2
+    pd_source = abs((s1 + e1) // 2 - (s2 + e2) // 2) / position_distance_normalizer
+    pd_dest = abs(signature1.get_destination()[1] - signature2.get_destination()[1]) / position_distance_normalizer
+    return pd_source + pd_dest + abs(span1 - span2) / max(span1, span2)
+
+
+def partition_and_cluster_candidates(candidates, options, type):
+    """COMBINE-step re-clustering of interspersed-duplication candidates (src/svim/SVIM_clustering.py:306-372, called at
+    src/svim/SVIM_COMBINE.py:476).  The candidate set is small (O(#clusters)): partitioning, the seeded down-sampling and
+    the pair distances are host scalars with the reference's arithmetic; average linkage + flat cut of all partitions run
+    as one batch of the LDS linkage kernel (svx_linkage_fcluster).  The merged candidates are built with the class of the
+    inputs (svim's CandidateDuplicationInterspersed or any class with that constructor)."""
+    import logging
+    from random import seed, sample
+    from statistics import mean
+    partitions = form_partitions(candidates, options.partition_max_distance)
+    clusters = [None] * len(partitions)
+    problems, where = [], []
+    seed(1524)
+    for k, partition in enumerate(partitions):
+        if len(partition) == 1:
+            clusters[k] = [[partition[0]]]
+            continue
+        part = sample(partition, 100) if len(partition) > 100 else partition
+        d = [span_position_distance_intdup_candidates(part[i], part[j], options.position_distance_normalizer)
+             for i in range(len(part) - 1) for j in range(i + 1, len(part))]
+        problems.append((len(part), d))
+        where.append((k, part))
+    if problems:
+        for (k, part), labels in zip(where, _lib.engine().linkage_fcluster(problems, float(options.cluster_max_distance))):
+            groups = [[] for _ in range(int(labels.max()))]
+            for idx, lab in enumerate(labels):
+                groups[int(lab) - 1].append(part[idx])
+            clusters[k] = groups
+    flat = [c for groups in clusters for c in groups]
+    logging.info("Clustered {0}: {1} partitions and {2} clusters".format(type, len(partitions), len(flat)))
+    final = []
+    for cluster in flat:
+        if cluster[0].type != "DUP_INT":
+            continue
+        stds_span = [c.std_span for c in cluster if c.std_span is not None]
+        stds_pos = [c.std_pos for c in cluster if c.std_pos is not None]
+        n = len(cluster)
+        cls = cluster[0].__class__
+        final.append(cls(cluster[0].get_source()[0], int(round(sum(c.get_source()[1] for c in cluster) / n)),
+                         int(round(sum(c.get_source()[2] for c in cluster) / n)), cluster[0].get_destination()[0],
+                         int(round(sum(c.get_destination()[1] for c in cluster) / n)),
+                         int(round(sum(c.get_destination()[2] for c in cluster) / n)),
+                         [m for c in cluster for m in c.members], max(c.score for c in cluster),
+                         mean(stds_span) if stds_span else None, mean(stds_pos) if stds_pos else None,
+                         any(c.cutpaste for c in cluster)))
+    return final

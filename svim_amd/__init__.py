@@ -12,8 +12,10 @@ from .SVIM_inter import analyze_read_segments, is_similar                       
 from .SVIM_COLLECT import (analyze_alignment_file_coordsorted, analyze_alignment_file_querysorted,   # noqa: F401
                            bam_iterator, retrieve_other_alignments)
 from .SVIM_CLUSTER import cluster_sv_signatures                                             # noqa: F401
-from .SVIM_clustering import partition_and_cluster, form_partitions                         # noqa: F401
+from .SVIM_clustering import (partition_and_cluster, form_partitions, partition_and_cluster_candidates,   # noqa: F401
+                              span_position_distance_clusters, calculate_score)
 
 __all__ = ["analyze_cigar_indel", "analyze_alignment_indel", "analyze_read_segments", "is_similar",
            "analyze_alignment_file_coordsorted", "analyze_alignment_file_querysorted", "bam_iterator",
-           "retrieve_other_alignments", "cluster_sv_signatures", "partition_and_cluster", "form_partitions"]
+           "retrieve_other_alignments", "cluster_sv_signatures", "partition_and_cluster", "form_partitions",
+           "partition_and_cluster_candidates", "span_position_distance_clusters", "calculate_score"]

@@ -522,6 +522,53 @@ def gen_c1():
                           "source": "svim.SVIM_COLLECT.analyze_alignment_file_coordsorted + svim.SVIM_CLUSTER.cluster_sv_signatures"})
 
 
+def gen_entrypoints(collect_cases):
+    """Per-read entry points (analyze_alignment_indel, analyze_read_segments) and the COMBINE-side re-clustering
+    (partition_and_cluster_candidates) as the reference computes them."""
+    from svim import SVCandidate
+    case = [c for c in collect_cases if c["name"] == "fuzzA" and c["mode"] == "coordinate" and c.get("sam")][0]
+    bam = records.AlignmentFile(text=case["sam"])
+    recs = list(bam.fetch(until_eof=True))
+    out = []
+    for all_bnds in (False, True):
+        o = options(all_bnds=all_bnds)
+        per = []
+        for i, a in enumerate(recs[:400]):
+            if a.is_unmapped or a.is_secondary:
+                continue
+            s1, b1 = SVIM_intra.analyze_alignment_indel(a, bam, a.query_name, o)
+            entry = {"rec": i, "indel": [sig_row(s) for s in s1], "indel_bnd": [sig_row(s) for s in b1]}
+            if not a.is_supplementary:
+                sup = [x for x in SVIM_COLLECT.retrieve_other_alignments(a, bam) if x.mapping_quality >= o.min_mapq]
+                s2, b2 = SVIM_inter.analyze_read_segments(a, sup, bam, o)
+                entry["segments"] = [sig_row(s) for s in s2]
+                entry["segments_bnd"] = [sig_row(s) for s in b2]
+            per.append(entry)
+        out.append({"all_bnds": all_bnds, "options": opt_dict(o), "per_record": per})
+    # candidates: DUP_INT candidates scattered so that partitions of 1, 2, several and > 100 members occur
+    rng = random.Random(17)
+    cand_rows = []
+    pos = 20000
+    for n in (1, 2, 5, 30, 130, 3, 1, 101):
+        for k in range(n):
+            s = pos + rng.randint(-60, 60)
+            ln = rng.choice((300, 320, 900))
+            d = 70000 + (pos // 7) % 30000 + rng.randint(-80, 80)
+            cand_rows.append(["chr1", s, s + ln, "chr2", d, d + ln, rng.randint(1, 40), rng.choice((None, 3.5, 10.25)), rng.choice((None, 1.5, 7.0)),
+                              rng.random() < 0.2, ["m%d_%d" % (pos, k)]])
+        pos += rng.choice((700, 2500, 6000))
+    rng.shuffle(cand_rows)
+    cands = [SVCandidate.CandidateDuplicationInterspersed(r[0], r[1], r[2], r[3], r[4], r[5], list(r[10]), r[6], r[7], r[8], r[9]) for r in cand_rows]
+    o = options()
+    res = SVIM_clustering.partition_and_cluster_candidates(cands, o, "interspersed duplication candidates")
+    res_rows = [[c.source_contig, c.source_start, c.source_end, c.dest_contig, c.dest_start, c.dest_end, c.score, c.std_span, c.std_pos,
+                 bool(c.cutpaste), list(c.members)] for c in res]
+    dump("g_entrypoints.json.gz", {"sam_case": "fuzzA/coordinate of g2_collect.json.gz", "runs": out, "candidates": cand_rows,
+                                   "merged_candidates": res_rows, "options": opt_dict(o),
+                                   "source": "svim.SVIM_intra.analyze_alignment_indel, svim.SVIM_inter.analyze_read_segments, "
+                                             "svim.SVIM_clustering.partition_and_cluster_candidates"})
+
+
 def main():
     contigs = [("chr1", 180000), ("chr2", 60000), ("chr10", 60000)]   # tid order != Python string order
     refs = synth.make_reference(1, contigs)
@@ -535,6 +582,7 @@ def main():
     gen_intra()
     collect_cases = gen_collect(refs, references, lengths)
     gen_cluster(collect_cases, refs, references, lengths)
+    gen_entrypoints(collect_cases)
     gen_linkage()
     gen_rng()
     gen_edit()

@@ -341,3 +341,64 @@ def test_c1_config0_through_bam_file(eng, tmp_path):
                          c.std_pos, mem])
         got.append(rows)
     H.compare_cluster_rows(got, g["clusters"])
+
+
+def test_per_read_entry_points_match_reference(eng):
+    """analyze_alignment_indel / analyze_read_segments (the per-read functions of SVIM_intra.py / SVIM_inter.py) through the
+    drop-in names, record by record, against what the reference returned."""
+    import svim_amd
+    g = H.load("g_entrypoints.json.gz")
+    g2 = H.load("g2_collect.json.gz")
+    text = [c for c in g2["cases"] if c["name"] == "fuzzA" and c["mode"] == "coordinate" and c.get("sam")][0]["sam"]
+    bam = records.AlignmentFile(text=text)
+    recs = list(bam.fetch(until_eof=True))
+    for run in g["runs"]:
+        o = H.options(run["options"])
+        for e in run["per_record"][:120]:
+            a = recs[e["rec"]]
+            s1, b1 = svim_amd.analyze_alignment_indel(a, bam, a.query_name, o)
+            assert [H.sig_row(s) for s in s1] == e["indel"], e["rec"]
+            assert [H.sig_row(s) for s in b1] == e["indel_bnd"], e["rec"]
+            if "segments" in e:
+                sup = [x for x in svim_amd.retrieve_other_alignments(a, bam) if x.mapping_quality >= o.min_mapq]
+                s2, b2 = svim_amd.analyze_read_segments(a, sup, bam, o)
+                assert [H.sig_row(s) for s in s2] == e["segments"], e["rec"]
+                assert [H.sig_row(s) for s in b2] == e["segments_bnd"], e["rec"]
+
+
+class _Cand(object):
+    """stand-in with the constructor / accessors of svim.SVCandidate.CandidateDuplicationInterspersed"""
+    type = "DUP_INT"
+
+    def __init__(self, source_contig, source_start, source_end, dest_contig, dest_start, dest_end, members, score, std_span, std_pos,
+                 cutpaste=False):
+        self.source_contig, self.source_start, self.source_end = source_contig, max(0, source_start), source_end
+        self.dest_contig, self.dest_start, self.dest_end = dest_contig, max(0, dest_start), dest_end
+        self.members, self.score, self.std_span, self.std_pos, self.cutpaste = members, score, std_span, std_pos, cutpaste
+
+    def get_source(self):
+        return (self.source_contig, self.source_start, self.source_end)
+
+    def get_destination(self):
+        return (self.dest_contig, self.dest_start, self.dest_end)
+
+    def get_key(self):
+        return (self.type, self.source_contig, self.source_end)
+
+    def downstream_distance_to(self, other):
+        if self.type == other.type and self.source_contig == other.source_contig:
+            return max(0, other.source_start - self.source_end)
+        return float("inf")
+
+
+def test_partition_and_cluster_candidates_matches_reference(eng):
+    import svim_amd
+    g = H.load("g_entrypoints.json.gz")
+    cands = [_Cand(r[0], r[1], r[2], r[3], r[4], r[5], list(r[10]), r[6], r[7], r[8], r[9]) for r in g["candidates"]]
+    res = svim_amd.partition_and_cluster_candidates(cands, H.options(g["options"]), "interspersed duplication candidates")
+    got = [[c.source_contig, c.source_start, c.source_end, c.dest_contig, c.dest_start, c.dest_end, c.score, c.std_span, c.std_pos,
+            bool(c.cutpaste), list(c.members)] for c in res]
+    assert len(got) == len(g["merged_candidates"])
+    for a, b in zip(got, g["merged_candidates"]):
+        assert a[:7] == b[:7] and a[9:] == b[9:], (a, b)
+        assert H.close(a[7], b[7]) and H.close(a[8], b[8])
