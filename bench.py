@@ -196,7 +196,7 @@ def main():
         "config": {"workload": "configs[1]: %d synthetic ONT reads per GPU (N50 %d), single %d Mb contig, DEL/INS/INV"
                                % (args.reads, args.n50, args.contig_len // 1_000_000),
                    "records_per_gpu": meta["n_records"], "cigar_ops_per_gpu": meta["n_ops"], "planted_sites": meta["n_sites"],
-                   "parallelism": "1 process/GPU, records sharded, partitions sharded by index", "options": "SVIM alignment-mode defaults"},
+                   "parallelism": "1 process/GPU, records sharded, signature columns all-gathered, partitions owned by origin rank", "options": "SVIM alignment-mode defaults"},
         "signatures_per_s": tot_sig * args.steps / elapsed,
         "signatures_per_s_cluster_only": st["n_sig"] / (st["t_cluster_ms"] * 1e-3) if st["t_cluster_ms"] > 0 else None,
         "counts": {"reads_used": tot_used, "signatures": tot_sig, "cigar_ops": tot_ops, "partitions": st["n_partitions"],

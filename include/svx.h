@@ -174,6 +174,13 @@ int  svx_cluster_fetch(svx_ctx* ctx, svx_cluster_view* host_out);
  * the per-rank cluster tables (RCCL) and merges them by partition index (returned in part_index) */
 int  svx_cluster_set_shard(svx_ctx* ctx, int rank, int world);
 int  svx_cluster_fetch_part_index(svx_ctx* ctx, int64_t* host_out /* [n_clusters] */);
+/* alternative ownership for contig-sharded input: the table passed to svx_cluster is the rank-major concatenation of the
+ * per-rank tables, origin_prefix[r] = first global index of rank r; a partition belongs to the rank that produced its first
+ * sorted member, so its inserted sequences are already local (only that rank's seq ranges need to be non-empty).
+ * svx_cluster_remote_members reports how many members of this rank's insertion partitions came from another rank
+ * (non-zero: the caller must supply all sequences and use svx_cluster_set_shard instead). */
+int  svx_cluster_set_shard_by_origin(svx_ctx* ctx, int rank, int world, const int64_t* origin_prefix_host /* [world+1] */);
+int  svx_cluster_remote_members(svx_ctx* ctx, int64_t* out);
 
 /* ---- single-function entry points kept importable by the reference's API ------------------------ */
 /* analyze_cigar_indel (src/svim/SVIM_intra.py:8-30) on one packed CIGAR; out arrays sized n_ops */

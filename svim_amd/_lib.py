@@ -20,6 +20,7 @@ _ENGINES = {}
 SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream",
            "svx_collect", "svx_collect_count", "svx_collect_fetch", "svx_set_genome", "svx_cluster",
            "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_shard", "svx_cluster_fetch_part_index",
+           "svx_cluster_set_shard_by_origin", "svx_cluster_remote_members",
            "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster",
            "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names"]
 
@@ -102,8 +103,11 @@ class Engine(object):
         self._keep = [off, codes]
         _check(self.L.svx_set_genome(self.ctx, C.byref(g)), "svx_set_genome")
 
-    def cluster(self, params, contig_rank, table=None, source=2, shard=None, fetch=True):
-        if shard is not None:
+    def cluster(self, params, contig_rank, table=None, source=2, shard=None, fetch=True, origin_prefix=None):
+        if shard is not None and origin_prefix is not None:
+            pre = np.ascontiguousarray(origin_prefix, dtype=np.int64)
+            _check(self.L.svx_cluster_set_shard_by_origin(self.ctx, shard[0], shard[1], ptr(pre)), "svx_cluster_set_shard_by_origin")
+        elif shard is not None:
             _check(self.L.svx_cluster_set_shard(self.ctx, shard[0], shard[1]), "svx_cluster_set_shard")
         v = table.view() if (table is not None and hasattr(table, "view")) else (table if table is not None else _abi.SigView())
         rank = np.ascontiguousarray(contig_rank, dtype=np.int32)
@@ -123,6 +127,11 @@ class Engine(object):
         _check(self.L.svx_cluster_fetch_part_index(self.ctx, ptr(pi)), "svx_cluster_fetch_part_index")
         ct.part_index = pi[:n.value]
         return ct
+
+    def remote_members(self):
+        n = C.c_int64()
+        _check(self.L.svx_cluster_remote_members(self.ctx, C.byref(n)), "svx_cluster_remote_members")
+        return n.value
 
     def stats(self):
         s = _abi.Stats()

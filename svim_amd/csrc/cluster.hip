@@ -24,6 +24,21 @@ struct EditWork { uint32_t a, b; long long slot; };
 
 #define MAXN 100
 
+// Which rank clusters a partition.  mode 0: partition index modulo world.  mode 1 ("by origin"): the rank whose COLLECT
+// produced the partition's first sorted member (the signature table is the rank-major concatenation, origin_prefix[r] =
+// first global index of rank r): with contig-sharded input every member - and every inserted sequence - is already local.
+struct Shard { int mode, rank, world; const int64_t* origin_prefix; };
+__device__ __forceinline__ int origin_of(const Shard& sh, uint32_t sig) {
+    int r = 0;
+    while (r + 1 < sh.world && (int64_t)sig >= sh.origin_prefix[r + 1]) r++;
+    return r;
+}
+__device__ __forceinline__ bool shard_mine(const Shard& sh, long long pt, uint32_t first_member) {
+    if (sh.world <= 1) return true;
+    if (sh.mode == 0) return (pt % sh.world) == sh.rank;
+    return origin_of(sh, first_member) == sh.rank;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // sort keys (get_key): hi = type | rank1 | rank2, lo = biased coordinate
 // ---------------------------------------------------------------------------------------------------------
@@ -79,7 +94,7 @@ __global__ void k_part_starts(const int64_t* flag, const int64_t* pid_excl, long
 }
 
 // per-partition derived sizes: ns = min(size, 100); large flag; INS pair slots
-__global__ void k_part_sizes(const int64_t* part_start, long long n_part, const uint8_t* type, const uint32_t* sidx, int rank_, int world,
+__global__ void k_part_sizes(const int64_t* part_start, long long n_part, const uint8_t* type, const uint32_t* sidx, Shard sh,
                              int64_t* ns, int64_t* large, int64_t* pairs) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n_part) return;
@@ -88,7 +103,7 @@ __global__ void k_part_sizes(const int64_t* part_start, long long n_part, const 
     const long long m = size > MAXN ? MAXN : size;
     ns[p] = m;
     large[p] = size > MAXN;
-    const bool mine = (p % world) == rank_;
+    const bool mine = shard_mine(sh, p, sidx[part_start[p]]);
     pairs[p] = (mine && type[sidx[part_start[p]]] == SVX_INS) ? m * (m - 1) / 2 : 0;
 }
 
@@ -344,13 +359,18 @@ __device__ __forceinline__ uint32_t member_gidx(long long pstart, long long size
 // enumerate the INS pairs that need an edit distance (one wave per INS partition of this shard)
 __global__ __launch_bounds__(64) void k_ins_pairs(long long n_part, const int64_t* part_start, const uint32_t* sidx, const int32_t* sample_idx,
                                                   const int64_t* large_excl, const int64_t* pair_cnt, const int64_t* pair_off, ClusterIn in,
-                                                  svx_params p, EditWork* work, unsigned long long* n_work, long long work_cap) {
+                                                  svx_params p, EditWork* work, unsigned long long* n_work, long long work_cap, Shard sh,
+                                                  unsigned long long* n_remote) {
     const long long pt = blockIdx.x;
     if (pt >= n_part || pair_cnt[pt] == 0) return;
     __shared__ int m_start[MAXN]; __shared__ uint32_t m_g[MAXN];
     const long long ps = part_start[pt], size = part_start[pt + 1] - ps;
     const int ns = size > MAXN ? MAXN : (int)size;
-    for (int q = lane_id(); q < ns; q += 64) { const uint32_t g = member_gidx(ps, size, q, sidx, sample_idx, large_excl, pt); m_g[q] = g; m_start[q] = in.start[g]; }
+    for (int q = lane_id(); q < ns; q += 64) {
+        const uint32_t g = member_gidx(ps, size, q, sidx, sample_idx, large_excl, pt); m_g[q] = g; m_start[q] = in.start[g];
+        // by-origin sharding promises that the inserted sequences of an owned partition are local: count the exceptions
+        if (sh.world > 1 && sh.mode == 1 && origin_of(sh, g) != sh.rank) atomicAdd(n_remote, 1ull);
+    }
     __syncthreads();
     const int npairs = ns * (ns - 1) / 2;
     const long long base = pair_off[pt];
@@ -611,13 +631,13 @@ __device__ void consolidate_one(int t, int contig, const Member* mem, const int*
 template <int CAP, int LO>
 __global__ __launch_bounds__(64) void k_cluster(long long n_part, const int64_t* part_start, const uint32_t* sidx, const int32_t* sample_idx,
                                                 const int64_t* large_excl, const int64_t* samp_base, const int64_t* pair_off, const int32_t* ed,
-                                                ClusterIn in, svx_params p, int rank_, int world, Stage st, int32_t* ncl_out, int32_t* nmem_out,
+                                                ClusterIn in, svx_params p, Shard sh, Stage st, int32_t* ncl_out, int32_t* nmem_out,
                                                 unsigned long long* n_pairs_stat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const long long pt = blockIdx.x;
     if (pt >= n_part) return;
     const int lane = lane_id();
-    if ((pt % world) != rank_) { if (lane == 0 && LO == 0) { ncl_out[pt] = 0; nmem_out[pt] = 0; } return; }
+    if (!shard_mine(sh, pt, sidx[part_start[pt]])) { if (lane == 0 && LO == 0) { ncl_out[pt] = 0; nmem_out[pt] = 0; } return; }
     const long long ps = part_start[pt], size = part_start[pt + 1] - ps;
     const int ns = size > MAXN ? MAXN : (int)size;
     if (ns > CAP || ns <= LO) return;                                               // the other size class owns this partition
@@ -799,6 +819,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     svx_stats& S = c->stats;
     S.n_partitions = S.n_large_partitions = S.n_pairs = S.n_edit_pairs = S.n_edit_cells = S.n_clusters = S.n_hap_bytes = 0;
     S.t_cluster_ms = S.t_partition_ms = S.t_edit_ms = S.t_linkage_ms = 0;
+    c->n_remote_members = 0;
     if (n == 0) return SVX_OK;
     if (n >= (1ll << 31)) return svx_fail(SVX_E_ARG, "more than 2^31 signatures in one call", __FILE__, __LINE__, hipSuccess);
     const int T = 256;
@@ -827,7 +848,8 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     int64_t* ns_a = c->part_meta.as<int64_t>(); int64_t* large_a = ns_a + PM; int64_t* pairs_a = large_a + PM;
     int64_t* samp_base = pairs_a + PM; int64_t* large_excl = samp_base + PM; int64_t* pair_off = large_excl + PM;
     int64_t* clu_off = pair_off + PM; int64_t* mem_off = clu_off + PM;
-    k_part_sizes<<<GRID(n_part + 1, T), T, 0, st>>>(c->part_start.as<int64_t>(), n_part, in.type, sidx, c->shard_rank, c->shard_world, ns_a, large_a, pairs_a);
+    Shard sh{c->shard_mode, c->shard_rank, c->shard_world, c->shard_prefix.as<int64_t>()};
+    k_part_sizes<<<GRID(n_part + 1, T), T, 0, st>>>(c->part_start.as<int64_t>(), n_part, in.type, sidx, sh, ns_a, large_a, pairs_a);
     SVXCHK(svx_exclusive_scan_i64(c, ns_a, samp_base, n_part + 1));
     SVXCHK(svx_exclusive_scan_i64(c, large_a, large_excl, n_part + 1));
     SVXCHK(svx_exclusive_scan_i64(c, pairs_a, pair_off, n_part + 1));
@@ -877,11 +899,12 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
         if (!c->g_off_p) return svx_fail(SVX_E_STATE, "svx_set_genome must precede clustering of insertions", __FILE__, __LINE__, hipSuccess);
         SVXCHK(c->work.reserve((size_t)pair_total * sizeof(EditWork)));
         k_ins_pairs<<<(unsigned)n_part, 64, 0, st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl, pairs_a, pair_off, in, p,
-                                                    c->work.as<EditWork>(), cnt + 8, pair_total);
+                                                    c->work.as<EditWork>(), cnt + 8, pair_total, sh, cnt + 11);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_cnt, cnt, 16 * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         const int64_t n_work = (int64_t)h_cnt[8];
+        c->n_remote_members = (int64_t)h_cnt[11];
         SVXCHK(c->cell_shards.reserve(1024 * 8));
         HIPCHK(hipMemsetAsync(c->cell_shards.p, 0, 1024 * 8, st));
         SVXCHK(svx_launch_edit_pairs(c, n_work, c->work.p, in, c->ed.as<int32_t>(), c->cell_shards.as<unsigned long long>()));
@@ -910,10 +933,10 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     constexpr int SMALL = 48;
     auto cluster_lds = [](int cap) { return link_lds_bytes(cap) + sizeof(Member) * cap * 2 + sizeof(int) * (3 * cap + 2) + sizeof(double) * cap * 2 + 64; };
     k_cluster<SMALL, 0><<<(unsigned)n_part, 64, cluster_lds(SMALL), st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
-                                                                      samp_base, pair_off, c->ed.as<int32_t>(), in, p, c->shard_rank, c->shard_world, stg,
+                                                                      samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
                                                                       ncl_a, nmem_a, cnt + 10);
     k_cluster<MAXN, SMALL><<<(unsigned)n_part, 64, cluster_lds(MAXN), st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
-                                                                        samp_base, pair_off, c->ed.as<int32_t>(), in, p, c->shard_rank, c->shard_world, stg,
+                                                                        samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
                                                                         ncl_a, nmem_a, cnt + 10);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[11], st));

@@ -125,7 +125,9 @@ struct svx_ctx {
     DevBuf pair_off, ed, work, stage, stage_members, labels;
     DevBuf e_words, e_off, e_scratch, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off;     // edit-distance pipeline
     DevClusters clu;
-    int shard_rank = 0, shard_world = 1;
+    int shard_rank = 0, shard_world = 1, shard_mode = 0;
+    DevBuf shard_prefix;            // origin prefix (world+1 int64) for by-origin sharding
+    int64_t n_remote_members = 0;   // members of owned INS partitions produced by another rank (by-origin mode)
     bool edit_force_full = false;  // debugging aid (env SVX_EDIT_FORCE_FULL=1): every pair through the full-matrix kernel
     bool no_seq_gather = false;   // svx_cigar_indel hook: positions only
     svx_stats stats;

@@ -165,11 +165,17 @@ def _all_gather_var(t, counts, dist, torch):
 
 def device_pipeline_step(eng, params, rank, world, dev, read_id_stride=1 << 26):
     """COLLECT already ran on this rank's records (results resident in its context).  Exchange the signature tables,
-    cluster the partitions this rank owns, gather the cluster tables.  Returns the merged ClusterTable on rank 0.
+    cluster the partitions this rank owns, gather the cluster tables.  Returns the merged ClusterTable (every rank).
 
-    Each rank's batch lives on its own contig: contig id := rank, read ids are made globally unique by a per-rank stride."""
+    Each rank's batch lives on its own contig: contig id := rank, read ids are made globally unique by a per-rank stride.
+    Fast path: only the fixed-width columns (37 B/signature) are all-gathered and partitions are owned "by origin"
+    (svx_cluster_set_shard_by_origin): with contig-sharded input every member of an owned insertion partition - hence every
+    inserted sequence - is already local.  If any rank reports remote members, the step is redone with the inserted
+    sequences all-gathered as well and index-modulo ownership (always correct, more traffic)."""
+    import ctypes as C
     import torch
     import torch.distributed as dist
+    from ._lib import _check
     n, nseq, _ = eng.collect_counts()
     cnt = torch.tensor([n, nseq], dtype=torch.int64, device=dev)
     allc = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -186,28 +192,42 @@ def device_pipeline_step(eng, params, rank, world, dev, read_id_stride=1 << 26):
     for k, _ in _DEV_COLS:
         setattr(v, k, _abi.ptr(cols[k]))
     v.seq_off, v.seq = _abi.ptr(seq_off), _abi.ptr(seq)
-    import ctypes as C
-    from ._lib import _check
     _check(eng.L.svx_collect_fetch(eng.ctx, 0, C.byref(v)), "svx_collect_fetch")
     cols["contig"] = cols["contig"] + rank                       # this rank's contig
     cols["contig2"] = torch.where(cols["contig2"] >= 0, cols["contig2"] + rank, cols["contig2"])
     cols["read_id"] = cols["read_id"] + rank * read_id_stride
     g = {k: _all_gather_var(cols[k][:n], ns, dist, torch) for k, _ in _DEV_COLS}
-    lens = (seq_off[1:] - seq_off[:-1])
-    g_len = _all_gather_var(lens, ns, dist, torch)
-    g_seq = _all_gather_var(seq[:nseq], nq, dist, torch)
     N = sum(ns)
+    prefix = np.zeros(world + 1, dtype=np.int64)
+    prefix[1:] = np.cumsum(ns)
+    lens = (seq_off[1:] - seq_off[:-1])
+    contig_rank = np.arange(world, dtype=np.int32)
+
+    def view(g_off, g_seq):
+        gv = _abi.SigView()
+        gv.on_device, gv.n = 1, N
+        for k, _ in _DEV_COLS:
+            setattr(gv, k, _abi.ptr(g[k] if g[k].numel() else torch.zeros(1, dtype=g[k].dtype, device=dev)))
+        gv.seq_off, gv.seq = _abi.ptr(g_off), _abi.ptr(g_seq if g_seq.numel() else torch.zeros(1, dtype=torch.uint8, device=dev))
+        return gv
+
+    # fast path: remote signatures carry empty sequence ranges
+    g_len = torch.zeros(N, dtype=torch.int64, device=dev)
+    g_len[int(prefix[rank]):int(prefix[rank + 1])] = lens
     g_off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
     torch.cumsum(g_len, 0, out=g_off[1:])
-    gv = _abi.SigView()
-    gv.on_device, gv.n = 1, N
-    for k, _ in _DEV_COLS:
-        setattr(gv, k, _abi.ptr(g[k] if g[k].numel() else torch.zeros(1, dtype=g[k].dtype, device=dev)))
-    gv.seq_off, gv.seq = _abi.ptr(g_off), _abi.ptr(g_seq if g_seq.numel() else torch.zeros(1, dtype=torch.uint8, device=dev))
-    contig_rank = np.arange(world, dtype=np.int32)
-    # the gathered tensors were produced on torch's / RCCL's streams; libsvx runs on its own non-blocking stream
-    torch.cuda.synchronize()
-    ct = eng.cluster(params, contig_rank, table=gv, source=2, shard=(rank, world))
+    torch.cuda.synchronize()      # the gathered tensors were produced on torch's / RCCL's streams; libsvx has its own stream
+    ct = eng.cluster(params, contig_rank, table=view(g_off, seq[:max(1, nseq)]), source=2, shard=(rank, world), origin_prefix=prefix)
+    remote = torch.tensor([eng.remote_members()], dtype=torch.int64, device=dev)
+    dist.all_reduce(remote, op=dist.ReduceOp.MAX)
+    if int(remote.item()) > 0:
+        # some insertion partition mixes origins: ship the sequences too and shard by partition index
+        a_len = _all_gather_var(lens, ns, dist, torch)
+        a_seq = _all_gather_var(seq[:nseq], nq, dist, torch)
+        a_off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(a_len, 0, out=a_off[1:])
+        torch.cuda.synchronize()
+        ct = eng.cluster(params, contig_rank, table=view(a_off, a_seq), source=2, shard=(rank, world))
     return gather_clusters(ct, contig_rank, device=dev)
 
 

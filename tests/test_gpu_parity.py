@@ -402,3 +402,47 @@ def test_partition_and_cluster_candidates_matches_reference(eng):
     for a, b in zip(got, g["merged_candidates"]):
         assert a[:7] == b[:7] and a[9:] == b[9:], (a, b)
         assert H.close(a[7], b[7]) and H.close(a[8], b[8])
+
+
+def test_shard_by_origin_two_virtual_ranks(eng, oracle):
+    """By-origin ownership (contig-sharded multi-GPU fast path), emulated on one GPU: rank 0 'collected' the chr1 records,
+    rank 1 the rest; each virtual rank sees the rank-major table with ONLY ITS OWN inserted sequences and clusters the
+    partitions it owns; the merged result equals the unsharded run."""
+    from svim_amd.distributed import concat_sig_tables, merge_cluster_tables
+    bam, refs, references = _planted_case(91, 1500, 40)
+    recs = list(bam.fetch(until_eof=True))
+    o = H.options({"min_mapq": 20, "min_sv_size": 40, "max_sv_size": 100000, "segment_gap_tolerance": 10, "segment_overlap_tolerance": 5,
+                   "partition_max_distance": 1000, "position_distance_normalizer": 900, "edit_distance_normalizer": 1.0,
+                   "cluster_max_distance": 0.5, "all_bnds": False})
+    p = _abi.Params.from_options(o)
+    off, codes = convert.genome_arrays(refs, references)
+    eng.set_genome(off, codes)
+    groups = [[a for a in recs if a.reference_id == 0], [a for a in recs if a.reference_id != 0]]
+    tabs, names = [], []
+    for grp in groups:
+        hb = batch.build_batch(bam, o, mode="coordinate", records=grp)
+        sig, _ = eng.collect(hb, p)
+        # keep only signatures that live entirely on this rank's contigs (split reads may bridge contigs)
+        sig.read_id = sig.read_id + len(names)
+        names += hb.read_names
+        tabs.append(sig)
+    full_tab = concat_sig_tables(tabs)
+    rank_arr = batch.contig_ranks(references)
+    full = eng.cluster(p, rank_arr, table=full_tab, shard=(0, 1))
+    prefix = np.array([0, tabs[0].n, tabs[0].n + tabs[1].n], dtype=np.int64)
+    parts, remote = [], []
+    for r in range(2):
+        local = concat_sig_tables(tabs)
+        lens = np.diff(local.seq_off)
+        lo, hi = int(prefix[r]), int(prefix[r + 1])
+        lens[:lo] = 0
+        lens[hi:] = 0                                   # remote sequences are NOT available on this rank
+        own = tabs[r]
+        local.seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        local.seq = own.seq[:max(1, int(own.seq_off[own.n]))].copy()
+        parts.append(eng.cluster(p, rank_arr, table=local, shard=(r, 2), origin_prefix=prefix))
+        remote.append(eng.remote_members())
+    eng.cluster(p, rank_arr, table=full_tab, shard=(0, 1), fetch=False)
+    assert remote == [0, 0]
+    merged = merge_cluster_tables(parts, rank_arr)
+    assert merged.first_difference(full) is None
