@@ -25,6 +25,11 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount; }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& ev : c->ev) HIPCHK(hipEventCreate(&ev));
+    {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        for (int k = 0; k < SVX_N_AUX; k++) HIPCHK(hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, k < 3 ? greatest : least));
+    }
     memset(&c->stats, 0, sizeof c->stats);
     { const char* e = getenv("SVX_EDIT_FORCE_FULL"); c->edit_force_full = e && e[0] == '1'; }
     *out = c;
@@ -45,6 +50,7 @@ extern "C" void svx_ctx_destroy(svx_ctx* c) {
     for (auto* b : bufs) b->release();
     for (auto& b : c->user_sig) b.release();
     for (auto& ev : c->ev) (void)hipEventDestroy(ev);
+    for (auto& a : c->aux) (void)hipStreamDestroy(a);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

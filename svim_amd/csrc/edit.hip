@@ -143,9 +143,11 @@ __device__ __forceinline__ int need_window(int m, int n, int ub) {
 }
 
 __device__ __forceinline__ unsigned long long work_key(int cls, int m, int n) {
+    // descending cost inside a class: the longest-running waves are dispatched first, the short ones fill the tail
     const unsigned long long nn = (unsigned long long)(n > 0x3ffff ? 0x3ffff : n);
-    if (cls == CLS_FULL) return ((unsigned long long)(m > 0x3fff ? 0x3fff : m) << 18) | nn;       // systolic: rows decide the lane count
-    return nn;
+    unsigned long long k = nn;
+    if (cls == CLS_FULL) k = ((unsigned long long)(m > 0x3fff ? 0x3fff : m) << 18) | nn;          // systolic: rows decide the lane count
+    return 0xffffffffull - k;
 }
 
 __device__ __forceinline__ int full_class_for(int m) {
@@ -744,6 +746,41 @@ __global__ void k_class_bounds(const uint64_t* keys, long long n, long long* bou
 }
 
 // ---- host orchestration -----------------------------------------------------------------------------------------
+// SVX_EDIT_PROFILE=1: per round and class, the pair count and the 32-bit word-columns the class kernel executes
+// (useful = sum over pairs, issued = what the lock-stepped waves pay: 64 x the longest text of each wave); stderr, one line per class
+static void profile_round(svx_ctx* c, int round, const long long* bounds, const uint32_t* list_dev, const PairDesc* desc_dev, long long pending) {
+    hipStream_t st = c->stream;
+    std::vector<uint32_t> list((size_t)pending);
+    if (hipMemcpyAsync(list.data(), list_dev, (size_t)pending * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return;
+    (void)hipStreamSynchronize(st);
+    uint32_t mx = 0;
+    for (uint32_t v : list) mx = v > mx ? v : mx;
+    std::vector<PairDesc> desc((size_t)mx + 1);
+    if (hipMemcpyAsync(desc.data(), desc_dev, ((size_t)mx + 1) * sizeof(PairDesc), hipMemcpyDeviceToHost, st) != hipSuccess) return;
+    (void)hipStreamSynchronize(st);
+    for (int cls = 0; cls < N_CLASSES; cls++) {
+        const long long lo = bounds[cls], cn = bounds[cls + 1] - lo;
+        if (cn <= 0) continue;
+        int words = 0, per_wave = 64;                       // 32-bit words of column state per pair; pairs per wave
+        if (cls <= 4) words = 1 << cls;
+        else if (cls >= CLS_LANE0 && cls < CLS_WIDE0) words = 1 << (cls - CLS_LANE0);
+        else if (cls >= CLS_WIDE0) { words = 16 * (2 << (cls - CLS_WIDE0)); per_wave = 64 / (2 << (cls - CLS_WIDE0)); }
+        double useful = 0, issued = 0, sum_m = 0, sum_n = 0;
+        for (long long i = 0; i < cn; i += per_wave) {
+            long long nmax = 0;
+            for (long long k = i; k < cn && k < i + per_wave; k++) {
+                const PairDesc& pd = desc[list[(size_t)(lo + k)]];
+                const int w = cls == CLS_FULL ? (pd.m + 31) / 32 : words;
+                useful += (double)pd.n * w; sum_m += pd.m; sum_n += pd.n;
+                if (cls == CLS_FULL) issued += (double)pd.n * w; else if (pd.n > nmax) nmax = pd.n;
+            }
+            if (cls != CLS_FULL) issued += (double)nmax * words * per_wave;
+        }
+        fprintf(stderr, "{\"edit_profile\": {\"round\": %d, \"cls\": %d, \"pairs\": %lld, \"mean_m\": %.1f, \"mean_n\": %.1f, \"word_cols_useful\": %.4g, \"word_cols_issued\": %.4g}}\n",
+                round, cls, cn, sum_m / cn, sum_n / cn, useful, issued);
+    }
+}
+
 static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src, int32_t* ed_dev, unsigned long long* cells_dev) {
     if (n_work <= 0) return SVX_OK;
     if (n_work >= (1ll << 32)) return svx_fail(SVX_E_ARG, "more than 2^32 edit-distance pairs in one call", __FILE__, __LINE__, hipSuccess);
@@ -759,7 +796,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     HIPCHK(hipStreamSynchronize(st));
     SVXCHK(c->e_scratch.reserve((size_t)(total_words + 64) * 4));
     SVXCHK(c->e_desc.reserve((size_t)n_work * sizeof(PairDesc)));
-    SVXCHK(c->e_key.reserve((size_t)n_work * 8 * 2)); SVXCHK(c->e_val.reserve((size_t)n_work * 4 * 2));
+    SVXCHK(c->e_key.reserve((size_t)n_work * 8 * 2)); SVXCHK(c->e_val.reserve((size_t)n_work * 4 * 3));
     SVXCHK(c->e_slot.reserve((size_t)n_work * 8));
     SVXCHK(c->e_fail.reserve((size_t)n_work * (4 + 8) + 256 + 64));
     uint64_t* key_a = c->e_key.as<uint64_t>(); uint64_t* key_b = key_a + n_work;
@@ -774,68 +811,103 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     k_slots<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, src, slot_of);
     k_edit_prep<<<(unsigned)((n_work + 3) / 4), 256, 0, st>>>(n_work, src, c->e_off.as<int64_t>(), scratch, desc, key_a, val_a, ed_dev, cells_dev, c->edit_force_full ? 1 : 0);
     HIPCHK(hipGetLastError());
-    long long pending = n_work;
+    // Streams: the band classes (0..4, may fail) run on high-priority side streams, the full-matrix classes (lane / wide /
+    // systolic, never fail) on low-priority ones.  A round only waits for its band kernels; the retry rounds - small, poorly
+    // parallel - therefore overlap with the full-matrix work of the earlier rounds, which fills the rest of the chip.
+    // The runtime multiplexes streams onto 4 hardware queues per priority level and streams that share a queue serialise, hence
+    // at most 3 + 4 side streams: band16 | band8 | band4,2,1 and wide8 | wide4 | systolic, wide2 | lane classes.
+    hipStream_t band_st[5] = {c->aux[2], c->aux[2], c->aux[2], c->aux[1], c->aux[0]};
+    hipStream_t full_st[9] = {c->aux[6], c->aux[6], c->aux[6], c->aux[6], c->aux[6], c->aux[5], c->aux[4], c->aux[3], c->aux[5]};     // lane 0..4, wide 0..2, systolic
+    SVXCHK(c->e_big_list.reserve((size_t)n_work * 4 + 64));
+    long long pending = n_work, cum = 0;
     const uint64_t* keys_in = key_a; const uint32_t* vals_in = val_a;
+    const bool profile = getenv("SVX_EDIT_PROFILE") != nullptr;
+    HIPCHK(hipMemsetAsync(cnt, 0, 16, st));
+    auto join_full = [&]() -> int { for (int k = 3; k < SVX_N_AUX; k++) HIPCHK(hipStreamSynchronize(c->aux[k])); return SVX_OK; };
     for (int round = 0; round < 8 && pending > 0; round++) {
-        // 3. group by class (and by text length inside a class, so that the 64 pairs of a wave finish together)
-        SVXCHK(svx_sort_pairs_u64(c, keys_in, key_b, vals_in, val_b, pending, 0, 40));
+        // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
+        if (cum + pending > 2 * n_work) { SVXCHK(join_full()); cum = 0; }      // list space of this call exhausted (pathological retry pattern)
+        uint32_t* list = val_b + cum;
+        SVXCHK(svx_sort_pairs_u64(c, keys_in, key_b, vals_in, list, pending, 0, 40));
         k_class_bounds<<<1, 64, 0, st>>>(key_b, pending, reinterpret_cast<long long*>(cnt + 8));
-        HIPCHK(hipMemsetAsync(cnt, 0, 16, st));
+        HIPCHK(hipMemsetAsync(cnt, 0, 8, st));
         long long bounds[N_CLASSES + 1];
         HIPCHK(hipMemcpyAsync(bounds, cnt + 8, (N_CLASSES + 1) * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        for (int cls = 0; cls <= 4; cls++) {
+        if (profile) profile_round(c, round, bounds, list, desc, pending);
+        bool band_used[5] = {false, false, false, false, false};
+        for (int cls = 4; cls >= 0; cls--) {
             const long long lo = bounds[cls], cn = bounds[cls + 1] - lo;
             if (cn <= 0) continue;
             const unsigned grid = (unsigned)((cn + T - 1) / T);
+            hipStream_t ks = band_st[cls];
+            band_used[cls] = true;
             switch (cls) {
-                case 0: k_edit_band<1><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
-                case 1: k_edit_band<2><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
-                case 2: k_edit_band<4><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
-                case 3: k_edit_band<8><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
-                default: k_edit_band<16><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+                case 0: k_edit_band<1><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+                case 1: k_edit_band<2><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+                case 2: k_edit_band<4><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+                case 3: k_edit_band<8><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+                default: k_edit_band<16><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
             }
             HIPCHK(hipGetLastError());
         }
-        for (int lc = 0; lc <= 4; lc++) {                      // whole-pattern-in-a-lane classes
-            const long long lo = bounds[CLS_LANE0 + lc], cn = bounds[CLS_LANE0 + lc + 1] - lo;
-            if (cn <= 0) continue;
-            const unsigned grid = (unsigned)((cn + T - 1) / T);
-            switch (lc) {
-                case 0: k_edit_lane<1><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
-                case 1: k_edit_lane<2><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
-                case 2: k_edit_lane<4><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
-                case 3: k_edit_lane<8><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
-                default: k_edit_lane<16><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
+        {   // systolic full-matrix class (one wave per pair); pairs beyond 16384 rows are listed for k_edit_full_big
+            const long long lo = bounds[5], cn = bounds[6] - lo;
+            if (cn > 0) {
+                k_edit_full<<<(unsigned)((cn + 3) / 4), 256, 0, full_st[8]>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
+                HIPCHK(hipGetLastError());
             }
-            HIPCHK(hipGetLastError());
         }
-        for (int wc = 0; wc < 3; wc++) {                       // G lanes per pair, full matrix
+        for (int wc = 2; wc >= 0; wc--) {                      // G lanes per pair, full matrix
             const long long lo = bounds[CLS_WIDE0 + wc], cn = bounds[CLS_WIDE0 + wc + 1] - lo;
             if (cn <= 0) continue;
             const int G = 2 << wc;
             const unsigned grid = (unsigned)((cn * G + T - 1) / T);
+            hipStream_t ks = full_st[5 + wc];
             switch (wc) {
-                case 0: k_edit_wide<2><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
-                case 1: k_edit_wide<4><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
-                default: k_edit_wide<8><<<grid, T, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev); break;
+                case 0: k_edit_wide<2><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
+                case 1: k_edit_wide<4><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
+                default: k_edit_wide<8><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
             }
             HIPCHK(hipGetLastError());
         }
-        {   // full-matrix class
-            const long long lo = bounds[5], cn = bounds[6] - lo;
-            if (cn > 0) {
-                SVXCHK(c->e_big_list.reserve((size_t)cn * 4 + 64));
-                k_edit_full<<<(unsigned)((cn + 3) / 4), 256, 0, st>>>(cn, val_b + lo, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
-                HIPCHK(hipGetLastError());
+        for (int lc = 4; lc >= 0; lc--) {                      // whole-pattern-in-a-lane classes
+            const long long lo = bounds[CLS_LANE0 + lc], cn = bounds[CLS_LANE0 + lc + 1] - lo;
+            if (cn <= 0) continue;
+            const unsigned grid = (unsigned)((cn + T - 1) / T);
+            hipStream_t ks = full_st[lc];
+            switch (lc) {
+                case 0: k_edit_lane<1><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
+                case 1: k_edit_lane<2><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
+                case 2: k_edit_lane<4><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
+                case 3: k_edit_lane<8><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
+                default: k_edit_lane<16><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
             }
+            HIPCHK(hipGetLastError());
         }
-        unsigned long long h[2];
-        HIPCHK(hipMemcpyAsync(h, cnt, 16, hipMemcpyDeviceToHost, st));
+        // only the band kernels can hand pairs to the next round
+        for (int cls = 0; cls <= 4; cls++) if (band_used[cls]) HIPCHK(hipStreamSynchronize(band_st[cls]));
+        unsigned long long h0 = 0;
+        HIPCHK(hipMemcpyAsync(&h0, cnt, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (h[1]) {
+        cum += pending;
+        pending = (long long)h0;
+        if (pending > 0) {
+            // retry list becomes the next round's input (copied: the band kernels of the next round append to fail_list again)
+            HIPCHK(hipMemcpyAsync(key_a, fail_key, (size_t)pending * 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(val_a, fail_list, (size_t)pending * 4, hipMemcpyDeviceToDevice, st));
+            keys_in = key_a; vals_in = val_a;
+        }
+        c->stats.n_hap_bytes += (round == 0) ? total_words * 4 : 0;
+    }
+    SVXCHK(join_full());
+    {
+        unsigned long long nb = 0;
+        HIPCHK(hipMemcpyAsync(&nb, cnt + 1, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (nb) {
             // rare: shorter core > 16384 symbols.  Size the block-state scratch exactly from the core lengths.
-            const long long nbig = (long long)h[1];
+            const long long nbig = (long long)nb;
             std::vector<uint32_t> items((size_t)nbig);
             HIPCHK(hipMemcpyAsync(items.data(), c->e_big_list.p, (size_t)nbig * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -852,14 +924,6 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));
         }
-        pending = (long long)h[0];
-        if (pending > 0) {
-            // retry list becomes the next round's input (copied, because the sort ping-pongs between key_a/key_b)
-            HIPCHK(hipMemcpyAsync(key_a, fail_key, (size_t)pending * 8, hipMemcpyDeviceToDevice, st));
-            HIPCHK(hipMemcpyAsync(val_a, fail_list, (size_t)pending * 4, hipMemcpyDeviceToDevice, st));
-            keys_in = key_a; vals_in = val_a;
-        }
-        c->stats.n_hap_bytes += (round == 0) ? total_words * 4 : 0;
     }
     if (pending > 0) return svx_fail(SVX_E_STATE, "edit-distance retry loop did not converge", __FILE__, __LINE__, hipSuccess);
     return SVX_OK;
