@@ -119,6 +119,18 @@ struct PairDesc {
 #define CLS_WIDE0 11          /* 11..13: full matrix, 2/4/8 lanes per pair with 512 rows each (m <= 1024 / 2048 / 4096) */
 #define N_CLASSES 14
 #define MIN_MARGIN 16
+// A pair whose two cores hold only A/C/G/T (BAM codes 1,2,4,8) runs the 2-bit-plane kernels (P = 2); anything else (N, IUPAC codes,
+// the '=' filler) the generic 4-plane ones (P = 4).  PairDesc.cls bit 8 carries that flag; the sort class is flag*16 + class.
+#define CLS_GENERIC 0x100
+#define N_SORT_CLASSES 32
+__device__ __forceinline__ unsigned long long sort_class(int cls_with_flag) {
+    return (unsigned long long)(((cls_with_flag & CLS_GENERIC) ? 16 : 0) + (cls_with_flag & 0xff));
+}
+// symbol as the P-plane kernels see it: P = 4 the BAM code itself, P = 2 A,C,G,T -> 0,1,2,3
+template <int P> __device__ __forceinline__ uint32_t sym(uint32_t c) {
+    if (P == 4) return c;
+    return (((c >> 1) | (c >> 3)) & 1u) | ((((c >> 2) | (c >> 3)) & 1u) << 1);
+}
 
 // secondary sort key: pairs that share a wave should cost the same (full-matrix class: rows first, then text length)
 __device__ __forceinline__ unsigned long long work_key(int cls, int m, int n);
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     }
     // pack the cores, count mismatches of the trivial left-justified alignment and look for code 0
     uint32_t* pw = scratch + pd.pat; uint32_t* tw = scratch + pd.txt;
-    int ham_l = 0, zero = 0;
+    int ham_l = 0, zero = 0, other = 0;
     for (int base = 0; base < pd.n; base += 512) {     // 64 lanes x 8 symbols
         const int i0 = base + lane * 8;
         if (i0 < pd.n) {
@@ -220,6 +232,9 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
             const int vt = pd.n - i0 >= 8 ? 8 : pd.n - i0;
             const uint32_t nzt = (wt | (wt >> 1) | (wt >> 2) | (wt >> 3)) & 0x11111111u;
             zero |= (__popc(nzt) < vt);
+            const uint32_t vmt = vt >= 8 ? 0xffffffffu : ((1u << (4 * vt)) - 1u);
+            const uint32_t onest = (wt & 0x11111111u) + ((wt >> 1) & 0x11111111u) + ((wt >> 2) & 0x11111111u) + ((wt >> 3) & 0x11111111u);
+            other |= ((onest ^ 0x11111111u) & vmt) != 0u;          // a symbol that is not exactly one of A,C,G,T
             if (i0 < pd.m) {
                 const uint32_t wp = P.pack8(pre + i0, pre + pd.m);
                 pw[i0 >> 3] = wp;
@@ -227,6 +242,8 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
                 const uint32_t nzp = (wp | (wp >> 1) | (wp >> 2) | (wp >> 3)) & 0x11111111u;
                 zero |= (__popc(nzp) < vp);
                 const uint32_t vmask = vp >= 8 ? 0xffffffffu : ((1u << (4 * vp)) - 1u);
+                const uint32_t onesp = (wp & 0x11111111u) + ((wp >> 1) & 0x11111111u) + ((wp >> 2) & 0x11111111u) + ((wp >> 3) & 0x11111111u);
+                other |= ((onesp ^ 0x11111111u) & vmask) != 0u;
                 const uint32_t x = (wp ^ wt) & vmask;
                 ham_l += __popc((x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u);
             }
@@ -234,6 +251,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     }
     ham_l = wave_sum_i32(ham_l);
     zero = __any(zero);
+    other = __any(other);
     if (lane == 0) {
         const int ub = ham_l + (pd.n - pd.m);
         pd.ub = ub;
@@ -253,9 +271,9 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
             if (cls > 0 && pd.m <= 512 && lane_class_for(pd.m) <= cls) cls = CLS_LANE0 + lane_class_for(pd.m);
             else if (cls == CLS_FULL) cls = full_class_for(pd.m);
         }
-        pd.cls = cls;
+        pd.cls = cls | (other ? CLS_GENERIC : 0);
         desc[w] = pd;
-        sort_key[w] = ((unsigned long long)cls << 32) | work_key(cls, pd.m, pd.n);
+        sort_key[w] = (sort_class(pd.cls) << 32) | work_key(cls, pd.m, pd.n);
         sort_val[w] = (uint32_t)w;
         if (cells) atomicAdd(cells + (w & 1023), (unsigned long long)pd.m * (unsigned long long)pd.n);      // 1024 shards: no same-address pile-up
     }
@@ -264,7 +282,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
 // ---- 3. banded lane-per-pair kernel -----------------------------------------------------------------------------
 // Window of W = 32*Q bits; bit b of column j <-> row (j - dmax) + b.  dmax = 7 (mod 8) so that the row entering at the
 // bottom of the window and the text symbol of the column sit at the same nibble phase of their packed words.
-template <int Q>
+template <int Q, int P>
 __global__ __launch_bounds__(256) void k_edit_band(long long count, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
                                                    const long long* slot_of, int32_t* ed, unsigned long long* n_fail, uint32_t* fail_list,
                                                    uint64_t* fail_key) {
@@ -283,14 +301,15 @@ __global__ __launch_bounds__(256) void k_edit_band(long long count, const uint32
     const int a_bot = W - 1 - dmax;                    // multiple of 8
     const uint32_t* pat = scratch + pd.pat;
     const uint32_t* txt = scratch + pd.txt;
-    uint32_t pv[Q], mv[Q], p0[Q], p1[Q], p2[Q], p3[Q];
+    uint32_t pv[Q], mv[Q], pl[P][Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int lo = 32 * q, nvirt = dmax + 1;        // rows <= 0 : vertical delta -1
         uint32_t mlow;
         if (nvirt >= lo + 32) mlow = 0xffffffffu; else if (nvirt <= lo) mlow = 0u; else mlow = (1u << (nvirt - lo)) - 1u;
         mv[q] = mlow; pv[q] = ~mlow;
-        p0[q] = p1[q] = p2[q] = p3[q] = 0u;
+#pragma unroll
+        for (int b = 0; b < P; b++) pl[b][q] = 0u;
     }
     const int pat_words = (m + 7) >> 3;
     // pre-roll: rows 1..a_bot enter the window (a_bot/8 whole words)
@@ -299,14 +318,13 @@ __global__ __launch_bounds__(256) void k_edit_band(long long count, const uint32
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int row = wi * 8 + k + 1;
-            const uint32_t c = (row <= m) ? ((word >> (4 * k)) & 15u) : 0u;
+            const uint32_t c = (row <= m) ? sym<P>((word >> (4 * k)) & 15u) : 0u;
 #pragma unroll
-            for (int q = 0; q < Q - 1; q++) {
-                p0[q] = __builtin_amdgcn_alignbit(p0[q + 1], p0[q], 1); p1[q] = __builtin_amdgcn_alignbit(p1[q + 1], p1[q], 1);
-                p2[q] = __builtin_amdgcn_alignbit(p2[q + 1], p2[q], 1); p3[q] = __builtin_amdgcn_alignbit(p3[q + 1], p3[q], 1);
+            for (int b = 0; b < P; b++) {
+#pragma unroll
+                for (int q = 0; q < Q - 1; q++) pl[b][q] = __builtin_amdgcn_alignbit(pl[b][q + 1], pl[b][q], 1);
+                pl[b][Q - 1] = (pl[b][Q - 1] >> 1) | (((c >> b) & 1u) << 31);
             }
-            p0[Q - 1] = (p0[Q - 1] >> 1) | ((c & 1u) << 31); p1[Q - 1] = (p1[Q - 1] >> 1) | (((c >> 1) & 1u) << 31);
-            p2[Q - 1] = (p2[Q - 1] >> 1) | (((c >> 2) & 1u) << 31); p3[Q - 1] = (p3[Q - 1] >> 1) | (((c >> 3) & 1u) << 31);
         }
     }
     int S = dmax;
@@ -326,24 +344,27 @@ __global__ __launch_bounds__(256) void k_edit_band(long long count, const uint32
         for (int k = 0; k < 8; k++) {
             const int j = jb * 8 + k + 1;
             if (j <= n) {
-                const uint32_t c = (tw >> (4 * k)) & 15u;
-                const uint32_t pc = (j + a_bot <= m) ? ((pw >> (4 * k)) & 15u) : 0u;
+                const uint32_t c = sym<P>((tw >> (4 * k)) & 15u);
+                const uint32_t pc = (j + a_bot <= m) ? sym<P>((pw >> (4 * k)) & 15u) : 0u;
                 // slide the window one row down
 #pragma unroll
-                for (int q = 0; q < Q - 1; q++) {
-                    pv[q] = __builtin_amdgcn_alignbit(pv[q + 1], pv[q], 1); mv[q] = __builtin_amdgcn_alignbit(mv[q + 1], mv[q], 1);
-                    p0[q] = __builtin_amdgcn_alignbit(p0[q + 1], p0[q], 1); p1[q] = __builtin_amdgcn_alignbit(p1[q + 1], p1[q], 1);
-                    p2[q] = __builtin_amdgcn_alignbit(p2[q + 1], p2[q], 1); p3[q] = __builtin_amdgcn_alignbit(p3[q + 1], p3[q], 1);
-                }
+                for (int q = 0; q < Q - 1; q++) { pv[q] = __builtin_amdgcn_alignbit(pv[q + 1], pv[q], 1); mv[q] = __builtin_amdgcn_alignbit(mv[q + 1], mv[q], 1); }
                 pv[Q - 1] = (pv[Q - 1] >> 1) | 0x80000000u; mv[Q - 1] >>= 1;
-                p0[Q - 1] = (p0[Q - 1] >> 1) | ((pc & 1u) << 31); p1[Q - 1] = (p1[Q - 1] >> 1) | (((pc >> 1) & 1u) << 31);
-                p2[Q - 1] = (p2[Q - 1] >> 1) | (((pc >> 2) & 1u) << 31); p3[Q - 1] = (p3[Q - 1] >> 1) | (((pc >> 3) & 1u) << 31);
+                uint32_t nk[P];
+#pragma unroll
+                for (int b = 0; b < P; b++) {
+#pragma unroll
+                    for (int q = 0; q < Q - 1; q++) pl[b][q] = __builtin_amdgcn_alignbit(pl[b][q + 1], pl[b][q], 1);
+                    pl[b][Q - 1] = (pl[b][Q - 1] >> 1) | (((pc >> b) & 1u) << 31);
+                    nk[b] = ((c >> b) & 1u) - 1u;
+                }
                 S += (int)(pv[0] & 1u) - (int)(mv[0] & 1u);
-                const uint32_t n0 = (c & 1u) - 1u, n1 = ((c >> 1) & 1u) - 1u, n2 = ((c >> 2) & 1u) - 1u, n3 = ((c >> 3) & 1u) - 1u;
                 uint32_t carry = 0, ph_in = 1u, mh_in = 0u;
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    const uint32_t eq = (p0[q] ^ n0) & (p1[q] ^ n1) & (p2[q] ^ n2) & (p3[q] ^ n3);
+                    uint32_t eq = pl[0][q] ^ nk[0];
+#pragma unroll
+                    for (int b = 1; b < P; b++) eq &= pl[b][q] ^ nk[b];
                     const uint32_t PV = pv[q], MV = mv[q];
                     const uint32_t xv = eq | MV;
                     const unsigned long long sum = (unsigned long long)(eq & PV) + (unsigned long long)PV + (unsigned long long)carry;
@@ -378,16 +399,18 @@ __global__ __launch_bounds__(256) void k_edit_band(long long count, const uint32
     else {
         // d is a valid alignment cost, hence an upper bound: the band it guarantees succeeds next time
         const int ub = d < pd.ub ? d : pd.ub;
+        const int cur = pd.cls & 0xff;
         int cls = band_class_for(need_window(m, n, ub));   // cannot fail, but d from a too-narrow band can be a gross over-estimate:
-        if (cls > pd.cls + 1) cls = pd.cls + 1;            // widen geometrically instead
-        if (cls <= pd.cls) cls = pd.cls + 1;               // never retry the same width (can only differ by the alignment slack)
+        if (cls > cur + 1) cls = cur + 1;                  // widen geometrically instead
+        if (cls <= cur) cls = cur + 1;                     // never retry the same width (can only differ by the alignment slack)
         if (cls > 4) cls = CLS_FULL;
         if (m <= 512 && lane_class_for(m) <= cls) cls = CLS_LANE0 + lane_class_for(m);
         else if (cls == CLS_FULL) cls = full_class_for(m);
-        desc[widx].ub = ub; desc[widx].cls = cls;
+        const int flagged = cls | (pd.cls & CLS_GENERIC);
+        desc[widx].ub = ub; desc[widx].cls = flagged;
         const unsigned long long i = atomicAdd(n_fail, 1ull);
         fail_list[i] = widx;
-        fail_key[i] = ((unsigned long long)cls << 32) | work_key(cls, m, n);
+        fail_key[i] = (sort_class(flagged) << 32) | work_key(cls, m, n);
     }
 }
 
@@ -397,7 +420,7 @@ __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
 }
 
 // ---- 3b. whole pattern in one lane (m <= 32*Q), full matrix: plain multi-word Myers, 64 pairs per wave ----------
-template <int Q>
+template <int Q, int P>
 __global__ __launch_bounds__(256) void k_edit_lane(long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
                                                    const long long* slot_of, int32_t* ed) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -408,24 +431,25 @@ __global__ __launch_bounds__(256) void k_edit_lane(long long count, const uint32
     const int m = pd.m, n = live ? pd.n : 0;
     const uint32_t* pat = scratch + pd.pat;
     const uint32_t* txt = scratch + pd.txt;
-    uint32_t pv[Q], mv[Q], p0[Q], p1[Q], p2[Q], p3[Q], vm[Q];
+    uint32_t pv[Q], mv[Q], pl[P][Q];       // rows beyond m compute garbage that never reaches row m (all dependencies point down the column)
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        uint32_t acc[P];
+#pragma unroll
+        for (int b = 0; b < P; b++) acc[b] = 0u;
 #pragma unroll
         for (int wq = 0; wq < 4; wq++) {                 // 4 packed words = 32 rows
             const int row0 = q * 32 + wq * 8;
             const uint32_t word = (live && row0 < m) ? pat[(row0 >> 3)] : 0u;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const uint32_t c = (word >> (4 * k)) & 15u;
-                const int b = wq * 8 + k;
-                a0 |= (c & 1u) << b; a1 |= ((c >> 1) & 1u) << b; a2 |= ((c >> 2) & 1u) << b; a3 |= ((c >> 3) & 1u) << b;
+                const uint32_t c = sym<P>((word >> (4 * k)) & 15u);
+#pragma unroll
+                for (int b = 0; b < P; b++) acc[b] |= ((c >> b) & 1u) << (wq * 8 + k);
             }
         }
-        const int rows = m - q * 32;
-        vm[q] = rows >= 32 ? 0xffffffffu : (rows <= 0 ? 0u : ((1u << rows) - 1u));
-        p0[q] = a0; p1[q] = a1; p2[q] = a2; p3[q] = a3;
+#pragma unroll
+        for (int b = 0; b < P; b++) pl[b][q] = acc[b];
         pv[q] = 0xffffffffu; mv[q] = 0u;
     }
     const int lastq = (m - 1) >> 5;
@@ -443,12 +467,16 @@ __global__ __launch_bounds__(256) void k_edit_lane(long long count, const uint32
         for (int k = 0; k < 8; k++) {
             const int j = jb * 8 + k + 1;
             if (j <= n) {
-                const uint32_t c = (tw >> (4 * k)) & 15u;
-                const uint32_t n0 = (c & 1u) - 1u, n1 = ((c >> 1) & 1u) - 1u, n2 = ((c >> 2) & 1u) - 1u, n3 = ((c >> 3) & 1u) - 1u;
+                const uint32_t c = sym<P>((tw >> (4 * k)) & 15u);
+                uint32_t nk[P];
+#pragma unroll
+                for (int b = 0; b < P; b++) nk[b] = ((c >> b) & 1u) - 1u;
                 uint32_t carry = 0, ph_in = 1u, mh_in = 0u;           // first row: horizontal delta +1
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    const uint32_t eq = (p0[q] ^ n0) & (p1[q] ^ n1) & (p2[q] ^ n2) & (p3[q] ^ n3) & vm[q];
+                    uint32_t eq = pl[0][q] ^ nk[0];
+#pragma unroll
+                    for (int b = 1; b < P; b++) eq &= pl[b][q] ^ nk[b];
                     const uint32_t PV = pv[q], MV = mv[q];
                     const uint32_t xv = eq | MV;
                     // the Q words form ONE wide bit-vector: a single adder carry chain, shifts cross the word borders
@@ -475,7 +503,7 @@ __global__ __launch_bounds__(256) void k_edit_lane(long long count, const uint32
 // (symbol, adder carry, shifted-out plus/minus bits) to lane g+1 through a DPP wave shift.  64/G pairs share a wave, every
 // lane carries 16 words of state, so the per-step overhead is amortised over 512 cells (the 1-block-per-lane systolic kernel
 // pays it per 32 cells).
-template <int G>
+template <int G, int P>
 __global__ __launch_bounds__(256) void k_edit_wide(long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
                                                    const long long* slot_of, int32_t* ed) {
     constexpr int Q = 16;
@@ -491,24 +519,25 @@ __global__ __launch_bounds__(256) void k_edit_wide(long long count, const uint32
     const uint32_t* txt = scratch + pd.txt;
     const int row_base = gl * 512;
     const int rows = m - row_base;                           // rows of this lane that exist (<= 0: lane unused)
-    uint32_t pv[Q], mv[Q], p0[Q], p1[Q], p2[Q], p3[Q], vm[Q];
+    uint32_t pv[Q], mv[Q], pl[P][Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        uint32_t acc[P];
+#pragma unroll
+        for (int b = 0; b < P; b++) acc[b] = 0u;
 #pragma unroll
         for (int wq = 0; wq < 4; wq++) {
             const int row0 = row_base + q * 32 + wq * 8;
             const uint32_t word = (live && row0 < m) ? pat[row0 >> 3] : 0u;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const uint32_t c = (word >> (4 * k)) & 15u;
-                const int b = wq * 8 + k;
-                a0 |= (c & 1u) << b; a1 |= ((c >> 1) & 1u) << b; a2 |= ((c >> 2) & 1u) << b; a3 |= ((c >> 3) & 1u) << b;
+                const uint32_t c = sym<P>((word >> (4 * k)) & 15u);
+#pragma unroll
+                for (int b = 0; b < P; b++) acc[b] |= ((c >> b) & 1u) << (wq * 8 + k);
             }
         }
-        const int rq = rows - q * 32;
-        vm[q] = rq >= 32 ? 0xffffffffu : (rq <= 0 ? 0u : ((1u << rq) - 1u));
-        p0[q] = a0; p1[q] = a1; p2[q] = a2; p3[q] = a3;
+#pragma unroll
+        for (int b = 0; b < P; b++) pl[b][q] = acc[b];
         pv[q] = 0xffffffffu; mv[q] = 0u;
     }
     const int lanes_used = live ? (m + 511) / 512 : 0;
@@ -530,14 +559,18 @@ __global__ __launch_bounds__(256) void k_edit_wide(long long count, const uint32
         for (int k = 0; k < 8; k++) {
             const int st = jb * 8 + k;                       // step; the group's first lane is at text column st
             uint32_t in = dpp_wave_shr1(out);
-            if (gl == 0) in = (st < n) ? (((tw >> (4 * k)) & 15u) | 0x20u | 0x80u) : 0u;      // top row: plus bit 1, no carry
+            if (gl == 0) in = (st < n) ? (sym<P>((tw >> (4 * k)) & 15u) | 0x20u | 0x80u) : 0u;      // top row: plus bit 1, no carry
             if ((in & 0x80u) && gl < lanes_used) {
-                const uint32_t c = in & 15u;
-                const uint32_t n0 = (c & 1u) - 1u, n1 = ((c >> 1) & 1u) - 1u, n2 = ((c >> 2) & 1u) - 1u, n3 = ((c >> 3) & 1u) - 1u;
+                const uint32_t c = in & 15u;                 // already mapped by the feeder lane
+                uint32_t nk[P];
+#pragma unroll
+                for (int b = 0; b < P; b++) nk[b] = ((c >> b) & 1u) - 1u;
                 uint32_t carry = (in >> 4) & 1u, ph_in = (in >> 5) & 1u, mh_in = (in >> 6) & 1u;
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    const uint32_t eq = (p0[q] ^ n0) & (p1[q] ^ n1) & (p2[q] ^ n2) & (p3[q] ^ n3) & vm[q];
+                    uint32_t eq = pl[0][q] ^ nk[0];
+#pragma unroll
+                    for (int b = 1; b < P; b++) eq &= pl[b][q] ^ nk[b];
                     const uint32_t PV = pv[q], MV = mv[q];
                     const uint32_t xv = eq | MV;
                     const unsigned long long sum = (unsigned long long)(eq & PV) + (unsigned long long)PV + (unsigned long long)carry;
@@ -578,27 +611,30 @@ __device__ __forceinline__ void myers_block(uint32_t eq, uint32_t& pv, uint32_t&
 
 // Exact distance between pat (length m >= 1, the shorter) and txt (length n >= m); whole wave cooperates.
 // R = 32-row blocks per lane held in registers (m <= 64*32*R).
-template <int R>
+template <int R, int P>
 __device__ int systolic_distance(const Packed& pat, int m, const Packed& txt, int n) {
     const int lane = lane_id();
     const int nb = (m + 31) >> 5;
-    uint32_t pl[R][4], vm[R], pv[R], mv[R], top[R];
+    uint32_t pl[R][P], pv[R], mv[R], top[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int blk = lane * R + r;
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, v = 0;
+        uint32_t acc[P];
+#pragma unroll
+        for (int b = 0; b < P; b++) acc[b] = 0u;
         if (blk < nb) {
             const int row0 = blk << 5;
             for (int i = 0; i < 32; i++) {
                 const int row = row0 + i;
                 if (row < m) {
-                    const uint32_t c = pat.at(row);
-                    a0 |= (c & 1u) << i; a1 |= ((c >> 1) & 1u) << i; a2 |= ((c >> 2) & 1u) << i; a3 |= ((c >> 3) & 1u) << i;
-                    v |= 1u << i;
+                    const uint32_t c = sym<P>(pat.at(row));
+#pragma unroll
+                    for (int b = 0; b < P; b++) acc[b] |= ((c >> b) & 1u) << i;
                 }
             }
         }
-        pl[r][0] = a0; pl[r][1] = a1; pl[r][2] = a2; pl[r][3] = a3; vm[r] = v;
+#pragma unroll
+        for (int b = 0; b < P; b++) pl[r][b] = acc[b];
         pv[r] = 0xffffffffu; mv[r] = 0u;
         top[r] = (blk == nb - 1) ? (1u << ((m - 1) & 31)) : 0x80000000u;
     }
@@ -619,15 +655,19 @@ __device__ int systolic_distance(const Packed& pat, int m, const Packed& txt, in
             if (t >= steps) break;
             uint32_t in = dpp_wave_shr1(out);
             const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)tc, j);
-            if (lane == 0) in = (t < n) ? (c0 | 0x10u | 0x40u) : 0u;       // top row: horizontal delta +1
+            if (lane == 0) in = (t < n) ? (sym<P>(c0) | 0x10u | 0x40u) : 0u;       // top row: horizontal delta +1
             if ((in & 0x40u) && lane < lanes_used) {
                 const uint32_t c = in & 15u;
-                const uint32_t n0 = (c & 1u) - 1u, n1 = ((c >> 1) & 1u) - 1u, n2 = ((c >> 2) & 1u) - 1u, n3 = ((c >> 3) & 1u) - 1u;
+                uint32_t nk[P];
+#pragma unroll
+                for (int b = 0; b < P; b++) nk[b] = ((c >> b) & 1u) - 1u;
                 uint32_t hp = (in >> 4) & 1u, hm = (in >> 5) & 1u;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     if (lane * R + r < nb) {
-                        const uint32_t eq = (pl[r][0] ^ n0) & (pl[r][1] ^ n1) & (pl[r][2] ^ n2) & (pl[r][3] ^ n3) & vm[r];
+                        uint32_t eq = pl[r][0] ^ nk[0];
+#pragma unroll
+                        for (int b = 1; b < P; b++) eq &= pl[r][b] ^ nk[b];
                         myers_block(eq, pv[r], mv[r], hp, hm, top[r]);
                         if (lane == last_lane && r == last_r) score += (int)hp - (int)hm;
                     }
@@ -703,19 +743,20 @@ __device__ int systolic_distance_big(const Packed& pat, int m, const Packed& txt
 }
 
 // one wave per pair of the FULL class; pairs with more than 16384 rows are deferred to k_edit_full_big
+template <int P>
 __global__ __launch_bounds__(256) void k_edit_full(long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
                                                    const long long* slot_of, int32_t* ed, unsigned long long* n_big, uint32_t* big_list) {
     const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= count) return;
     const uint32_t widx = list[t];
     const PairDesc pd = desc[widx];
-    Packed P{scratch + pd.pat}, T{scratch + pd.txt};
+    Packed PP{scratch + pd.pat}, T{scratch + pd.txt};
     const int nb = (pd.m + 31) >> 5;
     int d;
-    if (nb <= 64) d = systolic_distance<1>(P, pd.m, T, pd.n);
-    else if (nb <= 128) d = systolic_distance<2>(P, pd.m, T, pd.n);
-    else if (nb <= 256) d = systolic_distance<4>(P, pd.m, T, pd.n);
-    else if (nb <= 512) d = systolic_distance<8>(P, pd.m, T, pd.n);
+    if (nb <= 64) d = systolic_distance<1, P>(PP, pd.m, T, pd.n);
+    else if (nb <= 128) d = systolic_distance<2, P>(PP, pd.m, T, pd.n);
+    else if (nb <= 256) d = systolic_distance<4, P>(PP, pd.m, T, pd.n);
+    else if (nb <= 512) d = systolic_distance<8, P>(PP, pd.m, T, pd.n);
     else { if (lane_id() == 0) { const unsigned long long i = atomicAdd(n_big, 1ull); big_list[i] = widx; } return; }
     if (lane_id() == 0) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
 }
@@ -736,10 +777,10 @@ __global__ void k_slots(long long n_work, PairSource src, long long* slot_of) {
     if (w < n_work) slot_of[w] = src.slot(w);
 }
 
-// class boundaries in the sorted key array: first index whose class >= c, for c = 0..N_CLASSES
+// class boundaries in the sorted key array: first index whose sort class >= c, for c = 0..N_SORT_CLASSES
 __global__ void k_class_bounds(const uint64_t* keys, long long n, long long* bounds) {
     const int c = threadIdx.x;
-    if (c > N_CLASSES) return;
+    if (c > N_SORT_CLASSES) return;
     long long lo = 0, hi = n;
     while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)(keys[mid] >> 32) < c) lo = mid + 1; else hi = mid; }
     bounds[c] = lo;
@@ -758,8 +799,10 @@ static void profile_round(svx_ctx* c, int round, const long long* bounds, const 
     std::vector<PairDesc> desc((size_t)mx + 1);
     if (hipMemcpyAsync(desc.data(), desc_dev, ((size_t)mx + 1) * sizeof(PairDesc), hipMemcpyDeviceToHost, st) != hipSuccess) return;
     (void)hipStreamSynchronize(st);
-    for (int cls = 0; cls < N_CLASSES; cls++) {
-        const long long lo = bounds[cls], cn = bounds[cls + 1] - lo;
+    for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
+        const int cls = sc & 15, generic = sc >> 4;
+        if (cls >= N_CLASSES) continue;
+        const long long lo = bounds[sc], cn = bounds[sc + 1] - lo;
         if (cn <= 0) continue;
         int words = 0, per_wave = 64;                       // 32-bit words of column state per pair; pairs per wave
         if (cls <= 4) words = 1 << cls;
@@ -776,8 +819,8 @@ static void profile_round(svx_ctx* c, int round, const long long* bounds, const 
             }
             if (cls != CLS_FULL) issued += (double)nmax * words * per_wave;
         }
-        fprintf(stderr, "{\"edit_profile\": {\"round\": %d, \"cls\": %d, \"pairs\": %lld, \"mean_m\": %.1f, \"mean_n\": %.1f, \"word_cols_useful\": %.4g, \"word_cols_issued\": %.4g}}\n",
-                round, cls, cn, sum_m / cn, sum_n / cn, useful, issued);
+        fprintf(stderr, "{\"edit_profile\": {\"round\": %d, \"cls\": %d, \"generic\": %d, \"pairs\": %lld, \"mean_m\": %.1f, \"mean_n\": %.1f, \"word_cols_useful\": %.4g, \"word_cols_issued\": %.4g}}\n",
+                round, cls, generic, cn, sum_m / cn, sum_n / cn, useful, issued);
     }
 }
 
@@ -798,12 +841,12 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     SVXCHK(c->e_desc.reserve((size_t)n_work * sizeof(PairDesc)));
     SVXCHK(c->e_key.reserve((size_t)n_work * 8 * 2)); SVXCHK(c->e_val.reserve((size_t)n_work * 4 * 3));
     SVXCHK(c->e_slot.reserve((size_t)n_work * 8));
-    SVXCHK(c->e_fail.reserve((size_t)n_work * (4 + 8) + 256 + 64));
+    SVXCHK(c->e_fail.reserve((size_t)n_work * (4 + 8) + 1024 + 64));
     uint64_t* key_a = c->e_key.as<uint64_t>(); uint64_t* key_b = key_a + n_work;
     uint32_t* val_a = c->e_val.as<uint32_t>(); uint32_t* val_b = val_a + n_work;
     long long* slot_of = c->e_slot.as<long long>();
-    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(c->e_fail.as<char>());           // [0] fails, [1] big, [8..15] bounds
-    uint32_t* fail_list = reinterpret_cast<uint32_t*>(cnt + 32);
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(c->e_fail.as<char>());           // [0] fails, [1] big, [8..40] class bounds
+    uint32_t* fail_list = reinterpret_cast<uint32_t*>(cnt + 64);
     uint64_t* fail_key = reinterpret_cast<uint64_t*>(fail_list + ((n_work + 1) & ~1ll));
     PairDesc* desc = c->e_desc.as<PairDesc>();
     uint32_t* scratch = c->e_scratch.as<uint32_t>();
@@ -831,60 +874,63 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         SVXCHK(svx_sort_pairs_u64(c, keys_in, key_b, vals_in, list, pending, 0, 40));
         k_class_bounds<<<1, 64, 0, st>>>(key_b, pending, reinterpret_cast<long long*>(cnt + 8));
         HIPCHK(hipMemsetAsync(cnt, 0, 8, st));
-        long long bounds[N_CLASSES + 1];
-        HIPCHK(hipMemcpyAsync(bounds, cnt + 8, (N_CLASSES + 1) * 8, hipMemcpyDeviceToHost, st));
+        long long bounds[N_SORT_CLASSES + 1];
+        HIPCHK(hipMemcpyAsync(bounds, cnt + 8, (N_SORT_CLASSES + 1) * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (profile) profile_round(c, round, bounds, list, desc, pending);
         bool band_used[5] = {false, false, false, false, false};
-        for (int cls = 4; cls >= 0; cls--) {
-            const long long lo = bounds[cls], cn = bounds[cls + 1] - lo;
-            if (cn <= 0) continue;
-            const unsigned grid = (unsigned)((cn + T - 1) / T);
-            hipStream_t ks = band_st[cls];
-            band_used[cls] = true;
-            switch (cls) {
-                case 0: k_edit_band<1><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
-                case 1: k_edit_band<2><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
-                case 2: k_edit_band<4><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
-                case 3: k_edit_band<8><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
-                default: k_edit_band<16><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key); break;
+#define EDIT_LAUNCH(KERNEL, ...) do { if (generic) KERNEL, 4> __VA_ARGS__; else KERNEL, 2> __VA_ARGS__; HIPCHK(hipGetLastError()); } while (0)
+        for (int generic = 0; generic <= 1; generic++) {
+            const long long* bd = bounds + 16 * generic;
+            for (int cls = 4; cls >= 0; cls--) {
+                const long long lo = bd[cls], cn = bd[cls + 1] - lo;
+                if (cn <= 0) continue;
+                const unsigned grid = (unsigned)((cn + T - 1) / T);
+                hipStream_t ks = band_st[cls];
+                band_used[cls] = true;
+                switch (cls) {
+                    case 0: EDIT_LAUNCH(k_edit_band<1, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key)); break;
+                    case 1: EDIT_LAUNCH(k_edit_band<2, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key)); break;
+                    case 2: EDIT_LAUNCH(k_edit_band<4, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key)); break;
+                    case 3: EDIT_LAUNCH(k_edit_band<8, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key)); break;
+                    default: EDIT_LAUNCH(k_edit_band<16, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key)); break;
+                }
             }
-            HIPCHK(hipGetLastError());
-        }
-        {   // systolic full-matrix class (one wave per pair); pairs beyond 16384 rows are listed for k_edit_full_big
-            const long long lo = bounds[5], cn = bounds[6] - lo;
-            if (cn > 0) {
-                k_edit_full<<<(unsigned)((cn + 3) / 4), 256, 0, full_st[8]>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
-                HIPCHK(hipGetLastError());
+            {   // systolic full-matrix class (one wave per pair); pairs beyond 16384 rows are listed for k_edit_full_big
+                const long long lo = bd[CLS_FULL], cn = bd[CLS_FULL + 1] - lo;
+                if (cn > 0) {
+                    if (generic) k_edit_full<4><<<(unsigned)((cn + 3) / 4), 256, 0, full_st[8]>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
+                    else k_edit_full<2><<<(unsigned)((cn + 3) / 4), 256, 0, full_st[8]>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
+                    HIPCHK(hipGetLastError());
+                }
+            }
+            for (int wc = 2; wc >= 0; wc--) {                      // G lanes per pair, full matrix
+                const long long lo = bd[CLS_WIDE0 + wc], cn = bd[CLS_WIDE0 + wc + 1] - lo;
+                if (cn <= 0) continue;
+                const int G = 2 << wc;
+                const unsigned grid = (unsigned)((cn * G + T - 1) / T);
+                hipStream_t ks = full_st[5 + wc];
+                switch (wc) {
+                    case 0: EDIT_LAUNCH(k_edit_wide<2, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
+                    case 1: EDIT_LAUNCH(k_edit_wide<4, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
+                    default: EDIT_LAUNCH(k_edit_wide<8, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
+                }
+            }
+            for (int lc = 4; lc >= 0; lc--) {                      // whole-pattern-in-a-lane classes
+                const long long lo = bd[CLS_LANE0 + lc], cn = bd[CLS_LANE0 + lc + 1] - lo;
+                if (cn <= 0) continue;
+                const unsigned grid = (unsigned)((cn + T - 1) / T);
+                hipStream_t ks = full_st[lc];
+                switch (lc) {
+                    case 0: EDIT_LAUNCH(k_edit_lane<1, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
+                    case 1: EDIT_LAUNCH(k_edit_lane<2, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
+                    case 2: EDIT_LAUNCH(k_edit_lane<4, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
+                    case 3: EDIT_LAUNCH(k_edit_lane<8, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
+                    default: EDIT_LAUNCH(k_edit_lane<16, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
+                }
             }
         }
-        for (int wc = 2; wc >= 0; wc--) {                      // G lanes per pair, full matrix
-            const long long lo = bounds[CLS_WIDE0 + wc], cn = bounds[CLS_WIDE0 + wc + 1] - lo;
-            if (cn <= 0) continue;
-            const int G = 2 << wc;
-            const unsigned grid = (unsigned)((cn * G + T - 1) / T);
-            hipStream_t ks = full_st[5 + wc];
-            switch (wc) {
-                case 0: k_edit_wide<2><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
-                case 1: k_edit_wide<4><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
-                default: k_edit_wide<8><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
-            }
-            HIPCHK(hipGetLastError());
-        }
-        for (int lc = 4; lc >= 0; lc--) {                      // whole-pattern-in-a-lane classes
-            const long long lo = bounds[CLS_LANE0 + lc], cn = bounds[CLS_LANE0 + lc + 1] - lo;
-            if (cn <= 0) continue;
-            const unsigned grid = (unsigned)((cn + T - 1) / T);
-            hipStream_t ks = full_st[lc];
-            switch (lc) {
-                case 0: k_edit_lane<1><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
-                case 1: k_edit_lane<2><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
-                case 2: k_edit_lane<4><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
-                case 3: k_edit_lane<8><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
-                default: k_edit_lane<16><<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev); break;
-            }
-            HIPCHK(hipGetLastError());
-        }
+#undef EDIT_LAUNCH
         // only the band kernels can hand pairs to the next round
         for (int cls = 0; cls <= 4; cls++) if (band_used[cls]) HIPCHK(hipStreamSynchronize(band_st[cls]));
         unsigned long long h0 = 0;
