@@ -100,14 +100,14 @@ struct DevClusters {
     DevBuf type, contig, start, end, contig2, start2, end2, aux, score, std_span, std_pos, size, member_off, members, part_index;
 };
 
-#define SVX_N_AUX 7
+#define SVX_N_AUX 4
 
 struct svx_ctx {
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev[16];
-    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..2] high priority (band classes), [3..6] low (full-matrix classes)
+    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] high priority (band classes), [2..3] low (full-matrix classes)
     // device copies of a host-resident batch
     std::vector<DevBuf> batch_bufs;
     // COLLECT results
@@ -126,7 +126,8 @@ struct svx_ctx {
     DevBuf k_hi, k_lo, k_idx, k_hi2, k_lo2, k_idx2, part_flag, part_id, part_start, part_meta, samp_idx, large_list, samp_stream;
     DevBuf cell_shards;
     DevBuf pair_off, ed, work, stage, stage_members, labels;
-    DevBuf e_words, e_off, e_scratch, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off;     // edit-distance pipeline
+    DevBuf e_words, e_off, e_scratch, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off;
+    DevBuf e_retry[3];              // per-class retry lists of the edit-distance rounds (rotating)     // edit-distance pipeline
     DevClusters clu;
     int shard_rank = 0, shard_world = 1, shard_mode = 0;
     DevBuf shard_prefix;            // origin prefix (world+1 int64) for by-origin sharding

@@ -138,13 +138,14 @@ __device__ __forceinline__ unsigned long long work_key(int cls, int m, int n);
 __device__ __forceinline__ int full_class_for(int m);
 __device__ __forceinline__ int lane_class_for(int m) { return m <= 32 ? 0 : m <= 64 ? 1 : m <= 128 ? 2 : m <= 256 ? 3 : 4; }
 
-__device__ __forceinline__ int band_class_for(int need_w) {      // smallest class whose window keeps the needed margin after dmax is aligned to 7 (mod 8)
-    const int w = need_w + 14;
-    if (w <= 32) return 0;
-    if (w <= 64) return 1;
-    if (w <= 128) return 2;
-    if (w <= 256) return 3;
-    if (w <= 512) return 4;
+__device__ __forceinline__ int band_class_for(int need_w) {      // smallest class whose window keeps the needed margin
+    // classes 0..2 (sliding window, d_edit_band): 14 diagonals are lost to the alignment of dmax to 7 (mod 8);
+    // classes 3, 4 (staircase window, d_edit_stair): the window stands still for 32 columns, which costs 32 more diagonals
+    if (need_w + 14 <= 32) return 0;
+    if (need_w + 14 <= 64) return 1;
+    if (need_w + 14 <= 128) return 2;
+    if (need_w + 46 <= 256) return 3;
+    if (need_w + 46 <= 512) return 4;
     return CLS_FULL;
 }
 // window that guarantees exactness when the true distance is <= ub
@@ -169,6 +170,26 @@ __device__ __forceinline__ int full_class_for(int m) {
     if (m <= 4096) return CLS_WIDE0 + 2;
     return CLS_FULL;
 }
+
+// one column of the multi-word recurrence; returns (plus, minus) bits pushed out of the last word in bit 31 of ph_top / mh_top
+#define MYERS_COLUMN(Q_, P_, pl_, pv_, mv_, nk_, carry_, ph_prev_, mh_prev_)                                   \
+    _Pragma("unroll") for (int q = 0; q < Q_; q++) {                                                            \
+        uint32_t eq = pl_[0][q] ^ nk_[0];                                                                       \
+        _Pragma("unroll") for (int b = 1; b < P_; b++) eq &= pl_[b][q] ^ nk_[b];                                \
+        const uint32_t PV = pv_[q], MV = mv_[q];                                                                \
+        const uint32_t xv = eq | MV;                                                                            \
+        unsigned carry_out;                                                                                     \
+        const uint32_t sum = __builtin_addc(eq & PV, PV, carry_, &carry_out);      /* v_addc_co_u32: the carry stays in an SGPR pair */ \
+        carry_ = carry_out;                                                                                     \
+        const uint32_t xh = (sum ^ PV) | eq;                                                                    \
+        const uint32_t ph = MV | ~(xh | PV);                                                                    \
+        const uint32_t mh = PV & xh;                                                                            \
+        const uint32_t phs = __builtin_amdgcn_alignbit(ph, ph_prev_, 31);          /* (ph << 1) | top bit of the word below */ \
+        const uint32_t mhs = __builtin_amdgcn_alignbit(mh, mh_prev_, 31);                                       \
+        ph_prev_ = ph; mh_prev_ = mh;                                                                           \
+        pv_[q] = mhs | ~(xv | phs);                                                                             \
+        mv_[q] = phs & xv;                                                                                      \
+    }
 
 // ---- 1. scratch sizing --------------------------------------------------------------------------------------
 __global__ void k_pair_words(long long n_work, PairSource src, int64_t* words) {
@@ -279,14 +300,33 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     }
 }
 
+// a band kernel could not certify its result: d (a valid alignment cost, hence an upper bound) picks the next class
+__device__ __forceinline__ void band_retry(const PairDesc& pd, uint32_t widx, int m, int n, int d, PairDesc* desc, unsigned long long* fail_cnt,
+                                           uint32_t* fail_lists, long long fail_cap) {
+    const int ub = d < pd.ub ? d : pd.ub;
+    const int cur = pd.cls & 0xff;
+    int cls = band_class_for(need_window(m, n, ub));   // cannot fail, but d from a too-narrow band can be a gross over-estimate:
+    if (cls > cur + 1) cls = cur + 1;                  // widen geometrically instead
+    if (cls <= cur) cls = cur + 1;                     // never retry the same width (can only differ by the alignment slack)
+    if (cls > 4) cls = CLS_FULL;
+    if (m <= 512 && lane_class_for(m) <= cls) cls = CLS_LANE0 + lane_class_for(m);
+    else if (cls == CLS_FULL) cls = full_class_for(m);
+    const int flagged = cls | (pd.cls & CLS_GENERIC);
+    desc[widx].ub = ub; desc[widx].cls = flagged;
+    // retry list of the new class (the lists of a round are consumed as they are: no re-sort between rounds)
+    const unsigned long long sc = sort_class(flagged);
+    const unsigned long long i = atomicAdd(fail_cnt + sc, 1ull);
+    fail_lists[sc * (unsigned long long)fail_cap + i] = widx;
+}
+
 // ---- 3. banded lane-per-pair kernel -----------------------------------------------------------------------------
 // Window of W = 32*Q bits; bit b of column j <-> row (j - dmax) + b.  dmax = 7 (mod 8) so that the row entering at the
 // bottom of the window and the text symbol of the column sit at the same nibble phase of their packed words.
 template <int Q, int P>
-__global__ __launch_bounds__(256) void k_edit_band(long long count, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
-                                                   const long long* slot_of, int32_t* ed, unsigned long long* n_fail, uint32_t* fail_list,
-                                                   uint64_t* fail_key) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void d_edit_band(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
+                                                   const long long* slot_of, int32_t* ed, unsigned long long* fail_cnt, uint32_t* fail_lists,
+                                                   long long fail_cap) {
+    const long long t = blk * 256 + threadIdx.x;
     const bool live = t < count;
     uint32_t widx = 0;
     PairDesc pd; pd.m = 0; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
@@ -367,9 +407,10 @@ __global__ __launch_bounds__(256) void k_edit_band(long long count, const uint32
                     for (int b = 1; b < P; b++) eq &= pl[b][q] ^ nk[b];
                     const uint32_t PV = pv[q], MV = mv[q];
                     const uint32_t xv = eq | MV;
-                    const unsigned long long sum = (unsigned long long)(eq & PV) + (unsigned long long)PV + (unsigned long long)carry;
-                    carry = (uint32_t)(sum >> 32);
-                    const uint32_t xh = (((uint32_t)sum) ^ PV) | eq;
+                    unsigned carry_out;
+                    const uint32_t sum = __builtin_addc(eq & PV, PV, carry, &carry_out);      // v_addc_co_u32: the carry stays in an SGPR pair
+                    carry = carry_out;
+                    const uint32_t xh = (sum ^ PV) | eq;
                     uint32_t ph = MV | ~(xh | PV);
                     uint32_t mh = PV & xh;
                     if (q == 0) S += (int)(ph & 1u) - (int)(mh & 1u);
@@ -396,22 +437,143 @@ __global__ __launch_bounds__(256) void k_edit_band(long long count, const uint32
     }
     const int x = (d - (n - m)) >> 1;                    // floor: d >= n-m always
     if (margin >= 0 && x >= 0 && x <= margin) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
-    else {
-        // d is a valid alignment cost, hence an upper bound: the band it guarantees succeeds next time
-        const int ub = d < pd.ub ? d : pd.ub;
-        const int cur = pd.cls & 0xff;
-        int cls = band_class_for(need_window(m, n, ub));   // cannot fail, but d from a too-narrow band can be a gross over-estimate:
-        if (cls > cur + 1) cls = cur + 1;                  // widen geometrically instead
-        if (cls <= cur) cls = cur + 1;                     // never retry the same width (can only differ by the alignment slack)
-        if (cls > 4) cls = CLS_FULL;
-        if (m <= 512 && lane_class_for(m) <= cls) cls = CLS_LANE0 + lane_class_for(m);
-        else if (cls == CLS_FULL) cls = full_class_for(m);
-        const int flagged = cls | (pd.cls & CLS_GENERIC);
-        desc[widx].ub = ub; desc[widx].cls = flagged;
-        const unsigned long long i = atomicAdd(n_fail, 1ull);
-        fail_list[i] = widx;
-        fail_key[i] = (sort_class(flagged) << 32) | work_key(cls, m, n);
+    else band_retry(pd, widx, m, n, d, desc, fail_cnt, fail_lists, fail_cap);
+}
+
+// ---- 3a. banded lane-per-pair kernel, staircase window (classes 3, 4) ------------------------------------------------------
+// Sliding the window one row per column costs four v_alignbit per state word and column - and v_alignbit is a half-rate
+// instruction on gfx950 (4 cycles per wave64 against 2 for v_xor / v_bitop3; tools/micro/valu_ops.hip), 44 % of the sliding
+// kernel's cycles.  Here the window of W = 32*Q rows stands still for a block of 32 columns and then drops by one whole word:
+// the per-column work is the plain multi-word Myers/Hyyro update, the drop is 4*Q register moves plus one bit-plane word
+// built from 4 packed pattern words.  Block kb (columns 32*kb+1 .. 32*kb+32) covers rows 32*kb-off .. 32*kb-off+W-1; the
+// row above the window is assumed to step +1 per column and a word entering at the bottom to step +1 per row (both upper
+// bounds, exact in the virtual rows <= 0).  A path of cost d leaves the corridor of diagonals [0, n-m] by at most
+// x = floor((d-(n-m))/2) on either side, so the result is exact iff x <= min(W-off-33, off+1-(n-m)); off = 7 (mod 8) keeps
+// the pattern words that enter aligned.
+__device__ __forceinline__ uint32_t squeeze8(uint32_t x) {       // bits 0,4,..,28 -> bits 0..7
+    x = (x | (x >> 3)) & 0x03030303u;
+    x = (x | (x >> 6)) & 0x000f000fu;
+    return (x | (x >> 12)) & 0xffu;
+}
+template <int P>
+__device__ __forceinline__ void planes8(uint32_t w, uint32_t (&out)[P]) {       // one packed word (8 symbols) -> 8 bits of each plane
+    if (P == 2) {
+        out[0] = squeeze8(((w >> 1) | (w >> 3)) & 0x11111111u);
+        out[1] = squeeze8(((w >> 2) | (w >> 3)) & 0x11111111u);
+    } else {
+#pragma unroll
+        for (int b = 0; b < P; b++) out[b] = squeeze8((w >> b) & 0x11111111u);
     }
+}
+
+// bit-plane words of 32 rows given as 4 packed words.  Deliberately NOT inlined: unrolled into the Q-word set-up loops it drives the
+// kernels' register allocation up (155 -> fewer waves per SIMD) for code that runs once per pair / once per 32 columns.
+template <int P>
+__device__ __attribute__((noinline)) void planes32(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t (&out)[P]) {
+    uint32_t e0[P], e1[P], e2[P], e3[P];
+    planes8<P>(w0, e0); planes8<P>(w1, e1); planes8<P>(w2, e2); planes8<P>(w3, e3);
+#pragma unroll
+    for (int b = 0; b < P; b++) out[b] = e0[b] | (e1[b] << 8) | (e2[b] << 16) | (e3[b] << 24);
+}
+
+template <int Q, int P>
+__device__ __forceinline__ void d_edit_stair(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
+                                             const long long* slot_of, int32_t* ed, unsigned long long* fail_cnt, uint32_t* fail_lists,
+                                             long long fail_cap) {
+    const long long t = blk * 256 + threadIdx.x;
+    const bool live = t < count;
+    uint32_t widx = 0;
+    PairDesc pd; pd.m = 1; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
+    if (live) { widx = list[t]; pd = desc[widx]; }
+    const int W = 32 * Q;
+    const int m = pd.m, n = live ? pd.n : 0;
+    const int delta = n - m;
+    int off = (W - 34 + delta) / 2;
+    if (off < 7) off = 7;
+    off -= ((off - 7) & 7);
+    const int margin_lo = W - off - 33, margin_up = off + 1 - delta;
+    const int margin = margin_lo < margin_up ? margin_lo : margin_up;
+    const uint32_t* pat = scratch + pd.pat;
+    const uint32_t* txt = scratch + pd.txt;
+    const int pat_words = (m + 7) >> 3, txt_words = (n + 7) >> 3;
+    const int w0 = -((off + 1) >> 3);                   // packed pattern word that holds bit 0 of the window (row -off)
+    auto pat_word = [&](int idx) -> uint32_t { return (live && idx >= 0 && idx < pat_words) ? pat[idx] : 0u; };
+    uint32_t pv[Q], mv[Q], pl[P][Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int nvirt = off + 1 - 32 * q;             // bits of this word that are rows <= 0: vertical delta -1
+        const uint32_t mlow = nvirt >= 32 ? 0xffffffffu : (nvirt <= 0 ? 0u : ((1u << nvirt) - 1u));
+        mv[q] = mlow; pv[q] = ~mlow;
+        uint32_t acc[P];
+        planes32<P>(pat_word(w0 + 4 * q), pat_word(w0 + 4 * q + 1), pat_word(w0 + 4 * q + 2), pat_word(w0 + 4 * q + 3), acc);
+#pragma unroll
+        for (int b = 0; b < P; b++) pl[b][q] = acc[b];
+    }
+    int top = off + 1;                                   // D[row above the window][column]
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
+    uint32_t tw_next[4], pw_next[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        tw_next[i] = (live && i < txt_words) ? txt[i] : 0u;
+        pw_next[i] = pat_word(w0 + 4 * Q + i);
+    }
+    for (int kb = 0; kb * 32 < nmax; kb++) {
+        uint32_t tw[4];
+        if (kb > 0 && kb * 32 < n) {
+            // the window drops 32 rows: word 0 leaves (its deltas move into `top`), a fresh word enters at the bottom
+            top += __popc(pv[0]) - __popc(mv[0]);
+#pragma unroll
+            for (int q = 0; q < Q - 1; q++) {
+                pv[q] = pv[q + 1]; mv[q] = mv[q + 1];
+#pragma unroll
+                for (int b = 0; b < P; b++) pl[b][q] = pl[b][q + 1];
+            }
+            pv[Q - 1] = 0xffffffffu; mv[Q - 1] = 0u;
+            uint32_t acc[P];
+            planes32<P>(pw_next[0], pw_next[1], pw_next[2], pw_next[3], acc);
+#pragma unroll
+            for (int b = 0; b < P; b++) pl[b][Q - 1] = acc[b];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            tw[i] = tw_next[i];
+            const int ti = 4 * (kb + 1) + i;
+            tw_next[i] = (live && ti < txt_words) ? txt[ti] : 0u;
+            pw_next[i] = pat_word(w0 + 4 * (kb + Q) + i);           // enters when the window drops into block kb + 1
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int j = kb * 32 + i * 8 + k + 1;
+                if (j <= n) {
+                    const uint32_t c = sym<P>((tw[i] >> (4 * k)) & 15u);
+                    uint32_t nk[P];
+#pragma unroll
+                    for (int b = 0; b < P; b++) nk[b] = ((c >> b) & 1u) - 1u;
+                    top += 1;
+                    unsigned carry = 0;
+                    uint32_t ph_prev = 0x80000000u, mh_prev = 0u;          // the row above the window steps +1
+                    MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
+                }
+            }
+        }
+    }
+    if (!live) return;
+    // D[m][n] = D[row above the window][n] + vertical deltas of window bits 0 .. (m - first row of the last block)
+    const int bm = m - (((n - 1) >> 5) * 32 - off);
+    int d = top;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int hi_bit = bm - 32 * q;
+        const uint32_t mask = hi_bit >= 31 ? 0xffffffffu : (hi_bit < 0 ? 0u : ((2u << hi_bit) - 1u));
+        d += __popc(pv[q] & mask) - __popc(mv[q] & mask);
+    }
+    const int x = (d - delta) >> 1;
+    if (margin >= 0 && bm >= 0 && bm < W && x >= 0 && x <= margin) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
+    else band_retry(pd, widx, m, n, (margin >= 0 && bm >= 0 && bm < W) ? d : pd.ub, desc, fail_cnt, fail_lists, fail_cap);
 }
 
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
@@ -420,10 +582,26 @@ __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
 }
 
 // ---- 3b. whole pattern in one lane (m <= 32*Q), full matrix: plain multi-word Myers, 64 pairs per wave ----------
+// The pattern is BOTTOM-aligned: row m is bit 31 of the last word, the 32*Q - m bits above row 1 are virtual rows <= 0
+// (D[r][j] = j - r: vertical delta -1, horizontal +1 - a match there changes nothing).  The horizontal delta of row m is then
+// simply the bit the shifts push out of the last word: no per-word test for "the word that holds row m".
+// 8 symbols starting at symbol index s (any alignment, may be negative) of a packed string of n_words words; outside -> 0
+__device__ __forceinline__ uint32_t packed8_at(const uint32_t* w, int n_words, int s, bool live) {
+    const int i = s >> 3, sh = (s & 7) * 4;
+    const uint32_t lo = (live && i >= 0 && i < n_words) ? w[i] : 0u;
+    const uint32_t hi = (live && sh && i + 1 >= 0 && i + 1 < n_words) ? w[i + 1] : 0u;
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+// bit-plane words of the 32 rows whose first pattern symbol index is s
+template <int P>
+__device__ __forceinline__ void planes32_at(const uint32_t* w, int n_words, int s, bool live, uint32_t (&out)[P]) {
+    planes32<P>(packed8_at(w, n_words, s, live), packed8_at(w, n_words, s + 8, live), packed8_at(w, n_words, s + 16, live), packed8_at(w, n_words, s + 24, live), out);
+}
+
 template <int Q, int P>
-__global__ __launch_bounds__(256) void k_edit_lane(long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
-                                                   const long long* slot_of, int32_t* ed) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void d_edit_lane(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
+                                            const long long* slot_of, int32_t* ed) {
+    const long long t = blk * 256 + threadIdx.x;
     const bool live = t < count;
     uint32_t widx = 0;
     PairDesc pd; pd.m = 1; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
@@ -431,29 +609,19 @@ __global__ __launch_bounds__(256) void k_edit_lane(long long count, const uint32
     const int m = pd.m, n = live ? pd.n : 0;
     const uint32_t* pat = scratch + pd.pat;
     const uint32_t* txt = scratch + pd.txt;
-    uint32_t pv[Q], mv[Q], pl[P][Q];       // rows beyond m compute garbage that never reaches row m (all dependencies point down the column)
+    const int pat_words = (m + 7) >> 3;
+    const int pad = 32 * Q - m;                          // virtual rows above row 1
+    uint32_t pv[Q], mv[Q], pl[P][Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        uint32_t acc[P];
+        const int nvirt = pad - 32 * q;
+        const uint32_t mlow = nvirt >= 32 ? 0xffffffffu : (nvirt <= 0 ? 0u : ((1u << nvirt) - 1u));
+        mv[q] = mlow; pv[q] = ~mlow;
+        uint32_t e[P];
+        planes32_at<P>(pat, pat_words, 32 * q - pad, live, e);
 #pragma unroll
-        for (int b = 0; b < P; b++) acc[b] = 0u;
-#pragma unroll
-        for (int wq = 0; wq < 4; wq++) {                 // 4 packed words = 32 rows
-            const int row0 = q * 32 + wq * 8;
-            const uint32_t word = (live && row0 < m) ? pat[(row0 >> 3)] : 0u;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t c = sym<P>((word >> (4 * k)) & 15u);
-#pragma unroll
-                for (int b = 0; b < P; b++) acc[b] |= ((c >> b) & 1u) << (wq * 8 + k);
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < P; b++) pl[b][q] = acc[b];
-        pv[q] = 0xffffffffu; mv[q] = 0u;
+        for (int b = 0; b < P; b++) pl[b][q] = e[b];
     }
-    const int lastq = (m - 1) >> 5;
-    const uint32_t topbit = 1u << ((m - 1) & 31);
     int score = m;
     int nmax = n;
 #pragma unroll
@@ -471,27 +639,10 @@ __global__ __launch_bounds__(256) void k_edit_lane(long long count, const uint32
                 uint32_t nk[P];
 #pragma unroll
                 for (int b = 0; b < P; b++) nk[b] = ((c >> b) & 1u) - 1u;
-                uint32_t carry = 0, ph_in = 1u, mh_in = 0u;           // first row: horizontal delta +1
-#pragma unroll
-                for (int q = 0; q < Q; q++) {
-                    uint32_t eq = pl[0][q] ^ nk[0];
-#pragma unroll
-                    for (int b = 1; b < P; b++) eq &= pl[b][q] ^ nk[b];
-                    const uint32_t PV = pv[q], MV = mv[q];
-                    const uint32_t xv = eq | MV;
-                    // the Q words form ONE wide bit-vector: a single adder carry chain, shifts cross the word borders
-                    const unsigned long long sum = (unsigned long long)(eq & PV) + (unsigned long long)PV + (unsigned long long)carry;
-                    carry = (uint32_t)(sum >> 32);
-                    const uint32_t xh = (((uint32_t)sum) ^ PV) | eq;
-                    uint32_t ph = MV | ~(xh | PV);
-                    uint32_t mh = PV & xh;
-                    if (q == lastq) score += (int)((ph & topbit) != 0) - (int)((mh & topbit) != 0);
-                    const uint32_t ph_out = ph >> 31, mh_out = mh >> 31;
-                    ph = (ph << 1) | ph_in; mh = (mh << 1) | mh_in;
-                    ph_in = ph_out; mh_in = mh_out;
-                    pv[q] = mh | ~(xv | ph);
-                    mv[q] = ph & xv;
-                }
+                unsigned carry = 0;
+                uint32_t ph_prev = 0x80000000u, mh_prev = 0u;           // the row above the column steps +1
+                MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
+                score += (int)(ph_prev >> 31) - (int)(mh_prev >> 31);
             }
         }
     }
@@ -499,17 +650,17 @@ __global__ __launch_bounds__(256) void k_edit_lane(long long count, const uint32
 }
 
 // ---- 3c. full matrix, G lanes per pair, 512 rows (16 words) per lane --------------------------------------------------------
-// The m-row column is ONE wide bit-vector spread over G lanes; lane g of a group works on text column t-g at step t and hands
-// (symbol, adder carry, shifted-out plus/minus bits) to lane g+1 through a DPP wave shift.  64/G pairs share a wave, every
-// lane carries 16 words of state, so the per-step overhead is amortised over 512 cells (the 1-block-per-lane systolic kernel
-// pays it per 32 cells).
+// The column is ONE wide bit-vector spread over the first L = ceil(m/512) lanes of a group, bottom-aligned like above (row m is
+// bit 31 of lane L-1's last word); lane g of a group works on text column t-g at step t and hands (symbol, adder carry,
+// pushed-out plus/minus bits) to lane g+1 through a DPP wave shift.  64/G pairs share a wave, every lane carries 16 words of
+// state, so the per-step overhead is amortised over 512 cells (the 1-block-per-lane systolic kernel pays it per 32 cells).
 template <int G, int P>
-__global__ __launch_bounds__(256) void k_edit_wide(long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
-                                                   const long long* slot_of, int32_t* ed) {
+__device__ __forceinline__ void d_edit_wide(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
+                                            const long long* slot_of, int32_t* ed) {
     constexpr int Q = 16;
     const int lane = lane_id();
     const int gl = lane & (G - 1);
-    const long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const long long t = (blk * 256 + threadIdx.x) / G;
     const bool live = t < count;
     uint32_t widx = 0;
     PairDesc pd; pd.m = 1; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
@@ -517,33 +668,22 @@ __global__ __launch_bounds__(256) void k_edit_wide(long long count, const uint32
     const int m = pd.m, n = live ? pd.n : 0;
     const uint32_t* pat = scratch + pd.pat;
     const uint32_t* txt = scratch + pd.txt;
-    const int row_base = gl * 512;
-    const int rows = m - row_base;                           // rows of this lane that exist (<= 0: lane unused)
+    const int pat_words = (m + 7) >> 3;
+    const int lanes_used = live ? (m + 511) / 512 : 0;
+    const int pad = lanes_used * 512 - m;                    // virtual rows above row 1 (all in lane 0)
+    const int bit_base = gl * 512;                           // first bit of this lane in the wide vector
     uint32_t pv[Q], mv[Q], pl[P][Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
-        uint32_t acc[P];
+        const int nvirt = pad - (bit_base + 32 * q);
+        const uint32_t mlow = nvirt >= 32 ? 0xffffffffu : (nvirt <= 0 ? 0u : ((1u << nvirt) - 1u));
+        mv[q] = mlow; pv[q] = ~mlow;
+        uint32_t e[P];
+        planes32_at<P>(pat, pat_words, bit_base + 32 * q - pad, live && gl < lanes_used, e);
 #pragma unroll
-        for (int b = 0; b < P; b++) acc[b] = 0u;
-#pragma unroll
-        for (int wq = 0; wq < 4; wq++) {
-            const int row0 = row_base + q * 32 + wq * 8;
-            const uint32_t word = (live && row0 < m) ? pat[row0 >> 3] : 0u;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t c = sym<P>((word >> (4 * k)) & 15u);
-#pragma unroll
-                for (int b = 0; b < P; b++) acc[b] |= ((c >> b) & 1u) << (wq * 8 + k);
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < P; b++) pl[b][q] = acc[b];
-        pv[q] = 0xffffffffu; mv[q] = 0u;
+        for (int b = 0; b < P; b++) pl[b][q] = e[b];
     }
-    const int lanes_used = live ? (m + 511) / 512 : 0;
-    const bool has_last = rows > 0 && rows <= 512;           // this lane holds row m
-    const int lastq = has_last ? ((rows - 1) >> 5) : -1;
-    const uint32_t topbit = has_last ? (1u << ((rows - 1) & 31)) : 0u;
+    const bool is_last = gl == lanes_used - 1;               // this lane holds row m (in bit 31 of its last word)
     int score = m;
     int steps = live ? n + lanes_used - 1 : 0, smax = steps;
 #pragma unroll
@@ -565,33 +705,18 @@ __global__ __launch_bounds__(256) void k_edit_wide(long long count, const uint32
                 uint32_t nk[P];
 #pragma unroll
                 for (int b = 0; b < P; b++) nk[b] = ((c >> b) & 1u) - 1u;
-                uint32_t carry = (in >> 4) & 1u, ph_in = (in >> 5) & 1u, mh_in = (in >> 6) & 1u;
-#pragma unroll
-                for (int q = 0; q < Q; q++) {
-                    uint32_t eq = pl[0][q] ^ nk[0];
-#pragma unroll
-                    for (int b = 1; b < P; b++) eq &= pl[b][q] ^ nk[b];
-                    const uint32_t PV = pv[q], MV = mv[q];
-                    const uint32_t xv = eq | MV;
-                    const unsigned long long sum = (unsigned long long)(eq & PV) + (unsigned long long)PV + (unsigned long long)carry;
-                    carry = (uint32_t)(sum >> 32);
-                    const uint32_t xh = (((uint32_t)sum) ^ PV) | eq;
-                    uint32_t ph = MV | ~(xh | PV);
-                    uint32_t mh = PV & xh;
-                    if (q == lastq) score += (int)((ph & topbit) != 0) - (int)((mh & topbit) != 0);
-                    const uint32_t ph_out = ph >> 31, mh_out = mh >> 31;
-                    ph = (ph << 1) | ph_in; mh = (mh << 1) | mh_in;
-                    ph_in = ph_out; mh_in = mh_out;
-                    pv[q] = mh | ~(xv | ph);
-                    mv[q] = ph & xv;
-                }
-                out = c | (carry << 4) | (ph_in << 5) | (mh_in << 6) | 0x80u;
+                unsigned carry = (in >> 4) & 1u;
+                uint32_t ph_prev = (in & 0x20u) << 26, mh_prev = (in & 0x40u) << 25;      // bit 31 = what the lane above pushed out
+                MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
+                const uint32_t po = ph_prev >> 31, mo = mh_prev >> 31;
+                if (is_last) score += (int)po - (int)mo;
+                out = c | (carry << 4) | (po << 5) | (mo << 6) | 0x80u;
             } else {
                 out = 0;
             }
         }
     }
-    if (live && has_last) ed[slot_of ? slot_of[widx] : (long long)widx] = score;
+    if (live && is_last) ed[slot_of ? slot_of[widx] : (long long)widx] = score;
 }
 
 // ---- 4. full-matrix systolic kernel ----------------------------------------------------------------------------
@@ -744,9 +869,9 @@ __device__ int systolic_distance_big(const Packed& pat, int m, const Packed& txt
 
 // one wave per pair of the FULL class; pairs with more than 16384 rows are deferred to k_edit_full_big
 template <int P>
-__global__ __launch_bounds__(256) void k_edit_full(long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
+__device__ __forceinline__ void d_edit_full(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
                                                    const long long* slot_of, int32_t* ed, unsigned long long* n_big, uint32_t* big_list) {
-    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long t = blk * 4 + (threadIdx.x >> 6);
     if (t >= count) return;
     const uint32_t widx = list[t];
     const PairDesc pd = desc[widx];
@@ -760,6 +885,57 @@ __global__ __launch_bounds__(256) void k_edit_full(long long count, const uint32
     else { if (lane_id() == 0) { const unsigned long long i = atomicAdd(n_big, 1ull); big_list[i] = widx; } return; }
     if (lane_id() == 0) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
 }
+
+// ---- 5. one launch per round and kind ---------------------------------------------------------------------------------
+// The classes of a round are independent.  Launching them as separate kernels leaves the chip under-filled whenever a class is
+// small or its last waves drag on (and the runtime multiplexes streams onto a handful of hardware queues), so a round is TWO
+// launches: every band class in one grid, every full-matrix class in another.  Segments are laid out costliest first; a block
+// looks up its segment (uniform, scalar) and runs that class's routine.
+#define SEG_MAX 10
+struct FusedTab {
+    int n;
+    int kind[SEG_MAX];                     // class id (0..13)
+    unsigned first_block[SEG_MAX + 1];
+    long long lo[SEG_MAX], cn[SEG_MAX];    // range of the class in the sorted list
+};
+
+template <int P>
+__global__ __launch_bounds__(256) void k_edit_bands(FusedTab tab, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
+                                                    const long long* slot_of, int32_t* ed, unsigned long long* fail_cnt, uint32_t* fail_lists,
+                                                    long long fail_cap) {
+    int s = 0;
+    while (s + 1 < tab.n && blockIdx.x >= tab.first_block[s + 1]) s++;
+    const long long blk = (long long)(blockIdx.x - tab.first_block[s]);
+    const uint32_t* l = list + tab.lo[s];
+    switch (tab.kind[s]) {
+        case 0: d_edit_band<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
+        case 1: d_edit_band<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
+        case 2: d_edit_band<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
+        case 3: d_edit_stair<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
+        default: d_edit_stair<16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_edit_fulls(FusedTab tab, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
+                                                    const long long* slot_of, int32_t* ed, unsigned long long* n_big, uint32_t* big_list) {
+    int s = 0;
+    while (s + 1 < tab.n && blockIdx.x >= tab.first_block[s + 1]) s++;
+    const long long blk = (long long)(blockIdx.x - tab.first_block[s]);
+    const uint32_t* l = list + tab.lo[s];
+    switch (tab.kind[s]) {
+        case CLS_FULL: d_edit_full<P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, n_big, big_list); break;
+        case CLS_LANE0: d_edit_lane<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
+        case CLS_LANE0 + 1: d_edit_lane<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
+        case CLS_LANE0 + 2: d_edit_lane<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
+        case CLS_LANE0 + 3: d_edit_lane<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
+        case CLS_LANE0 + 4: d_edit_lane<16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
+        case CLS_WIDE0: d_edit_wide<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
+        case CLS_WIDE0 + 1: d_edit_wide<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
+        default: d_edit_wide<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
+    }
+}
+
 
 __global__ __launch_bounds__(64) void k_edit_full_big(long long count, const uint32_t* big_list, const long long* state_off, const uint32_t* scratch,
                                                       const PairDesc* desc, const long long* slot_of, int32_t* ed, uint32_t* state) {
@@ -789,21 +965,18 @@ __global__ void k_class_bounds(const uint64_t* keys, long long n, long long* bou
 // ---- host orchestration -----------------------------------------------------------------------------------------
 // SVX_EDIT_PROFILE=1: per round and class, the pair count and the 32-bit word-columns the class kernel executes
 // (useful = sum over pairs, issued = what the lock-stepped waves pay: 64 x the longest text of each wave); stderr, one line per class
-static void profile_round(svx_ctx* c, int round, const long long* bounds, const uint32_t* list_dev, const PairDesc* desc_dev, long long pending) {
+static void profile_round(svx_ctx* c, int round, const long long* seg_lo, const long long* seg_cn, const uint32_t* list_dev, const PairDesc* desc_dev, long long n_desc) {
     hipStream_t st = c->stream;
-    std::vector<uint32_t> list((size_t)pending);
-    if (hipMemcpyAsync(list.data(), list_dev, (size_t)pending * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return;
-    (void)hipStreamSynchronize(st);
-    uint32_t mx = 0;
-    for (uint32_t v : list) mx = v > mx ? v : mx;
-    std::vector<PairDesc> desc((size_t)mx + 1);
-    if (hipMemcpyAsync(desc.data(), desc_dev, ((size_t)mx + 1) * sizeof(PairDesc), hipMemcpyDeviceToHost, st) != hipSuccess) return;
+    std::vector<PairDesc> desc((size_t)n_desc);
+    if (hipMemcpyAsync(desc.data(), desc_dev, (size_t)n_desc * sizeof(PairDesc), hipMemcpyDeviceToHost, st) != hipSuccess) return;
     (void)hipStreamSynchronize(st);
     for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
         const int cls = sc & 15, generic = sc >> 4;
-        if (cls >= N_CLASSES) continue;
-        const long long lo = bounds[sc], cn = bounds[sc + 1] - lo;
-        if (cn <= 0) continue;
+        const long long cn = seg_cn[sc];
+        if (cls >= N_CLASSES || cn <= 0) continue;
+        std::vector<uint32_t> list((size_t)cn);
+        if (hipMemcpyAsync(list.data(), list_dev + seg_lo[sc], (size_t)cn * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return;
+        (void)hipStreamSynchronize(st);
         int words = 0, per_wave = 64;                       // 32-bit words of column state per pair; pairs per wave
         if (cls <= 4) words = 1 << cls;
         else if (cls >= CLS_LANE0 && cls < CLS_WIDE0) words = 1 << (cls - CLS_LANE0);
@@ -812,7 +985,7 @@ static void profile_round(svx_ctx* c, int round, const long long* bounds, const 
         for (long long i = 0; i < cn; i += per_wave) {
             long long nmax = 0;
             for (long long k = i; k < cn && k < i + per_wave; k++) {
-                const PairDesc& pd = desc[list[(size_t)(lo + k)]];
+                const PairDesc& pd = desc[list[(size_t)k]];
                 const int w = cls == CLS_FULL ? (pd.m + 31) / 32 : words;
                 useful += (double)pd.n * w; sum_m += pd.m; sum_n += pd.n;
                 if (cls == CLS_FULL) issued += (double)pd.n * w; else if (pd.n > nmax) nmax = pd.n;
@@ -823,6 +996,8 @@ static void profile_round(svx_ctx* c, int round, const long long* bounds, const 
                 round, cls, generic, cn, sum_m / cn, sum_n / cn, useful, issued);
     }
 }
+
+#define MAX_ROUNDS 8
 
 static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src, int32_t* ed_dev, unsigned long long* cells_dev) {
     if (n_work <= 0) return SVX_OK;
@@ -839,114 +1014,104 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     HIPCHK(hipStreamSynchronize(st));
     SVXCHK(c->e_scratch.reserve((size_t)(total_words + 64) * 4));
     SVXCHK(c->e_desc.reserve((size_t)n_work * sizeof(PairDesc)));
-    SVXCHK(c->e_key.reserve((size_t)n_work * 8 * 2)); SVXCHK(c->e_val.reserve((size_t)n_work * 4 * 3));
+    SVXCHK(c->e_key.reserve((size_t)n_work * 8 * 2)); SVXCHK(c->e_val.reserve((size_t)n_work * 4 * 2));
     SVXCHK(c->e_slot.reserve((size_t)n_work * 8));
-    SVXCHK(c->e_fail.reserve((size_t)n_work * (4 + 8) + 1024 + 64));
+    SVXCHK(c->e_fail.reserve((size_t)(64 + MAX_ROUNDS * N_SORT_CLASSES) * 8));
+    SVXCHK(c->e_big_list.reserve((size_t)n_work * 4 + 64));
     uint64_t* key_a = c->e_key.as<uint64_t>(); uint64_t* key_b = key_a + n_work;
     uint32_t* val_a = c->e_val.as<uint32_t>(); uint32_t* val_b = val_a + n_work;
     long long* slot_of = c->e_slot.as<long long>();
-    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(c->e_fail.as<char>());           // [0] fails, [1] big, [8..40] class bounds
-    uint32_t* fail_list = reinterpret_cast<uint32_t*>(cnt + 64);
-    uint64_t* fail_key = reinterpret_cast<uint64_t*>(fail_list + ((n_work + 1) & ~1ll));
+    unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..40] class bounds of round 0, [64 + 32 r ..] retry counters written by round r
     PairDesc* desc = c->e_desc.as<PairDesc>();
     uint32_t* scratch = c->e_scratch.as<uint32_t>();
+    c->stats.n_hap_bytes += total_words * 4;
     // 2. trim + pack + classify
+    HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(64 + MAX_ROUNDS * N_SORT_CLASSES) * 8, st));
     k_slots<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, src, slot_of);
     k_edit_prep<<<(unsigned)((n_work + 3) / 4), 256, 0, st>>>(n_work, src, c->e_off.as<int64_t>(), scratch, desc, key_a, val_a, ed_dev, cells_dev, c->edit_force_full ? 1 : 0);
     HIPCHK(hipGetLastError());
-    // Streams: the band classes (0..4, may fail) run on high-priority side streams, the full-matrix classes (lane / wide /
-    // systolic, never fail) on low-priority ones.  A round only waits for its band kernels; the retry rounds - small, poorly
-    // parallel - therefore overlap with the full-matrix work of the earlier rounds, which fills the rest of the chip.
-    // The runtime multiplexes streams onto 4 hardware queues per priority level and streams that share a queue serialise, hence
-    // at most 3 + 4 side streams: band16 | band8 | band4,2,1 and wide8 | wide4 | systolic, wide2 | lane classes.
-    hipStream_t band_st[5] = {c->aux[2], c->aux[2], c->aux[2], c->aux[1], c->aux[0]};
-    hipStream_t full_st[9] = {c->aux[6], c->aux[6], c->aux[6], c->aux[6], c->aux[6], c->aux[5], c->aux[4], c->aux[3], c->aux[5]};     // lane 0..4, wide 0..2, systolic
-    SVXCHK(c->e_big_list.reserve((size_t)n_work * 4 + 64));
-    long long pending = n_work, cum = 0;
-    const uint64_t* keys_in = key_a; const uint32_t* vals_in = val_a;
-    const bool profile = getenv("SVX_EDIT_PROFILE") != nullptr;
-    HIPCHK(hipMemsetAsync(cnt, 0, 16, st));
-    auto join_full = [&]() -> int { for (int k = 3; k < SVX_N_AUX; k++) HIPCHK(hipStreamSynchronize(c->aux[k])); return SVX_OK; };
-    for (int round = 0; round < 8 && pending > 0; round++) {
-        // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
-        if (cum + pending > 2 * n_work) { SVXCHK(join_full()); cum = 0; }      // list space of this call exhausted (pathological retry pattern)
-        uint32_t* list = val_b + cum;
-        SVXCHK(svx_sort_pairs_u64(c, keys_in, key_b, vals_in, list, pending, 0, 40));
-        k_class_bounds<<<1, 64, 0, st>>>(key_b, pending, reinterpret_cast<long long*>(cnt + 8));
-        HIPCHK(hipMemsetAsync(cnt, 0, 8, st));
-        long long bounds[N_SORT_CLASSES + 1];
-        HIPCHK(hipMemcpyAsync(bounds, cnt + 8, (N_SORT_CLASSES + 1) * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (profile) profile_round(c, round, bounds, list, desc, pending);
-        bool band_used[5] = {false, false, false, false, false};
-#define EDIT_LAUNCH(KERNEL, ...) do { if (generic) KERNEL, 4> __VA_ARGS__; else KERNEL, 2> __VA_ARGS__; HIPCHK(hipGetLastError()); } while (0)
+    // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
+    SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, 40));
+    k_class_bounds<<<1, 64, 0, st>>>(key_b, n_work, reinterpret_cast<long long*>(cnt + 8));
+    long long bounds[N_SORT_CLASSES + 1];
+    HIPCHK(hipMemcpyAsync(bounds, cnt + 8, (N_SORT_CLASSES + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+
+    // 4. rounds.  Band classes (may fail) run on high-priority streams, full-matrix classes (never fail) on low-priority ones,
+    // each kind as ONE fused launch per round.  A failing pair is appended to the retry list of its next class; a round only waits
+    // for its band launch, reads 32 counters and launches the next round straight from those lists - no sort, no small kernels
+    // that would queue behind the long-running waves - so the retry rounds overlap the full-matrix work of the earlier ones.
+    hipStream_t band_st[2] = {c->aux[0], c->aux[1]};     // A/C/G/T-only pairs, generic pairs
+    hipStream_t full_st[2] = {c->aux[2], c->aux[3]};     // even / odd rounds
+    const bool profile = getenv("SVX_EDIT_PROFILE") != nullptr, serial = getenv("SVX_EDIT_SERIAL") != nullptr;
+    long long seg_lo[N_SORT_CLASSES], seg_cn[N_SORT_CLASSES];
+    long long pending = 0;
+    for (int sc = 0; sc < N_SORT_CLASSES; sc++) { seg_lo[sc] = bounds[sc]; seg_cn[sc] = bounds[sc + 1] - bounds[sc]; pending += seg_cn[sc]; }
+    const uint32_t* list = val_b;
+    for (int round = 0; pending > 0; round++) {
+        if (round >= MAX_ROUNDS) return svx_fail(SVX_E_STATE, "edit-distance retry loop did not converge", __FILE__, __LINE__, hipSuccess);
+        if (profile) profile_round(c, round, seg_lo, seg_cn, list, desc, n_work);
+        // retry lists this round's band launch appends to: 32 lists of `pending` slots.  Three buffers rotate; the one reused now was
+        // last read by round-2's launches
+        DevBuf& fb = c->e_retry[round % 3];
+        if (round >= 2) HIPCHK(hipStreamSynchronize(full_st[round & 1]));
+        SVXCHK(fb.reserve((size_t)N_SORT_CLASSES * (size_t)pending * 4 + 64));
+        unsigned long long* fail_cnt = cnt + 64 + (size_t)round * N_SORT_CLASSES;
+        bool band_used[2] = {false, false};
         for (int generic = 0; generic <= 1; generic++) {
-            const long long* bd = bounds + 16 * generic;
-            for (int cls = 4; cls >= 0; cls--) {
-                const long long lo = bd[cls], cn = bd[cls + 1] - lo;
+            const int base = 16 * generic;
+            FusedTab tb; memset(&tb, 0, sizeof tb);
+            unsigned nblk = 0;
+            for (int cls = 4; cls >= 0; cls--) {                                  // widest band first
+                const long long cn = seg_cn[base + cls];
                 if (cn <= 0) continue;
-                const unsigned grid = (unsigned)((cn + T - 1) / T);
-                hipStream_t ks = band_st[cls];
-                band_used[cls] = true;
-                switch (cls) {
-                    case 0: EDIT_LAUNCH(k_edit_band<1, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key)); break;
-                    case 1: EDIT_LAUNCH(k_edit_band<2, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key)); break;
-                    case 2: EDIT_LAUNCH(k_edit_band<4, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key)); break;
-                    case 3: EDIT_LAUNCH(k_edit_band<8, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key)); break;
-                    default: EDIT_LAUNCH(k_edit_band<16, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt, fail_list, fail_key)); break;
-                }
+                tb.kind[tb.n] = cls; tb.lo[tb.n] = seg_lo[base + cls]; tb.cn[tb.n] = cn; tb.first_block[tb.n] = nblk;
+                nblk += (unsigned)((cn + T - 1) / T); tb.n++;
             }
-            {   // systolic full-matrix class (one wave per pair); pairs beyond 16384 rows are listed for k_edit_full_big
-                const long long lo = bd[CLS_FULL], cn = bd[CLS_FULL + 1] - lo;
-                if (cn > 0) {
-                    if (generic) k_edit_full<4><<<(unsigned)((cn + 3) / 4), 256, 0, full_st[8]>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
-                    else k_edit_full<2><<<(unsigned)((cn + 3) / 4), 256, 0, full_st[8]>>>(cn, list + lo, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
-                    HIPCHK(hipGetLastError());
-                }
+            tb.first_block[tb.n] = nblk;
+            if (tb.n) {
+                band_used[generic] = true;
+                if (generic) k_edit_bands<4><<<nblk, T, 0, band_st[1]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending);
+                else k_edit_bands<2><<<nblk, T, 0, band_st[0]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending);
+                HIPCHK(hipGetLastError());
             }
-            for (int wc = 2; wc >= 0; wc--) {                      // G lanes per pair, full matrix
-                const long long lo = bd[CLS_WIDE0 + wc], cn = bd[CLS_WIDE0 + wc + 1] - lo;
+            if (serial && tb.n) HIPCHK(hipStreamSynchronize(band_st[generic]));      // SVX_EDIT_SERIAL=1: stand-alone kernel durations for profiling
+            FusedTab tf; memset(&tf, 0, sizeof tf);
+            nblk = 0;
+            // longest serial chains first: systolic (one wave per pair), 8/4/2 lanes per pair, then the lane classes
+            static const int order[9] = {CLS_FULL, CLS_WIDE0 + 2, CLS_WIDE0 + 1, CLS_WIDE0, CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};
+            for (int k = 0; k < 9; k++) {
+                const int cls = order[k];
+                const long long cn = seg_cn[base + cls];
                 if (cn <= 0) continue;
-                const int G = 2 << wc;
-                const unsigned grid = (unsigned)((cn * G + T - 1) / T);
-                hipStream_t ks = full_st[5 + wc];
-                switch (wc) {
-                    case 0: EDIT_LAUNCH(k_edit_wide<2, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
-                    case 1: EDIT_LAUNCH(k_edit_wide<4, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
-                    default: EDIT_LAUNCH(k_edit_wide<8, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
-                }
+                long long threads = cn;
+                if (cls == CLS_FULL) threads = cn * 64; else if (cls >= CLS_WIDE0) threads = cn * (2 << (cls - CLS_WIDE0));
+                tf.kind[tf.n] = cls; tf.lo[tf.n] = seg_lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
+                nblk += (unsigned)((threads + T - 1) / T); tf.n++;
             }
-            for (int lc = 4; lc >= 0; lc--) {                      // whole-pattern-in-a-lane classes
-                const long long lo = bd[CLS_LANE0 + lc], cn = bd[CLS_LANE0 + lc + 1] - lo;
-                if (cn <= 0) continue;
-                const unsigned grid = (unsigned)((cn + T - 1) / T);
-                hipStream_t ks = full_st[lc];
-                switch (lc) {
-                    case 0: EDIT_LAUNCH(k_edit_lane<1, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
-                    case 1: EDIT_LAUNCH(k_edit_lane<2, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
-                    case 2: EDIT_LAUNCH(k_edit_lane<4, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
-                    case 3: EDIT_LAUNCH(k_edit_lane<8, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
-                    default: EDIT_LAUNCH(k_edit_lane<16, <<<grid, T, 0, ks>>>(cn, list + lo, scratch, desc, slot_of, ed_dev)); break;
-                }
+            tf.first_block[tf.n] = nblk;
+            if (tf.n) {
+                hipStream_t fs = full_st[round & 1];
+                if (generic) k_edit_fulls<4><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
+                else k_edit_fulls<2><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
+                HIPCHK(hipGetLastError());
             }
         }
-#undef EDIT_LAUNCH
-        // only the band kernels can hand pairs to the next round
-        for (int cls = 0; cls <= 4; cls++) if (band_used[cls]) HIPCHK(hipStreamSynchronize(band_st[cls]));
-        unsigned long long h0 = 0;
-        HIPCHK(hipMemcpyAsync(&h0, cnt, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        cum += pending;
-        pending = (long long)h0;
-        if (pending > 0) {
-            // retry list becomes the next round's input (copied: the band kernels of the next round append to fail_list again)
-            HIPCHK(hipMemcpyAsync(key_a, fail_key, (size_t)pending * 8, hipMemcpyDeviceToDevice, st));
-            HIPCHK(hipMemcpyAsync(val_a, fail_list, (size_t)pending * 4, hipMemcpyDeviceToDevice, st));
-            keys_in = key_a; vals_in = val_a;
+        if (serial) HIPCHK(hipStreamSynchronize(full_st[round & 1]));
+        // only the band launches can hand pairs to the next round
+        const long long cap = pending;
+        pending = 0;
+        for (int sc = 0; sc < N_SORT_CLASSES; sc++) { seg_lo[sc] = (long long)sc * cap; seg_cn[sc] = 0; }
+        if (band_used[0] || band_used[1]) {
+            for (int g = 0; g <= 1; g++) if (band_used[g]) HIPCHK(hipStreamSynchronize(band_st[g]));
+            unsigned long long h[N_SORT_CLASSES];
+            HIPCHK(hipMemcpyAsync(h, fail_cnt, sizeof h, hipMemcpyDeviceToHost, band_st[0]));
+            HIPCHK(hipStreamSynchronize(band_st[0]));
+            for (int sc = 0; sc < N_SORT_CLASSES; sc++) { seg_cn[sc] = (long long)h[sc]; pending += seg_cn[sc]; }
         }
-        c->stats.n_hap_bytes += (round == 0) ? total_words * 4 : 0;
+        list = fb.as<uint32_t>();
     }
-    SVXCHK(join_full());
+    for (int k = 0; k < 2; k++) HIPCHK(hipStreamSynchronize(full_st[k]));
     {
         unsigned long long nb = 0;
         HIPCHK(hipMemcpyAsync(&nb, cnt + 1, 8, hipMemcpyDeviceToHost, st));
@@ -971,7 +1136,6 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             HIPCHK(hipStreamSynchronize(st));
         }
     }
-    if (pending > 0) return svx_fail(SVX_E_STATE, "edit-distance retry loop did not converge", __FILE__, __LINE__, hipSuccess);
     return SVX_OK;
 }
 
