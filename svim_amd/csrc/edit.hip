@@ -171,24 +171,39 @@ __device__ __forceinline__ int full_class_for(int m) {
     return CLS_FULL;
 }
 
-// one column of the multi-word recurrence; returns (plus, minus) bits pushed out of the last word in bit 31 of ph_top / mh_top
+// One column of the multi-word recurrence; leaves the (plus, minus) bits pushed out of the last word in bit 31 of ph_prev_ / mh_prev_.
+// A dependent chain that alternates full-rate (v_xor, v_bitop3: 2 cycles per wave64) and half-rate (v_alignbit, v_addc_co: 4 cycles)
+// instructions issues at ~4 cycles per instruction on gfx950, four independent chains at ~2.8 (tools/micro/valu_dep.hip).  Left to
+// itself the compiler emits each word's ~14 instructions almost back to back, so the words are processed in groups of 4 with the
+// recurrence cut into phases, every phase running over the 4 words before the next starts (sched_barrier keeps the phases apart).
+#define MYERS_GROUP(Q_) ((Q_) >= 4 ? 4 : (Q_))
 #define MYERS_COLUMN(Q_, P_, pl_, pv_, mv_, nk_, carry_, ph_prev_, mh_prev_)                                   \
-    _Pragma("unroll") for (int q = 0; q < Q_; q++) {                                                            \
-        uint32_t eq = pl_[0][q] ^ nk_[0];                                                                       \
-        _Pragma("unroll") for (int b = 1; b < P_; b++) eq &= pl_[b][q] ^ nk_[b];                                \
-        const uint32_t PV = pv_[q], MV = mv_[q];                                                                \
-        const uint32_t xv = eq | MV;                                                                            \
-        unsigned carry_out;                                                                                     \
-        const uint32_t sum = __builtin_addc(eq & PV, PV, carry_, &carry_out);      /* v_addc_co_u32: the carry stays in an SGPR pair */ \
-        carry_ = carry_out;                                                                                     \
-        const uint32_t xh = (sum ^ PV) | eq;                                                                    \
-        const uint32_t ph = MV | ~(xh | PV);                                                                    \
-        const uint32_t mh = PV & xh;                                                                            \
-        const uint32_t phs = __builtin_amdgcn_alignbit(ph, ph_prev_, 31);          /* (ph << 1) | top bit of the word below */ \
-        const uint32_t mhs = __builtin_amdgcn_alignbit(mh, mh_prev_, 31);                                       \
-        ph_prev_ = ph; mh_prev_ = mh;                                                                           \
-        pv_[q] = mhs | ~(xv | phs);                                                                             \
-        mv_[q] = phs & xv;                                                                                      \
+    _Pragma("unroll") for (int q0 = 0; q0 < Q_; q0 += MYERS_GROUP(Q_)) {                                        \
+        constexpr int GQ = MYERS_GROUP(Q_);                                                                     \
+        uint32_t eq_[GQ], xv_[GQ], sum_[GQ], ph_[GQ], mh_[GQ], phs_[GQ], mhs_[GQ];                              \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) {                                                        \
+            uint32_t e = pl_[0][q0 + g] ^ nk_[0];                                                               \
+            _Pragma("unroll") for (int b = 1; b < P_; b++) e &= pl_[b][q0 + g] ^ nk_[b];                        \
+            eq_[g] = e;                                                                                         \
+        }                                                                                                       \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) { xv_[g] = eq_[g] | mv_[q0 + g]; sum_[g] = eq_[g] & pv_[q0 + g]; } \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) {                                                        \
+            unsigned carry_out;                                                                                 \
+            sum_[g] = __builtin_addc(sum_[g], pv_[q0 + g], carry_, &carry_out);    /* v_addc_co_u32: the carry stays in an SGPR pair */ \
+            carry_ = carry_out;                                                                                 \
+        }                                                                                                       \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) sum_[g] = (sum_[g] ^ pv_[q0 + g]) | eq_[g];              /* xh */ \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) { ph_[g] = mv_[q0 + g] | ~(sum_[g] | pv_[q0 + g]); mh_[g] = pv_[q0 + g] & sum_[g]; } \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) {                                                        \
+            phs_[g] = __builtin_amdgcn_alignbit(ph_[g], g ? ph_[g - 1] : ph_prev_, 31);      /* (ph << 1) | top bit of the word below */ \
+            mhs_[g] = __builtin_amdgcn_alignbit(mh_[g], g ? mh_[g - 1] : mh_prev_, 31);                         \
+        }                                                                                                       \
+        ph_prev_ = ph_[GQ - 1]; mh_prev_ = mh_[GQ - 1];                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) { pv_[q0 + g] = mhs_[g] | ~(xv_[g] | phs_[g]); mv_[q0 + g] = phs_[g] & xv_[g]; } \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
     }
 
 // ---- 1. scratch sizing --------------------------------------------------------------------------------------
