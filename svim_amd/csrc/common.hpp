@@ -126,7 +126,7 @@ struct svx_ctx {
     DevBuf k_hi, k_lo, k_idx, k_hi2, k_lo2, k_idx2, part_flag, part_id, part_start, part_meta, samp_idx, large_list, samp_stream;
     DevBuf cell_shards;
     DevBuf pair_off, ed, work, stage, stage_members, labels;
-    DevBuf e_words, e_off, e_scratch, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off;
+    DevBuf e_words, e_off, e_scratch, e_rec, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off;
     DevBuf e_retry[3];              // per-class retry lists of the edit-distance rounds (rotating)     // edit-distance pipeline
     DevClusters clu;
     int shard_rank = 0, shard_world = 1, shard_mode = 0;

@@ -55,11 +55,18 @@ struct Hap {
     }
 };
 
-// 4-bit packed string: symbol i = (w[i>>3] >> 4*(i&7)) & 15
+// A core inside the packed store: symbol i is nibble (i + sh) of w[] (sh = 0..7, the core starts anywhere inside its record).
+// word(idx) = symbols 8 idx .. 8 idx + 7 as one word; every record is followed by two pad words, so w[idx + 1] is always readable.
 struct Packed {
-    const uint32_t* w;
-    __device__ __forceinline__ uint32_t at(int i) const { return (w[i >> 3] >> ((i & 7) << 2)) & 15u; }
+    const uint32_t* w; int sh4;
+    __device__ __forceinline__ uint32_t word(int idx) const { return __builtin_amdgcn_alignbit(w[idx + 1], w[idx], sh4); }
+    __device__ __forceinline__ uint32_t at(int i) const { const int k = i + (sh4 >> 2); return (w[k >> 3] >> ((k & 7) << 2)) & 15u; }
 };
+// 8 symbols starting at symbol s of a packed record (s >= -7: the store begins with one pad word)
+__device__ __forceinline__ uint32_t fetch8(const uint32_t* w, int s) {
+    const int i = s >> 3;
+    return __builtin_amdgcn_alignbit(w[i + 1], w[i], (s & 7) << 2);
+}
 
 __device__ __forceinline__ void hap_fetch(const int64_t* g_off, const uint8_t* g_codes, int contig, long long a, long long b,
                                           const uint8_t*& p, int& n) {
@@ -85,21 +92,59 @@ __device__ __forceinline__ Hap plain_hap(const uint8_t* s, int n) {
     Hap h; h.p0 = s; h.n0 = 0; h.p1 = s; h.n1 = n; h.p2 = s; h.n2 = 0; h.len = n; return h;
 }
 
+// One packed record per string: for a signature the stored string is  ref[start-R, start) + inserted bases + ref[start, start+R)
+// (R = largest |start_a - start_b| over the work list + 100, clipped to the contig like FastaFile.fetch), so the haplotype of ANY
+// pair the signature takes part in is a substring of its record; for the plain entry point a record is the string itself.
+#define HAP_ZERO 1            /* the record holds code 0 ('=') */
+#define HAP_OTHER 2           /* the record holds a symbol that is not exactly one of A, C, G, T */
+struct HapRec { unsigned long long word_off; int left, len, right, flags; };
+// a haplotype as the pair kernels see it: `len` symbols starting `off` symbols into record words w[]
+struct HapView { unsigned long long word_off; int off, len, flags; };
+
+__device__ __forceinline__ int fetch_len(long long clen, long long a, long long b) {       // length of FastaFile.fetch(a, b) as hap_fetch clips it
+    if (a < 0) a = 0;
+    if (b < 0) b = 0;
+    if (b > clen) b = clen;
+    return a >= b ? 0 : (int)(b - a);
+}
+
 // where the two strings of a work item come from
 struct PairSource {
     int plain;                       // 1: codes + a_off/b_off ; 0: signature pairs
+    long long n_pairs;
     const uint8_t* codes; const int64_t* a_off; const int64_t* b_off;
     const EditWork* work; ClusterIn in; const int64_t* g_off; const uint8_t* g_codes;
-    __device__ __forceinline__ void haps(long long w, Hap& A, Hap& B) const {
+    long long radius;                // R
+    const HapRec* rec;
+    __device__ __forceinline__ long long n_records() const { return plain ? 2 * n_pairs : in.n; }
+    // the string record r stores, as a virtual concatenation of byte ranges
+    __device__ __forceinline__ Hap record_hap(long long r) const {
         if (plain) {
-            A = plain_hap(codes + a_off[w], (int)(a_off[w + 1] - a_off[w]));
-            B = plain_hap(codes + b_off[w], (int)(b_off[w + 1] - b_off[w]));
+            if (r < n_pairs) return plain_hap(codes + a_off[r], (int)(a_off[r + 1] - a_off[r]));
+            r -= n_pairs;
+            return plain_hap(codes + b_off[r], (int)(b_off[r + 1] - b_off[r]));
+        }
+        if (in.type[r] != SVX_INS) return plain_hap(g_codes, 0);
+        const long long st = in.start[r];
+        return make_hap(g_off, g_codes, in.contig[r], st, in.seq + in.seq_off[r], (int)(in.seq_off[r + 1] - in.seq_off[r]), st - radius, st + radius);
+    }
+    // compute_haplotype_edit_distance (src/svim/SVIM_clustering.py:32-45): window = min/max start -+ 100
+    __device__ __forceinline__ void views(long long w, HapView& A, HapView& B) const {
+        if (plain) {
+            const HapRec ra = rec[w], rb = rec[n_pairs + w];
+            A.word_off = ra.word_off; A.off = 0; A.len = ra.len; A.flags = ra.flags;
+            B.word_off = rb.word_off; B.off = 0; B.len = rb.len; B.flags = rb.flags;
         } else {
             const EditWork wk = work[w];
             const long long s1 = in.start[wk.a], s2 = in.start[wk.b];
             const long long ws = (s1 < s2 ? s1 : s2) - 100, we = (s1 > s2 ? s1 : s2) + 100;
-            A = make_hap(g_off, g_codes, in.contig[wk.a], s1, in.seq + in.seq_off[wk.a], (int)(in.seq_off[wk.a + 1] - in.seq_off[wk.a]), ws, we);
-            B = make_hap(g_off, g_codes, in.contig[wk.b], s2, in.seq + in.seq_off[wk.b], (int)(in.seq_off[wk.b + 1] - in.seq_off[wk.b]), ws, we);
+            const int c1 = in.contig[wk.a], c2 = in.contig[wk.b];
+            const long long l1 = g_off[c1 + 1] - g_off[c1], l2 = g_off[c2 + 1] - g_off[c2];
+            const HapRec ra = rec[wk.a], rb = rec[wk.b];
+            const int la = fetch_len(l1, ws, s1), ra_ = fetch_len(l1, s1, we);
+            const int lb = fetch_len(l2, ws, s2), rb_ = fetch_len(l2, s2, we);
+            A.word_off = ra.word_off; A.off = ra.left - la; A.len = la + ra.len + ra_; A.flags = ra.flags;
+            B.word_off = rb.word_off; B.off = rb.left - lb; B.len = lb + rb.len + rb_; B.flags = rb.flags;
         }
     }
     __device__ __forceinline__ long long slot(long long w) const { return plain ? w : work[w].slot; }
@@ -107,12 +152,14 @@ struct PairSource {
 
 // per-pair descriptor after trimming
 struct PairDesc {
-    unsigned long long pat;     // word offset of the shorter core in the scratch
-    unsigned long long txt;     // word offset of the longer core
+    unsigned long long pat;     // packed-store word that holds the first symbol of the shorter core
+    unsigned long long txt;     // same for the longer core
     int m, n;                   // core lengths, m <= n
     int ub;                     // upper bound of the distance known so far
-    int cls;                    // next class to try: 0..4 = band of 32<<cls diagonals, 5 = full matrix
+    int cls;                    // bits 0..7 next class to try, bit 8 CLS_GENERIC, bits 12..14 / 16..18 nibble of the first pattern / text symbol
 };
+#define CLS_PAT_SH(c) ((((c) >> 12) & 7) << 2)
+#define CLS_TXT_SH(c) ((((c) >> 16) & 7) << 2)
 
 #define CLS_FULL 5
 #define CLS_LANE0 6           /* 6..10: whole pattern (<= 32<<k rows) in one lane, full matrix, never fails */
@@ -206,88 +253,120 @@ __device__ __forceinline__ int full_class_for(int m) {
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     }
 
-// ---- 1. scratch sizing --------------------------------------------------------------------------------------
-__global__ void k_pair_words(long long n_work, PairSource src, int64_t* words) {
-    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w > n_work) return;
-    if (w == n_work) { words[w] = 0; return; }
-    Hap A, B;
-    src.haps(w, A, B);
-    words[w] = (A.len + 7) / 8 + (B.len + 7) / 8 + 2;
+// ---- 1. packed store ---------------------------------------------------------------------------------------------
+__global__ void k_pair_span(long long n_work, PairSource src, unsigned long long* span) {           // max |start_a - start_b| over the work list
+    long long d = 0;
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < n_work; w += (long long)gridDim.x * blockDim.x) {
+        const EditWork wk = src.work[w];
+        long long x = (long long)src.in.start[wk.a] - (long long)src.in.start[wk.b];
+        if (x < 0) x = -x;
+        d = x > d ? x : d;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const long long v = __shfl_xor(d, o, 64); d = v > d ? v : d; }
+    if (lane_id() == 0 && d > 0) atomicMax(span + 16 + (blockIdx.x & 15), (unsigned long long)d);          // 16 shards
 }
 
-// ---- 2. trim + pack ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource src, const int64_t* word_off, uint32_t* scratch, PairDesc* desc,
+__global__ void k_hap_words(long long n_rec, PairSource src, int64_t* words) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rec) return;
+    if (r == n_rec) { words[r] = 0; return; }
+    const Hap h = src.record_hap(r);
+    words[r] = h.len ? (h.len + 7) / 8 + 2 : 0;          // two pad words: word(idx) may read one word past the last symbol
+}
+
+// one wave per record: 4-bit pack (8 symbols per lane and step), note the alphabet
+__global__ __launch_bounds__(256) void k_hap_pack(long long n_rec, PairSource src, const int64_t* word_off, uint32_t* packed, HapRec* rec) {
+    const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (r >= n_rec) return;
+    const int lane = lane_id();
+    const Hap h = src.record_hap(r);
+    const unsigned long long base = (unsigned long long)word_off[r] + 1ull;          // word 0 of the store is a pad
+    uint32_t* out = packed + base;
+    int zero = 0, other = 0;
+    for (int i0 = lane * 8; h.len > 0 && i0 < h.len + 16; i0 += 512) {                 // + 16: the pad words are zeroed; an empty record owns no words
+        const uint32_t wd = i0 < h.len ? h.pack8(i0, h.len) : 0u;
+        out[i0 >> 3] = wd;
+        const int v = h.len - i0 >= 8 ? 8 : (h.len - i0 < 0 ? 0 : h.len - i0);
+        const uint32_t vm = v >= 8 ? 0xffffffffu : ((1u << (4 * v)) - 1u);
+        const uint32_t nz = (wd | (wd >> 1) | (wd >> 2) | (wd >> 3)) & 0x11111111u;
+        zero |= (__popc(nz) < v);
+        const uint32_t ones = (wd & 0x11111111u) + ((wd >> 1) & 0x11111111u) + ((wd >> 2) & 0x11111111u) + ((wd >> 3) & 0x11111111u);
+        other |= ((ones ^ 0x11111111u) & vm) != 0u;                                   // a symbol that is not exactly one of A,C,G,T
+    }
+    zero = __any(zero); other = __any(other);
+    if (lane == 0) {
+        HapRec hr; hr.word_off = base; hr.left = h.n0; hr.len = h.n1; hr.right = h.n2; hr.flags = (zero ? HAP_ZERO : 0) | (other ? HAP_OTHER : 0);
+        if (src.plain) { hr.left = 0; hr.len = h.len; hr.right = 0; }
+        rec[r] = hr;
+    }
+}
+
+// ---- 2. trim + classify (one wave per pair, reads only the packed store) ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource src, const uint32_t* packed, PairDesc* desc,
                                                    uint64_t* sort_key, uint32_t* sort_val, int32_t* ed, unsigned long long* cells, int force_full) {
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long w = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (w >= n_work) return;
     const int lane = lane_id();
-    Hap A, B;
-    src.haps(w, A, B);
+    HapView A, B;
+    src.views(w, A, B);
+    const uint32_t* wa = packed + A.word_off; const uint32_t* wb = packed + B.word_off;
     const int la = A.len, lb = B.len;
     const int mn = la < lb ? la : lb;
-    int pre = 0;
-    while (pre < mn) {
-        const int i = pre + lane;
-        const bool diff = (i >= mn) || (A.at(i) != B.at(i));
-        const unsigned long long d = __ballot(diff);
-        if (d) { pre += __ffsll((long long)d) - 1; break; }
-        pre += 64;
+    // common prefix / suffix, 8 symbols per lane and step
+    int pre = mn;
+    for (int base = 0; base < mn; base += 512) {
+        const int i0 = base + lane * 8;
+        const int cnt = mn - i0 >= 8 ? 8 : (mn - i0 < 0 ? 0 : mn - i0);
+        uint32_t x = 0;
+        if (cnt > 0) x = fetch8(wa, A.off + i0) ^ fetch8(wb, B.off + i0);
+        const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
+        int k = nz ? (__ffs((int)nz) - 1) >> 2 : 8;                       // first differing symbol of the chunk
+        if (k > cnt) k = cnt;
+        const unsigned long long stop = __ballot(k < 8);                   // a difference, or the shorter string ends here
+        if (stop) { const int f = __ffsll((long long)stop) - 1; pre = base + f * 8 + __shfl(k, f, 64); break; }
     }
-    if (pre > mn) pre = mn;
-    int suf = 0;
     const int lim = mn - pre;
-    while (suf < lim) {
-        const int i = suf + lane;
-        const bool diff = (i >= lim) || (A.at(la - 1 - i) != B.at(lb - 1 - i));
-        const unsigned long long d = __ballot(diff);
-        if (d) { suf += __ffsll((long long)d) - 1; break; }
-        suf += 64;
+    int suf = lim;
+    for (int base = 0; base < lim; base += 512) {
+        const int i0 = base + lane * 8;
+        const int cnt = lim - i0 >= 8 ? 8 : (lim - i0 < 0 ? 0 : lim - i0);
+        uint32_t x = 0;
+        if (cnt > 0) x = fetch8(wa, A.off + la - i0 - 8) ^ fetch8(wb, B.off + lb - i0 - 8);
+        const uint32_t nz = (x | (x << 1) | (x << 2) | (x << 3)) & 0x88888888u;
+        int k = nz ? __clz((int)nz) >> 2 : 8;                              // matching symbols counted from the end of the chunk
+        if (k > cnt) k = cnt;
+        const unsigned long long stop = __ballot(k < 8);
+        if (stop) { const int f = __ffsll((long long)stop) - 1; suf = base + f * 8 + __shfl(k, f, 64); break; }
     }
-    if (suf > lim) suf = lim;
     const int ca = la - pre - suf, cb = lb - pre - suf;
     PairDesc pd;
     const bool a_short = ca <= cb;
-    const Hap& P = a_short ? A : B;
-    const Hap& T = a_short ? B : A;
+    const HapView& P = a_short ? A : B;
+    const HapView& T = a_short ? B : A;
     pd.m = a_short ? ca : cb; pd.n = a_short ? cb : ca;
-    pd.pat = (unsigned long long)word_off[w];
-    pd.txt = pd.pat + (unsigned long long)((pd.m + 7) / 8) + 1ull;
+    const int p0 = P.off + pre, t0 = T.off + pre;                          // first core symbols inside their records
+    pd.pat = P.word_off + (unsigned long long)(p0 >> 3);
+    pd.txt = T.word_off + (unsigned long long)(t0 >> 3);
+    const int sh_bits = ((p0 & 7) << 12) | ((t0 & 7) << 16);
     if (pd.m == 0) {                                   // one core is empty: the distance is the other's length
         if (lane == 0) { ed[src.slot(w)] = pd.n; pd.ub = pd.n; pd.cls = -1; desc[w] = pd; sort_key[w] = 0xffull << 32; sort_val[w] = (uint32_t)w; }
         return;
     }
-    // pack the cores, count mismatches of the trivial left-justified alignment and look for code 0
-    uint32_t* pw = scratch + pd.pat; uint32_t* tw = scratch + pd.txt;
-    int ham_l = 0, zero = 0, other = 0;
-    for (int base = 0; base < pd.n; base += 512) {     // 64 lanes x 8 symbols
+    // mismatches of the trivial left-justified alignment
+    const uint32_t* wp = packed + P.word_off; const uint32_t* wt = packed + T.word_off;
+    int ham_l = 0;
+    for (int base = 0; base < pd.m; base += 512) {
         const int i0 = base + lane * 8;
-        if (i0 < pd.n) {
-            const uint32_t wt = T.pack8(pre + i0, pre + pd.n);
-            tw[i0 >> 3] = wt;
-            const int vt = pd.n - i0 >= 8 ? 8 : pd.n - i0;
-            const uint32_t nzt = (wt | (wt >> 1) | (wt >> 2) | (wt >> 3)) & 0x11111111u;
-            zero |= (__popc(nzt) < vt);
-            const uint32_t vmt = vt >= 8 ? 0xffffffffu : ((1u << (4 * vt)) - 1u);
-            const uint32_t onest = (wt & 0x11111111u) + ((wt >> 1) & 0x11111111u) + ((wt >> 2) & 0x11111111u) + ((wt >> 3) & 0x11111111u);
-            other |= ((onest ^ 0x11111111u) & vmt) != 0u;          // a symbol that is not exactly one of A,C,G,T
-            if (i0 < pd.m) {
-                const uint32_t wp = P.pack8(pre + i0, pre + pd.m);
-                pw[i0 >> 3] = wp;
-                const int vp = pd.m - i0 >= 8 ? 8 : pd.m - i0;
-                const uint32_t nzp = (wp | (wp >> 1) | (wp >> 2) | (wp >> 3)) & 0x11111111u;
-                zero |= (__popc(nzp) < vp);
-                const uint32_t vmask = vp >= 8 ? 0xffffffffu : ((1u << (4 * vp)) - 1u);
-                const uint32_t onesp = (wp & 0x11111111u) + ((wp >> 1) & 0x11111111u) + ((wp >> 2) & 0x11111111u) + ((wp >> 3) & 0x11111111u);
-                other |= ((onesp ^ 0x11111111u) & vmask) != 0u;
-                const uint32_t x = (wp ^ wt) & vmask;
-                ham_l += __popc((x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u);
-            }
+        if (i0 < pd.m) {
+            const int v = pd.m - i0 >= 8 ? 8 : pd.m - i0;
+            const uint32_t vmask = v >= 8 ? 0xffffffffu : ((1u << (4 * v)) - 1u);
+            const uint32_t x = (fetch8(wp, p0 + i0) ^ fetch8(wt, t0 + i0)) & vmask;
+            ham_l += __popc((x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u);
         }
     }
     ham_l = wave_sum_i32(ham_l);
-    zero = __any(zero);
-    other = __any(other);
+    const int zero = (A.flags | B.flags) & HAP_ZERO, other = (A.flags | B.flags) & HAP_OTHER;      // of the whole records: conservative
     if (lane == 0) {
         const int ub = ham_l + (pd.n - pd.m);
         pd.ub = ub;
@@ -307,7 +386,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
             if (cls > 0 && pd.m <= 512 && lane_class_for(pd.m) <= cls) cls = CLS_LANE0 + lane_class_for(pd.m);
             else if (cls == CLS_FULL) cls = full_class_for(pd.m);
         }
-        pd.cls = cls | (other ? CLS_GENERIC : 0);
+        pd.cls = cls | (other ? CLS_GENERIC : 0) | sh_bits;
         desc[w] = pd;
         sort_key[w] = (sort_class(pd.cls) << 32) | work_key(cls, pd.m, pd.n);
         sort_val[w] = (uint32_t)w;
@@ -326,7 +405,7 @@ __device__ __forceinline__ void band_retry(const PairDesc& pd, uint32_t widx, in
     if (cls > 4) cls = CLS_FULL;
     if (m <= 512 && lane_class_for(m) <= cls) cls = CLS_LANE0 + lane_class_for(m);
     else if (cls == CLS_FULL) cls = full_class_for(m);
-    const int flagged = cls | (pd.cls & CLS_GENERIC);
+    const int flagged = cls | (pd.cls & ~0xff);          // keeps the alphabet flag and the nibble offsets
     desc[widx].ub = ub; desc[widx].cls = flagged;
     // retry list of the new class (the lists of a round are consumed as they are: no re-sort between rounds)
     const unsigned long long sc = sort_class(flagged);
@@ -354,8 +433,7 @@ __device__ __forceinline__ void d_edit_band(long long blk, long long count, cons
     dmax -= ((dmax - 7) & 7);
     const int margin = dmax - (n - m);                 // top margin; bottom margin W-1-dmax >= margin
     const int a_bot = W - 1 - dmax;                    // multiple of 8
-    const uint32_t* pat = scratch + pd.pat;
-    const uint32_t* txt = scratch + pd.txt;
+    const Packed pat{scratch + pd.pat, CLS_PAT_SH(pd.cls)}, txt{scratch + pd.txt, CLS_TXT_SH(pd.cls)};
     uint32_t pv[Q], mv[Q], pl[P][Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
@@ -369,7 +447,7 @@ __device__ __forceinline__ void d_edit_band(long long blk, long long count, cons
     const int pat_words = (m + 7) >> 3;
     // pre-roll: rows 1..a_bot enter the window (a_bot/8 whole words)
     for (int wi = 0; wi < (a_bot >> 3); wi++) {
-        const uint32_t word = (live && wi < pat_words) ? pat[wi] : 0u;
+        const uint32_t word = (live && wi < pat_words) ? pat.word(wi) : 0u;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int row = wi * 8 + k + 1;
@@ -389,12 +467,12 @@ __device__ __forceinline__ void d_edit_band(long long blk, long long count, cons
     for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
     const int txt_words = (n + 7) >> 3;
     const int pbase = a_bot >> 3;                        // pattern word holding row j + a_bot for j = 8*jb+1..
-    uint32_t tw_next = (live && txt_words > 0) ? txt[0] : 0u;
-    uint32_t pw_next = (live && pbase < pat_words) ? pat[pbase] : 0u;
+    uint32_t tw_next = (live && txt_words > 0) ? txt.word(0) : 0u;
+    uint32_t pw_next = (live && pbase < pat_words) ? pat.word(pbase) : 0u;
     for (int jb = 0; jb * 8 < nmax; jb++) {
         const uint32_t tw = tw_next, pw = pw_next;
-        tw_next = (live && jb + 1 < txt_words) ? txt[jb + 1] : 0u;
-        pw_next = (live && pbase + jb + 1 < pat_words) ? pat[pbase + jb + 1] : 0u;
+        tw_next = (live && jb + 1 < txt_words) ? txt.word(jb + 1) : 0u;
+        pw_next = (live && pbase + jb + 1 < pat_words) ? pat.word(pbase + jb + 1) : 0u;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int j = jb * 8 + k + 1;
@@ -508,11 +586,10 @@ __device__ __forceinline__ void d_edit_stair(long long blk, long long count, con
     off -= ((off - 7) & 7);
     const int margin_lo = W - off - 33, margin_up = off + 1 - delta;
     const int margin = margin_lo < margin_up ? margin_lo : margin_up;
-    const uint32_t* pat = scratch + pd.pat;
-    const uint32_t* txt = scratch + pd.txt;
+    const Packed pat{scratch + pd.pat, CLS_PAT_SH(pd.cls)}, txt{scratch + pd.txt, CLS_TXT_SH(pd.cls)};
     const int pat_words = (m + 7) >> 3, txt_words = (n + 7) >> 3;
     const int w0 = -((off + 1) >> 3);                   // packed pattern word that holds bit 0 of the window (row -off)
-    auto pat_word = [&](int idx) -> uint32_t { return (live && idx >= 0 && idx < pat_words) ? pat[idx] : 0u; };
+    auto pat_word = [&](int idx) -> uint32_t { return (live && idx >= 0 && idx < pat_words) ? pat.word(idx) : 0u; };
     uint32_t pv[Q], mv[Q], pl[P][Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
@@ -531,7 +608,7 @@ __device__ __forceinline__ void d_edit_stair(long long blk, long long count, con
     uint32_t tw_next[4], pw_next[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        tw_next[i] = (live && i < txt_words) ? txt[i] : 0u;
+        tw_next[i] = (live && i < txt_words) ? txt.word(i) : 0u;
         pw_next[i] = pat_word(w0 + 4 * Q + i);
     }
     for (int kb = 0; kb * 32 < nmax; kb++) {
@@ -555,7 +632,7 @@ __device__ __forceinline__ void d_edit_stair(long long blk, long long count, con
         for (int i = 0; i < 4; i++) {
             tw[i] = tw_next[i];
             const int ti = 4 * (kb + 1) + i;
-            tw_next[i] = (live && ti < txt_words) ? txt[ti] : 0u;
+            tw_next[i] = (live && ti < txt_words) ? txt.word(ti) : 0u;
             pw_next[i] = pat_word(w0 + 4 * (kb + Q) + i);           // enters when the window drops into block kb + 1
         }
 #pragma unroll
@@ -600,17 +677,16 @@ __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
 // The pattern is BOTTOM-aligned: row m is bit 31 of the last word, the 32*Q - m bits above row 1 are virtual rows <= 0
 // (D[r][j] = j - r: vertical delta -1, horizontal +1 - a match there changes nothing).  The horizontal delta of row m is then
 // simply the bit the shifts push out of the last word: no per-word test for "the word that holds row m".
-// 8 symbols starting at symbol index s (any alignment, may be negative) of a packed string of n_words words; outside -> 0
-__device__ __forceinline__ uint32_t packed8_at(const uint32_t* w, int n_words, int s, bool live) {
-    const int i = s >> 3, sh = (s & 7) * 4;
-    const uint32_t lo = (live && i >= 0 && i < n_words) ? w[i] : 0u;
-    const uint32_t hi = (live && sh && i + 1 >= 0 && i + 1 < n_words) ? w[i + 1] : 0u;
-    return __builtin_amdgcn_alignbit(hi, lo, sh);
+// 8 symbols starting at core symbol s (any alignment); a chunk that lies entirely above the core (virtual rows) reads as 0, one that
+// straddles its start picks up the symbols stored in front of the core - harmless there, see above
+__device__ __forceinline__ uint32_t packed8_at(const Packed& pk, int s, bool live) {
+    if (!live || s + 8 <= 0) return 0u;
+    return fetch8(pk.w, s + (pk.sh4 >> 2));
 }
 // bit-plane words of the 32 rows whose first pattern symbol index is s
 template <int P>
-__device__ __forceinline__ void planes32_at(const uint32_t* w, int n_words, int s, bool live, uint32_t (&out)[P]) {
-    planes32<P>(packed8_at(w, n_words, s, live), packed8_at(w, n_words, s + 8, live), packed8_at(w, n_words, s + 16, live), packed8_at(w, n_words, s + 24, live), out);
+__device__ __forceinline__ void planes32_at(const Packed& pk, int s, bool live, uint32_t (&out)[P]) {
+    planes32<P>(packed8_at(pk, s, live), packed8_at(pk, s + 8, live), packed8_at(pk, s + 16, live), packed8_at(pk, s + 24, live), out);
 }
 
 template <int Q, int P>
@@ -622,8 +698,7 @@ __device__ __forceinline__ void d_edit_lane(long long blk, long long count, cons
     PairDesc pd; pd.m = 1; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
     if (live) { widx = list[t]; pd = desc[widx]; }
     const int m = pd.m, n = live ? pd.n : 0;
-    const uint32_t* pat = scratch + pd.pat;
-    const uint32_t* txt = scratch + pd.txt;
+    const Packed pat{scratch + pd.pat, CLS_PAT_SH(pd.cls)}, txt{scratch + pd.txt, CLS_TXT_SH(pd.cls)};
     const int pat_words = (m + 7) >> 3;
     const int pad = 32 * Q - m;                          // virtual rows above row 1
     uint32_t pv[Q], mv[Q], pl[P][Q];
@@ -633,7 +708,7 @@ __device__ __forceinline__ void d_edit_lane(long long blk, long long count, cons
         const uint32_t mlow = nvirt >= 32 ? 0xffffffffu : (nvirt <= 0 ? 0u : ((1u << nvirt) - 1u));
         mv[q] = mlow; pv[q] = ~mlow;
         uint32_t e[P];
-        planes32_at<P>(pat, pat_words, 32 * q - pad, live, e);
+        planes32_at<P>(pat, 32 * q - pad, live, e);
 #pragma unroll
         for (int b = 0; b < P; b++) pl[b][q] = e[b];
     }
@@ -642,10 +717,10 @@ __device__ __forceinline__ void d_edit_lane(long long blk, long long count, cons
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
     const int txt_words = (n + 7) >> 3;
-    uint32_t tw_next = (live && txt_words > 0) ? txt[0] : 0u;
+    uint32_t tw_next = (live && txt_words > 0) ? txt.word(0) : 0u;
     for (int jb = 0; jb * 8 < nmax; jb++) {
         const uint32_t tw = tw_next;
-        tw_next = (live && jb + 1 < txt_words) ? txt[jb + 1] : 0u;
+        tw_next = (live && jb + 1 < txt_words) ? txt.word(jb + 1) : 0u;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int j = jb * 8 + k + 1;
@@ -681,8 +756,7 @@ __device__ __forceinline__ void d_edit_wide(long long blk, long long count, cons
     PairDesc pd; pd.m = 1; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
     if (live) { widx = list[t]; pd = desc[widx]; }
     const int m = pd.m, n = live ? pd.n : 0;
-    const uint32_t* pat = scratch + pd.pat;
-    const uint32_t* txt = scratch + pd.txt;
+    const Packed pat{scratch + pd.pat, CLS_PAT_SH(pd.cls)}, txt{scratch + pd.txt, CLS_TXT_SH(pd.cls)};
     const int pat_words = (m + 7) >> 3;
     const int lanes_used = live ? (m + 511) / 512 : 0;
     const int pad = lanes_used * 512 - m;                    // virtual rows above row 1 (all in lane 0)
@@ -694,7 +768,7 @@ __device__ __forceinline__ void d_edit_wide(long long blk, long long count, cons
         const uint32_t mlow = nvirt >= 32 ? 0xffffffffu : (nvirt <= 0 ? 0u : ((1u << nvirt) - 1u));
         mv[q] = mlow; pv[q] = ~mlow;
         uint32_t e[P];
-        planes32_at<P>(pat, pat_words, bit_base + 32 * q - pad, live && gl < lanes_used, e);
+        planes32_at<P>(pat, bit_base + 32 * q - pad, live && gl < lanes_used, e);
 #pragma unroll
         for (int b = 0; b < P; b++) pl[b][q] = e[b];
     }
@@ -705,11 +779,11 @@ __device__ __forceinline__ void d_edit_wide(long long blk, long long count, cons
     for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(smax, o, 64); smax = v > smax ? v : smax; }
     const int txt_words = (n + 7) >> 3;
     const bool feeder = live && gl == 0;
-    uint32_t tw_next = (feeder && txt_words > 0) ? txt[0] : 0u;
+    uint32_t tw_next = (feeder && txt_words > 0) ? txt.word(0) : 0u;
     uint32_t out = 0;
     for (int jb = 0; jb * 8 < smax; jb++) {
         const uint32_t tw = tw_next;
-        tw_next = (feeder && jb + 1 < txt_words) ? txt[jb + 1] : 0u;
+        tw_next = (feeder && jb + 1 < txt_words) ? txt.word(jb + 1) : 0u;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int st = jb * 8 + k;                       // step; the group's first lane is at text column st
@@ -890,7 +964,7 @@ __device__ __forceinline__ void d_edit_full(long long blk, long long count, cons
     if (t >= count) return;
     const uint32_t widx = list[t];
     const PairDesc pd = desc[widx];
-    Packed PP{scratch + pd.pat}, T{scratch + pd.txt};
+    Packed PP{scratch + pd.pat, CLS_PAT_SH(pd.cls)}, T{scratch + pd.txt, CLS_TXT_SH(pd.cls)};
     const int nb = (pd.m + 31) >> 5;
     int d;
     if (nb <= 64) d = systolic_distance<1, P>(PP, pd.m, T, pd.n);
@@ -958,7 +1032,7 @@ __global__ __launch_bounds__(64) void k_edit_full_big(long long count, const uin
     if (q >= count) return;
     const uint32_t widx = big_list[q];
     const PairDesc pd = desc[widx];
-    Packed P{scratch + pd.pat}, T{scratch + pd.txt};
+    Packed P{scratch + pd.pat, CLS_PAT_SH(pd.cls)}, T{scratch + pd.txt, CLS_TXT_SH(pd.cls)};
     const int d = systolic_distance_big(P, pd.m, T, pd.n, state + state_off[q]);
     if (lane_id() == 0) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
 }
@@ -1014,36 +1088,53 @@ static void profile_round(svx_ctx* c, int round, const long long* seg_lo, const 
 
 #define MAX_ROUNDS 8
 
-static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src, int32_t* ed_dev, unsigned long long* cells_dev) {
+static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src_in, int32_t* ed_dev, unsigned long long* cells_dev) {
     if (n_work <= 0) return SVX_OK;
     if (n_work >= (1ll << 32)) return svx_fail(SVX_E_ARG, "more than 2^32 edit-distance pairs in one call", __FILE__, __LINE__, hipSuccess);
     hipStream_t st = c->stream;
     const int T = 256;
-    // 1. scratch sizing
-    SVXCHK(c->e_words.reserve((size_t)(n_work + 1) * 8));
-    SVXCHK(c->e_off.reserve((size_t)(n_work + 1) * 8));
-    k_pair_words<<<(unsigned)((n_work + 1 + T - 1) / T), T, 0, st>>>(n_work, src, c->e_words.as<int64_t>());
-    SVXCHK(svx_exclusive_scan_i64(c, c->e_words.as<int64_t>(), c->e_off.as<int64_t>(), n_work + 1));
+    PairSource src = src_in;
+    src.n_pairs = n_work;
+    SVXCHK(c->e_fail.reserve((size_t)(64 + MAX_ROUNDS * N_SORT_CLASSES) * 8));
+    unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..40] class bounds of round 0 (first [16..31] the span shards), [64 + 32 r ..] retry counters written by round r
+    HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(64 + MAX_ROUNDS * N_SORT_CLASSES) * 8, st));
+    // 1. packed store: one record per string / signature
+    src.radius = 0;
+    if (!src.plain) {
+        k_pair_span<<<(unsigned)(c->n_cu * 4), T, 0, st>>>(n_work, src, cnt);
+        unsigned long long shard[16], span = 0;
+        HIPCHK(hipMemcpyAsync(shard, cnt + 16, sizeof shard, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (unsigned long long v : shard) span = v > span ? v : span;
+        src.radius = (long long)span + 100;
+    }
+    const long long n_rec = src.plain ? 2 * n_work : src.in.n;
+    SVXCHK(c->e_words.reserve((size_t)(n_rec + 1) * 8));
+    SVXCHK(c->e_off.reserve((size_t)(n_rec + 1) * 8));
+    SVXCHK(c->e_rec.reserve((size_t)n_rec * sizeof(HapRec) + 64));
+    src.rec = c->e_rec.as<HapRec>();
+    k_hap_words<<<(unsigned)((n_rec + 1 + T - 1) / T), T, 0, st>>>(n_rec, src, c->e_words.as<int64_t>());
+    SVXCHK(svx_exclusive_scan_i64(c, c->e_words.as<int64_t>(), c->e_off.as<int64_t>(), n_rec + 1));
     int64_t total_words = 0;
-    HIPCHK(hipMemcpyAsync(&total_words, c->e_off.as<int64_t>() + n_work, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&total_words, c->e_off.as<int64_t>() + n_rec, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     SVXCHK(c->e_scratch.reserve((size_t)(total_words + 64) * 4));
+    HIPCHK(hipMemsetAsync(c->e_scratch.p, 0, 4, st));                    // the leading pad word
+    k_hap_pack<<<(unsigned)((n_rec + 3) / 4), 256, 0, st>>>(n_rec, src, c->e_off.as<int64_t>(), c->e_scratch.as<uint32_t>(), c->e_rec.as<HapRec>());
+    HIPCHK(hipGetLastError());
     SVXCHK(c->e_desc.reserve((size_t)n_work * sizeof(PairDesc)));
     SVXCHK(c->e_key.reserve((size_t)n_work * 8 * 2)); SVXCHK(c->e_val.reserve((size_t)n_work * 4 * 2));
     SVXCHK(c->e_slot.reserve((size_t)n_work * 8));
-    SVXCHK(c->e_fail.reserve((size_t)(64 + MAX_ROUNDS * N_SORT_CLASSES) * 8));
     SVXCHK(c->e_big_list.reserve((size_t)n_work * 4 + 64));
     uint64_t* key_a = c->e_key.as<uint64_t>(); uint64_t* key_b = key_a + n_work;
     uint32_t* val_a = c->e_val.as<uint32_t>(); uint32_t* val_b = val_a + n_work;
     long long* slot_of = c->e_slot.as<long long>();
-    unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..40] class bounds of round 0, [64 + 32 r ..] retry counters written by round r
     PairDesc* desc = c->e_desc.as<PairDesc>();
     uint32_t* scratch = c->e_scratch.as<uint32_t>();
     c->stats.n_hap_bytes += total_words * 4;
-    // 2. trim + pack + classify
-    HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(64 + MAX_ROUNDS * N_SORT_CLASSES) * 8, st));
+    // 2. trim + classify
     k_slots<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, src, slot_of);
-    k_edit_prep<<<(unsigned)((n_work + 3) / 4), 256, 0, st>>>(n_work, src, c->e_off.as<int64_t>(), scratch, desc, key_a, val_a, ed_dev, cells_dev, c->edit_force_full ? 1 : 0);
+    k_edit_prep<<<(unsigned)((n_work + 3) / 4), 256, 0, st>>>(n_work, src, scratch, desc, key_a, val_a, ed_dev, cells_dev, c->edit_force_full ? 1 : 0);
     HIPCHK(hipGetLastError());
     // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
     SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, 40));
@@ -1157,7 +1248,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
 int svx_edit_distance_pairs(svx_ctx* c, int64_t n_pairs, const uint8_t* codes_dev, const int64_t* a_off_dev, const int64_t* b_off_dev,
                             int32_t* out_dev) {
     PairSource src; memset(&src, 0, sizeof src);
-    src.plain = 1; src.codes = codes_dev; src.a_off = a_off_dev; src.b_off = b_off_dev;
+    src.plain = 1; src.codes = codes_dev; src.a_off = a_off_dev; src.b_off = b_off_dev; src.g_codes = codes_dev;
     return run_edit_pipeline(c, n_pairs, src, out_dev, nullptr);
 }
 
