@@ -163,8 +163,8 @@ struct PairDesc {
 
 #define CLS_FULL 5
 #define CLS_LANE0 6           /* 6..10: whole pattern (<= 32<<k rows) in one lane, full matrix, never fails */
-#define CLS_WIDE0 11          /* 11..13: full matrix, 2/4/8 lanes per pair with 512 rows each (m <= 1024 / 2048 / 4096) */
-#define N_CLASSES 14
+#define CLS_WIDE0 11          /* 11..14: full matrix, 2/4/8/16 lanes per pair with 512 rows each (m <= 1024 / 2048 / 4096 / 8192) */
+#define N_CLASSES 15
 #define MIN_MARGIN 16
 // A pair whose two cores hold only A/C/G/T (BAM codes 1,2,4,8) runs the 2-bit-plane kernels (P = 2); anything else (N, IUPAC codes,
 // the '=' filler) the generic 4-plane ones (P = 4).  PairDesc.cls bit 8 carries that flag; the sort class is flag*16 + class.
@@ -215,6 +215,7 @@ __device__ __forceinline__ int full_class_for(int m) {
     if (m <= 1024) return CLS_WIDE0;
     if (m <= 2048) return CLS_WIDE0 + 1;
     if (m <= 4096) return CLS_WIDE0 + 2;
+    if (m <= 8192) return CLS_WIDE0 + 3;
     return CLS_FULL;
 }
 
@@ -1021,7 +1022,8 @@ __global__ __launch_bounds__(256) void k_edit_fulls(FusedTab tab, const uint32_t
         case CLS_LANE0 + 4: d_edit_lane<16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
         case CLS_WIDE0: d_edit_wide<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
         case CLS_WIDE0 + 1: d_edit_wide<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
-        default: d_edit_wide<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
+        case CLS_WIDE0 + 2: d_edit_wide<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
+        default: d_edit_wide<16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
     }
 }
 
@@ -1185,8 +1187,8 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             FusedTab tf; memset(&tf, 0, sizeof tf);
             nblk = 0;
             // longest serial chains first: systolic (one wave per pair), 8/4/2 lanes per pair, then the lane classes
-            static const int order[9] = {CLS_FULL, CLS_WIDE0 + 2, CLS_WIDE0 + 1, CLS_WIDE0, CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};
-            for (int k = 0; k < 9; k++) {
+            static const int order[10] = {CLS_FULL, CLS_WIDE0 + 3, CLS_WIDE0 + 2, CLS_WIDE0 + 1, CLS_WIDE0, CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};
+            for (int k = 0; k < 10; k++) {
                 const int cls = order[k];
                 const long long cn = seg_cn[base + cls];
                 if (cn <= 0) continue;

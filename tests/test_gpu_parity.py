@@ -40,7 +40,7 @@ def test_edit_distance_long_vs_oracle(eng, oracle, alphabet):
     pairs = []
     for la, lb, sim in ((2047, 2049, True), (2100, 2300, True), (4000, 4100, False), (5000, 300, False),
                         (8200, 8300, True), (9000, 9100, False), (17000, 16500, True), (1, 5000, False), (0, 70, False),
-                        (3000, 3000, True)):
+                        (3000, 3000, True), (6000, 6500, False), (4100, 8000, False)):
         a = synth.random_seq(rng, la)
         if sim:
             b = list(a)
