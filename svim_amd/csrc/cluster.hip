@@ -632,7 +632,8 @@ template <int CAP, int LO>
 __global__ __launch_bounds__(64) void k_cluster(long long n_part, const int64_t* part_start, const uint32_t* sidx, const int32_t* sample_idx,
                                                 const int64_t* large_excl, const int64_t* samp_base, const int64_t* pair_off, const int32_t* ed,
                                                 ClusterIn in, svx_params p, Shard sh, Stage st, int32_t* ncl_out, int32_t* nmem_out,
-                                                unsigned long long* n_pairs_stat) {
+                                                unsigned long long* n_pairs_stat, int phase) {
+    // phase 0: every partition; 1: all but insertions (they need no edit distances and run beside the edit-distance rounds); 2: insertions
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const long long pt = blockIdx.x;
     if (pt >= n_part) return;
@@ -653,6 +654,7 @@ __global__ __launch_bounds__(64) void k_cluster(long long n_part, const int64_t*
     const long long sbase = samp_base[pt];
     const uint32_t g0 = member_gidx(ps, size, 0, sidx, sample_idx, large_excl, pt);
     const int t = in.type[g0];
+    if ((phase == 1 && t == SVX_INS) || (phase == 2 && t != SVX_INS)) return;
     const int contig = in.contig[g0];
     for (int q = lane; q < ns; q += 64) {
         const uint32_t g = member_gidx(ps, size, q, sidx, sample_idx, large_excl, pt);
@@ -892,26 +894,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
         }
     }
     HIPCHK(hipEventRecord(c->ev[9], st));
-    // ---- INS haplotype edit distances -----------------------------------------------------------------------------
-    SVXCHK(c->ed.reserve((size_t)(pair_total + 1) * 4));
-    unsigned long long h_cnt[16] = {0};
-    if (pair_total > 0) {
-        if (!c->g_off_p) return svx_fail(SVX_E_STATE, "svx_set_genome must precede clustering of insertions", __FILE__, __LINE__, hipSuccess);
-        SVXCHK(c->work.reserve((size_t)pair_total * sizeof(EditWork)));
-        k_ins_pairs<<<(unsigned)n_part, 64, 0, st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl, pairs_a, pair_off, in, p,
-                                                    c->work.as<EditWork>(), cnt + 8, pair_total, sh, cnt + 11);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h_cnt, cnt, 16 * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        const int64_t n_work = (int64_t)h_cnt[8];
-        c->n_remote_members = (int64_t)h_cnt[11];
-        SVXCHK(c->cell_shards.reserve(1024 * 8));
-        HIPCHK(hipMemsetAsync(c->cell_shards.p, 0, 1024 * 8, st));
-        SVXCHK(svx_launch_edit_pairs(c, n_work, c->work.p, in, c->ed.as<int32_t>(), c->cell_shards.as<unsigned long long>()));
-        S.n_edit_pairs = n_work;
-    }
-    HIPCHK(hipEventRecord(c->ev[10], st));
-    // ---- per-partition clustering into the staging area ---------------------------------------------------------
+    // ---- staging area of the per-partition clustering --------------------------------------------------------------
     const size_t SN = (size_t)(samp_total + 1);
     SVXCHK(c->stage.reserve(SN * (2 + 4 * 7 + 8 * 3) + 64));
     Stage stg;
@@ -932,12 +915,45 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     HIPCHK(hipMemsetAsync(ncl_a, 0, PM * 8, st));
     constexpr int SMALL = 48;
     auto cluster_lds = [](int cap) { return link_lds_bytes(cap) + sizeof(Member) * cap * 2 + sizeof(int) * (3 * cap + 2) + sizeof(double) * cap * 2 + 64; };
-    k_cluster<SMALL, 0><<<(unsigned)n_part, 64, cluster_lds(SMALL), st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
-                                                                      samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
-                                                                      ncl_a, nmem_a, cnt + 10);
-    k_cluster<MAXN, SMALL><<<(unsigned)n_part, 64, cluster_lds(MAXN), st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
-                                                                        samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
-                                                                        ncl_a, nmem_a, cnt + 10);
+    auto launch_cluster = [&](hipStream_t ks, int phase) {
+        k_cluster<SMALL, 0><<<(unsigned)n_part, 64, cluster_lds(SMALL), ks>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
+                                                                          samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
+                                                                          ncl_a, nmem_a, cnt + 10, phase);
+        k_cluster<MAXN, SMALL><<<(unsigned)n_part, 64, cluster_lds(MAXN), ks>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
+                                                                            samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
+                                                                            ncl_a, nmem_a, cnt + 10, phase);
+    };
+    SVXCHK(c->ed.reserve((size_t)(pair_total + 1) * 4));
+    // partitions without insertions need nothing from the edit-distance rounds: their linkage runs beside them on a side stream
+    const bool split = pair_total > 0;
+    if (split) {
+        HIPCHK(hipEventRecord(c->ev[13], st));
+        HIPCHK(hipStreamWaitEvent(c->aux[SVX_N_AUX - 1], c->ev[13], 0));
+        launch_cluster(c->aux[SVX_N_AUX - 1], 1);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev[14], c->aux[SVX_N_AUX - 1]));
+    }
+    // ---- INS haplotype edit distances -----------------------------------------------------------------------------
+    unsigned long long h_cnt[16] = {0};
+    if (pair_total > 0) {
+        if (!c->g_off_p) return svx_fail(SVX_E_STATE, "svx_set_genome must precede clustering of insertions", __FILE__, __LINE__, hipSuccess);
+        SVXCHK(c->work.reserve((size_t)pair_total * sizeof(EditWork)));
+        k_ins_pairs<<<(unsigned)n_part, 64, 0, st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl, pairs_a, pair_off, in, p,
+                                                    c->work.as<EditWork>(), cnt + 8, pair_total, sh, cnt + 11);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_cnt, cnt, 16 * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const int64_t n_work = (int64_t)h_cnt[8];
+        c->n_remote_members = (int64_t)h_cnt[11];
+        SVXCHK(c->cell_shards.reserve(1024 * 8));
+        HIPCHK(hipMemsetAsync(c->cell_shards.p, 0, 1024 * 8, st));
+        SVXCHK(svx_launch_edit_pairs(c, n_work, c->work.p, in, c->ed.as<int32_t>(), c->cell_shards.as<unsigned long long>()));
+        S.n_edit_pairs = n_work;
+    }
+    HIPCHK(hipEventRecord(c->ev[10], st));
+    // ---- per-partition clustering into the staging area ---------------------------------------------------------
+    launch_cluster(st, split ? 2 : 0);
+    if (split) HIPCHK(hipStreamWaitEvent(st, c->ev[14], 0));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[11], st));
     // ---- dense output ------------------------------------------------------------------------------------------------
