@@ -121,18 +121,14 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// MT19937 word source for one signature type.  The tempered words are also appended to a global stream so that the
-// per-partition sampling (phase B) can run in parallel once phase A has fixed where each partition starts reading.
-struct MtStream {
-    uint32_t* s;            // LDS state, 624 words
-    uint32_t* stream;       // global copy of every tempered word, in generation order
-    long long cap;          // capacity of `stream` (words)
-    long long gen;          // words generated so far (multiple of 624)
-    uint32_t buf;           // lane i: tempered word base+i of the current 624-block
-    int base, pos, lim;     // uniform cursor inside the block
-    int overflow;
-    __device__ void twist() {
-        const int lane = lane_id();
+// The tempered MT19937 words after random.seed(1524) are the same for every type and every call: they are generated ONCE per
+// context (k_mt_generate, regenerated only when a call needs a longer prefix) and every consumer just reads them.
+__global__ __launch_bounds__(64) void k_mt_generate(const uint32_t* mt_init, uint32_t* words, long long n_blocks) {
+    __shared__ uint32_t s[624];
+    const int lane = lane_id();
+    for (int i = lane; i < 624; i += 64) s[i] = mt_init[i];
+    __syncthreads();
+    for (long long blk = 0; blk < n_blocks; blk++) {
         // three dependency phases; inside a phase every lane reads before any lane of the same instruction writes
         for (int k0 = 0; k0 < 227; k0 += 64) { const int k = k0 + lane; uint32_t v = 0; const bool ok = k < 227;
             if (ok) { const uint32_t y = (s[k] & 0x80000000u) | (s[k + 1] & 0x7fffffffu); v = s[k + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
@@ -145,31 +141,44 @@ struct MtStream {
             __syncthreads(); if (ok) s[k] = v; __syncthreads(); }
         if (lane == 0) { const uint32_t y = (s[623] & 0x80000000u) | (s[0] & 0x7fffffffu); s[623] = s[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
         __syncthreads();
-        if (gen + 624 <= cap) { for (int k = lane; k < 624; k += 64) stream[gen + k] = mt_temper(s[k]); }
-        else overflow = 1;
-        gen += 624;
+        for (int k = lane; k < 624; k += 64) words[blk * 624 + k] = mt_temper(s[k]);
     }
-    __device__ long long position() const { return gen - 624 + base + pos; }      // global index of the next word
-    __device__ uint32_t next() {
-        if (pos == lim) {
-            base += 64;
-            if (base >= 624) { twist(); base = 0; }
-            const int k = base + lane_id();
-            buf = (k < 624) ? mt_temper(s[k]) : 0u;
-            lim = (624 - base) < 64 ? (624 - base) : 64;
-            pos = 0;
+}
+
+// cursor of one signature type over the shared word stream: lane i of `buf` holds word cur + i.  The words are staged through LDS
+// 4096 at a time: the walk is one lone wave, which cannot hide a dependent HBM/L2 round trip (~2 us) per 64 words.
+#define MT_STAGE 4096
+struct MtStream {
+    const uint32_t* words;  // tempered words, generation order
+    uint32_t* stage;        // LDS, MT_STAGE words
+    long long cap;          // words available
+    long long cur, sbase;   // global index of buf's lane 0 / of stage[0]
+    uint32_t buf;
+    int pos, lim;           // uniform cursor inside buf
+    int overflow;
+    __device__ void start() { cur = -64; sbase = -(long long)MT_STAGE; pos = 0; lim = 0; overflow = 0; buf = 0; }
+    __device__ long long position() const { return cur + pos; }      // global index of the next word
+    __device__ void refill() {
+        cur += 64;
+        if (cur + 64 > cap) overflow = 1;
+        if (cur + 64 > sbase + MT_STAGE) {
+            sbase = cur;
+            uint32_t v[MT_STAGE / 64];
+#pragma unroll
+            for (int i = 0; i < MT_STAGE / 64; i++) { const long long k = sbase + i * 64 + lane_id(); v[i] = (k < cap) ? words[k] : 0u; }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT_STAGE / 64; i++) stage[i * 64 + lane_id()] = v[i];
+            __syncthreads();
         }
+        buf = stage[(int)(cur - sbase) + lane_id()];
+        lim = 64; pos = 0;
+    }
+    __device__ uint32_t next() {
+        if (pos == lim) refill();
         const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)buf, pos);
         pos++;
         return w;
-    }
-    __device__ void refill() {
-        base += 64;
-        if (base >= 624) { twist(); base = 0; }
-        const int k = base + lane_id();
-        buf = (k < 624) ? mt_temper(s[k]) : 0u;
-        lim = (624 - base) < 64 ? (624 - base) : 64;
-        pos = 0;
     }
     // Consume exactly the words random.sample(range(n), 100) consumes with the pool method (n <= 1045) WITHOUT producing
     // the sample: draw i accepts a word iff word >> (32-k) < n-i.  64 words are classified at once; the only coupling
@@ -220,9 +229,8 @@ struct MtStream {
 // consumes (pool method, n <= 1045: acceptance does not depend on the sampled values).  Partitions above 1045 use the
 // set method, whose rejections depend on the values drawn: they are sampled right here.
 __global__ __launch_bounds__(64) void k_sample_scan(const int32_t* large_list, long long n_large, const int64_t* part_start, const uint32_t* sidx,
-                                                    const uint8_t* type, const int64_t* large_excl, const uint32_t* mt_init, uint32_t* stream,
-                                                    long long cap_per_type, long long* samp_start, int32_t* sample_idx, int* err) {
-    __shared__ uint32_t s[624];
+                                                    const uint8_t* type, const int64_t* large_excl, const uint32_t* stream,
+                                                    long long cap, long long* samp_start, int32_t* sample_idx, int* err) {
     const int t = blockIdx.x, lane = lane_id();
     // range of large partitions whose type is t (types are non-decreasing along the sorted order)
     long long lo = 0, hi = n_large;
@@ -232,16 +240,20 @@ __global__ __launch_bounds__(64) void k_sample_scan(const int32_t* large_list, l
     while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((int)type[sidx[part_start[large_list[mid]]]] <= t) lo = mid + 1; else hi = mid; }
     const long long end = lo;
     if (begin == end) return;
-    for (int i = lane; i < 624; i += 64) s[i] = mt_init[i];
-    __syncthreads();
-    MtStream mt; mt.s = s; mt.stream = stream + (long long)t * cap_per_type; mt.cap = cap_per_type; mt.gen = 0; mt.buf = 0;
-    mt.base = 624; mt.pos = 0; mt.lim = 0; mt.overflow = 0;                       // first next() twists (index == 624 after seeding)
+    __shared__ uint32_t stage[MT_STAGE];
+    MtStream mt; mt.words = stream; mt.stage = stage; mt.cap = cap; mt.start();
+    mt.refill();
+    int p_lane = 0; uint32_t n_lane = 0;                 // partition ids / sizes of 64 list entries at a time: no dependent loads in the walk
     for (long long q = begin; q < end; q++) {
-        const int p = large_list[q];
-        const uint32_t n = (uint32_t)(part_start[p + 1] - part_start[p]);
+        const int qi = (int)((q - begin) & 63);
+        if (qi == 0) {
+            const long long ql = q + lane;
+            p_lane = ql < end ? large_list[ql] : 0;
+            n_lane = ql < end ? (uint32_t)(part_start[p_lane + 1] - part_start[p_lane]) : 0u;
+        }
+        const int p = __builtin_amdgcn_readlane(p_lane, qi);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_lane, qi);
         if (n <= 1045) {
-            // before the very first twist position() has no block to refer to: generate it now
-            if (mt.gen == 0) { mt.twist(); mt.base = 0; mt.lim = 0; mt.pos = 0; const int k = lane; mt.buf = mt_temper(s[k]); mt.lim = 64; }
             if (lane == 0) samp_start[q] = mt.position();
             mt.skip_pool_sample(n);
         } else {
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(64) void k_sample_apply(const int32_t* large_list, 
     const int lane = lane_id();
     const int p = large_list[q];
     const int t = type[sidx[part_start[p]]];
-    const uint32_t* strm = stream + (long long)t * cap_per_type;
+    const uint32_t* strm = stream;              // one stream: every type restarts from seed(1524)
     const uint32_t n = (uint32_t)(part_start[p + 1] - part_start[p]);
     long long chunk = st;                   // words [chunk, chunk+64) sit in `buf`
     uint32_t buf = (chunk + lane < cap_per_type) ? strm[chunk + lane] : 0u;
@@ -867,30 +879,38 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     // ---- sampling ----------------------------------------------------------------------------------------------------
     SVXCHK(c->samp_idx.reserve((size_t)(n_large + 1) * 100 * 4));
     if (n_large > 0) {
-        SVXCHK(c->large_list.reserve((size_t)n_large * 4 + 624 * 4 + 64));
-        uint32_t* mt_dev = reinterpret_cast<uint32_t*>(c->large_list.as<int32_t>() + ((n_large + 1) & ~1ll));
-        uint32_t mt_host[624];
-        mt_seed_state(1524u, mt_host);
-        HIPCHK(hipMemcpyAsync(mt_dev, mt_host, sizeof mt_host, hipMemcpyHostToDevice, st));
+        SVXCHK(c->large_list.reserve((size_t)n_large * 4 + 64));
         k_large_list<<<GRID(n_part, T), T, 0, st>>>(large_a, large_excl, n_part, c->large_list.as<int32_t>());
         long long cap = n_large * 512 + 4 * 624;                       // expected use: <= ~200 words per partition
         for (int attempt = 0; attempt < 6; attempt++) {
-            SVXCHK(c->samp_stream.reserve((size_t)cap * SVX_NTYPES * 4 + (size_t)n_large * 8 + 64));
-            uint32_t* stream = c->samp_stream.as<uint32_t>();
-            long long* samp_start = reinterpret_cast<long long*>(stream + cap * SVX_NTYPES);
+            if (c->mt_have < cap) {
+                // (re)generate the prefix of the seed(1524) word stream this context keeps
+                const long long blocks = (2 * cap + 623) / 624;
+                SVXCHK(c->mt_words.reserve((size_t)blocks * 624 * 4 + 624 * 4 + 64));
+                uint32_t* mt_dev = c->mt_words.as<uint32_t>() + blocks * 624;
+                uint32_t mt_host[624];
+                mt_seed_state(1524u, mt_host);
+                HIPCHK(hipMemcpyAsync(mt_dev, mt_host, sizeof mt_host, hipMemcpyHostToDevice, st));
+                k_mt_generate<<<1, 64, 0, st>>>(mt_dev, c->mt_words.as<uint32_t>(), blocks);
+                HIPCHK(hipStreamSynchronize(st));       // mt_host is a stack buffer
+                c->mt_have = blocks * 624;
+            }
+            SVXCHK(c->samp_stream.reserve((size_t)n_large * 8 + 64));
+            const uint32_t* stream = c->mt_words.as<uint32_t>();
+            long long* samp_start = c->samp_stream.as<long long>();
             int* err = reinterpret_cast<int*>(cnt + 15);
             HIPCHK(hipMemsetAsync(err, 0, 8, st));
-            k_sample_scan<<<SVX_NTYPES, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl, mt_dev,
-                                                    stream, cap, samp_start, c->samp_idx.as<int32_t>(), err);
+            k_sample_scan<<<SVX_NTYPES, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
+                                                    stream, c->mt_have, samp_start, c->samp_idx.as<int32_t>(), err);
             k_sample_apply<<<(unsigned)n_large, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
-                                                            stream, cap, samp_start, c->samp_idx.as<int32_t>());
+                                                            stream, c->mt_have, samp_start, c->samp_idx.as<int32_t>());
             HIPCHK(hipGetLastError());
             int h_err = 0;
             HIPCHK(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));       // also covers mt_host (stack buffer)
+            HIPCHK(hipStreamSynchronize(st));
             if (!h_err) break;
             if (attempt == 5) return svx_fail(SVX_E_CAPACITY, "random word stream", __FILE__, __LINE__, hipSuccess);
-            cap *= 4;
+            cap = c->mt_have * 4;
         }
     }
     HIPCHK(hipEventRecord(c->ev[9], st));

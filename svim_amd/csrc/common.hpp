@@ -125,6 +125,7 @@ struct svx_ctx {
     DevBuf user_sig[12]; DevBuf c_rank;
     DevBuf k_hi, k_lo, k_idx, k_hi2, k_lo2, k_idx2, part_flag, part_id, part_start, part_meta, samp_idx, large_list, samp_stream;
     DevBuf cell_shards;
+    DevBuf mt_words; long long mt_have = 0;      // tempered MT19937 words after seed(1524), kept across calls
     DevBuf pair_off, ed, work, stage, stage_members, labels;
     DevBuf e_words, e_off, e_scratch, e_rec, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off;
     DevBuf e_retry[3];              // per-class retry lists of the edit-distance rounds (rotating)     // edit-distance pipeline
@@ -132,6 +133,12 @@ struct svx_ctx {
     int shard_rank = 0, shard_world = 1, shard_mode = 0;
     DevBuf shard_prefix;            // origin prefix (world+1 int64) for by-origin sharding
     int64_t n_remote_members = 0;   // members of owned INS partitions produced by another rank (by-origin mode)
+    // Band speculation: a pair without a useful distance bound starts in the band sized for edit_guess * (core length) differences beyond
+    // the length gap.  0.125 on a context's first call; afterwards the value that would have been cheapest for the previous call's
+    // pairs (their divergence histogram, see run_edit_pipeline) - the batches of one input share an error profile.  Routing only:
+    // results never depend on it.  SVX_EDIT_GUESS=<fraction> pins it.
+    float edit_guess = 0.125f; bool edit_guess_pinned = false;
+    DevBuf e_hist;
     bool edit_force_full = false;  // debugging aid (env SVX_EDIT_FORCE_FULL=1): every pair through the full-matrix kernel
     bool no_seq_gather = false;   // svx_cigar_indel hook: positions only
     svx_stats stats;

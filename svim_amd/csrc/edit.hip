@@ -161,17 +161,21 @@ struct PairDesc {
 #define CLS_PAT_SH(c) ((((c) >> 12) & 7) << 2)
 #define CLS_TXT_SH(c) ((((c) >> 16) & 7) << 2)
 
-#define CLS_FULL 5
-#define CLS_LANE0 6           /* 6..10: whole pattern (<= 32<<k rows) in one lane, full matrix, never fails */
-#define CLS_WIDE0 11          /* 11..14: full matrix, 2/4/8/16 lanes per pair with 512 rows each (m <= 1024 / 2048 / 4096 / 8192) */
-#define N_CLASSES 15
+// Band classes 0..NBAND-1: window of 32 * BAND_WORDS diagonals (0..2 sliding window, 3.. staircase window), tried in rounds.
+#define NBAND 9
+__host__ __device__ __forceinline__ int band_words(int b) { return b <= 2 ? (1 << b) : 2 * b; }     // 1 2 4 | 6 8 10 12 14 16
+#define CLS_FULL 9            /* systolic full matrix, one wave per pair */
+#define CLS_LANE0 10          /* 10..14: whole pattern (<= 32<<k rows) in one lane, full matrix, never fails */
+#define CLS_WIDE0 15          /* 15..18: full matrix, 2/4/8/16 lanes per pair with 512 rows each (m <= 1024 / 2048 / 4096 / 8192) */
+#define N_CLASSES 19
 #define MIN_MARGIN 16
 // A pair whose two cores hold only A/C/G/T (BAM codes 1,2,4,8) runs the 2-bit-plane kernels (P = 2); anything else (N, IUPAC codes,
-// the '=' filler) the generic 4-plane ones (P = 4).  PairDesc.cls bit 8 carries that flag; the sort class is flag*16 + class.
+// the '=' filler) the generic 4-plane ones (P = 4).  PairDesc.cls bit 8 carries that flag; the sort class is flag*32 + class.
 #define CLS_GENERIC 0x100
-#define N_SORT_CLASSES 32
+#define GENERIC_BASE 32
+#define N_SORT_CLASSES 64
 __device__ __forceinline__ unsigned long long sort_class(int cls_with_flag) {
-    return (unsigned long long)(((cls_with_flag & CLS_GENERIC) ? 16 : 0) + (cls_with_flag & 0xff));
+    return (unsigned long long)(((cls_with_flag & CLS_GENERIC) ? GENERIC_BASE : 0) + (cls_with_flag & 0xff));
 }
 // symbol as the P-plane kernels see it: P = 4 the BAM code itself, P = 2 A,C,G,T -> 0,1,2,3
 template <int P> __device__ __forceinline__ uint32_t sym(uint32_t c) {
@@ -187,12 +191,14 @@ __device__ __forceinline__ int lane_class_for(int m) { return m <= 32 ? 0 : m <=
 
 __device__ __forceinline__ int band_class_for(int need_w) {      // smallest class whose window keeps the needed margin
     // classes 0..2 (sliding window, d_edit_band): 14 diagonals are lost to the alignment of dmax to 7 (mod 8);
-    // classes 3, 4 (staircase window, d_edit_stair): the window stands still for 32 columns, which costs 32 more diagonals
-    if (need_w + 14 <= 32) return 0;
-    if (need_w + 14 <= 64) return 1;
-    if (need_w + 14 <= 128) return 2;
-    if (need_w + 46 <= 256) return 3;
-    if (need_w + 46 <= 512) return 4;
+    // classes 3.. (staircase window, d_edit_stair): the window stands still for 32 columns, which costs 32 more diagonals
+    for (int b = 0; b < NBAND; b++)
+        if (need_w + (b <= 2 ? 14 : 46) <= 32 * band_words(b)) return b;
+    return CLS_FULL;
+}
+// first band class with at least `words` state words (CLS_FULL if none)
+__device__ __forceinline__ int band_class_with_words(int words) {
+    for (int b = 0; b < NBAND; b++) if (band_words(b) >= words) return b;
     return CLS_FULL;
 }
 // window that guarantees exactness when the true distance is <= ub
@@ -228,29 +234,30 @@ __device__ __forceinline__ int full_class_for(int m) {
 #define MYERS_COLUMN(Q_, P_, pl_, pv_, mv_, nk_, carry_, ph_prev_, mh_prev_)                                   \
     _Pragma("unroll") for (int q0 = 0; q0 < Q_; q0 += MYERS_GROUP(Q_)) {                                        \
         constexpr int GQ = MYERS_GROUP(Q_);                                                                     \
+        const int gn = Q_ - q0 < GQ ? Q_ - q0 : GQ;                              /* words in this group (the last one may be short) */ \
         uint32_t eq_[GQ], xv_[GQ], sum_[GQ], ph_[GQ], mh_[GQ], phs_[GQ], mhs_[GQ];                              \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) {                                                        \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
             uint32_t e = pl_[0][q0 + g] ^ nk_[0];                                                               \
             _Pragma("unroll") for (int b = 1; b < P_; b++) e &= pl_[b][q0 + g] ^ nk_[b];                        \
             eq_[g] = e;                                                                                         \
         }                                                                                                       \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) { xv_[g] = eq_[g] | mv_[q0 + g]; sum_[g] = eq_[g] & pv_[q0 + g]; } \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) { xv_[g] = eq_[g] | mv_[q0 + g]; sum_[g] = eq_[g] & pv_[q0 + g]; } \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) {                                                        \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
             unsigned carry_out;                                                                                 \
             sum_[g] = __builtin_addc(sum_[g], pv_[q0 + g], carry_, &carry_out);    /* v_addc_co_u32: the carry stays in an SGPR pair */ \
             carry_ = carry_out;                                                                                 \
         }                                                                                                       \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) sum_[g] = (sum_[g] ^ pv_[q0 + g]) | eq_[g];              /* xh */ \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) { ph_[g] = mv_[q0 + g] | ~(sum_[g] | pv_[q0 + g]); mh_[g] = pv_[q0 + g] & sum_[g]; } \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) sum_[g] = (sum_[g] ^ pv_[q0 + g]) | eq_[g];  /* xh */ \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) { ph_[g] = mv_[q0 + g] | ~(sum_[g] | pv_[q0 + g]); mh_[g] = pv_[q0 + g] & sum_[g]; } \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) {                                                        \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
             phs_[g] = __builtin_amdgcn_alignbit(ph_[g], g ? ph_[g - 1] : ph_prev_, 31);      /* (ph << 1) | top bit of the word below */ \
             mhs_[g] = __builtin_amdgcn_alignbit(mh_[g], g ? mh_[g - 1] : mh_prev_, 31);                         \
         }                                                                                                       \
-        ph_prev_ = ph_[GQ - 1]; mh_prev_ = mh_[GQ - 1];                                                         \
+        ph_prev_ = ph_[gn - 1]; mh_prev_ = mh_[gn - 1];                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) { pv_[q0 + g] = mhs_[g] | ~(xv_[g] | phs_[g]); mv_[q0 + g] = phs_[g] & xv_[g]; } \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) { pv_[q0 + g] = mhs_[g] | ~(xv_[g] | phs_[g]); mv_[q0 + g] = phs_[g] & xv_[g]; } \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     }
 
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256) void k_hap_pack(long long n_rec, PairSource sr
 
 // ---- 2. trim + classify (one wave per pair, reads only the packed store) ---------------------------------------------------
 __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource src, const uint32_t* packed, PairDesc* desc,
-                                                   uint64_t* sort_key, uint32_t* sort_val, int32_t* ed, unsigned long long* cells, int force_full) {
+                                                   uint64_t* sort_key, uint32_t* sort_val, int32_t* ed, unsigned long long* cells, int force_full, float guess_frac) {
     const long long w = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (w >= n_work) return;
     const int lane = lane_id();
@@ -376,15 +383,16 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
         else if (zero) cls = full_class_for(pd.m);                       // symbol '=' (code 0) is the band kernel's "never matches" filler
         else {
             // `guaranteed` cannot fail (the trivial alignments bound the distance); when that bound is useless (position jitter
-            // shifts the two cores against each other) start from a band sized for ~12 % divergence and widen on failure.
+            // shifts the two cores against each other) start from a band sized for guess_frac * m differences and widen on failure.
             const int guaranteed = band_class_for(need_window(pd.m, pd.n, ub));
             int guess = 2 * MIN_MARGIN;
-            if (pd.m / 8 > guess) guess = pd.m / 8;
+            const int by_frac = (int)ceilf(guess_frac * (float)pd.m);
+            if (by_frac > guess) guess = by_frac;
             int spec = band_class_for((pd.n - pd.m) + guess + 1);
-            if (spec > 4 && band_class_for((pd.n - pd.m) + 2 * MIN_MARGIN + 1) <= 4) spec = 4;      // widest band before giving up on banding
+            if (spec == CLS_FULL && band_class_for((pd.n - pd.m) + 2 * MIN_MARGIN + 1) != CLS_FULL) spec = NBAND - 1;      // widest band before giving up on banding
             cls = guaranteed <= spec ? guaranteed : spec;
             // short patterns: the whole column fits one lane (k_edit_lane), nothing to speculate about
-            if (cls > 0 && pd.m <= 512 && lane_class_for(pd.m) <= cls) cls = CLS_LANE0 + lane_class_for(pd.m);
+            if (cls > 0 && cls < NBAND && pd.m <= 512 && (1 << lane_class_for(pd.m)) <= band_words(cls)) cls = CLS_LANE0 + lane_class_for(pd.m);
             else if (cls == CLS_FULL) cls = full_class_for(pd.m);
         }
         pd.cls = cls | (other ? CLS_GENERIC : 0) | sh_bits;
@@ -401,10 +409,11 @@ __device__ __forceinline__ void band_retry(const PairDesc& pd, uint32_t widx, in
     const int ub = d < pd.ub ? d : pd.ub;
     const int cur = pd.cls & 0xff;
     int cls = band_class_for(need_window(m, n, ub));   // cannot fail, but d from a too-narrow band can be a gross over-estimate:
-    if (cls > cur + 1) cls = cur + 1;                  // widen geometrically instead
-    if (cls <= cur) cls = cur + 1;                     // never retry the same width (can only differ by the alignment slack)
-    if (cls > 4) cls = CLS_FULL;
-    if (m <= 512 && lane_class_for(m) <= cls) cls = CLS_LANE0 + lane_class_for(m);
+    const int lo = band_class_with_words(2 * band_words(cur)), hi = band_class_with_words(4 * band_words(cur));
+    if (cls > hi) cls = hi;                            // widen geometrically (at most x4) instead
+    if (cls < lo) cls = lo;                            // and at least x2: a retry at nearly the same width mostly fails again
+    if (cls >= NBAND) cls = CLS_FULL;
+    if (cls < NBAND && m <= 512 && (1 << lane_class_for(m)) <= band_words(cls)) cls = CLS_LANE0 + lane_class_for(m);
     else if (cls == CLS_FULL) cls = full_class_for(m);
     const int flagged = cls | (pd.cls & ~0xff);          // keeps the alphabet flag and the nibble offsets
     desc[widx].ub = ub; desc[widx].cls = flagged;
@@ -1001,7 +1010,11 @@ __global__ __launch_bounds__(256) void k_edit_bands(FusedTab tab, const uint32_t
         case 0: d_edit_band<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
         case 1: d_edit_band<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
         case 2: d_edit_band<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
-        case 3: d_edit_stair<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
+        case 3: d_edit_stair<6, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
+        case 4: d_edit_stair<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
+        case 5: d_edit_stair<10, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
+        case 6: d_edit_stair<12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
+        case 7: d_edit_stair<14, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
         default: d_edit_stair<16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
     }
 }
@@ -1053,6 +1066,26 @@ __global__ void k_class_bounds(const uint64_t* keys, long long n, long long* bou
     bounds[c] = lo;
 }
 
+// ---- 6. divergence histogram ------------------------------------------------------------------------------------------
+// (d - (n-m)) / m of every pair with a core of at least 128 symbols, 256 bins, weighted by the core length: what the band
+// speculation of the NEXT call is calibrated with (svx_ctx::edit_guess)
+__global__ __launch_bounds__(256) void k_edit_hist(long long n_work, const PairDesc* desc, const long long* slot_of, const int32_t* ed, unsigned long long* hist) {
+    __shared__ unsigned long long h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < n_work; w += (long long)gridDim.x * 256) {
+        const PairDesc pd = desc[w];
+        if (pd.m < 128) continue;
+        const long long x = (long long)ed[slot_of[w]] - (pd.n - pd.m);
+        long long b = x * 256 / pd.m;
+        if (b < 0) b = 0;
+        if (b > 255) b = 255;
+        atomicAdd(&h[b], (unsigned long long)pd.m);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(hist + threadIdx.x, h[threadIdx.x]);
+}
+
 // ---- host orchestration -----------------------------------------------------------------------------------------
 // SVX_EDIT_PROFILE=1: per round and class, the pair count and the 32-bit word-columns the class kernel executes
 // (useful = sum over pairs, issued = what the lock-stepped waves pay: 64 x the longest text of each wave); stderr, one line per class
@@ -1062,14 +1095,14 @@ static void profile_round(svx_ctx* c, int round, const long long* seg_lo, const 
     if (hipMemcpyAsync(desc.data(), desc_dev, (size_t)n_desc * sizeof(PairDesc), hipMemcpyDeviceToHost, st) != hipSuccess) return;
     (void)hipStreamSynchronize(st);
     for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
-        const int cls = sc & 15, generic = sc >> 4;
+        const int cls = sc & (GENERIC_BASE - 1), generic = sc / GENERIC_BASE;
         const long long cn = seg_cn[sc];
         if (cls >= N_CLASSES || cn <= 0) continue;
         std::vector<uint32_t> list((size_t)cn);
         if (hipMemcpyAsync(list.data(), list_dev + seg_lo[sc], (size_t)cn * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return;
         (void)hipStreamSynchronize(st);
         int words = 0, per_wave = 64;                       // 32-bit words of column state per pair; pairs per wave
-        if (cls <= 4) words = 1 << cls;
+        if (cls < NBAND) words = band_words(cls);
         else if (cls >= CLS_LANE0 && cls < CLS_WIDE0) words = 1 << (cls - CLS_LANE0);
         else if (cls >= CLS_WIDE0) { words = 16 * (2 << (cls - CLS_WIDE0)); per_wave = 64 / (2 << (cls - CLS_WIDE0)); }
         double useful = 0, issued = 0, sum_m = 0, sum_n = 0;
@@ -1097,9 +1130,9 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     const int T = 256;
     PairSource src = src_in;
     src.n_pairs = n_work;
-    SVXCHK(c->e_fail.reserve((size_t)(64 + MAX_ROUNDS * N_SORT_CLASSES) * 8));
-    unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..40] class bounds of round 0 (first [16..31] the span shards), [64 + 32 r ..] retry counters written by round r
-    HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(64 + MAX_ROUNDS * N_SORT_CLASSES) * 8, st));
+    SVXCHK(c->e_fail.reserve((size_t)(128 + MAX_ROUNDS * N_SORT_CLASSES) * 8));
+    unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..40] class bounds of round 0 (first [16..31] the span shards), [128 + 64 r ..] retry counters written by round r
+    HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(128 + MAX_ROUNDS * N_SORT_CLASSES) * 8, st));
     // 1. packed store: one record per string / signature
     src.radius = 0;
     if (!src.plain) {
@@ -1136,11 +1169,11 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     c->stats.n_hap_bytes += total_words * 4;
     // 2. trim + classify
     k_slots<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, src, slot_of);
-    k_edit_prep<<<(unsigned)((n_work + 3) / 4), 256, 0, st>>>(n_work, src, scratch, desc, key_a, val_a, ed_dev, cells_dev, c->edit_force_full ? 1 : 0);
+    k_edit_prep<<<(unsigned)((n_work + 3) / 4), 256, 0, st>>>(n_work, src, scratch, desc, key_a, val_a, ed_dev, cells_dev, c->edit_force_full ? 1 : 0, c->edit_guess);
     HIPCHK(hipGetLastError());
     // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
     SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, 40));
-    k_class_bounds<<<1, 64, 0, st>>>(key_b, n_work, reinterpret_cast<long long*>(cnt + 8));
+    k_class_bounds<<<1, 128, 0, st>>>(key_b, n_work, reinterpret_cast<long long*>(cnt + 8));
     long long bounds[N_SORT_CLASSES + 1];
     HIPCHK(hipMemcpyAsync(bounds, cnt + 8, (N_SORT_CLASSES + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1159,18 +1192,18 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     for (int round = 0; pending > 0; round++) {
         if (round >= MAX_ROUNDS) return svx_fail(SVX_E_STATE, "edit-distance retry loop did not converge", __FILE__, __LINE__, hipSuccess);
         if (profile) profile_round(c, round, seg_lo, seg_cn, list, desc, n_work);
-        // retry lists this round's band launch appends to: 32 lists of `pending` slots.  Three buffers rotate; the one reused now was
+        // retry lists this round's band launch appends to: one list of `pending` slots per sort class.  Three buffers rotate; the one reused now was
         // last read by round-2's launches
         DevBuf& fb = c->e_retry[round % 3];
         if (round >= 2) HIPCHK(hipStreamSynchronize(full_st[round & 1]));
         SVXCHK(fb.reserve((size_t)N_SORT_CLASSES * (size_t)pending * 4 + 64));
-        unsigned long long* fail_cnt = cnt + 64 + (size_t)round * N_SORT_CLASSES;
+        unsigned long long* fail_cnt = cnt + 128 + (size_t)round * N_SORT_CLASSES;
         bool band_used[2] = {false, false};
         for (int generic = 0; generic <= 1; generic++) {
-            const int base = 16 * generic;
+            const int base = GENERIC_BASE * generic;
             FusedTab tb; memset(&tb, 0, sizeof tb);
             unsigned nblk = 0;
-            for (int cls = 4; cls >= 0; cls--) {                                  // widest band first
+            for (int cls = NBAND - 1; cls >= 0; cls--) {                          // widest band first
                 const long long cn = seg_cn[base + cls];
                 if (cn <= 0) continue;
                 tb.kind[tb.n] = cls; tb.lo[tb.n] = seg_lo[base + cls]; tb.cn[tb.n] = cn; tb.first_block[tb.n] = nblk;
@@ -1242,6 +1275,33 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                                                           c->e_big_state.as<uint32_t>());
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));
+        }
+    }
+    if (!c->edit_guess_pinned && n_work >= 4096) {
+        // calibrate the next call's band speculation: the fraction g that minimises  g + 0.75 * (weight of the pairs beyond g)
+        // (a band costs ~ g per cell column, a failed speculation roughly a full matrix)
+        SVXCHK(c->e_hist.reserve(256 * 8));
+        HIPCHK(hipMemsetAsync(c->e_hist.p, 0, 256 * 8, st));
+        k_edit_hist<<<(unsigned)(c->n_cu * 2), 256, 0, st>>>(n_work, desc, slot_of, ed_dev, c->e_hist.as<unsigned long long>());
+        unsigned long long h[256];
+        HIPCHK(hipMemcpyAsync(h, c->e_hist.p, sizeof h, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double total = 0, below = 0, best_cost = 1e300;
+        for (int b = 0; b < 256; b++) total += (double)h[b];
+        if (total > 0) {
+            int best = 31;
+            for (int b = 0; b < 128; b++) {
+                below += (double)h[b];
+                const double g = (b + 1) / 256.0, cost = g + 0.75 * (1.0 - below / total);
+                if (cost < best_cost) { best_cost = cost; best = b; }
+            }
+            c->edit_guess = (float)((best + 2) / 256.0);
+            if (profile) {
+                double acc = 0;
+                fprintf(stderr, "{\"edit_guess\": %.4f, \"cum_weight_by_bin\": [", c->edit_guess);
+                for (int b = 0; b < 256; b++) { acc += (double)h[b]; if (b % 8 == 7) fprintf(stderr, "%.3f%s", acc / total, b == 255 ? "" : ", "); }
+                fprintf(stderr, "]}\n");
+            }
         }
     }
     return SVX_OK;
