@@ -168,12 +168,12 @@ int  svx_set_genome(svx_ctx* ctx, const svx_genome* g);      /* FastaFile(option
 int  svx_cluster(svx_ctx* ctx, int source, const svx_sig_view* sigs, int32_t n_contig,
                  const int32_t* contig_rank_host, const svx_params* p);
 int  svx_cluster_count(svx_ctx* ctx, int64_t* n_clusters, int64_t* n_members);
-int  svx_cluster_fetch(svx_ctx* ctx, svx_cluster_view* host_out);
+int  svx_cluster_fetch(svx_ctx* ctx, svx_cluster_view* out);  /* destination arrays: host or device memory */
 
 /* multi-GPU: cluster only partitions with (global partition index % world) == rank; the caller gathers
  * the per-rank cluster tables (RCCL) and merges them by partition index (returned in part_index) */
 int  svx_cluster_set_shard(svx_ctx* ctx, int rank, int world);
-int  svx_cluster_fetch_part_index(svx_ctx* ctx, int64_t* host_out /* [n_clusters] */);
+int  svx_cluster_fetch_part_index(svx_ctx* ctx, int64_t* out /* [n_clusters], host or device memory */);
 /* alternative ownership for contig-sharded input: the table passed to svx_cluster is the rank-major concatenation of the
  * per-rank tables, origin_prefix[r] = first global index of rank r; a partition belongs to the rank that produced its first
  * sorted member, so its inserted sequences are already local (only that rank's seq ranges need to be non-empty).

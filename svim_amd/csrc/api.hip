@@ -212,11 +212,13 @@ extern "C" int svx_cluster_fetch(svx_ctx* c, svx_cluster_view* o) {
     DevClusters& v = c->clu;
     const size_t n = (size_t)v.n;
     hipStream_t st = c->stream;
-#define D2H(dst, buf, bytes) do { if ((bytes) && (dst)) HIPCHK(hipMemcpyAsync((dst), (buf).p, (bytes), hipMemcpyDeviceToHost, st)); } while (0)
+    // hipMemcpyDefault: the destination arrays may be host or device memory (the multi-GPU exchange keeps them in HBM)
+#define D2H(dst, buf, bytes) do { if ((bytes) && (dst)) HIPCHK(hipMemcpyAsync((dst), (buf).p, (bytes), hipMemcpyDefault, st)); } while (0)
     D2H(o->type, v.type, n); D2H(o->aux, v.aux, n); D2H(o->contig, v.contig, n * 4); D2H(o->start, v.start, n * 4); D2H(o->end, v.end, n * 4);
     D2H(o->contig2, v.contig2, n * 4); D2H(o->start2, v.start2, n * 4); D2H(o->end2, v.end2, n * 4); D2H(o->score, v.score, n * 8);
     D2H(o->std_span, v.std_span, n * 8); D2H(o->std_pos, v.std_pos, n * 8); D2H(o->size, v.size, n * 4);
-    if (o->member_off) { if (n) HIPCHK(hipMemcpyAsync(o->member_off, v.member_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, st)); else o->member_off[0] = 0; }
+    static const int64_t zero_off = 0;
+    if (o->member_off) { if (n) HIPCHK(hipMemcpyAsync(o->member_off, v.member_off.p, (n + 1) * 8, hipMemcpyDefault, st)); else HIPCHK(hipMemcpyAsync(o->member_off, &zero_off, 8, hipMemcpyDefault, st)); }
     D2H(o->members, v.members, (size_t)v.n_members * 4);
 #undef D2H
     HIPCHK(hipStreamSynchronize(st));
@@ -227,7 +229,7 @@ extern "C" int svx_cluster_fetch(svx_ctx* c, svx_cluster_view* o) {
 
 extern "C" int svx_cluster_fetch_part_index(svx_ctx* c, int64_t* host_out) {
     HIPCHK(hipSetDevice(c->device));
-    if (c->clu.n) HIPCHK(hipMemcpyAsync(host_out, c->clu.part_index.p, (size_t)c->clu.n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (c->clu.n) HIPCHK(hipMemcpyAsync(host_out, c->clu.part_index.p, (size_t)c->clu.n * 8, hipMemcpyDefault, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return SVX_OK;
 }

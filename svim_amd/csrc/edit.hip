@@ -4,21 +4,30 @@
 //   hap_k = ref[ws:start_k] + inserted_k + ref[start_k:we]   (window = min/max start -+ 100, clipped to the contig)
 // as Python strings with four FASTA fetches per pair and calls edlib.align(h1, h2)["editDistance"].
 //
-// Pipeline (all exact):
-//   1. k_pair_words / scan      size the scratch that will hold every pair's two trimmed cores
-//   2. k_edit_prep (wave/pair)  a `Hap` is a virtual concatenation of three byte ranges in HBM (genome codes + the
-//                               signature's inserted bases); the common prefix/suffix is stripped wave-parallel and the
-//                               two cores are written 4-bit packed (8 symbols per 32-bit word), plus a Hamming-style
-//                               upper bound of the distance
-//   3. k_edit_band<Q> (LANE/pair) Ukkonen band of 32*Q diagonals around the main corridor, Myers/Hyyro bit-vector
-//                               recurrence in band-relative coordinates (the window slides one row per column), all
-//                               state in registers: Q words each of Pv, Mv and the 4 bit-planes of the pattern window.
-//                               The result d is exact iff floor((d-(n-m))/2) <= band margin; otherwise d is only an
-//                               upper bound and the pair is retried with the band that bound guarantees
-//   4. k_edit_full (wave/pair)  pairs whose band would exceed 512 diagonals: full matrix as a 64-lane systolic array
-//                               (lane l owns R 32-row blocks, column t-l at step t, carries handed down with one DPP
-//                               wave shift); cores longer than 16384 rows keep their block state in a scratch area
-// No LDS, no MFMA: integer-ALU bound (reported as cell updates/s).
+// Pipeline (all exact; what varies with the data is only the ROUTE a pair takes, never its result):
+//   1. k_hap_words / scan / k_hap_pack   one 4-bit packed record per insertion signature:
+//                               ref[start-R, start) + inserted bases + ref[start, start+R), R = largest |start_a - start_b| of the
+//                               work list + 100.  The haplotype of any pair a signature takes part in is a substring of its record
+//                               (a nibble offset + a length), so nothing is materialised per pair.
+//   2. k_edit_prep (wave/pair)  common prefix / suffix stripped on the packed words (8 symbols per lane and step), Hamming-style
+//                               upper bound, class choice.  A pair is described by 32 bytes (PairDesc).
+//   3. rounds.  Per round TWO fused launches: k_edit_bands (every band class, may fail) on a high-priority stream and
+//      k_edit_fulls (every full-matrix class, never fails) on a low-priority one; a block looks up its class segment.
+//        d_edit_band<Q>  (lane/pair, classes 0..2: 32/64/128 diagonals)  Ukkonen band in band-relative coordinates, the window
+//                               slides one row per column
+//        d_edit_stair<Q> (lane/pair, classes 3..8: 192..512 diagonals)   window stands still for 32 columns, then drops a word
+//        d_edit_lane<Q>  (lane/pair)  whole pattern (<= 512 rows) in one lane, full matrix
+//        d_edit_wide<G>  (G = 2..16 lanes/pair, 512 rows each)           full matrix up to 8192 rows, DPP hand-off between lanes
+//        d_edit_full     (wave/pair)  64-lane systolic full matrix; cores beyond 16384 rows keep block state in a scratch area
+//      All share one column update (MYERS_COLUMN: Myers/Hyyro bit-vector recurrence, add-with-carry chain, explicit v_bitop3),
+//      in a 2-bit-plane (A/C/G/T only) and a 4-bit-plane (any BAM code) instantiation.
+//      A band result d is exact iff floor((d-(n-m))/2) <= band margin; otherwise d is only an upper bound and the pair is appended
+//      to the retry list of a wider class (2x..4x), consumed by the next round without re-sorting.  A round waits only for its
+//      band launch, so retry rounds overlap the full-matrix work of earlier rounds.
+//   4. k_edit_hist              divergence histogram of this call's pairs; calibrates the NEXT call's band speculation.
+// No LDS, no MFMA: integer-ALU bound (reported as cell updates/s).  Instruction-rate facts the kernels are shaped by are
+// measured by tools/micro/valu_ops.hip and valu_dep.hip (v_alignbit / v_addc_co are half rate, v_bitop3 full rate, a dependent
+// chain mixing both issues at ~4 cycles per instruction).
 #include "common.hpp"
 
 struct EditWork { uint32_t a, b; long long slot; };

@@ -163,9 +163,89 @@ def _all_gather_var(t, counts, dist, torch):
     return torch.cat([out[r * mx:r * mx + c] for r, c in enumerate(counts)])
 
 
+class DeviceClusterTable:
+    """Merged cluster table resident in HBM (torch tensors, same columns as ClusterTable); to_host() for consumers on the CPU."""
+
+    def __init__(self, cols, member_off, members, part_index):
+        self.cols, self.member_off, self.members, self.part_index = cols, member_off, members, part_index
+        self.n, self.n_members = int(part_index.numel()), int(members.numel())
+
+    def to_host(self):
+        out = ClusterTable(self.n, self.n_members)
+        for k in CLU_DTYPES:
+            setattr(out, k, self.cols[k].cpu().numpy())
+        out.member_off = self.member_off.cpu().numpy()
+        out.members = self.members.cpu().numpy()
+        out.part_index = self.part_index.cpu().numpy()
+        out.n, out.n_members = self.n, self.n_members
+        out.type_count = [int((out.type == k).sum()) for k in range(6)]
+        return out
+
+
+def fetch_clusters_device(eng, dev):
+    """This rank's cluster table as device tensors (svx_cluster_fetch with device destinations): (cols, members, part_index)."""
+    import ctypes as C
+    import torch
+    from ._lib import _check
+    n, nm = C.c_int64(), C.c_int64()
+    _check(eng.L.svx_cluster_count(eng.ctx, C.byref(n), C.byref(nm)), "svx_cluster_count")
+    n, nm = n.value, nm.value
+    tdt = {np.uint8: torch.uint8, np.int32: torch.int32, np.float64: torch.float64}
+    cols = {k: torch.empty(max(1, n), dtype=tdt[dt], device=dev) for k, dt in CLU_DTYPES.items()}
+    member_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    members = torch.empty(max(1, nm), dtype=torch.int32, device=dev)
+    part_index = torch.empty(max(1, n), dtype=torch.int64, device=dev)
+    cv = _abi.ClusterView()
+    cv.n = n
+    for k in CLU_DTYPES:
+        setattr(cv, k, _abi.ptr(cols[k]))
+    cv.member_off, cv.members = _abi.ptr(member_off), _abi.ptr(members)
+    _check(eng.L.svx_cluster_fetch(eng.ctx, C.byref(cv)), "svx_cluster_fetch")
+    _check(eng.L.svx_cluster_fetch_part_index(eng.ctx, _abi.ptr(part_index)), "svx_cluster_fetch_part_index")
+    return {k: v[:n] for k, v in cols.items()}, members[:nm], part_index[:n]
+
+
+def gather_clusters_device(eng, contig_rank, dev):
+    """RCCL all-gather of the per-rank cluster tables and the merge of merge_cluster_tables, all on the device: nothing of the
+    exchange touches the host (the member lists are ~4 B per signature; a host merge grows with the world size)."""
+    import torch
+    import torch.distributed as dist
+    cols, members, part_index = fetch_clusters_device(eng, dev)
+    world = dist.get_world_size()
+    cnt = torch.tensor([part_index.numel(), members.numel()], dtype=torch.int64, device=dev)
+    allc = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(allc, cnt)
+    ns = [int(c[0].item()) for c in allc]
+    nms = [int(c[1].item()) for c in allc]
+    g = {k: _all_gather_var(v, ns, dist, torch) for k, v in cols.items()}
+    g_part = _all_gather_var(part_index, ns, dist, torch)
+    g_mem = _all_gather_var(members, nms, dist, torch)
+    n, nm = sum(ns), sum(nms)
+    sizes = g["size"].to(torch.int64)
+    # first member of every gathered cluster inside g_mem (tables are concatenated rank-major, members likewise)
+    src_off = torch.cumsum(sizes, 0) - sizes
+    rank_t = torch.as_tensor(np.asarray(contig_rank), dtype=torch.int64, device=dev)
+    t = g["type"].to(torch.int64)
+    uni = t <= 2
+    zero = torch.zeros_like(t)
+    k1 = torch.where(uni, rank_t[g["contig"].to(torch.int64).clamp_min(0)], zero)
+    k2 = torch.where(uni, g["start"].to(torch.int64) + g["end"].to(torch.int64), zero)
+    # lexsort((arange, part_index, k2, k1, t)) as a chain of stable sorts, least significant key first
+    order = torch.arange(n, dtype=torch.int64, device=dev)
+    for key in (g_part, k2, k1, t):
+        order = order[torch.sort(key[order], stable=True).indices]
+    out_cols = {k: v[order] for k, v in g.items()}
+    out_sizes = sizes[order]
+    member_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(out_sizes, 0, out=member_off[1:])
+    src_idx = torch.repeat_interleave(src_off[order] - member_off[:-1], out_sizes) + torch.arange(nm, dtype=torch.int64, device=dev)
+    return DeviceClusterTable(out_cols, member_off, g_mem[src_idx], g_part[order])
+
+
 def device_pipeline_step(eng, params, rank, world, dev, read_id_stride=1 << 26):
     """COLLECT already ran on this rank's records (results resident in its context).  Exchange the signature tables,
-    cluster the partitions this rank owns, gather the cluster tables.  Returns the merged ClusterTable (every rank).
+    cluster the partitions this rank owns, all-gather and merge the cluster tables on the device.  Returns the merged
+    DeviceClusterTable (every rank; .to_host() gives the ClusterTable).
 
     Each rank's batch lives on its own contig: contig id := rank, read ids are made globally unique by a per-rank stride.
     Fast path: only the fixed-width columns (37 B/signature) are all-gathered and partitions are owned "by origin"
@@ -173,9 +253,20 @@ def device_pipeline_step(eng, params, rank, world, dev, read_id_stride=1 << 26):
     inserted sequence - is already local.  If any rank reports remote members, the step is redone with the inserted
     sequences all-gathered as well and index-modulo ownership (always correct, more traffic)."""
     import ctypes as C
+    import os
+    import time
     import torch
     import torch.distributed as dist
     from ._lib import _check
+    timing = os.environ.get("SVX_DIST_TIMING") == "1" and rank == 0
+    marks = []
+
+    def mark(label):
+        if timing:
+            torch.cuda.synchronize()
+            marks.append((label, time.perf_counter()))
+
+    mark("start")
     n, nseq, _ = eng.collect_counts()
     cnt = torch.tensor([n, nseq], dtype=torch.int64, device=dev)
     allc = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -193,10 +284,12 @@ def device_pipeline_step(eng, params, rank, world, dev, read_id_stride=1 << 26):
         setattr(v, k, _abi.ptr(cols[k]))
     v.seq_off, v.seq = _abi.ptr(seq_off), _abi.ptr(seq)
     _check(eng.L.svx_collect_fetch(eng.ctx, 0, C.byref(v)), "svx_collect_fetch")
+    mark("fetch own table")
     cols["contig"] = cols["contig"] + rank                       # this rank's contig
     cols["contig2"] = torch.where(cols["contig2"] >= 0, cols["contig2"] + rank, cols["contig2"])
     cols["read_id"] = cols["read_id"] + rank * read_id_stride
     g = {k: _all_gather_var(cols[k][:n], ns, dist, torch) for k, _ in _DEV_COLS}
+    mark("all-gather columns")
     N = sum(ns)
     prefix = np.zeros(world + 1, dtype=np.int64)
     prefix[1:] = np.cumsum(ns)
@@ -217,7 +310,8 @@ def device_pipeline_step(eng, params, rank, world, dev, read_id_stride=1 << 26):
     g_off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
     torch.cumsum(g_len, 0, out=g_off[1:])
     torch.cuda.synchronize()      # the gathered tensors were produced on torch's / RCCL's streams; libsvx has its own stream
-    ct = eng.cluster(params, contig_rank, table=view(g_off, seq[:max(1, nseq)]), source=2, shard=(rank, world), origin_prefix=prefix)
+    eng.cluster(params, contig_rank, table=view(g_off, seq[:max(1, nseq)]), source=2, shard=(rank, world), origin_prefix=prefix, fetch=False)
+    mark("cluster owned partitions")
     remote = torch.tensor([eng.remote_members()], dtype=torch.int64, device=dev)
     dist.all_reduce(remote, op=dist.ReduceOp.MAX)
     if int(remote.item()) > 0:
@@ -227,8 +321,13 @@ def device_pipeline_step(eng, params, rank, world, dev, read_id_stride=1 << 26):
         a_off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
         torch.cumsum(a_len, 0, out=a_off[1:])
         torch.cuda.synchronize()
-        ct = eng.cluster(params, contig_rank, table=view(a_off, a_seq), source=2, shard=(rank, world))
-    return gather_clusters(ct, contig_rank, device=dev)
+        eng.cluster(params, contig_rank, table=view(a_off, a_seq), source=2, shard=(rank, world), fetch=False)
+    out = gather_clusters_device(eng, contig_rank, dev)
+    mark("gather + merge clusters")
+    if timing:
+        import sys
+        sys.stderr.write("dist step: " + ", ".join("%s %.2f ms" % (b[0], (b[1] - a[1]) * 1e3) for a, b in zip(marks, marks[1:])) + "\n")
+    return out
 
 
 def all_gather_genomes(genome, dev):

@@ -257,7 +257,7 @@ def test_dropin_api_matches_reference_golden(eng):
 
 def test_device_pipeline_step_single_rank(eng, oracle):
     """bench.py's multi-GPU step (device-to-device fetch, RCCL all-gather of the signature tables, sharded clustering,
-    cluster gather) with a process group of one rank must reproduce the plain single-GPU result."""
+    cluster all-gather + merge on the device) with a process group of one rank must reproduce the plain single-GPU result."""
     import os
     import socket
     import torch
@@ -281,7 +281,8 @@ def test_device_pipeline_step_single_rank(eng, oracle):
         eng.collect(b.struct(), p, fetch=False)
         direct = eng.cluster(p, np.zeros(1, np.int32), source=0)
         eng.collect(b.struct(), p, fetch=False)
-        merged = device_pipeline_step(eng, p, 0, 1, dev)
+        merged_dev = device_pipeline_step(eng, p, 0, 1, dev)
+        merged = merged_dev.to_host()
         assert merged.n > 50
         assert merged.first_difference(direct) is None
         # and the device-generated batch agrees with the oracle (device pointers in, host tables out)
