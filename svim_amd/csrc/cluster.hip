@@ -277,6 +277,61 @@ __global__ __launch_bounds__(64) void k_sample_scan(const int32_t* large_list, l
     if (mt.overflow && lane == 0) *err = 1;
 }
 
+// ---- Phase A without the serial walk -----------------------------------------------------------------------------------
+// How many words a pool-method partition consumes depends only on its size and on where in the stream it starts.  The host
+// brackets every partition's start (window = expected start -+ 6 sigma, from the exact mean / variance of the rejection
+// sampling), k_sample_tables simulates EVERY (partition, candidate start) with one lane each - ~10^6 independent ~150-word
+// walks, ideal GPU work - and k_sample_chase is left with one table lookup per partition.  Any surprise (a start outside its
+// window, a set-method partition, the stream running out) raises `err` and the caller falls back to k_sample_scan.
+struct SampleMeta { long long lo; int width; int n; long long off; };      // window [lo, lo + width), partition size, first table slot
+
+__global__ void k_large_info(const int32_t* large_list, long long n_large, const int64_t* part_start, const uint32_t* sidx, const uint8_t* type,
+                             int32_t* info /* [2 n_large]: type, size */) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_large) return;
+    const int p = large_list[q];
+    info[2 * q] = type[sidx[part_start[p]]];
+    info[2 * q + 1] = (int32_t)(part_start[p + 1] - part_start[p]);
+}
+
+__global__ __launch_bounds__(256) void k_sample_tables(const SampleMeta* meta, const uint32_t* stream, long long cap, uint16_t* table) {
+    const SampleMeta m = meta[blockIdx.y];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= m.width) return;
+    long long pos = m.lo + s;
+    const long long start = pos;
+    uint32_t bound = (uint32_t)m.n;
+    bool ok = true;
+    for (int i = 0; i < 100; i++, bound--) {
+        const int k = 32 - __clz((int)bound);           // Random._randbelow_with_getrandbits: k = bound.bit_length()
+        for (;;) {
+            if (pos >= cap) { ok = false; break; }
+            const uint32_t r = stream[pos++] >> (32 - k);
+            if (r < bound) break;
+        }
+        if (!ok) break;
+    }
+    const long long used = pos - start;
+    table[m.off + s] = (ok && used < 0xffff) ? (uint16_t)used : (uint16_t)0xffff;
+}
+
+// one lane per type follows its partitions through the tables
+__global__ void k_sample_chase(const SampleMeta* meta, const long long* type_begin /* [NTYPES + 1] */, const uint16_t* table, long long* samp_start,
+                               int* err) {
+    const int t = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    long long pos = 0;
+    for (long long q = type_begin[t]; q < type_begin[t + 1]; q++) {
+        const SampleMeta m = meta[q];
+        const long long idx = pos - m.lo;
+        if (m.width <= 0 || idx < 0 || idx >= m.width) { *err = 1; return; }
+        const uint16_t used = table[m.off + idx];
+        if (used == 0xffff) { *err = 1; return; }
+        samp_start[q] = pos;
+        pos += used;
+    }
+}
+
 // Phase B: one wave per pool-method partition replays random.sample from its slice of the word stream.
 __global__ __launch_bounds__(64) void k_sample_apply(const int32_t* large_list, long long n_large, const int64_t* part_start, const uint32_t* sidx,
                                                      const uint8_t* type, const int64_t* large_excl, const uint32_t* stream, long long cap_per_type,
@@ -882,23 +937,86 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
         SVXCHK(c->large_list.reserve((size_t)n_large * 4 + 64));
         k_large_list<<<GRID(n_part, T), T, 0, st>>>(large_a, large_excl, n_part, c->large_list.as<int32_t>());
         long long cap = n_large * 512 + 4 * 624;                       // expected use: <= ~200 words per partition
-        for (int attempt = 0; attempt < 6; attempt++) {
-            if (c->mt_have < cap) {
-                // (re)generate the prefix of the seed(1524) word stream this context keeps
-                const long long blocks = (2 * cap + 623) / 624;
-                SVXCHK(c->mt_words.reserve((size_t)blocks * 624 * 4 + 624 * 4 + 64));
-                uint32_t* mt_dev = c->mt_words.as<uint32_t>() + blocks * 624;
-                uint32_t mt_host[624];
-                mt_seed_state(1524u, mt_host);
-                HIPCHK(hipMemcpyAsync(mt_dev, mt_host, sizeof mt_host, hipMemcpyHostToDevice, st));
-                k_mt_generate<<<1, 64, 0, st>>>(mt_dev, c->mt_words.as<uint32_t>(), blocks);
-                HIPCHK(hipStreamSynchronize(st));       // mt_host is a stack buffer
-                c->mt_have = blocks * 624;
+        auto ensure_stream = [&](long long want) -> int {
+            if (c->mt_have >= want) return SVX_OK;
+            // (re)generate the prefix of the seed(1524) word stream this context keeps
+            const long long blocks = (2 * want + 623) / 624;
+            SVXCHK(c->mt_words.reserve((size_t)blocks * 624 * 4 + 624 * 4 + 64));
+            uint32_t* mt_dev = c->mt_words.as<uint32_t>() + blocks * 624;
+            uint32_t mt_host[624];
+            mt_seed_state(1524u, mt_host);
+            HIPCHK(hipMemcpyAsync(mt_dev, mt_host, sizeof mt_host, hipMemcpyHostToDevice, st));
+            k_mt_generate<<<1, 64, 0, st>>>(mt_dev, c->mt_words.as<uint32_t>(), blocks);
+            HIPCHK(hipStreamSynchronize(st));       // mt_host is a stack buffer
+            c->mt_have = blocks * 624;
+            return SVX_OK;
+        };
+        SVXCHK(ensure_stream(cap));
+        SVXCHK(c->samp_stream.reserve((size_t)n_large * 8 + 64));
+        long long* samp_start = c->samp_stream.as<long long>();
+        int* err = reinterpret_cast<int*>(cnt + 15);
+        bool done = false;
+        {   // table path
+            SVXCHK(c->samp_meta.reserve((size_t)n_large * (8 + sizeof(SampleMeta)) + (SVX_NTYPES + 1) * 8 + 64));
+            int32_t* info_dev = c->samp_meta.as<int32_t>();
+            k_large_info<<<GRID(n_large, T), T, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, info_dev);
+            std::vector<int32_t> info((size_t)n_large * 2);
+            HIPCHK(hipMemcpyAsync(info.data(), info_dev, (size_t)n_large * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            std::vector<SampleMeta> meta((size_t)n_large);
+            long long type_begin[SVX_NTYPES + 1];
+            bool table_ok = true;
+            long long slots = 0, q = 0;
+            int max_width = 0;
+            for (int t = 0; t <= SVX_NTYPES; t++) type_begin[t] = n_large;
+            for (int t = 0; t < SVX_NTYPES && table_ok; t++) {
+                while (q < n_large && info[(size_t)q * 2] < t) q++;
+                type_begin[t] = q;
+                double mean = 0, var = 0;
+                long long least = 0;
+                for (; q < n_large && info[(size_t)q * 2] == t; q++) {
+                    const int n_q = info[(size_t)q * 2 + 1];
+                    if (n_q > 1045) { table_ok = false; break; }                       // set method: the walk depends on the values drawn
+                    const double sd = sqrt(var);
+                    long long lo = (long long)floor(mean - 6.0 * sd) - 32, hi = (long long)ceil(mean + 6.0 * sd) + 32;
+                    if (lo < least) lo = least;
+                    SampleMeta& m = meta[(size_t)q];
+                    m.lo = lo; m.width = (int)(hi - lo + 1); m.n = n_q; m.off = slots;
+                    slots += m.width;
+                    if (m.width > max_width) max_width = m.width;
+                    for (int i = 0; i < 100; i++) {                                      // draw i accepts a word with probability (n-i) / 2^k
+                        const double bound = (double)(n_q - i);
+                        int k = 0; while ((1u << k) <= (unsigned)(n_q - i)) k++;
+                        const double pacc = bound / (double)(1u << k);
+                        mean += 1.0 / pacc; var += (1.0 - pacc) / (pacc * pacc);
+                    }
+                    least += 100;
+                }
             }
-            SVXCHK(c->samp_stream.reserve((size_t)n_large * 8 + 64));
+            type_begin[SVX_NTYPES] = n_large;
+            for (int t = SVX_NTYPES - 1; t >= 0; t--) if (type_begin[t] > type_begin[t + 1]) type_begin[t] = type_begin[t + 1];
+            if (table_ok && slots > 0 && slots < (1ll << 31) && n_large <= 65535) {
+                SVXCHK(c->samp_table.reserve((size_t)slots * 2 + 64));
+                SampleMeta* meta_dev = reinterpret_cast<SampleMeta*>(c->samp_meta.as<char>() + (size_t)n_large * 8);
+                long long* tb_dev = reinterpret_cast<long long*>(meta_dev + n_large);
+                HIPCHK(hipMemcpyAsync(meta_dev, meta.data(), (size_t)n_large * sizeof(SampleMeta), hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(tb_dev, type_begin, sizeof type_begin, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemsetAsync(err, 0, 8, st));
+                k_sample_tables<<<dim3((unsigned)((max_width + 255) / 256), (unsigned)n_large), 256, 0, st>>>(meta_dev, c->mt_words.as<uint32_t>(), c->mt_have,
+                                                                                                             c->samp_table.as<uint16_t>());
+                k_sample_chase<<<SVX_NTYPES, 64, 0, st>>>(meta_dev, tb_dev, c->samp_table.as<uint16_t>(), samp_start, err);
+                k_sample_apply<<<(unsigned)n_large, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
+                                                                c->mt_words.as<uint32_t>(), c->mt_have, samp_start, c->samp_idx.as<int32_t>());
+                HIPCHK(hipGetLastError());
+                int h_err = 0;
+                HIPCHK(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));       // also covers the host vectors
+                done = !h_err;
+            }
+        }
+        for (int attempt = 0; !done && attempt < 6; attempt++) {
+            SVXCHK(ensure_stream(cap));
             const uint32_t* stream = c->mt_words.as<uint32_t>();
-            long long* samp_start = c->samp_stream.as<long long>();
-            int* err = reinterpret_cast<int*>(cnt + 15);
             HIPCHK(hipMemsetAsync(err, 0, 8, st));
             k_sample_scan<<<SVX_NTYPES, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
                                                     stream, c->mt_have, samp_start, c->samp_idx.as<int32_t>(), err);
