@@ -1296,21 +1296,26 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         }
     }
     if (!c->edit_guess_pinned && n_work >= 4096) {
-        // calibrate the next call's band speculation: the fraction g that minimises  g + 0.75 * (weight of the pairs beyond g)
-        // (a band costs ~ g per cell column, a failed speculation roughly a full matrix)
+        // calibrate the next call's band speculation: the fraction g with the least expected cost over this call's (core-length weighted) pairs
         SVXCHK(c->e_hist.reserve(256 * 8));
         HIPCHK(hipMemsetAsync(c->e_hist.p, 0, 256 * 8, st));
         k_edit_hist<<<(unsigned)(c->n_cu * 2), 256, 0, st>>>(n_work, desc, slot_of, ed_dev, c->e_hist.as<unsigned long long>());
         unsigned long long h[256];
         HIPCHK(hipMemcpyAsync(h, c->e_hist.p, sizeof h, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        double total = 0, below = 0, best_cost = 1e300;
-        for (int b = 0; b < 256; b++) total += (double)h[b];
+        double total = 0, best_cost = 1e300;
+        double cum[257];
+        cum[0] = 0;
+        for (int b = 0; b < 256; b++) { total += (double)h[b]; cum[b + 1] = total; }
         if (total > 0) {
+            // expected relative cost of starting at fraction g: the first band costs ~g per cell column; a pair beyond g retries at 2g, 4g, ...
+            // (a band wider than half the core is a full matrix, ~0.75)
+            auto beyond = [&](double g) { int b = (int)(g * 256.0); if (b > 256) b = 256; return 1.0 - cum[b] / total; };
             int best = 31;
-            for (int b = 0; b < 128; b++) {
-                below += (double)h[b];
-                const double g = (b + 1) / 256.0, cost = g + 0.75 * (1.0 - below / total);
+            for (int b = 3; b < 128; b++) {
+                const double g = (b + 1) / 256.0;
+                double cost = g;
+                for (double w = g; w < 1.0; w *= 2) cost += (2 * w <= 0.5 ? 2 * w : 0.75) * beyond(w);
                 if (cost < best_cost) { best_cost = cost; best = b; }
             }
             c->edit_guess = (float)((best + 2) / 256.0);
