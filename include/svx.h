@@ -182,6 +182,30 @@ int  svx_cluster_fetch_part_index(svx_ctx* ctx, int64_t* out /* [n_clusters], ho
 int  svx_cluster_set_shard_by_origin(svx_ctx* ctx, int rank, int world, const int64_t* origin_prefix_host /* [world+1] */);
 int  svx_cluster_remote_members(svx_ctx* ctx, int64_t* out);
 
+/* ---- GENOTYPE: replaces the per-candidate BAM re-fetch of genotype() (src/svim/SVIM_genotyping.py:34-93) --------
+ * by an interval join over the alignment records, resident in HBM.  Records are in file order of a coordinate-sorted BAM
+ * (tid, pos non-decreasing); AlignmentFile.fetch(contig, start, stop) of the reference (:48) becomes "records of that contig with
+ * pos < stop and end_or_pos1 > start, in order" (htslib's overlap rule; end_or_pos1 = reference_end, or pos + 1 for a record
+ * without reference span). */
+typedef struct svx_aln_index {
+    int64_t n;                      /* records */
+    int32_t n_contig;
+    int32_t reserved;
+    const int64_t* contig_first;    /* [n_contig+1] first record of every contig */
+    const int64_t* contig_len;      /* [n_contig]   bam.get_reference_length */
+    const int32_t* pos;             /* reference_start */
+    const int32_t* end;             /* reference_end (pos when the record has no reference span) */
+    const uint16_t* flag;
+    const uint8_t*  mapq;
+    const int32_t* name_id;         /* query_name interned: records of one read share the id */
+} svx_aln_index;
+int  svx_set_alignment_index(svx_ctx* ctx, const svx_aln_index* host_index);
+/* mode 0 = DEL / INV candidates (locus = source start..end), 1 = INS / DUP_INT (locus = destination start, end == start).
+ * member_names: interned read names of the candidate's members, SORTED within every candidate; out_ref_reads[i] =
+ * len(reads_supporting_reference) of candidate i (:52-77: first 500 eligible alignments around the locus, distinct names). */
+int  svx_genotype(svx_ctx* ctx, int32_t mode, int64_t n_cand, const int32_t* cand_tid, const int32_t* cand_start, const int32_t* cand_end,
+                  const int64_t* member_off /* [n_cand+1] */, const int32_t* member_names, int32_t min_mapq, int32_t* out_ref_reads);
+
 /* ---- single-function entry points kept importable by the reference's API ------------------------ */
 /* analyze_cigar_indel (src/svim/SVIM_intra.py:8-30) on one packed CIGAR; out arrays sized n_ops */
 int  svx_cigar_indel(svx_ctx* ctx, const uint32_t* cigar_host, int64_t n_ops, int32_t min_length,

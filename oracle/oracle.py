@@ -98,6 +98,21 @@ class Oracle(object):
                                ptr(o_del), C.byref(m))
         return [(int(o_ref[i]), int(o_read[i]), int(o_len[i]), "DEL" if o_del[i] else "INS") for i in range(m.value)]
 
+    def set_alignment_index(self, index):
+        self._index = index                      # the C side borrows the arrays
+        v = index.view()
+        self.L.svo_set_alignment_index(self.ctx, C.byref(v))
+
+    def genotype(self, mode, tid, start, end, member_off, member_names, min_mapq):
+        n = len(tid)
+        out = np.zeros(max(1, n), dtype=np.int32)
+        tid = np.ascontiguousarray(tid, dtype=np.int32); start = np.ascontiguousarray(start, dtype=np.int32)
+        end = np.ascontiguousarray(end, dtype=np.int32); member_off = np.ascontiguousarray(member_off, dtype=np.int64)
+        member_names = np.ascontiguousarray(member_names, dtype=np.int32)
+        self.L.svo_genotype(self.ctx, C.c_int32(mode), C.c_int64(n), ptr(tid), ptr(start), ptr(end), ptr(member_off),
+                            ptr(member_names if member_names.size else np.zeros(1, np.int32)), C.c_int32(min_mapq), ptr(out))
+        return out[:n]
+
     def edit_distance(self, a, b):
         ca, cb = _abi.encode_bases(a), _abi.encode_bases(b)
         ca = np.ascontiguousarray(np.concatenate([ca, np.zeros(1, np.uint8)]))

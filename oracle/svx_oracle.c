@@ -1029,3 +1029,52 @@ int svo_form_partitions(const svx_sig_view* v, const int32_t* rank, int64_t max_
     free(keys);
     return 0;
 }
+
+/* ---------------------------------------------------------------- GENOTYPE ----
+ * genotype() of src/svim/SVIM_genotyping.py:34-93, the part that touches alignments: for every candidate walk
+ * bam.fetch(contig, max(0, start-1000), min(contig_length, end+1000)) (:47-48) in file order, skip reads of the variant (:63) and
+ * unmapped / secondary / low-mapq alignments (:65), stop after 500 eligible ones (:56,68) and collect the names of those spanning
+ * the locus (:70-77).  fetch() = htslib's overlap rule over a coordinate-sorted file: pos < stop and bam_endpos > start, where
+ * bam_endpos is pos + 1 for a record without reference span. */
+static svx_aln_index g_index;
+
+int svo_set_alignment_index(svo_ctx* c, const svx_aln_index* h) { (void)c; g_index = *h; return 0; }   /* borrows the caller's arrays */
+
+int svo_genotype(svo_ctx* c, int32_t mode, int64_t n_cand, const int32_t* cand_tid, const int32_t* cand_start, const int32_t* cand_end,
+                 const int64_t* member_off, const int32_t* member_names, int32_t min_mapq, int32_t* out_ref_reads) {
+    (void)c;
+    const svx_aln_index* ix = &g_index;
+    int32_t names[500];
+    for (int64_t k = 0; k < n_cand; k++) {
+        out_ref_reads[k] = 0;
+        const int tid = cand_tid[k];
+        if (tid < 0 || tid >= ix->n_contig) continue;
+        const int64_t start = cand_start[k], end = cand_end[k];
+        const int64_t clen = ix->contig_len[tid];
+        const int64_t ws = start - 1000 > 0 ? start - 1000 : 0, we = end + 1000 < clen ? end + 1000 : clen;
+        const double minimum_overlap = fmin((double)(end - start) / 2.0, 2000.0);          /* :71 */
+        int aln_no = 0, n_names = 0;
+        for (int64_t i = ix->contig_first[tid]; i < ix->contig_first[tid + 1] && aln_no < 500; i++) {
+            const int64_t rs = ix->pos[i], re = ix->end[i];
+            const int64_t endp = re > rs ? re : rs + 1;
+            if (!(rs < we && endp > ws)) continue;                                          /* not returned by fetch */
+            const int32_t name = ix->name_id[i];
+            int in_variant = 0;
+            for (int64_t m = member_off[k]; m < member_off[k + 1]; m++) if (member_names[m] == name) { in_variant = 1; break; }
+            if (in_variant) continue;                                                       /* :63 */
+            if ((ix->flag[i] & 0x4) || (ix->flag[i] & 0x100) || ix->mapq[i] < min_mapq) continue;   /* :65 */
+            aln_no++;                                                                       /* :68 */
+            int support;
+            if (mode == 0)
+                support = ((double)rs < (double)end - minimum_overlap && re > end + 100) || (rs < start - 100 && (double)re > (double)start + minimum_overlap);
+            else
+                support = rs < start - 100 && re > end + 100;
+            if (!support) continue;
+            int seen = 0;
+            for (int j = 0; j < n_names; j++) if (names[j] == name) { seen = 1; break; }
+            if (!seen) names[n_names++] = name;
+        }
+        out_ref_reads[k] = n_names;
+    }
+    return 0;
+}

@@ -94,6 +94,11 @@ class ClusterView(C.Structure):
                 ("n_members", C.c_int64)]
 
 
+class AlnIndex(C.Structure):
+    _fields_ = [("n", C.c_int64), ("n_contig", C.c_int32), ("reserved", C.c_int32), ("contig_first", _P), ("contig_len", _P),
+                ("pos", _P), ("end", _P), ("flag", _P), ("mapq", _P), ("name_id", _P)]
+
+
 CLU_DTYPES = dict(type=np.uint8, contig=np.int32, start=np.int32, end=np.int32, contig2=np.int32, start2=np.int32,
                   end2=np.int32, aux=np.uint8, score=np.float64, std_span=np.float64, std_pos=np.float64,
                   size=np.int32)

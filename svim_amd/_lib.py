@@ -21,6 +21,7 @@ SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version",
            "svx_collect", "svx_collect_count", "svx_collect_fetch", "svx_set_genome", "svx_cluster",
            "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_shard", "svx_cluster_fetch_part_index",
            "svx_cluster_set_shard_by_origin", "svx_cluster_remote_members",
+           "svx_set_alignment_index", "svx_genotype",
            "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster",
            "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names"]
 
@@ -127,6 +128,21 @@ class Engine(object):
         _check(self.L.svx_cluster_fetch_part_index(self.ctx, ptr(pi)), "svx_cluster_fetch_part_index")
         ct.part_index = pi[:n.value]
         return ct
+
+    def set_alignment_index(self, index):
+        """index: svim_amd.SVIM_genotyping.AlignmentIndex (arrays are copied to the device)"""
+        v = index.view()
+        _check(self.L.svx_set_alignment_index(self.ctx, C.byref(v)), "svx_set_alignment_index")
+
+    def genotype(self, mode, tid, start, end, member_off, member_names, min_mapq):
+        n = len(tid)
+        out = np.zeros(max(1, n), dtype=np.int32)
+        tid = np.ascontiguousarray(tid, dtype=np.int32); start = np.ascontiguousarray(start, dtype=np.int32)
+        end = np.ascontiguousarray(end, dtype=np.int32); member_off = np.ascontiguousarray(member_off, dtype=np.int64)
+        member_names = np.ascontiguousarray(member_names, dtype=np.int32)
+        _check(self.L.svx_genotype(self.ctx, C.c_int32(mode), C.c_int64(n), ptr(tid), ptr(start), ptr(end), ptr(member_off),
+                                   ptr(member_names if member_names.size else np.zeros(1, np.int32)), C.c_int32(min_mapq), ptr(out)), "svx_genotype")
+        return out[:n]
 
     def remote_members(self):
         n = C.c_int64()

@@ -50,6 +50,7 @@ extern "C" void svx_ctx_destroy(svx_ctx* c) {
                       &c->clu.std_span, &c->clu.std_pos, &c->clu.size, &c->clu.member_off, &c->clu.members, &c->clu.part_index};
     for (auto* b : bufs) b->release();
     for (auto& b : c->user_sig) b.release();
+    for (auto& b : c->geno) b.release();
     for (auto& ev : c->ev) (void)hipEventDestroy(ev);
     for (auto& a : c->aux) (void)hipStreamDestroy(a);
     (void)hipStreamDestroy(c->stream);
@@ -305,4 +306,18 @@ extern "C" int svx_linkage_fcluster(svx_ctx* c, int64_t n_problems, const int32_
     HIPCHK(hipMemcpyAsync(labels_out, c->tmp4.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return SVX_OK;
+}
+
+// ---- GENOTYPE ---------------------------------------------------------------------------------------------------------------
+extern "C" int svx_set_alignment_index(svx_ctx* c, const svx_aln_index* h) {
+    if (!c || !h || h->n < 0 || h->n_contig < 0) return svx_fail(SVX_E_ARG, "bad alignment index", __FILE__, __LINE__, hipSuccess);
+    HIPCHK(hipSetDevice(c->device));
+    return svx_set_alignment_index_impl(c, h);
+}
+extern "C" int svx_genotype(svx_ctx* c, int32_t mode, int64_t n_cand, const int32_t* cand_tid, const int32_t* cand_start, const int32_t* cand_end,
+                            const int64_t* member_off, const int32_t* member_names, int32_t min_mapq, int32_t* out_ref_reads) {
+    if (!c || n_cand < 0 || (n_cand && (!cand_tid || !cand_start || !cand_end || !member_off || !out_ref_reads)))
+        return svx_fail(SVX_E_ARG, "null argument", __FILE__, __LINE__, hipSuccess);
+    HIPCHK(hipSetDevice(c->device));
+    return svx_genotype_impl(c, mode, n_cand, cand_tid, cand_start, cand_end, member_off, member_names, min_mapq, out_ref_reads);
 }

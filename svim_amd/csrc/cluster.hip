@@ -342,7 +342,6 @@ __global__ __launch_bounds__(64) void k_sample_apply(const int32_t* large_list, 
     if (st < 0) return;
     const int lane = lane_id();
     const int p = large_list[q];
-    const int t = type[sidx[part_start[p]]];
     const uint32_t* strm = stream;              // one stream: every type restarts from seed(1524)
     const uint32_t n = (uint32_t)(part_start[p + 1] - part_start[p]);
     long long chunk = st;                   // words [chunk, chunk+64) sit in `buf`

@@ -125,6 +125,7 @@ struct svx_ctx {
     DevBuf user_sig[12]; DevBuf c_rank;
     DevBuf k_hi, k_lo, k_idx, k_hi2, k_lo2, k_idx2, part_flag, part_id, part_start, part_meta, samp_idx, large_list, samp_stream;
     DevBuf cell_shards;
+    DevBuf geno[11]; int64_t geno_n = 0; int32_t geno_contigs = -1;      // GENOTYPE: resident alignment index + per-call candidate buffers
     DevBuf samp_meta, samp_table;                // consumption tables of the sampling walk
     DevBuf mt_words; long long mt_have = 0;      // tempered MT19937 words after seed(1524), kept across calls
     DevBuf pair_off, ed, work, stage, stage_members, labels;
@@ -155,6 +156,9 @@ int svx_exclusive_scan_i32_to_i64(svx_ctx* c, const int32_t* in, int64_t* out, i
 // ---- stage entry points ------------------------------------------------------------------------------------
 int svx_collect_impl(svx_ctx* c, const svx_batch* b_dev, const svx_params* p);
 int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const int32_t* rank_dev, const svx_params* p);
+int svx_set_alignment_index_impl(svx_ctx* c, const svx_aln_index* h);
+int svx_genotype_impl(svx_ctx* c, int32_t mode, int64_t n_cand, const int32_t* tid, const int32_t* start, const int32_t* end, const int64_t* moff,
+                      const int32_t* mnames, int32_t min_mapq, int32_t* out);
 int svx_edit_distance_pairs(svx_ctx* c, int64_t n_pairs, const uint8_t* codes_dev, const int64_t* a_off_dev, const int64_t* b_off_dev, int32_t* out_dev);
 int svx_linkage_batch(svx_ctx* c, int64_t n_problems, const int32_t* n_dev, const int64_t* d_off_dev, const double* d_dev, double cutoff,
                       const int64_t* label_off_dev, int32_t* labels_dev);

@@ -727,7 +727,6 @@ __device__ __forceinline__ void d_edit_lane(long long blk, long long count, cons
     if (live) { widx = list[t]; pd = desc[widx]; }
     const int m = pd.m, n = live ? pd.n : 0;
     const Packed pat{scratch + pd.pat, CLS_PAT_SH(pd.cls)}, txt{scratch + pd.txt, CLS_TXT_SH(pd.cls)};
-    const int pat_words = (m + 7) >> 3;
     const int pad = 32 * Q - m;                          // virtual rows above row 1
     uint32_t pv[Q], mv[Q], pl[P][Q];
 #pragma unroll
@@ -785,7 +784,6 @@ __device__ __forceinline__ void d_edit_wide(long long blk, long long count, cons
     if (live) { widx = list[t]; pd = desc[widx]; }
     const int m = pd.m, n = live ? pd.n : 0;
     const Packed pat{scratch + pd.pat, CLS_PAT_SH(pd.cls)}, txt{scratch + pd.txt, CLS_TXT_SH(pd.cls)};
-    const int pat_words = (m + 7) >> 3;
     const int lanes_used = live ? (m + 511) / 512 : 0;
     const int pad = lanes_used * 512 - m;                    // virtual rows above row 1 (all in lane 0)
     const int bit_base = gl * 512;                           // first bit of this lane in the wide vector

@@ -316,6 +316,7 @@ class AlignmentFile(object):
         self.header = {}
         self._records = None
         self._sam_lines = None
+        self._cache = None
         self._bam = None
         if text is not None:
             self._init_sam(text)
@@ -391,9 +392,34 @@ class AlignmentFile(object):
 
     gettid = get_tid
 
+    def get_reference_length(self, name):
+        return self.lengths[self.references.index(name)]
+
     def fetch(self, contig=None, start=None, stop=None, until_eof=True):
-        if contig is not None:
-            raise NotImplementedError("random access fetch is outside the COLLECT+CLUSTER path")
+        """Without a region: every record in file order.  With one: the records pysam / htslib return for
+        fetch(contig, start, stop) on a coordinate-sorted file - reference_id == tid, pos < stop and bam_endpos > start
+        (bam_endpos = reference_end, or pos + 1 for a record without reference span), in file order."""
+        if contig is None:
+            for rec in self._all_records():
+                yield rec
+            return
+        tid = self.get_tid(contig)
+        if tid < 0:
+            raise ValueError("invalid contig `%s`" % contig)
+        lo = 0 if start is None else start
+        hi = self.lengths[tid] if stop is None else stop
+        if self._cache is None:
+            self._cache = list(self._all_records())
+        for rec in self._cache:
+            if rec.reference_id != tid:
+                continue
+            rs = rec.reference_start
+            re = rec.reference_end
+            endp = re if (re is not None and re > rs) else rs + 1
+            if rs < hi and endp > lo:
+                yield rec
+
+    def _all_records(self):
         if self._sam_lines is not None:
             for line in self._sam_lines:
                 yield parse_sam_line(line, self._name_to_tid)

@@ -385,3 +385,49 @@ def sam_text(references, lengths, recs, sort_order="coordinate"):
              a.query_sequence or "*", "*"] + tags
         lines.append("\t".join(f))
     return "\n".join(lines) + "\n"
+
+
+def genotype_rows(seed, lengths, n_reads=2600, hot=((0, 20000, 700),)):
+    """Alignment rows [name, flag, tid, pos, mapq, ref_len] for the GENOTYPE tests: plain one-op alignments, a share of secondary /
+    unmapped-but-placed / low-mapq / supplementary records, `hot` = (tid, centre, extra reads) piles deep enough for the
+    500-alignment cap of the reference's loop.  Coordinate-sorted (stable)."""
+    rng = random.Random(seed)
+    rows = []
+    k = 0
+
+    def add(tid, pos, ln):
+        nonlocal k
+        name = "g%05d" % k
+        k += 1
+        u = rng.random()
+        flag = 16 if rng.random() < 0.5 else 0
+        mapq = 60
+        if u < 0.05:
+            flag |= 256
+        elif u < 0.08:
+            flag |= 4
+        elif u < 0.16:
+            mapq = rng.choice((0, 5, 19))
+        elif u < 0.20:
+            mapq = 20
+        rows.append([name, flag, tid, pos, mapq, ln])
+        if rng.random() < 0.12:                       # a second record of the same read (supplementary) close by
+            p2 = max(0, min(lengths[tid] - 50, pos + rng.randint(-3000, 3000)))
+            rows.append([name, (flag & 16) | 2048, tid, p2, 60, rng.randint(200, 4000)])
+
+    for _ in range(n_reads):
+        tid = rng.randrange(len(lengths))
+        ln = rng.randint(300, 9000)
+        add(tid, rng.randint(0, max(1, lengths[tid] - ln - 1)), min(ln, lengths[tid] - 1))
+    for tid, centre, extra in hot:
+        for _ in range(extra):
+            ln = rng.randint(1500, 9000)
+            add(tid, max(0, centre - rng.randint(0, ln)), ln)
+    rows.sort(key=lambda r: (r[2], r[3]))
+    return rows
+
+
+def genotype_sam_text(references, lengths, rows):
+    head = ["@HD\tVN:1.6\tSO:coordinate"] + ["@SQ\tSN:%s\tLN:%d" % (n, l) for n, l in zip(references, lengths)]
+    body = ["%s\t%d\t%s\t%d\t%d\t%dM\t*\t0\t0\t*\t*" % (r[0], r[1], references[r[2]], r[3] + 1, r[4], r[5]) for r in rows]
+    return "\n".join(head + body) + "\n"

@@ -569,6 +569,53 @@ def gen_entrypoints(collect_cases):
                                              "svim.SVIM_clustering.partition_and_cluster_candidates"})
 
 
+def gen_genotype():
+    """GENOTYPE: the reference's genotype() on synthetic alignments; the AlignmentFile stand-in answers
+    fetch(contig, start, stop) with htslib's overlap rule (svim_amd/records.py)."""
+    from svim import SVIM_genotyping, SVCandidate
+    rng = random.Random(77)
+    references, lengths = ["chr1", "chr2"], [60000, 30000]
+    rows = synth.genotype_rows(5, lengths)
+    bam = records.AlignmentFile(text=synth.genotype_sam_text(references, lengths, rows))
+    o = options(minimum_score=3, minimum_depth=4, homozygous_threshold=0.8, heterozygous_threshold=0.2)
+    by_tid = {t: [r for r in rows if r[2] == t] for t in range(len(lengths))}
+    cases = []
+    for typ in ("DEL", "INV", "INS", "DUP_INT"):
+        cand_rows = []
+        for k in range(70):
+            tid = rng.randrange(2)
+            span = rng.choice((45, 120, 900, 3000, 4100, 7000))
+            if k % 9 == 0:
+                start = 20000 - rng.randint(0, 400) if tid == 0 else rng.randint(0, 800)         # the deep pile / the contig start
+            elif k % 9 == 1:
+                start = lengths[tid] - span - rng.randint(1, 600)                                # the contig end
+            else:
+                start = rng.randint(0, lengths[tid] - span - 1)
+            near = [r for r in by_tid[tid] if r[3] < start + span + 300 and r[3] + r[5] > start - 300 and not (r[1] & 4)]
+            rng.shuffle(near)
+            members = [r[0] for r in near[:rng.choice((0, 1, 2, 3, 6, 12, 40))]]
+            if members and rng.random() < 0.3:
+                members.append(members[0])                                                       # two signatures of one read
+            score = rng.choice((1, 2, 3, 4, 10, 40))
+            cand_rows.append([references[tid], start, start + span, members, score])
+        cands = []
+        for contig, s, e, members, score in cand_rows:
+            sigs = [SVSignature.SignatureDeletion(contig, s, e, "cigar", m) for m in members]
+            if typ == "DEL":
+                cands.append(SVCandidate.CandidateDeletion(contig, s, e, sigs, score, 1.0, 1.0))
+            elif typ == "INV":
+                cands.append(SVCandidate.CandidateInversion(contig, s, e, sigs, score, 1.0, 1.0))
+            elif typ == "INS":
+                cands.append(SVCandidate.CandidateNovelInsertion(contig, s, e, "", sigs, score, 1.0, 1.0))
+            else:
+                cands.append(SVCandidate.CandidateDuplicationInterspersed("chr1", 100, 100 + e - s, contig, s, e, sigs, score, 1.0, 1.0))
+        SVIM_genotyping.genotype(cands, bam, typ, o)
+        cases.append({"type": typ, "candidates": cand_rows,
+                      "expected": [[c.support_fraction, c.genotype, c.ref_reads, c.alt_reads] for c in cands]})
+    dump("g_genotype.json.gz", {"references": references, "lengths": lengths, "rows": rows, "options": opt_dict(o), "cases": cases,
+                                "source": "svim.SVIM_genotyping.genotype (reads via svim_amd.records.AlignmentFile.fetch: htslib overlap rule)"})
+
+
 def main():
     contigs = [("chr1", 180000), ("chr2", 60000), ("chr10", 60000)]   # tid order != Python string order
     refs = synth.make_reference(1, contigs)
@@ -587,7 +634,11 @@ def main():
     gen_rng()
     gen_edit()
     gen_c1()
+    gen_genotype()
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "genotype":
+        gen_genotype()                 # this fixture only (the others are untouched)
+    else:
+        main()
