@@ -449,3 +449,47 @@ def test_shard_by_origin_two_virtual_ranks(eng, oracle):
     assert remote == [0, 0]
     merged = merge_cluster_tables(parts, rank_arr)
     assert merged.first_difference(full) is None
+
+
+def test_edit_distance_routes_do_not_change_results(oracle, monkeypatch):
+    """The band speculation (SVX_EDIT_GUESS pinned tiny / huge, or learned from the previous call) and the forced full-matrix
+    route are performance choices only: every route must return the oracle's distances."""
+    from svim_amd._lib import Engine
+    rng = random.Random(5)
+    pairs = []
+    for _ in range(5000):
+        la = rng.choice((150, 700, 1400, 2600, 4500))
+        a = synth.random_seq(rng, la)
+        b = list(a)
+        for _ in range(int(rng.choice((0.0, 0.02, 0.06, 0.15)) * la)):
+            p = rng.randrange(len(b))
+            r = rng.random()
+            if r < 0.4:
+                b[p] = rng.choice("ACGT")
+            elif r < 0.7:
+                del b[p]
+            else:
+                b.insert(p, rng.choice("ACGT"))
+        b = "".join(b)
+        if rng.random() < 0.2:
+            b = synth.random_seq(rng, rng.choice((9, 60))) + b               # shifted: the Hamming bound is useless, the band is a guess
+        if rng.random() < 0.05:
+            b = synth.random_seq(rng, rng.randrange(50, 3000))               # unrelated
+        pairs.append((a, b))
+    exp = [oracle.edit_distance(a, b) for a, b in pairs[:400]]
+    results = []
+    for env in ({"SVX_EDIT_GUESS": "0.004"}, {"SVX_EDIT_GUESS": "0.45"}, {"SVX_EDIT_FORCE_FULL": "1"}, {}):
+        for k in ("SVX_EDIT_GUESS", "SVX_EDIT_FORCE_FULL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = Engine()
+        try:
+            first = e.edit_distances(pairs)
+            second = e.edit_distances(pairs)       # without a pin the second call runs with the guess learned from the first
+        finally:
+            e.close()
+        assert first == second
+        results.append(first)
+    assert all(r == results[0] for r in results)
+    assert results[0][:400] == exp
