@@ -62,8 +62,11 @@ class Oracle(object):
         self._keep = [off, codes]
         self.L.svo_set_genome(self.ctx, C.byref(g))
 
-    def cluster(self, params, contig_rank, table=None, source=2, shard=None):
-        if shard is not None:
+    def cluster(self, params, contig_rank, table=None, source=2, shard=None, origin_prefix=None):
+        if shard is not None and origin_prefix is not None:
+            pre = np.ascontiguousarray(origin_prefix, dtype=np.int64)
+            assert self.L.svo_cluster_set_shard_by_origin(self.ctx, shard[0], shard[1], ptr(pre)) == 0
+        elif shard is not None:
             self.L.svo_cluster_set_shard(self.ctx, shard[0], shard[1])
         v = table.view() if table is not None else _abi.SigView()
         rank = np.ascontiguousarray(contig_rank, dtype=np.int32)
@@ -97,6 +100,11 @@ class Oracle(object):
         self.L.svo_cigar_indel(ptr(c), C.c_int64(n), C.c_int32(min_length), ptr(o_ref), ptr(o_read), ptr(o_len),
                                ptr(o_del), C.byref(m))
         return [(int(o_ref[i]), int(o_read[i]), int(o_len[i]), "DEL" if o_del[i] else "INS") for i in range(m.value)]
+
+    def remote_members(self):
+        n = C.c_int64()
+        self.L.svo_cluster_remote_members(self.ctx, C.byref(n))
+        return n.value
 
     def set_alignment_index(self, index):
         self._index = index                      # the C side borrows the arrays

@@ -65,6 +65,9 @@ typedef struct svo_ctx {
     /* cluster results */
     svx_cluster_view clu; int64_t clu_cap, mem_cap; int64_t* part_index;
     int shard_rank, shard_world;
+    int shard_mode;                 /* 0: partition index % world, 1: origin rank of the first sorted member */
+    int64_t shard_prefix[65];       /* mode 1: first global index of every rank */
+    int64_t n_remote_members;
     svx_stats stats;
 } svo_ctx;
 
@@ -870,7 +873,7 @@ int svo_cluster(svo_ctx* c, int source, const svx_sig_view* sigs_in, int32_t n_c
     out->n = 0; out->n_members = 0; memset(out->type_count, 0, sizeof out->type_count);
     clu_reserve(c, 1, 1); out->member_off[0] = 0;
     int64_t e_pairs0 = c->stats.n_edit_pairs; (void)e_pairs0;
-    c->stats.n_partitions = c->stats.n_large_partitions = c->stats.n_pairs = 0; c->stats.n_edit_pairs = c->stats.n_edit_cells = 0;
+    c->stats.n_partitions = c->stats.n_large_partitions = c->stats.n_pairs = 0; c->stats.n_edit_pairs = c->stats.n_edit_cells = 0; c->n_remote_members = 0;
     skey* keys = malloc(sizeof(skey) * (size_t)(n ? n : 1));
     for (int64_t i = 0; i < n; i++) {
         skey k; k.type = v->type[i]; k.idx = i; k.r2 = 0;
@@ -911,6 +914,16 @@ int svo_cluster(svo_ctx* c, int source, const svx_sig_view* sigs_in, int32_t n_c
             if (psize > 100) { mt_sample100(&rng, psize, sample); ns = 100; c->stats.n_large_partitions++; }
             else { ns = (int)psize; for (int k = 0; k < ns; k++) sample[k] = k; }
             int mine = (global_part % c->shard_world) == c->shard_rank;
+            if (c->shard_mode == 1) {
+                /* svx_cluster_set_shard_by_origin: the table is the rank-major concatenation, a partition belongs to the rank that
+                 * produced its first sorted member; members from other ranks are counted (the caller must then fall back) */
+                int owner = 0; int64_t g0 = keys[ps].idx;
+                while (owner + 1 < c->shard_world && g0 >= c->shard_prefix[owner + 1]) owner++;
+                mine = owner == c->shard_rank;
+                if (mine && type == SVX_INS)
+                    for (int k = 0; k < ns; k++) { int64_t g = keys[ps + sample[k]].idx;
+                        if (g < c->shard_prefix[owner] || g >= c->shard_prefix[owner + 1]) c->n_remote_members++; }
+            }
             if (mine) {
                 csig m[100]; int32_t midx[100];
                 for (int k = 0; k < ns; k++) { midx[k] = (int32_t)keys[ps + sample[k]].idx; m[k] = get_sig(v, midx[k]); }
@@ -984,7 +997,14 @@ int svo_cluster(svo_ctx* c, int source, const svx_sig_view* sigs_in, int32_t n_c
     c->stats.n_clusters = out->n;
     return 0;
 }
-int svo_cluster_set_shard(svo_ctx* c, int rank, int world) { c->shard_rank = rank; c->shard_world = world; return 0; }
+int svo_cluster_set_shard(svo_ctx* c, int rank, int world) { c->shard_rank = rank; c->shard_world = world; c->shard_mode = 0; return 0; }
+int svo_cluster_set_shard_by_origin(svo_ctx* c, int rank, int world, const int64_t* prefix) {
+    if (world > 64) return -1;
+    c->shard_rank = rank; c->shard_world = world; c->shard_mode = 1;
+    for (int r = 0; r <= world; r++) c->shard_prefix[r] = prefix[r];
+    return 0;
+}
+int svo_cluster_remote_members(svo_ctx* c, int64_t* out) { *out = c->n_remote_members; return 0; }
 int svo_cluster_count(svo_ctx* c, int64_t* ncl, int64_t* nmem) { *ncl = c->clu.n; *nmem = c->clu.n_members; return 0; }
 int svo_cluster_fetch(svo_ctx* c, svx_cluster_view* o) {
     svx_cluster_view* v = &c->clu; size_t n = (size_t)v->n;
