@@ -26,8 +26,8 @@
 //      band launch, so retry rounds overlap the full-matrix work of earlier rounds.
 //   4. k_edit_hist              divergence histogram of this call's pairs; calibrates the NEXT call's band speculation.
 // No LDS, no MFMA: integer-ALU bound (reported as cell updates/s).  Instruction-rate facts the kernels are shaped by are
-// measured by tools/micro/valu_ops.hip and valu_dep.hip (v_alignbit / v_addc_co are half rate, v_bitop3 full rate, a dependent
-// chain mixing both issues at ~4 cycles per instruction).
+// measured by tools/micro/valu_ops.hip, valu_dep.hip and column_rate.hip (v_alignbit, v_addc_co and every instruction reading three
+// different VGPRs are half rate; the column update costs 38 issue cycles per word-column and runs at 42-44 stand-alone).
 #include "common.hpp"
 
 struct EditWork { uint32_t a, b; long long slot; };
@@ -234,50 +234,7 @@ __device__ __forceinline__ int full_class_for(int m) {
     return CLS_FULL;
 }
 
-// One column of the multi-word recurrence; leaves the (plus, minus) bits pushed out of the last word in bit 31 of ph_prev_ / mh_prev_.
-// A dependent chain that alternates full-rate (v_xor, v_bitop3: 2 cycles per wave64) and half-rate (v_alignbit, v_addc_co: 4 cycles)
-// instructions issues at ~4 cycles per instruction on gfx950, four independent chains at ~2.8 (tools/micro/valu_dep.hip).  Left to
-// itself the compiler emits each word's ~14 instructions almost back to back, so the words are processed in groups of 4 with the
-// recurrence cut into phases, every phase running over the 4 words before the next starts (sched_barrier keeps the phases apart).
-#define MYERS_GROUP(Q_) ((Q_) >= 4 ? 4 : (Q_))
-// v_bitop3_b32 (any function of three words, full rate): truth table = the function applied to 0xF0, 0xCC, 0xAA
-#define BITOP3(a_, b_, c_, tt_) ((uint32_t)__builtin_amdgcn_bitop3_b32((int)(a_), (int)(b_), (int)(c_), (tt_)))
-#define MYERS_COLUMN(Q_, P_, pl_, pv_, mv_, nk_, carry_, ph_prev_, mh_prev_)                                   \
-    _Pragma("unroll") for (int q0 = 0; q0 < Q_; q0 += MYERS_GROUP(Q_)) {                                        \
-        constexpr int GQ = MYERS_GROUP(Q_);                                                                     \
-        const int gn = Q_ - q0 < GQ ? Q_ - q0 : GQ;                              /* words in this group (the last one may be short) */ \
-        uint32_t eq_[GQ], xv_[GQ], sum_[GQ], ph_[GQ], mh_[GQ], phs_[GQ], mhs_[GQ];                              \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
-            uint32_t e = pl_[0][q0 + g] ^ nk_[0];                                                               \
-            if (P_ == 2) e = BITOP3(e, pl_[1][q0 + g], nk_[1], 0x60);             /* e & (p1 ^ n1) */              \
-            else { _Pragma("unroll") for (int b = 1; b < P_; b++) e &= pl_[b][q0 + g] ^ nk_[b]; }               \
-            eq_[g] = e;                                                                                         \
-        }                                                                                                       \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) { xv_[g] = eq_[g] | mv_[q0 + g]; sum_[g] = eq_[g] & pv_[q0 + g]; } \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
-            unsigned carry_out;                                                                                 \
-            sum_[g] = __builtin_addc(sum_[g], pv_[q0 + g], carry_, &carry_out);    /* v_addc_co_u32: the carry stays in an SGPR pair */ \
-            carry_ = carry_out;                                                                                 \
-        }                                                                                                       \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) sum_[g] = BITOP3(sum_[g], pv_[q0 + g], eq_[g], 0xBE);     /* xh = (sum ^ pv) | eq */ \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
-            ph_[g] = BITOP3(mv_[q0 + g], sum_[g], pv_[q0 + g], 0xF1);             /* mv | ~(xh | pv) */           \
-            mh_[g] = pv_[q0 + g] & sum_[g];                                                                     \
-        }                                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
-            phs_[g] = __builtin_amdgcn_alignbit(ph_[g], g ? ph_[g - 1] : ph_prev_, 31);      /* (ph << 1) | top bit of the word below */ \
-            mhs_[g] = __builtin_amdgcn_alignbit(mh_[g], g ? mh_[g - 1] : mh_prev_, 31);                         \
-        }                                                                                                       \
-        ph_prev_ = ph_[gn - 1]; mh_prev_ = mh_[gn - 1];                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
-            pv_[q0 + g] = BITOP3(mhs_[g], xv_[g], phs_[g], 0xF1);                 /* mhs | ~(xv | phs) */         \
-            mv_[q0 + g] = phs_[g] & xv_[g];                                                                     \
-        }                                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-    }
+#include "myers_column.hpp"
 
 // ---- 1. packed store ---------------------------------------------------------------------------------------------
 __global__ void k_pair_span(long long n_work, PairSource src, unsigned long long* span) {           // max |start_a - start_b| over the work list

@@ -1,0 +1,51 @@
+// myers_column.hpp - the column update shared by every edit-distance kernel (edit.hip) and by tools/micro/column_rate.hip.
+#pragma once
+#include <stdint.h>
+
+// One column of the multi-word recurrence; leaves the (plus, minus) bits pushed out of the last word in bit 31 of ph_prev_ / mh_prev_.
+// Issue cost on gfx950 (tools/micro/valu_ops.hip, column_rate.hip): two-operand v_xor / v_and / v_or 2 cycles per wave64;
+// v_alignbit, v_addc_co and any instruction reading three different VGPRs (v_bitop3 included) 4.  v_bitop3 therefore pays where it
+// replaces THREE two-operand instructions (a | ~(b | c)); per word-column the update below costs 38 issue cycles and runs at 42-44.
+// Left to itself the compiler emits each word's instructions almost back to back (a dependent chain mixing both rates stalls, see
+// valu_dep.hip), so the words are processed in groups of 4 with the recurrence cut into phases, every phase running over the 4
+// words before the next starts (sched_barrier keeps the phases apart).
+#define MYERS_GROUP(Q_) ((Q_) >= 4 ? 4 : (Q_))
+// v_bitop3_b32 (any function of three words): truth table = the function applied to 0xF0, 0xCC, 0xAA
+#define BITOP3(a_, b_, c_, tt_) ((uint32_t)__builtin_amdgcn_bitop3_b32((int)(a_), (int)(b_), (int)(c_), (tt_)))
+#define MYERS_COLUMN(Q_, P_, pl_, pv_, mv_, nk_, carry_, ph_prev_, mh_prev_)                                   \
+    _Pragma("unroll") for (int q0 = 0; q0 < Q_; q0 += MYERS_GROUP(Q_)) {                                        \
+        constexpr int GQ = MYERS_GROUP(Q_);                                                                     \
+        const int gn = Q_ - q0 < GQ ? Q_ - q0 : GQ;                              /* words in this group (the last one may be short) */ \
+        uint32_t eq_[GQ], xv_[GQ], sum_[GQ], ph_[GQ], mh_[GQ], phs_[GQ], mhs_[GQ];                              \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
+            uint32_t e = pl_[0][q0 + g] ^ nk_[0];                                                               \
+            if (P_ == 2) e = BITOP3(e, pl_[1][q0 + g], nk_[1], 0x60);             /* e & (p1 ^ n1) */              \
+            else { _Pragma("unroll") for (int b = 1; b < P_; b++) e &= pl_[b][q0 + g] ^ nk_[b]; }               \
+            eq_[g] = e;                                                                                         \
+        }                                                                                                       \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) { xv_[g] = eq_[g] | mv_[q0 + g]; sum_[g] = eq_[g] & pv_[q0 + g]; } \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
+            unsigned carry_out;                                                                                 \
+            sum_[g] = __builtin_addc(sum_[g], pv_[q0 + g], carry_, &carry_out);    /* v_addc_co_u32: the carry stays in an SGPR pair */ \
+            carry_ = carry_out;                                                                                 \
+        }                                                                                                       \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) sum_[g] = BITOP3(sum_[g], pv_[q0 + g], eq_[g], 0xBE);     /* xh = (sum ^ pv) | eq */ \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
+            ph_[g] = BITOP3(mv_[q0 + g], sum_[g], pv_[q0 + g], 0xF1);             /* mv | ~(xh | pv) */           \
+            mh_[g] = pv_[q0 + g] & sum_[g];                                                                     \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
+            phs_[g] = __builtin_amdgcn_alignbit(ph_[g], g ? ph_[g - 1] : ph_prev_, 31);      /* (ph << 1) | top bit of the word below */ \
+            mhs_[g] = __builtin_amdgcn_alignbit(mh_[g], g ? mh_[g - 1] : mh_prev_, 31);                         \
+        }                                                                                                       \
+        ph_prev_ = ph_[gn - 1]; mh_prev_ = mh_[gn - 1];                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
+            pv_[q0 + g] = BITOP3(mhs_[g], xv_[g], phs_[g], 0xF1);                 /* mhs | ~(xv | phs) */         \
+            mv_[q0 + g] = phs_[g] & xv_[g];                                                                     \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    }
+
