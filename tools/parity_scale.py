@@ -6,8 +6,10 @@ from svim_amd import _abi, _lib, devsynth
 from oracle import oracle as om
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
 contig = int(sys.argv[2]) if len(sys.argv) > 2 else 15_000_000
+pmd = int(sys.argv[3]) if len(sys.argv) > 3 else 1000              # options.partition_max_distance (C5 sweeps 1000 .. 100000)
+all_bnds = len(sys.argv) > 4 and sys.argv[4] == "all_bnds"
 o = types.SimpleNamespace(min_mapq=20, min_sv_size=40, max_sv_size=100000, segment_gap_tolerance=10, segment_overlap_tolerance=5,
-                          partition_max_distance=1000, position_distance_normalizer=900, edit_distance_normalizer=1.0, cluster_max_distance=0.5, all_bnds=False)
+                          partition_max_distance=pmd, position_distance_normalizer=900, edit_distance_normalizer=1.0, cluster_max_distance=0.5, all_bnds=all_bnds)
 p = _abi.Params.from_options(o)
 b, genome, meta = devsynth.make_batch(n_reads=n_reads, contig_len=contig, seed=2, device="cuda:0")
 eng = _lib.Engine(0)
@@ -25,7 +27,7 @@ oc = orc.cluster(p, np.zeros(1, np.int32), source=0)
 print("oracle:", osig.n, oc.n, "%.1fs" % (time.time() - t))
 d1 = sig.first_difference(osig)
 d2 = ct.first_difference(oc, rtol=1e-12)
-print("sig diff:", d1, "| cluster diff:", d2)
+print("sig diff:", d1, "| cluster diff:", d2, "| side list diff:", bnd.first_difference(obnd) if all_bnds else "n/a")
 if d2:
     # locate the first differing cluster by partition
     k = 0
