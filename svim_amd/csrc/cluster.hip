@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void k_sample_scan(const int32_t* large_list, l
 // How many words a pool-method partition consumes depends only on its size and on where in the stream it starts.  The host
 // brackets every partition's start (window = expected start -+ 6 sigma, from the exact mean / variance of the rejection
 // sampling), k_sample_tables simulates EVERY (partition, candidate start) with one lane each - ~10^6 independent ~150-word
-// walks, ideal GPU work - and k_sample_chase is left with one table lookup per partition.  Any surprise (a start outside its
+// walks, ideal GPU work - and following the chain is one table lookup per partition (k_chase_*).  Any surprise (a start outside its
 // window, a set-method partition, the stream running out) raises `err` and the caller falls back to k_sample_scan.
 struct SampleMeta { long long lo; int width; int n; long long off; };      // window [lo, lo + width), partition size, first table slot
 
@@ -315,20 +315,57 @@ __global__ __launch_bounds__(256) void k_sample_tables(const SampleMeta* meta, c
     table[m.off + s] = (ok && used < 0xffff) ? (uint16_t)used : (uint16_t)0xffff;
 }
 
-// one lane per type follows its partitions through the tables
-__global__ void k_sample_chase(const SampleMeta* meta, const long long* type_begin /* [NTYPES + 1] */, const uint16_t* table, long long* samp_start,
-                               int* err) {
+// Following the tables is one dependent lookup per partition (0.55 us each for a lone lane).  The chain is therefore cut into runs of
+// CHASE_RUN partitions: (1) every candidate start of a run's first partition is followed to the end of the run, all in parallel;
+// (2) one lane per type hops from run to run; (3) one lane per run fills in the starts inside it.  Serial depth: 2 CHASE_RUN + runs.
+#define CHASE_RUN 64
+struct ChaseRun { long long first, last; long long eoff; int type; int pad; };      // partitions [first, last), slot of its first candidate in `ends`
+
+__global__ __launch_bounds__(256) void k_chase_runs(const SampleMeta* meta, const ChaseRun* runs, const uint16_t* table, long long* ends) {
+    const ChaseRun r = runs[blockIdx.y];
+    const SampleMeta m0 = meta[r.first];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= m0.width) return;
+    long long pos = m0.lo + s;
+    for (long long q = r.first; q < r.last; q++) {
+        const SampleMeta m = meta[q];
+        const long long idx = pos - m.lo;
+        if (idx < 0 || idx >= m.width) { pos = -1; break; }
+        const uint16_t used = table[m.off + idx];
+        if (used == 0xffff) { pos = -1; break; }
+        pos += used;
+    }
+    ends[r.eoff + s] = pos;                                   // stream position after the run, -1: left the windows
+}
+
+__global__ void k_chase_top(const SampleMeta* meta, const ChaseRun* runs, const long long* type_run_begin /* [NTYPES + 1] */, const long long* ends,
+                            long long* run_start, int* err) {
     const int t = blockIdx.x;
     if (threadIdx.x != 0) return;
     long long pos = 0;
-    for (long long q = type_begin[t]; q < type_begin[t + 1]; q++) {
+    for (long long b = type_run_begin[t]; b < type_run_begin[t + 1]; b++) {
+        const ChaseRun r = runs[b];
+        const SampleMeta m0 = meta[r.first];
+        const long long idx = pos - m0.lo;
+        run_start[b] = pos;
+        if (idx < 0 || idx >= m0.width) { *err = 1; return; }
+        pos = ends[r.eoff + idx];
+        if (pos < 0) { *err = 1; return; }
+    }
+}
+
+__global__ void k_chase_fill(const SampleMeta* meta, const ChaseRun* runs, long long n_runs, const uint16_t* table, const long long* run_start,
+                             long long* samp_start) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_runs) return;
+    const ChaseRun r = runs[b];
+    long long pos = run_start[b];
+    for (long long q = r.first; q < r.last; q++) {
         const SampleMeta m = meta[q];
         const long long idx = pos - m.lo;
-        if (m.width <= 0 || idx < 0 || idx >= m.width) { *err = 1; return; }
-        const uint16_t used = table[m.off + idx];
-        if (used == 0xffff) { *err = 1; return; }
+        if (idx < 0 || idx >= m.width) return;                // only after k_chase_top raised err
         samp_start[q] = pos;
-        pos += used;
+        pos += table[m.off + idx];
     }
 }
 
@@ -995,15 +1032,37 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
             type_begin[SVX_NTYPES] = n_large;
             for (int t = SVX_NTYPES - 1; t >= 0; t--) if (type_begin[t] > type_begin[t + 1]) type_begin[t] = type_begin[t + 1];
             if (table_ok && slots > 0 && slots < (1ll << 31) && n_large <= 65535) {
+                // runs of CHASE_RUN partitions, never across a type boundary
+                std::vector<ChaseRun> runs;
+                long long type_run_begin[SVX_NTYPES + 1];
+                long long end_slots = 0;
+                for (int t = 0; t < SVX_NTYPES; t++) {
+                    type_run_begin[t] = (long long)runs.size();
+                    for (long long f = type_begin[t]; f < type_begin[t + 1]; f += CHASE_RUN) {
+                        ChaseRun r; r.first = f; r.last = f + CHASE_RUN < type_begin[t + 1] ? f + CHASE_RUN : type_begin[t + 1];
+                        r.eoff = end_slots; r.type = t; r.pad = 0;
+                        end_slots += meta[(size_t)f].width;
+                        runs.push_back(r);
+                    }
+                }
+                type_run_begin[SVX_NTYPES] = (long long)runs.size();
+                const long long n_runs = (long long)runs.size();
                 SVXCHK(c->samp_table.reserve((size_t)slots * 2 + 64));
+                SVXCHK(c->samp_runs.reserve((size_t)n_runs * (sizeof(ChaseRun) + 8) + (size_t)end_slots * 8 + (SVX_NTYPES + 1) * 8 + 64));
                 SampleMeta* meta_dev = reinterpret_cast<SampleMeta*>(c->samp_meta.as<char>() + (size_t)n_large * 8);
-                long long* tb_dev = reinterpret_cast<long long*>(meta_dev + n_large);
+                ChaseRun* runs_dev = c->samp_runs.as<ChaseRun>();
+                long long* run_start_dev = reinterpret_cast<long long*>(runs_dev + n_runs);
+                long long* trb_dev = run_start_dev + n_runs;
+                long long* ends_dev = trb_dev + (SVX_NTYPES + 1);
                 HIPCHK(hipMemcpyAsync(meta_dev, meta.data(), (size_t)n_large * sizeof(SampleMeta), hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(tb_dev, type_begin, sizeof type_begin, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(runs_dev, runs.data(), (size_t)n_runs * sizeof(ChaseRun), hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(trb_dev, type_run_begin, sizeof type_run_begin, hipMemcpyHostToDevice, st));
                 HIPCHK(hipMemsetAsync(err, 0, 8, st));
                 k_sample_tables<<<dim3((unsigned)((max_width + 255) / 256), (unsigned)n_large), 256, 0, st>>>(meta_dev, c->mt_words.as<uint32_t>(), c->mt_have,
                                                                                                              c->samp_table.as<uint16_t>());
-                k_sample_chase<<<SVX_NTYPES, 64, 0, st>>>(meta_dev, tb_dev, c->samp_table.as<uint16_t>(), samp_start, err);
+                k_chase_runs<<<dim3((unsigned)((max_width + 255) / 256), (unsigned)n_runs), 256, 0, st>>>(meta_dev, runs_dev, c->samp_table.as<uint16_t>(), ends_dev);
+                k_chase_top<<<SVX_NTYPES, 64, 0, st>>>(meta_dev, runs_dev, trb_dev, ends_dev, run_start_dev, err);
+                k_chase_fill<<<GRID(n_runs, 64), 64, 0, st>>>(meta_dev, runs_dev, n_runs, c->samp_table.as<uint16_t>(), run_start_dev, samp_start);
                 k_sample_apply<<<(unsigned)n_large, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
                                                                 c->mt_words.as<uint32_t>(), c->mt_have, samp_start, c->samp_idx.as<int32_t>());
                 HIPCHK(hipGetLastError());
