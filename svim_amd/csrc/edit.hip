@@ -285,12 +285,20 @@ __global__ __launch_bounds__(256) void k_hap_pack(long long n_rec, PairSource sr
     }
 }
 
-// ---- 2. trim + classify (one wave per pair, reads only the packed store) ---------------------------------------------------
+#ifndef PREP_LANES
+#define PREP_LANES 16
+#endif
+// ---- 2. trim + classify (PREP_LANES lanes per pair, reads only the packed store) ---------------------------------------------------
+// G lanes per pair (64 / G pairs per wave): the kernel is bound by the latency of its dependent loads, so what counts is the number of
+// pairs in flight, not the symbols compared per step
+template <int G>
 __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource src, const uint32_t* packed, PairDesc* desc,
                                                    uint64_t* sort_key, uint32_t* sort_val, int32_t* ed, unsigned long long* cells, int force_full, float guess_frac) {
-    const long long w = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave_lane = lane_id();
+    const int sg = wave_lane / G, lane = wave_lane % G;                   // sub-group of the wave / lane inside it
+    const unsigned long long sg_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (sg * G);
+    const long long w = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + sg;
     if (w >= n_work) return;
-    const int lane = lane_id();
     HapView A, B;
     src.views(w, A, B);
     const uint32_t* wa = packed + A.word_off; const uint32_t* wb = packed + B.word_off;
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     const int mn = la < lb ? la : lb;
     // common prefix / suffix, 8 symbols per lane and step
     int pre = mn;
-    for (int base = 0; base < mn; base += 512) {
+    for (int base = 0; base < mn; base += 8 * G) {
         const int i0 = base + lane * 8;
         const int cnt = mn - i0 >= 8 ? 8 : (mn - i0 < 0 ? 0 : mn - i0);
         uint32_t x = 0;
@@ -306,12 +314,12 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
         const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
         int k = nz ? (__ffs((int)nz) - 1) >> 2 : 8;                       // first differing symbol of the chunk
         if (k > cnt) k = cnt;
-        const unsigned long long stop = __ballot(k < 8);                   // a difference, or the shorter string ends here
-        if (stop) { const int f = __ffsll((long long)stop) - 1; pre = base + f * 8 + __shfl(k, f, 64); break; }
+        const unsigned long long stop = __ballot(k < 8) & sg_mask;         // a difference, or the shorter string ends here
+        if (stop) { const int f = __ffsll((long long)stop) - 1; pre = base + (f - sg * G) * 8 + __shfl(k, f, 64); break; }
     }
     const int lim = mn - pre;
     int suf = lim;
-    for (int base = 0; base < lim; base += 512) {
+    for (int base = 0; base < lim; base += 8 * G) {
         const int i0 = base + lane * 8;
         const int cnt = lim - i0 >= 8 ? 8 : (lim - i0 < 0 ? 0 : lim - i0);
         uint32_t x = 0;
@@ -319,8 +327,8 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
         const uint32_t nz = (x | (x << 1) | (x << 2) | (x << 3)) & 0x88888888u;
         int k = nz ? __clz((int)nz) >> 2 : 8;                              // matching symbols counted from the end of the chunk
         if (k > cnt) k = cnt;
-        const unsigned long long stop = __ballot(k < 8);
-        if (stop) { const int f = __ffsll((long long)stop) - 1; suf = base + f * 8 + __shfl(k, f, 64); break; }
+        const unsigned long long stop = __ballot(k < 8) & sg_mask;
+        if (stop) { const int f = __ffsll((long long)stop) - 1; suf = base + (f - sg * G) * 8 + __shfl(k, f, 64); break; }
     }
     const int ca = la - pre - suf, cb = lb - pre - suf;
     PairDesc pd;
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     // mismatches of the trivial left-justified alignment
     const uint32_t* wp = packed + P.word_off; const uint32_t* wt = packed + T.word_off;
     int ham_l = 0;
-    for (int base = 0; base < pd.m; base += 512) {
+    for (int base = 0; base < pd.m; base += 8 * G) {
         const int i0 = base + lane * 8;
         if (i0 < pd.m) {
             const int v = pd.m - i0 >= 8 ? 8 : pd.m - i0;
@@ -348,7 +356,8 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
             ham_l += __popc((x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u);
         }
     }
-    ham_l = wave_sum_i32(ham_l);
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) ham_l += __shfl_xor(ham_l, o, 64);          // sum over the sub-group
     const int zero = (A.flags | B.flags) & HAP_ZERO, other = (A.flags | B.flags) & HAP_OTHER;      // of the whole records: conservative
     if (lane == 0) {
         const int ub = ham_l + (pd.n - pd.m);
@@ -1142,7 +1151,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     c->stats.n_hap_bytes += total_words * 4;
     // 2. trim + classify
     k_slots<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, src, slot_of);
-    k_edit_prep<<<(unsigned)((n_work + 3) / 4), 256, 0, st>>>(n_work, src, scratch, desc, key_a, val_a, ed_dev, cells_dev, c->edit_force_full ? 1 : 0, c->edit_guess);
+    k_edit_prep<PREP_LANES><<<(unsigned)((n_work + 4 * (64 / PREP_LANES) - 1) / (4 * (64 / PREP_LANES))), 256, 0, st>>>(n_work, src, scratch, desc, key_a, val_a, ed_dev, cells_dev, c->edit_force_full ? 1 : 0, c->edit_guess);
     HIPCHK(hipGetLastError());
     // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
     SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, 40));
