@@ -477,16 +477,48 @@ __global__ __launch_bounds__(64) void k_ins_pairs(long long n_part, const int64_
     __syncthreads();
     const int npairs = ns * (ns - 1) / 2;
     const long long base = pair_off[pt];
-    for (int k = lane_id(); k < npairs; k += 64) {
-        // invert the condensed index
-        int i = 0, rem = k;
-        while (rem >= ns - 1 - i) { rem -= ns - 1 - i; i++; }
-        const int j = i + 1 + rem;
-        const double pd = (double)labs64((long long)m_start[i] - m_start[j]) / p.position_distance_normalizer;
-        if (!(pd > 2 * p.cluster_max_distance)) {
-            const unsigned long long w = atomicAdd(n_work, 1ull);
+    const double two_n1 = 2.0 * ns - 1.0;
+    // pass 1: which pairs need an edit distance (one ballot mask per 64 condensed indices, kept in LDS); pass 2: write them after ONE
+    // atomic for the whole partition - a returning atomic per step costs a lone wave ~2 us each
+    __shared__ unsigned long long want_mask[(MAXN * (MAXN - 1) / 2 + 63) / 64];
+    int total = 0;
+    for (int k0 = 0; k0 < npairs; k0 += 64) {
+        const int k = k0 + lane_id();
+        bool want = false;
+        if (k < npairs) {
+            // invert the condensed index k = i*ns - i*(i+1)/2 + (j-i-1): closed form, then one step of correction either way
+            int i = (int)((two_n1 - sqrt(two_n1 * two_n1 - 8.0 * k)) * 0.5);
+            if (i < 0) i = 0;
+            if (i > ns - 2) i = ns - 2;
+            while (i > 0 && i * ns - i * (i + 1) / 2 > k) i--;
+            while (i < ns - 2 && (i + 1) * ns - (i + 1) * (i + 2) / 2 <= k) i++;
+            const int j = i + 1 + (k - (i * ns - i * (i + 1) / 2));
+            const double pd = (double)labs64((long long)m_start[i] - m_start[j]) / p.position_distance_normalizer;
+            want = !(pd > 2 * p.cluster_max_distance);
+        }
+        const unsigned long long mask = __ballot(want);
+        if (lane_id() == 0) want_mask[k0 >> 6] = mask;
+        total += (int)__popcll(mask);
+    }
+    if (total == 0) return;
+    unsigned long long w0 = 0;
+    if (lane_id() == 0) w0 = atomicAdd(n_work, (unsigned long long)total);
+    w0 = ((unsigned long long)(unsigned)__shfl((int)(w0 >> 32), 0, 64) << 32) | (unsigned)__shfl((int)w0, 0, 64);
+    __syncthreads();
+    for (int k0 = 0; k0 < npairs; k0 += 64) {
+        const unsigned long long mask = want_mask[k0 >> 6];
+        const int k = k0 + lane_id();
+        if ((mask >> lane_id()) & 1ull) {
+            int i = (int)((two_n1 - sqrt(two_n1 * two_n1 - 8.0 * k)) * 0.5);
+            if (i < 0) i = 0;
+            if (i > ns - 2) i = ns - 2;
+            while (i > 0 && i * ns - i * (i + 1) / 2 > k) i--;
+            while (i < ns - 2 && (i + 1) * ns - (i + 1) * (i + 2) / 2 <= k) i++;
+            const int j = i + 1 + (k - (i * ns - i * (i + 1) / 2));
+            const unsigned long long w = w0 + (unsigned long long)__popcll(mask & lanemask_lt());
             if ((long long)w < work_cap) { EditWork e; e.a = m_g[i]; e.b = m_g[j]; e.slot = base + k; work[w] = e; }
         }
+        w0 += (unsigned long long)__popcll(mask);
     }
 }
 
