@@ -14,15 +14,21 @@ struct AlnIndexDev {
 };
 
 // running maximum of end_or_pos1 inside every contig: the first record that can overlap a window start is found by bisection
-__global__ void k_end_prefmax(AlnIndexDev ix, int32_t* prefmax) {
+__global__ __launch_bounds__(64) void k_end_prefmax(AlnIndexDev ix, int32_t* prefmax) {       // one wave per contig, 64 records per step
     const int c = blockIdx.x;
-    if (c >= ix.n_contig || threadIdx.x != 0) return;
-    int32_t m = INT32_MIN;
-    for (int64_t i = ix.contig_first[c]; i < ix.contig_first[c + 1]; i++) {
-        int32_t e = ix.end[i];
-        if (e <= ix.pos[i]) e = ix.pos[i] + 1;
-        if (e > m) m = e;
-        prefmax[i] = m;
+    if (c >= ix.n_contig) return;
+    const int lane = lane_id();
+    const long long first = ix.contig_first[c], last = ix.contig_first[c + 1];
+    int32_t carry = INT32_MIN;
+    for (long long base = first; base < last; base += 64) {
+        const long long i = base + lane;
+        int32_t v = INT32_MIN;
+        if (i < last) { v = ix.end[i]; if (v <= ix.pos[i]) v = ix.pos[i] + 1; }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(v, o, 64); if (lane >= o && u > v) v = u; }
+        if (carry > v) v = carry;
+        if (i < last) prefmax[i] = v;
+        carry = __shfl(v, 63, 64);
     }
 }
 
