@@ -631,14 +631,15 @@ __device__ __forceinline__ void d_edit_stair(long long blk, long long count, con
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
+            uint32_t tp[P];
+            planes8<P>(tw[i], tp);                                      // bit k of tp[b]: plane b of the word's k-th symbol
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int j = kb * 32 + i * 8 + k + 1;
                 if (j <= n) {
-                    const uint32_t c = sym<P>((tw[i] >> (4 * k)) & 15u);
                     uint32_t nk[P];
 #pragma unroll
-                    for (int b = 0; b < P; b++) nk[b] = ((c >> b) & 1u) - 1u;
+                    for (int b = 0; b < P; b++) nk[b] = ((tp[b] >> k) & 1u) - 1u;
                     top += 1;
                     unsigned carry = 0;
                     uint32_t ph_prev = 0x80000000u, mh_prev = 0u;          // the row above the window steps +1
@@ -714,14 +715,15 @@ __device__ __forceinline__ void d_edit_lane(long long blk, long long count, cons
     for (int jb = 0; jb * 8 < nmax; jb++) {
         const uint32_t tw = tw_next;
         tw_next = (live && jb + 1 < txt_words) ? txt.word(jb + 1) : 0u;
+        uint32_t tp[P];
+        planes8<P>(tw, tp);                                             // bit k of tp[b]: plane b of the word's k-th symbol
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int j = jb * 8 + k + 1;
             if (j <= n) {
-                const uint32_t c = sym<P>((tw >> (4 * k)) & 15u);
                 uint32_t nk[P];
 #pragma unroll
-                for (int b = 0; b < P; b++) nk[b] = ((c >> b) & 1u) - 1u;
+                for (int b = 0; b < P; b++) nk[b] = ((tp[b] >> k) & 1u) - 1u;
                 unsigned carry = 0;
                 uint32_t ph_prev = 0x80000000u, mh_prev = 0u;           // the row above the column steps +1
                 MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
