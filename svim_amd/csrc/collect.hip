@@ -565,10 +565,27 @@ __global__ __launch_bounds__(256) void k_gather_seq(SigPtrs s, long long n, cons
     const uint8_t* src = rec_seq + rec_seq_off[s.rec[i]];
     uint8_t* dst = seq_out + seq_off[i];
     const int q0 = s.qpos[i];
-    for (int k = lane_id(); k < len; k += 64) {
-        const int q = q0 + k;
-        const uint8_t by = src[q >> 1];
-        dst[k] = (q & 1) ? (by & 15) : (by >> 4);
+    // 8 bases per lane and step: one 8-byte load + one 8-byte store while 16 more bases of THIS slice remain (the load then stays inside
+    // the record's own bytes), byte accesses for the last chunks
+    for (int k0 = lane_id() * 8; k0 < len; k0 += 512) {
+        const int q = q0 + k0;
+        if (k0 + 16 <= len) {
+            unsigned long long x;
+            __builtin_memcpy(&x, src + (q >> 1), 8);
+            unsigned long long out = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int nib = (q & 1) + t;                         // nibble index from the first loaded byte, high nibble first
+                const unsigned by = (unsigned)(x >> (8 * (nib >> 1))) & 0xffu;
+                out |= (unsigned long long)((nib & 1) ? (by & 15u) : (by >> 4)) << (8 * t);
+            }
+            __builtin_memcpy(dst + k0, &out, 8);
+        } else {
+            for (int t = 0; t < 8 && k0 + t < len; t++) {
+                const uint8_t by = src[(q + t) >> 1];
+                dst[k0 + t] = ((q + t) & 1) ? (by & 15) : (by >> 4);
+            }
+        }
     }
 }
 
