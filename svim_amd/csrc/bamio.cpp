@@ -9,6 +9,9 @@
 // SURVEY.md section 8(f) row 1.
 #include <zlib.h>
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <future>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -20,6 +23,34 @@
 
 extern thread_local std::string g_svx_err;
 static int bam_fail(int code, const std::string& what) { g_svx_err = what; return code; }
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// growable array WITHOUT value-initialisation: the big arrays (inflated bytes, CIGAR words, packed bases) are written exactly once by
+// the decoder threads; std::vector::resize would first zero them (a memset of every batch)
+template <class T> struct RawVec {
+    T* p = nullptr; size_t n = 0, cap = 0;
+    RawVec() = default;
+    RawVec(const RawVec&) = delete; RawVec& operator=(const RawVec&) = delete;
+    ~RawVec() { free(p); }
+    void reserve(size_t c) {
+        if (c <= cap) return;
+        size_t nc = cap + cap / 2 + 1024;
+        if (nc < c) nc = c;
+        T* q = (T*)realloc(p, nc * sizeof(T));
+        if (!q) throw std::string("out of host memory");
+        p = q; cap = nc;
+    }
+    void resize_uninit(size_t m) { reserve(m); n = m; }
+    void push_back(const T& v) { reserve(n + 1); p[n++] = v; }
+    void append(const T* src, size_t m) { reserve(n + m); if (m) memcpy(p + n, src, m * sizeof(T)); n += m; }
+    void clear() { n = 0; }
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
 
 struct svx_bam {
     FILE* f = nullptr;
@@ -29,18 +60,25 @@ struct svx_bam {
     std::unordered_map<std::string, int32_t> tid_of, read_id_of;
     std::string read_names_blob;          // NUL-separated, id order
     std::vector<uint64_t> read_name_off;
-    // uncompressed stream window
-    std::vector<uint8_t> buf; size_t pos = 0; bool file_eof = false;
+    // uncompressed stream window + the chunk a background thread is inflating meanwhile
+    RawVec<uint8_t> buf; size_t pos = 0; bool file_eof = false;
+    // The background thread inflates the next chunk into `next` BEHIND `WIN_HEAD` bytes of headroom: switching windows then only moves
+    // the unconsumed tail of the old one (a partial record) in front of the new data instead of copying the chunk.
+    std::future<void> prefetch; bool prefetch_active = false; RawVec<uint8_t> next; size_t next_len = 0; bool next_eof = false; std::string prefetch_err;
     int n_threads = 8;
+    double t_wait = 0, t_copy = 0, t_walk = 0, t_decode = 0, t_intern = 0, t_post = 0;       // SVX_BAM_TIMING=1: seconds per stage, printed at close
     // batch arrays
     std::vector<uint16_t> flag; std::vector<int32_t> tid, bpos, lseq, read_id; std::vector<uint8_t> mapq;
-    std::vector<uint32_t> order, seg_order, seg_off, cigar, seg_cigar;
+    std::vector<uint32_t> order, seg_order, seg_off, seg_cigar;
+    RawVec<uint32_t> cigar; RawVec<uint8_t> seq;
     std::vector<uint64_t> cigar_off, seq_off, seg_cigar_off;
-    std::vector<uint8_t> seq, seg_rev, seg_mapq;
+    std::vector<uint8_t> seg_rev, seg_mapq;
     std::vector<int32_t> seg_tid, seg_pos, seg_lseq;
     // per-record SA strings of the current batch (offset, length into sa_blob; length 0 = none)
     std::string sa_blob; std::vector<uint64_t> sa_at; std::vector<uint32_t> sa_len;
     std::vector<uint32_t> name_id_tmp;
+    struct RecRef { const uint8_t* r; const uint8_t* end; const uint8_t* cig; uint32_t n_cig; };
+    std::vector<RecRef> refs; std::vector<const char*> t_name, t_sa; std::vector<uint32_t> t_name_len, t_sa_len;
     int64_t total_records = 0;
 };
 
@@ -83,32 +121,69 @@ static void inflate_block(const RawBlock& b, uint8_t* out) {
     if (rc != Z_STREAM_END || zs.avail_out != 0) throw std::string("BGZF inflate failed");
 }
 
-// make at least `need` bytes available from h->pos (false at clean EOF with nothing left)
-static bool ensure(svx_bam* h, size_t need) {
-    while (h->buf.size() - h->pos < need) {
-        if (h->file_eof) return false;
-        if (h->pos > (64u << 20)) { h->buf.erase(h->buf.begin(), h->buf.begin() + (long)h->pos); h->pos = 0; }
+// Inflate the next chunk of BGZF blocks (<= 1024 blocks / 48 MB) into h->next: n_threads workers, runs on a background thread while the
+// caller decodes the previous chunk.  Only this function touches the FILE after open.
+#define WIN_HEAD ((size_t)8 << 20)
+static void inflate_next_chunk(svx_bam* h) {
+    try {
         std::vector<RawBlock> blocks;
         size_t total = 0;
+        h->next_eof = false;
         while (blocks.size() < 1024 && total < (48u << 20)) {
             RawBlock b;
-            if (!read_block(h, b)) { h->file_eof = true; break; }
+            if (!read_block(h, b)) { h->next_eof = true; break; }
             b.out_at = total; total += b.isize;
             blocks.push_back(std::move(b));
         }
-        const size_t base = h->buf.size();
-        h->buf.resize(base + total);
+        h->next.resize_uninit(WIN_HEAD + total);
+        h->next_len = total;
         const int T = std::max(1, std::min<int>(h->n_threads, (int)blocks.size()));
         std::vector<std::thread> th;
         std::vector<std::string> errs((size_t)T);
         for (int t = 0; t < T; t++)
             th.emplace_back([&, t]() {
-                try { for (size_t i = (size_t)t; i < blocks.size(); i += (size_t)T) inflate_block(blocks[i], h->buf.data() + base + blocks[i].out_at); }
+                try { for (size_t i = (size_t)t; i < blocks.size(); i += (size_t)T) inflate_block(blocks[i], h->next.data() + WIN_HEAD + blocks[i].out_at); }
                 catch (const std::string& e) { errs[(size_t)t] = e; }
             });
         for (auto& x : th) x.join();
         for (auto& e : errs) if (!e.empty()) throw e;
-        if (blocks.empty()) break;
+    } catch (const std::string& e) { h->prefetch_err = e; }
+}
+
+static void start_prefetch(svx_bam* h) {
+    if (h->prefetch_active || h->file_eof) return;
+    h->prefetch = std::async(std::launch::async, inflate_next_chunk, h);
+    h->prefetch_active = true;
+}
+
+// make at least `need` bytes available from h->pos (false at clean EOF with nothing left)
+static bool ensure(svx_bam* h, size_t need) {
+    while (h->buf.size() - h->pos < need) {
+        if (h->file_eof) return false;
+        start_prefetch(h);
+        double t0 = now_s();
+        h->prefetch.get();
+        h->prefetch_active = false;
+        h->t_wait += now_s() - t0; t0 = now_s();
+        if (!h->prefetch_err.empty()) { const std::string e = h->prefetch_err; h->prefetch_err.clear(); h->file_eof = true; throw e; }
+        // the unconsumed tail of the current window (a partial record) moves in front of the new chunk; the old buffer becomes the
+        // next inflate target
+        const size_t keep = h->buf.size() - h->pos;
+        if (keep <= WIN_HEAD) {
+            memcpy(h->next.data() + WIN_HEAD - keep, h->buf.data() + h->pos, keep);
+            std::swap(h->buf.p, h->next.p); std::swap(h->buf.cap, h->next.cap);
+            h->buf.n = WIN_HEAD + h->next_len;
+            h->pos = WIN_HEAD - keep;
+        } else {
+            // a record longer than the headroom straddles the chunks: fall back to appending
+            if (h->pos) { memmove(h->buf.data(), h->buf.data() + h->pos, keep); h->buf.n = keep; h->pos = 0; }
+            h->buf.append(h->next.data() + WIN_HEAD, h->next_len);
+        }
+        if (h->next_eof) h->file_eof = true;
+        const bool got = h->next_len > 0;
+        h->t_copy += now_s() - t0;
+        start_prefetch(h);
+        if (!got && h->file_eof) break;
     }
     return h->buf.size() - h->pos >= need;
 }
@@ -119,15 +194,15 @@ static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] <
 extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out) {
     svx_bam* h = new svx_bam();
     h->path = path;
-    h->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    h->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     h->f = fopen(path, "rb");
     if (!h->f) { delete h; return bam_fail(SVX_E_ARG, std::string("cannot open ") + path); }
     try {
-        if (!ensure(h, 12) || memcmp(h->buf.data(), "BAM\1", 4) != 0) throw std::string("not a BAM file");
-        const uint32_t l_text = rd32(h->buf.data() + 4);
-        if (!ensure(h, 12 + l_text)) throw std::string("truncated BAM header");
-        std::string text((const char*)h->buf.data() + 8, l_text);
-        h->pos = 8 + l_text;
+        if (!ensure(h, 12) || memcmp(h->buf.data() + h->pos, "BAM\1", 4) != 0) throw std::string("not a BAM file");
+        const uint32_t l_text = rd32(h->buf.data() + h->pos + 4);
+        if (!ensure(h, 12 + (size_t)l_text)) throw std::string("truncated BAM header");
+        std::string text((const char*)h->buf.data() + h->pos + 8, l_text);
+        h->pos += 8 + (size_t)l_text;
         // @HD SO:
         const size_t hd = text.find("@HD");
         if (hd != std::string::npos) {
@@ -153,13 +228,17 @@ extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out) {
         std::sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return h->ref_names[(size_t)a] < h->ref_names[(size_t)b]; });
         h->contig_rank.assign(n_ref ? n_ref : 1, 0);
         for (uint32_t r = 0; r < n_ref; r++) h->contig_rank[(size_t)idx[r]] = (int32_t)r;
-    } catch (const std::string& e) { fclose(h->f); delete h; return bam_fail(SVX_E_ARG, e); }
+    } catch (const std::string& e) { if (h->prefetch_active) h->prefetch.wait(); fclose(h->f); delete h; return bam_fail(SVX_E_ARG, e); }
     *out = h;
     return SVX_OK;
 }
 
 extern "C" void svx_bam_close(svx_bam* h) {
     if (!h) return;
+    if (h->prefetch_active) { h->prefetch.wait(); h->prefetch_active = false; }
+    if (getenv("SVX_BAM_TIMING"))
+        fprintf(stderr, "bamio %d threads: wait for inflate %.3f s, window copy %.3f, record walk %.3f, decode %.3f, names + SA %.3f\n", h->n_threads,
+                h->t_wait, h->t_copy, h->t_walk, h->t_decode, h->t_intern);
     if (h->f) fclose(h->f);
     delete h;
 }
@@ -226,6 +305,118 @@ static int append_sa(svx_bam* h, const char* sa, size_t len, int32_t primary_lse
     return SVX_OK;
 }
 
+// aux fields of one record: SA (Z) and CG (B,I)
+static void scan_aux(const uint8_t* q, const uint8_t* end, const char*& sa, size_t& sa_n, const uint8_t*& cg, uint32_t& cg_n) {
+    sa = nullptr; sa_n = 0; cg = nullptr; cg_n = 0;
+    while (q + 3 <= end) {
+        const char t0 = (char)q[0], t1 = (char)q[1], ty = (char)q[2]; q += 3;
+        size_t sz = 0;
+        switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': { const uint8_t* z = (const uint8_t*)memchr(q, 0, (size_t)(end - q)); if (!z) throw std::string("unterminated aux string");
+                if (t0 == 'S' && t1 == 'A' && ty == 'Z') { sa = (const char*)q; sa_n = (size_t)(z - q); } sz = (size_t)(z - q) + 1; break; }
+            case 'B': { const char sub = (char)q[0]; const uint32_t cnt = rd32(q + 1); const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                if (t0 == 'C' && t1 == 'G' && sub == 'I') { cg = q + 5; cg_n = cnt; } sz = 5 + es * cnt; break; }
+            default: throw std::string("unknown BAM aux type");
+        }
+        q += sz;
+    }
+}
+
+// Bulk decode: every complete record in the window (at most max_count) -> batch arrays.  Three phases: (1) serial walk over the
+// block_size fields sizes the arrays (prefix sums of CIGAR ops and packed sequence bytes), (2) the records are decoded by n_threads
+// workers into their slots (numeric fields, CIGAR words, packed bases, SA / name pointers), (3) serial: read names are interned in
+// record order and the SA strings copied.  Returns the number of records decoded (0: no complete record in the window).
+static int64_t decode_run(svx_bam* h, int64_t max_count) {
+    auto& refs = h->refs;
+    refs.clear();
+    double t0 = now_s();
+    const uint8_t* buf = h->buf.data();
+    size_t p = h->pos;
+    const size_t end = h->buf.size();
+    uint64_t cig_total = h->cigar.size(), seq_total = h->seq.size();
+    while ((int64_t)refs.size() < max_count && p + 4 <= end) {
+        const uint32_t bs = rd32(buf + p);
+        if (p + 4 + (size_t)bs > end) break;
+        svx_bam::RecRef rr;
+        rr.r = buf + p + 4; rr.end = rr.r + bs;
+        if (bs < 32) throw std::string("corrupt BAM record");
+        const unsigned l_name = rr.r[8];
+        rr.n_cig = rd16(rr.r + 12);
+        const uint32_t l_seq = rd32(rr.r + 16);
+        rr.cig = rr.r + 32 + l_name;
+        if (rr.cig + 4 * (size_t)rr.n_cig + (l_seq + 1) / 2 + l_seq > rr.end) throw std::string("corrupt BAM record");
+        // long CIGARs (> 65535 ops) live in CG:B,I behind a <l_seq>S<ref_len>N placeholder
+        if (rr.n_cig == 2 && (rd32(rr.cig) & 15) == 4 && (rd32(rr.cig) >> 4) == l_seq && (rd32(rr.cig + 4) & 15) == 3) {
+            const char* sa; size_t sa_n; const uint8_t* cg; uint32_t cg_n;
+            scan_aux(rr.cig + 8 + (l_seq + 1) / 2 + l_seq, rr.end, sa, sa_n, cg, cg_n);
+            if (cg) { rr.cig = cg; rr.n_cig = cg_n; }
+        }
+        cig_total += rr.n_cig; seq_total += (l_seq + 1) / 2;
+        h->cigar_off.push_back(cig_total); h->seq_off.push_back(seq_total);
+        refs.push_back(rr);
+        p += 4 + (size_t)bs;
+    }
+    const size_t n = refs.size();
+    if (n == 0) return 0;
+    h->t_walk += now_s() - t0; t0 = now_s();
+    const size_t base = h->flag.size();
+    h->flag.resize(base + n); h->tid.resize(base + n); h->bpos.resize(base + n); h->mapq.resize(base + n); h->lseq.resize(base + n);
+    h->read_id.resize(base + n); h->sa_at.resize(base + n); h->sa_len.resize(base + n);
+    h->t_name.resize(n); h->t_name_len.resize(n); h->t_sa.resize(n); h->t_sa_len.resize(n);
+    h->cigar.resize_uninit(cig_total); h->seq.resize_uninit(seq_total);
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)h->n_threads, n / 16 + 1));
+    std::vector<std::string> errs((size_t)T);
+    auto work = [&](int t) {
+        try {
+            for (size_t i = n * (size_t)t / (size_t)T; i < n * (size_t)(t + 1) / (size_t)T; i++) {
+                const svx_bam::RecRef& rr = refs[i];
+                const uint8_t* r = rr.r;
+                const size_t k = base + i;
+                const unsigned l_name = r[8];
+                const uint32_t l_seq = rd32(r + 16);
+                h->tid[k] = (int32_t)rd32(r); h->bpos[k] = (int32_t)rd32(r + 4); h->mapq[k] = r[9];
+                h->flag[k] = (uint16_t)(rd16(r + 14) & 0x0fff); h->lseq[k] = (int32_t)l_seq;
+                h->t_name[i] = (const char*)r + 32; h->t_name_len[i] = l_name ? l_name - 1 : 0;
+                const uint8_t* q = r + 32 + l_name + 4 * (size_t)rd16(r + 12);       // the record's own CIGAR field, CG or not
+                uint32_t* cw = h->cigar.data() + h->cigar_off[k];
+                for (uint32_t c = 0; c < rr.n_cig; c++) cw[c] = rd32(rr.cig + 4 * (size_t)c);
+                memcpy(h->seq.data() + h->seq_off[k], q, (l_seq + 1) / 2);
+                const char* sa; size_t sa_n; const uint8_t* cg; uint32_t cg_n;
+                scan_aux(q + (l_seq + 1) / 2 + l_seq, rr.end, sa, sa_n, cg, cg_n);
+                h->t_sa[i] = sa; h->t_sa_len[i] = (uint32_t)sa_n;
+            }
+        } catch (const std::string& e) { errs[(size_t)t] = e; }
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    for (auto& e : errs) if (!e.empty()) throw e;
+    h->t_decode += now_s() - t0; t0 = now_s();
+    for (size_t i = 0; i < n; i++) {
+        const std::string name(h->t_name[i], h->t_name_len[i]);
+        auto it = h->read_id_of.find(name);
+        int32_t rid;
+        if (it == h->read_id_of.end()) {
+            rid = (int32_t)h->read_name_off.size();
+            h->read_id_of.emplace(name, rid);
+            h->read_name_off.push_back(h->read_names_blob.size());
+            h->read_names_blob += name; h->read_names_blob.push_back('\0');
+        } else rid = it->second;
+        h->read_id[base + i] = rid;
+        h->sa_at[base + i] = h->sa_blob.size(); h->sa_len[base + i] = h->t_sa_len[i];
+        if (h->t_sa_len[i]) h->sa_blob.append(h->t_sa[i], h->t_sa_len[i]);
+    }
+    h->pos = p;
+    h->t_intern += now_s() - t0;
+    return (int64_t)n;
+}
+
 // next record -> appended to the batch arrays; returns 1 = ok, 0 = EOF
 static int parse_record(svx_bam* h) {
     if (!ensure(h, 4)) return 0;
@@ -244,23 +435,8 @@ static int parse_record(svx_bam* h) {
     const uint8_t* cig = q; q += 4 * (size_t)n_cig;
     const uint8_t* sq = q; q += (l_seq + 1) / 2;
     q += l_seq;
-    // aux: SA (Z) and CG (B,I)
-    const char* sa = nullptr; size_t sa_n = 0; const uint8_t* cg = nullptr; uint32_t cg_n = 0;
-    while (q + 3 <= end) {
-        const char t0 = (char)q[0], t1 = (char)q[1], ty = (char)q[2]; q += 3;
-        size_t sz = 0;
-        switch (ty) {
-            case 'A': case 'c': case 'C': sz = 1; break;
-            case 's': case 'S': sz = 2; break;
-            case 'i': case 'I': case 'f': sz = 4; break;
-            case 'Z': case 'H': { const uint8_t* z = (const uint8_t*)memchr(q, 0, (size_t)(end - q)); if (!z) throw std::string("unterminated aux string");
-                if (t0 == 'S' && t1 == 'A' && ty == 'Z') { sa = (const char*)q; sa_n = (size_t)(z - q); } sz = (size_t)(z - q) + 1; break; }
-            case 'B': { const char sub = (char)q[0]; const uint32_t cnt = rd32(q + 1); const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                if (t0 == 'C' && t1 == 'G' && sub == 'I') { cg = q + 5; cg_n = cnt; } sz = 5 + es * cnt; break; }
-            default: throw std::string("unknown BAM aux type");
-        }
-        q += sz;
-    }
+    const char* sa; size_t sa_n; const uint8_t* cg; uint32_t cg_n;
+    scan_aux(q, end, sa, sa_n, cg, cg_n);
     // long CIGARs (> 65535 ops) live in CG:B,I behind a <l_seq>S<ref_len>N placeholder
     if (cg && n_cig == 2 && (rd32(cig) & 15) == 4 && (rd32(cig) >> 4) == l_seq && (rd32(cig + 4) & 15) == 3) { cig = cg; n_cig = cg_n; }
     auto it = h->read_id_of.find(name);
@@ -274,10 +450,10 @@ static int parse_record(svx_bam* h) {
     h->flag.push_back((uint16_t)(flag & 0x0fff)); h->tid.push_back(tid); h->bpos.push_back(pos); h->mapq.push_back((uint8_t)mq);
     h->lseq.push_back((int32_t)l_seq); h->read_id.push_back(rid);
     const size_t c0 = h->cigar.size();
-    h->cigar.resize(c0 + n_cig);
+    h->cigar.resize_uninit(c0 + n_cig);
     for (unsigned i = 0; i < n_cig; i++) h->cigar[c0 + i] = rd32(cig + 4 * (size_t)i);
     h->cigar_off.push_back(h->cigar.size());
-    h->seq.insert(h->seq.end(), sq, sq + (l_seq + 1) / 2);
+    h->seq.append(sq, (l_seq + 1) / 2);
     h->seq_off.push_back(h->seq.size());
     h->sa_at.push_back(h->sa_blob.size()); h->sa_len.push_back((uint32_t)sa_n);
     if (sa_n) h->sa_blob.append(sa, sa_n);
@@ -298,7 +474,12 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
     try {
         clear_batch(h);
         int64_t n = 0;
-        while (n < max_records) { if (!parse_record(h)) break; n++; }
+        while (n < max_records) {
+            if (!ensure(h, 4)) break;                                                   // end of file
+            const uint32_t bs = rd32(h->buf.data() + h->pos);
+            if (!ensure(h, 4 + (size_t)bs)) throw std::string("truncated BAM record");
+            n += decode_run(h, max_records - n);                                         // at least the record just made available
+        }
         if (mode == 1 && n == max_records) {
             // finish the current read group: keep reading while the name does not change (peek = parse, names are interned)
             for (;;) {
@@ -364,7 +545,9 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
         }
         // never hand out null pointers for empty arrays
         auto pad = [](auto& v) { if (v.empty()) v.resize(1); };
-        pad(h->cigar); pad(h->seq); pad(h->seg_tid); pad(h->seg_pos); pad(h->seg_rev); pad(h->seg_mapq); pad(h->seg_lseq); pad(h->seg_cigar);
+        if (h->cigar.empty()) { h->cigar.reserve(1); h->cigar[0] = 0; }
+        if (h->seq.empty()) { h->seq.reserve(1); h->seq[0] = 0; }
+        pad(h->seg_tid); pad(h->seg_pos); pad(h->seg_rev); pad(h->seg_mapq); pad(h->seg_lseq); pad(h->seg_cigar);
         pad(h->flag); pad(h->tid); pad(h->bpos); pad(h->mapq); pad(h->lseq); pad(h->read_id); pad(h->order); pad(h->seg_order);
         memset(out, 0, sizeof *out);
         out->on_device = 0; out->n_rec = n; out->flag = h->flag.data(); out->tid = h->tid.data(); out->pos = h->bpos.data(); out->mapq = h->mapq.data();
