@@ -66,6 +66,7 @@ struct svx_bam {
     // the unconsumed tail of the old one (a partial record) in front of the new data instead of copying the chunk.
     std::future<void> prefetch; bool prefetch_active = false; RawVec<uint8_t> next; size_t next_len = 0; bool next_eof = false; std::string prefetch_err;
     int n_threads = 8;
+    size_t win_head = (size_t)8 << 20, chunk_blocks = 1024;      // test hooks: SVX_BAM_WIN_HEAD (bytes), SVX_BAM_CHUNK_BLOCKS
     double t_wait = 0, t_copy = 0, t_walk = 0, t_decode = 0, t_intern = 0, t_post = 0;       // SVX_BAM_TIMING=1: seconds per stage, printed at close
     // batch arrays
     std::vector<uint16_t> flag; std::vector<int32_t> tid, bpos, lseq, read_id; std::vector<uint8_t> mapq;
@@ -123,13 +124,13 @@ static void inflate_block(const RawBlock& b, uint8_t* out) {
 
 // Inflate the next chunk of BGZF blocks (<= 1024 blocks / 48 MB) into h->next: n_threads workers, runs on a background thread while the
 // caller decodes the previous chunk.  Only this function touches the FILE after open.
-#define WIN_HEAD ((size_t)8 << 20)
 static void inflate_next_chunk(svx_bam* h) {
+    const size_t WIN_HEAD = h->win_head;
     try {
         std::vector<RawBlock> blocks;
         size_t total = 0;
         h->next_eof = false;
-        while (blocks.size() < 1024 && total < (48u << 20)) {
+        while (blocks.size() < h->chunk_blocks && total < (48u << 20)) {
             RawBlock b;
             if (!read_block(h, b)) { h->next_eof = true; break; }
             b.out_at = total; total += b.isize;
@@ -168,6 +169,7 @@ static bool ensure(svx_bam* h, size_t need) {
         if (!h->prefetch_err.empty()) { const std::string e = h->prefetch_err; h->prefetch_err.clear(); h->file_eof = true; throw e; }
         // the unconsumed tail of the current window (a partial record) moves in front of the new chunk; the old buffer becomes the
         // next inflate target
+        const size_t WIN_HEAD = h->win_head;
         const size_t keep = h->buf.size() - h->pos;
         if (keep <= WIN_HEAD) {
             memcpy(h->next.data() + WIN_HEAD - keep, h->buf.data() + h->pos, keep);
@@ -195,6 +197,8 @@ extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out) {
     svx_bam* h = new svx_bam();
     h->path = path;
     h->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    { const char* e = getenv("SVX_BAM_WIN_HEAD"); if (e && atoll(e) >= 0) h->win_head = (size_t)atoll(e); }
+    { const char* e = getenv("SVX_BAM_CHUNK_BLOCKS"); if (e && atoll(e) > 0) h->chunk_blocks = (size_t)atoll(e); }
     h->f = fopen(path, "rb");
     if (!h->f) { delete h; return bam_fail(SVX_E_ARG, std::string("cannot open ") + path); }
     try {

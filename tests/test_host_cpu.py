@@ -225,3 +225,42 @@ def test_native_bam_reader_matches_python_batcher(tmp_path, mode):
     assert tot == hb.n_rec
     assert np.array_equal(np.concatenate(flags), hb.arrays["flag"] & 0x0fff)
     nb.close()
+
+
+@pytest.mark.parametrize("env", [{"SVX_BAM_CHUNK_BLOCKS": "1"}, {"SVX_BAM_CHUNK_BLOCKS": "2", "SVX_BAM_WIN_HEAD": "16"},
+                                 {"SVX_BAM_CHUNK_BLOCKS": "3", "SVX_BAM_WIN_HEAD": "0"}])
+def test_native_bam_reader_chunk_switches(tmp_path, monkeypatch, env):
+    """The reader inflates the file in chunks on a background thread and carries the partial record at the end of a chunk into the next
+    window (through the headroom, or by appending when it does not fit).  Tiny chunks / tiny headroom exercise both paths on
+    every switch; the result must not depend on them."""
+    from svim_amd.bamio import NativeBam
+    refs, lens = ["chr1", "chr2"], [400000, 60000]
+    recs = synth.coordinate_sort(synth.fuzz_split_reads(5, 400, refs, lens, read_len=(3000, 30000)))
+    path = str(tmp_path / "t.bam")
+    records.write_bam(path, refs, lens, recs, sort_order="coordinate")
+    assert os.path.getsize(path) > 400000                     # dozens of BGZF blocks
+
+    def read_all(batch_size):
+        nb = NativeBam(path, threads=4)
+        out = {k: [] for k in ("flag", "pos", "lseq", "cigar", "seq", "read_id")}
+        n_tot = 0
+        while True:
+            b, n = nb.read_batch(batch_size, 20, "coordinate")
+            if n == 0:
+                break
+            A = nb.batch_arrays(b)
+            for k in out:
+                out[k].append(A[k].copy())
+            n_tot += n
+        names = nb.read_names()
+        nb.close()
+        return n_tot, {k: np.concatenate(v) for k, v in out.items()}, names
+
+    ref_n, ref_arrays, ref_names = read_all(1 << 30)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for batch_size in (1 << 30, 50):
+        n, arrays, names = read_all(batch_size)
+        assert n == ref_n == len(recs) and names == ref_names
+        for k in arrays:
+            assert np.array_equal(arrays[k], ref_arrays[k]), (k, batch_size)
