@@ -220,7 +220,15 @@ def gather_clusters_device(eng, contig_rank, dev):
     g = {k: _all_gather_var(v, ns, dist, torch) for k, v in cols.items()}
     g_part = _all_gather_var(part_index, ns, dist, torch)
     g_mem = _all_gather_var(members, nms, dist, torch)
-    n, nm = sum(ns), sum(nms)
+    return merge_gathered_clusters(g, g_part, g_mem, contig_rank)
+
+
+def merge_gathered_clusters(g, g_part, g_mem, contig_rank):
+    """The merge of merge_cluster_tables on torch tensors (any device): `g` = cluster columns of all ranks concatenated rank-major,
+    `g_part` their global partition indices, `g_mem` the member lists concatenated in the same order."""
+    import torch
+    dev = g_part.device
+    n, nm = int(g_part.numel()), int(g_mem.numel())
     sizes = g["size"].to(torch.int64)
     # first member of every gathered cluster inside g_mem (tables are concatenated rank-major, members likewise)
     src_off = torch.cumsum(sizes, 0) - sizes

@@ -123,7 +123,20 @@ def _worker_by_origin(rank, world, port, ret):
         ct = orc.cluster(p, hb_all.contig_rank, table=local, shard=(rank, world), origin_prefix=prefix)
         remote = orc.remote_members()
         merged = gather_clusters(ct, hb_all.contig_rank)
-        ok = merged.first_difference(full) is None and remote == 0 and merged.n > 20 and len(kept) > len(mine) > 0
+        # the device-side exchange of bench.py (all-gather of the columns + torch merge), here on CPU tensors over gloo
+        import torch
+        from svim_amd._abi import CLU_DTYPES
+        from svim_amd.distributed import _all_gather_var, merge_gathered_clusters
+        cnt = torch.tensor([ct.n, ct.n_members], dtype=torch.int64)
+        allc = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allc, cnt)
+        ns, nms = [int(c[0]) for c in allc], [int(c[1]) for c in allc]
+        g = {k: _all_gather_var(torch.from_numpy(np.ascontiguousarray(getattr(ct, k)[:ct.n])), ns, dist, torch) for k in CLU_DTYPES}
+        g_part = _all_gather_var(torch.from_numpy(np.ascontiguousarray(ct.part_index[:ct.n]).astype(np.int64)), ns, dist, torch)
+        g_mem = _all_gather_var(torch.from_numpy(np.ascontiguousarray(ct.members[:ct.n_members])), nms, dist, torch)
+        merged_t = merge_gathered_clusters(g, g_part, g_mem, hb_all.contig_rank).to_host()
+        same_t = merged_t.first_difference(full) is None and np.array_equal(merged_t.part_index, merged.part_index)
+        ok = merged.first_difference(full) is None and same_t and remote == 0 and merged.n > 20 and len(kept) > len(mine) > 0
         ret[rank] = "ok" if ok else "diff %s remote %d n %d" % (merged.first_difference(full), remote, merged.n)
     finally:
         dist.destroy_process_group()
