@@ -117,3 +117,21 @@ def test_gpu_genotype_random_vs_oracle(oracle):
         b = [[c.support_fraction, c.genotype, c.ref_reads, c.alt_reads] for c in cands_b]
         assert a == b
         assert max(x[2] for x in a) > 300
+
+
+def test_alignment_index_rejects_unsorted_input(golden):
+    g, _ = golden
+    rows = list(reversed(g["rows"][:50]))
+    bam = records.AlignmentFile(text=synth.genotype_sam_text(g["references"], g["lengths"], rows))
+    with pytest.raises(ValueError):
+        SVIM_genotyping.AlignmentIndex(bam)
+
+
+def test_candidates_below_minimum_score_are_left_untouched(golden, oracle):
+    g, bam = golden
+    o = types.SimpleNamespace(**g["options"])
+    low = _Candidate("DEL", "chr1", 1000, 2000, ["g00001"], o.minimum_score - 1)
+    ok = _Candidate("DEL", "chr1", 1000, 2000, ["g00001"], o.minimum_score)
+    SVIM_genotyping.genotype([low, ok], bam, "DEL", o, engine=oracle)
+    assert (low.support_fraction, low.genotype, low.ref_reads, low.alt_reads) == (".", "./.", None, None)
+    assert ok.alt_reads == 1 and ok.ref_reads is not None
