@@ -2,16 +2,17 @@
 """bench.py - COLLECT+CLUSTER throughput on MI355X (BASELINE.json metric: aligned reads/sec through
 COLLECT+CLUSTER; SV signatures/sec clustered).
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 1 --steps 3 --warmup 1                          # configs[1], the configuration the metric is quoted on
+    python bench.py --workload c2                                          # configs[2] stand-in: HiFi profile, full SV-type set
+    python bench.py --workload c4 --partition-max-distance 20000           # configs[4] stand-in: 60x CLR profile, large partitions
+    python bench.py --bam reads.bam --fasta ref.fa                         # a real coordinate-sorted BAM (configs[2]-[4] proper)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (svx_collect + svx_cluster through the C ABI) over one synthetic record batch
-that is already resident in HBM: BASELINE.json configs[1] - 1M synthetic ONT reads (N50 20 kb), one 250 Mb contig,
-planted DEL/INS/INV (svim_amd/devsynth.py).  Weak scaling: every rank owns its own batch of that size (its own
-contig); signatures are all-gathered over RCCL so that partitioning and the sequential random.sample stream see
-the whole list, the quadratic per-partition work is sharded by partition index, and the cluster tables are gathered
-at the end (svim_amd/distributed.py).  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path (svx_collect + svx_cluster through the C ABI) over one record batch that is
+already resident in HBM.  Default workload: BASELINE.json configs[1] - 1M synthetic ONT reads (N50 20 kb), one 250 Mb
+contig, planted DEL/INS/INV (svim_amd/devsynth.py); c2 / c4: svim_amd/workloads.py.  Weak scaling: every rank owns its own
+batch of that size (its own contigs); see svim_amd/distributed.py for what crosses xGMI.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -25,21 +26,26 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+# VALU issue peak of the edit-distance kernels: 1024 SIMDs x 2.4 GHz, one wave64 instruction per 2 cycles (MI355X_MICROARCH.md)
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2
+# the Myers/Hyyro column update: VALU instructions per 32-bit word-column (svim_amd/csrc/myers_column.hpp; 38 issue cycles)
+INSTR_PER_WORDCOL = 12.4
+CYCLES_PER_WORDCOL = 38.0
 
-def options():
+
+def options(pmd=1000):
     return types.SimpleNamespace(min_mapq=20, min_sv_size=40, max_sv_size=100000, segment_gap_tolerance=10,
-                                 segment_overlap_tolerance=5, partition_max_distance=1000, position_distance_normalizer=900,
+                                 segment_overlap_tolerance=5, partition_max_distance=pmd, position_distance_normalizer=900,
                                  edit_distance_normalizer=1.0, cluster_max_distance=0.5, all_bnds=False)
 
 
-def cpu_baseline(batch, genome, params, eng=None, budget_s=20.0):
+def cpu_baseline(batch, g_off, genome, params, eng=None, budget_s=20.0):
     """The oracle (single-threaded C restatement of the reference algorithm, kind 'port') on a bounded, contiguous
     slice of the same batch (contiguous in coordinate order = full local coverage, so per-partition work is
     representative)."""
     from oracle import oracle as om
     orc = om.Oracle()
-    g = genome.cpu().numpy()
-    orc.set_genome(np.array([0, g.size], dtype=np.int64), g)
+    orc.set_genome(g_off.cpu().numpy().astype(np.int64), genome.cpu().numpy())
     n = min(batch.n_rec, 4000)
     best = None
     for _ in range(4):
@@ -47,7 +53,7 @@ def cpu_baseline(batch, genome, params, eng=None, budget_s=20.0):
         t0 = time.perf_counter()
         sig, _ = orc.collect(hb, params)
         t1 = time.perf_counter()
-        ct = orc.cluster(params, np.zeros(1, np.int32), source=0)
+        ct = orc.cluster(params, hb.contig_rank, source=0)
         t2 = time.perf_counter()
         st = orc.stats()
         best = dict(n_rec=n, used=st["n_rec_used"], n_sig=sig.n, t_collect=t1 - t0, t_cluster=t2 - t1, n_clusters=ct.n,
@@ -60,10 +66,13 @@ def cpu_baseline(batch, genome, params, eng=None, budget_s=20.0):
     if eng is not None:
         # the same slice through the HIP path (host batch this time): the bench line carries its own parity evidence
         gs, _ = eng.collect(hb, params)
-        gc = eng.cluster(params, np.zeros(1, np.int32), source=0)
+        gc = eng.cluster(params, hb.contig_rank, source=0)
         parity = {"records": best["n_rec"], "signatures_identical": gs.first_difference(sig) is None,
                   "clusters_identical": gc.first_difference(ct, rtol=1e-12) is None}
     return {"parity_vs_gpu_on_sample": parity, "value": best["used"] / t, "unit": "reads/s", "cores": 1, "kind": "port",
+            "what": "oracle/svx_oracle.c: single-threaded C restatement of the reference's algorithm (a STRONGER baseline than the "
+                    "reference's Python loops: tests/golden/g_c1.json.gz records 1.99 s + 4.75 s of reference Python for 10 k records; "
+                    "the reference itself cannot travel to the GPU box)",
             "sample": "first %d records of the same batch (coordinate order): %d reads used, %d signatures, %d clusters; "
                       "collect %.2f s + cluster %.2f s on 1 host core (of %d)" % (
                           best["n_rec"], best["used"], best["n_sig"], best["n_clusters"], best["t_collect"], best["t_cluster"],
@@ -73,16 +82,30 @@ def cpu_baseline(batch, genome, params, eng=None, budget_s=20.0):
             "edit_cells_per_s": best["edit_cells"] / max(best["t_cluster"], 1e-9)}
 
 
+def load_profile_json(name):
+    try:
+        with open(os.path.join(REPO, "profiles", name)) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=("c1", "c2", "c4"), default="c1")
+    ap.add_argument("--scale", type=float, default=1.0, help="c2 / c4: scale of the contig lengths (reads and sites follow)")
+    ap.add_argument("--partition-max-distance", type=int, default=1000)
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--n50", type=int, default=20000)
     ap.add_argument("--contig-len", type=int, default=250_000_000)
     ap.add_argument("--sites", type=int, default=None)
+    ap.add_argument("--bam", default=None, help="coordinate-sorted BAM instead of a synthetic workload (needs --fasta)")
+    ap.add_argument("--fasta", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -103,28 +126,51 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from svim_amd import _abi, _lib, devsynth
-    p = _abi.Params.from_options(options())
+    opts = options(args.partition_max_distance)
+    p = _abi.Params.from_options(opts)
+    if args.bam:
+        from svim_amd import harness
+        out = harness.run_bam(args.bam, args.fasta, opts, rank=rank, world=world, device=local_rank, steps=args.steps, warmup=args.warmup)
+        if rank == 0:
+            print(json.dumps(out))
+        if use_dist:
+            dist.destroy_process_group()
+        return
     t0 = time.perf_counter()
-    batch, genome, meta = devsynth.make_batch(n_reads=args.reads, n50=args.n50, contig_len=args.contig_len, n_sites=args.sites,
-                                              seed=2 + rank, device=dev)
+    if args.workload == "c1":
+        batch, genome, meta = devsynth.make_batch(n_reads=args.reads, n50=args.n50, contig_len=args.contig_len, n_sites=args.sites,
+                                                  seed=2 + rank, device=dev)
+        g_off = torch.tensor([0, genome.numel()], dtype=torch.int64, device=dev)
+        label = "configs[1]: %d synthetic ONT reads per GPU (N50 %d), single %d Mb contig, DEL/INS/INV" % (
+            args.reads, args.n50, args.contig_len // 1_000_000)
+    else:
+        from svim_amd import workloads
+        prof = workloads.profile(args.workload, args.scale)
+        batch, genome, g_off, meta = workloads.make_batch_full(prof, seed=3 + rank, device=dev)
+        label = {"c2": "configs[2] stand-in: PacBio-HiFi profile (%d reads of 17.5 kb, %d contigs, %.0f Mb), full SV-type set incl. BND, "
+                       "DUP_TAN, DUP_INT and split-read INS (edit-distance path)",
+                 "c4": "configs[4] stand-in: 60x PacBio-CLR profile (%d reads, %d contig, %.0f Mb), dense sites, "
+                       "--partition_max_distance %d" % (meta["n_reads"], meta["n_contig"], meta["genome_bases"] / 1e6, args.partition_max_distance)
+                 }[args.workload]
+        if args.workload == "c2":
+            label = label % (meta["n_reads"], meta["n_contig"], meta["genome_bases"] / 1e6)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
     eng = _lib.Engine(local_rank)
     if use_dist:
         from svim_amd import distributed as D
-        g_off, g_all = D.all_gather_genomes(genome, dev)
-        eng.set_genome(g_off, g_all, on_device=True)
+        g_off_all, g_all = D.all_gather_genomes(genome, dev, g_off)
+        eng.set_genome(g_off_all, g_all, on_device=True)
     else:
-        g_off = torch.tensor([0, genome.numel()], dtype=torch.int64, device=dev)
         eng.set_genome(g_off, genome, on_device=True)
-    rank_arr = np.zeros(1, dtype=np.int32)
+    rank_arr = batch.t["contig_rank"].cpu().numpy().astype(np.int32)
     bstruct = batch.struct()
 
     def step():
         eng.collect(bstruct, p, fetch=False)
         if use_dist:
             from svim_amd import distributed as D
-            D.device_pipeline_step(eng, p, rank, world, dev)
+            D.device_pipeline_step(eng, p, rank, world, dev, n_contig=len(rank_arr), contig_rank=rank_arr)
         else:
             eng.cluster(p, rank_arr, source=0, fetch=False)
 
@@ -134,18 +180,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # the very first pass of a fresh context: includes every device allocation; the library keeps NO tuning state between calls
+    barrier()
+    f0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    first_step_ms = 1e3 * (time.perf_counter() - f0)
+    for _ in range(max(0, args.warmup - 1)):
         step()
     barrier()
     t0 = time.perf_counter()
-    per_step = []
+    acc = {}
     for _ in range(args.steps):
-        s0 = time.perf_counter()
         step()
-        per_step.append(time.perf_counter() - s0)
+        s = eng.stats()
+        for k, v in s.items():
+            acc[k] = acc.get(k, 0) + v
     barrier()
     elapsed = time.perf_counter() - t0
     st = eng.stats()
+    avg = {k: acc[k] / args.steps for k in acc}                       # per-step averages over the timed region (HIP events inside libsvx)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -163,48 +217,89 @@ def main():
     reads_per_s = tot_used * args.steps / elapsed
     # ---- roofline of the HBM-bound kernel (k_cigar_scan), algorithmic bytes per SURVEY.md section 8(d) ----
     n_ins = st["n_ins_bases"]
-    bytes_collect = 32 * st["n_rec_used"] + 4 * st["n_ops"] + 16 * st["n_seg"] + 4 * st["n_seg_ops"] + 32 * st["n_sig"] + n_ins // 2
-    scan_s = st["t_cigar_scan_ms"] * 1e-3
     scan_bytes = 32 * st["n_rec_used"] + 4 * st["n_ops"] + 16 * st["n_seg"] + 4 * st["n_seg_ops"] + 32 * st["n_sig"]
+    bytes_collect = scan_bytes + n_ins // 2
+    bytes_cluster = 36 * st["n_sig"] + 48 * st["n_clusters"] + st["n_hap_bytes"]
+    scan_s = avg["t_cigar_scan_ms"] * 1e-3
     achieved = scan_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
-    # HBM traffic of that kernel from the PMC counters (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction):
-    # measured once for the default workload and committed under profiles/; null for any other workload
+    # HBM traffic of that kernel from the PMC counters (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction): measured
+    # for the default workload and committed under profiles/ with the commit it was measured at; null for any other workload
     traffic = None
-    try:
-        with open(os.path.join(REPO, "profiles", "traffic_k_cigar_scan.json")) as fh:
-            tj = json.load(fh)
-        if tj.get("workload_cigar_ops") == meta["n_ops"]:
-            traffic = tj["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        traffic = None
+    tj = load_profile_json("traffic_k_cigar_scan.json")
+    if tj and tj.get("workload_cigar_ops") == meta["n_ops"]:
+        traffic = tj.get("traffic_bytes_per_launch")
     roofline = {"kernel": "k_cigar_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": traffic,
-                "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": st["t_cigar_scan_ms"]}
+                "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": (tj or {}).get("source"),
+                "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": avg["t_cigar_scan_ms"],
+                "whole_path": {"algorithmic_bytes_per_step": bytes_collect + bytes_cluster,
+                               "achieved_GBps": (bytes_collect + bytes_cluster) / (ms_per_step * 1e-3) / 1e9,
+                               "frac_of_hbm": (bytes_collect + bytes_cluster) / (ms_per_step * 1e-3) / 8e12,
+                               "note": "the path as a whole is integer-VALU bound in the edit-distance kernels: see roofline_edit"}}
+    # ---- roofline of the dominant kernels (k_edit_bands + k_edit_fulls): integer VALU issue ----
+    edit_s = avg["t_edit_ms"] * 1e-3
+    wc_issued, wc_useful = st.get("n_edit_wordcols_issued", 0), st.get("n_edit_wordcols_useful", 0)
+    roofline_edit = None
+    if edit_s > 0 and wc_issued:
+        instr = wc_issued / 64.0 * INSTR_PER_WORDCOL
+        pj = load_profile_json("pmc_edit_kernels.json")
+        roofline_edit = {
+            "kernels": "k_edit_bands<P> + k_edit_fulls<P> (all rounds; the window also holds pack/prep/sort/pilot)", "bound": "valu",
+            "seconds": edit_s, "word_columns_executed": wc_issued, "word_columns_useful": wc_useful,
+            "word_columns_retry_rounds": st.get("n_edit_wordcols_retry"), "retry_fraction": st.get("n_edit_wordcols_retry", 0) / wc_issued,
+            "cells_executed": wc_issued * 32, "cells_full_matrix": st["n_edit_cells"],
+            "wave_valu_instr_model": instr, "instr_per_word_column_model": INSTR_PER_WORDCOL,
+            "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave64 VALU instructions/s (1024 SIMD x 2.4 GHz / 2)",
+            "achieved": instr / edit_s, "frac": instr / edit_s / VALU_PEAK_WAVE_INSTR_PER_S,
+            "frac_issue_cycles": (wc_issued / 64.0 * CYCLES_PER_WORDCOL) / (edit_s * 1024 * 2.4e9),
+            "frac_useful_work_only": (wc_useful / 64.0 * CYCLES_PER_WORDCOL) / (edit_s * 1024 * 2.4e9),
+            "note": "frac counts 2 cycles per instruction; the update's instruction mix (v_bitop3 / v_alignbit / v_addc_co are half rate) "
+                    "needs 38 issue cycles per word-column: frac_issue_cycles prices exactly that",
+            "pmc": pj, "band_speculation_fraction": st.get("edit_guess"),
+            "gcups_executed": wc_issued * 32 / edit_s / 1e9, "gcups_full_matrix_equivalent": st["n_edit_cells"] / edit_s / 1e9,
+        }
     kernels = {
-        "k_cigar_scan_ms": st["t_cigar_scan_ms"], "k_segments_ms": st["t_segments_ms"], "collect_order_ms": st["t_sort_ms"],
-        "collect_gather_ms": st["t_gather_ms"], "collect_total_ms": st["t_collect_ms"],
-        "cluster_partition_sample_ms": st["t_partition_ms"], "cluster_edit_distance_ms": st["t_edit_ms"],
-        "cluster_linkage_ms": st["t_linkage_ms"], "cluster_total_ms": st["t_cluster_ms"],
-        "edit_distance_gcups": (st["n_edit_cells"] / (st["t_edit_ms"] * 1e-3) / 1e9) if st["t_edit_ms"] > 0 else None,
-        "edit_pairs": st["n_edit_pairs"], "edit_cells": st["n_edit_cells"], "pair_distances": st["n_pairs"],
-        "bytes_collect_model": bytes_collect,
+        "k_cigar_scan_ms": avg["t_cigar_scan_ms"], "k_segments_ms": avg["t_segments_ms"], "collect_order_ms": avg["t_sort_ms"],
+        "collect_gather_ms": avg["t_gather_ms"], "collect_total_ms": avg["t_collect_ms"],
+        "cluster_partition_sample_ms": avg["t_partition_ms"], "cluster_edit_distance_ms": avg["t_edit_ms"],
+        "cluster_linkage_ms": avg["t_linkage_ms"], "cluster_total_ms": avg["t_cluster_ms"],
+        "edit_pairs": st["n_edit_pairs"], "edit_cells_full_matrix": st["n_edit_cells"], "pair_distances": st["n_pairs"],
+        "bytes_collect_model": bytes_collect, "bytes_cluster_model": bytes_cluster,
+        "edit_wordcols_issued": wc_issued, "edit_wordcols_useful": wc_useful,
+        "edit_wordcols_retry_rounds": st.get("n_edit_wordcols_retry"), "edit_wordcols_band_kernels": st.get("n_edit_wordcols_band"),
+        "edit_guess": st.get("edit_guess"),
     }
+    cfg = {"workload": label, "records_per_gpu": meta["n_records"], "cigar_ops_per_gpu": meta["n_ops"], "planted_sites": meta["n_sites"],
+           "parallelism": "1 process/GPU, records sharded by contig, partitions owned by origin rank (svim_amd/distributed.py)",
+           "options": "SVIM alignment-mode defaults" + ("" if args.partition_max_distance == 1000 else ", partition_max_distance %d" % args.partition_max_distance)}
+    if "reads_by_layout" in meta:
+        cfg["reads_by_layout"] = meta["reads_by_layout"]
     out = {
         "metric": "aligned reads/sec through COLLECT+CLUSTER", "value": reads_per_s, "unit": "reads/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u32/i32 CIGAR + u8 bases, int64 positions, f64 distances", "data": "synthetic",
-        "config": {"workload": "configs[1]: %d synthetic ONT reads per GPU (N50 %d), single %d Mb contig, DEL/INS/INV"
-                               % (args.reads, args.n50, args.contig_len // 1_000_000),
-                   "records_per_gpu": meta["n_records"], "cigar_ops_per_gpu": meta["n_ops"], "planted_sites": meta["n_sites"],
-                   "parallelism": "1 process/GPU, records sharded, signature columns all-gathered, partitions owned by origin rank", "options": "SVIM alignment-mode defaults"},
+        "config": cfg,
         "signatures_per_s": tot_sig * args.steps / elapsed,
-        "signatures_per_s_cluster_only": st["n_sig"] / (st["t_cluster_ms"] * 1e-3) if st["t_cluster_ms"] > 0 else None,
+        "signatures_per_s_cluster_only": st["n_sig"] / (avg["t_cluster_ms"] * 1e-3) if avg["t_cluster_ms"] > 0 else None,
+        "first_step_ms": first_step_ms,
+        "first_step_note": "first pass of a fresh context (every device allocation included); libsvx keeps no tuning state between calls - "
+                           "the band speculation is chosen inside each call from a sample of its own pairs",
         "counts": {"reads_used": tot_used, "signatures": tot_sig, "cigar_ops": tot_ops, "partitions": st["n_partitions"],
                    "large_partitions": st["n_large_partitions"], "clusters": st["n_clusters"], "ins_bases": n_ins},
-        "roofline": roofline, "kernels": kernels, "synth_seconds": t_gen,
+        "roofline": roofline, "roofline_edit": roofline_edit, "kernels": kernels, "synth_seconds": t_gen,
     }
+    if world == 1 and not use_dist:
+        fetch = getattr(eng, "fetch_clusters", None)
+        if fetch is not None:
+            ct = eng.fetch_clusters()
+            out["counts"]["clusters_by_type"] = dict(zip(_abi.TYPE_NAMES, [int(x) for x in ct.type_count]))
+    if not args.no_end_to_end and world == 1 and not use_dist and args.workload == "c1":
+        try:
+            from svim_amd import harness
+            out["end_to_end"] = harness.end_to_end_sample(batch, g_off, genome, opts, device=local_rank, resident_reads_per_s=reads_per_s)
+        except Exception as e:                                          # the headline number must not depend on the e2e sample
+            out["end_to_end"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(batch, genome, p, eng)
+        out["cpu_baseline"] = cpu_baseline(batch, g_off, genome, p, eng)
         out["speedup_vs_cpu_port"] = reads_per_s / world / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     if use_dist:

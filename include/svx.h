@@ -145,6 +145,11 @@ typedef struct svx_stats {
     double  t_cigar_scan_ms, t_segments_ms, t_sort_ms, t_partition_ms, t_edit_ms, t_linkage_ms, t_gather_ms;
     int64_t n_rec_used, n_ops, n_seg, n_seg_ops, n_sig, n_bnd_side, n_ins_bases;
     int64_t n_partitions, n_large_partitions, n_pairs, n_edit_pairs, n_edit_cells, n_clusters, n_hap_bytes;
+    /* edit-distance work actually executed by the last svx_cluster: 32-bit word-columns (32 DP cells each) the waves issued (lock-step
+     * and padding included), the ones the pairs needed, the issued ones of retry rounds (>= 1) and of the band kernels; the band
+     * speculation fraction the call's pilot chose */
+    int64_t n_edit_wordcols_issued, n_edit_wordcols_useful, n_edit_wordcols_retry, n_edit_wordcols_band;
+    double  edit_guess;
 } svx_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */

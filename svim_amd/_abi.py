@@ -109,7 +109,9 @@ class Stats(C.Structure):
                                           "t_sort_ms", "t_partition_ms", "t_edit_ms", "t_linkage_ms", "t_gather_ms")] + \
                [(n, C.c_int64) for n in ("n_rec_used", "n_ops", "n_seg", "n_seg_ops", "n_sig", "n_bnd_side",
                                          "n_ins_bases", "n_partitions", "n_large_partitions", "n_pairs",
-                                         "n_edit_pairs", "n_edit_cells", "n_clusters", "n_hap_bytes")]
+                                         "n_edit_pairs", "n_edit_cells", "n_clusters", "n_hap_bytes",
+                                         "n_edit_wordcols_issued", "n_edit_wordcols_useful", "n_edit_wordcols_retry",
+                                         "n_edit_wordcols_band")] + [("edit_guess", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

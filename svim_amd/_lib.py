@@ -13,7 +13,7 @@ from . import _abi
 from ._abi import ClusterTable, SigTable, ptr
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libsvx.so")
+_LIB_PATH = os.environ.get("SVX_LIB") or os.path.join(_HERE, "libsvx.so")      # SVX_LIB: an experiment build (tools/build_variants.sh)
 _LIB = None
 _ENGINES = {}
 

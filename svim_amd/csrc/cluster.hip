@@ -955,6 +955,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     for (int t = 0; t < SVX_NTYPES; t++) out.type_count[t] = 0;
     svx_stats& S = c->stats;
     S.n_partitions = S.n_large_partitions = S.n_pairs = S.n_edit_pairs = S.n_edit_cells = S.n_clusters = S.n_hap_bytes = 0;
+    S.n_edit_wordcols_issued = S.n_edit_wordcols_useful = S.n_edit_wordcols_retry = S.n_edit_wordcols_band = 0; S.edit_guess = 0;
     S.t_cluster_ms = S.t_partition_ms = S.t_edit_ms = S.t_linkage_ms = 0;
     c->n_remote_members = 0;
     if (n == 0) return SVX_OK;

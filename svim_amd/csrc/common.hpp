@@ -136,10 +136,9 @@ struct svx_ctx {
     DevBuf shard_prefix;            // origin prefix (world+1 int64) for by-origin sharding
     int64_t n_remote_members = 0;   // members of owned INS partitions produced by another rank (by-origin mode)
     // Band speculation: a pair without a useful distance bound starts in the band sized for edit_guess * (core length) differences beyond
-    // the length gap.  0.125 on a context's first call; afterwards the value that would have been cheapest for the previous call's
-    // pairs (their divergence histogram, see run_edit_pipeline) - the batches of one input share an error profile.  Routing only:
-    // results never depend on it.  SVX_EDIT_GUESS=<fraction> pins it.
-    float edit_guess = 0.125f; bool edit_guess_pinned = false;
+    // the length gap.  Chosen per call from a sample of that call's own pairs (k_edit_pilot, edit.hip) - no state survives a call;
+    // 0.125 is only the fallback for calls too small to sample.  Routing only: results never depend on it.  SVX_EDIT_GUESS=<fraction> pins it.
+    float edit_guess = 0.125f; bool edit_guess_pinned = false; float edit_guess_last = 0.125f;
     DevBuf e_hist;
     bool edit_force_full = false;  // debugging aid (env SVX_EDIT_FORCE_FULL=1): every pair through the full-matrix kernel
     bool no_seq_gather = false;   // svx_cigar_indel hook: positions only

@@ -29,6 +29,7 @@
 // measured by tools/micro/valu_ops.hip, valu_dep.hip and column_rate.hip (v_alignbit, v_addc_co and every instruction reading three
 // different VGPRs are half rate; the column update costs 38 issue cycles per word-column and runs at 42-44 stand-alone).
 #include "common.hpp"
+#include <type_traits>
 
 struct EditWork { uint32_t a, b; long long slot; };
 
@@ -138,7 +139,10 @@ struct PairSource {
         return make_hap(g_off, g_codes, in.contig[r], st, in.seq + in.seq_off[r], (int)(in.seq_off[r + 1] - in.seq_off[r]), st - radius, st + radius);
     }
     // compute_haplotype_edit_distance (src/svim/SVIM_clustering.py:32-45): window = min/max start -+ 100
-    __device__ __forceinline__ void views(long long w, HapView& A, HapView& B) const {
+    // shift = |start_a - start_b|: the haplotype of the later insertion carries that many reference bases in FRONT of its inserted
+    // sequence which the other one carries BEHIND it, i.e. the alignment leaves the main diagonal by `shift` whatever the sequences are
+    __device__ __forceinline__ void views(long long w, HapView& A, HapView& B, int& shift) const {
+        shift = 0;
         if (plain) {
             const HapRec ra = rec[w], rb = rec[n_pairs + w];
             A.word_off = ra.word_off; A.off = 0; A.len = ra.len; A.flags = ra.flags;
@@ -147,6 +151,7 @@ struct PairSource {
             const EditWork wk = work[w];
             const long long s1 = in.start[wk.a], s2 = in.start[wk.b];
             const long long ws = (s1 < s2 ? s1 : s2) - 100, we = (s1 > s2 ? s1 : s2) + 100;
+            shift = (int)(s1 < s2 ? s2 - s1 : s1 - s2);
             const int c1 = in.contig[wk.a], c2 = in.contig[wk.b];
             const long long l1 = g_off[c1 + 1] - g_off[c1], l2 = g_off[c2 + 1] - g_off[c2];
             const HapRec ra = rec[wk.a], rb = rec[wk.b];
@@ -165,8 +170,10 @@ struct PairDesc {
     unsigned long long txt;     // same for the longer core
     int m, n;                   // core lengths, m <= n
     int ub;                     // upper bound of the distance known so far
-    int cls;                    // bits 0..7 next class to try, bit 8 CLS_GENERIC, bits 12..14 / 16..18 nibble of the first pattern / text symbol
+    int cls;                    // bits 0..7 next class to try, bit 8 CLS_GENERIC, bit 9 CLS_ZERO, bits 12..14 / 16..18 nibble of the first pattern / text symbol,
+                                // bits 20..30 the pair's position shift (clamped to 2047); -1 = answered by k_edit_prep
 };
+#define CLS_SHIFT(c) (((c) >> 20) & 2047)
 #define CLS_PAT_SH(c) ((((c) >> 12) & 7) << 2)
 #define CLS_TXT_SH(c) ((((c) >> 16) & 7) << 2)
 
@@ -176,11 +183,13 @@ __host__ __device__ __forceinline__ int band_words(int b) { return b <= 2 ? (1 <
 #define CLS_FULL 9            /* systolic full matrix, one wave per pair */
 #define CLS_LANE0 10          /* 10..14: whole pattern (<= 32<<k rows) in one lane, full matrix, never fails */
 #define CLS_WIDE0 15          /* 15..18: full matrix, 2/4/8/16 lanes per pair with 512 rows each (m <= 1024 / 2048 / 4096 / 8192) */
-#define N_CLASSES 19
+#define CLS_WIDE12 19         /* 19..22: the same with 384 rows (12 words) per lane (m <= 768 / 1536 / 3072 / 6144): halves the rows a pair pads up to */
+#define N_CLASSES 23
 #define MIN_MARGIN 16
 // A pair whose two cores hold only A/C/G/T (BAM codes 1,2,4,8) runs the 2-bit-plane kernels (P = 2); anything else (N, IUPAC codes,
 // the '=' filler) the generic 4-plane ones (P = 4).  PairDesc.cls bit 8 carries that flag; the sort class is flag*32 + class.
 #define CLS_GENERIC 0x100
+#define CLS_ZERO 0x200           /* a record of the pair holds code 0 ('='): full-matrix classes only (the band kernels use 0 as the never-matching filler) */
 #define GENERIC_BASE 32
 #define N_SORT_CLASSES 64
 __device__ __forceinline__ unsigned long long sort_class(int cls_with_flag) {
@@ -227,14 +236,36 @@ __device__ __forceinline__ unsigned long long work_key(int cls, int m, int n) {
 
 __device__ __forceinline__ int full_class_for(int m) {
     if (m <= 512) return CLS_LANE0 + lane_class_for(m);
-    if (m <= 1024) return CLS_WIDE0;
-    if (m <= 2048) return CLS_WIDE0 + 1;
-    if (m <= 4096) return CLS_WIDE0 + 2;
-    if (m <= 8192) return CLS_WIDE0 + 3;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#ifndef SVX_NO_WIDE12          /* experiment switch (tools/build_variants.sh) */
+        if (m <= (768 << k)) return CLS_WIDE12 + k;
+#endif
+        if (m <= (1024 << k)) return CLS_WIDE0 + k;
+    }
     return CLS_FULL;
 }
 
 #include "myers_column.hpp"
+
+// Work accounting for the roofline of the edit kernels (bench.py `roofline_edit`): 32-bit word-columns a wave EXECUTES (issued: every lane
+// pays for the longest text of its wave and for padded / idle state words) and the ones its pairs need (useful).  One atomic pair per
+// wave at its very end, 32 shards; wc == nullptr switches it off.
+#define WC_SHARDS 32
+__device__ __forceinline__ void wc_account(unsigned long long* wc, long long issued_wave, long long useful_lane) {
+    if (!wc) return;
+    const long long useful = wave_sum_i64(useful_lane);
+    if (lane_id() == 0) {
+        unsigned long long* w = wc + 2 * (blockIdx.x & (WC_SHARDS - 1));
+        atomicAdd(w, (unsigned long long)issued_wave);
+        atomicAdd(w + 1, (unsigned long long)useful);
+    }
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
 
 // ---- 1. packed store ---------------------------------------------------------------------------------------------
 __global__ void k_pair_span(long long n_work, PairSource src, unsigned long long* span) {           // max |start_a - start_b| over the work list
@@ -293,14 +324,15 @@ __global__ __launch_bounds__(256) void k_hap_pack(long long n_rec, PairSource sr
 // pairs in flight, not the symbols compared per step
 template <int G>
 __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource src, const uint32_t* packed, PairDesc* desc,
-                                                   uint64_t* sort_key, uint32_t* sort_val, int32_t* ed, unsigned long long* cells, int force_full, float guess_frac) {
+                                                   uint64_t* sort_key, uint32_t* sort_val, int32_t* ed, unsigned long long* cells) {
     const int wave_lane = lane_id();
     const int sg = wave_lane / G, lane = wave_lane % G;                   // sub-group of the wave / lane inside it
     const unsigned long long sg_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (sg * G);
     const long long w = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + sg;
     if (w >= n_work) return;
     HapView A, B;
-    src.views(w, A, B);
+    int shift;
+    src.views(w, A, B, shift);
     const uint32_t* wa = packed + A.word_off; const uint32_t* wb = packed + B.word_off;
     const int la = A.len, lb = B.len;
     const int mn = la < lb ? la : lb;
@@ -339,7 +371,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     const int p0 = P.off + pre, t0 = T.off + pre;                          // first core symbols inside their records
     pd.pat = P.word_off + (unsigned long long)(p0 >> 3);
     pd.txt = T.word_off + (unsigned long long)(t0 >> 3);
-    const int sh_bits = ((p0 & 7) << 12) | ((t0 & 7) << 16);
+    const int sh_bits = ((p0 & 7) << 12) | ((t0 & 7) << 16) | ((shift > 2047 ? 2047 : shift) << 20);
     if (pd.m == 0) {                                   // one core is empty: the distance is the other's length
         if (lane == 0) { ed[src.slot(w)] = pd.n; pd.ub = pd.n; pd.cls = -1; desc[w] = pd; sort_key[w] = 0xffull << 32; sort_val[w] = (uint32_t)w; }
         return;
@@ -360,31 +392,41 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     for (int o = G / 2; o >= 1; o >>= 1) ham_l += __shfl_xor(ham_l, o, 64);          // sum over the sub-group
     const int zero = (A.flags | B.flags) & HAP_ZERO, other = (A.flags | B.flags) & HAP_OTHER;      // of the whole records: conservative
     if (lane == 0) {
-        const int ub = ham_l + (pd.n - pd.m);
-        pd.ub = ub;
-        int cls;
-        if (force_full) cls = CLS_FULL;
-        else if (zero) cls = full_class_for(pd.m);                       // symbol '=' (code 0) is the band kernel's "never matches" filler
-        else {
-            // `guaranteed` cannot fail (the trivial alignments bound the distance); when that bound is useless (position jitter
-            // shifts the two cores against each other) start from a band sized for guess_frac * m differences and widen on failure.
-            const int guaranteed = band_class_for(need_window(pd.m, pd.n, ub));
-            int guess = 2 * MIN_MARGIN;
-            const int by_frac = (int)ceilf(guess_frac * (float)pd.m);
-            if (by_frac > guess) guess = by_frac;
-            int spec = band_class_for((pd.n - pd.m) + guess + 1);
-            if (spec == CLS_FULL && band_class_for((pd.n - pd.m) + 2 * MIN_MARGIN + 1) != CLS_FULL) spec = NBAND - 1;      // widest band before giving up on banding
-            cls = guaranteed <= spec ? guaranteed : spec;
-            // short patterns: the whole column fits one lane (k_edit_lane), nothing to speculate about
-            if (cls > 0 && cls < NBAND && pd.m <= 512 && (1 << lane_class_for(pd.m)) <= band_words(cls)) cls = CLS_LANE0 + lane_class_for(pd.m);
-            else if (cls == CLS_FULL) cls = full_class_for(pd.m);
-        }
-        pd.cls = cls | (other ? CLS_GENERIC : 0) | sh_bits;
+        pd.ub = ham_l + (pd.n - pd.m);
+        pd.cls = (other ? CLS_GENERIC : 0) | (zero ? CLS_ZERO : 0) | sh_bits;       // the class itself: k_edit_classify
         desc[w] = pd;
-        sort_key[w] = (sort_class(pd.cls) << 32) | work_key(cls, pd.m, pd.n);
-        sort_val[w] = (uint32_t)w;
         if (cells) atomicAdd(cells + (w & 1023), (unsigned long long)pd.m * (unsigned long long)pd.n);      // 1024 shards: no same-address pile-up
     }
+}
+
+// first class of every pair + its sort key (one thread per pair)
+__global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort_key, uint32_t* sort_val, int force_full, float guess_frac) {
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_work) return;
+    const PairDesc pd = desc[w];
+    if (pd.cls == -1) return;                               // empty core: answered by k_edit_prep, key already written
+    int cls;
+    if (force_full) cls = CLS_FULL;
+    else if (pd.cls & CLS_ZERO) cls = full_class_for(pd.m);
+    else {
+        // `guaranteed` cannot fail (the trivial alignments bound the distance); when that bound is useless (position jitter
+        // shifts the two cores against each other) start from a band sized for guess_frac * m differences and widen on failure.
+        const int guaranteed = band_class_for(need_window(pd.m, pd.n, pd.ub));
+        int guess = 2 * MIN_MARGIN;
+        const int by_frac = (int)ceilf(guess_frac * (float)pd.m);
+        if (by_frac > guess) guess = by_frac;
+        guess += 2 * CLS_SHIFT(pd.cls);                 // what the position shift alone costs (see PairSource::views)
+        int spec = band_class_for((pd.n - pd.m) + guess + 1);
+        if (spec == CLS_FULL && band_class_for((pd.n - pd.m) + 2 * MIN_MARGIN + 1) != CLS_FULL) spec = NBAND - 1;      // widest band before giving up on banding
+        cls = guaranteed <= spec ? guaranteed : spec;
+        // short patterns: the whole column fits one lane (k_edit_lane), nothing to speculate about
+        if (cls > 0 && cls < NBAND && pd.m <= 512 && (1 << lane_class_for(pd.m)) <= band_words(cls)) cls = CLS_LANE0 + lane_class_for(pd.m);
+        else if (cls == CLS_FULL) cls = full_class_for(pd.m);
+    }
+    const int flagged = cls | (pd.cls & ~0xff);
+    desc[w].cls = flagged;
+    sort_key[w] = (sort_class(flagged) << 32) | work_key(cls, pd.m, pd.n);
+    sort_val[w] = (uint32_t)w;
 }
 
 // a band kernel could not certify its result: d (a valid alignment cost, hence an upper bound) picks the next class
@@ -410,15 +452,10 @@ __device__ __forceinline__ void band_retry(const PairDesc& pd, uint32_t widx, in
 // ---- 3. banded lane-per-pair kernel -----------------------------------------------------------------------------
 // Window of W = 32*Q bits; bit b of column j <-> row (j - dmax) + b.  dmax = 7 (mod 8) so that the row entering at the
 // bottom of the window and the text symbol of the column sit at the same nibble phase of their packed words.
+// returns the cost d of the best path inside the window (an upper bound of the distance) and the window's margin: d is the exact
+// distance iff 0 <= floor((d - (n-m)) / 2) <= margin.  Every lane of the wave must call (uniform trip count); dead lanes pass live = false.
 template <int Q, int P>
-__device__ __forceinline__ void d_edit_band(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
-                                                   const long long* slot_of, int32_t* ed, unsigned long long* fail_cnt, uint32_t* fail_lists,
-                                                   long long fail_cap) {
-    const long long t = blk * 256 + threadIdx.x;
-    const bool live = t < count;
-    uint32_t widx = 0;
-    PairDesc pd; pd.m = 0; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
-    if (live) { widx = list[t]; pd = desc[widx]; }
+__device__ __forceinline__ int band_core(const bool live, const PairDesc& pd, const uint32_t* scratch, int& margin_out) {
     const int W = 32 * Q;
     const int m = pd.m, n = live ? pd.n : 0;
     // largest dmax <= (n-m) + floor((W-1-(n-m))/2) with dmax = 7 (mod 8)
@@ -510,7 +547,7 @@ __device__ __forceinline__ void d_edit_band(long long blk, long long count, cons
             }
         }
     }
-    if (!live) return;
+    margin_out = margin;
     // D[m][n] = D[top][n] + vertical deltas of rows top+1..m  (bits 1..margin)
     int d = S;
 #pragma unroll
@@ -522,9 +559,63 @@ __device__ __forceinline__ void d_edit_band(long long blk, long long count, cons
         if (q == 0) mask &= ~1u;
         d += __popc(pv[q] & mask) - __popc(mv[q] & mask);
     }
+    return d;
+}
+
+template <int Q, int P>
+__device__ __forceinline__ void d_edit_band(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
+                                                   const long long* slot_of, int32_t* ed, unsigned long long* fail_cnt, uint32_t* fail_lists,
+                                                   long long fail_cap, unsigned long long* wc) {
+    const long long t = blk * 256 + threadIdx.x;
+    const bool live = t < count;
+    uint32_t widx = 0;
+    PairDesc pd; pd.m = 0; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
+    if (live) { widx = list[t]; pd = desc[widx]; }
+    int margin;
+    const int d = band_core<Q, P>(live, pd, scratch, margin);
+    wc_account(wc, (long long)wave_max_i32(live ? pd.n : 0) * Q * 64, live ? (long long)pd.n * Q : 0);
+    if (!live) return;
+    const int m = pd.m, n = pd.n;
     const int x = (d - (n - m)) >> 1;                    // floor: d >= n-m always
     if (margin >= 0 && x >= 0 && x <= margin) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
     else band_retry(pd, widx, m, n, d, desc, fail_cnt, fail_lists, fail_cap);
+}
+
+// ---- 3'. pilot: how far apart are this call's pairs? -------------------------------------------------------------------------
+// A pair whose trivial alignments give no useful bound starts in a band sized for 2 * shift + guess_frac * (core length) differences
+// beyond the length gap (k_edit_classify): the position shift of the two insertions is known, how much their SEQUENCES differ is
+// not.  guess_frac is chosen per CALL from a strided sample of its own pairs: the 64-diagonal band kernel over the first <= 512
+// symbols of both cores gives each sampled pair's cost, minus the 2 * shift that leaving and re-joining the main diagonal costs
+// = its sequence divergence per symbol (beyond ~10 % only an upper bound, which is all the cost model needs), weighted by the core
+// length like the work it stands for.  No state is carried from one call to the next; routing only, results never depend on it.
+#define PILOT_MAX 16384
+#define PILOT_PREFIX 512
+__global__ __launch_bounds__(256) void k_edit_pilot(long long n_work, long long stride, const PairDesc* desc, const uint32_t* scratch, unsigned long long* hist) {
+    __shared__ unsigned long long h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const long long w = ((long long)blockIdx.x * 256 + threadIdx.x) * stride;
+    PairDesc pd; pd.m = 0; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
+    bool live = w < n_work;
+    int full_m = 0;
+    if (live) {
+        pd = desc[w];
+        full_m = pd.m;
+        // '=' is the band kernel's filler symbol; short cores do not speculate; a large shift does not fit the pilot's band
+        live = pd.cls != -1 && !(pd.cls & CLS_ZERO) && pd.m >= 128 && CLS_SHIFT(pd.cls) <= 12;
+        const int L = pd.m < PILOT_PREFIX ? pd.m : PILOT_PREFIX;
+        pd.m = L; pd.n = L;
+    }
+    int margin;
+    const int d = band_core<2, 4>(live, pd, scratch, margin);
+    if (live) {
+        long long b = (long long)(d - 2 * CLS_SHIFT(pd.cls)) * 256 / pd.m;
+        if (b < 0) b = 0;
+        if (b > 255) b = 255;
+        atomicAdd(&h[b], (unsigned long long)full_m);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(hist + threadIdx.x, h[threadIdx.x]);
 }
 
 // ---- 3a. banded lane-per-pair kernel, staircase window (classes 3, 4) ------------------------------------------------------
@@ -566,7 +657,7 @@ __device__ __attribute__((noinline)) void planes32(uint32_t w0, uint32_t w1, uin
 template <int Q, int P>
 __device__ __forceinline__ void d_edit_stair(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
                                              const long long* slot_of, int32_t* ed, unsigned long long* fail_cnt, uint32_t* fail_lists,
-                                             long long fail_cap) {
+                                             long long fail_cap, unsigned long long* wc) {
     const long long t = blk * 256 + threadIdx.x;
     const bool live = t < count;
     uint32_t widx = 0;
@@ -599,55 +690,74 @@ __device__ __forceinline__ void d_edit_stair(long long blk, long long count, con
     int nmax = n;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
-    uint32_t tw_next[4], pw_next[4];
+    // Columns are processed one packed text word (8 columns) per loop trip - the unrolled body of a whole 32-column block is 18-45 KB
+    // of code per class, which several classes resident on one CU pair do not keep in the instruction cache.  The pairs of a wave are
+    // sorted by text length, so all but the last few trips run without the per-column `j <= n` test (PRED = false).
+    int nmin = live ? n : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(nmin, o, 64); nmin = v < nmin ? v : nmin; }
+    if (nmin == 0x7fffffff) nmin = 0;
+    uint32_t tq[4], tw_next[4], pw_next[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        tw_next[i] = (live && i < txt_words) ? txt.word(i) : 0u;
+        tq[i] = (live && i < txt_words) ? txt.word(i) : 0u;
+        tw_next[i] = (live && 4 + i < txt_words) ? txt.word(4 + i) : 0u;
         pw_next[i] = pat_word(w0 + 4 * Q + i);
     }
-    for (int kb = 0; kb * 32 < nmax; kb++) {
-        uint32_t tw[4];
-        if (kb > 0 && kb * 32 < n) {
-            // the window drops 32 rows: word 0 leaves (its deltas move into `top`), a fresh word enters at the bottom
-            top += __popc(pv[0]) - __popc(mv[0]);
+    auto columns8 = [&](const uint32_t tword, const int j0, auto pred_tag) {
+        constexpr bool PRED = decltype(pred_tag)::value;
+        uint32_t tp[P];
+        planes8<P>(tword, tp);                                          // bit k of tp[b]: plane b of the word's k-th symbol
 #pragma unroll
-            for (int q = 0; q < Q - 1; q++) {
-                pv[q] = pv[q + 1]; mv[q] = mv[q + 1];
+        for (int k = 0; k < 8; k++) {
+            if (!PRED || j0 + k + 1 <= n) {
+                uint32_t nk[P];
 #pragma unroll
-                for (int b = 0; b < P; b++) pl[b][q] = pl[b][q + 1];
+                for (int b = 0; b < P; b++) nk[b] = ((tp[b] >> k) & 1u) - 1u;
+                top += 1;
+                unsigned carry = 0;
+                uint32_t ph_prev = 0x80000000u, mh_prev = 0u;          // the row above the window steps +1
+                MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
             }
-            pv[Q - 1] = 0xffffffffu; mv[Q - 1] = 0u;
-            uint32_t acc[P];
-            planes32<P>(pw_next[0], pw_next[1], pw_next[2], pw_next[3], acc);
-#pragma unroll
-            for (int b = 0; b < P; b++) pl[b][Q - 1] = acc[b];
         }
+    };
+#pragma unroll 1
+    for (int jb = 0; jb * 8 < nmax; jb++) {
+        if ((jb & 3) == 0 && jb > 0) {
+            const int kb = jb >> 2;
+            if (kb * 32 < n) {
+                // the window drops 32 rows: word 0 leaves (its deltas move into `top`), a fresh word enters at the bottom
+                top += __popc(pv[0]) - __popc(mv[0]);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            tw[i] = tw_next[i];
-            const int ti = 4 * (kb + 1) + i;
-            tw_next[i] = (live && ti < txt_words) ? txt.word(ti) : 0u;
-            pw_next[i] = pat_word(w0 + 4 * (kb + Q) + i);           // enters when the window drops into block kb + 1
-        }
+                for (int q = 0; q < Q - 1; q++) {
+                    pv[q] = pv[q + 1]; mv[q] = mv[q + 1];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint32_t tp[P];
-            planes8<P>(tw[i], tp);                                      // bit k of tp[b]: plane b of the word's k-th symbol
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int j = kb * 32 + i * 8 + k + 1;
-                if (j <= n) {
-                    uint32_t nk[P];
-#pragma unroll
-                    for (int b = 0; b < P; b++) nk[b] = ((tp[b] >> k) & 1u) - 1u;
-                    top += 1;
-                    unsigned carry = 0;
-                    uint32_t ph_prev = 0x80000000u, mh_prev = 0u;          // the row above the window steps +1
-                    MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
+                    for (int b = 0; b < P; b++) pl[b][q] = pl[b][q + 1];
                 }
+                pv[Q - 1] = 0xffffffffu; mv[Q - 1] = 0u;
+                uint32_t acc[P];
+                planes32<P>(pw_next[0], pw_next[1], pw_next[2], pw_next[3], acc);
+#pragma unroll
+                for (int b = 0; b < P; b++) pl[b][Q - 1] = acc[b];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                tq[i] = tw_next[i];
+                const int ti = 4 * (kb + 1) + i;
+                tw_next[i] = (live && ti < txt_words) ? txt.word(ti) : 0u;
+                pw_next[i] = pat_word(w0 + 4 * (kb + Q) + i);           // enters when the window drops into block kb + 1
             }
         }
+        const uint32_t tword = tq[0];
+        tq[0] = tq[1]; tq[1] = tq[2]; tq[2] = tq[3];
+#ifdef SVX_STAIR_PRED_ALWAYS    /* experiment switch (tools/build_variants.sh) */
+        if (false) {}
+#else
+        if (jb * 8 + 8 <= nmin) columns8(tword, jb * 8, std::false_type{});
+#endif
+        else columns8(tword, jb * 8, std::true_type{});
     }
+    wc_account(wc, (long long)nmax * Q * 64, (long long)n * Q);
     if (!live) return;
     // D[m][n] = D[row above the window][n] + vertical deltas of window bits 0 .. (m - first row of the last block)
     const int bm = m - (((n - 1) >> 5) * 32 - off);
@@ -686,7 +796,7 @@ __device__ __forceinline__ void planes32_at(const Packed& pk, int s, bool live, 
 
 template <int Q, int P>
 __device__ __forceinline__ void d_edit_lane(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
-                                            const long long* slot_of, int32_t* ed) {
+                                            const long long* slot_of, int32_t* ed, unsigned long long* wc) {
     const long long t = blk * 256 + threadIdx.x;
     const bool live = t < count;
     uint32_t widx = 0;
@@ -731,18 +841,19 @@ __device__ __forceinline__ void d_edit_lane(long long blk, long long count, cons
             }
         }
     }
+    wc_account(wc, (long long)nmax * Q * 64, (long long)n * Q);
     if (live) ed[slot_of ? slot_of[widx] : (long long)widx] = score;
 }
 
-// ---- 3c. full matrix, G lanes per pair, 512 rows (16 words) per lane --------------------------------------------------------
-// The column is ONE wide bit-vector spread over the first L = ceil(m/512) lanes of a group, bottom-aligned like above (row m is
+// ---- 3c. full matrix, G lanes per pair, 32 Q rows (Q = 16 or 12 words) per lane ------------------------------------------------
+// The column is ONE wide bit-vector spread over the first L = ceil(m / (32 Q)) lanes of a group, bottom-aligned like above (row m is
 // bit 31 of lane L-1's last word); lane g of a group works on text column t-g at step t and hands (symbol, adder carry,
 // pushed-out plus/minus bits) to lane g+1 through a DPP wave shift.  64/G pairs share a wave, every lane carries 16 words of
 // state, so the per-step overhead is amortised over 512 cells (the 1-block-per-lane systolic kernel pays it per 32 cells).
-template <int G, int P>
+template <int G, int Q, int P>
 __device__ __forceinline__ void d_edit_wide(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
-                                            const long long* slot_of, int32_t* ed) {
-    constexpr int Q = 16;
+                                            const long long* slot_of, int32_t* ed, unsigned long long* wc) {
+    constexpr int RL = 32 * Q;                               // rows per lane
     const int lane = lane_id();
     const int gl = lane & (G - 1);
     const long long t = (blk * 256 + threadIdx.x) / G;
@@ -752,9 +863,9 @@ __device__ __forceinline__ void d_edit_wide(long long blk, long long count, cons
     if (live) { widx = list[t]; pd = desc[widx]; }
     const int m = pd.m, n = live ? pd.n : 0;
     const Packed pat{scratch + pd.pat, CLS_PAT_SH(pd.cls)}, txt{scratch + pd.txt, CLS_TXT_SH(pd.cls)};
-    const int lanes_used = live ? (m + 511) / 512 : 0;
-    const int pad = lanes_used * 512 - m;                    // virtual rows above row 1 (all in lane 0)
-    const int bit_base = gl * 512;                           // first bit of this lane in the wide vector
+    const int lanes_used = live ? (m + RL - 1) / RL : 0;
+    const int pad = lanes_used * RL - m;                     // virtual rows above row 1 (all in lane 0)
+    const int bit_base = gl * RL;                            // first bit of this lane in the wide vector
     uint32_t pv[Q], mv[Q], pl[P][Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
@@ -799,6 +910,7 @@ __device__ __forceinline__ void d_edit_wide(long long blk, long long count, cons
             }
         }
     }
+    wc_account(wc, (long long)smax * Q * 64, (live && gl == 0) ? (long long)n * ((m + 31) >> 5) : 0);
     if (live && is_last) ed[slot_of ? slot_of[widx] : (long long)widx] = score;
 }
 
@@ -953,7 +1065,7 @@ __device__ int systolic_distance_big(const Packed& pat, int m, const Packed& txt
 // one wave per pair of the FULL class; pairs with more than 16384 rows are deferred to k_edit_full_big
 template <int P>
 __device__ __forceinline__ void d_edit_full(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
-                                                   const long long* slot_of, int32_t* ed, unsigned long long* n_big, uint32_t* big_list) {
+                                                   const long long* slot_of, int32_t* ed, unsigned long long* n_big, uint32_t* big_list, unsigned long long* wc) {
     const long long t = blk * 4 + (threadIdx.x >> 6);
     if (t >= count) return;
     const uint32_t widx = list[t];
@@ -966,6 +1078,10 @@ __device__ __forceinline__ void d_edit_full(long long blk, long long count, cons
     else if (nb <= 256) d = systolic_distance<4, P>(PP, pd.m, T, pd.n);
     else if (nb <= 512) d = systolic_distance<8, P>(PP, pd.m, T, pd.n);
     else { if (lane_id() == 0) { const unsigned long long i = atomicAdd(n_big, 1ull); big_list[i] = widx; } return; }
+    {
+        const int R = nb <= 64 ? 1 : nb <= 128 ? 2 : nb <= 256 ? 4 : 8;
+        wc_account(wc, (long long)(pd.n + (nb + R - 1) / R - 1) * R * 64, lane_id() == 0 ? (long long)pd.n * nb : 0);
+    }
     if (lane_id() == 0) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
 }
 
@@ -974,7 +1090,7 @@ __device__ __forceinline__ void d_edit_full(long long blk, long long count, cons
 // small or its last waves drag on (and the runtime multiplexes streams onto a handful of hardware queues), so a round is TWO
 // launches: every band class in one grid, every full-matrix class in another.  Segments are laid out costliest first; a block
 // looks up its segment (uniform, scalar) and runs that class's routine.
-#define SEG_MAX 10
+#define SEG_MAX 14
 struct FusedTab {
     int n;
     int kind[SEG_MAX];                     // class id (0..13)
@@ -985,42 +1101,46 @@ struct FusedTab {
 template <int P>
 __global__ __launch_bounds__(256) void k_edit_bands(FusedTab tab, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
                                                     const long long* slot_of, int32_t* ed, unsigned long long* fail_cnt, uint32_t* fail_lists,
-                                                    long long fail_cap) {
+                                                    long long fail_cap, unsigned long long* wc) {
     int s = 0;
     while (s + 1 < tab.n && blockIdx.x >= tab.first_block[s + 1]) s++;
     const long long blk = (long long)(blockIdx.x - tab.first_block[s]);
     const uint32_t* l = list + tab.lo[s];
     switch (tab.kind[s]) {
-        case 0: d_edit_band<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
-        case 1: d_edit_band<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
-        case 2: d_edit_band<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
-        case 3: d_edit_stair<6, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
-        case 4: d_edit_stair<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
-        case 5: d_edit_stair<10, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
-        case 6: d_edit_stair<12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
-        case 7: d_edit_stair<14, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
-        default: d_edit_stair<16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap); break;
+        case 0: d_edit_band<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
+        case 1: d_edit_band<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
+        case 2: d_edit_band<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
+        case 3: d_edit_stair<6, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
+        case 4: d_edit_stair<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
+        case 5: d_edit_stair<10, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
+        case 6: d_edit_stair<12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
+        case 7: d_edit_stair<14, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
+        default: d_edit_stair<16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
     }
 }
 
 template <int P>
 __global__ __launch_bounds__(256) void k_edit_fulls(FusedTab tab, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
-                                                    const long long* slot_of, int32_t* ed, unsigned long long* n_big, uint32_t* big_list) {
+                                                    const long long* slot_of, int32_t* ed, unsigned long long* n_big, uint32_t* big_list, unsigned long long* wc) {
     int s = 0;
     while (s + 1 < tab.n && blockIdx.x >= tab.first_block[s + 1]) s++;
     const long long blk = (long long)(blockIdx.x - tab.first_block[s]);
     const uint32_t* l = list + tab.lo[s];
     switch (tab.kind[s]) {
-        case CLS_FULL: d_edit_full<P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, n_big, big_list); break;
-        case CLS_LANE0: d_edit_lane<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
-        case CLS_LANE0 + 1: d_edit_lane<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
-        case CLS_LANE0 + 2: d_edit_lane<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
-        case CLS_LANE0 + 3: d_edit_lane<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
-        case CLS_LANE0 + 4: d_edit_lane<16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
-        case CLS_WIDE0: d_edit_wide<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
-        case CLS_WIDE0 + 1: d_edit_wide<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
-        case CLS_WIDE0 + 2: d_edit_wide<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
-        default: d_edit_wide<16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed); break;
+        case CLS_FULL: d_edit_full<P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, n_big, big_list, wc); break;
+        case CLS_LANE0: d_edit_lane<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_LANE0 + 1: d_edit_lane<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_LANE0 + 2: d_edit_lane<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_LANE0 + 3: d_edit_lane<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_LANE0 + 4: d_edit_lane<16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE0: d_edit_wide<2, 16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE0 + 1: d_edit_wide<4, 16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE0 + 2: d_edit_wide<8, 16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE0 + 3: d_edit_wide<16, 16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE12: d_edit_wide<2, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE12 + 1: d_edit_wide<4, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE12 + 2: d_edit_wide<8, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        default: d_edit_wide<16, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
     }
 }
 
@@ -1060,7 +1180,7 @@ __global__ __launch_bounds__(256) void k_edit_hist(long long n_work, const PairD
     for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < n_work; w += (long long)gridDim.x * 256) {
         const PairDesc pd = desc[w];
         if (pd.m < 128) continue;
-        const long long x = (long long)ed[slot_of[w]] - (pd.n - pd.m);
+        const long long x = (long long)ed[slot_of[w]] - (pd.n - pd.m) - 2 * CLS_SHIFT(pd.cls);
         long long b = x * 256 / pd.m;
         if (b < 0) b = 0;
         if (b > 255) b = 255;
@@ -1088,6 +1208,7 @@ static void profile_round(svx_ctx* c, int round, const long long* seg_lo, const 
         int words = 0, per_wave = 64;                       // 32-bit words of column state per pair; pairs per wave
         if (cls < NBAND) words = band_words(cls);
         else if (cls >= CLS_LANE0 && cls < CLS_WIDE0) words = 1 << (cls - CLS_LANE0);
+        else if (cls >= CLS_WIDE12) { words = 12 * (2 << (cls - CLS_WIDE12)); per_wave = 64 / (2 << (cls - CLS_WIDE12)); }
         else if (cls >= CLS_WIDE0) { words = 16 * (2 << (cls - CLS_WIDE0)); per_wave = 64 / (2 << (cls - CLS_WIDE0)); }
         double useful = 0, issued = 0, sum_m = 0, sum_n = 0;
         for (long long i = 0; i < cn; i += per_wave) {
@@ -1107,6 +1228,25 @@ static void profile_round(svx_ctx* c, int round, const long long* seg_lo, const 
 
 #define MAX_ROUNDS 8
 
+// the speculation fraction g with the least expected cost over a (core-length weighted) divergence histogram of 256 bins:
+// the first band costs ~g per cell column; a pair beyond g retries at 2g, 4g, ... (a band wider than half the core is a full matrix, ~0.75)
+static float guess_from_histogram(const unsigned long long* h, float fallback) {
+    double total = 0, best_cost = 1e300;
+    double cum[257];
+    cum[0] = 0;
+    for (int b = 0; b < 256; b++) { total += (double)h[b]; cum[b + 1] = total; }
+    if (total <= 0) return fallback;
+    auto beyond = [&](double g) { int b = (int)(g * 256.0); if (b > 256) b = 256; return 1.0 - cum[b] / total; };
+    int best = 31;
+    for (int b = 3; b < 128; b++) {
+        const double g = (b + 1) / 256.0;
+        double cost = g;
+        for (double w = g; w < 1.0; w *= 2) cost += (2 * w <= 0.5 ? 2 * w : 0.75) * beyond(w);
+        if (cost < best_cost) { best_cost = cost; best = b; }
+    }
+    return (float)((best + 2) / 256.0);
+}
+
 static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src_in, int32_t* ed_dev, unsigned long long* cells_dev) {
     if (n_work <= 0) return SVX_OK;
     if (n_work >= (1ll << 32)) return svx_fail(SVX_E_ARG, "more than 2^32 edit-distance pairs in one call", __FILE__, __LINE__, hipSuccess);
@@ -1114,9 +1254,10 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     const int T = 256;
     PairSource src = src_in;
     src.n_pairs = n_work;
-    SVXCHK(c->e_fail.reserve((size_t)(128 + MAX_ROUNDS * N_SORT_CLASSES) * 8));
-    unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..40] class bounds of round 0 (first [16..31] the span shards), [128 + 64 r ..] retry counters written by round r
-    HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(128 + MAX_ROUNDS * N_SORT_CLASSES) * 8, st));
+    const size_t WC_OFF = 128 + MAX_ROUNDS * N_SORT_CLASSES, WC_PER_LAUNCH = 2 * WC_SHARDS, CNT_WORDS = WC_OFF + MAX_ROUNDS * 2 * WC_PER_LAUNCH;
+    SVXCHK(c->e_fail.reserve(CNT_WORDS * 8));
+    unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..40] class bounds of round 0 (first [16..31] the span shards), [128 + 64 r ..] retry counters written by round r, [WC_OFF ..] word-column counters per (round, kind)
+    HIPCHK(hipMemsetAsync(cnt, 0, CNT_WORDS * 8, st));
     // 1. packed store: one record per string / signature
     src.radius = 0;
     if (!src.plain) {
@@ -1153,7 +1294,24 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     c->stats.n_hap_bytes += total_words * 4;
     // 2. trim + classify
     k_slots<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, src, slot_of);
-    k_edit_prep<PREP_LANES><<<(unsigned)((n_work + 4 * (64 / PREP_LANES) - 1) / (4 * (64 / PREP_LANES))), 256, 0, st>>>(n_work, src, scratch, desc, key_a, val_a, ed_dev, cells_dev, c->edit_force_full ? 1 : 0, c->edit_guess);
+    k_edit_prep<PREP_LANES><<<(unsigned)((n_work + 4 * (64 / PREP_LANES) - 1) / (4 * (64 / PREP_LANES))), 256, 0, st>>>(n_work, src, scratch, desc, key_a, val_a, ed_dev, cells_dev);
+    HIPCHK(hipGetLastError());
+    const bool profile = getenv("SVX_EDIT_PROFILE") != nullptr, serial = getenv("SVX_EDIT_SERIAL") != nullptr;
+    // 2a. band speculation of THIS call from a strided sample of its own pairs (k_edit_pilot); SVX_EDIT_GUESS pins it instead
+    float guess = c->edit_guess;
+    if (!c->edit_guess_pinned && !c->edit_force_full && n_work >= 4096) {
+        SVXCHK(c->e_hist.reserve(256 * 8));
+        HIPCHK(hipMemsetAsync(c->e_hist.p, 0, 256 * 8, st));
+        const long long stride = (n_work + PILOT_MAX - 1) / PILOT_MAX, n_samp = (n_work + stride - 1) / stride;
+        k_edit_pilot<<<(unsigned)((n_samp + 255) / 256), 256, 0, st>>>(n_work, stride, desc, scratch, c->e_hist.as<unsigned long long>());
+        unsigned long long h[256];
+        HIPCHK(hipMemcpyAsync(h, c->e_hist.p, sizeof h, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        guess = guess_from_histogram(h, guess);
+        c->edit_guess_last = guess;
+        if (profile) fprintf(stderr, "{\"edit_guess_pilot\": %.4f, \"sampled_pairs\": %lld}\n", guess, n_samp);
+    }
+    k_edit_classify<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, desc, key_a, val_a, c->edit_force_full ? 1 : 0, guess);
     HIPCHK(hipGetLastError());
     // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
     SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, 40));
@@ -1168,7 +1326,6 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     // that would queue behind the long-running waves - so the retry rounds overlap the full-matrix work of the earlier ones.
     hipStream_t band_st[2] = {c->aux[0], c->aux[1]};     // A/C/G/T-only pairs, generic pairs
     hipStream_t full_st[2] = {c->aux[2], c->aux[3]};     // even / odd rounds
-    const bool profile = getenv("SVX_EDIT_PROFILE") != nullptr, serial = getenv("SVX_EDIT_SERIAL") != nullptr;
     long long seg_lo[N_SORT_CLASSES], seg_cn[N_SORT_CLASSES];
     long long pending = 0;
     for (int sc = 0; sc < N_SORT_CLASSES; sc++) { seg_lo[sc] = bounds[sc]; seg_cn[sc] = bounds[sc + 1] - bounds[sc]; pending += seg_cn[sc]; }
@@ -1182,6 +1339,8 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         if (round >= 2) HIPCHK(hipStreamSynchronize(full_st[round & 1]));
         SVXCHK(fb.reserve((size_t)N_SORT_CLASSES * (size_t)pending * 4 + 64));
         unsigned long long* fail_cnt = cnt + 128 + (size_t)round * N_SORT_CLASSES;
+        unsigned long long* wc_band = cnt + WC_OFF + (size_t)(round * 2) * WC_PER_LAUNCH;
+        unsigned long long* wc_full = wc_band + WC_PER_LAUNCH;
         bool band_used[2] = {false, false};
         for (int generic = 0; generic <= 1; generic++) {
             const int base = GENERIC_BASE * generic;
@@ -1196,33 +1355,46 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             tb.first_block[tb.n] = nblk;
             if (tb.n) {
                 band_used[generic] = true;
-                if (generic) k_edit_bands<4><<<nblk, T, 0, band_st[1]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending);
-                else k_edit_bands<2><<<nblk, T, 0, band_st[0]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending);
+                if (serial) HIPCHK(hipEventRecord(c->ev[6], band_st[generic]));
+                if (generic) k_edit_bands<4><<<nblk, T, 0, band_st[1]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
+                else k_edit_bands<2><<<nblk, T, 0, band_st[0]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
                 HIPCHK(hipGetLastError());
+                if (serial) {                                                        // SVX_EDIT_SERIAL=1: stand-alone kernel durations for profiling
+                    HIPCHK(hipEventRecord(c->ev[7], band_st[generic]));
+                    HIPCHK(hipStreamSynchronize(band_st[generic]));
+                    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
+                    fprintf(stderr, "{\"edit_launch\": {\"round\": %d, \"kind\": \"bands\", \"generic\": %d, \"blocks\": %u, \"ms\": %.4f}}\n", round, generic, nblk, ms);
+                }
             }
-            if (serial && tb.n) HIPCHK(hipStreamSynchronize(band_st[generic]));      // SVX_EDIT_SERIAL=1: stand-alone kernel durations for profiling
             FusedTab tf; memset(&tf, 0, sizeof tf);
             nblk = 0;
             // longest serial chains first: systolic (one wave per pair), 8/4/2 lanes per pair, then the lane classes
-            static const int order[10] = {CLS_FULL, CLS_WIDE0 + 3, CLS_WIDE0 + 2, CLS_WIDE0 + 1, CLS_WIDE0, CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};
-            for (int k = 0; k < 10; k++) {
+            static const int order[14] = {CLS_FULL, CLS_WIDE0 + 3, CLS_WIDE12 + 3, CLS_WIDE0 + 2, CLS_WIDE12 + 2, CLS_WIDE0 + 1, CLS_WIDE12 + 1, CLS_WIDE0, CLS_WIDE12,
+                                          CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};
+            for (int k = 0; k < 14; k++) {
                 const int cls = order[k];
                 const long long cn = seg_cn[base + cls];
                 if (cn <= 0) continue;
                 long long threads = cn;
-                if (cls == CLS_FULL) threads = cn * 64; else if (cls >= CLS_WIDE0) threads = cn * (2 << (cls - CLS_WIDE0));
+                if (cls == CLS_FULL) threads = cn * 64; else if (cls >= CLS_WIDE12) threads = cn * (2 << (cls - CLS_WIDE12)); else if (cls >= CLS_WIDE0) threads = cn * (2 << (cls - CLS_WIDE0));
                 tf.kind[tf.n] = cls; tf.lo[tf.n] = seg_lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
                 nblk += (unsigned)((threads + T - 1) / T); tf.n++;
             }
             tf.first_block[tf.n] = nblk;
             if (tf.n) {
                 hipStream_t fs = full_st[round & 1];
-                if (generic) k_edit_fulls<4><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
-                else k_edit_fulls<2><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>());
+                if (serial) HIPCHK(hipEventRecord(c->ev[6], fs));
+                if (generic) k_edit_fulls<4><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc_full);
+                else k_edit_fulls<2><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc_full);
                 HIPCHK(hipGetLastError());
+                if (serial) {
+                    HIPCHK(hipEventRecord(c->ev[7], fs));
+                    HIPCHK(hipStreamSynchronize(fs));
+                    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
+                    fprintf(stderr, "{\"edit_launch\": {\"round\": %d, \"kind\": \"fulls\", \"generic\": %d, \"blocks\": %u, \"ms\": %.4f}}\n", round, generic, nblk, ms);
+                }
             }
         }
-        if (serial) HIPCHK(hipStreamSynchronize(full_st[round & 1]));
         // only the band launches can hand pairs to the next round
         const long long cap = pending;
         pending = 0;
@@ -1238,9 +1410,20 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     }
     for (int k = 0; k < 2; k++) HIPCHK(hipStreamSynchronize(full_st[k]));
     {
+        std::vector<unsigned long long> wch((size_t)MAX_ROUNDS * 2 * WC_PER_LAUNCH);
         unsigned long long nb = 0;
         HIPCHK(hipMemcpyAsync(&nb, cnt + 1, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(wch.data(), cnt + WC_OFF, wch.size() * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        for (int r = 0; r < MAX_ROUNDS; r++)
+            for (int k = 0; k < 2; k++)
+                for (int sh = 0; sh < WC_SHARDS; sh++) {
+                    const unsigned long long iss = wch[((size_t)(r * 2 + k)) * WC_PER_LAUNCH + 2 * sh], use = wch[((size_t)(r * 2 + k)) * WC_PER_LAUNCH + 2 * sh + 1];
+                    c->stats.n_edit_wordcols_issued += (int64_t)iss; c->stats.n_edit_wordcols_useful += (int64_t)use;
+                    if (r > 0) c->stats.n_edit_wordcols_retry += (int64_t)iss;
+                    if (k == 0) c->stats.n_edit_wordcols_band += (int64_t)iss;
+                }
+        c->stats.edit_guess = guess;
         if (nb) {
             // rare: shorter core > 16384 symbols.  Size the block-state scratch exactly from the core lengths.
             const long long nbig = (long long)nb;
@@ -1261,37 +1444,19 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             HIPCHK(hipStreamSynchronize(st));
         }
     }
-    if (!c->edit_guess_pinned && n_work >= 4096) {
-        // calibrate the next call's band speculation: the fraction g with the least expected cost over this call's (core-length weighted) pairs
+    if (profile && n_work >= 4096) {
+        // the divergence histogram of the exact distances, next to what the pilot guessed from its sample
         SVXCHK(c->e_hist.reserve(256 * 8));
         HIPCHK(hipMemsetAsync(c->e_hist.p, 0, 256 * 8, st));
         k_edit_hist<<<(unsigned)(c->n_cu * 2), 256, 0, st>>>(n_work, desc, slot_of, ed_dev, c->e_hist.as<unsigned long long>());
         unsigned long long h[256];
         HIPCHK(hipMemcpyAsync(h, c->e_hist.p, sizeof h, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        double total = 0, best_cost = 1e300;
-        double cum[257];
-        cum[0] = 0;
-        for (int b = 0; b < 256; b++) { total += (double)h[b]; cum[b + 1] = total; }
-        if (total > 0) {
-            // expected relative cost of starting at fraction g: the first band costs ~g per cell column; a pair beyond g retries at 2g, 4g, ...
-            // (a band wider than half the core is a full matrix, ~0.75)
-            auto beyond = [&](double g) { int b = (int)(g * 256.0); if (b > 256) b = 256; return 1.0 - cum[b] / total; };
-            int best = 31;
-            for (int b = 3; b < 128; b++) {
-                const double g = (b + 1) / 256.0;
-                double cost = g;
-                for (double w = g; w < 1.0; w *= 2) cost += (2 * w <= 0.5 ? 2 * w : 0.75) * beyond(w);
-                if (cost < best_cost) { best_cost = cost; best = b; }
-            }
-            c->edit_guess = (float)((best + 2) / 256.0);
-            if (profile) {
-                double acc = 0;
-                fprintf(stderr, "{\"edit_guess\": %.4f, \"cum_weight_by_bin\": [", c->edit_guess);
-                for (int b = 0; b < 256; b++) { acc += (double)h[b]; if (b % 8 == 7) fprintf(stderr, "%.3f%s", acc / total, b == 255 ? "" : ", "); }
-                fprintf(stderr, "]}\n");
-            }
-        }
+        double total = 0, acc = 0;
+        for (int b = 0; b < 256; b++) total += (double)h[b];
+        fprintf(stderr, "{\"edit_guess_used\": %.4f, \"edit_guess_exact_histogram\": %.4f, \"cum_weight_by_bin\": [", guess, guess_from_histogram(h, guess));
+        for (int b = 0; b < 256; b++) { acc += (double)h[b]; if (b % 8 == 7) fprintf(stderr, "%.3f%s", total > 0 ? acc / total : 0.0, b == 255 ? "" : ", "); }
+        fprintf(stderr, "]}\n");
     }
     return SVX_OK;
 }

@@ -65,7 +65,7 @@ class DeviceBatch(object):
         hb = HostBatch()
         t = self.t
         hb.n_rec = hi - lo
-        hb.references = ["chr1"]
+        hb.references = list(getattr(self, "references", None) or ["chr1"])
         A = hb.arrays
         for k in ("flag", "tid", "pos", "mapq", "lseq", "read_id", "order", "seg_order"):
             A[k] = t[k][lo:hi].cpu().numpy().copy()
@@ -88,7 +88,7 @@ class DeviceBatch(object):
             v = t[k][s0:s1].cpu().numpy().copy()
             A[k] = v if v.size else np.zeros(1, dtype=v.dtype)
         A["seg_cigar_off"], A["seg_cigar"] = cut("seg_cigar_off", "seg_cigar", s0, s1, np.uint64)
-        A["contig_rank"] = np.zeros(1, dtype=np.int32)
+        A["contig_rank"] = t["contig_rank"].cpu().numpy().astype(np.int32).copy()
         hb.read_names = None
         return hb
 

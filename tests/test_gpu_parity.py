@@ -451,9 +451,25 @@ def test_shard_by_origin_two_virtual_ranks(eng, oracle):
     assert merged.first_difference(full) is None
 
 
+def test_edit_distance_full_matrix_classes_vs_oracle(eng, oracle):
+    """Unrelated pairs at every row-count boundary of the full-matrix classes (one lane <= 512 rows; 2/4/8/16 lanes of 12 or 16
+    words; systolic beyond 8192), short and long texts."""
+    rng = random.Random(17)
+    pairs = []
+    for m in (1, 31, 32, 33, 64, 65, 128, 129, 256, 257, 511, 512, 513, 700, 768, 769, 1000, 1024, 1025, 1500, 1536, 1537, 2048, 2049,
+              3000, 3072, 3073, 4096, 4097, 6000, 6144, 6145, 8192, 8193):
+        for extra in (0, 3, 700):
+            a = synth.random_seq(rng, m)
+            b = synth.random_seq(rng, m + extra)
+            pairs.append((a, b) if rng.random() < 0.5 else (b, a))
+    got = eng.edit_distances(pairs)
+    exp = [oracle.edit_distance(a, b) for a, b in pairs]
+    assert got == exp
+
+
 def test_edit_distance_routes_do_not_change_results(oracle, monkeypatch):
-    """The band speculation (SVX_EDIT_GUESS pinned tiny / huge, or learned from the previous call) and the forced full-matrix
-    route are performance choices only: every route must return the oracle's distances."""
+    """The band speculation (SVX_EDIT_GUESS pinned tiny / huge, or chosen by the per-call pilot from a sample of the call's own
+    pairs) and the forced full-matrix route are performance choices only: every route must return the oracle's distances."""
     from svim_amd._lib import Engine
     rng = random.Random(5)
     pairs = []
@@ -486,7 +502,7 @@ def test_edit_distance_routes_do_not_change_results(oracle, monkeypatch):
         e = Engine()
         try:
             first = e.edit_distances(pairs)
-            second = e.edit_distances(pairs)       # without a pin the second call runs with the guess learned from the first
+            second = e.edit_distances(pairs)       # a context carries no speculation state from call to call
         finally:
             e.close()
         assert first == second
