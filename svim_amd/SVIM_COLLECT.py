@@ -2,12 +2,16 @@
 
     sv_signatures, translocation_signatures_all_bnds = analyze_alignment_file_coordsorted(bam, options)
 
+Both results are svim_amd.lazy.SignatureList: list-like views of the signature tables that build the Signature objects on first
+access (cluster_sv_signatures takes them without building any).
+
 `bam` may be a path, our svim_amd.records.AlignmentFile, or any object with pysam's
 fetch(until_eof=True) / get_tid / references (records need the pysam attribute names).
 """
 import logging
 
 from . import _abi, _lib, batch, convert, records
+from .lazy import SignatureList
 from .SVIM_intra import analyze_alignment_indel          # noqa: F401  (re-exported like the reference module)
 from .SVIM_inter import analyze_read_segments            # noqa: F401
 
@@ -87,10 +91,13 @@ def _run_native(path, options, mode, batch_records=2000000):
         bnds.append(t)
     names = bam.read_names()
     refs = bam.references
-    sig = concat_sig_tables(sigs) if sigs else _abi.SigTable(0)
-    bnd = concat_sig_tables(bnds) if bnds else _abi.SigTable(0)
+    single = len(sigs) == 1
+    sig = (sigs[0] if single else concat_sig_tables(sigs)) if sigs else _abi.SigTable(0)
+    bnd = (bnds[0] if single else concat_sig_tables(bnds)) if bnds else _abi.SigTable(0)
     bam.close()
-    return convert.objects_from_sigtable(sig, refs, names), convert.objects_from_sigtable(bnd, refs, names)
+    # one batch: the device still holds exactly these tables (CLUSTER can start from them without an upload)
+    return (SignatureList(sig, refs, names, origin=(eng, eng.collect_generation, 0) if single else None),
+            SignatureList(bnd, refs, names, origin=(eng, eng.collect_generation, 1) if single else None))
 
 
 def _run(bam, options, mode):
@@ -99,10 +106,11 @@ def _run(bam, options, mode):
     bam = _open(bam)
     hb = batch.build_batch(bam, options, mode=mode)
     logging.info("Processed read {0}".format(hb.n_rec))
-    sig, bnd = _lib.engine().collect(hb, _abi.Params.from_options(options))
+    eng = _lib.engine()
+    sig, bnd = eng.collect(hb, _abi.Params.from_options(options))
     refs = hb.references
-    return (convert.objects_from_sigtable(sig, refs, hb.read_names),
-            convert.objects_from_sigtable(bnd, refs, hb.read_names))
+    return (SignatureList(sig, refs, hb.read_names, origin=(eng, eng.collect_generation, 0)),
+            SignatureList(bnd, refs, hb.read_names, origin=(eng, eng.collect_generation, 1)))
 
 
 def analyze_alignment_file_coordsorted(bam, options):

@@ -23,19 +23,34 @@ def _genome_for(engine, options, contigs):
 
 
 def _cluster_tables(signatures, options):
+    """-> (ClusterTable, contig names, the sequence cluster members index into)"""
+    from .lazy import SignatureList
     eng = _lib.engine()
+    p = _abi.Params.from_options(options)
+    if isinstance(signatures, SignatureList):
+        # a COLLECT result: its table is used as it is - no objects are built, and when the context still holds this very table
+        # (same engine, no svx_collect since) nothing is uploaded either
+        table, names = signatures.table, signatures.references
+        if bool((table.type[:table.n] == TYPE_CODE["INS"]).any()):
+            _genome_for(eng, options, names)
+        o = signatures.origin
+        if o is not None and o[0] is eng and o[1] == eng.collect_generation:
+            ct = eng.cluster(p, batch.contig_ranks(names), source=o[2])
+        else:
+            ct = eng.cluster(p, batch.contig_ranks(names), table=table)
+        return ct, names, signatures
+    signatures = list(signatures)
     table, contigs, reads = convert.sigtable_from_objects(signatures)
-    need_genome = bool((table.type == TYPE_CODE["INS"]).any())
-    if need_genome:
+    if bool((table.type == TYPE_CODE["INS"]).any()):
         _genome_for(eng, options, contigs.names)
-    ct = eng.cluster(_abi.Params.from_options(options), batch.contig_ranks(contigs.names), table=table)
-    return ct, contigs
+    ct = eng.cluster(p, batch.contig_ranks(contigs.names), table=table)
+    return ct, contigs.names, signatures
 
 
 def cluster_signature_lists(signatures, options):
-    """All six types in one device pass -> the reference's 6-tuple (DEL, INS, INV, DUP_TAN, DUP_INT, BND)."""
-    ct, contigs = _cluster_tables(signatures, options)
-    return convert.cluster_objects(ct, signatures, contigs.names)
+    """All six types in one device pass -> the reference's 6-tuple (DEL, INS, INV, DUP_TAN, DUP_INT, BND) of lazy cluster lists."""
+    ct, names, members_from = _cluster_tables(signatures, options)
+    return convert.cluster_objects(ct, members_from, names)
 
 
 def partition_and_cluster(signatures, options, type):

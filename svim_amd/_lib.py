@@ -66,6 +66,7 @@ class Engine(object):
         _check(self.L.svx_ctx_create(C.c_int(device), C.byref(self.ctx)), "svx_ctx_create")
         self.device = device
         self._keep = []
+        self.collect_generation = 0          # bumped by every svx_collect: identifies which tables the context holds (svim_amd/lazy.py)
 
     def close(self):
         if self.ctx:
@@ -81,6 +82,7 @@ class Engine(object):
     # ---- COLLECT ----
     def collect(self, hb, params, fetch=True):
         b = hb.struct() if hasattr(hb, "struct") else hb
+        self.collect_generation += 1
         _check(self.L.svx_collect(self.ctx, C.byref(b), C.byref(params)), "svx_collect")
         if not fetch:
             return None

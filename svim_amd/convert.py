@@ -100,56 +100,86 @@ def sigtable_from_objects(sigs, contigs=None, reads=None):
 
 
 def objects_from_sigtable(t, references, read_names):
-    """SigTable -> list of Signature objects.  The columns are converted to Python lists and the inserted sequences decoded in one
-    go; the loop then only calls the constructors."""
+    """SigTable -> list of Signature objects.  Vectorised per type: the columns of one type become Python lists (names looked up
+    through object arrays), one constructor call per row via map(), and the objects are scattered back into list order."""
     n = t.n
-    typ, srcs, aux = t.type[:n].tolist(), t.src[:n].tolist(), t.aux[:n].tolist()
-    rid, c1, c2 = t.read_id[:n].tolist(), t.contig[:n].tolist(), t.contig2[:n].tolist()
-    st, en, p2 = t.start[:n].tolist(), t.end[:n].tolist(), t.pos2[:n].tolist()
-    off = t.seq_off[:n + 1].tolist()
-    all_seq = _abi.decode_bases(t.seq[:off[n]]) if n and off[n] else ""
-    dirs = ("fwd", "rev")
-    out = []
-    add = out.append
-    for i in range(n):
-        code = typ[i]
-        src = SRC_NAMES[srcs[i]]
-        read = read_names[rid[i]]
-        c = references[c1[i]]
+    out = [None] * n
+    if n == 0:
+        return out
+    typ = t.type[:n]
+    refs = np.asarray(list(references) + [None], dtype=object)            # index -1 (no second contig) -> None
+    names = np.asarray(read_names, dtype=object) if not isinstance(read_names, np.ndarray) else read_names
+    srcs = np.asarray(SRC_NAMES, dtype=object)
+    dirs = np.asarray(("fwd", "rev"), dtype=object)
+    inv_dirs = np.asarray(INV_DIRECTIONS, dtype=object)
+    for code in range(6):
+        idx = np.nonzero(typ == code)[0]
+        if idx.size == 0:
+            continue
+        c1 = refs[t.contig[idx]].tolist()
+        st, en = t.start[idx].tolist(), t.end[idx].tolist()
+        src = srcs[t.src[idx]].tolist()
+        rd = names[t.read_id[idx]].tolist()
         if code == SVX_DEL:
-            add(SignatureDeletion(c, st[i], en[i], src, read))
+            objs = map(SignatureDeletion, c1, st, en, src, rd)
         elif code == SVX_INS:
-            add(SignatureInsertion(c, st[i], en[i], src, read, all_seq[off[i]:off[i + 1]]))
+            off = t.seq_off
+            lo, hi = off[idx].tolist(), off[idx + 1].tolist()
+            all_seq = _abi.decode_bases(t.seq[:int(off[n])]) if int(off[n]) else ""
+            objs = map(SignatureInsertion, c1, st, en, src, rd, [all_seq[a:b] for a, b in zip(lo, hi)])
         elif code == SVX_INV:
-            add(SignatureInversion(c, st[i], en[i], src, read, INV_DIRECTIONS[aux[i]]))
+            objs = map(SignatureInversion, c1, st, en, src, rd, inv_dirs[t.aux[idx]].tolist())
         elif code == SVX_DUP_TAN:
-            add(SignatureDuplicationTandem(c, st[i], en[i], p2[i], bool(aux[i] & 1), src, read))
+            objs = map(SignatureDuplicationTandem, c1, st, en, t.pos2[idx].tolist(), (t.aux[idx] & 1).astype(bool).tolist(), src, rd)
         elif code == SVX_DUP_INT:
-            add(SignatureInsertionFrom(c, st[i], en[i], references[c2[i]], p2[i], src, read))
+            objs = map(SignatureInsertionFrom, c1, st, en, refs[t.contig2[idx]].tolist(), t.pos2[idx].tolist(), src, rd)
         else:
-            add(SignatureTranslocation(c, st[i], dirs[aux[i] & 1], references[c2[i]], p2[i], dirs[(aux[i] >> 1) & 1], src, read))
+            aux = t.aux[idx]
+            objs = map(SignatureTranslocation, c1, st, dirs[aux & 1].tolist(), refs[t.contig2[idx]].tolist(), t.pos2[idx].tolist(),
+                       dirs[(aux >> 1) & 1].tolist(), src, rd)
+        for i, o in zip(idx.tolist(), objs):
+            out[i] = o
     return out
+
+
+def object_from_row(t, i, references, read_names):
+    """One Signature object from row i of a SigTable (SignatureList's single-element access)."""
+    code = int(t.type[i])
+    src = SRC_NAMES[int(t.src[i])]
+    read = read_names[int(t.read_id[i])]
+    c = references[int(t.contig[i])]
+    st, en, aux = int(t.start[i]), int(t.end[i]), int(t.aux[i])
+    dirs = ("fwd", "rev")
+    if code == SVX_DEL:
+        return SignatureDeletion(c, st, en, src, read)
+    if code == SVX_INS:
+        return SignatureInsertion(c, st, en, src, read, _abi.decode_bases(t.seq[int(t.seq_off[i]):int(t.seq_off[i + 1])]))
+    if code == SVX_INV:
+        return SignatureInversion(c, st, en, src, read, INV_DIRECTIONS[aux])
+    if code == SVX_DUP_TAN:
+        return SignatureDuplicationTandem(c, st, en, int(t.pos2[i]), bool(aux & 1), src, read)
+    if code == SVX_DUP_INT:
+        return SignatureInsertionFrom(c, st, en, references[int(t.contig2[i])], int(t.pos2[i]), src, read)
+    return SignatureTranslocation(c, st, dirs[aux & 1], references[int(t.contig2[i])], int(t.pos2[i]), dirs[(aux >> 1) & 1], src, read)
 
 
 def _none_if_nan(x):
     return None if math.isnan(x) else float(x)
 
 
-def cluster_objects(ct, sig_objects, references):
-    """ClusterTable -> the 6-tuple cluster_sv_signatures returns (src/svim/SVIM_CLUSTER.py:26):
-    (DEL, INS, INV, DUP_TAN, DUP_INT, BND)."""
+def cluster_objects_range(ct, lo, hi, sig_objects, references):
+    """Rows [lo, hi) of a ClusterTable -> SignatureCluster objects.  `members` stays an index list until it is read
+    (signatures.py: the cluster classes resolve it against sig_objects on first access)."""
     dirs = ("fwd", "rev")
-    by_type = [[] for _ in range(6)]
-    n = ct.n
-    typ, aux, size = ct.type[:n].tolist(), ct.aux[:n].tolist(), ct.size[:n].tolist()
-    c1, st, en = ct.contig[:n].tolist(), ct.start[:n].tolist(), ct.end[:n].tolist()
-    c2, st2, en2 = ct.contig2[:n].tolist(), ct.start2[:n].tolist(), ct.end2[:n].tolist()
-    score, sspan, spos = ct.score[:n].tolist(), ct.std_span[:n].tolist(), ct.std_pos[:n].tolist()
-    moff = ct.member_off[:n + 1].tolist()
-    mem = ct.members[:moff[n] if n else 0].tolist()
-    for k in range(n):
+    out = []
+    typ, aux, size = ct.type[lo:hi].tolist(), ct.aux[lo:hi].tolist(), ct.size[lo:hi].tolist()
+    c1, st, en = ct.contig[lo:hi].tolist(), ct.start[lo:hi].tolist(), ct.end[lo:hi].tolist()
+    c2, st2, en2 = ct.contig2[lo:hi].tolist(), ct.start2[lo:hi].tolist(), ct.end2[lo:hi].tolist()
+    score, sspan, spos = ct.score[lo:hi].tolist(), ct.std_span[lo:hi].tolist(), ct.std_pos[lo:hi].tolist()
+    moff = ct.member_off[lo:hi + 1].tolist()
+    for k in range(hi - lo):
         code = typ[k]
-        members = [sig_objects[j] for j in mem[moff[k]:moff[k + 1]]]
+        members = (sig_objects, ct.members[moff[k]:moff[k + 1]])            # resolved lazily
         sp, po = _none_if_nan(sspan[k]), _none_if_nan(spos[k])
         name = TYPE_NAMES[code]
         if code <= SVX_INV:
@@ -160,9 +190,19 @@ def cluster_objects(ct, sig_objects, references):
             if code == SVX_BND:
                 o.direction1 = dirs[aux[k] & 1]
                 o.direction2 = dirs[(aux[k] >> 1) & 1]
-        by_type[code].append(o)
-    return (by_type[SVX_DEL], by_type[SVX_INS], by_type[SVX_INV], by_type[SVX_DUP_TAN], by_type[SVX_DUP_INT],
-            by_type[SVX_BND])
+        out.append(o)
+    return out
+
+
+def cluster_objects(ct, sig_objects, references):
+    """ClusterTable -> the 6-tuple cluster_sv_signatures returns (src/svim/SVIM_CLUSTER.py:26):
+    (DEL, INS, INV, DUP_TAN, DUP_INT, BND), each a lazy ClusterList view (the table is grouped by type in SVX_* order)."""
+    from .lazy import ClusterList
+    bounds = [0]
+    for c in ct.type_count:
+        bounds.append(bounds[-1] + int(c))
+    views = [ClusterList(ct, bounds[k], bounds[k + 1], sig_objects, references) for k in range(6)]
+    return (views[SVX_DEL], views[SVX_INS], views[SVX_INV], views[SVX_DUP_TAN], views[SVX_DUP_INT], views[SVX_BND])
 
 
 def genome_arrays(path_or_dict, references):

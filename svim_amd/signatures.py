@@ -182,7 +182,24 @@ def _members_text(members):
     return "[" + "][".join(m.as_string("|") for m in members) + "]"
 
 
-class SignatureClusterUniLocal(Signature):
+class _LazyMembers(object):
+    """`members` of a cluster: a list of signature objects, or - until first read - (signature sequence, index array) as the GPU
+    path hands it over (svim_amd/convert.py:cluster_objects_range)."""
+
+    @property
+    def members(self):
+        m = self._members
+        if type(m) is tuple and len(m) == 2 and hasattr(m[1], "dtype"):
+            sigs, idx = m
+            m = self._members = [sigs[int(j)] for j in idx]
+        return m
+
+    @members.setter
+    def members(self, value):
+        self._members = value
+
+
+class SignatureClusterUniLocal(_LazyMembers, Signature):
     def __init__(self, contig, start, end, score, size, members, type, std_span, std_pos):
         self.contig, self.start, self.end = contig, start, end
         self.score, self.size, self.members, self.type = score, size, members, type
@@ -205,7 +222,7 @@ class SignatureClusterUniLocal(Signature):
         return self.end - self.start
 
 
-class SignatureClusterBiLocal(Signature):
+class SignatureClusterBiLocal(_LazyMembers, Signature):
     def __init__(self, source_contig, source_start, source_end, dest_contig, dest_start, dest_end, score, size,
                  members, type, std_span, std_pos):
         self.source_contig, self.source_start, self.source_end = source_contig, source_start, source_end

@@ -27,6 +27,7 @@ sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
 sys.path.insert(0, "/root/reference/src")
 
 from svim_amd import records, synth   # noqa: E402
@@ -616,6 +617,51 @@ def gen_genotype():
                                 "source": "svim.SVIM_genotyping.genotype (reads via svim_amd.records.AlignmentFile.fetch: htslib overlap rule)"})
 
 
+def _read_tree(d):
+    out = {}
+    for root, _, files in os.walk(d):
+        for f in sorted(files):
+            with open(os.path.join(root, f)) as fh:
+                out[os.path.relpath(os.path.join(root, f), d)] = fh.read()
+    return out
+
+
+def gen_writers():
+    """The reference's own writers (src/svim/SVIM_CLUSTER.py:29-106) on the reference's clusters of g5's 'stress31' case - and, as a
+    check at generation time, the SAME reference writers driven by OUR objects (CPU path: oracle tables -> svim_amd objects): the text
+    must agree except for the last digits of the FP columns (statistics.stdev vs the FP64 two-pass formula)."""
+    import tempfile
+    from svim_amd import _abi, batch as sbatch, convert
+    from oracle import oracle as om
+    import helpers as H
+    g5 = H.load("g5_cluster.json.gz")
+    case = [c for c in g5["cases"] if c["name"] == "stress31"][0]
+    o = options(**{k: v for k, v in case["options"].items() if k != "genome"})
+    sigs = [row_sig(r) for r in case["signatures"]]
+    res = SVIM_CLUSTER.cluster_sv_signatures(sigs, o)
+    with tempfile.TemporaryDirectory() as d:
+        SVIM_CLUSTER.write_signature_clusters_bed(d, res)
+        SVIM_CLUSTER.write_signature_clusters_vcf(d, res, "2.0.0")
+        ref_text = _read_tree(d)
+    ours_sigs = [H.row_sig(r) for r in case["signatures"]]
+    tab, contigs, reads = convert.sigtable_from_objects(ours_sigs, convert.Interner(g5["references"]))
+    orc = om.Oracle()
+    off, codes = convert.genome_arrays(os.path.join(HERE, "ref.fa.gz"), contigs.names)
+    orc.set_genome(off, codes)
+    ct = orc.cluster(_abi.Params.from_options(o), sbatch.contig_ranks(contigs.names), table=tab)
+    ours = convert.cluster_objects(ct, ours_sigs, contigs.names)
+    with tempfile.TemporaryDirectory() as d:
+        SVIM_CLUSTER.write_signature_clusters_bed(d, ours)            # the REFERENCE's writers, our objects
+        SVIM_CLUSTER.write_signature_clusters_vcf(d, ours, "2.0.0")
+        our_text = _read_tree(d)
+    assert sorted(ref_text) == sorted(our_text)
+    for name in ref_text:
+        assert H.text_close(our_text[name], ref_text[name]) is None, (name, H.text_close(our_text[name], ref_text[name]))
+    dump("g_writers.json.gz", {"case": "stress31 of g5_cluster.json.gz", "version": "2.0.0", "files": ref_text,
+                               "source": "svim.SVIM_CLUSTER.write_signature_clusters_bed / _vcf (src/svim/SVIM_CLUSTER.py:29-106) on the reference's "
+                                         "clusters; the same writers driven by svim_amd's objects produced the same text at generation time"})
+
+
 def main():
     contigs = [("chr1", 180000), ("chr2", 60000), ("chr10", 60000)]   # tid order != Python string order
     refs = synth.make_reference(1, contigs)
@@ -635,10 +681,13 @@ def main():
     gen_edit()
     gen_c1()
     gen_genotype()
+    gen_writers()
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "genotype":
         gen_genotype()                 # this fixture only (the others are untouched)
+    elif len(sys.argv) > 1 and sys.argv[1] == "writers":
+        gen_writers()
     else:
         main()

@@ -136,3 +136,28 @@ def c1_case():
         assert len(recs) == g["n_records"] and sum(len(a.cigartuples) for a in recs) == g["n_ops"]
         _C1.update(g=g, refs=refs, recs=recs)
     return _C1["g"], _C1["refs"], _C1["recs"]
+
+
+def text_close(got, exp, rtol=1e-9):
+    """Two writer outputs token by token: identical except that tokens which parse as floats may differ by rtol (the FP columns:
+    score, std_span, std_pos).  Returns None when equal, else a description of the first difference."""
+    import re
+    gl, el = got.splitlines(), exp.splitlines()
+    if len(gl) != len(el):
+        return "%d lines != %d" % (len(gl), len(el))
+    for i, (a, b) in enumerate(zip(gl, el)):
+        if a == b:
+            continue
+        ta, tb = re.split(r"([\t;|\[\]=])", a), re.split(r"([\t;|\[\]=])", b)
+        if len(ta) != len(tb):
+            return "line %d: %r != %r" % (i, a[:200], b[:200])
+        for x, y in zip(ta, tb):
+            if x == y:
+                continue
+            try:
+                fx, fy = float(x), float(y)
+            except ValueError:
+                return "line %d: %r != %r" % (i, x, y)
+            if abs(fx - fy) > rtol * max(1.0, abs(fy)):
+                return "line %d: %r != %r" % (i, x, y)
+    return None

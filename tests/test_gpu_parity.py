@@ -346,6 +346,73 @@ def test_c1_config0_through_bam_file(eng, tmp_path):
     H.compare_cluster_rows(got, g["clusters"])
 
 
+def test_dropin_collect_to_cluster_stays_resident_and_lazy(eng, tmp_path):
+    """COLLECT -> CLUSTER through the drop-in names without building a single Python object: the SignatureList returned by
+    analyze_alignment_file_coordsorted still mirrors the table resident in HBM, so cluster_sv_signatures runs with source = 0
+    (nothing is uploaded - checked through the call arguments) and hands back lazy cluster lists.  The Python time of the two
+    entry points at configs[0] size is asserted to be well below what object conversion alone used to cost."""
+    import time
+    import svim_amd
+    from svim_amd import _lib, lazy
+    g, refs, recs = H.c1_case()
+    path = str(tmp_path / "c1.bam")
+    records.write_bam(path, ["chr1"], [2000000], recs)
+    fa = str(tmp_path / "c1.fa")
+    synth.write_fasta(fa, refs)
+    o = H.options(g["options"])
+    o.genome = fa
+    svim_amd.cluster_sv_signatures(svim_amd.analyze_alignment_file_coordsorted(path, o)[0], o)      # warm: genome upload, allocations
+    seen = []
+    engine = _lib.engine()
+    orig = engine.cluster
+
+    def spy(*a, **kw):
+        seen.append((kw.get("source", 2), kw.get("table")))
+        return orig(*a, **kw)
+    engine.cluster = spy
+    try:
+        t0 = time.perf_counter()
+        sigs, bnds = svim_amd.analyze_alignment_file_coordsorted(path, o)
+        t1 = time.perf_counter()
+        res = svim_amd.cluster_sv_signatures(sigs, o)
+        t2 = time.perf_counter()
+    finally:
+        engine.cluster = orig
+    assert isinstance(sigs, lazy.SignatureList) and sigs._objs is None and not sigs._one
+    assert seen == [(0, None)]                                           # clustered from the resident table
+    assert all(isinstance(r, lazy.ClusterList) and r._objs is None for r in res)
+    assert len(sigs) == len(g["signatures"]) and [len(r) for r in res] == [len(x) for x in g["clusters"]]
+    assert t2 - t1 < 0.25, "cluster_sv_signatures on a resident table took %.3f s" % (t2 - t1)
+    # the side list clusters from the device too
+    seen.clear()
+    engine.cluster = spy
+    try:
+        svim_amd.cluster_sv_signatures(bnds, o)
+    finally:
+        engine.cluster = orig
+    assert seen == [(1, None)]
+    # reading the results builds them, and they are the reference's
+    assert [H.sig_row(s) for s in sigs] == g["signatures"]
+    idx = {id(s): i for i, s in enumerate(sigs)}
+    got = []
+    for k, lst in enumerate(res):
+        got.append([[c.contig, c.start, c.end, c.score, c.size, c.std_span, c.std_pos, [idx[id(m)] for m in c.members]] if k < 3 else
+                    [c.source_contig, c.source_start, c.source_end, c.dest_contig, c.dest_start, c.dest_end, c.score, c.size, c.std_span,
+                     c.std_pos, [idx[id(m)] for m in c.members]] for c in lst])
+    H.compare_cluster_rows(got, g["clusters"])
+    # a list that no longer mirrors the device table (another COLLECT ran since) is uploaded as a table, still without objects
+    sigs2, _ = svim_amd.analyze_alignment_file_coordsorted(path, o)
+    svim_amd.analyze_alignment_file_coordsorted(path, o)
+    seen.clear()
+    engine.cluster = spy
+    try:
+        res2 = svim_amd.cluster_sv_signatures(sigs2, o)
+    finally:
+        engine.cluster = orig
+    assert seen[0][0] == 2 and seen[0][1] is sigs2.table and sigs2._objs is None
+    assert [len(r) for r in res2] == [len(x) for x in g["clusters"]]
+
+
 def test_per_read_entry_points_match_reference(eng):
     """analyze_alignment_indel / analyze_read_segments (the per-read functions of SVIM_intra.py / SVIM_inter.py) through the
     drop-in names, record by record, against what the reference returned."""

@@ -69,7 +69,7 @@ def test_c4_clr_partition_max_distance_sweep_vs_oracle(eng, oracle, pmd):
     prof = workloads.profile("c4", 0.01)
     batch, genome, g_off, meta = workloads.make_batch_full(prof, seed=3, device="cuda:0")
     sig, ct, st = _both(eng, oracle, batch, g_off, genome, _options(pmd=pmd))
-    assert st["n_large_partitions"] >= 4          # beyond 100 members: random.sample pool path; at 100000 beyond 1045: set path
+    assert st["n_large_partitions"] >= 2          # beyond 100 members: random.sample pool path; at 100000 beyond 1045: set path
 
 
 @pytest.mark.skipif(os.environ.get("SVX_SKIP_SLOW") == "1", reason="SVX_SKIP_SLOW=1")

@@ -264,3 +264,65 @@ def test_native_bam_reader_chunk_switches(tmp_path, monkeypatch, env):
         assert n == ref_n == len(recs) and names == ref_names
         for k in arrays:
             assert np.array_equal(arrays[k], ref_arrays[k]), (k, batch_size)
+
+
+def _stress31_objects(oracle):
+    """g5's 'stress31' case through the CPU stand-in engine (the oracle) -> our signature objects + the lazy cluster 6-tuple."""
+    g5 = H.load("g5_cluster.json.gz")
+    case = [c for c in g5["cases"] if c["name"] == "stress31"][0]
+    o = H.options(case["options"])
+    sigs = [H.row_sig(r) for r in case["signatures"]]
+    tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(g5["references"]))
+    off, codes = convert.genome_arrays(o.genome, contigs.names)
+    oracle.set_genome(off, codes)
+    ct = oracle.cluster(_abi.Params.from_options(o), batch.contig_ranks(contigs.names), table=tab)
+    return case, tab, contigs, reads, sigs, ct
+
+
+def test_writers_match_reference_writer_text(oracle, tmp_path):
+    """write_signature_clusters_bed / _vcf (src/svim/SVIM_CLUSTER.py:29-106): the files the reference's writers produced for the
+    reference's clusters (tests/golden/g_writers.json.gz) vs our writers on our objects; FP columns within 1e-9."""
+    from svim_amd import SVIM_CLUSTER
+    gold = H.load("g_writers.json.gz")
+    case, tab, contigs, reads, sigs, ct = _stress31_objects(oracle)
+    clusters = convert.cluster_objects(ct, sigs, contigs.names)
+    SVIM_CLUSTER.write_signature_clusters_bed(str(tmp_path), clusters)
+    SVIM_CLUSTER.write_signature_clusters_vcf(str(tmp_path), clusters, gold["version"])
+    import os
+    for name, exp in gold["files"].items():
+        with open(os.path.join(str(tmp_path), name)) as fh:
+            got = fh.read()
+        assert exp.strip() != "" or name.endswith(".bed")
+        assert H.text_close(got, exp) is None, (name, H.text_close(got, exp))
+    assert sum(len(t) for t in gold["files"].values()) > 100000
+
+
+def test_lazy_lists_build_objects_only_when_read(oracle):
+    from svim_amd.lazy import ClusterList, SignatureList
+    case, tab, contigs, reads, sigs, ct = _stress31_objects(oracle)
+    lazy = SignatureList(tab, contigs.names, reads.names)
+    assert len(lazy) == len(sigs) and lazy._objs is None
+    assert lazy.count_by_type()["INS"] == sum(1 for s in sigs if s.type == "INS")
+    assert H.sig_row(lazy[5]) == H.sig_row(sigs[5]) and H.sig_row(lazy[-1]) == H.sig_row(sigs[-1])
+    assert lazy._objs is None and len(lazy._one) == 2                      # single reads do not build the whole list
+    clusters = convert.cluster_objects(ct, lazy, contigs.names)
+    assert all(isinstance(c, ClusterList) for c in clusters) and lazy._objs is None
+    assert [len(c) for c in clusters] == [len(x) for x in case["clusters"]]
+    first = clusters[1][0]                                                 # building a cluster object leaves its members alone
+    assert type(first._members) is tuple and lazy._objs is None
+    m = first.members
+    assert [H.sig_row(s) for s in m] == [case["signatures"][j] for j in case["clusters"][1][0][7]]
+    assert first.members is m                                              # resolved once
+    with pytest.raises(IndexError):
+        lazy[len(sigs)]
+    # iteration builds everything in one vectorised pass, in list order; reference-style filters work
+    assert [H.sig_row(s) for s in lazy] == case["signatures"] and lazy._objs is not None
+    assert len([ev for ev in lazy if ev.type == "DEL"]) == lazy.count_by_type()["DEL"]
+    assert lazy[2:4] == lazy.materialise()[2:4] and (lazy + [1])[-1] == 1
+    # the whole reference tuple, rows compared with the golden
+    rows = []
+    for k, lst in enumerate(clusters):
+        idx = {id(s): i for i, s in enumerate(lazy)}
+        rows.append([[idx[id(x)] for x in c.members] for c in lst])
+    exp = [[r[7] if k < 3 else r[10] for r in case["clusters"][k]] for k in range(6)]
+    assert rows == exp
