@@ -12,7 +12,7 @@ COLLECT+CLUSTER; SV signatures/sec clustered).
 One "step" = one pass of the hot path (svx_collect + svx_cluster through the C ABI) over one record batch that is
 already resident in HBM.  Default workload: BASELINE.json configs[1] - 1M synthetic ONT reads (N50 20 kb), one 250 Mb
 contig, planted DEL/INS/INV (svim_amd/devsynth.py); c2 / c4: svim_amd/workloads.py.  Weak scaling: every rank owns its own
-batch of that size (its own contigs); see svim_amd/distributed.py for what crosses xGMI.  Rank 0 prints ONE JSON line.
+batch of that size (its own contigs); see svim_amd/multigpu.py for what crosses xGMI.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -157,22 +157,42 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
     eng = _lib.Engine(local_rank)
+    rank_arr = batch.t["contig_rank"].cpu().numpy().astype(np.int32)
     if use_dist:
-        from svim_amd import distributed as D
-        g_off_all, g_all = D.all_gather_genomes(genome, dev, g_off)
-        eng.set_genome(g_off_all, g_all, on_device=True)
+        # Contig-sharded layout (svim_amd/multigpu.py): rank r's contigs are "g<r>_<name>" - global contig id = r * n_local + local id,
+        # name order is rank-major.  The batch carries GLOBAL contig ids; every rank holds the reference sequence of ITS contigs only.
+        from svim_amd import multigpu as MG
+        n_local = len(rank_arr)
+        n_global = n_local * world
+        names = ["g%03d_%s" % (r, nm) for r in range(world) for nm in (getattr(batch, "references", None) or ["chr1"])]
+        order = sorted(range(n_global), key=lambda i: names[i])
+        crank_global = np.zeros(n_global, dtype=np.int32)
+        crank_global[order] = np.arange(n_global, dtype=np.int32)
+        owner = np.repeat(np.arange(world, dtype=np.int32), n_local)
+        base = rank * n_local
+        batch.t["tid"] = batch.t["tid"] + base
+        batch.t["seg_tid"] = batch.t["seg_tid"] + base
+        batch.t["contig_rank"] = torch.as_tensor(crank_global, device=dev)
+        batch.n_contig = n_global
+        rank_arr = crank_global
+        g_off_global = torch.zeros(n_global + 1, dtype=torch.int64, device=dev)
+        g_off_global[base:base + n_local + 1] = g_off
+        g_off_global[base + n_local + 1:] = g_off[-1]
+        eng.set_genome(g_off_global, genome, on_device=True)
+        sizes = MG._all_gather_counts([batch.n_rec, int(batch.t["read_id"].max().item()) + 1], dev)
+        key_base = 2 * sum(c[0] for c in sizes[:rank])
+        read_base = sum(c[1] for c in sizes[:rank])
+        adapter = MG.SvxAdapter(eng, dev)
+        gid = np.arange(n_global, dtype=np.int64)
     else:
         eng.set_genome(g_off, genome, on_device=True)
-    rank_arr = batch.t["contig_rank"].cpu().numpy().astype(np.int32)
     bstruct = batch.struct()
 
     def step():
         eng.collect(bstruct, p, fetch=False)
         if use_dist:
-            from svim_amd import distributed as D
-            D.device_pipeline_step(eng, p, rank, world, dev, n_contig=len(rank_arr), contig_rank=rank_arr)
-        else:
-            eng.cluster(p, rank_arr, source=0, fetch=False)
+            return MG.cluster_step(adapter, p, rank, world, gid, crank_global, owner, key_base=key_base, read_base=read_base)
+        eng.cluster(p, rank_arr, source=0, fetch=False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -269,7 +289,9 @@ def main():
         "edit_guess": st.get("edit_guess"),
     }
     cfg = {"workload": label, "records_per_gpu": meta["n_records"], "cigar_ops_per_gpu": meta["n_ops"], "planted_sites": meta["n_sites"],
-           "parallelism": "1 process/GPU, records sharded by contig, partitions owned by origin rank (svim_amd/distributed.py)",
+           "parallelism": "1 process/GPU; contigs sharded over ranks, every partition local; per step over xGMI: foreign signatures (none "
+                          "here), 48 B of random.sample stream positions rank to rank, final gather of clusters + members + fixed-width "
+                          "signature columns to rank 0 (svim_amd/multigpu.py)",
            "options": "SVIM alignment-mode defaults" + ("" if args.partition_max_distance == 1000 else ", partition_max_distance %d" % args.partition_max_distance)}
     if "reads_by_layout" in meta:
         cfg["reads_by_layout"] = meta["reads_by_layout"]
@@ -298,7 +320,7 @@ def main():
             out["end_to_end"] = harness.end_to_end_sample(batch, g_off, genome, opts, device=local_rank, resident_reads_per_s=reads_per_s)
         except Exception as e:                                          # the headline number must not depend on the e2e sample
             out["end_to_end"] = {"error": repr(e)}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1 and not use_dist:           # the CPU baseline is a rank-0, N=1 measurement
         out["cpu_baseline"] = cpu_baseline(batch, g_off, genome, p, eng)
         out["speedup_vs_cpu_port"] = reads_per_s / world / out["cpu_baseline"]["value"]
     print(json.dumps(out))

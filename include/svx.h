@@ -185,6 +185,15 @@ int  svx_cluster_fetch_part_index(svx_ctx* ctx, int64_t* out /* [n_clusters], ho
  * svx_cluster_remote_members reports how many members of this rank's insertion partitions came from another rank
  * (non-zero: the caller must supply all sequences and use svx_cluster_set_shard instead). */
 int  svx_cluster_set_shard_by_origin(svx_ctx* ctx, int rank, int world, const int64_t* origin_prefix_host /* [world+1] */);
+/* multi-GPU, contig-sharded ranks (each rank clusters ONLY the signatures of the contigs it owns - every partition is local): what
+ * still couples the ranks is the random.sample word stream, which a signature type's > 100-member partitions consume in global
+ * sorted order without re-seeding (src/svim/SVIM_clustering.py:129-134).  When ranks own consecutive ranges of the name-sorted
+ * contig list that order is rank-major: rank r continues each type's stream where rank r-1 stopped.  svx_cluster calls
+ * fn(user, 0, words) before sampling to OBTAIN the 6 start positions (32-bit words already consumed, SVX_* type order; rank 0
+ * fills zeros) and fn(user, 1, words) after it to HAND ON the 6 end positions.  fn == NULL (default): streams start at 0.
+ * 48 bytes per rank and step cross the fabric for this. */
+typedef int (*svx_chain_fn)(void* user, int phase, int64_t* words /* [SVX_NTYPES] */);
+int  svx_cluster_set_chain(svx_ctx* ctx, svx_chain_fn fn, void* user);
 int  svx_cluster_remote_members(svx_ctx* ctx, int64_t* out);
 
 /* ---- GENOTYPE: replaces the per-candidate BAM re-fetch of genotype() (src/svim/SVIM_genotyping.py:34-93) --------

@@ -62,6 +62,31 @@ class Oracle(object):
         self._keep = [off, codes]
         self.L.svo_set_genome(self.ctx, C.byref(g))
 
+    def set_chain(self, fn):
+        """same contract as svim_amd._lib.Engine.set_chain (svx_cluster_set_chain)"""
+        if fn is None:
+            self._chain_cb = None
+            self.L.svo_cluster_set_chain(self.ctx, None, None)
+            return
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int64))
+
+        def tramp(user, phase, words):
+            try:
+                w = [int(words[i]) for i in range(6)]
+                fn(int(phase), w)
+                if phase == 0:
+                    for i in range(6):
+                        words[i] = int(w[i])
+                else:
+                    self._last_chain_end = list(w)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._chain_cb = proto(tramp)
+        self.L.svo_cluster_set_chain(self.ctx, self._chain_cb, None)
+
     def cluster(self, params, contig_rank, table=None, source=2, shard=None, origin_prefix=None):
         if shard is not None and origin_prefix is not None:
             pre = np.ascontiguousarray(origin_prefix, dtype=np.int64)

@@ -68,6 +68,7 @@ typedef struct svo_ctx {
     int shard_mode;                 /* 0: partition index % world, 1: origin rank of the first sorted member */
     int64_t shard_prefix[65];       /* mode 1: first global index of every rank */
     int64_t n_remote_members;
+    svx_chain_fn chain_fn; void* chain_user;      /* svo_cluster_set_chain (same contract as svx_cluster_set_chain) */
     svx_stats stats;
 } svo_ctx;
 
@@ -460,11 +461,11 @@ int svo_cigar_indel(const uint32_t* c, int64_t n, int32_t min_length, int64_t* o
 /* ================================================================= CLUSTER ==================== */
 
 /* ---- MT19937 as CPython uses it (random.seed(int) -> init_by_array; Modules/_randommodule.c) ---- */
-typedef struct mt { uint32_t s[624]; int idx; } mt;
+typedef struct mt { uint32_t s[624]; int idx; int64_t drawn; } mt;
 static void mt_init_genrand(mt* m, uint32_t s) {
     m->s[0] = s;
     for (int i = 1; i < 624; i++) m->s[i] = 1812433253u * (m->s[i - 1] ^ (m->s[i - 1] >> 30)) + (uint32_t)i;
-    m->idx = 624;
+    m->idx = 624; m->drawn = 0;
 }
 static void mt_seed_int(mt* m, uint32_t key0) {            /* init_by_array(key=[key0], 1) */
     mt_init_genrand(m, 19650218u);
@@ -488,6 +489,7 @@ static uint32_t mt_u32(mt* m) {
         m->idx = 0;
     }
     uint32_t y = m->s[m->idx++];
+    m->drawn++;
     y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
     return y;
 }
@@ -888,12 +890,15 @@ int svo_cluster(svo_ctx* c, int source, const svx_sig_view* sigs_in, int32_t n_c
     qsort(keys, (size_t)n, sizeof(skey), cmp_skey);
     int64_t global_part = 0;
     int64_t i0 = 0;
+    int64_t chain_words[SVX_NTYPES] = {0, 0, 0, 0, 0, 0}, chain_end[SVX_NTYPES];
+    if (c->chain_fn && c->chain_fn(c->chain_user, 0, chain_words) != 0) return -5;
     for (int type = 0; type < SVX_NTYPES; type++) {
         int64_t t_begin = i0;
         while (i0 < n && keys[i0].type == type) i0++;
         int64_t t_end = i0;
         int64_t first_cluster = out->n;
         mt rng; mt_seed_int(&rng, 1524u);                     /* seed(1524) once per type call, :129 */
+        for (int64_t w = 0; w < chain_words[type]; w++) (void)mt_u32(&rng);     /* svo_cluster_set_chain: words earlier ranks consumed */
         int64_t ps = t_begin;
         while (ps < t_end) {
             /* grow the partition while downstream_distance_to(prev, cur) <= max_distance */
@@ -992,11 +997,14 @@ int svo_cluster(svo_ctx* c, int source, const svx_sig_view* sigs_in, int32_t n_c
             free(newm); free(newoff); free(ck);
         }
         out->type_count[type] = ncl;
+        chain_end[type] = rng.drawn;
     }
     free(keys);
     c->stats.n_clusters = out->n;
+    if (c->chain_fn && c->chain_fn(c->chain_user, 1, chain_end) != 0) return -5;
     return 0;
 }
+int svo_cluster_set_chain(svo_ctx* c, svx_chain_fn fn, void* user) { c->chain_fn = fn; c->chain_user = user; return 0; }
 int svo_cluster_set_shard(svo_ctx* c, int rank, int world) { c->shard_rank = rank; c->shard_world = world; c->shard_mode = 0; return 0; }
 int svo_cluster_set_shard_by_origin(svo_ctx* c, int rank, int world, const int64_t* prefix) {
     if (world > 64) return -1;

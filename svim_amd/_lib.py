@@ -20,7 +20,7 @@ _ENGINES = {}
 SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream",
            "svx_collect", "svx_collect_count", "svx_collect_fetch", "svx_set_genome", "svx_cluster",
            "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_shard", "svx_cluster_fetch_part_index",
-           "svx_cluster_set_shard_by_origin", "svx_cluster_remote_members",
+           "svx_cluster_set_shard_by_origin", "svx_cluster_remote_members", "svx_cluster_set_chain",
            "svx_set_alignment_index", "svx_genotype",
            "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster",
            "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names"]
@@ -145,6 +145,30 @@ class Engine(object):
         _check(self.L.svx_genotype(self.ctx, C.c_int32(mode), C.c_int64(n), ptr(tid), ptr(start), ptr(end), ptr(member_off),
                                    ptr(member_names if member_names.size else np.zeros(1, np.int32)), C.c_int32(min_mapq), ptr(out)), "svx_genotype")
         return out[:n]
+
+    def set_chain(self, fn):
+        """fn(phase, words) -> None: phase 0 fills the six per-type stream start positions into `words` (a list of 6 ints,
+        modified in place), phase 1 receives the six end positions (svx_cluster_set_chain); None switches it off."""
+        if fn is None:
+            self._chain_cb = None
+            _check(self.L.svx_cluster_set_chain(self.ctx, None, None), "svx_cluster_set_chain")
+            return
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int64))
+
+        def tramp(user, phase, words):
+            try:
+                w = [int(words[i]) for i in range(6)]
+                fn(int(phase), w)
+                if phase == 0:
+                    for i in range(6):
+                        words[i] = int(w[i])
+                return 0
+            except Exception:                       # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._chain_cb = proto(tramp)
+        _check(self.L.svx_cluster_set_chain(self.ctx, self._chain_cb, None), "svx_cluster_set_chain")
 
     def remote_members(self):
         n = C.c_int64()

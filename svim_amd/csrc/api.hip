@@ -190,6 +190,12 @@ extern "C" int svx_cluster_set_shard(svx_ctx* c, int rank, int world) {
     return SVX_OK;
 }
 
+extern "C" int svx_cluster_set_chain(svx_ctx* c, svx_chain_fn fn, void* user) {
+    if (!c) return svx_fail(SVX_E_ARG, "null context", __FILE__, __LINE__, hipSuccess);
+    c->chain_fn = fn; c->chain_user = user;
+    return SVX_OK;
+}
+
 extern "C" int svx_cluster_set_shard_by_origin(svx_ctx* c, int rank, int world, const int64_t* origin_prefix_host) {
     if (world < 1 || rank < 0 || rank >= world || !origin_prefix_host) return svx_fail(SVX_E_ARG, "bad shard", __FILE__, __LINE__, hipSuccess);
     HIPCHK(hipSetDevice(c->device));

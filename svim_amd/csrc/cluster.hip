@@ -230,8 +230,10 @@ struct MtStream {
 // set method, whose rejections depend on the values drawn: they are sampled right here.
 __global__ __launch_bounds__(64) void k_sample_scan(const int32_t* large_list, long long n_large, const int64_t* part_start, const uint32_t* sidx,
                                                     const uint8_t* type, const int64_t* large_excl, const uint32_t* stream,
-                                                    long long cap, long long* samp_start, int32_t* sample_idx, int* err) {
+                                                    long long cap, long long* samp_start, int32_t* sample_idx, int* err,
+                                                    long long* chain /* [2 NTYPES]: stream position where each type starts / (out) stops */) {
     const int t = blockIdx.x, lane = lane_id();
+    if (lane == 0) chain[SVX_NTYPES + t] = chain[t];
     // range of large partitions whose type is t (types are non-decreasing along the sorted order)
     long long lo = 0, hi = n_large;
     while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((int)type[sidx[part_start[large_list[mid]]]] < t) lo = mid + 1; else hi = mid; }
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(64) void k_sample_scan(const int32_t* large_list, l
     if (begin == end) return;
     __shared__ uint32_t stage[MT_STAGE];
     MtStream mt; mt.words = stream; mt.stage = stage; mt.cap = cap; mt.start();
+    mt.cur += chain[t];                                  // this rank continues the type's stream where the previous one stopped
     mt.refill();
     int p_lane = 0; uint32_t n_lane = 0;                 // partition ids / sizes of 64 list entries at a time: no dependent loads in the walk
     for (long long q = begin; q < end; q++) {
@@ -274,6 +277,7 @@ __global__ __launch_bounds__(64) void k_sample_scan(const int32_t* large_list, l
             if (lane < 36) out[64 + lane] = (int32_t)res_b;
         }
     }
+    if (lane == 0) chain[SVX_NTYPES + t] = mt.position();
     if (mt.overflow && lane == 0) *err = 1;
 }
 
@@ -339,10 +343,11 @@ __global__ __launch_bounds__(256) void k_chase_runs(const SampleMeta* meta, cons
 }
 
 __global__ void k_chase_top(const SampleMeta* meta, const ChaseRun* runs, const long long* type_run_begin /* [NTYPES + 1] */, const long long* ends,
-                            long long* run_start, int* err) {
+                            long long* run_start, int* err, long long* chain /* [2 NTYPES]: start / (out) end position per type */) {
     const int t = blockIdx.x;
     if (threadIdx.x != 0) return;
-    long long pos = 0;
+    long long pos = chain[t];
+    chain[SVX_NTYPES + t] = pos;
     for (long long b = type_run_begin[t]; b < type_run_begin[t + 1]; b++) {
         const ChaseRun r = runs[b];
         const SampleMeta m0 = meta[r.first];
@@ -352,6 +357,7 @@ __global__ void k_chase_top(const SampleMeta* meta, const ChaseRun* runs, const 
         pos = ends[r.eoff + idx];
         if (pos < 0) { *err = 1; return; }
     }
+    chain[SVX_NTYPES + t] = pos;
 }
 
 __global__ void k_chase_fill(const SampleMeta* meta, const ChaseRun* runs, long long n_runs, const uint16_t* table, const long long* run_start,
@@ -784,7 +790,7 @@ __global__ __launch_bounds__(64) void k_cluster(long long n_part, const int64_t*
     int* dup = reinterpret_cast<int*>(sm); sm += sizeof(int) * CAP;
     int* orig = reinterpret_cast<int*>(sm); sm += sizeof(int) * CAP;
     int* cl_off = reinterpret_cast<int*>(sm); sm += sizeof(int) * (CAP + 2);
-    double* xs = reinterpret_cast<double*>(sm); sm += sizeof(double) * CAP * 2;     // per-lane scratch is carved below
+    double* xs = reinterpret_cast<double*>(sm); sm += sizeof(double) * 4;           // scratch of a single-member cluster; larger ones are carved from D below
 
     const long long sbase = samp_base[pt];
     const uint32_t g0 = member_gidx(ps, size, 0, sidx, sample_idx, large_excl, pt);
@@ -958,7 +964,14 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     S.n_edit_wordcols_issued = S.n_edit_wordcols_useful = S.n_edit_wordcols_retry = S.n_edit_wordcols_band = 0; S.edit_guess = 0;
     S.t_cluster_ms = S.t_partition_ms = S.t_edit_ms = S.t_linkage_ms = 0;
     c->n_remote_members = 0;
-    if (n == 0) return SVX_OK;
+    if (n == 0) {
+        if (c->chain_fn) {                                   // an empty rank still relays the stream positions
+            int64_t w[SVX_NTYPES] = {0, 0, 0, 0, 0, 0};
+            if (c->chain_fn(c->chain_user, 0, w) != 0 || c->chain_fn(c->chain_user, 1, w) != 0)
+                return svx_fail(SVX_E_STATE, "chain callback failed", __FILE__, __LINE__, hipSuccess);
+        }
+        return SVX_OK;
+    }
     if (n >= (1ll << 31)) return svx_fail(SVX_E_ARG, "more than 2^31 signatures in one call", __FILE__, __LINE__, hipSuccess);
     const int T = 256;
     HIPCHK(hipEventRecord(c->ev[8], st));
@@ -1001,11 +1014,24 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     HIPCHK(hipMemsetAsync(cnt, 0, 16 * 8, st));
     // ---- sampling ----------------------------------------------------------------------------------------------------
+    // multi-GPU (svx_cluster_set_chain): the word stream of every type continues where the previous rank's partitions left it
+    long long chain[2 * SVX_NTYPES];
+    for (int t = 0; t < 2 * SVX_NTYPES; t++) chain[t] = 0;
+    if (c->chain_fn) {
+        int64_t w[SVX_NTYPES] = {0, 0, 0, 0, 0, 0};
+        if (c->chain_fn(c->chain_user, 0, w) != 0) return svx_fail(SVX_E_STATE, "chain callback (start positions) failed", __FILE__, __LINE__, hipSuccess);
+        for (int t = 0; t < SVX_NTYPES; t++) { if (w[t] < 0) return svx_fail(SVX_E_ARG, "negative stream position", __FILE__, __LINE__, hipSuccess); chain[t] = chain[SVX_NTYPES + t] = w[t]; }
+    }
+    long long chain_max = 0;
+    for (int t = 0; t < SVX_NTYPES; t++) chain_max = chain[t] > chain_max ? chain[t] : chain_max;
     SVXCHK(c->samp_idx.reserve((size_t)(n_large + 1) * 100 * 4));
     if (n_large > 0) {
         SVXCHK(c->large_list.reserve((size_t)n_large * 4 + 64));
         k_large_list<<<GRID(n_part, T), T, 0, st>>>(large_a, large_excl, n_part, c->large_list.as<int32_t>());
-        long long cap = n_large * 512 + 4 * 624;                       // expected use: <= ~200 words per partition
+        long long cap = chain_max + n_large * 512 + 4 * 624;           // expected use: <= ~200 words per partition
+        SVXCHK(c->samp_chain.reserve(2 * SVX_NTYPES * 8));
+        long long* chain_dev = c->samp_chain.as<long long>();
+        HIPCHK(hipMemcpyAsync(chain_dev, chain, sizeof chain, hipMemcpyHostToDevice, st));
         auto ensure_stream = [&](long long want) -> int {
             if (c->mt_have >= want) return SVX_OK;
             // (re)generate the prefix of the seed(1524) word stream this context keeps
@@ -1041,8 +1067,8 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
             for (int t = 0; t < SVX_NTYPES && table_ok; t++) {
                 while (q < n_large && info[(size_t)q * 2] < t) q++;
                 type_begin[t] = q;
-                double mean = 0, var = 0;
-                long long least = 0;
+                double mean = (double)chain[t], var = 0;
+                long long least = chain[t];
                 for (; q < n_large && info[(size_t)q * 2] == t; q++) {
                     const int n_q = info[(size_t)q * 2 + 1];
                     if (n_q > 1045) { table_ok = false; break; }                       // set method: the walk depends on the values drawn
@@ -1094,7 +1120,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
                 k_sample_tables<<<dim3((unsigned)((max_width + 255) / 256), (unsigned)n_large), 256, 0, st>>>(meta_dev, c->mt_words.as<uint32_t>(), c->mt_have,
                                                                                                              c->samp_table.as<uint16_t>());
                 k_chase_runs<<<dim3((unsigned)((max_width + 255) / 256), (unsigned)n_runs), 256, 0, st>>>(meta_dev, runs_dev, c->samp_table.as<uint16_t>(), ends_dev);
-                k_chase_top<<<SVX_NTYPES, 64, 0, st>>>(meta_dev, runs_dev, trb_dev, ends_dev, run_start_dev, err);
+                k_chase_top<<<SVX_NTYPES, 64, 0, st>>>(meta_dev, runs_dev, trb_dev, ends_dev, run_start_dev, err, chain_dev);
                 k_chase_fill<<<GRID(n_runs, 64), 64, 0, st>>>(meta_dev, runs_dev, n_runs, c->samp_table.as<uint16_t>(), run_start_dev, samp_start);
                 k_sample_apply<<<(unsigned)n_large, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
                                                                 c->mt_words.as<uint32_t>(), c->mt_have, samp_start, c->samp_idx.as<int32_t>());
@@ -1110,7 +1136,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
             const uint32_t* stream = c->mt_words.as<uint32_t>();
             HIPCHK(hipMemsetAsync(err, 0, 8, st));
             k_sample_scan<<<SVX_NTYPES, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
-                                                    stream, c->mt_have, samp_start, c->samp_idx.as<int32_t>(), err);
+                                                    stream, c->mt_have, samp_start, c->samp_idx.as<int32_t>(), err, chain_dev);
             k_sample_apply<<<(unsigned)n_large, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
                                                             stream, c->mt_have, samp_start, c->samp_idx.as<int32_t>());
             HIPCHK(hipGetLastError());
@@ -1121,6 +1147,15 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
             if (attempt == 5) return svx_fail(SVX_E_CAPACITY, "random word stream", __FILE__, __LINE__, hipSuccess);
             cap = c->mt_have * 4;
         }
+        if (c->chain_fn) {
+            HIPCHK(hipMemcpyAsync(chain, chain_dev, sizeof chain, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    }
+    if (c->chain_fn) {
+        int64_t w[SVX_NTYPES];
+        for (int t = 0; t < SVX_NTYPES; t++) w[t] = chain[SVX_NTYPES + t];
+        if (c->chain_fn(c->chain_user, 1, w) != 0) return svx_fail(SVX_E_STATE, "chain callback (end positions) failed", __FILE__, __LINE__, hipSuccess);
     }
     HIPCHK(hipEventRecord(c->ev[9], st));
     // ---- staging area of the per-partition clustering --------------------------------------------------------------
@@ -1142,15 +1177,20 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     SVXCHK(c->labels.reserve(PM * 4 * 2));
     int32_t* ncl_a = c->labels.as<int32_t>(); int32_t* nmem_a = ncl_a + PM;
     HIPCHK(hipMemsetAsync(ncl_a, 0, PM * 8, st));
-    constexpr int SMALL = 48;
-    auto cluster_lds = [](int cap) { return link_lds_bytes(cap) + sizeof(Member) * cap * 2 + sizeof(int) * (3 * cap + 2) + sizeof(double) * cap * 2 + 64; };
+    // three LDS size classes: 14 KB (<= 48 members: 11 partitions resident per CU), 30 KB (<= 72: 5), 53 KB (<= 100: 3) - the kernel is
+    // bound by the latency of its LDS round trips, so what counts is how many partitions a CU works on at once
+    constexpr int SMALL = 48, MID = 72;
+    auto cluster_lds = [](int cap) { return link_lds_bytes(cap) + sizeof(Member) * cap * 2 + sizeof(int) * (3 * cap + 2) + sizeof(double) * 4 + 64; };
     auto launch_cluster = [&](hipStream_t ks, int phase) {
         k_cluster<SMALL, 0><<<(unsigned)n_part, 64, cluster_lds(SMALL), ks>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
                                                                           samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
                                                                           ncl_a, nmem_a, cnt + 10, phase);
-        k_cluster<MAXN, SMALL><<<(unsigned)n_part, 64, cluster_lds(MAXN), ks>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
-                                                                            samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
-                                                                            ncl_a, nmem_a, cnt + 10, phase);
+        k_cluster<MID, SMALL><<<(unsigned)n_part, 64, cluster_lds(MID), ks>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
+                                                                          samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
+                                                                          ncl_a, nmem_a, cnt + 10, phase);
+        k_cluster<MAXN, MID><<<(unsigned)n_part, 64, cluster_lds(MAXN), ks>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
+                                                                          samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
+                                                                          ncl_a, nmem_a, cnt + 10, phase);
     };
     SVXCHK(c->ed.reserve((size_t)(pair_total + 1) * 4));
     // partitions without insertions need nothing from the edit-distance rounds: their linkage runs beside them on a side stream

@@ -126,7 +126,8 @@ struct svx_ctx {
     DevBuf k_hi, k_lo, k_idx, k_hi2, k_lo2, k_idx2, part_flag, part_id, part_start, part_meta, samp_idx, large_list, samp_stream;
     DevBuf cell_shards;
     DevBuf geno[11]; int64_t geno_n = 0; int32_t geno_contigs = -1;      // GENOTYPE: resident alignment index + per-call candidate buffers
-    DevBuf samp_meta, samp_table, samp_runs;                // consumption tables of the sampling walk
+    DevBuf samp_meta, samp_table, samp_runs, samp_chain;    // consumption tables of the sampling walk; per-type stream positions
+    svx_chain_fn chain_fn = nullptr; void* chain_user = nullptr;      // svx_cluster_set_chain
     DevBuf mt_words; long long mt_have = 0;      // tempered MT19937 words after seed(1524), kept across calls
     DevBuf pair_off, ed, work, stage, stage_members, labels;
     DevBuf e_words, e_off, e_scratch, e_rec, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off;

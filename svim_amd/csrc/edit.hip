@@ -584,12 +584,12 @@ __device__ __forceinline__ void d_edit_band(long long blk, long long count, cons
 // ---- 3'. pilot: how far apart are this call's pairs? -------------------------------------------------------------------------
 // A pair whose trivial alignments give no useful bound starts in a band sized for 2 * shift + guess_frac * (core length) differences
 // beyond the length gap (k_edit_classify): the position shift of the two insertions is known, how much their SEQUENCES differ is
-// not.  guess_frac is chosen per CALL from a strided sample of its own pairs: the 64-diagonal band kernel over the first <= 512
+// not.  guess_frac is chosen per CALL from a strided sample of its own pairs: the 64-diagonal band kernel over the first <= 384
 // symbols of both cores gives each sampled pair's cost, minus the 2 * shift that leaving and re-joining the main diagonal costs
 // = its sequence divergence per symbol (beyond ~10 % only an upper bound, which is all the cost model needs), weighted by the core
 // length like the work it stands for.  No state is carried from one call to the next; routing only, results never depend on it.
 #define PILOT_MAX 16384
-#define PILOT_PREFIX 512
+#define PILOT_PREFIX 384
 __global__ __launch_bounds__(256) void k_edit_pilot(long long n_work, long long stride, const PairDesc* desc, const uint32_t* scratch, unsigned long long* hist) {
     __shared__ unsigned long long h[256];
     h[threadIdx.x] = 0;

@@ -1,5 +1,5 @@
-"""Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in CPU tests).
+"""Table helpers shared by the multi-batch COLLECT driver and the partition-sharded clustering modes (svx_cluster_set_shard /
+_by_origin); the multi-GPU step itself lives in svim_amd/multigpu.py (contig-sharded ranks, every partition local).
 
 Sharding (DESIGN.md "Multi-GPU"):
   * COLLECT shards the record batch by contiguous record ranges - records are independent;
@@ -248,108 +248,3 @@ def merge_gathered_clusters(g, g_part, g_mem, contig_rank):
     torch.cumsum(out_sizes, 0, out=member_off[1:])
     src_idx = torch.repeat_interleave(src_off[order] - member_off[:-1], out_sizes) + torch.arange(nm, dtype=torch.int64, device=dev)
     return DeviceClusterTable(out_cols, member_off, g_mem[src_idx], g_part[order])
-
-
-def device_pipeline_step(eng, params, rank, world, dev, read_id_stride=1 << 26):
-    """COLLECT already ran on this rank's records (results resident in its context).  Exchange the signature tables,
-    cluster the partitions this rank owns, all-gather and merge the cluster tables on the device.  Returns the merged
-    DeviceClusterTable (every rank; .to_host() gives the ClusterTable).
-
-    Each rank's batch lives on its own contig: contig id := rank, read ids are made globally unique by a per-rank stride.
-    Fast path: only the fixed-width columns (37 B/signature) are all-gathered and partitions are owned "by origin"
-    (svx_cluster_set_shard_by_origin): with contig-sharded input every member of an owned insertion partition - hence every
-    inserted sequence - is already local.  If any rank reports remote members, the step is redone with the inserted
-    sequences all-gathered as well and index-modulo ownership (always correct, more traffic)."""
-    import ctypes as C
-    import os
-    import time
-    import torch
-    import torch.distributed as dist
-    from ._lib import _check
-    timing = os.environ.get("SVX_DIST_TIMING") == "1" and rank == 0
-    marks = []
-
-    def mark(label):
-        if timing:
-            torch.cuda.synchronize()
-            marks.append((label, time.perf_counter()))
-
-    mark("start")
-    n, nseq, _ = eng.collect_counts()
-    cnt = torch.tensor([n, nseq], dtype=torch.int64, device=dev)
-    allc = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(allc, cnt)
-    ns = [int(c[0].item()) for c in allc]
-    nq = [int(c[1].item()) for c in allc]
-    cols = {k: torch.empty(max(1, n), dtype=getattr(torch, dt), device=dev) for k, dt in _DEV_COLS}
-    key = torch.empty(max(1, n), dtype=torch.int64, device=dev)
-    seq_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
-    seq = torch.empty(max(1, nseq), dtype=torch.uint8, device=dev)
-    v = _abi.SigView()
-    v.on_device, v.n = 1, n
-    v.key = _abi.ptr(key)
-    for k, _ in _DEV_COLS:
-        setattr(v, k, _abi.ptr(cols[k]))
-    v.seq_off, v.seq = _abi.ptr(seq_off), _abi.ptr(seq)
-    _check(eng.L.svx_collect_fetch(eng.ctx, 0, C.byref(v)), "svx_collect_fetch")
-    mark("fetch own table")
-    cols["contig"] = cols["contig"] + rank                       # this rank's contig
-    cols["contig2"] = torch.where(cols["contig2"] >= 0, cols["contig2"] + rank, cols["contig2"])
-    cols["read_id"] = cols["read_id"] + rank * read_id_stride
-    g = {k: _all_gather_var(cols[k][:n], ns, dist, torch) for k, _ in _DEV_COLS}
-    mark("all-gather columns")
-    N = sum(ns)
-    prefix = np.zeros(world + 1, dtype=np.int64)
-    prefix[1:] = np.cumsum(ns)
-    lens = (seq_off[1:] - seq_off[:-1])
-    contig_rank = np.arange(world, dtype=np.int32)
-
-    def view(g_off, g_seq):
-        gv = _abi.SigView()
-        gv.on_device, gv.n = 1, N
-        for k, _ in _DEV_COLS:
-            setattr(gv, k, _abi.ptr(g[k] if g[k].numel() else torch.zeros(1, dtype=g[k].dtype, device=dev)))
-        gv.seq_off, gv.seq = _abi.ptr(g_off), _abi.ptr(g_seq if g_seq.numel() else torch.zeros(1, dtype=torch.uint8, device=dev))
-        return gv
-
-    # fast path: remote signatures carry empty sequence ranges
-    g_len = torch.zeros(N, dtype=torch.int64, device=dev)
-    g_len[int(prefix[rank]):int(prefix[rank + 1])] = lens
-    g_off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(g_len, 0, out=g_off[1:])
-    torch.cuda.synchronize()      # the gathered tensors were produced on torch's / RCCL's streams; libsvx has its own stream
-    eng.cluster(params, contig_rank, table=view(g_off, seq[:max(1, nseq)]), source=2, shard=(rank, world), origin_prefix=prefix, fetch=False)
-    mark("cluster owned partitions")
-    remote = torch.tensor([eng.remote_members()], dtype=torch.int64, device=dev)
-    dist.all_reduce(remote, op=dist.ReduceOp.MAX)
-    if int(remote.item()) > 0:
-        # some insertion partition mixes origins: ship the sequences too and shard by partition index
-        a_len = _all_gather_var(lens, ns, dist, torch)
-        a_seq = _all_gather_var(seq[:nseq], nq, dist, torch)
-        a_off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(a_len, 0, out=a_off[1:])
-        torch.cuda.synchronize()
-        eng.cluster(params, contig_rank, table=view(a_off, a_seq), source=2, shard=(rank, world), fetch=False)
-    out = gather_clusters_device(eng, contig_rank, dev)
-    mark("gather + merge clusters")
-    if timing:
-        import sys
-        sys.stderr.write("dist step: " + ", ".join("%s %.2f ms" % (b[0], (b[1] - a[1]) * 1e3) for a, b in zip(marks, marks[1:])) + "\n")
-    return out
-
-
-def all_gather_genomes(genome, dev):
-    """Every rank ends up with the concatenation of all ranks' contigs (+ offsets): the equivalent of loading the same
-    reference FASTA on every GPU.  Untimed setup."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size()
-    n = torch.tensor([genome.numel()], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(x.item()) for x in sizes]
-    full = _all_gather_var(genome, sizes, dist, torch)
-    off = torch.zeros(world + 1, dtype=torch.int64, device=dev)
-    off[1:] = torch.cumsum(torch.tensor(sizes, dtype=torch.int64, device=dev), 0)
-    torch.cuda.synchronize()          # consumers run on another stream
-    return off, full

@@ -1,0 +1,420 @@
+"""Contig-sharded multi-GPU COLLECT+CLUSTER: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  SURVEY.md section 8(e), DESIGN.md section 6.
+
+Ownership.  Every contig belongs to one rank; ranks own CONSECUTIVE ranges of the NAME-SORTED contig list (assign_contigs).
+A signature belongs to the owner of the contig its partition key starts with (`contig`, for DUP_INT the destination `contig2`:
+src/svim/SVSignature.py get_key, SVIM_clustering.py:17-29) - so every partition is local to one rank, and the global sorted
+order of all partitions of a type is rank-major.
+
+What crosses the fabric per step
+  1. foreign signatures: a read's record is collected by the rank that owns the record's contig, but a split read can emit a
+     signature that belongs to another contig's owner (a BND whose canonical first end lies elsewhere, a DUP_INT inserted
+     elsewhere, a DEL between two supplementary segments on another contig).  Those rows - typically none to a few per
+     thousand - are exchanged (one count exchange; nothing else when every count is zero).
+  2. the random.sample stream positions: 6 x int64 from rank r to rank r+1 (ChainRelay; svx_cluster_set_chain).  The stream of
+     a type is consumed by its > 100-member partitions in global order without re-seeding (SVIM_clustering.py:129-134).
+  3. the final candidate gather to rank 0: cluster records, member lists, and the fixed-width signature columns.
+Signature columns of ordinary (non-foreign) signatures and inserted sequences never leave their rank before the final gather.
+
+The same code runs on CPU tensors over gloo with the oracle as stand-in engine (tests/test_distributed_gloo.py).
+"""
+import numpy as np
+
+from . import _abi
+from ._abi import CLU_DTYPES, SIG_DTYPES
+
+SIG_COLS = ("key", "type", "src", "aux", "contig", "start", "end", "contig2", "pos2", "read_id")
+
+
+def assign_contigs(names, lengths, world):
+    """owner rank of every contig: the name-sorted contig list is cut into `world` consecutive ranges of about equal total length
+    (a contig goes to the range its midpoint falls into).  Returns int32 [n_contig]."""
+    n = len(names)
+    order = sorted(range(n), key=lambda i: names[i])
+    total = float(sum(lengths)) or 1.0
+    owner = np.zeros(n, dtype=np.int32)
+    acc = 0.0
+    for i in order:
+        mid = acc + lengths[i] / 2.0
+        owner[i] = min(world - 1, int(mid * world / total))
+        acc += lengths[i]
+    # ranges must be monotone in name order (midpoints are), and no rank may be skipped when there are enough contigs
+    return owner
+
+
+def owner_contig(typ, contig, contig2):
+    """contig whose owner clusters the signature (torch tensors or numpy arrays)"""
+    is_dup_int = typ == _abi.SVX_DUP_INT
+    if isinstance(typ, np.ndarray):
+        return np.where(is_dup_int, contig2, contig)
+    import torch
+    return torch.where(is_dup_int, contig2, contig)
+
+
+class ChainRelay(object):
+    """The callback of svx_cluster_set_chain: receive the six stream start positions from rank-1, hand the six end positions to
+    rank+1 (48 bytes each way per step)."""
+
+    def __init__(self, rank, world, device="cpu"):
+        self.rank, self.world, self.device = rank, world, device
+        self.last = None
+
+    def __call__(self, phase, words):
+        import torch
+        import torch.distributed as dist
+        if phase == 0:
+            if self.rank > 0:
+                t = torch.zeros(6, dtype=torch.int64, device=self.device)
+                dist.recv(t, src=self.rank - 1)
+                words[:] = [int(x) for x in t.tolist()]
+        else:
+            self.last = list(words)
+            if self.rank + 1 < self.world:
+                dist.send(torch.tensor(words, dtype=torch.int64, device=self.device), dst=self.rank + 1)
+
+
+def _all_gather_counts(values, device):
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    t = torch.tensor(values, dtype=torch.int64, device=device)
+    out = torch.zeros(world * len(values), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, t)
+    return out.view(world, len(values)).tolist()
+
+
+def _all_gather_rows(t, counts):
+    """all-gather of 1-D tensors with per-rank lengths `counts` (known from ONE count exchange) -> list of per-rank tensors"""
+    import torch
+    import torch.distributed as dist
+    mx = max(max(counts), 1)
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[:t.numel()] = t
+    out = torch.empty(mx * len(counts), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad)
+    return [out[r * mx:r * mx + c] for r, c in enumerate(counts)]
+
+
+def _gather_to_root(t, counts, rank):
+    """dist.gather of 1-D tensors with per-rank lengths `counts` to rank 0 -> concatenation (rank 0) / None"""
+    import torch
+    import torch.distributed as dist
+    mx = max(max(counts), 1)
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[:t.numel()] = t
+    if rank == 0:
+        bufs = [torch.empty(mx, dtype=t.dtype, device=t.device) for _ in counts]
+        dist.gather(pad, bufs, dst=0)
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)])
+    dist.gather(pad, None, dst=0)
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# engine adapters: the step below works on torch tensors; an adapter moves them in and out of an engine
+# ---------------------------------------------------------------------------------------------------------------------
+_TORCH = {"uint8": "uint8", "int32": "int32", "uint64": "int64", "int64": "int64", "float64": "float64"}
+
+
+def _tdtype(np_dtype):
+    import torch
+    return getattr(torch, _TORCH[np.dtype(np_dtype).name])
+
+
+class SvxAdapter(object):
+    """libsvx engine, everything resident in HBM (device pointers through the C ABI)."""
+
+    def __init__(self, eng, device):
+        self.eng, self.device = eng, device
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def set_chain(self, relay):
+        self.eng.set_chain(relay)
+
+    def collect_counts(self):
+        n, nseq, _ = self.eng.collect_counts()
+        return n, nseq
+
+    def fetch_signatures(self):
+        """the COLLECT result as device tensors: columns dict, seq_off, seq"""
+        import ctypes as C
+        import torch
+        from ._lib import _check
+        n, nseq = self.collect_counts()
+        cols = {k: torch.empty(max(1, n), dtype=_tdtype(SIG_DTYPES[k]), device=self.device) for k in SIG_COLS}
+        seq_off = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        seq = torch.zeros(max(1, nseq), dtype=torch.uint8, device=self.device)
+        v = _abi.SigView()
+        v.on_device, v.n = 1, n
+        for k in SIG_COLS:
+            setattr(v, k, _abi.ptr(cols[k]))
+        v.seq_off, v.seq = _abi.ptr(seq_off), _abi.ptr(seq)
+        _check(self.eng.L.svx_collect_fetch(self.eng.ctx, 0, C.byref(v)), "svx_collect_fetch")
+        return {k: c[:n] for k, c in cols.items()}, seq_off, seq[:nseq]
+
+    def cluster(self, params, contig_rank, table=None):
+        """table None: the resident COLLECT result (source 0); else (cols, seq_off, seq) device tensors (source 2)"""
+        import torch
+        if table is None:
+            self.eng.cluster(params, contig_rank, source=0, fetch=False)
+            return
+        cols, seq_off, seq = table
+        n = int(cols["type"].numel())
+        keep = []
+        v = _abi.SigView()
+        v.on_device, v.n = 1, n
+        for k in SIG_COLS:
+            c = cols[k].contiguous() if n else torch.zeros(1, dtype=cols[k].dtype, device=self.device)
+            keep.append(c)
+            setattr(v, k, _abi.ptr(c))
+        so = seq_off.contiguous()
+        sq = seq.contiguous() if seq.numel() else torch.zeros(1, dtype=torch.uint8, device=self.device)
+        keep += [so, sq]
+        v.seq_off, v.seq = _abi.ptr(so), _abi.ptr(sq)
+        torch.cuda.synchronize()              # the tensors were produced on torch's / RCCL's streams; libsvx runs on its own
+        self.eng.cluster(params, contig_rank, table=v, source=2, fetch=False)
+        self._keep = keep
+
+    def fetch_clusters(self):
+        from .distributed import fetch_clusters_device
+        cols, members, part_index = fetch_clusters_device(self.eng, self.device)
+        return cols, members
+
+
+class HostAdapter(object):
+    """An engine with host tables (the oracle in the gloo tests; also libsvx with host arrays): tensors are CPU tensors."""
+
+    def __init__(self, engine, sig_table):
+        self.engine, self.sig, self.device = engine, sig_table, "cpu"
+        self.ct = None
+
+    def sync(self):
+        pass
+
+    def set_chain(self, relay):
+        self.engine.set_chain(relay)
+
+    def collect_counts(self):
+        return self.sig.n, int(self.sig.seq_off[self.sig.n])
+
+    def fetch_signatures(self):
+        import torch
+        t = self.sig
+        cols = {}
+        for k in SIG_COLS:
+            a = np.ascontiguousarray(getattr(t, k)[:t.n])
+            cols[k] = torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).clone()
+        nseq = int(t.seq_off[t.n])
+        return cols, torch.from_numpy(t.seq_off[:t.n + 1].astype(np.int64)), torch.from_numpy(np.ascontiguousarray(t.seq[:nseq])).clone()
+
+    def cluster(self, params, contig_rank, table=None):
+        if table is None:
+            tab = self.sig
+        else:
+            cols, seq_off, seq = table
+            n = int(cols["type"].numel())
+            tab = _abi.SigTable(n, int(seq.numel()))
+            for k in SIG_COLS:
+                a = cols[k].numpy()
+                getattr(tab, k)[:] = a.view(np.uint64) if SIG_DTYPES[k] == np.uint64 else a
+            tab.seq_off[:] = seq_off.numpy()
+            if seq.numel():
+                tab.seq[:seq.numel()] = seq.numpy()
+        self.ct = self.engine.cluster(params, contig_rank, table=tab)
+
+    def fetch_clusters(self):
+        import torch
+        ct = self.ct
+        cols = {k: torch.from_numpy(np.ascontiguousarray(getattr(ct, k)[:ct.n])) for k in CLU_DTYPES}
+        return cols, torch.from_numpy(np.ascontiguousarray(ct.members[:ct.n_members]))
+
+
+class StepResult(object):
+    """Rank 0's merged result: cluster columns (type-major, then rank-major = the reference's order), member lists as indices
+    into the gathered signature table, that table's fixed-width columns (torch tensors), per-rank signature counts."""
+
+    def __init__(self, clusters, member_off, members, sig_cols, sig_counts, chain_end):
+        self.clusters, self.member_off, self.members = clusters, member_off, members
+        self.sig_cols, self.sig_counts, self.chain_end = sig_cols, sig_counts, chain_end
+        self.n = int(clusters["type"].numel()) if clusters is not None else 0
+
+    def to_host(self):
+        out = _abi.ClusterTable(self.n, int(self.members.numel()))
+        for k in CLU_DTYPES:
+            setattr(out, k, self.clusters[k].cpu().numpy())
+        out.member_off = self.member_off.cpu().numpy()
+        out.members = self.members.cpu().numpy().astype(np.int32)
+        out.n_members = int(self.members.numel())
+        out.type_count = [int((out.type == k).sum()) for k in range(6)]
+        return out
+
+
+def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, owner_of_contig, key_base=0, read_base=0,
+                 gather_signatures=True, names_of=None, ids_of=None):
+    """One multi-GPU CLUSTER step after this rank's COLLECT.
+
+    contig_gid          int64 [n_local_contig]: global id of every LOCAL contig id the COLLECT tables use
+    contig_rank_global  int32 [n_global]: rank of every contig NAME in str order
+    owner_of_contig     int32 [n_global]: assign_contigs
+    key_base            added to the slot half of the emission keys: 2 x (records in file order before this rank's first record)
+    read_base           added to the read ids (unique across ranks when reads never span ranks: the synthetic bench layout)
+    names_of, ids_of    real inputs: a read can have records on contigs of different ranks, and the same-read rules of the
+                        clustering (SVIM_clustering.py:141-167) need ONE id per read inside a rank's table.  Read ids stay
+                        rank-local; foreign rows travel with their read NAMES (names_of(local ids) -> list of str) and the
+                        receiving rank interns them into its own numbering (ids_of(list of str) -> ids).
+    Returns StepResult on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    dev = adapter.device
+    gid = torch.as_tensor(np.asarray(contig_gid), dtype=torch.int64, device=dev)
+    owner_t = torch.as_tensor(np.asarray(owner_of_contig), dtype=torch.int64, device=dev)
+    relay = ChainRelay(rank, world, dev)
+    adapter.set_chain(relay)
+    n_own, _ = adapter.collect_counts()
+    # ---- 1. foreign signatures --------------------------------------------------------------------------------------------
+    cols = seq_off = seq = None
+    n_foreign = 0
+    if world > 1 and n_own:
+        cols, seq_off, seq = adapter.fetch_signatures()
+        own_c = owner_contig(cols["type"], gid[cols["contig"].long()], torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()], cols["contig2"].long()))
+        foreign = owner_t[own_c] != rank
+        n_foreign = int(foreign.sum().item())
+    counts = _all_gather_counts([n_foreign], dev) if world > 1 else [[0]]
+    any_foreign = any(c[0] for c in counts)
+    local_rank_arr = np.asarray(contig_rank_global, dtype=np.int32)[np.asarray(contig_gid, dtype=np.int64)]
+    if not any_foreign:
+        # the common case: every signature stays where it was collected; cluster the resident table as it is (local contig ids)
+        adapter.cluster(params, local_rank_arr, table=None)
+        n_sig = n_own
+        if gather_signatures and cols is None and n_own:
+            cols, seq_off, seq = adapter.fetch_signatures()
+        if cols is not None:
+            cols = dict(cols)
+            cols["contig"] = gid[cols["contig"].long()].to(torch.int32)
+            cols["contig2"] = torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()].to(torch.int32), cols["contig2"])
+            cols["read_id"] = cols["read_id"] + read_base
+            cols["key"] = cols["key"] + (int(key_base) << 32)
+        local_to_global_contig = gid
+    else:
+        if cols is None:
+            cols, seq_off, seq = adapter.fetch_signatures()
+            foreign = torch.zeros(0, dtype=torch.bool, device=dev)
+        # globalise ids, split off the foreign rows, exchange them (with their inserted sequences), keep the rows this rank owns
+        cols = dict(cols)
+        cols["contig"] = gid[cols["contig"].long()].to(torch.int32)
+        cols["contig2"] = torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()].to(torch.int32), cols["contig2"])
+        cols["read_id"] = cols["read_id"] + read_base
+        cols["key"] = cols["key"] + (int(key_base) << 32)
+        lens = seq_off[1:] - seq_off[:-1]
+        fidx = torch.nonzero(foreign).flatten()
+        f_cols = {k: cols[k][fidx] for k in SIG_COLS}
+        f_len = lens[fidx]
+        g_names = None
+        if names_of is not None:
+            mine_names = names_of((f_cols["read_id"] - read_base).cpu().numpy())
+            g_names = [None] * world
+            dist.all_gather_object(g_names, list(mine_names))
+        # inserted sequences of the foreign rows (rare: an INS between supplementary segments of another contig)
+        f_bytes = int(f_len.sum().item())
+        if f_bytes:
+            src = torch.repeat_interleave(seq_off[:-1][fidx] - (torch.cumsum(f_len, 0) - f_len), f_len) + torch.arange(f_bytes, device=dev)
+            f_seq = seq[src]
+        else:
+            f_seq = torch.zeros(0, dtype=torch.uint8, device=dev)
+        cnt2 = _all_gather_counts([int(fidx.numel()), f_bytes], dev)
+        rows = [c[0] for c in cnt2]
+        g_cols = {k: _all_gather_rows(f_cols[k], rows) for k in SIG_COLS}
+        g_len = _all_gather_rows(f_len, rows)
+        g_seq = _all_gather_rows(f_seq, [c[1] for c in cnt2])
+        keep = ~foreign
+        parts_cols = {k: [cols[k][keep]] for k in SIG_COLS}
+        parts_len, parts_seq = [lens[keep]], []
+        kidx = torch.nonzero(keep).flatten()
+        k_bytes = int(lens[keep].sum().item())
+        if k_bytes:
+            kl = lens[kidx]
+            src = torch.repeat_interleave(seq_off[:-1][kidx] - (torch.cumsum(kl, 0) - kl), kl) + torch.arange(k_bytes, device=dev)
+            parts_seq.append(seq[src])
+        for r in range(world):
+            if r == rank or rows[r] == 0:
+                continue
+            oc = owner_contig(g_cols["type"][r], g_cols["contig"][r].long(), g_cols["contig2"][r].long())
+            take = owner_t[oc] == rank
+            if not bool(take.any()):
+                continue
+            tidx = torch.nonzero(take).flatten()
+            for k in SIG_COLS:
+                if k == "read_id" and g_names is not None:
+                    got = [g_names[r][int(i)] for i in tidx.tolist()]
+                    parts_cols[k].append(torch.as_tensor(np.asarray(ids_of(got), dtype=np.int32), device=dev) + read_base)
+                else:
+                    parts_cols[k].append(g_cols[k][r][tidx])
+            tl = g_len[r][tidx]
+            parts_len.append(tl)
+            tb = int(tl.sum().item())
+            if tb:
+                starts = torch.cumsum(g_len[r], 0) - g_len[r]
+                src = torch.repeat_interleave(starts[tidx] - (torch.cumsum(tl, 0) - tl), tl) + torch.arange(tb, device=dev)
+                parts_seq.append(g_seq[r][src])
+        cols = {k: torch.cat(v) for k, v in parts_cols.items()}
+        lens = torch.cat(parts_len)
+        seq = torch.cat(parts_seq) if parts_seq else torch.zeros(0, dtype=torch.uint8, device=dev)
+        # list order = emission order (the partition sort is stable with respect to it): sort by the global key
+        order = torch.sort(cols["key"], stable=True).indices
+        starts = torch.cumsum(lens, 0) - lens
+        cols = {k: v[order] for k, v in cols.items()}
+        ol = lens[order]
+        tot = int(ol.sum().item())
+        if tot:
+            src = torch.repeat_interleave(starts[order] - (torch.cumsum(ol, 0) - ol), ol) + torch.arange(tot, device=dev)
+            seq = seq[src]
+        seq_off = torch.zeros(ol.numel() + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(ol, 0, out=seq_off[1:])
+        n_sig = int(ol.numel())
+        adapter.cluster(params, np.asarray(contig_rank_global, dtype=np.int32), table=(cols, seq_off, seq))
+        local_to_global_contig = None
+    # ---- 3. final candidate gather to rank 0 ----------------------------------------------------------------------------
+    c_cols, members = adapter.fetch_clusters()
+    if local_to_global_contig is not None and int(c_cols["type"].numel()):
+        c_cols = dict(c_cols)
+        c_cols["contig"] = local_to_global_contig[c_cols["contig"].long()].to(torch.int32)
+        c_cols["contig2"] = torch.where(c_cols["contig2"] >= 0, local_to_global_contig[c_cols["contig2"].clamp_min(0).long()].to(torch.int32), c_cols["contig2"])
+    ncl, nmem = int(c_cols["type"].numel()), int(members.numel())
+    if world == 1:
+        allc = [[ncl, nmem, n_sig]]
+    else:
+        allc = _all_gather_counts([ncl, nmem, n_sig], dev)
+    sig_counts = [c[2] for c in allc]
+    sig_base = int(sum(sig_counts[:rank]))
+    members = members.to(torch.int64) + sig_base                           # indices into the rank-major gathered signature table
+    if world == 1:
+        g = {k: v for k, v in c_cols.items()}
+        g_mem = members
+        g_sig = cols if gather_signatures else None
+    else:
+        g = {k: _gather_to_root(c_cols[k], [c[0] for c in allc], rank) for k in CLU_DTYPES}
+        g_mem = _gather_to_root(members, [c[1] for c in allc], rank)
+        g_sig = None
+        if gather_signatures:
+            empty = {k: torch.zeros(0, dtype=_tdtype(SIG_DTYPES[k]), device=dev) for k in SIG_COLS}
+            src = cols if cols is not None else empty
+            g_sig = {k: _gather_to_root(src[k], sig_counts, rank) for k in SIG_COLS}
+    adapter.set_chain(None)
+    if rank != 0:
+        return None
+    # rank-major concatenation -> type-major: a stable sort by type keeps, inside a type, rank order and each rank's own order -
+    # which is the reference's (unilocal: (contig name, (start + end) / 2); bilocal: partition order)
+    sizes = g["size"].to(torch.int64)
+    src_off = torch.cumsum(sizes, 0) - sizes
+    order = torch.sort(g["type"].to(torch.int64), stable=True).indices
+    out_cols = {k: v[order] for k, v in g.items()}
+    out_sizes = sizes[order]
+    n = int(out_sizes.numel())
+    member_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(out_sizes, 0, out=member_off[1:])
+    nm = int(g_mem.numel())
+    src_idx = torch.repeat_interleave(src_off[order] - member_off[:-1], out_sizes) + torch.arange(nm, dtype=torch.int64, device=dev)
+    return StepResult(out_cols, member_off, g_mem[src_idx], g_sig, sig_counts, relay.last)

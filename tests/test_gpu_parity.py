@@ -255,15 +255,16 @@ def test_dropin_api_matches_reference_golden(eng):
         [(30, 50, 40, "DEL"), (70, 50, 50, "INS")]
 
 
-def test_device_pipeline_step_single_rank(eng, oracle):
-    """bench.py's multi-GPU step (device-to-device fetch, RCCL all-gather of the signature tables, sharded clustering,
-    cluster all-gather + merge on the device) with a process group of one rank must reproduce the plain single-GPU result."""
+def test_multigpu_step_single_rank_device_path(eng, oracle):
+    """bench.py's multi-GPU step (svim_amd/multigpu.py: SvxAdapter, everything device-resident, RCCL process group of one rank) must
+    reproduce the plain single-GPU result, both when it clusters the resident table (no foreign rows: the bench layout) and when it
+    is handed a table of device tensors (the route taken after an exchange of foreign rows); the stream relay hook reports where the
+    random.sample streams ended."""
     import os
     import socket
     import torch
     import torch.distributed as dist
-    from svim_amd import devsynth
-    from svim_amd.distributed import device_pipeline_step
+    from svim_amd import multigpu as MG, workloads
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -272,27 +273,52 @@ def test_device_pipeline_step_single_rank(eng, oracle):
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         dev = "cuda:0"
-        b, genome, meta = devsynth.make_batch(n_reads=6000, n50=8000, contig_len=4_000_000, n_sites=80, seed=9, device=dev)
+        prof = workloads.profile("c2", 0.012)
+        b, genome, g_off, meta = workloads.make_batch_full(prof, seed=5, device=dev)
         o = H.options({"min_mapq": 20, "min_sv_size": 40, "max_sv_size": 100000, "segment_gap_tolerance": 10, "segment_overlap_tolerance": 5,
-                       "partition_max_distance": 1000, "position_distance_normalizer": 900, "edit_distance_normalizer": 1.0,
+                       "partition_max_distance": 5000, "position_distance_normalizer": 900, "edit_distance_normalizer": 1.0,
                        "cluster_max_distance": 0.5, "all_bnds": False})
         p = _abi.Params.from_options(o)
-        eng.set_genome(torch.tensor([0, genome.numel()], dtype=torch.int64, device=dev), genome, on_device=True)
+        crank = b.t["contig_rank"].cpu().numpy().astype(np.int32)
+        eng.set_genome(g_off, genome, on_device=True)
         eng.collect(b.struct(), p, fetch=False)
-        direct = eng.cluster(p, np.zeros(1, np.int32), source=0)
+        direct = eng.cluster(p, crank, source=0)
+        sig = eng.fetch_signatures(0)
+        ad = MG.SvxAdapter(eng, dev)
+        gid = np.arange(len(crank))
+        owner = np.zeros(len(crank), dtype=np.int32)
         eng.collect(b.struct(), p, fetch=False)
-        merged_dev = device_pipeline_step(eng, p, 0, 1, dev)
-        merged = merged_dev.to_host()
-        assert merged.n > 50
+        res = MG.cluster_step(ad, p, 0, 1, gid, crank, owner)
+        merged = res.to_host()
+        assert merged.n > 100 and all(c > 0 for c in merged.type_count)
         assert merged.first_difference(direct) is None
-        # and the device-generated batch agrees with the oracle (device pointers in, host tables out)
-        g = genome.cpu().numpy()
-        oracle.set_genome(np.array([0, g.size], dtype=np.int64), g)
+        assert np.array_equal(res.sig_cols["key"].cpu().numpy().view(np.uint64), sig.key[:sig.n])
+        # the table route: the same signatures handed over as device tensors
+        cols, seq_off, seq = ad.fetch_signatures()
+        relay_log = []
+        eng.set_chain(lambda phase, w: relay_log.append((phase, list(w))))
+        ad.cluster(p, crank, table=(cols, seq_off, seq))
+        eng.set_chain(None)
+        again = eng.fetch_clusters()
+        assert again.first_difference(direct) is None
+        assert [ph for ph, _ in relay_log] == [0, 1] and relay_log[0][1] == [0] * 6
+        # continuing every stream from an offset changes the samples of the large partitions - and only because of that offset
+        eng.set_chain(lambda phase, w: w.__setitem__(slice(None), [1000] * 6) if phase == 0 else relay_log.append((2, list(w))))
+        eng.cluster(p, crank, source=0, fetch=False)
+        eng.set_chain(None)
+        ends0, ends1 = relay_log[1][1], relay_log[2][1]
+        assert all((e1 == 1000 and e0 == 0) or e1 > 1000 for e0, e1 in zip(ends0, ends1))
+        # and the device-generated batch agrees with the oracle, relay included
+        oracle.set_genome(g_off.cpu().numpy().astype(np.int64), genome.cpu().numpy())
         hb = b.slice_records(0, b.n_rec)
         osig, _ = oracle.collect(hb, p)
-        oc = oracle.cluster(p, np.zeros(1, np.int32), source=0)
-        assert eng.fetch_signatures(0).first_difference(osig) is None
+        olog = []
+        oracle.set_chain(lambda phase, w: olog.append(list(w)))
+        oc = oracle.cluster(p, hb.contig_rank, source=0)
+        oracle.set_chain(None)
+        assert sig.first_difference(osig) is None
         assert direct.first_difference(oc, rtol=1e-12) is None
+        assert olog[1] == ends0                                          # both engines consumed the streams to the same positions
     finally:
         dist.destroy_process_group()
 
