@@ -89,6 +89,14 @@ typedef struct svx_batch {
     const uint32_t* seg_cigar;
     int32_t n_contig;
     const int32_t*  contig_rank; /* [n_contig] rank of each contig NAME in Python str order */
+    /* optional sparse SEQ (NULL: every record's whole SEQ sits at seq_off): COLLECT reads a record's bases only for reported insertions,
+     * so a reader may keep just those ranges (svx_bam_set_seq_filter).  Record i then owns ranges seq_rng_off[i] .. seq_rng_off[i+1]-1,
+     * range r holds bases seq_rng_q0[r] (even) .. +seq_rng_len[r]-1 of the read, packed from byte seq_rng_byte[r] of seq on. */
+    const uint32_t* seq_rng_off; /* [n_rec+1] */
+    const int32_t*  seq_rng_q0;
+    const int32_t*  seq_rng_len;
+    const uint64_t* seq_rng_byte;
+    int64_t n_seq_rng;
 } svx_batch;
 
 /* Signature table (SoA).  Mirrors the fields of the six Signature classes (src/svim/SVSignature.py:3-233). */
@@ -162,6 +170,14 @@ void* svx_stream(svx_ctx* ctx);                              /* hipStream_t the 
 
 /* ---- COLLECT: replaces analyze_alignment_file_* (src/svim/SVIM_COLLECT.py:96-167) -------------- */
 int  svx_collect(svx_ctx* ctx, const svx_batch* batch, const svx_params* p);
+/* One input file usually arrives as several record batches (svx_bam_read_batch).  With accumulation on (mode 1; it also clears what was
+ * accumulated before) every svx_collect APPENDS its two lists to the lists resident in the context, so that svx_collect_count / _fetch and
+ * svx_cluster(source 0 / 1) see the whole file - the loop of src/svim/SVIM_COLLECT.py:132-167 over all records - without a table ever
+ * leaving HBM.  The emission keys of a batch are shifted by slot_base << 32: pass the number of emission slots of all earlier batches
+ * (2 per record is always enough).  mode 0: back to one batch per call; what was accumulated stays resident as "the result of the last
+ * COLLECT" (count / fetch / svx_cluster source 0 and 1 keep seeing the whole file). */
+int  svx_collect_accumulate(svx_ctx* ctx, int mode);
+int  svx_collect_set_slot_base(svx_ctx* ctx, uint64_t slot_base);
 int  svx_collect_count(svx_ctx* ctx, int64_t* n_sig, int64_t* n_seq_bytes, int64_t* n_bnd_side);
 /* which: 0 = sv_signatures, 1 = translocation_signatures_all_bnds (second list of the reference's tuple) */
 int  svx_collect_fetch(svx_ctx* ctx, int which, svx_sig_view* host_out);
@@ -243,6 +259,11 @@ int  svx_bam_open(const char* path, int n_threads /* 0 = auto */, svx_bam** out)
 void svx_bam_close(svx_bam* h);
 int  svx_bam_header(svx_bam* h, int32_t* n_ref, const char** names_nul_separated, const int32_t** lengths, const char** sort_order);
 int  svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int min_mapq, svx_batch* out, int64_t* n_out);
+/* The arrays of a batch stay valid until the SECOND next svx_bam_read_batch (two sets alternate): the caller can upload / collect batch i
+ * while another thread already reads batch i+1.
+ * svx_bam_set_seq_filter(h, min_ins_len > 0): coordinate mode keeps only the SEQ ranges COLLECT can read - insertions of at least
+ * min_ins_len bases (pass params.min_sv_size) and the whole SEQ of records with an SA tag - and describes them in svx_batch.seq_rng_*. */
+int  svx_bam_set_seq_filter(svx_bam* h, int min_ins_len);
 int  svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** nul_separated, int64_t* blob_len);
 
 #ifdef __cplusplus

@@ -44,9 +44,9 @@ class Oracle(object):
             pass
 
     def collect(self, hb, params):
-        b = hb.struct()
+        b = hb.struct() if hasattr(hb, "struct") else hb
         rc = self.L.svo_collect(self.ctx, C.byref(b), C.byref(params))
-        assert rc == 0
+        assert rc == 0, "svo_collect failed (%d)" % rc
         n, ns, nb = C.c_int64(), C.c_int64(), C.c_int64()
         self.L.svo_collect_count(self.ctx, C.byref(n), C.byref(ns), C.byref(nb))
         out = []

@@ -421,8 +421,15 @@ int svo_collect(svo_ctx* ctx, const svx_batch* b, const svx_params* p) {
     for (int64_t i = 0; i < t->n; i++) {
         if (!t->qlen[i]) continue;
         const uint8_t* s = b->seq + b->seq_off[t->rec[i]];
+        int64_t q0 = t->qpos[i];
+        if (b->seq_rng_off) {                              /* sparse SEQ (svx_batch.seq_rng_*): the range that holds the insertion */
+            s = NULL;
+            for (uint32_t r = b->seq_rng_off[t->rec[i]]; r < b->seq_rng_off[t->rec[i] + 1]; r++)
+                if (b->seq_rng_q0[r] <= q0 && q0 + t->qlen[i] <= (int64_t)b->seq_rng_q0[r] + b->seq_rng_len[r]) { s = b->seq + b->seq_rng_byte[r]; q0 -= b->seq_rng_q0[r]; break; }
+            if (!s) return -3;
+        }
         uint8_t* o = ctx->sig_seq + ctx->sig_seq_off[i];
-        for (int64_t k = 0; k < t->qlen[i]; k++) { int64_t q = t->qpos[i] + k; uint8_t by = s[q >> 1]; o[k] = (q & 1) ? (by & 15) : (by >> 4); }
+        for (int64_t k = 0; k < t->qlen[i]; k++) { int64_t q = q0 + k; uint8_t by = s[q >> 1]; o[k] = (q & 1) ? (by & 15) : (by >> 4); }
     }
     ctx->stats.n_sig = t->n; ctx->stats.n_bnd_side = ctx->bnd.n; ctx->stats.n_ins_bases = tot;
     return 0;

@@ -71,33 +71,23 @@ def _is_bam_path(bam):
         return False
 
 
-def _run_native(path, options, mode, batch_records=2000000):
-    """BAM path: native reader (svim_amd/csrc/bamio.cpp) -> batches of svx_batch -> svx_collect, tables concatenated in
-    file order."""
-    from .bamio import NativeBam
-    from .distributed import concat_sig_tables
-    bam = NativeBam(path)
+def _run_native(path, options, mode, batch_records=200000):
+    """BAM path: native reader (svim_amd/csrc/bamio.cpp) reading batch i+1 while svx_collect works on batch i; the signature lists of
+    all batches accumulate in HBM (svim_amd/harness.py:BamPipeline), so the returned lists still mirror what the device holds and
+    cluster_sv_signatures starts from there."""
+    from .harness import BamPipeline
     eng = _lib.engine()
-    p = _abi.Params.from_options(options)
-    sigs, bnds, n_rec = [], [], 0
-    while True:
-        b, n = bam.read_batch(batch_records, int(getattr(options, "min_mapq", 20)), mode)
-        if n == 0:
-            break
-        n_rec += n
+    pipe = BamPipeline(path, options, eng, batch_records=batch_records, mode=mode)
+    try:
+        n_rec = pipe.run()
         logging.info("Processed read {0}".format(n_rec))
-        s, t = eng.collect(b, p)
-        sigs.append(s)
-        bnds.append(t)
-    names = bam.read_names()
-    refs = bam.references
-    single = len(sigs) == 1
-    sig = (sigs[0] if single else concat_sig_tables(sigs)) if sigs else _abi.SigTable(0)
-    bnd = (bnds[0] if single else concat_sig_tables(bnds)) if bnds else _abi.SigTable(0)
-    bam.close()
-    # one batch: the device still holds exactly these tables (CLUSTER can start from them without an upload)
-    return (SignatureList(sig, refs, names, origin=(eng, eng.collect_generation, 0) if single else None),
-            SignatureList(bnd, refs, names, origin=(eng, eng.collect_generation, 1) if single else None))
+        names = pipe.bam.read_names()
+        refs = pipe.bam.references
+    finally:
+        pipe.close()                       # accumulation off: the accumulated lists stay resident as the last COLLECT result
+    sig, bnd = eng.fetch_signatures(0), eng.fetch_signatures(1)
+    return (SignatureList(sig, refs, names, origin=(eng, eng.collect_generation, 0)),
+            SignatureList(bnd, refs, names, origin=(eng, eng.collect_generation, 1)))
 
 
 def _run(bam, options, mode):

@@ -63,7 +63,8 @@ class Batch(C.Structure):
                 ("order", _P), ("seg_order", _P), ("cigar_off", _P), ("cigar", _P), ("seq_off", _P), ("seq", _P),
                 ("seg_off", _P), ("n_seg", C.c_int64), ("seg_tid", _P), ("seg_pos", _P), ("seg_rev", _P),
                 ("seg_mapq", _P), ("seg_lseq", _P), ("seg_cigar_off", _P), ("seg_cigar", _P),
-                ("n_contig", C.c_int32), ("contig_rank", _P)]
+                ("n_contig", C.c_int32), ("contig_rank", _P),
+                ("seq_rng_off", _P), ("seq_rng_q0", _P), ("seq_rng_len", _P), ("seq_rng_byte", _P), ("n_seq_rng", C.c_int64)]
 
 
 BATCH_DTYPES = dict(flag=np.uint16, tid=np.int32, pos=np.int32, mapq=np.uint8, lseq=np.int32, read_id=np.int32,

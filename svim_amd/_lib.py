@@ -18,12 +18,12 @@ _LIB = None
 _ENGINES = {}
 
 SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream",
-           "svx_collect", "svx_collect_count", "svx_collect_fetch", "svx_set_genome", "svx_cluster",
+           "svx_collect", "svx_collect_count", "svx_collect_fetch", "svx_collect_accumulate", "svx_collect_set_slot_base", "svx_set_genome", "svx_cluster",
            "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_shard", "svx_cluster_fetch_part_index",
            "svx_cluster_set_shard_by_origin", "svx_cluster_remote_members", "svx_cluster_set_chain",
            "svx_set_alignment_index", "svx_genotype",
            "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster",
-           "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names"]
+           "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names", "svx_bam_set_seq_filter"]
 
 
 class SvxError(RuntimeError):
@@ -87,6 +87,14 @@ class Engine(object):
         if not fetch:
             return None
         return self.fetch_signatures(0), self.fetch_signatures(1)
+
+    def accumulate(self, on):
+        """on: every following collect() appends to the resident signature lists (the batches of one file); off: one batch per call"""
+        _check(self.L.svx_collect_accumulate(self.ctx, C.c_int(1 if on else 0)), "svx_collect_accumulate")
+        self.collect_generation += 1
+
+    def set_slot_base(self, base):
+        _check(self.L.svx_collect_set_slot_base(self.ctx, C.c_uint64(int(base))), "svx_collect_set_slot_base")
 
     def collect_counts(self):
         n, ns, nb = C.c_int64(), C.c_int64(), C.c_int64()

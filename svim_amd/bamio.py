@@ -43,6 +43,12 @@ class NativeBam(object):
 
     get_reference_name = getrname
 
+    def set_seq_filter(self, min_ins_len):
+        """coordinate mode: keep only the SEQ ranges COLLECT can read (svx_bam_set_seq_filter); pass options.min_sv_size"""
+        rc = self.L.svx_bam_set_seq_filter(self.h, C.c_int(int(min_ins_len)))
+        if rc != 0:
+            raise SvxError("svx_bam_set_seq_filter failed")
+
     def read_batch(self, max_records, min_mapq, mode="coordinate"):
         """-> (svx_batch struct with host pointers owned by the reader, n_records); n_records == 0 at EOF."""
         b = _abi.Batch()
@@ -74,6 +80,11 @@ class NativeBam(object):
         A["seg_cigar_off"] = arr(b.seg_cigar_off, ns + 1, np.uint64)
         A["seg_cigar"] = arr(b.seg_cigar, int(A["seg_cigar_off"][-1]) if ns else 0, np.uint32)
         A["contig_rank"] = arr(b.contig_rank, b.n_contig, np.int32)
+        if b.seq_rng_off:
+            nr = int(b.n_seq_rng)
+            A["seq_rng_off"] = arr(b.seq_rng_off, n + 1, np.uint32)
+            A["seq_rng_q0"], A["seq_rng_len"] = arr(b.seq_rng_q0, nr, np.int32), arr(b.seq_rng_len, nr, np.int32)
+            A["seq_rng_byte"] = arr(b.seq_rng_byte, nr, np.uint64)
         return A
 
     def read_names(self):

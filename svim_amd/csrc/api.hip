@@ -1,5 +1,6 @@
 // api.hip - the extern "C" boundary of libsvx.so (include/svx.h).
 #include "common.hpp"
+#include <utility>
 #include <cstdlib>
 
 thread_local std::string g_svx_err;
@@ -67,6 +68,29 @@ static int upload(svx_ctx* c, DevBuf& d, const void* host, size_t bytes, size_t 
 }
 
 // ---- COLLECT -----------------------------------------------------------------------------------------------
+__global__ void k_acc_fix(long long n, uint64_t* key, uint64_t key_add, int64_t* seq_off_dst, const int64_t* seq_off_src, int64_t seq_add) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] += key_add;
+    if (i <= n) seq_off_dst[i] = seq_off_src[i] + seq_add;
+}
+
+// append the batch table `s` (sorted by key) to the accumulator: keys shifted by the batch's slot base, sequence offsets by the bases held so far
+static int append_sigs(svx_ctx* c, DevSigs& acc, DevSigs& s) {
+    hipStream_t st = c->stream;
+    const int64_t n = s.n, at = acc.n;
+    SVXCHK(acc.reserve_keep(at + n + 1, st));
+    SVXCHK(acc.seq.reserve((size_t)(acc.n_seq + s.n_seq) + 16, true, st));
+#define APP(f, w) do { if (n) HIPCHK(hipMemcpyAsync(acc.f.as<char>() + (size_t)at * (w), s.f.p, (size_t)n * (w), hipMemcpyDeviceToDevice, st)); } while (0)
+    APP(key, 8); APP(type, 1); APP(src, 1); APP(aux, 1); APP(contig, 4); APP(start, 4); APP(end, 4); APP(contig2, 4); APP(pos2, 4); APP(read_id, 4);
+#undef APP
+    if (s.n_seq) HIPCHK(hipMemcpyAsync(acc.seq.as<char>() + acc.n_seq, s.seq.p, (size_t)s.n_seq, hipMemcpyDeviceToDevice, st));
+    k_acc_fix<<<(unsigned)((n + 1 + 255) / 256), 256, 0, st>>>(n, acc.key.as<uint64_t>() + at, c->slot_base << 32, acc.seq_off.as<int64_t>() + at,
+                                                              s.seq_off.as<int64_t>(), acc.n_seq);
+    HIPCHK(hipGetLastError());
+    acc.n = at + n; acc.n_seq += s.n_seq;
+    return SVX_OK;
+}
+
 extern "C" int svx_collect(svx_ctx* c, const svx_batch* b, const svx_params* p) {
     if (!c || !b || !p) return svx_fail(SVX_E_ARG, "null argument", __FILE__, __LINE__, hipSuccess);
     HIPCHK(hipSetDevice(c->device));
@@ -76,7 +100,7 @@ extern "C" int svx_collect(svx_ctx* c, const svx_batch* b, const svx_params* p) 
         const size_t n = (size_t)b->n_rec, ns = (size_t)b->n_seg;
         const size_t n_ops = n ? (size_t)b->cigar_off[n] : 0, n_seq = n ? (size_t)b->seq_off[n] : 0;
         const size_t n_sops = ns ? (size_t)b->seg_cigar_off[ns] : 0;
-        if (c->batch_bufs.size() < 21) c->batch_bufs.resize(21);
+        if (c->batch_bufs.size() < 25) c->batch_bufs.resize(25);
         auto& B = c->batch_bufs;
         SVXCHK(upload(c, B[0], b->flag, n * 2)); d.flag = B[0].as<uint16_t>();
         SVXCHK(upload(c, B[1], b->tid, n * 4)); d.tid = B[1].as<int32_t>();
@@ -99,21 +123,65 @@ extern "C" int svx_collect(svx_ctx* c, const svx_batch* b, const svx_params* p) 
         SVXCHK(upload(c, B[18], b->seg_cigar_off, (ns + 1) * 8)); d.seg_cigar_off = B[18].as<uint64_t>();
         SVXCHK(upload(c, B[19], b->seg_cigar, n_sops * 4)); d.seg_cigar = B[19].as<uint32_t>();
         SVXCHK(upload(c, B[20], b->contig_rank, (size_t)b->n_contig * 4)); d.contig_rank = B[20].as<int32_t>();
+        if (b->seq_rng_off) {
+            const size_t nr = (size_t)b->n_seq_rng;
+            SVXCHK(upload(c, B[21], b->seq_rng_off, (n + 1) * 4)); d.seq_rng_off = B[21].as<uint32_t>();
+            SVXCHK(upload(c, B[22], b->seq_rng_q0, nr * 4)); d.seq_rng_q0 = B[22].as<int32_t>();
+            SVXCHK(upload(c, B[23], b->seq_rng_len, nr * 4)); d.seq_rng_len = B[23].as<int32_t>();
+            SVXCHK(upload(c, B[24], b->seq_rng_byte, nr * 8)); d.seq_rng_byte = B[24].as<uint64_t>();
+        }
         d.on_device = 1;
     }
-    return svx_collect_impl(c, &d, p);
+    SVXCHK(svx_collect_impl(c, &d, p));
+    if (c->accumulate) {
+        SVXCHK(append_sigs(c, c->acc_sig, c->sig));
+        SVXCHK(append_sigs(c, c->acc_bnd, c->bnd));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return SVX_OK;
+}
+
+// One input file usually arrives as several record batches (svx_bam_read_batch): with accumulation on, every svx_collect APPENDS its
+// two signature lists to the lists resident in the context - keys are made global by `slot_base` (the caller passes the number of
+// emission slots of all earlier batches, 2 per record is always enough) - so that svx_cluster(source 0 / 1) sees the whole file without
+// the tables ever leaving HBM.  mode 1 starts a fresh accumulation, 0 returns to one-batch-per-call semantics.
+extern "C" int svx_collect_accumulate(svx_ctx* c, int mode) {
+    if (!c) return svx_fail(SVX_E_ARG, "null context", __FILE__, __LINE__, hipSuccess);
+    if (c->accumulate && mode == 0) {
+        // the accumulated lists become "the result of the last COLLECT": svx_collect_count / _fetch / svx_cluster(source 0 / 1) keep seeing
+        // the whole file after accumulation is switched off (buffers are exchanged, nothing is copied)
+        auto promote = [](DevSigs& s, DevSigs& a) {
+            std::swap(s.key, a.key); std::swap(s.type, a.type); std::swap(s.src, a.src); std::swap(s.aux, a.aux); std::swap(s.contig, a.contig);
+            std::swap(s.start, a.start); std::swap(s.end, a.end); std::swap(s.contig2, a.contig2); std::swap(s.pos2, a.pos2); std::swap(s.read_id, a.read_id);
+            std::swap(s.seq_off, a.seq_off); std::swap(s.seq, a.seq);
+            const int64_t cap = s.cap < a.cap ? s.cap : a.cap;         // every buffer of either table holds at least this many rows
+            s.n = a.n; s.n_seq = a.n_seq; s.cap = cap; a.cap = cap;
+        };
+        promote(c->sig, c->acc_sig); promote(c->bnd, c->acc_bnd);
+    }
+    c->accumulate = mode != 0;
+    c->acc_sig.n = c->acc_sig.n_seq = 0; c->acc_bnd.n = c->acc_bnd.n_seq = 0;
+    c->slot_base = 0;
+    return SVX_OK;
+}
+extern "C" int svx_collect_set_slot_base(svx_ctx* c, uint64_t slot_base) {
+    if (!c) return svx_fail(SVX_E_ARG, "null context", __FILE__, __LINE__, hipSuccess);
+    c->slot_base = slot_base;
+    return SVX_OK;
 }
 
 extern "C" int svx_collect_count(svx_ctx* c, int64_t* n_sig, int64_t* n_seq, int64_t* n_bnd) {
-    if (n_sig) *n_sig = c->sig.n;
-    if (n_seq) *n_seq = c->sig.n_seq;
-    if (n_bnd) *n_bnd = c->bnd.n;
+    const DevSigs& s = c->accumulate ? c->acc_sig : c->sig;
+    const DevSigs& b = c->accumulate ? c->acc_bnd : c->bnd;
+    if (n_sig) *n_sig = s.n;
+    if (n_seq) *n_seq = s.n_seq;
+    if (n_bnd) *n_bnd = b.n;
     return SVX_OK;
 }
 
 extern "C" int svx_collect_fetch(svx_ctx* c, int which, svx_sig_view* o) {
     HIPCHK(hipSetDevice(c->device));
-    DevSigs& s = which ? c->bnd : c->sig;
+    DevSigs& s = c->accumulate ? (which ? c->acc_bnd : c->acc_sig) : (which ? c->bnd : c->sig);
     const size_t n = (size_t)s.n;
     hipStream_t st = c->stream;
     // o->on_device: the caller's arrays live in HBM (e.g. torch tensors feeding an RCCL all-gather) -> device-to-device copies
@@ -154,7 +222,7 @@ extern "C" int svx_cluster(svx_ctx* c, int source, const svx_sig_view* sigs, int
     SVXCHK(upload(c, c->c_rank, contig_rank_host, (size_t)n_contig * 4));
     ClusterIn in;
     if (source == 0 || source == 1) {
-        DevSigs& s = source ? c->bnd : c->sig;
+        DevSigs& s = c->accumulate ? (source ? c->acc_bnd : c->acc_sig) : (source ? c->bnd : c->sig);
         in.n = s.n; in.type = s.type.as<uint8_t>(); in.aux = s.aux.as<uint8_t>(); in.contig = s.contig.as<int32_t>(); in.start = s.start.as<int32_t>();
         in.end = s.end.as<int32_t>(); in.contig2 = s.contig2.as<int32_t>(); in.pos2 = s.pos2.as<int32_t>(); in.read_id = s.read_id.as<int32_t>();
         in.seq_off = s.seq_off.as<int64_t>(); in.seq = s.seq.as<uint8_t>();

@@ -19,6 +19,9 @@
 #include <thread>
 #include <unordered_map>
 #include <vector>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include "../../include/svx.h"
 
 extern thread_local std::string g_svx_err;
@@ -52,6 +55,51 @@ template <class T> struct RawVec {
     const T& operator[](size_t i) const { return p[i]; }
 };
 
+// Persistent worker threads: a chunk of BGZF blocks inflates in about a millisecond on a many-core host, so spawning threads per chunk
+// would cost as much as the work.  run(n, fn) executes fn(0..n-1) on the pool (the caller takes part) and returns when all are done.
+struct Pool {
+    std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
+    std::function<void(int)> job; int n_tasks = 0, next = 0, running = 0; unsigned long long gen = 0; bool stop = false;
+    explicit Pool(int n) {
+        for (int i = 0; i < n; i++) th.emplace_back([this]() {
+            unsigned long long seen = 0;
+            for (;;) {
+                std::unique_lock<std::mutex> lk(m);
+                cv_go.wait(lk, [&]() { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                while (next < n_tasks) { const int t = next++; lk.unlock(); job(t); lk.lock(); }
+                if (--running == 0) cv_done.notify_all();
+            }
+        });
+    }
+    ~Pool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv_go.notify_all(); for (auto& t : th) t.join(); }
+    void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (th.empty() || n == 1) { for (int t = 0; t < n; t++) fn(t); return; }
+        std::unique_lock<std::mutex> lk(m);
+        job = fn; n_tasks = n; next = 0; running = (int)th.size() + 1; gen++;
+        cv_go.notify_all();
+        while (next < n_tasks) { const int t = next++; lk.unlock(); fn(t); lk.lock(); }
+        if (--running != 0) cv_done.wait(lk, [&]() { return running == 0; });
+    }
+};
+
+// the arrays of one record batch; the reader owns TWO sets and alternates between them, so that the batch handed out by
+// svx_bam_read_batch stays valid while the next one is being read (the caller overlaps its upload / COLLECT with the next read)
+struct BatchArrays {
+    std::vector<uint16_t> flag; std::vector<int32_t> tid, bpos, lseq, read_id; std::vector<uint8_t> mapq;
+    std::vector<uint32_t> order, seg_order, seg_off, seg_cigar;
+    RawVec<uint32_t> cigar; RawVec<uint8_t> seq;
+    std::vector<uint64_t> cigar_off, seq_off, seg_cigar_off;
+    std::vector<uint8_t> seg_rev, seg_mapq;
+    std::vector<int32_t> seg_tid, seg_pos, seg_lseq;
+    // sparse SEQ (svx_bam_set_seq_filter): the stored ranges of every record
+    std::vector<uint32_t> rng_off; std::vector<int32_t> rng_q0, rng_len; std::vector<uint64_t> rng_byte;
+    // per-record SA strings of the current batch (offset, length into sa_blob; length 0 = none)
+    std::string sa_blob; std::vector<uint64_t> sa_at; std::vector<uint32_t> sa_len;
+};
+
 struct svx_bam {
     FILE* f = nullptr;
     std::string path, sort_order, names_blob;
@@ -66,17 +114,14 @@ struct svx_bam {
     // the unconsumed tail of the old one (a partial record) in front of the new data instead of copying the chunk.
     std::future<void> prefetch; bool prefetch_active = false; RawVec<uint8_t> next; size_t next_len = 0; bool next_eof = false; std::string prefetch_err;
     int n_threads = 8;
-    size_t win_head = (size_t)8 << 20, chunk_blocks = 1024;      // test hooks: SVX_BAM_WIN_HEAD (bytes), SVX_BAM_CHUNK_BLOCKS
+    size_t win_head = (size_t)8 << 20, chunk_blocks = 1024, chunk_bytes = (size_t)48 << 20;      // test hooks: SVX_BAM_WIN_HEAD (bytes), SVX_BAM_CHUNK_BLOCKS
     double t_wait = 0, t_copy = 0, t_walk = 0, t_decode = 0, t_intern = 0, t_post = 0;       // SVX_BAM_TIMING=1: seconds per stage, printed at close
-    // batch arrays
-    std::vector<uint16_t> flag; std::vector<int32_t> tid, bpos, lseq, read_id; std::vector<uint8_t> mapq;
-    std::vector<uint32_t> order, seg_order, seg_off, seg_cigar;
-    RawVec<uint32_t> cigar; RawVec<uint8_t> seq;
-    std::vector<uint64_t> cigar_off, seq_off, seg_cigar_off;
-    std::vector<uint8_t> seg_rev, seg_mapq;
-    std::vector<int32_t> seg_tid, seg_pos, seg_lseq;
-    // per-record SA strings of the current batch (offset, length into sa_blob; length 0 = none)
-    std::string sa_blob; std::vector<uint64_t> sa_at; std::vector<uint32_t> sa_len;
+    BatchArrays ba[2]; BatchArrays* b = &ba[0];
+    Pool* pool = nullptr; Pool* pool_inflate = nullptr;
+    int seq_min_ins = 0;            // > 0: sparse SEQ (coordinate mode): only insertions of at least this length + whole split-read primaries
+    struct KeptRange { uint32_t rec; int32_t q0, len; };
+    std::vector<std::vector<KeptRange>> t_ranges;          // per decode task
+    std::vector<uint32_t> t_rng_cnt; std::vector<uint64_t> t_seq_bytes;
     std::vector<uint32_t> name_id_tmp;
     struct RecRef { const uint8_t* r; const uint8_t* end; const uint8_t* cig; uint32_t n_cig; };
     std::vector<RecRef> refs; std::vector<const char*> t_name, t_sa; std::vector<uint32_t> t_name_len, t_sa_len;
@@ -130,7 +175,8 @@ static void inflate_next_chunk(svx_bam* h) {
         std::vector<RawBlock> blocks;
         size_t total = 0;
         h->next_eof = false;
-        while (blocks.size() < h->chunk_blocks && total < (48u << 20)) {
+        const size_t max_bytes = h->chunk_bytes;
+        while (blocks.size() < h->chunk_blocks && total < max_bytes) {
             RawBlock b;
             if (!read_block(h, b)) { h->next_eof = true; break; }
             b.out_at = total; total += b.isize;
@@ -138,15 +184,13 @@ static void inflate_next_chunk(svx_bam* h) {
         }
         h->next.resize_uninit(WIN_HEAD + total);
         h->next_len = total;
-        const int T = std::max(1, std::min<int>(h->n_threads, (int)blocks.size()));
-        std::vector<std::thread> th;
-        std::vector<std::string> errs((size_t)T);
-        for (int t = 0; t < T; t++)
-            th.emplace_back([&, t]() {
-                try { for (size_t i = (size_t)t; i < blocks.size(); i += (size_t)T) inflate_block(blocks[i], h->next.data() + WIN_HEAD + blocks[i].out_at); }
-                catch (const std::string& e) { errs[(size_t)t] = e; }
-            });
-        for (auto& x : th) x.join();
+        // blocks in runs of 8 per task: dynamic scheduling over the pool evens out the cost differences between blocks
+        const int n_tasks = (int)((blocks.size() + 7) / 8);
+        std::vector<std::string> errs((size_t)std::max(1, n_tasks));
+        h->pool_inflate->run(n_tasks, [&](int t) {
+            try { for (size_t i = (size_t)t * 8; i < blocks.size() && i < (size_t)(t + 1) * 8; i++) inflate_block(blocks[i], h->next.data() + WIN_HEAD + blocks[i].out_at); }
+            catch (const std::string& e) { errs[(size_t)t] = e; }
+        });
         for (auto& e : errs) if (!e.empty()) throw e;
     } catch (const std::string& e) { h->prefetch_err = e; }
 }
@@ -196,9 +240,14 @@ static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] <
 extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out) {
     svx_bam* h = new svx_bam();
     h->path = path;
-    h->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    h->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
+    // a chunk must keep every worker busy for a while: ~4 MB of inflated data per thread
+    h->chunk_bytes = std::max<size_t>((size_t)48 << 20, (size_t)h->n_threads * ((size_t)4 << 20));
+    h->chunk_blocks = std::max<size_t>(1024, h->chunk_bytes / 48000);
     { const char* e = getenv("SVX_BAM_WIN_HEAD"); if (e && atoll(e) >= 0) h->win_head = (size_t)atoll(e); }
     { const char* e = getenv("SVX_BAM_CHUNK_BLOCKS"); if (e && atoll(e) > 0) h->chunk_blocks = (size_t)atoll(e); }
+    h->pool = new Pool(h->n_threads - 1);                 // record decode (the calling thread takes part)
+    h->pool_inflate = new Pool(h->n_threads - 1);         // BGZF inflate of the NEXT chunk, concurrently with the decode of this one
     h->f = fopen(path, "rb");
     if (!h->f) { delete h; return bam_fail(SVX_E_ARG, std::string("cannot open ") + path); }
     try {
@@ -232,7 +281,7 @@ extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out) {
         std::sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return h->ref_names[(size_t)a] < h->ref_names[(size_t)b]; });
         h->contig_rank.assign(n_ref ? n_ref : 1, 0);
         for (uint32_t r = 0; r < n_ref; r++) h->contig_rank[(size_t)idx[r]] = (int32_t)r;
-    } catch (const std::string& e) { if (h->prefetch_active) h->prefetch.wait(); fclose(h->f); delete h; return bam_fail(SVX_E_ARG, e); }
+    } catch (const std::string& e) { if (h->prefetch_active) h->prefetch.wait(); fclose(h->f); delete h->pool; delete h->pool_inflate; delete h; return bam_fail(SVX_E_ARG, e); }
     *out = h;
     return SVX_OK;
 }
@@ -244,7 +293,19 @@ extern "C" void svx_bam_close(svx_bam* h) {
         fprintf(stderr, "bamio %d threads: wait for inflate %.3f s, window copy %.3f, record walk %.3f, decode %.3f, names + SA %.3f\n", h->n_threads,
                 h->t_wait, h->t_copy, h->t_walk, h->t_decode, h->t_intern);
     if (h->f) fclose(h->f);
+    delete h->pool; delete h->pool_inflate;
     delete h;
+}
+
+// Sparse SEQ for coordinate-sorted input: COLLECT reads a record's bases only for the insertions it reports (CIGAR I of at least
+// min_sv_size, src/svim/SVIM_intra.py:24-27,41-47) and - for a primary with an SA tag - for the read gap between two segments
+// (src/svim/SVIM_inter.py:85,91).  With min_ins_len > 0 the reader keeps exactly those ranges (whole SEQ for records carrying an SA
+// tag) and describes them in svx_batch.seq_rng_*; about 2 % of the bases of an ONT file survive, which is what then crosses PCIe.
+// 0 (default): every record's full SEQ, seq_rng_off = NULL.  Query-name mode always keeps everything.
+extern "C" int svx_bam_set_seq_filter(svx_bam* h, int min_ins_len) {
+    if (!h) return bam_fail(SVX_E_ARG, "null reader");
+    h->seq_min_ins = min_ins_len > 0 ? min_ins_len : 0;
+    return SVX_OK;
 }
 
 extern "C" int svx_bam_header(svx_bam* h, int32_t* n_ref, const char** names_blob, const int32_t** lengths, const char** sort_order) {
@@ -282,9 +343,9 @@ static int append_sa(svx_bam* h, const char* sa, size_t len, int32_t primary_lse
                 fld(5, s, n); if (!parse_int(s, n, nm)) return bam_fail(SVX_E_ARG, "malformed SA tag (NM)");
                 if (mq < 0 || mq > 255) mq = 0;
                 auto it = h->tid_of.find(rname);
-                h->seg_tid.push_back(it == h->tid_of.end() ? -1 : it->second);
-                h->seg_pos.push_back((int32_t)(pos - 1)); h->seg_rev.push_back(rev ? 1 : 0); h->seg_mapq.push_back((uint8_t)mq);
-                h->seg_lseq.push_back(primary_lseq);
+                h->b->seg_tid.push_back(it == h->tid_of.end() ? -1 : it->second);
+                h->b->seg_pos.push_back((int32_t)(pos - 1)); h->b->seg_rev.push_back(rev ? 1 : 0); h->b->seg_mapq.push_back((uint8_t)mq);
+                h->b->seg_lseq.push_back(primary_lseq);
                 long long num = 0; bool have = false;
                 if (!(cn == 1 && cs[0] == '*')) {
                     for (size_t i = 0; i < cn; i++) {
@@ -293,12 +354,12 @@ static int append_sa(svx_bam* h, const char* sa, size_t len, int32_t primary_lse
                         else {
                             const char* ops = "MIDNSHP=XB"; const char* q = strchr(ops, ch);
                             if (!q || !have) return bam_fail(SVX_E_ARG, "malformed CIGAR in SA tag");
-                            h->seg_cigar.push_back((uint32_t)(num << 4) | (uint32_t)(q - ops)); num = 0; have = false;
+                            h->b->seg_cigar.push_back((uint32_t)(num << 4) | (uint32_t)(q - ops)); num = 0; have = false;
                         }
                     }
                     if (have) return bam_fail(SVX_E_ARG, "malformed CIGAR in SA tag");
                 }
-                h->seg_cigar_off.push_back(h->seg_cigar.size());
+                h->b->seg_cigar_off.push_back(h->b->seg_cigar.size());
             } else {
                 fprintf(stderr, "WARNING: SA tag does not consist of 6 fields. This could be a sign of invalid characters "
                                 "(e.g. commas or semicolons) in a chromosome name of the reference genome.\n");
@@ -329,18 +390,19 @@ static void scan_aux(const uint8_t* q, const uint8_t* end, const char*& sa, size
     }
 }
 
-// Bulk decode: every complete record in the window (at most max_count) -> batch arrays.  Three phases: (1) serial walk over the
-// block_size fields sizes the arrays (prefix sums of CIGAR ops and packed sequence bytes), (2) the records are decoded by n_threads
-// workers into their slots (numeric fields, CIGAR words, packed bases, SA / name pointers), (3) serial: read names are interned in
-// record order and the SA strings copied.  Returns the number of records decoded (0: no complete record in the window).
-static int64_t decode_run(svx_bam* h, int64_t max_count) {
+// Bulk decode: every complete record in the window (at most max_count) -> batch arrays.  (1) a serial walk over the block_size fields
+// finds the records and sizes the CIGAR array; (2) the pool decodes the records in runs of 256 (numeric fields, CIGAR words, SA / name
+// pointers) and plans which SEQ ranges to keep; (3) prefix sums over the plan; (4) the pool copies the kept bases; (5) serial: read names
+// are interned in record order and the SA strings copied.  Returns the number of records decoded (0: no complete record in the window).
+static int64_t decode_run(svx_bam* h, int64_t max_count, bool sparse) {
     auto& refs = h->refs;
     refs.clear();
     double t0 = now_s();
+    BatchArrays& B = *h->b;
     const uint8_t* buf = h->buf.data();
     size_t p = h->pos;
     const size_t end = h->buf.size();
-    uint64_t cig_total = h->cigar.size(), seq_total = h->seq.size();
+    uint64_t cig_total = B.cigar.size();
     while ((int64_t)refs.size() < max_count && p + 4 <= end) {
         const uint32_t bs = rd32(buf + p);
         if (p + 4 + (size_t)bs > end) break;
@@ -358,49 +420,93 @@ static int64_t decode_run(svx_bam* h, int64_t max_count) {
             scan_aux(rr.cig + 8 + (l_seq + 1) / 2 + l_seq, rr.end, sa, sa_n, cg, cg_n);
             if (cg) { rr.cig = cg; rr.n_cig = cg_n; }
         }
-        cig_total += rr.n_cig; seq_total += (l_seq + 1) / 2;
-        h->cigar_off.push_back(cig_total); h->seq_off.push_back(seq_total);
+        cig_total += rr.n_cig;
+        B.cigar_off.push_back(cig_total);
         refs.push_back(rr);
         p += 4 + (size_t)bs;
     }
     const size_t n = refs.size();
     if (n == 0) return 0;
     h->t_walk += now_s() - t0; t0 = now_s();
-    const size_t base = h->flag.size();
-    h->flag.resize(base + n); h->tid.resize(base + n); h->bpos.resize(base + n); h->mapq.resize(base + n); h->lseq.resize(base + n);
-    h->read_id.resize(base + n); h->sa_at.resize(base + n); h->sa_len.resize(base + n);
+    const size_t base = B.flag.size();
+    B.flag.resize(base + n); B.tid.resize(base + n); B.bpos.resize(base + n); B.mapq.resize(base + n); B.lseq.resize(base + n);
+    B.read_id.resize(base + n); B.sa_at.resize(base + n); B.sa_len.resize(base + n);
     h->t_name.resize(n); h->t_name_len.resize(n); h->t_sa.resize(n); h->t_sa_len.resize(n);
-    h->cigar.resize_uninit(cig_total); h->seq.resize_uninit(seq_total);
-    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)h->n_threads, n / 16 + 1));
-    std::vector<std::string> errs((size_t)T);
-    auto work = [&](int t) {
+    B.cigar.resize_uninit(cig_total);
+    const size_t RUN = 256;
+    const int n_tasks = (int)((n + RUN - 1) / RUN);
+    h->t_ranges.resize((size_t)n_tasks);
+    h->t_rng_cnt.assign(n, 0); h->t_seq_bytes.assign(n, 0);
+    std::vector<std::string> errs((size_t)n_tasks);
+    const int min_ins = h->seq_min_ins;
+    h->pool->run(n_tasks, [&](int t) {
         try {
-            for (size_t i = n * (size_t)t / (size_t)T; i < n * (size_t)(t + 1) / (size_t)T; i++) {
+            auto& kept = h->t_ranges[(size_t)t];
+            kept.clear();
+            for (size_t i = (size_t)t * RUN; i < n && i < (size_t)(t + 1) * RUN; i++) {
                 const svx_bam::RecRef& rr = refs[i];
                 const uint8_t* r = rr.r;
                 const size_t k = base + i;
                 const unsigned l_name = r[8];
                 const uint32_t l_seq = rd32(r + 16);
-                h->tid[k] = (int32_t)rd32(r); h->bpos[k] = (int32_t)rd32(r + 4); h->mapq[k] = r[9];
-                h->flag[k] = (uint16_t)(rd16(r + 14) & 0x0fff); h->lseq[k] = (int32_t)l_seq;
+                B.tid[k] = (int32_t)rd32(r); B.bpos[k] = (int32_t)rd32(r + 4); B.mapq[k] = r[9];
+                B.flag[k] = (uint16_t)(rd16(r + 14) & 0x0fff); B.lseq[k] = (int32_t)l_seq;
                 h->t_name[i] = (const char*)r + 32; h->t_name_len[i] = l_name ? l_name - 1 : 0;
                 const uint8_t* q = r + 32 + l_name + 4 * (size_t)rd16(r + 12);       // the record's own CIGAR field, CG or not
-                uint32_t* cw = h->cigar.data() + h->cigar_off[k];
-                for (uint32_t c = 0; c < rr.n_cig; c++) cw[c] = rd32(rr.cig + 4 * (size_t)c);
-                memcpy(h->seq.data() + h->seq_off[k], q, (l_seq + 1) / 2);
                 const char* sa; size_t sa_n; const uint8_t* cg; uint32_t cg_n;
                 scan_aux(q + (l_seq + 1) / 2 + l_seq, rr.end, sa, sa_n, cg, cg_n);
                 h->t_sa[i] = sa; h->t_sa_len[i] = (uint32_t)sa_n;
+                uint32_t* cw = B.cigar.data() + B.cigar_off[k];
+                if (!sparse || sa_n || l_seq == 0) {
+                    for (uint32_t c = 0; c < rr.n_cig; c++) cw[c] = rd32(rr.cig + 4 * (size_t)c);
+                    if (l_seq) { kept.push_back({(uint32_t)i, 0, (int32_t)l_seq}); h->t_rng_cnt[i] = 1; h->t_seq_bytes[i] = (l_seq + 1) / 2; }
+                } else {
+                    // walk the query offset along the CIGAR (M, I, S, =, X consume stored bases) and keep what a reported insertion reads
+                    uint32_t qpos = 0, cnt = 0; uint64_t bytes = 0;
+                    for (uint32_t c = 0; c < rr.n_cig; c++) {
+                        const uint32_t w = rd32(rr.cig + 4 * (size_t)c);
+                        cw[c] = w;
+                        const uint32_t op = w & 15u, len = w >> 4;
+                        if (op == 1 && (int)len >= min_ins) {
+                            const uint32_t q0 = qpos & ~1u;                              // whole bytes: ranges start at an even base
+                            uint32_t q1 = qpos + len; if (q1 > l_seq) q1 = l_seq;
+                            if (q1 > q0) { kept.push_back({(uint32_t)i, (int32_t)q0, (int32_t)(q1 - q0)}); cnt++; bytes += (q1 - q0 + 1) / 2; }
+                        }
+                        if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qpos += len;
+                    }
+                    h->t_rng_cnt[i] = cnt; h->t_seq_bytes[i] = bytes;
+                }
             }
         } catch (const std::string& e) { errs[(size_t)t] = e; }
-    };
-    if (T == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++) th.emplace_back(work, t);
-        for (auto& x : th) x.join();
-    }
+    });
     for (auto& e : errs) if (!e.empty()) throw e;
+    // (3) offsets of the kept ranges and their bytes
+    uint64_t seq_total = B.seq.size();
+    uint32_t rng_total = (uint32_t)B.rng_q0.size();
+    for (size_t i = 0; i < n; i++) {
+        rng_total += h->t_rng_cnt[i]; seq_total += h->t_seq_bytes[i];
+        B.rng_off.push_back(rng_total); B.seq_off.push_back(seq_total);
+    }
+    B.rng_q0.resize(rng_total); B.rng_len.resize(rng_total); B.rng_byte.resize(rng_total);
+    B.seq.resize_uninit(seq_total);
+    // (4) copy the kept bases
+    h->pool->run(n_tasks, [&](int t) {
+        const auto& kept = h->t_ranges[(size_t)t];
+        size_t j = 0;
+        while (j < kept.size()) {
+            const size_t i = kept[j].rec, k = base + i;
+            const svx_bam::RecRef& rr = refs[i];
+            const uint8_t* sq = rr.r + 32 + rr.r[8] + 4 * (size_t)rd16(rr.r + 12);
+            uint32_t slot = B.rng_off[k];                     // rng_off[k] = first range of record k (rng_off has a leading 0)
+            uint64_t at = B.seq_off[k];
+            for (; j < kept.size() && kept[j].rec == i; j++, slot++) {
+                const uint32_t nb = ((uint32_t)kept[j].len + 1) / 2;
+                memcpy(B.seq.data() + at, sq + kept[j].q0 / 2, nb);
+                B.rng_q0[slot] = kept[j].q0; B.rng_len[slot] = kept[j].len; B.rng_byte[slot] = at;
+                at += nb;
+            }
+        }
+    });
     h->t_decode += now_s() - t0; t0 = now_s();
     for (size_t i = 0; i < n; i++) {
         const std::string name(h->t_name[i], h->t_name_len[i]);
@@ -412,9 +518,9 @@ static int64_t decode_run(svx_bam* h, int64_t max_count) {
             h->read_name_off.push_back(h->read_names_blob.size());
             h->read_names_blob += name; h->read_names_blob.push_back('\0');
         } else rid = it->second;
-        h->read_id[base + i] = rid;
-        h->sa_at[base + i] = h->sa_blob.size(); h->sa_len[base + i] = h->t_sa_len[i];
-        if (h->t_sa_len[i]) h->sa_blob.append(h->t_sa[i], h->t_sa_len[i]);
+        B.read_id[base + i] = rid;
+        B.sa_at[base + i] = B.sa_blob.size(); B.sa_len[base + i] = h->t_sa_len[i];
+        if (h->t_sa_len[i]) B.sa_blob.append(h->t_sa[i], h->t_sa_len[i]);
     }
     h->pos = p;
     h->t_intern += now_s() - t0;
@@ -451,24 +557,26 @@ static int parse_record(svx_bam* h) {
         h->read_name_off.push_back(h->read_names_blob.size());
         h->read_names_blob += name; h->read_names_blob.push_back('\0');
     } else rid = it->second;
-    h->flag.push_back((uint16_t)(flag & 0x0fff)); h->tid.push_back(tid); h->bpos.push_back(pos); h->mapq.push_back((uint8_t)mq);
-    h->lseq.push_back((int32_t)l_seq); h->read_id.push_back(rid);
-    const size_t c0 = h->cigar.size();
-    h->cigar.resize_uninit(c0 + n_cig);
-    for (unsigned i = 0; i < n_cig; i++) h->cigar[c0 + i] = rd32(cig + 4 * (size_t)i);
-    h->cigar_off.push_back(h->cigar.size());
-    h->seq.append(sq, (l_seq + 1) / 2);
-    h->seq_off.push_back(h->seq.size());
-    h->sa_at.push_back(h->sa_blob.size()); h->sa_len.push_back((uint32_t)sa_n);
-    if (sa_n) h->sa_blob.append(sa, sa_n);
+    h->b->flag.push_back((uint16_t)(flag & 0x0fff)); h->b->tid.push_back(tid); h->b->bpos.push_back(pos); h->b->mapq.push_back((uint8_t)mq);
+    h->b->lseq.push_back((int32_t)l_seq); h->b->read_id.push_back(rid);
+    const size_t c0 = h->b->cigar.size();
+    h->b->cigar.resize_uninit(c0 + n_cig);
+    for (unsigned i = 0; i < n_cig; i++) h->b->cigar[c0 + i] = rd32(cig + 4 * (size_t)i);
+    h->b->cigar_off.push_back(h->b->cigar.size());
+    h->b->seq.append(sq, (l_seq + 1) / 2);
+    h->b->seq_off.push_back(h->b->seq.size());
+    h->b->sa_at.push_back(h->b->sa_blob.size()); h->b->sa_len.push_back((uint32_t)sa_n);
+    if (sa_n) h->b->sa_blob.append(sa, sa_n);
     return 1;
 }
 
 static void clear_batch(svx_bam* h) {
-    h->flag.clear(); h->tid.clear(); h->bpos.clear(); h->mapq.clear(); h->lseq.clear(); h->read_id.clear(); h->order.clear(); h->seg_order.clear();
-    h->seg_off.clear(); h->cigar.clear(); h->seg_cigar.clear(); h->cigar_off.assign(1, 0); h->seq_off.assign(1, 0); h->seg_cigar_off.assign(1, 0);
-    h->seq.clear(); h->seg_rev.clear(); h->seg_mapq.clear(); h->seg_tid.clear(); h->seg_pos.clear(); h->seg_lseq.clear();
-    h->sa_blob.clear(); h->sa_at.clear(); h->sa_len.clear();
+    BatchArrays& B = *h->b;
+    B.flag.clear(); B.tid.clear(); B.bpos.clear(); B.mapq.clear(); B.lseq.clear(); B.read_id.clear(); B.order.clear(); B.seg_order.clear();
+    B.seg_off.clear(); B.cigar.clear(); B.seg_cigar.clear(); B.cigar_off.assign(1, 0); B.seq_off.assign(1, 0); B.seg_cigar_off.assign(1, 0);
+    B.seq.clear(); B.seg_rev.clear(); B.seg_mapq.clear(); B.seg_tid.clear(); B.seg_pos.clear(); B.seg_lseq.clear();
+    B.sa_blob.clear(); B.sa_at.clear(); B.sa_len.clear();
+    B.rng_off.assign(1, 0); B.rng_q0.clear(); B.rng_len.clear(); B.rng_byte.clear();
 }
 
 // Read up to max_records records (query-name mode: never splits a read's group) and lay them out as an svx_batch whose
@@ -476,13 +584,15 @@ static void clear_batch(svx_bam* h) {
 // (src/svim/SVIM_COLLECT.py:132-167), 1 = query-name-sorted rules (:96-129).
 extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int min_mapq, svx_batch* out, int64_t* n_out) {
     try {
+        h->b = &h->ba[h->b == &h->ba[0] ? 1 : 0];                                        // the previous batch stays valid during this read
         clear_batch(h);
+        const bool sparse = h->seq_min_ins > 0 && mode == 0;
         int64_t n = 0;
         while (n < max_records) {
             if (!ensure(h, 4)) break;                                                   // end of file
             const uint32_t bs = rd32(h->buf.data() + h->pos);
             if (!ensure(h, 4 + (size_t)bs)) throw std::string("truncated BAM record");
-            n += decode_run(h, max_records - n);                                         // at least the record just made available
+            n += decode_run(h, max_records - n, sparse);                                 // at least the record just made available
         }
         if (mode == 1 && n == max_records) {
             // finish the current read group: keep reading while the name does not change (peek = parse, names are interned)
@@ -494,72 +604,77 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
                 const uint8_t* r = h->buf.data() + h->pos + 4;
                 const std::string name((const char*)r + 32, r[8] ? r[8] - 1 : 0);
                 auto it = h->read_id_of.find(name);
-                if (it == h->read_id_of.end() || it->second != h->read_id[(size_t)n - 1]) { h->pos = save_pos; break; }
+                if (it == h->read_id_of.end() || it->second != h->b->read_id[(size_t)n - 1]) { h->pos = save_pos; break; }
                 parse_record(h); n++;
             }
         }
         *n_out = n;
-        h->order.assign((size_t)n, 0); h->seg_order.assign((size_t)n, 0); h->seg_off.assign((size_t)n + 1, 0);
+        h->b->order.assign((size_t)n, 0); h->b->seg_order.assign((size_t)n, 0); h->b->seg_off.assign((size_t)n + 1, 0);
         if (mode == 0) {
             for (int64_t i = 0; i < n; i++) {
-                h->order[(size_t)i] = (uint32_t)(2 * i); h->seg_order[(size_t)i] = (uint32_t)(2 * i + 1);
-                h->seg_off[(size_t)i] = (uint32_t)h->seg_tid.size();
-                const unsigned f = h->flag[(size_t)i];
-                if ((f & (4u | 256u | 2048u)) || (int)h->mapq[(size_t)i] < min_mapq || !h->sa_len[(size_t)i]) continue;
-                h->flag[(size_t)i] |= SVX_FLAG_SA;
-                const int rc = append_sa(h, h->sa_blob.data() + h->sa_at[(size_t)i], h->sa_len[(size_t)i], h->lseq[(size_t)i]);
+                h->b->order[(size_t)i] = (uint32_t)(2 * i); h->b->seg_order[(size_t)i] = (uint32_t)(2 * i + 1);
+                h->b->seg_off[(size_t)i] = (uint32_t)h->b->seg_tid.size();
+                const unsigned f = h->b->flag[(size_t)i];
+                if ((f & (4u | 256u | 2048u)) || (int)h->b->mapq[(size_t)i] < min_mapq || !h->b->sa_len[(size_t)i]) continue;
+                h->b->flag[(size_t)i] |= SVX_FLAG_SA;
+                const int rc = append_sa(h, h->b->sa_blob.data() + h->b->sa_at[(size_t)i], h->b->sa_len[(size_t)i], h->b->lseq[(size_t)i]);
                 if (rc != SVX_OK) return rc;
             }
-            h->seg_off[(size_t)n] = (uint32_t)h->seg_tid.size();
+            h->b->seg_off[(size_t)n] = (uint32_t)h->b->seg_tid.size();
         } else {
             uint32_t slot = 0;
             int64_t i = 0;
             while (i < n) {
                 int64_t j = i;
-                while (j < n && h->read_id[(size_t)j] == h->read_id[(size_t)i]) j++;
+                while (j < n && h->b->read_id[(size_t)j] == h->b->read_id[(size_t)i]) j++;
                 std::vector<int64_t> prim, sup;
-                for (int64_t k = i; k < j; k++) { const unsigned f = h->flag[(size_t)k]; if (f & 256u) continue; if (f & 2048u) sup.push_back(k); else prim.push_back(k); }
-                const bool ok = prim.size() == 1 && !(h->flag[(size_t)prim[0]] & 4u) && (int)h->mapq[(size_t)prim[0]] >= min_mapq;
-                for (int64_t k = i; k < j; k++) { h->flag[(size_t)k] |= SVX_FLAG_SKIP; h->seg_off[(size_t)k] = (uint32_t)h->seg_tid.size(); }
+                for (int64_t k = i; k < j; k++) { const unsigned f = h->b->flag[(size_t)k]; if (f & 256u) continue; if (f & 2048u) sup.push_back(k); else prim.push_back(k); }
+                const bool ok = prim.size() == 1 && !(h->b->flag[(size_t)prim[0]] & 4u) && (int)h->b->mapq[(size_t)prim[0]] >= min_mapq;
+                for (int64_t k = i; k < j; k++) { h->b->flag[(size_t)k] |= SVX_FLAG_SKIP; h->b->seg_off[(size_t)k] = (uint32_t)h->b->seg_tid.size(); }
                 if (ok) {
                     const int64_t p = prim[0];
                     // segment rows belong to the primary: the offsets of the records after it inside the group move past them
                     std::vector<int64_t> good;
-                    for (int64_t k : sup) if (!(h->flag[(size_t)k] & 4u) && (int)h->mapq[(size_t)k] >= min_mapq) good.push_back(k);
-                    h->flag[(size_t)p] &= (uint16_t)~SVX_FLAG_SKIP;
-                    h->order[(size_t)p] = slot;
-                    for (int64_t k = i; k <= p; k++) h->seg_off[(size_t)k] = (uint32_t)h->seg_tid.size();
+                    for (int64_t k : sup) if (!(h->b->flag[(size_t)k] & 4u) && (int)h->b->mapq[(size_t)k] >= min_mapq) good.push_back(k);
+                    h->b->flag[(size_t)p] &= (uint16_t)~SVX_FLAG_SKIP;
+                    h->b->order[(size_t)p] = slot;
+                    for (int64_t k = i; k <= p; k++) h->b->seg_off[(size_t)k] = (uint32_t)h->b->seg_tid.size();
                     for (size_t qn = 0; qn < good.size(); qn++) {
                         const int64_t k = good[qn];
-                        h->flag[(size_t)k] &= (uint16_t)~SVX_FLAG_SKIP;
-                        h->order[(size_t)k] = slot + 1 + (uint32_t)qn;
-                        h->seg_tid.push_back(h->tid[(size_t)k]); h->seg_pos.push_back(h->bpos[(size_t)k]);
-                        h->seg_rev.push_back((h->flag[(size_t)k] & 16u) ? 1 : 0); h->seg_mapq.push_back(h->mapq[(size_t)k]);
-                        h->seg_lseq.push_back(h->lseq[(size_t)k]);
-                        for (uint64_t c = h->cigar_off[(size_t)k]; c < h->cigar_off[(size_t)k + 1]; c++) h->seg_cigar.push_back(h->cigar[(size_t)c]);
-                        h->seg_cigar_off.push_back(h->seg_cigar.size());
+                        h->b->flag[(size_t)k] &= (uint16_t)~SVX_FLAG_SKIP;
+                        h->b->order[(size_t)k] = slot + 1 + (uint32_t)qn;
+                        h->b->seg_tid.push_back(h->b->tid[(size_t)k]); h->b->seg_pos.push_back(h->b->bpos[(size_t)k]);
+                        h->b->seg_rev.push_back((h->b->flag[(size_t)k] & 16u) ? 1 : 0); h->b->seg_mapq.push_back(h->b->mapq[(size_t)k]);
+                        h->b->seg_lseq.push_back(h->b->lseq[(size_t)k]);
+                        for (uint64_t c = h->b->cigar_off[(size_t)k]; c < h->b->cigar_off[(size_t)k + 1]; c++) h->b->seg_cigar.push_back(h->b->cigar[(size_t)c]);
+                        h->b->seg_cigar_off.push_back(h->b->seg_cigar.size());
                     }
-                    for (int64_t k = p + 1; k < j; k++) h->seg_off[(size_t)k] = (uint32_t)h->seg_tid.size();
-                    h->seg_order[(size_t)p] = slot + 1 + (uint32_t)good.size();
+                    for (int64_t k = p + 1; k < j; k++) h->b->seg_off[(size_t)k] = (uint32_t)h->b->seg_tid.size();
+                    h->b->seg_order[(size_t)p] = slot + 1 + (uint32_t)good.size();
                     slot += (uint32_t)good.size() + 2;
                 }
                 i = j;
             }
-            h->seg_off[(size_t)n] = (uint32_t)h->seg_tid.size();
+            h->b->seg_off[(size_t)n] = (uint32_t)h->b->seg_tid.size();
         }
         // never hand out null pointers for empty arrays
         auto pad = [](auto& v) { if (v.empty()) v.resize(1); };
-        if (h->cigar.empty()) { h->cigar.reserve(1); h->cigar[0] = 0; }
-        if (h->seq.empty()) { h->seq.reserve(1); h->seq[0] = 0; }
-        pad(h->seg_tid); pad(h->seg_pos); pad(h->seg_rev); pad(h->seg_mapq); pad(h->seg_lseq); pad(h->seg_cigar);
-        pad(h->flag); pad(h->tid); pad(h->bpos); pad(h->mapq); pad(h->lseq); pad(h->read_id); pad(h->order); pad(h->seg_order);
+        if (h->b->cigar.empty()) { h->b->cigar.reserve(1); h->b->cigar[0] = 0; }
+        if (h->b->seq.empty()) { h->b->seq.reserve(1); h->b->seq[0] = 0; }
+        pad(h->b->seg_tid); pad(h->b->seg_pos); pad(h->b->seg_rev); pad(h->b->seg_mapq); pad(h->b->seg_lseq); pad(h->b->seg_cigar);
+        pad(h->b->flag); pad(h->b->tid); pad(h->b->bpos); pad(h->b->mapq); pad(h->b->lseq); pad(h->b->read_id); pad(h->b->order); pad(h->b->seg_order);
         memset(out, 0, sizeof *out);
-        out->on_device = 0; out->n_rec = n; out->flag = h->flag.data(); out->tid = h->tid.data(); out->pos = h->bpos.data(); out->mapq = h->mapq.data();
-        out->lseq = h->lseq.data(); out->read_id = h->read_id.data(); out->order = h->order.data(); out->seg_order = h->seg_order.data();
-        out->cigar_off = h->cigar_off.data(); out->cigar = h->cigar.data(); out->seq_off = h->seq_off.data(); out->seq = h->seq.data();
-        out->seg_off = h->seg_off.data(); out->n_seg = (int64_t)h->seg_cigar_off.size() - 1; out->seg_tid = h->seg_tid.data(); out->seg_pos = h->seg_pos.data();
-        out->seg_rev = h->seg_rev.data(); out->seg_mapq = h->seg_mapq.data(); out->seg_lseq = h->seg_lseq.data(); out->seg_cigar_off = h->seg_cigar_off.data();
-        out->seg_cigar = h->seg_cigar.data(); out->n_contig = (int32_t)h->ref_names.size(); out->contig_rank = h->contig_rank.data();
+        out->on_device = 0; out->n_rec = n; out->flag = h->b->flag.data(); out->tid = h->b->tid.data(); out->pos = h->b->bpos.data(); out->mapq = h->b->mapq.data();
+        out->lseq = h->b->lseq.data(); out->read_id = h->b->read_id.data(); out->order = h->b->order.data(); out->seg_order = h->b->seg_order.data();
+        out->cigar_off = h->b->cigar_off.data(); out->cigar = h->b->cigar.data(); out->seq_off = h->b->seq_off.data(); out->seq = h->b->seq.data();
+        out->seg_off = h->b->seg_off.data(); out->n_seg = (int64_t)h->b->seg_cigar_off.size() - 1; out->seg_tid = h->b->seg_tid.data(); out->seg_pos = h->b->seg_pos.data();
+        out->seg_rev = h->b->seg_rev.data(); out->seg_mapq = h->b->seg_mapq.data(); out->seg_lseq = h->b->seg_lseq.data(); out->seg_cigar_off = h->b->seg_cigar_off.data();
+        out->seg_cigar = h->b->seg_cigar.data(); out->n_contig = (int32_t)h->ref_names.size(); out->contig_rank = h->contig_rank.data();
+        if (sparse) {
+            pad(h->b->rng_q0); pad(h->b->rng_len); pad(h->b->rng_byte);
+            out->seq_rng_off = h->b->rng_off.data(); out->seq_rng_q0 = h->b->rng_q0.data(); out->seq_rng_len = h->b->rng_len.data();
+            out->seq_rng_byte = h->b->rng_byte.data(); out->n_seq_rng = (int64_t)h->b->rng_off[(size_t)n];
+        }
         h->total_records += n;
     } catch (const std::string& e) { return bam_fail(SVX_E_ARG, e); }
     return SVX_OK;

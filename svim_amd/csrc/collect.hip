@@ -14,7 +14,7 @@
 #include "common.hpp"
 #include <cstdlib>
 
-enum { CNT_SIG = 0, CNT_BND = 1, CNT_USED = 2, CNT_OPS = 3, CNT_SEGOPS = 4, CNT_INS_BASES = 5, CNT_RAW = 6, CNT_OVERFLOW = 7 };
+enum { CNT_SIG = 0, CNT_BND = 1, CNT_USED = 2, CNT_OPS = 3, CNT_SEGOPS = 4, CNT_INS_BASES = 5, CNT_RAW = 6, CNT_OVERFLOW = 7, CNT_SEQ_MISSING = 8 };
 #define RAW_SHARDS 8192      /* one private raw-output region per persistent wave: no allocation atomics at all in the scan
                                 (a single global counter serialised the launch at ~12 ns per same-address atomic) */
 
@@ -556,15 +556,27 @@ __global__ void k_permute_sigs(SigPtrs in, SigPtrs out, const uint32_t* idx, lon
 }
 
 // one wave per signature: unpack qlen 4-bit bases of the owning record into one code per byte
+// A batch with sparse SEQ (svx_batch.seq_rng_*: only some ranges of a record's bases are present, see svx_bam_set_seq_filter) is looked up
+// through the record's range list; a wanted range that is not there is counted (the caller fails loudly).
 __global__ __launch_bounds__(256) void k_gather_seq(SigPtrs s, long long n, const int64_t* seq_off, uint8_t* seq_out,
-                                                    const uint64_t* rec_seq_off, const uint8_t* rec_seq) {
+                                                    const uint64_t* rec_seq_off, const uint8_t* rec_seq, const uint32_t* rng_off, const int32_t* rng_q0,
+                                                    const int32_t* rng_len, const uint64_t* rng_byte, unsigned long long* missing) {
     const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const int len = s.qlen[i];
     if (len <= 0) return;
-    const uint8_t* src = rec_seq + rec_seq_off[s.rec[i]];
+    const uint8_t* src;
     uint8_t* dst = seq_out + seq_off[i];
-    const int q0 = s.qpos[i];
+    int q0 = s.qpos[i];
+    if (rng_off) {
+        const int rec = s.rec[i];
+        src = nullptr;
+        for (uint32_t r = rng_off[rec]; r < rng_off[rec + 1]; r++) {
+            const int a = rng_q0[r];
+            if (a <= q0 && q0 + len <= a + rng_len[r]) { src = rec_seq + rng_byte[r]; q0 -= a; break; }      // a is even: nibble parity is kept
+        }
+        if (!src) { if (lane_id() == 0) atomicAdd(missing, 1ull); return; }
+    } else src = rec_seq + rec_seq_off[s.rec[i]];
     // 8 bases per lane and step: one 8-byte load + one 8-byte store while 16 more bases of THIS slice remain (the load then stays inside
     // the record's own bytes), byte accesses for the last chunks
     for (int k0 = lane_id() * 8; k0 < len; k0 += 512) {
@@ -690,8 +702,16 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
         HIPCHK(hipStreamSynchronize(st));
         SVXCHK(c->sig.seq.reserve((size_t)n_seq + 16));
         k_gather_seq<<<(unsigned)((n_sig + 3) / 4), 256, 0, st>>>(sig_ptrs(c->sig), n_sig, c->sig.seq_off.as<int64_t>(), c->sig.seq.as<uint8_t>(),
-                                                                 b.seq_off, b.seq);
+                                                                 b.seq_off, b.seq, b.seq_rng_off, b.seq_rng_q0, b.seq_rng_len, b.seq_rng_byte,
+                                                                 c->counters.as<unsigned long long>() + CNT_SEQ_MISSING);
         HIPCHK(hipGetLastError());
+        if (b.seq_rng_off) {
+            unsigned long long miss = 0;
+            HIPCHK(hipMemcpyAsync(&miss, c->counters.as<unsigned long long>() + CNT_SEQ_MISSING, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (miss) return svx_fail(SVX_E_ARG, "sparse SEQ: the bases of a reported insertion are not in the batch (svx_bam_set_seq_filter larger than params.min_sv_size?)",
+                                      __FILE__, __LINE__, hipSuccess);
+        }
     } else {
         HIPCHK(hipMemsetAsync(c->sig.seq_off.p, 0, (size_t)(n_sig + 2) * 8, st));
         SVXCHK(c->sig.seq.reserve(16));

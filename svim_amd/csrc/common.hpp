@@ -65,6 +65,18 @@ struct DevSigs {
         cap = c;
         return SVX_OK;
     }
+    // grow to at least c entries KEEPING the first n (accumulator of several batches); rec / qpos / qlen are per-batch scratch and not kept
+    int reserve_keep(int64_t c, hipStream_t s) {
+        if (c <= cap) return SVX_OK;
+        const int64_t nc = c + c / 2 + 1024;
+        DevBuf* b8[] = {&key}; DevBuf* b1[] = {&type, &src, &aux}; DevBuf* b4[] = {&contig, &start, &end, &contig2, &pos2, &read_id};
+        for (auto* b : b8) SVXCHK(b->reserve((size_t)nc * 8, true, s));
+        for (auto* b : b1) SVXCHK(b->reserve((size_t)nc, true, s));
+        for (auto* b : b4) SVXCHK(b->reserve((size_t)nc * 4, true, s));
+        SVXCHK(seq_off.reserve((size_t)(nc + 2) * 8, true, s));
+        cap = nc;
+        return SVX_OK;
+    }
     void release() {
         DevBuf* all[] = {&key, &type, &src, &aux, &contig, &start, &end, &contig2, &pos2, &read_id, &rec, &qpos, &qlen, &seq_off, &seq};
         for (auto* b : all) b->release();
@@ -112,6 +124,8 @@ struct svx_ctx {
     std::vector<DevBuf> batch_bufs;
     // COLLECT results
     DevSigs sig, bnd;               // sorted by key
+    // svx_collect_accumulate: results of successive svx_collect calls (the batches of one input file) appended on the device
+    DevSigs acc_sig, acc_bnd; bool accumulate = false; uint64_t slot_base = 0;
     DevSigs raw_sig, raw_bnd;       // unordered emission buffers
     DevBuf counters;                // device counters (uint64 x 16)
     DevBuf shard_cnt;               // per-shard allocation counters + prefix of the raw indel buffer

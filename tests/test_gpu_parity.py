@@ -439,6 +439,61 @@ def test_dropin_collect_to_cluster_stays_resident_and_lazy(eng, tmp_path):
     assert [len(r) for r in res2] == [len(x) for x in g["clusters"]]
 
 
+def test_bam_pipeline_accumulates_batches_on_device(oracle, tmp_path):
+    """svim_amd/harness.py:BamPipeline - reader thread ahead of the GPU thread, sparse SEQ, the signature lists of all batches
+    appended in HBM (svx_collect_accumulate / svx_collect_set_slot_base) - must give what ONE batch holding the whole file gives:
+    same signature rows in the same order, same clusters; and that equals the oracle on the file's records."""
+    from svim_amd import _lib, harness, workloads
+    from svim_amd.bamio import NativeBam
+    prof = workloads.profile("c2", 0.012)
+    b, genome, g_off, meta = workloads.make_batch_full(prof, seed=11, device="cuda:0")
+    hb = b.slice_records(0, b.n_rec)
+    refs = list(hb.references)
+    lens = [int(x) for x in (g_off[1:] - g_off[:-1]).tolist()]
+    path = str(tmp_path / "p.bam")
+    n_written, raw = harness.write_bam_from_batch(path, hb, refs, lens)
+    assert n_written == b.n_rec
+    o = H.options({"min_mapq": 20, "min_sv_size": 40, "max_sv_size": 100000, "segment_gap_tolerance": 10, "segment_overlap_tolerance": 5,
+                   "partition_max_distance": 1000, "position_distance_normalizer": 900, "edit_distance_normalizer": 1.0,
+                   "cluster_max_distance": 0.5, "all_bnds": True})
+    p = _abi.Params.from_options(o)
+    e = _lib.Engine(0)
+    e.set_genome(g_off, genome, on_device=True)
+    # one batch, dense SEQ
+    nb = NativeBam(path, threads=4)
+    whole, n = nb.read_batch(1 << 30, 20, "coordinate")
+    assert n == b.n_rec
+    one_sig, one_bnd = e.collect(whole, p)
+    crank = batch.contig_ranks(refs)
+    one_ct = e.cluster(p, crank, source=0)
+    osig, obnd = oracle.collect(whole, p)
+    oracle.set_genome(g_off.cpu().numpy().astype(np.int64), genome.cpu().numpy())
+    oct_ = oracle.cluster(p, crank, source=0)
+    nb.close()
+    assert one_sig.first_difference(osig) is None and one_bnd.first_difference(obnd) is None
+    assert one_ct.first_difference(oct_, rtol=1e-12) is None
+    # many batches through the pipeline
+    pipe = harness.BamPipeline(path, o, e, threads=4, batch_records=max(64, n // 7))
+    assert pipe.run() == n and pipe.stats["batches"] >= 7
+    pipe.cluster()
+    many_ct = e.fetch_clusters()
+    counts = e.collect_counts()
+    pipe.close()
+    assert e.collect_counts() == counts == (one_sig.n, int(one_sig.seq_off[one_sig.n]), one_bnd.n)     # still resident after accumulation ends
+    many_sig, many_bnd = e.fetch_signatures(0), e.fetch_signatures(1)
+    for a, c in ((many_sig, one_sig), (many_bnd, one_bnd)):
+        for k in _abi.SIG_DTYPES:
+            if k != "key":
+                assert np.array_equal(getattr(a, k)[:a.n], getattr(c, k)[:c.n]), k
+        assert np.all(np.diff(a.key[:a.n].astype(np.int64)) > 0)                                       # one global emission order
+        assert np.array_equal(a.seq_off, c.seq_off) and np.array_equal(a.seq[:int(a.seq_off[a.n])], c.seq[:int(c.seq_off[c.n])])
+    assert many_ct.first_difference(one_ct) is None
+    # CLUSTER again from the promoted lists (what cluster_sv_signatures does after analyze_alignment_file_coordsorted(path))
+    again = e.cluster(p, crank, source=0)
+    assert again.first_difference(one_ct) is None
+    e.close()
+
+
 def test_per_read_entry_points_match_reference(eng):
     """analyze_alignment_indel / analyze_read_segments (the per-read functions of SVIM_intra.py / SVIM_inter.py) through the
     drop-in names, record by record, against what the reference returned."""

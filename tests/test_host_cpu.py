@@ -326,3 +326,56 @@ def test_lazy_lists_build_objects_only_when_read(oracle):
         rows.append([[idx[id(x)] for x in c.members] for c in lst])
     exp = [[r[7] if k < 3 else r[10] for r in case["clusters"][k]] for k in range(6)]
     assert rows == exp
+
+
+def test_native_bam_reader_sparse_seq_and_double_buffer(tmp_path, oracle):
+    """svx_bam_set_seq_filter: the reader keeps only the SEQ ranges COLLECT reads (insertions >= min_sv_size, whole split-read
+    primaries).  The oracle's COLLECT on the sparse batches must equal its COLLECT on the dense ones, sequences included, with a
+    fraction of the bases; and a batch stays intact while the next one is read (two array sets alternate)."""
+    from svim_amd.bamio import NativeBam
+    refs, lens = ["chr1", "chr2", "chr10"], [180000, 60000, 60000]
+    ref = synth.make_reference(1, list(zip(refs, lens)))
+    recs = synth.coordinate_sort(synth.fuzz_split_reads(31, 150, refs, lens) +
+                                 synth.planted_reads(32, 220, ref, refs, lens, n_sites=30, types=("DEL", "INS", "INV")))
+    path = str(tmp_path / "s.bam")
+    records.write_bam(path, refs, lens, recs)
+    o = H.options({"min_mapq": 20, "min_sv_size": 40, "max_sv_size": 100000, "segment_gap_tolerance": 10, "segment_overlap_tolerance": 5,
+                   "partition_max_distance": 1000, "position_distance_normalizer": 900, "edit_distance_normalizer": 1.0,
+                   "cluster_max_distance": 0.5, "all_bnds": True})
+    p = _abi.Params.from_options(o)
+
+    def collect_all(filter_len, per_batch):
+        nb = NativeBam(path, threads=3)
+        if filter_len:
+            nb.set_seq_filter(filter_len)
+        out, kept, prev = [], 0, None
+        while True:
+            b, n = nb.read_batch(per_batch, 20, "coordinate")
+            if n == 0:
+                break
+            if prev is not None:                    # the previous batch's arrays are still what they were
+                pb, snap = prev
+                assert np.array_equal(nb.batch_arrays(pb)["cigar"], snap)
+            A = nb.batch_arrays(b)
+            kept += A["seq"].size
+            assert (b.seq_rng_off is not None) == bool(filter_len)
+            s, t = oracle.collect(b, p)
+            out.append((s, t))
+            prev = (b, A["cigar"].copy())
+        nb.close()
+        return out, kept
+    dense, dense_bytes = collect_all(0, 90)
+    sparse, sparse_bytes = collect_all(40, 90)
+    assert len(dense) == len(sparse) >= 4
+    n_ins = 0
+    for (s0, t0), (s1, t1) in zip(dense, sparse):
+        assert s1.first_difference(s0) is None and t1.first_difference(t0) is None
+        n_ins += int((s0.type[:s0.n] == 1).sum())
+    assert n_ins > 50 and sparse_bytes < 0.7 * dense_bytes
+    # a filter larger than min_sv_size loses bases COLLECT needs: loud failure, not silence
+    nb = NativeBam(path, threads=2)
+    nb.set_seq_filter(400)
+    b, n = nb.read_batch(1 << 30, 20, "coordinate")
+    with pytest.raises(AssertionError):
+        oracle.collect(b, p)
+    nb.close()
