@@ -249,6 +249,12 @@ int  svx_edit_distance(svx_ctx* ctx, int64_t n_pairs, const uint8_t* codes_host,
 int  svx_linkage_fcluster(svx_ctx* ctx, int64_t n_problems, const int32_t* n_host, const int64_t* d_off,
                           const double* d_host, double cutoff, const int64_t* label_off, int32_t* labels_out);
 
+/* test / debug hook: span_position_distance (src/svim/SVIM_clustering.py:47-96) of n_pairs pairs (a[k], b[k]) of a HOST signature table
+ * through the device code the clustering itself runs - FP64 operation order and haplotype edit distances included (svx_set_genome
+ * first when insertions are among them) */
+int  svx_pair_distances(svx_ctx* ctx, const svx_sig_view* host_sigs, int64_t n_pairs, const int64_t* a, const int64_t* b, const svx_params* p,
+                        double* out);
+
 /* ---- native BAM front-end (host side) --------------------------------------------------
  * Replaces pysam.AlignmentFile(bam).fetch(until_eof=True) + the per-record accessors + the SA-tag string handling of
  * src/svim/SVIM_COLLECT.py:8-41,44-85,133 for BAM inputs: multi-threaded BGZF inflate, records decoded straight into

@@ -22,7 +22,7 @@ SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version",
            "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_shard", "svx_cluster_fetch_part_index",
            "svx_cluster_set_shard_by_origin", "svx_cluster_remote_members", "svx_cluster_set_chain",
            "svx_set_alignment_index", "svx_genotype",
-           "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster",
+           "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster", "svx_pair_distances",
            "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names", "svx_bam_set_seq_filter"]
 
 
@@ -227,6 +227,15 @@ class Engine(object):
         _check(self.L.svx_edit_distance(self.ctx, C.c_int64(len(pairs)), ptr(codes), ptr(a_off), ptr(b_off), ptr(out)),
                "svx_edit_distance")
         return [int(x) for x in out[:len(pairs)]]
+
+    def pair_distances(self, table, pairs, params):
+        """span_position_distance of (i, j) pairs of a host SigTable through the device path -> float64 array"""
+        ia = np.ascontiguousarray([i for i, _ in pairs], dtype=np.int64)
+        ib = np.ascontiguousarray([j for _, j in pairs], dtype=np.int64)
+        out = np.zeros(max(1, len(pairs)), dtype=np.float64)
+        v = table.view()
+        _check(self.L.svx_pair_distances(self.ctx, C.byref(v), C.c_int64(len(pairs)), ptr(ia), ptr(ib), C.byref(params), ptr(out)), "svx_pair_distances")
+        return out[:len(pairs)]
 
     def linkage_fcluster(self, problems, cutoff):
         """problems: list of (n, condensed distance array) -> list of label arrays (1-based, scipy numbering)."""

@@ -252,6 +252,35 @@ extern "C" int svx_cluster(svx_ctx* c, int source, const svx_sig_view* sigs, int
     return svx_cluster_impl(c, in, n_contig, c->c_rank.as<int32_t>(), p);
 }
 
+// Debug / test hook: span_position_distance (src/svim/SVIM_clustering.py:47-96) of n_pairs signature pairs (a[k], b[k]) of a HOST table,
+// computed by the same device code the clustering runs (FP64 arithmetic and haplotype edit distances included).
+extern "C" int svx_pair_distances(svx_ctx* c, const svx_sig_view* sigs, int64_t n_pairs, const int64_t* a_host, const int64_t* b_host, const svx_params* p,
+                                  double* out_host) {
+    if (!c || !sigs || !p || sigs->on_device) return svx_fail(SVX_E_ARG, "svx_pair_distances wants a host table", __FILE__, __LINE__, hipSuccess);
+    HIPCHK(hipSetDevice(c->device));
+    ClusterIn in;
+    const size_t n = (size_t)sigs->n;
+    const size_t nseq = n ? (size_t)sigs->seq_off[n] : 0;
+    auto& U = c->user_sig;
+    in.n = sigs->n;
+    SVXCHK(upload(c, U[0], sigs->type, n)); in.type = U[0].as<uint8_t>();
+    SVXCHK(upload(c, U[1], sigs->aux, n)); in.aux = U[1].as<uint8_t>();
+    SVXCHK(upload(c, U[2], sigs->contig, n * 4)); in.contig = U[2].as<int32_t>();
+    SVXCHK(upload(c, U[3], sigs->start, n * 4)); in.start = U[3].as<int32_t>();
+    SVXCHK(upload(c, U[4], sigs->end, n * 4)); in.end = U[4].as<int32_t>();
+    SVXCHK(upload(c, U[5], sigs->contig2, n * 4)); in.contig2 = U[5].as<int32_t>();
+    SVXCHK(upload(c, U[6], sigs->pos2, n * 4)); in.pos2 = U[6].as<int32_t>();
+    SVXCHK(upload(c, U[7], sigs->read_id, n * 4)); in.read_id = U[7].as<int32_t>();
+    SVXCHK(upload(c, U[8], sigs->seq_off, (n + 1) * 8)); in.seq_off = U[8].as<int64_t>();
+    SVXCHK(upload(c, U[9], sigs->seq, nseq)); in.seq = U[9].as<uint8_t>();
+    SVXCHK(upload(c, U[10], a_host, (size_t)n_pairs * 8));
+    SVXCHK(upload(c, U[11], b_host, (size_t)n_pairs * 8));
+    SVXCHK(c->tmp5.reserve((size_t)n_pairs * 8 + 8));
+    SVXCHK(svx_pair_distances_impl(c, in, n_pairs, U[10].as<int64_t>(), U[11].as<int64_t>(), p, c->tmp5.as<double>()));
+    HIPCHK(hipMemcpy(out_host, c->tmp5.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost));
+    return SVX_OK;
+}
+
 extern "C" int svx_cluster_set_shard(svx_ctx* c, int rank, int world) {
     if (world < 1 || rank < 0 || rank >= world) return svx_fail(SVX_E_ARG, "bad shard", __FILE__, __LINE__, hipSuccess);
     c->shard_rank = rank; c->shard_world = world; c->shard_mode = 0;

@@ -8,6 +8,10 @@
 // Host code (string / inflate work); the numeric work on the arrays built here happens on the GPU (collect.hip).
 // SURVEY.md section 8(f) row 1.
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -101,7 +105,9 @@ struct BatchArrays {
 };
 
 struct svx_bam {
-    FILE* f = nullptr;
+    // the file is memory-mapped: finding the BGZF block boundaries is a serial walk over 18-byte headers, the compressed payload is read
+    // (page-faulted in) by the inflating threads themselves - a serial fread of every block capped the reader at ~2 GB/s of BAM
+    int fd = -1; const uint8_t* map = nullptr; size_t map_len = 0, fpos = 0;
     std::string path, sort_order, names_blob;
     std::vector<std::string> ref_names;
     std::vector<int32_t> ref_len, contig_rank;
@@ -129,30 +135,30 @@ struct svx_bam {
 };
 
 // ---- BGZF ------------------------------------------------------------------------------------------------------------------
-struct RawBlock { std::vector<uint8_t> comp; uint32_t isize; size_t out_at; };
+struct RawBlock { const uint8_t* comp; size_t clen; uint32_t isize; size_t out_at; };
 
 static bool read_block(svx_bam* h, RawBlock& b) {
-    uint8_t hd[18];
-    size_t n = fread(hd, 1, 18, h->f);
-    if (n == 0) return false;
-    if (n != 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4)) throw std::string("not a BGZF block");
+    if (h->fpos >= h->map_len) return false;
+    const uint8_t* hd = h->map + h->fpos;
+    const size_t left = h->map_len - h->fpos;
+    if (left < 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4)) throw std::string("not a BGZF block");
     const unsigned xlen = hd[10] | (hd[11] << 8);
+    if (left < 12 + (size_t)xlen) throw std::string("truncated BGZF extra field");
     // the BC subfield is first in every BAM writer we know; be tolerant and scan the extra field
-    std::vector<uint8_t> extra(xlen);
-    memcpy(extra.data(), hd + 12, std::min<size_t>(6, xlen));
-    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, h->f) != xlen - 6) throw std::string("truncated BGZF extra field");
+    const uint8_t* extra = hd + 12;
     int bsize = -1;
     for (size_t p = 0; p + 4 <= xlen;) {
         const unsigned slen = extra[p + 2] | (extra[p + 3] << 8);
-        if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2) bsize = extra[p + 4] | (extra[p + 5] << 8);
+        if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8);
         p += 4 + slen;
     }
     if (bsize < 0) throw std::string("BGZF block without BC subfield");
+    if ((size_t)bsize + 1 < 12 + (size_t)xlen + 8 || left < (size_t)bsize + 1) throw std::string("truncated BGZF block");
     const size_t clen = (size_t)bsize + 1 - 12 - xlen - 8;
-    b.comp.resize(clen + 8);
-    if (fread(b.comp.data(), 1, clen + 8, h->f) != clen + 8) throw std::string("truncated BGZF block");
-    b.isize = b.comp[clen + 4] | (b.comp[clen + 5] << 8) | (b.comp[clen + 6] << 16) | ((uint32_t)b.comp[clen + 7] << 24);
-    b.comp.resize(clen);
+    b.comp = hd + 12 + xlen; b.clen = clen;
+    const uint8_t* tail = b.comp + clen;
+    b.isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+    h->fpos += (size_t)bsize + 1;
     return true;
 }
 
@@ -160,7 +166,7 @@ static void inflate_block(const RawBlock& b, uint8_t* out) {
     if (b.isize == 0) return;
     z_stream zs; memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) throw std::string("inflateInit2 failed");
-    zs.next_in = const_cast<Bytef*>(b.comp.data()); zs.avail_in = (uInt)b.comp.size();
+    zs.next_in = const_cast<Bytef*>(b.comp); zs.avail_in = (uInt)b.clen;
     zs.next_out = out; zs.avail_out = b.isize;
     const int rc = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
@@ -180,7 +186,7 @@ static void inflate_next_chunk(svx_bam* h) {
             RawBlock b;
             if (!read_block(h, b)) { h->next_eof = true; break; }
             b.out_at = total; total += b.isize;
-            blocks.push_back(std::move(b));
+            blocks.push_back(b);
         }
         h->next.resize_uninit(WIN_HEAD + total);
         h->next_len = total;
@@ -248,8 +254,16 @@ extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out) {
     { const char* e = getenv("SVX_BAM_CHUNK_BLOCKS"); if (e && atoll(e) > 0) h->chunk_blocks = (size_t)atoll(e); }
     h->pool = new Pool(h->n_threads - 1);                 // record decode (the calling thread takes part)
     h->pool_inflate = new Pool(h->n_threads - 1);         // BGZF inflate of the NEXT chunk, concurrently with the decode of this one
-    h->f = fopen(path, "rb");
-    if (!h->f) { delete h; return bam_fail(SVX_E_ARG, std::string("cannot open ") + path); }
+    h->fd = open(path, O_RDONLY);
+    struct stat sb;
+    if (h->fd < 0 || fstat(h->fd, &sb) != 0) { if (h->fd >= 0) close(h->fd); delete h; return bam_fail(SVX_E_ARG, std::string("cannot open ") + path); }
+    h->map_len = (size_t)sb.st_size;
+    if (h->map_len) {
+        void* m = mmap(nullptr, h->map_len, PROT_READ, MAP_PRIVATE, h->fd, 0);
+        if (m == MAP_FAILED) { close(h->fd); delete h; return bam_fail(SVX_E_ARG, std::string("cannot map ") + path); }
+        h->map = (const uint8_t*)m;
+        (void)madvise(m, h->map_len, MADV_SEQUENTIAL);
+    }
     try {
         if (!ensure(h, 12) || memcmp(h->buf.data() + h->pos, "BAM\1", 4) != 0) throw std::string("not a BAM file");
         const uint32_t l_text = rd32(h->buf.data() + h->pos + 4);
@@ -281,7 +295,12 @@ extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out) {
         std::sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return h->ref_names[(size_t)a] < h->ref_names[(size_t)b]; });
         h->contig_rank.assign(n_ref ? n_ref : 1, 0);
         for (uint32_t r = 0; r < n_ref; r++) h->contig_rank[(size_t)idx[r]] = (int32_t)r;
-    } catch (const std::string& e) { if (h->prefetch_active) h->prefetch.wait(); fclose(h->f); delete h->pool; delete h->pool_inflate; delete h; return bam_fail(SVX_E_ARG, e); }
+    } catch (const std::string& e) {
+        if (h->prefetch_active) h->prefetch.wait();
+        if (h->map) munmap((void*)h->map, h->map_len);
+        close(h->fd); delete h->pool; delete h->pool_inflate; delete h;
+        return bam_fail(SVX_E_ARG, e);
+    }
     *out = h;
     return SVX_OK;
 }
@@ -292,7 +311,8 @@ extern "C" void svx_bam_close(svx_bam* h) {
     if (getenv("SVX_BAM_TIMING"))
         fprintf(stderr, "bamio %d threads: wait for inflate %.3f s, window copy %.3f, record walk %.3f, decode %.3f, names + SA %.3f\n", h->n_threads,
                 h->t_wait, h->t_copy, h->t_walk, h->t_decode, h->t_intern);
-    if (h->f) fclose(h->f);
+    if (h->map) munmap((void*)h->map, h->map_len);
+    if (h->fd >= 0) close(h->fd);
     delete h->pool; delete h->pool_inflate;
     delete h;
 }

@@ -528,6 +528,47 @@ __global__ __launch_bounds__(64) void k_ins_pairs(long long n_part, const int64_
     }
 }
 
+// ---- svx_pair_distances: span_position_distance of arbitrary pairs through the very device functions the clustering uses ----------
+__device__ __forceinline__ Member member_of(const ClusterIn& in, long long g) {
+    Member m; m.start = in.start[g]; m.end = in.end[g]; m.pos2 = in.pos2[g]; m.read = in.read_id[g]; m.aux = in.aux[g]; m.gidx = (int)g; m.c2 = in.contig2[g]; m.pad = 0;
+    return m;
+}
+__global__ void k_pairs_need_edit(long long n_pairs, const int64_t* ia, const int64_t* ib, ClusterIn in, svx_params p, EditWork* work, unsigned long long* n_work) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pairs) return;
+    const long long a = ia[k], b = ib[k];
+    if (in.type[a] != SVX_INS || in.type[b] != SVX_INS || !ins_needs_edit(member_of(in, a), member_of(in, b), p)) return;
+    const unsigned long long w = atomicAdd(n_work, 1ull);
+    EditWork e; e.a = (uint32_t)a; e.b = (uint32_t)b; e.slot = k; work[w] = e;
+}
+__global__ void k_pairs_distance(long long n_pairs, const int64_t* ia, const int64_t* ib, ClusterIn in, svx_params p, const int32_t* ed, double* out) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pairs) return;
+    out[k] = span_position_distance(in.type[ia[k]], member_of(in, ia[k]), member_of(in, ib[k]), p, ed[k]);
+}
+int svx_pair_distances_impl(svx_ctx* c, const ClusterIn& in, int64_t n_pairs, const int64_t* ia_dev, const int64_t* ib_dev, const svx_params* pp, double* out_dev) {
+    hipStream_t st = c->stream;
+    if (n_pairs <= 0) return SVX_OK;
+    SVXCHK(c->counters.reserve(16 * 8));
+    unsigned long long* cnt = c->counters.as<unsigned long long>();
+    HIPCHK(hipMemsetAsync(cnt, 0, 16 * 8, st));
+    SVXCHK(c->work.reserve((size_t)n_pairs * sizeof(EditWork)));
+    SVXCHK(c->ed.reserve((size_t)(n_pairs + 1) * 4));
+    HIPCHK(hipMemsetAsync(c->ed.p, 0, (size_t)(n_pairs + 1) * 4, st));
+    k_pairs_need_edit<<<(unsigned)((n_pairs + 255) / 256), 256, 0, st>>>(n_pairs, ia_dev, ib_dev, in, *pp, c->work.as<EditWork>(), cnt + 8);
+    unsigned long long n_work = 0;
+    HIPCHK(hipMemcpyAsync(&n_work, cnt + 8, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_work) {
+        if (!c->g_off_p) return svx_fail(SVX_E_STATE, "svx_set_genome must precede insertion distances", __FILE__, __LINE__, hipSuccess);
+        SVXCHK(svx_launch_edit_pairs(c, (int64_t)n_work, c->work.p, in, c->ed.as<int32_t>(), nullptr));
+    }
+    k_pairs_distance<<<(unsigned)((n_pairs + 255) / 256), 256, 0, st>>>(n_pairs, ia_dev, ib_dev, in, *pp, c->ed.as<int32_t>(), out_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return SVX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // nn-chain average linkage + flat cut, entirely in LDS (scipy _hierarchy.nn_chain / label / cluster_dist)
 // ---------------------------------------------------------------------------------------------------------

@@ -170,6 +170,7 @@ int svx_exclusive_scan_i32_to_i64(svx_ctx* c, const int32_t* in, int64_t* out, i
 // ---- stage entry points ------------------------------------------------------------------------------------
 int svx_collect_impl(svx_ctx* c, const svx_batch* b_dev, const svx_params* p);
 int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const int32_t* rank_dev, const svx_params* p);
+int svx_pair_distances_impl(svx_ctx* c, const ClusterIn& in, int64_t n_pairs, const int64_t* ia_dev, const int64_t* ib_dev, const svx_params* p, double* out_dev);
 int svx_set_alignment_index_impl(svx_ctx* c, const svx_aln_index* h);
 int svx_genotype_impl(svx_ctx* c, int32_t mode, int64_t n_cand, const int32_t* tid, const int32_t* start, const int32_t* end, const int64_t* moff,
                       const int32_t* mnames, int32_t min_mapq, int32_t* out);

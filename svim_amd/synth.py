@@ -277,6 +277,53 @@ def fuzz_split_reads(seed, n_reads, references, lengths, max_sv_size=100000, rea
     return recs
 
 
+def inversion_insertion_layouts(seed, n_reads, references, lengths, max_sv_size=100000):
+    """Two-segment split reads aimed at the branches the random fuzz reaches rarely: the four inversion geometries of
+    src/svim/SVIM_inter.py:152-204 (left_fwd / left_rev / right_fwd / right_rev) and split-read insertions on both strands
+    (:78-92), with sizes around min_sv_size, in the bulk, and at max_sv_size."""
+    rng = random.Random(seed)
+    recs = []
+    kinds = ("inv_left_fwd", "inv_left_rev", "inv_right_fwd", "inv_right_rev", "ins_fwd", "ins_rev")
+    for r in range(n_reads):
+        kind = kinds[r % len(kinds)]
+        size = rng.choice((38, 39, 40, 41, 60, 150, 700, 2500, max_sv_size - 1, max_sv_size, max_sv_size + 1))
+        tid = rng.randrange(len(references))
+        l1, l2 = rng.randint(120, 900), rng.randint(120, 900)
+        if kind in ("inv_left_rev", "inv_right_fwd"):
+            l1 = max(45, min(l1, size))
+        if kind in ("inv_left_fwd", "inv_right_rev"):
+            l2 = max(45, min(l2, size))
+        gap = size if kind.startswith("ins") else rng.choice((0, 0, 0, -3, 6, 12))
+        lead, trail = rng.choice((0, rng.randint(1, 40))), rng.choice((0, rng.randint(1, 40)))
+        c1, c2 = noisy_core(rng, l1), noisy_core(rng, l2)
+        s1, s2 = ref_span(c1), ref_span(c2)
+        p = rng.randint(max_sv_size + 5000, max(max_sv_size + 6000, lengths[tid] - max_sv_size - 5000)) if lengths[tid] > 2 * max_sv_size + 12000 \
+            else rng.randint(3000, max(3001, lengths[tid] - 3000 - s1 - s2))
+        jit = rng.randint(-4, 4)
+        if kind == "inv_left_fwd":          # fwd [p, p+s1) then rev ending at cur.ref_end + size
+            a_rev, b_rev, a_start, b_start = False, True, p, p + s1 + size - s2
+        elif kind == "inv_left_rev":        # fwd then rev lying to its LEFT: INV(next.ref_end, cur.ref_end)
+            a_rev, b_rev, a_start, b_start = False, True, p, p + s1 - size - s2
+        elif kind == "inv_right_fwd":       # rev then fwd to its right: INV(cur.ref_start, next.ref_start)
+            a_rev, b_rev, a_start, b_start = True, False, p, p + size
+        elif kind == "inv_right_rev":       # rev then fwd to its left: INV(next.ref_start, cur.ref_start)
+            a_rev, b_rev, a_start, b_start = True, False, p, p - size
+        elif kind == "ins_fwd":             # same strand, adjacent on the reference, `size` unaligned read bases in between
+            a_rev, b_rev, a_start, b_start = False, False, p, p + s1 + jit
+        else:                               # reverse strand: the later read part maps to the LEFT
+            a_rev, b_rev, a_start, b_start = True, True, p, p - jit - s2
+        b_start = max(5, min(b_start, lengths[tid] - s2 - 5))
+        a_start = max(5, min(a_start, lengths[tid] - s1 - 5))
+        q1s, q1e = lead, lead + l1
+        q2s = max(q1e + gap, q1s + 1)
+        q2e = q2s + l2
+        L = q2e + trail
+        seq = random_seq(rng, L)
+        segs = [Segment(q1s, q1e, tid, a_start, a_rev, c1, 60), Segment(q2s, q2e, tid, b_start, b_rev, c2, rng.choice((60, 60, 60, 25)))]
+        recs.extend(records_for_read("lay%d" % r, seq, segs, references, hard_clip_suppl=rng.random() < 0.5))
+    return recs
+
+
 def planted_reads(seed, n_reads, refs, references, lengths, n_sites=40, types=("DEL", "INS"),
                   read_len=(2000, 12000), tid=0, size_range=(50, 2000), err=0.03):
     """Reads over contig `tid` carrying planted DEL/INS (in CIGAR) and INV (as fwd-rev-fwd split

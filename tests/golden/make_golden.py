@@ -263,10 +263,14 @@ def gen_collect(refs, references, lengths):
                                                                        segment_gap_tolerance=15,
                                                                        segment_overlap_tolerance=8)),
         ("fuzzC", dict(seed=13, n_reads=140, max_sv_size=100000), dict(min_mapq=5)),
+        ("layoutD", dict(seed=14, n_reads=240, max_sv_size=20000), dict(max_sv_size=20000)),     # INV geometries + split-read insertions
     ]
     stats = {}
     for name, gen_kw, opt_kw in fuzz_sets:
-        recs = synth.fuzz_split_reads(references=references, lengths=lengths, **gen_kw)
+        if name == "layoutD":
+            recs = synth.inversion_insertion_layouts(references=references, lengths=lengths, **gen_kw)
+        else:
+            recs = synth.fuzz_split_reads(references=references, lengths=lengths, **gen_kw)
         for mode in ("coordinate", "queryname"):
             if mode == "coordinate":
                 ordered = synth.coordinate_sort(recs)
@@ -278,6 +282,8 @@ def gen_collect(refs, references, lengths):
                 sigs, bnds = run_collect(text, o, mode)
                 for s in sigs:
                     stats[(s.type, s.signature)] = stats.get((s.type, s.signature), 0) + 1
+                    if s.type == "INV":
+                        stats[("INV", s.direction)] = stats.get(("INV", s.direction), 0) + 1
                 cases.append({"name": name, "sam": text if not all_bnds else None, "mode": mode,
                               "options": opt_dict(o), "signatures": [sig_row(s) for s in sigs],
                               "bnds": [sig_row(s) for s in bnds]})
@@ -513,7 +519,11 @@ def gen_c1():
     os.remove(fa)
     n_ops = sum(len(a.cigartuples) for a in recs)
     print("C1: %d records, %d ops, %d signatures, collect %.2fs cluster %.2fs" % (len(recs), n_ops, len(sigs), t1 - t0, t2 - t1))
-    dump("g_c1.json.gz", {"generator": "synth.planted_reads(8, 10000, make_reference(7, [('chr1', 2000000)]), ['chr1'], [2000000], n_sites=300, "
+    dump("g_c1.json.gz", {"note": "BASELINE.json configs[0] (10k-read synthetic 1-contig BAM, DEL/INS only).  Deviation from SURVEY.md section 8(d) C1: a 2 Mb "
+                                  "contig, reads of 1-6 kb and 4.1 M CIGAR operations instead of 250 Mb / up to 20 kb / ~2*10^7 operations - the reference's "
+                                  "Python loops need 7 s for this size (reference_seconds), which keeps regenerating the golden practical; same coverage "
+                                  "per site, same planted-site density per read",
+                          "generator": "synth.planted_reads(8, 10000, make_reference(7, [('chr1', 2000000)]), ['chr1'], [2000000], n_sites=300, "
                                        "types=('DEL','INS'), read_len=(1000,6000)) coordinate-sorted",
                           "n_records": len(recs), "n_ops": n_ops, "options": opt_dict(options()),
                           "signatures": [sig_row(s) for s in sigs], "clusters": cluster_rows(res, sigs),

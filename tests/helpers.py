@@ -161,3 +161,33 @@ def text_close(got, exp, rtol=1e-9):
             if abs(fx - fy) > rtol * max(1.0, abs(fy)):
                 return "line %d: %r != %r" % (i, x, y)
     return None
+
+
+def long_cigar_records():
+    """(a plain record, a record whose CIGAR has > 65535 operations with one reportable insertion and one deletion, that CIGAR)"""
+    import random
+    from svim_amd import synth
+    rng = random.Random(77)
+    n_units = 33500                                   # 2 ops per unit -> 67000 ops
+    cig, seq_parts = [(4, 7)], [synth.random_seq(rng, 7)]
+    for u in range(n_units):
+        m = rng.randint(2, 4)
+        cig.append((0, m)); seq_parts.append(synth.random_seq(rng, m))
+        if u == 12000:
+            cig.append((1, 57)); seq_parts.append("ACGT" * 14 + "A")          # the insertion COLLECT must report, bases included
+        elif u == 20000:
+            cig.append((2, 120))
+        else:
+            op = rng.choice((1, 2))
+            cig.append((op, 1))
+            if op == 1:
+                seq_parts.append(rng.choice("ACGT"))
+    cig.append((0, 5)); seq_parts.append(synth.random_seq(rng, 5))
+    assert len(cig) > 65535
+    a = records.AlignedSegment()
+    a.query_name, a.flag, a.reference_id, a.reference_start, a.mapping_quality = "long", 0, 0, 1000, 60
+    a.cigartuples, a.query_sequence = cig, "".join(seq_parts)
+    short = records.AlignedSegment()
+    short.query_name, short.flag, short.reference_id, short.reference_start, short.mapping_quality = "short", 0, 0, 500, 60
+    short.cigartuples, short.query_sequence = [(0, 50)], synth.random_seq(rng, 50)
+    return short, a, cig

@@ -379,3 +379,37 @@ def test_native_bam_reader_sparse_seq_and_double_buffer(tmp_path, oracle):
     with pytest.raises(AssertionError):
         oracle.collect(b, p)
     nb.close()
+
+
+def test_long_cigar_cg_tag_through_both_readers(tmp_path, oracle):
+    """A CIGAR beyond 65535 operations does not fit the BAM record's 16-bit count: it lives in the CG:B,I tag behind a <l_seq>S<ref_len>N
+    placeholder (SAM spec).  Both the Python reader (records.py) and the native one (bamio.cpp, dense and
+    sparse SEQ) must hand COLLECT the real CIGAR: same batch arrays, and the planted insertion / deletion come out with their bases."""
+    from svim_amd.bamio import NativeBam
+    short, a, cig = H.long_cigar_records()
+    path = str(tmp_path / "cg.bam")
+    records.write_bam(path, ["chr1"], [400000], [short, a])
+    o = H.options({"min_mapq": 20, "min_sv_size": 40, "max_sv_size": 100000, "segment_gap_tolerance": 10, "segment_overlap_tolerance": 5,
+                   "partition_max_distance": 1000, "position_distance_normalizer": 900, "edit_distance_normalizer": 1.0,
+                   "cluster_max_distance": 0.5, "all_bnds": False})
+    p = _abi.Params.from_options(o)
+    back = list(records.AlignmentFile(path).fetch(until_eof=True))
+    assert back[1].cigartuples == cig and back[1].query_sequence == a.query_sequence
+    hb = batch.build_batch(records.AlignmentFile(path), o, mode="coordinate")
+    exp, _ = oracle.collect(hb, p)
+    assert exp.n == 2 and sorted(exp.type[:2].tolist()) == [0, 1]
+    ins = int(np.nonzero(exp.type[:2] == 1)[0][0])
+    assert exp.sequence(ins) == "ACGT" * 14 + "A"
+    for filt in (0, 40):
+        nb = NativeBam(path, threads=2)
+        if filt:
+            nb.set_seq_filter(filt)
+        b, n = nb.read_batch(1 << 30, 20, "coordinate")
+        A = nb.batch_arrays(b)
+        assert n == 2 and int(A["cigar_off"][2] - A["cigar_off"][1]) == len(cig)
+        assert np.array_equal(A["cigar"], hb.arrays["cigar"][:A["cigar"].size])
+        got, _ = oracle.collect(b, p)
+        assert got.first_difference(exp) is None
+        if filt:
+            assert A["seq"].size < 64                 # one insertion's worth of bases instead of ~50 kb
+        nb.close()

@@ -53,7 +53,7 @@ def test_g3_satag_rebuild():
         assert a == b
 
 
-@pytest.mark.parametrize("idx", range(40))
+@pytest.mark.parametrize("idx", range(len(H.load("g2_collect.json.gz")["cases"])))
 def test_g2_collect(oracle, idx):
     g = H.load("g2_collect.json.gz")
     if idx >= len(g["cases"]):
@@ -94,7 +94,7 @@ def test_g6_distance(oracle):
         assert struct.pack("<d", d).hex() == hexd, (i, j, g["signatures"][i][0])
 
 
-@pytest.mark.parametrize("idx", range(16))
+@pytest.mark.parametrize("idx", range(len(H.load("g5_cluster.json.gz")["cases"])))
 def test_g5_cluster(oracle, idx):
     g = H.load("g5_cluster.json.gz")
     if idx >= len(g["cases"]):
