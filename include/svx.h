@@ -270,6 +270,8 @@ int  svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int min_mapq,
  * svx_bam_set_seq_filter(h, min_ins_len > 0): coordinate mode keeps only the SEQ ranges COLLECT can read - insertions of at least
  * min_ins_len bases (pass params.min_sv_size) and the whole SEQ of records with an SA tag - and describes them in svx_batch.seq_rng_*. */
 int  svx_bam_set_seq_filter(svx_bam* h, int min_ins_len);
+/* back to the first record, keeping buffers, worker threads and the interned read names (a second pass = the steady state of a long file) */
+int  svx_bam_rewind(svx_bam* h);
 int  svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** nul_separated, int64_t* blob_len);
 
 #ifdef __cplusplus

@@ -49,6 +49,11 @@ class NativeBam(object):
         if rc != 0:
             raise SvxError("svx_bam_set_seq_filter failed")
 
+    def rewind(self):
+        """back to the first record; buffers, threads and interned names are kept (svx_bam_rewind)"""
+        if self.L.svx_bam_rewind(self.h) != 0:
+            raise SvxError("svx_bam_rewind failed: %s" % self.L.svx_last_error().decode())
+
     def read_batch(self, max_records, min_mapq, mode="coordinate"):
         """-> (svx_batch struct with host pointers owned by the reader, n_records); n_records == 0 at EOF."""
         b = _abi.Batch()

@@ -39,11 +39,24 @@ template <class T> struct RawVec {
     RawVec() = default;
     RawVec(const RawVec&) = delete; RawVec& operator=(const RawVec&) = delete;
     ~RawVec() { free(p); }
+    // Large buffers (inflate windows, CIGAR words, packed bases: hundreds of MB that 100+ threads write for the first time at once) are
+    // 2 MB aligned and marked for transparent huge pages: first-touch page faults on 4 KB pages serialise the threads in the kernel.
     void reserve(size_t c) {
         if (c <= cap) return;
         size_t nc = cap + cap / 2 + 1024;
         if (nc < c) nc = c;
-        T* q = (T*)realloc(p, nc * sizeof(T));
+        const size_t bytes = nc * sizeof(T);
+        if (bytes >= ((size_t)32 << 20)) {
+            const size_t huge = (size_t)2 << 20, rounded = (bytes + huge - 1) / huge * huge;
+            void* q = nullptr;
+            if (posix_memalign(&q, huge, rounded) != 0 || !q) throw std::string("out of host memory");
+            (void)madvise(q, rounded, MADV_HUGEPAGE);
+            if (n) memcpy(q, p, n * sizeof(T));
+            free(p);
+            p = (T*)q; cap = rounded / sizeof(T);
+            return;
+        }
+        T* q = (T*)realloc(p, bytes);
         if (!q) throw std::string("out of host memory");
         p = q; cap = nc;
     }
@@ -162,15 +175,23 @@ static bool read_block(svx_bam* h, RawBlock& b) {
     return true;
 }
 
+// one inflate state per worker thread, reset per block (inflateInit2 allocates ~40 KB each time)
+struct TlsInflate {
+    z_stream zs; bool ok = false;
+    ~TlsInflate() { if (ok) inflateEnd(&zs); }
+};
 static void inflate_block(const RawBlock& b, uint8_t* out) {
     if (b.isize == 0) return;
-    z_stream zs; memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) throw std::string("inflateInit2 failed");
-    zs.next_in = const_cast<Bytef*>(b.comp); zs.avail_in = (uInt)b.clen;
-    zs.next_out = out; zs.avail_out = b.isize;
-    const int rc = inflate(&zs, Z_FINISH);
-    inflateEnd(&zs);
-    if (rc != Z_STREAM_END || zs.avail_out != 0) throw std::string("BGZF inflate failed");
+    static thread_local TlsInflate t;
+    if (!t.ok) {
+        memset(&t.zs, 0, sizeof t.zs);
+        if (inflateInit2(&t.zs, -15) != Z_OK) throw std::string("inflateInit2 failed");
+        t.ok = true;
+    } else if (inflateReset(&t.zs) != Z_OK) throw std::string("inflateReset failed");
+    t.zs.next_in = const_cast<Bytef*>(b.comp); t.zs.avail_in = (uInt)b.clen;
+    t.zs.next_out = out; t.zs.avail_out = b.isize;
+    const int rc = inflate(&t.zs, Z_FINISH);
+    if (rc != Z_STREAM_END || t.zs.avail_out != 0) throw std::string("BGZF inflate failed");
 }
 
 // Inflate the next chunk of BGZF blocks (<= 1024 blocks / 48 MB) into h->next: n_threads workers, runs on a background thread while the
@@ -325,6 +346,30 @@ extern "C" void svx_bam_close(svx_bam* h) {
 extern "C" int svx_bam_set_seq_filter(svx_bam* h, int min_ins_len) {
     if (!h) return bam_fail(SVX_E_ARG, "null reader");
     h->seq_min_ins = min_ins_len > 0 ? min_ins_len : 0;
+    return SVX_OK;
+}
+
+// Back to the first alignment record, keeping every buffer, thread and interned read name: a second pass over the same file (the
+// steady state of a long file: no first-touch allocation anywhere).
+extern "C" int svx_bam_rewind(svx_bam* h) {
+    if (!h) return bam_fail(SVX_E_ARG, "null reader");
+    if (h->prefetch_active) { h->prefetch.wait(); h->prefetch_active = false; }
+    h->prefetch_err.clear();
+    h->fpos = 0; h->file_eof = false; h->buf.clear(); h->pos = 0; h->next_len = 0; h->next_eof = false;
+    try {
+        if (!ensure(h, 12)) throw std::string("not a BAM file");
+        const uint32_t l_text = rd32(h->buf.data() + h->pos + 4);
+        if (!ensure(h, 12 + (size_t)l_text)) throw std::string("truncated BAM header");
+        h->pos += 8 + (size_t)l_text;
+        const uint32_t n_ref = rd32(h->buf.data() + h->pos); h->pos += 4;
+        for (uint32_t i = 0; i < n_ref; i++) {
+            if (!ensure(h, 4)) throw std::string("truncated BAM reference list");
+            const uint32_t l_name = rd32(h->buf.data() + h->pos); h->pos += 4;
+            if (!ensure(h, l_name + 4)) throw std::string("truncated BAM reference list");
+            h->pos += l_name + 4;
+        }
+    } catch (const std::string& e) { return bam_fail(SVX_E_ARG, e); }
+    h->total_records = 0;
     return SVX_OK;
 }
 

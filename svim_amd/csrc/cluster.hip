@@ -1222,16 +1222,31 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     // bound by the latency of its LDS round trips, so what counts is how many partitions a CU works on at once
     constexpr int SMALL = 48, MID = 72;
     auto cluster_lds = [](int cap) { return link_lds_bytes(cap) + sizeof(Member) * cap * 2 + sizeof(int) * (3 * cap + 2) + sizeof(double) * 4 + 64; };
-    auto launch_cluster = [&](hipStream_t ks, int phase) {
-        k_cluster<SMALL, 0><<<(unsigned)n_part, 64, cluster_lds(SMALL), ks>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
-                                                                          samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
-                                                                          ncl_a, nmem_a, cnt + 10, phase);
-        k_cluster<MID, SMALL><<<(unsigned)n_part, 64, cluster_lds(MID), ks>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
-                                                                          samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
-                                                                          ncl_a, nmem_a, cnt + 10, phase);
+    // The three size classes are independent: on the main stream (phase 0 / 2, nothing else is running any more) they go to three
+    // streams so that their tails overlap; the side-stream pass (phase 1, beside the edit-distance rounds) stays on its one stream.
+    auto launch_cluster = [&](hipStream_t ks, int phase) -> int {
+        hipStream_t s_mid = ks, s_small = ks;
+        const bool fork = phase != 1;
+        if (fork) {
+            HIPCHK(hipEventRecord(c->ev[15], ks));
+            HIPCHK(hipStreamWaitEvent(c->aux[0], c->ev[15], 0)); HIPCHK(hipStreamWaitEvent(c->aux[1], c->ev[15], 0));
+            s_mid = c->aux[0]; s_small = c->aux[1];
+        }
         k_cluster<MAXN, MID><<<(unsigned)n_part, 64, cluster_lds(MAXN), ks>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
                                                                           samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
                                                                           ncl_a, nmem_a, cnt + 10, phase);
+        k_cluster<MID, SMALL><<<(unsigned)n_part, 64, cluster_lds(MID), s_mid>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
+                                                                             samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
+                                                                             ncl_a, nmem_a, cnt + 10, phase);
+        k_cluster<SMALL, 0><<<(unsigned)n_part, 64, cluster_lds(SMALL), s_small>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
+                                                                               samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
+                                                                               ncl_a, nmem_a, cnt + 10, phase);
+        HIPCHK(hipGetLastError());
+        if (fork) {
+            HIPCHK(hipEventRecord(c->ev[16], s_mid)); HIPCHK(hipEventRecord(c->ev[17], s_small));
+            HIPCHK(hipStreamWaitEvent(ks, c->ev[16], 0)); HIPCHK(hipStreamWaitEvent(ks, c->ev[17], 0));
+        }
+        return SVX_OK;
     };
     SVXCHK(c->ed.reserve((size_t)(pair_total + 1) * 4));
     // partitions without insertions need nothing from the edit-distance rounds: their linkage runs beside them on a side stream
@@ -1239,7 +1254,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     if (split) {
         HIPCHK(hipEventRecord(c->ev[13], st));
         HIPCHK(hipStreamWaitEvent(c->aux[SVX_N_AUX - 1], c->ev[13], 0));
-        launch_cluster(c->aux[SVX_N_AUX - 1], 1);
+        SVXCHK(launch_cluster(c->aux[SVX_N_AUX - 1], 1));
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev[14], c->aux[SVX_N_AUX - 1]));
     }
@@ -1262,7 +1277,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     }
     HIPCHK(hipEventRecord(c->ev[10], st));
     // ---- per-partition clustering into the staging area ---------------------------------------------------------
-    launch_cluster(st, split ? 2 : 0);
+    SVXCHK(launch_cluster(st, split ? 2 : 0));
     if (split) HIPCHK(hipStreamWaitEvent(st, c->ev[14], 0));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[11], st));

@@ -413,3 +413,32 @@ def test_long_cigar_cg_tag_through_both_readers(tmp_path, oracle):
         if filt:
             assert A["seq"].size < 64                 # one insertion's worth of bases instead of ~50 kb
         nb.close()
+
+
+def test_native_bam_reader_rewind_repeats_the_file(tmp_path):
+    from svim_amd.bamio import NativeBam
+    refs, lens = ["chr1", "chr2", "chr10"], [180000, 60000, 60000]
+    recs = synth.coordinate_sort(synth.fuzz_split_reads(41, 90, refs, lens))
+    path = str(tmp_path / "r.bam")
+    records.write_bam(path, refs, lens, recs)
+    nb = NativeBam(path, threads=3)
+    nb.set_seq_filter(40)
+    passes = []
+    for it in range(3):
+        if it:
+            nb.rewind()
+        got = []
+        while True:
+            b, n = nb.read_batch(50, 20, "coordinate")
+            if n == 0:
+                break
+            A = nb.batch_arrays(b)
+            got.append({k: A[k].copy() for k in ("flag", "pos", "read_id", "cigar", "seq", "seg_pos", "seq_rng_q0")})
+        passes.append(got)
+    nb.close()
+    assert len(passes[0]) >= 3
+    for other in passes[1:]:
+        assert len(other) == len(passes[0])
+        for x, y in zip(passes[0], other):
+            for k in x:
+                assert np.array_equal(x[k], y[k]), k

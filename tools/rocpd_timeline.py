@@ -11,7 +11,7 @@ def main(db_path, marker="k_cigar_scan"):
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     rows = cur.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
-    starts = [s for n, s, e in rows if marker in n and e - s > 1000000]
+    starts = [s for n, s, e in rows if marker in n and e - s > 100000]
     if not starts:
         return
     t0 = starts[-1]

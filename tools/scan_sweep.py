@@ -7,7 +7,7 @@ o = types.SimpleNamespace(min_mapq=20, min_sv_size=40, max_sv_size=100000, segme
 p = _abi.Params.from_options(o)
 b, genome, meta = devsynth.make_batch(n_reads=1000000, contig_len=250_000_000, seed=2, device="cuda:0")
 bs = b.struct()
-for mp, blocks in itertools.product((0,), (4, 5, 6)):
+for mp, blocks in itertools.product((0, 1), (4, 6, 8)):
     os.environ["SVX_SCAN_MAP"] = str(mp); os.environ["SVX_SCAN_BLOCKS"] = str(blocks)
     eng = _lib.Engine(0)
     ts = []
