@@ -51,7 +51,7 @@ template <class T> struct RawVec {
             void* q = nullptr;
             if (posix_memalign(&q, huge, rounded) != 0 || !q) throw std::string("out of host memory");
             (void)madvise(q, rounded, MADV_HUGEPAGE);
-            if (n) memcpy(q, p, n * sizeof(T));
+            if (p && n) memcpy(q, p, (n < cap ? n : cap) * sizeof(T));
             free(p);
             p = (T*)q; cap = rounded / sizeof(T);
             return;
@@ -245,6 +245,7 @@ static bool ensure(svx_bam* h, size_t need) {
         if (keep <= WIN_HEAD) {
             memcpy(h->next.data() + WIN_HEAD - keep, h->buf.data() + h->pos, keep);
             std::swap(h->buf.p, h->next.p); std::swap(h->buf.cap, h->next.cap);
+            h->next.n = 0;                                   // the old window's content is dead: nothing to preserve when it grows
             h->buf.n = WIN_HEAD + h->next_len;
             h->pos = WIN_HEAD - keep;
         } else {
