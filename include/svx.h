@@ -272,6 +272,9 @@ int  svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int min_mapq,
 int  svx_bam_set_seq_filter(svx_bam* h, int min_ins_len);
 /* back to the first record, keeping buffers, worker threads and the interned read names (a second pass = the steady state of a long file) */
 int  svx_bam_rewind(svx_bam* h);
+/* contig-sharded ranks: continue at BGZF virtual offset `voff` (the .bai gives the first record of every contig) and report end-of-file at
+ * the first record whose reference id exceeds last_tid or that is unplaced (-2: no limit) */
+int  svx_bam_seek(svx_bam* h, uint64_t voff, int32_t last_tid);
 int  svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** nul_separated, int64_t* blob_len);
 
 #ifdef __cplusplus

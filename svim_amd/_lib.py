@@ -23,7 +23,7 @@ SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version",
            "svx_cluster_set_shard_by_origin", "svx_cluster_remote_members", "svx_cluster_set_chain",
            "svx_set_alignment_index", "svx_genotype",
            "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster", "svx_pair_distances",
-           "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names", "svx_bam_set_seq_filter", "svx_bam_rewind"]
+           "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names", "svx_bam_set_seq_filter", "svx_bam_rewind", "svx_bam_seek"]
 
 
 class SvxError(RuntimeError):

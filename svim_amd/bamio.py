@@ -49,6 +49,11 @@ class NativeBam(object):
         if rc != 0:
             raise SvxError("svx_bam_set_seq_filter failed")
 
+    def seek(self, voff, last_tid=-2):
+        """continue at BGZF virtual offset `voff`; records beyond reference id `last_tid` end the reading (svx_bam_seek)"""
+        if self.L.svx_bam_seek(self.h, C.c_uint64(int(voff)), C.c_int32(int(last_tid))) != 0:
+            raise SvxError("svx_bam_seek failed: %s" % self.L.svx_last_error().decode())
+
     def rewind(self):
         """back to the first record; buffers, threads and interned names are kept (svx_bam_rewind)"""
         if self.L.svx_bam_rewind(self.h) != 0:

@@ -137,6 +137,8 @@ struct svx_bam {
     double t_wait = 0, t_copy = 0, t_walk = 0, t_decode = 0, t_intern = 0, t_post = 0;       // SVX_BAM_TIMING=1: seconds per stage, printed at close
     BatchArrays ba[2]; BatchArrays* b = &ba[0];
     Pool* pool = nullptr; Pool* pool_inflate = nullptr;
+    bool region_done = false;
+    int32_t tid_limit = -2;         // svx_bam_seek: reading stops (like EOF) at the first record whose reference id exceeds this (-2 = none)
     int seq_min_ins = 0;            // > 0: sparse SEQ (coordinate mode): only insertions of at least this length + whole split-read primaries
     struct KeptRange { uint32_t rec; int32_t q0, len; };
     std::vector<std::vector<KeptRange>> t_ranges;          // per decode task
@@ -350,6 +352,23 @@ extern "C" int svx_bam_set_seq_filter(svx_bam* h, int min_ins_len) {
     return SVX_OK;
 }
 
+// Contig-range reading for contig-sharded ranks: continue at virtual offset `voff` (from the .bai: the first record of a contig) and
+// treat the first record whose reference id is above `last_tid` (or unplaced) as the end of the file.  last_tid = -2 lifts the limit.
+extern "C" int svx_bam_seek(svx_bam* h, uint64_t voff, int32_t last_tid) {
+    if (!h) return bam_fail(SVX_E_ARG, "null reader");
+    if (h->prefetch_active) { h->prefetch.wait(); h->prefetch_active = false; }
+    h->prefetch_err.clear();
+    const size_t coff = (size_t)(voff >> 16), uoff = (size_t)(voff & 0xffff);
+    if (coff > h->map_len) return bam_fail(SVX_E_ARG, "virtual offset beyond the end of the file");
+    h->fpos = coff; h->file_eof = false; h->buf.clear(); h->pos = 0; h->next_len = 0; h->next_eof = false;
+    h->tid_limit = last_tid; h->region_done = false;
+    try {
+        if (uoff && !ensure(h, uoff)) throw std::string("virtual offset beyond its block");
+        h->pos += uoff;
+    } catch (const std::string& e) { return bam_fail(SVX_E_ARG, e); }
+    return SVX_OK;
+}
+
 // Back to the first alignment record, keeping every buffer, thread and interned read name: a second pass over the same file (the
 // steady state of a long file: no first-touch allocation anywhere).
 extern "C" int svx_bam_rewind(svx_bam* h) {
@@ -370,7 +389,7 @@ extern "C" int svx_bam_rewind(svx_bam* h) {
             h->pos += l_name + 4;
         }
     } catch (const std::string& e) { return bam_fail(SVX_E_ARG, e); }
-    h->total_records = 0;
+    h->total_records = 0; h->tid_limit = -2; h->region_done = false;
     return SVX_OK;
 }
 
@@ -480,6 +499,10 @@ static int64_t decode_run(svx_bam* h, int64_t max_count, bool sparse) {
         const uint32_t l_seq = rd32(rr.r + 16);
         rr.cig = rr.r + 32 + l_name;
         if (rr.cig + 4 * (size_t)rr.n_cig + (l_seq + 1) / 2 + l_seq > rr.end) throw std::string("corrupt BAM record");
+        if (h->tid_limit != -2) {                          // contig-range reading: the range ends where the next contig (or the unplaced tail) begins
+            const int32_t t = (int32_t)rd32(rr.r);
+            if (t < 0 || t > h->tid_limit) { h->region_done = true; break; }
+        }
         // long CIGARs (> 65535 ops) live in CG:B,I behind a <l_seq>S<ref_len>N placeholder
         if (rr.n_cig == 2 && (rd32(rr.cig) & 15) == 4 && (rd32(rr.cig) >> 4) == l_seq && (rd32(rr.cig + 4) & 15) == 3) {
             const char* sa; size_t sa_n; const uint8_t* cg; uint32_t cg_n;
@@ -654,11 +677,13 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
         clear_batch(h);
         const bool sparse = h->seq_min_ins > 0 && mode == 0;
         int64_t n = 0;
-        while (n < max_records) {
+        while (n < max_records && !h->region_done) {
             if (!ensure(h, 4)) break;                                                   // end of file
             const uint32_t bs = rd32(h->buf.data() + h->pos);
             if (!ensure(h, 4 + (size_t)bs)) throw std::string("truncated BAM record");
-            n += decode_run(h, max_records - n, sparse);                                 // at least the record just made available
+            const int64_t got = decode_run(h, max_records - n, sparse);                  // at least the record just made available
+            if (got == 0 && !h->region_done) throw std::string("BAM record larger than the inflate window");
+            n += got;
         }
         if (mode == 1 && n == max_records) {
             // finish the current read group: keep reading while the name does not change (peek = parse, names are interned)

@@ -25,13 +25,15 @@ from . import _abi, _lib, convert
 class BamPipeline(object):
     """reader thread || GPU thread over one BAM file; results stay resident in the engine (accumulated lists)."""
 
-    def __init__(self, path, options, engine, threads=0, batch_records=200_000, mode="coordinate", sparse_seq=True):
+    def __init__(self, path, options, engine, threads=0, batch_records=200_000, mode="coordinate", sparse_seq=True, regions=None):
         from .bamio import NativeBam
         self.bam = NativeBam(path, threads=threads)
         self.options, self.eng, self.mode, self.batch_records = options, engine, mode, batch_records
         self.params = _abi.Params.from_options(options)
         if sparse_seq and mode == "coordinate":
             self.bam.set_seq_filter(int(getattr(options, "min_sv_size", 40)))
+        self.regions = regions            # [(virtual offset, last reference id)]: the contig runs this rank reads (None: the whole file)
+        self.region_slots = []            # per region: (first local emission slot, records)
         self.stats = {}
 
     def run(self):
@@ -43,18 +45,25 @@ class BamPipeline(object):
 
         def reader():
             try:
-                while True:
-                    free.acquire()
-                    t0 = time.perf_counter()
-                    b, n = bam.read_batch(self.batch_records, min_mapq, self.mode)
-                    t_read[0] += time.perf_counter() - t0
-                    box.append((b, n))
-                    ready.release()
-                    if n == 0:
-                        return
+                for region in (self.regions if self.regions is not None else [None]):
+                    if region is not None:
+                        bam.seek(region[0], region[1])
+                    while True:
+                        free.acquire()
+                        t0 = time.perf_counter()
+                        b, n = bam.read_batch(self.batch_records, min_mapq, self.mode)
+                        t_read[0] += time.perf_counter() - t0
+                        if n == 0:
+                            free.release()
+                            break
+                        box.append((b, n, region))
+                        ready.release()
+                free.acquire()
+                box.append((None, 0, None))
+                ready.release()
             except Exception as e:                     # surfaces in the GPU thread
                 err.append(e)
-                box.append((None, 0))
+                box.append((None, 0, None))
                 ready.release()
 
         eng.accumulate(True)
@@ -63,16 +72,22 @@ class BamPipeline(object):
         th.start()
         n_rec, slot_base, t_gpu, t_wait, n_batches = 0, 0, 0.0, 0.0, 0
         k = 0
+        self.region_slots = []
+        cur_region = object()
         while True:
             t0 = time.perf_counter()
             ready.acquire()
             t_wait += time.perf_counter() - t0
-            b, n = box[k]
+            b, n, region = box[k]
             k += 1
             if err:
                 raise err[0]
             if n == 0:
                 break
+            if region is not cur_region:
+                cur_region = region
+                self.region_slots.append([slot_base, 0])
+            self.region_slots[-1][1] += n
             t0 = time.perf_counter()
             eng.set_slot_base(slot_base)
             eng.collect(b, p, fetch=False)
@@ -281,11 +296,79 @@ def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s
     return out
 
 
+def shard_plan(references, lengths, bai, rank, world):
+    """Contig ownership (multigpu.assign_contigs) and the file regions this rank reads: maximal runs of consecutive reference ids that are
+    its own (contigs without records do not interrupt a run) -> (owner[n_ref], [(virtual offset of the run's first record, last reference id,
+    first reference id)])."""
+    from .multigpu import assign_contigs
+    owner = assign_contigs(references, lengths, world)
+    n = len(references)
+    runs, t = [], 0
+    while t < n:
+        if owner[t] == rank and bai[t] is not None:
+            a = b = t
+            while b + 1 < n and (owner[b + 1] == rank or bai[b + 1] is None):
+                b += 1
+            runs.append((bai[a][0], b, a))
+            t = b + 1
+        else:
+            t += 1
+    return owner, runs
+
+
+def collect_cluster_bam_sharded(bam_path, opts, engine, adapter, rank, world, threads=0, batch_records=200_000, bai_path=None):
+    """One rank of a contig-sharded run over an indexed, coordinate-sorted BAM: read this rank's contig runs (svx_bam_seek), COLLECT
+    them batch by batch (accumulating), exchange the region sizes so that emission slots are global, then multigpu.cluster_step.
+    Returns (StepResult or None, pipeline, read-name list of this rank)."""
+    import torch.distributed as dist
+    from . import multigpu, records
+    from .batch import contig_ranks
+    from .bamio import NativeBam
+    probe = NativeBam(bam_path, threads=1)
+    refs, lens = probe.references, probe.lengths
+    probe.close()
+    bai = records.read_bai(bai_path or bam_path + ".bai")
+    owner, runs = shard_plan(refs, lens, bai, rank, world)
+    pipe = BamPipeline(bam_path, opts, engine, threads=threads, batch_records=batch_records, regions=[(v, last) for v, last, _ in runs])
+    n_rec = pipe.run()
+    # emission slots in file order: every region's local slot range moves to the sum of the spans of the regions before it in the file
+    ends = [s for s, _ in pipe.region_slots[1:]] + [pipe.region_slots[-1][0] + 2 * pipe.region_slots[-1][1] + 2 * pipe.stats["batches"] + 2] if pipe.region_slots else []
+    local = [(runs[k][2], pipe.region_slots[k][0], ends[k] - pipe.region_slots[k][0]) for k in range(len(pipe.region_slots))]   # (first tid, local start, span)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, local)
+    order = sorted((first_tid, r, k, span) for r, regs in enumerate(everyone) for k, (first_tid, _, span) in enumerate(regs))
+    base, acc = {}, 0
+    for first_tid, r, k, span in order:
+        base[(r, k)] = acc
+        acc += span
+    key_runs = ([st for _, st, _ in local], [base[(rank, k)] for k in range(len(local))]) if local else ([0], [0])
+    names = pipe.bam.read_names()
+    index = None
+
+    def names_of(ids):
+        return [names[int(i)] for i in ids]
+
+    def ids_of(nms):
+        nonlocal index
+        if index is None:
+            index = {nm: i for i, nm in enumerate(names)}
+        out = []
+        for nm in nms:
+            i = index.get(nm)
+            if i is None:
+                i = index[nm] = len(names)
+                names.append(nm)
+            out.append(i)
+        return out
+    res = multigpu.cluster_step(adapter, pipe.params, rank, world, np.arange(len(refs)), contig_ranks(refs), owner, key_runs=key_runs,
+                                names_of=names_of, ids_of=ids_of)
+    pipe.stats["records"] = n_rec
+    return res, pipe, names
+
+
 def run_bam(bam_path, fasta_path, opts, rank=0, world=1, device=0, steps=1, warmup=0, threads=0):
     """bench.py --bam PATH --fasta PATH: read / op / signature / cluster counts and the end-to-end rates of a real
     coordinate-sorted BAM on ONE GPU (contig-sharded multi-GPU reading needs the .bai route)."""
-    if world != 1:
-        raise SystemExit("bench.py --bam: one GPU per file for now (contig-sharded reading is wired for the synthetic workloads; DESIGN.md section 6)")
     if not fasta_path:
         raise SystemExit("bench.py --bam needs --fasta (the reference genome the insertion haplotypes are built from)")
     eng = _lib.Engine(device)
@@ -299,6 +382,8 @@ def run_bam(bam_path, fasta_path, opts, rank=0, world=1, device=0, steps=1, warm
     off, codes = convert.genome_arrays(fasta_path, refs)
     t_genome = time.perf_counter() - t0
     eng.set_genome(off, codes)
+    if world > 1:
+        return _run_bam_sharded(bam_path, fasta_path, opts, eng, rank, world, device, steps, warmup, threads, refs, t_genome)
     runs = _timed_bam_passes(bam_path, opts, eng, None, passes=warmup + steps, threads=threads)
     n, wall, ps, st, counts = min(runs[warmup:], key=lambda r: r[1])
     size = os.path.getsize(bam_path)
@@ -314,3 +399,40 @@ def run_bam(bam_path, fasta_path, opts, rank=0, world=1, device=0, steps=1, warm
             "end_to_end": {"bam_file_reads_per_s": n / wall, "bam_MB_per_s": size / wall / 1e6, "reader_busy_s": ps["t_reader_busy"],
                            "gpu_collect_s": ps["t_gpu_collect"], "gpu_waits_for_reader_s": ps["t_gpu_waits_for_reader"], "cluster_s": ps["t_cluster_wall"],
                            "genome_load_s": t_genome, "host_cores": os.cpu_count()}}
+
+
+def _run_bam_sharded(bam_path, fasta_path, opts, eng, rank, world, device, steps, warmup, threads, refs, t_genome):
+    """bench.py --gpus N --bam: contig-sharded ranks over one indexed BAM (needs <bam>.bai); value = records of ALL ranks / max wall."""
+    import torch
+    import torch.distributed as dist
+    from . import multigpu
+    dev = "cuda:%d" % device
+    adapter = multigpu.SvxAdapter(eng, dev)
+    best = None
+    for it in range(warmup + steps):
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        res, pipe, _ = collect_cluster_bam_sharded(bam_path, opts, eng, adapter, rank, world, threads=threads)
+        torch.cuda.synchronize(); dist.barrier()
+        wall = time.perf_counter() - t0
+        n_local = pipe.stats["records"]
+        pipe.close()
+        tt = torch.tensor([wall, float(n_local)], dtype=torch.float64, device=dev)
+        walls = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(walls, tt)
+        wall = max(float(w[0]) for w in walls)
+        n_all = int(sum(float(w[1]) for w in walls))
+        if it >= warmup and (best is None or wall < best[0]):
+            best = (wall, n_all, res)
+    if rank != 0:
+        return None
+    wall, n_all, res = best
+    ct = res.to_host()
+    return {"metric": "aligned reads/sec through COLLECT+CLUSTER", "value": n_all / wall, "unit": "reads/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * wall, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "data": "file",
+            "dtype": "u32/i32 CIGAR + u8 bases, int64 positions, f64 distances",
+            "config": {"workload": "BAM file %s (%d contigs) + FASTA %s, END TO END on %d contig-sharded ranks (.bai seek per contig run)" % (
+                os.path.basename(bam_path), len(refs), os.path.basename(fasta_path), world), "options": "SVIM alignment-mode defaults"},
+            "counts": {"records": n_all, "signatures": int(sum(res.sig_counts)), "clusters": ct.n,
+                       "clusters_by_type": dict(zip(_abi.TYPE_NAMES, [int(x) for x in ct.type_count]))},
+            "end_to_end": {"bam_file_reads_per_s": n_all / wall, "genome_load_s": t_genome, "host_cores": os.cpu_count()}}

@@ -253,7 +253,7 @@ class StepResult(object):
 
 
 def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, owner_of_contig, key_base=0, read_base=0,
-                 gather_signatures=True, names_of=None, ids_of=None):
+                 gather_signatures=True, names_of=None, ids_of=None, key_runs=None):
     """One multi-GPU CLUSTER step after this rank's COLLECT.
 
     contig_gid          int64 [n_local_contig]: global id of every LOCAL contig id the COLLECT tables use
@@ -261,6 +261,9 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
     owner_of_contig     int32 [n_global]: assign_contigs
     key_base            added to the slot half of the emission keys: 2 x (records in file order before this rank's first record)
     read_base           added to the read ids (unique across ranks when reads never span ranks: the synthetic bench layout)
+    key_runs            (local_slot_starts, global_slot_starts): a rank that collected several file regions (contig runs of a BAM) numbered
+                        its emission slots locally; region k's slots [local_k, local_k+1) start at global_k in file order
+                        (harness.collect_bam_sharded exchanges the region sizes).  Replaces key_base.
     names_of, ids_of    real inputs: a read can have records on contigs of different ranks, and the same-read rules of the
                         clustering (SVIM_clustering.py:141-167) need ONE id per read inside a rank's table.  Read ids stay
                         rank-local; foreign rows travel with their read NAMES (names_of(local ids) -> list of str) and the
@@ -271,6 +274,18 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
     dev = adapter.device
     gid = torch.as_tensor(np.asarray(contig_gid), dtype=torch.int64, device=dev)
     owner_t = torch.as_tensor(np.asarray(owner_of_contig), dtype=torch.int64, device=dev)
+    if key_runs is not None:
+        kr_local = torch.as_tensor(np.asarray(key_runs[0], dtype=np.int64), device=dev)
+        kr_delta = torch.as_tensor(np.asarray(key_runs[1], dtype=np.int64) - np.asarray(key_runs[0], dtype=np.int64), device=dev)
+
+    def global_keys(key):
+        if key_runs is None:
+            return key + (int(key_base) << 32)
+        if key.numel() == 0:
+            return key
+        run = (torch.searchsorted(kr_local, key >> 32, right=True) - 1).clamp_min(0)
+        return key + (kr_delta[run] << 32)
+
     relay = ChainRelay(rank, world, dev)
     adapter.set_chain(relay)
     n_own, _ = adapter.collect_counts()
@@ -296,7 +311,7 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
             cols["contig"] = gid[cols["contig"].long()].to(torch.int32)
             cols["contig2"] = torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()].to(torch.int32), cols["contig2"])
             cols["read_id"] = cols["read_id"] + read_base
-            cols["key"] = cols["key"] + (int(key_base) << 32)
+            cols["key"] = global_keys(cols["key"])
         local_to_global_contig = gid
     else:
         if cols is None:
@@ -307,7 +322,7 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
         cols["contig"] = gid[cols["contig"].long()].to(torch.int32)
         cols["contig2"] = torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()].to(torch.int32), cols["contig2"])
         cols["read_id"] = cols["read_id"] + read_base
-        cols["key"] = cols["key"] + (int(key_base) << 32)
+        cols["key"] = global_keys(cols["key"])
         lens = seq_off[1:] - seq_off[:-1]
         fidx = torch.nonzero(foreign).flatten()
         f_cols = {k: cols[k][fidx] for k in SIG_COLS}

@@ -482,7 +482,9 @@ def write_bam(path, references, lengths, records, sort_order="coordinate"):
     for n, l in zip(references, lengths):
         nb = n.encode("ascii") + b"\0"
         out.write(struct.pack("<i", len(nb)) + nb + struct.pack("<i", l))
+    rec_at = []                                       # (reference_id, offset of the record in the uncompressed stream)
     for a in records:
+        rec_at.append((a.reference_id, out.tell()))
         name = a.query_name.encode("ascii") + b"\0"
         cig = a._cigar
         seq = a._seq or ""
@@ -508,12 +510,66 @@ def write_bam(path, references, lengths, records, sort_order="coordinate"):
         body = core + name + struct.pack("<%dI" % len(cig), *[(l << 4) | o for o, l in cig]) + sb + b"\xff" * l_seq + aux
         out.write(struct.pack("<i", len(body)) + body)
     raw = out.getvalue()
+    block_at = []                                     # file offset of every BGZF block
     with open(path, "wb") as fh:
         for i in range(0, len(raw), 0xff00):
             chunk = raw[i:i + 0xff00]
             comp = zlib.compressobj(6, zlib.DEFLATED, -15)
             cd = comp.compress(chunk) + comp.flush()
             bsize = len(cd) + 25
+            block_at.append(fh.tell())
             fh.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + cd +
                      struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+        block_at.append(fh.tell())
         fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    if sort_order == "coordinate":
+        write_bai(path + ".bai", len(references), rec_at, len(raw), block_at, 0xff00)
+
+
+def write_bai(path, n_ref, rec_at, raw_len, block_at, block_payload):
+    """Minimal BAM index (SAM spec 5.2): per reference ONE bin (the whole-reference bin 0) with one chunk spanning its records'
+    virtual offsets, no linear index.  Enough for what svim_amd reads from an index: where a contig's records start and stop."""
+    def voff(u):
+        return (block_at[u // block_payload] << 16) | (u % block_payload)
+    first, last = {}, {}
+    for k, (tid, u) in enumerate(rec_at):
+        if tid >= 0:
+            first.setdefault(tid, u)
+            last[tid] = rec_at[k + 1][1] if k + 1 < len(rec_at) else raw_len
+    with open(path, "wb") as fh:
+        fh.write(b"BAI\1" + struct.pack("<i", n_ref))
+        for t in range(n_ref):
+            if t in first:
+                fh.write(struct.pack("<i", 1) + struct.pack("<Ii", 0, 1) + struct.pack("<QQ", voff(first[t]), voff(last[t])))
+            else:
+                fh.write(struct.pack("<i", 0))
+            fh.write(struct.pack("<i", 0))                  # n_intv
+
+
+def read_bai(path):
+    """BAM index -> list of (first, last) virtual offsets per reference (None for a reference without records): the smallest chunk
+    begin and largest chunk end over all bins (the metadata pseudo-bin 37450 aside)."""
+    with open(path, "rb") as fh:
+        data = fh.read()
+    if data[:4] != b"BAI\1":
+        raise ValueError("not a BAM index: %s" % path)
+    n_ref = struct.unpack_from("<i", data, 4)[0]
+    p = 8
+    out = []
+    for _ in range(n_ref):
+        n_bin = struct.unpack_from("<i", data, p)[0]
+        p += 4
+        lo, hi = None, None
+        for _b in range(n_bin):
+            bin_id, n_chunk = struct.unpack_from("<Ii", data, p)
+            p += 8
+            for _c in range(n_chunk):
+                beg, end = struct.unpack_from("<QQ", data, p)
+                p += 16
+                if bin_id != 37450:
+                    lo = beg if lo is None or beg < lo else lo
+                    hi = end if hi is None or end > hi else hi
+        n_intv = struct.unpack_from("<i", data, p)[0]
+        p += 4 + 8 * n_intv
+        out.append((lo, hi) if lo is not None else None)
+    return out
