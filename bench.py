@@ -74,12 +74,17 @@ def cpu_baseline(batch, g_off, genome, params, eng=None, budget_s=20.0):
                     "reference's Python loops: tests/golden/g_c1.json.gz records 1.99 s + 4.75 s of reference Python for 10 k records; "
                     "the reference itself cannot travel to the GPU box)",
             "sample": "first %d records of the same batch (coordinate order): %d reads used, %d signatures, %d clusters; "
-                      "collect %.2f s + cluster %.2f s on 1 host core (of %d)" % (
+                      "collect %.2f s + cluster %.2f s on 1 host core (%d visible, %d granted by the cgroup CPU quota)" % (
                           best["n_rec"], best["used"], best["n_sig"], best["n_clusters"], best["t_collect"], best["t_cluster"],
-                          os.cpu_count()),
+                          os.cpu_count(), _granted_cpus()),
             "signatures_per_s": best["n_sig"] / max(best["t_cluster"], 1e-9),
             "cigar_ops_per_s": best["ops"] / max(best["t_collect"], 1e-9),
             "edit_cells_per_s": best["edit_cells"] / max(best["t_cluster"], 1e-9)}
+
+
+def _granted_cpus():
+    from svim_amd.harness import effective_cpus
+    return effective_cpus()
 
 
 def load_profile_json(name):

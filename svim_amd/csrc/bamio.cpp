@@ -267,10 +267,24 @@ static bool ensure(svx_bam* h, size_t need) {
 static inline uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
+// CPUs this process may actually use: the visible cores capped by the cgroup CPU quota (a container that shows 256 cores but is granted
+// 16 CPUs' worth of time gets throttled for the rest of every scheduler period once 100+ busy threads have burnt the quota)
+static int default_threads() {
+    unsigned n = std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = -1, period = 0;
+        char first[32] = {0};
+        if (fscanf(f, "%31s %lld", first, &period) == 2 && strcmp(first, "max") != 0) quota = atoll(first);
+        fclose(f);
+        if (quota > 0 && period > 0) { const unsigned q = (unsigned)((quota + period - 1) / period); if (q >= 1 && q < n) n = q; }
+    }
+    return (int)n;
+}
+
 extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out) {
     svx_bam* h = new svx_bam();
     h->path = path;
-    h->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
+    h->n_threads = n_threads > 0 ? n_threads : default_threads();
     // a chunk must keep every worker busy for a while: ~4 MB of inflated data per thread
     h->chunk_bytes = std::max<size_t>((size_t)48 << 20, (size_t)h->n_threads * ((size_t)4 << 20));
     h->chunk_blocks = std::max<size_t>(1024, h->chunk_bytes / 48000);

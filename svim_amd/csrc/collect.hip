@@ -118,6 +118,9 @@ __device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& ou
     const int min_len = b.min_sv_size;
     int acc_ref = 0, acc_read = 0, acc_n = 0, acc_h = 0, acc_s = 0;
     const unsigned long long a0 = off0 & ~3ull;
+    unsigned long long done_k = a0;                          // !GEOM: operations before done_k are in acc_ref / acc_read
+    // packed word of the shortest reportable indel (any op code); a filter only - the exact test follows in the emission branch
+    const uint32_t emit_floor = min_len > 0x0fffffff ? 0xffffffffu : ((uint32_t)(min_len > 0 ? min_len : 0) << 4);
     // NU consecutive 1 KiB chunks per trip: the loads of the next trip are all issued before the current one is decoded,
     // so a wave keeps NU KiB in flight (memory-level parallelism is what this kernel lives on)
     constexpr int NU = SVX_SCAN_NU;
@@ -150,15 +153,50 @@ __device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& ou
             if (k + 3 < off0 || k + 3 >= off1) q.w = 15u;
         }
         const uint32_t v[4] = {q.x, q.y, q.z, q.w};
+#if defined(SVX_SCAN_PROBE) && SVX_SCAN_PROBE == 1       /* experiment (tools/build_variants.sh): the access pattern alone, no decode */
+        acc_ref += (int)(v[0] ^ v[1] ^ v[2] ^ v[3]);
+        continue;
+#endif
         int t_ref = 0, t_read = 0;
         bool any_emit = false;
+#ifndef SVX_SCAN_ALWAYS_ACC      /* experiment switch: decode every chunk instead of catching up on demand */
+        if (!GEOM) {
+            // A record without segment rows needs its cursors only where it reports an indel: the streaming path just asks "is any of
+            // these operations a long I / D" (two compares per operation on the packed word) and leaves the running sums alone ...
+#pragma unroll
+            for (int j = 0; j < 4; j++) any_emit |= (v[j] >= emit_floor) && (((v[j] - 1u) & 15u) < 2u);
+            if (!__any(any_emit)) continue;
+            // ... and catches up when one turns up: the operations of [done_k, k0) are decoded now (they were streamed moments ago: L2)
+            for (unsigned long long kk = done_k; kk < k0; kk += 256ull) {
+                const unsigned long long kc = kk + (unsigned long long)lane * 4;
+                uint4 r = load_chunk(cig, kc, off1, tot);
+                if (kk < off0) {
+                    if (kc < off0) r.x = 15u;
+                    if (kc + 1 < off0) r.y = 15u;
+                    if (kc + 2 < off0) r.z = 15u;
+                    if (kc + 3 < off0) r.w = 15u;
+                }
+                const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int op = (int)(rv[j] & 15u), l = (int)(rv[j] >> 4);
+                    acc_ref += op_sel(MASK_REF, op, l);
+                    acc_read += op_sel(MASK_READ, op, l);
+                }
+            }
+            done_k = k0 + 256ull;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int op = (int)(v[j] & 15u), l = (int)(v[j] >> 4);
             t_ref += op_sel(MASK_REF, op, l);
             t_read += op_sel(MASK_READ, op, l);
+#ifdef SVX_SCAN_ALWAYS_ACC
             any_emit |= ((unsigned)(op - 1) < 2u) && l >= min_len;
+#endif
             if (GEOM) {
+                any_emit |= ((unsigned)(op - 1) < 2u) && l >= min_len;
                 acc_n += (op == 3) ? l : 0;
                 acc_h += (op == 5) ? l : 0;
                 acc_s += (op == 4) ? l : 0;
@@ -175,7 +213,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& ou
                 const bool e = ((unsigned)(op - 1) < 2u) && l >= min_len;
                 const unsigned long long m = __ballot(e);
                 if (m) {
-                    const long long slot = (long long)n_out + __popcll(m & lanemask_lt());
+                    const long long slot = (long long)n_out + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                     if (e && slot < out.shard_cap) {
                         RawIndel ri;
                         ri.item = (uint32_t)w; ri.opidx = (uint32_t)((k + j) - off0);

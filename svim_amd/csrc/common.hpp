@@ -183,11 +183,21 @@ int svx_linkage_batch(svx_ctx* c, int64_t n_problems, const int32_t* n_dev, cons
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// 32-bit inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (7 dependent VALU steps; __shfl_up goes through
+// ds_bpermute, the LDS crossbar, at ~10x the latency).  A lane switched off by the bank / row mask receives `old` = 0.
+#define SVX_DPP_ADD(dst_, src_, ctrl_, row_, bank_) dst_ += __builtin_amdgcn_update_dpp(0, src_, ctrl_, row_, bank_, true)
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    int s = v;
+    SVX_DPP_ADD(s, v, 0x111, 0xf, 0xf);          // row_shr:1
+    SVX_DPP_ADD(s, v, 0x112, 0xf, 0xf);          // row_shr:2
+    SVX_DPP_ADD(s, v, 0x113, 0xf, 0xf);          // row_shr:3   -> 4 neighbours
+    SVX_DPP_ADD(s, s, 0x114, 0xf, 0xe);          // row_shr:4, lanes 4..15 of a row  -> 8
+    SVX_DPP_ADD(s, s, 0x118, 0xf, 0xc);          // row_shr:8, lanes 8..15           -> the row of 16
+    SVX_DPP_ADD(s, s, 0x142, 0xa, 0xf);          // row_bcast:15 into rows 1 and 3
+    SVX_DPP_ADD(s, s, 0x143, 0xc, 0xf);          // row_bcast:31 into rows 2 and 3
+    return s;
 }
+__device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i32(v), 63); }
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -202,12 +212,5 @@ __device__ __forceinline__ long long wave_incl_scan_i64(long long v) {
     }
     return v;
 }
-__device__ __forceinline__ int wave_incl_scan_i32(int v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o, 64);
-        if (lane_id() >= o) v += t;
-    }
-    return v;
-}
+
 #endif

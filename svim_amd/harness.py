@@ -22,6 +22,19 @@ import numpy as np
 from . import _abi, _lib, convert
 
 
+def effective_cpus():
+    """CPUs this process may use: affinity mask capped by the cgroup CPU quota (what `os.cpu_count()` does not tell)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 class BamPipeline(object):
     """reader thread || GPU thread over one BAM file; results stay resident in the engine (accumulated lists)."""
 
@@ -258,7 +271,7 @@ def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s
     gen = (g_off, genome, True)
     p = _abi.Params.from_options(opts)
     out = {"sample": "first %d records of the batch as a BAM file (%.0f MB, %.0f MB inflated; written in %.1f s, untimed)" % (n, size / 1e6, raw_bytes / 1e6, t_write),
-           "host_cores": os.cpu_count()}
+           "host_cores_visible": os.cpu_count(), "host_cpus_granted": effective_cpus()}
     try:
         per_batch = max(1000, n // 6)                                      # several batches: the reader runs ahead of the GPU thread
         runs = _timed_bam_passes(path, opts, eng, gen, passes=4, batch_records=per_batch)
@@ -269,7 +282,7 @@ def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s
         out["bam_file"] = {"records": n_read, "wall_s": wall, "bam_MB_per_s": size / wall / 1e6, "inflated_MB_per_s": raw_bytes / wall / 1e6,
                            "batches": ps["batches"], "reader_busy_s": ps["t_reader_busy"], "gpu_collect_s": ps["t_gpu_collect"],
                            "gpu_waits_for_reader_s": ps["t_gpu_waits_for_reader"], "cluster_s": ps["t_cluster_wall"],
-                           "signatures": counts[0], "bound_by": "reader (BGZF inflate + decode on the host cores)" if ps["t_gpu_waits_for_reader"] > 0.5 * wall else "GPU"}
+                           "signatures": counts[0], "bound_by": "reader (BGZF inflate + decode on the granted host CPUs)" if ps["t_gpu_waits_for_reader"] > 0.5 * wall else "GPU"}
         # dense SEQ for comparison: what the sparse filter saves on PCIe and in the decoder
         r = min(_timed_bam_passes(path, opts, eng, gen, passes=3, batch_records=per_batch, sparse_seq=False)[1:], key=lambda x: x[1])
         out["bam_file_dense_seq_reads_per_s"] = r[0] / r[1]
@@ -398,7 +411,7 @@ def run_bam(bam_path, fasta_path, opts, rank=0, world=1, device=0, steps=1, warm
                        "large_partitions": st["n_large_partitions"], "edit_pairs": st["n_edit_pairs"]},
             "end_to_end": {"bam_file_reads_per_s": n / wall, "bam_MB_per_s": size / wall / 1e6, "reader_busy_s": ps["t_reader_busy"],
                            "gpu_collect_s": ps["t_gpu_collect"], "gpu_waits_for_reader_s": ps["t_gpu_waits_for_reader"], "cluster_s": ps["t_cluster_wall"],
-                           "genome_load_s": t_genome, "host_cores": os.cpu_count()}}
+                           "genome_load_s": t_genome, "host_cores_visible": os.cpu_count(), "host_cpus_granted": effective_cpus()}}
 
 
 def _run_bam_sharded(bam_path, fasta_path, opts, eng, rank, world, device, steps, warmup, threads, refs, t_genome):
@@ -435,4 +448,4 @@ def _run_bam_sharded(bam_path, fasta_path, opts, eng, rank, world, device, steps
                 os.path.basename(bam_path), len(refs), os.path.basename(fasta_path), world), "options": "SVIM alignment-mode defaults"},
             "counts": {"records": n_all, "signatures": int(sum(res.sig_counts)), "clusters": ct.n,
                        "clusters_by_type": dict(zip(_abi.TYPE_NAMES, [int(x) for x in ct.type_count]))},
-            "end_to_end": {"bam_file_reads_per_s": n_all / wall, "genome_load_s": t_genome, "host_cores": os.cpu_count()}}
+            "end_to_end": {"bam_file_reads_per_s": n_all / wall, "genome_load_s": t_genome, "host_cores_visible": os.cpu_count(), "host_cpus_granted": effective_cpus()}}
