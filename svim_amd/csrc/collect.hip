@@ -153,13 +153,8 @@ __device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& ou
             if (k + 3 < off0 || k + 3 >= off1) q.w = 15u;
         }
         const uint32_t v[4] = {q.x, q.y, q.z, q.w};
-#if defined(SVX_SCAN_PROBE) && SVX_SCAN_PROBE == 1       /* experiment (tools/build_variants.sh): the access pattern alone, no decode */
-        acc_ref += (int)(v[0] ^ v[1] ^ v[2] ^ v[3]);
-        continue;
-#endif
         int t_ref = 0, t_read = 0;
         bool any_emit = false;
-#ifndef SVX_SCAN_ALWAYS_ACC      /* experiment switch: decode every chunk instead of catching up on demand */
         if (!GEOM) {
             // A record without segment rows needs its cursors only where it reports an indel: the streaming path just asks "is any of
             // these operations a long I / D" (two compares per operation on the packed word) and leaves the running sums alone ...
@@ -186,15 +181,11 @@ __device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& ou
             }
             done_k = k0 + 256ull;
         }
-#endif
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int op = (int)(v[j] & 15u), l = (int)(v[j] >> 4);
             t_ref += op_sel(MASK_REF, op, l);
             t_read += op_sel(MASK_READ, op, l);
-#ifdef SVX_SCAN_ALWAYS_ACC
-            any_emit |= ((unsigned)(op - 1) < 2u) && l >= min_len;
-#endif
             if (GEOM) {
                 any_emit |= ((unsigned)(op - 1) < 2u) && l >= min_len;
                 acc_n += (op == 3) ? l : 0;

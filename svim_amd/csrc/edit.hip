@@ -238,9 +238,7 @@ __device__ __forceinline__ int full_class_for(int m) {
     if (m <= 512) return CLS_LANE0 + lane_class_for(m);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-#ifndef SVX_NO_WIDE12          /* experiment switch (tools/build_variants.sh) */
         if (m <= (768 << k)) return CLS_WIDE12 + k;
-#endif
         if (m <= (1024 << k)) return CLS_WIDE0 + k;
     }
     return CLS_FULL;
@@ -417,7 +415,9 @@ __global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort
         if (by_frac > guess) guess = by_frac;
         guess += 2 * CLS_SHIFT(pd.cls);                 // what the position shift alone costs (see PairSource::views)
         int spec = band_class_for((pd.n - pd.m) + guess + 1);
-        if (spec == CLS_FULL && band_class_for((pd.n - pd.m) + 2 * MIN_MARGIN + 1) != CLS_FULL) spec = NBAND - 1;      // widest band before giving up on banding
+        // widest band before giving up on banding - unless the position shift alone (which costs 2 * shift whatever the sequences are)
+        // already exceeds it: such a pair is either unrelated or out of every band's reach, the attempt would only delay its full matrix
+        if (spec == CLS_FULL && band_class_for((pd.n - pd.m) + 2 * CLS_SHIFT(pd.cls) + 2 * MIN_MARGIN + 1) != CLS_FULL) spec = NBAND - 1;
         cls = guaranteed <= spec ? guaranteed : spec;
         // short patterns: the whole column fits one lane (k_edit_lane), nothing to speculate about
         if (cls > 0 && cls < NBAND && pd.m <= 512 && (1 << lane_class_for(pd.m)) <= band_words(cls)) cls = CLS_LANE0 + lane_class_for(pd.m);
@@ -750,11 +750,7 @@ __device__ __forceinline__ void d_edit_stair(long long blk, long long count, con
         }
         const uint32_t tword = tq[0];
         tq[0] = tq[1]; tq[1] = tq[2]; tq[2] = tq[3];
-#ifdef SVX_STAIR_PRED_ALWAYS    /* experiment switch (tools/build_variants.sh) */
-        if (false) {}
-#else
         if (jb * 8 + 8 <= nmin) columns8(tword, jb * 8, std::false_type{});
-#endif
         else columns8(tword, jb * 8, std::true_type{});
     }
     wc_account(wc, (long long)nmax * Q * 64, (long long)n * Q);
@@ -1091,6 +1087,11 @@ __device__ __forceinline__ void d_edit_full(long long blk, long long count, cons
 // launches: every band class in one grid, every full-matrix class in another.  Segments are laid out costliest first; a block
 // looks up its segment (uniform, scalar) and runs that class's routine.
 #define SEG_MAX 14
+// A full-matrix pair is one serial chain of n steps, each as long as the words a lane holds.  When a round has only a few hundred long
+// pairs (HiFi-like data: related pairs need tiny bands, what is left are a few unrelated long ones) the launch lasts as long as its
+// slowest wave while most of the chip idles; the host then launches the classes beyond 2048 rows in their low-latency form - 64 lanes
+// with 2-4 words each instead of 8-16 lanes with 12-16 words: ~3x shorter chains for ~1.4x the instructions.
+#define KIND_LL 32
 struct FusedTab {
     int n;
     int kind[SEG_MAX];                     // class id (0..13)
@@ -1140,7 +1141,11 @@ __global__ __launch_bounds__(256) void k_edit_fulls(FusedTab tab, const uint32_t
         case CLS_WIDE12: d_edit_wide<2, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
         case CLS_WIDE12 + 1: d_edit_wide<4, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
         case CLS_WIDE12 + 2: d_edit_wide<8, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
-        default: d_edit_wide<16, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE12 + 3: d_edit_wide<16, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        // low-latency forms of the long classes (KIND_LL + words per lane): one pair per wave, 64 lanes x 2 / 3 / 4 words
+        case KIND_LL + 2: d_edit_wide<64, 2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case KIND_LL + 3: d_edit_wide<64, 3, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        default: d_edit_wide<64, 4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
     }
 }
 
@@ -1371,13 +1376,34 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             // longest serial chains first: systolic (one wave per pair), 8/4/2 lanes per pair, then the lane classes
             static const int order[14] = {CLS_FULL, CLS_WIDE0 + 3, CLS_WIDE12 + 3, CLS_WIDE0 + 2, CLS_WIDE12 + 2, CLS_WIDE0 + 1, CLS_WIDE12 + 1, CLS_WIDE0, CLS_WIDE12,
                                           CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};
+            auto class_threads = [&](int cls, long long cn) -> long long {
+                if (cls == CLS_FULL) return cn * 64;
+                if (cls >= CLS_WIDE12) return cn * (2 << (cls - CLS_WIDE12));
+                if (cls >= CLS_WIDE0) return cn * (2 << (cls - CLS_WIDE0));
+                return cn;
+            };
+            // low-latency form of a long class: KIND_LL + words per lane (64 lanes), 0 = none
+            auto ll_kind = [](int cls) -> int {
+                if (cls == CLS_WIDE0 + 2 || cls == CLS_WIDE12 + 2) return KIND_LL + 2;       // <= 4096 rows
+                if (cls == CLS_WIDE12 + 3) return KIND_LL + 3;                              // <= 6144
+                if (cls == CLS_WIDE0 + 3) return KIND_LL + 4;                               // <= 8192
+                return 0;
+            };
+            long long waves_normal = 0, waves_ll = 0;
+            for (int k = 0; k < 14; k++) {
+                const long long cn = seg_cn[base + order[k]];
+                if (cn <= 0) continue;
+                waves_normal += (class_threads(order[k], cn) + 63) / 64;
+                waves_ll += ll_kind(order[k]) ? cn : (class_threads(order[k], cn) + 63) / 64;
+            }
+            const bool low_latency = !getenv("SVX_EDIT_NO_LL") && waves_normal <= 2 * 4 * (long long)c->n_cu && waves_ll <= 8 * 4 * (long long)c->n_cu;
             for (int k = 0; k < 14; k++) {
                 const int cls = order[k];
                 const long long cn = seg_cn[base + cls];
                 if (cn <= 0) continue;
-                long long threads = cn;
-                if (cls == CLS_FULL) threads = cn * 64; else if (cls >= CLS_WIDE12) threads = cn * (2 << (cls - CLS_WIDE12)); else if (cls >= CLS_WIDE0) threads = cn * (2 << (cls - CLS_WIDE0));
-                tf.kind[tf.n] = cls; tf.lo[tf.n] = seg_lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
+                const int ll = low_latency ? ll_kind(cls) : 0;
+                const long long threads = ll ? cn * 64 : class_threads(cls, cn);
+                tf.kind[tf.n] = ll ? ll : cls; tf.lo[tf.n] = seg_lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
                 nblk += (unsigned)((threads + T - 1) / T); tf.n++;
             }
             tf.first_block[tf.n] = nblk;
