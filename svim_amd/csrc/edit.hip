@@ -376,7 +376,11 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     }
     // mismatches of the trivial left-justified alignment
     const uint32_t* wp = packed + P.word_off; const uint32_t* wt = packed + T.word_off;
+    // The bound is only worth its pass over the cores when it is SMALL (aligned copies of one sequence).  Most pairs are shifted against
+    // each other or unrelated: three quarters of their positions mismatch from the first symbols on.  After the first 8 G symbols a pair
+    // with more than 25 % mismatches gives up on the bound (ub = n: substitute the shorter core, insert the rest) and skips the pass.
     int ham_l = 0;
+    bool useless = false;
     for (int base = 0; base < pd.m; base += 8 * G) {
         const int i0 = base + lane * 8;
         if (i0 < pd.m) {
@@ -385,9 +389,16 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
             const uint32_t x = (fetch8(wp, p0 + i0) ^ fetch8(wt, t0 + i0)) & vmask;
             ham_l += __popc((x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u);
         }
+        if (base == 0 && pd.m > 8 * G) {
+            int first = ham_l;
+#pragma unroll
+            for (int o = G / 2; o >= 1; o >>= 1) first += __shfl_xor(first, o, 64);
+            if (first > 2 * G) { useless = true; break; }
+        }
     }
 #pragma unroll
     for (int o = G / 2; o >= 1; o >>= 1) ham_l += __shfl_xor(ham_l, o, 64);          // sum over the sub-group
+    if (useless) ham_l = pd.m;
     const int zero = (A.flags | B.flags) & HAP_ZERO, other = (A.flags | B.flags) & HAP_OTHER;      // of the whole records: conservative
     if (lane == 0) {
         pd.ub = ham_l + (pd.n - pd.m);
@@ -1319,7 +1330,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     k_edit_classify<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, desc, key_a, val_a, c->edit_force_full ? 1 : 0, guess);
     HIPCHK(hipGetLastError());
     // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
-    SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, 40));
+    SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, 40));      // 32 bits of cost order + 6 bits of class (+2 spare)
     k_class_bounds<<<1, 128, 0, st>>>(key_b, n_work, reinterpret_cast<long long*>(cnt + 8));
     long long bounds[N_SORT_CLASSES + 1];
     HIPCHK(hipMemcpyAsync(bounds, cnt + 8, (N_SORT_CLASSES + 1) * 8, hipMemcpyDeviceToHost, st));
