@@ -264,9 +264,9 @@ def main():
     edit_s = avg["t_edit_ms"] * 1e-3
     wc_issued, wc_useful = st.get("n_edit_wordcols_issued", 0), st.get("n_edit_wordcols_useful", 0)
     roofline_edit = None
+    pj = load_profile_json("pmc_edit_kernels.json")
     if edit_s > 0 and wc_issued:
         instr = wc_issued / 64.0 * INSTR_PER_WORDCOL
-        pj = load_profile_json("pmc_edit_kernels.json")
         roofline_edit = {
             "kernels": "k_edit_bands<P> + k_edit_fulls<P> (all rounds; the window also holds pack/prep/sort/pilot)", "bound": "valu",
             "seconds": edit_s, "word_columns_executed": wc_issued, "word_columns_useful": wc_useful,
@@ -279,9 +279,14 @@ def main():
             "frac_useful_work_only": (wc_useful / 64.0 * CYCLES_PER_WORDCOL) / (edit_s * 1024 * 2.4e9),
             "note": "frac counts 2 cycles per instruction; the update's instruction mix (v_bitop3 / v_alignbit / v_addc_co are half rate) "
                     "needs 38 issue cycles per word-column: frac_issue_cycles prices exactly that",
-            "pmc": pj, "band_speculation_fraction": st.get("edit_guess"),
+            "band_speculation_fraction": st.get("edit_guess"),
             "gcups_executed": wc_issued * 32 / edit_s / 1e9, "gcups_full_matrix_equivalent": st["n_edit_cells"] / edit_s / 1e9,
         }
+    if roofline_edit is not None and pj and pj.get("workload_cigar_ops") == meta["n_ops"]:
+        # the same kernels under rocprofv3 --pmc (profiles/, measured at the commit named inside): instructions actually issued
+        roofline_edit["pmc"] = {"wave_valu_instr": pj["wave_valu_instr_per_step"], "source": pj["source"], "commit": pj["measured_at_commit"],
+                                "valu_instr_per_word_column": pj["wave_valu_instr_per_step"] / (wc_issued / 64.0),
+                                "frac": pj["wave_valu_instr_per_step"] / edit_s / VALU_PEAK_WAVE_INSTR_PER_S}
     kernels = {
         "k_cigar_scan_ms": avg["t_cigar_scan_ms"], "k_segments_ms": avg["t_segments_ms"], "collect_order_ms": avg["t_sort_ms"],
         "collect_gather_ms": avg["t_gather_ms"], "collect_total_ms": avg["t_collect_ms"],

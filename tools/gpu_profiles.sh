@@ -11,7 +11,7 @@ rm -rf /tmp/kt && (cd $R && rocprofv3 --kernel-trace --stats -d /tmp/kt -o p -- 
 db=$(find /tmp/kt -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $db $R/gpurun_out/${tag}_kernel_stats.csv > /dev/null
 python $R/tools/rocpd_timeline.py $db > $R/gpurun_out/${tag}_step_timeline.txt
-for pass in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+for pass in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "FETCH_SIZE" "WRITE_SIZE" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES"; do
   t=$(echo $pass | tr ' ' '_' | cut -c1-24)
   rm -rf /tmp/pmc_$t
   (cd $R && timeout 300 rocprofv3 --kernel-trace --pmc $pass -d /tmp/pmc_$t -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2> /tmp/pmc_$t.err)
@@ -25,4 +25,8 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_c1.json 2> gpuru
 python bench.py --steps 10 --warmup 3 --workload c2 --no-cpu-baseline > gpurun_out/${tag}_bench_c2.json 2>/dev/null
 for pmd in 1000 5000 20000 100000; do python bench.py --steps 5 --warmup 2 --workload c4 --partition-max-distance $pmd --no-cpu-baseline > gpurun_out/${tag}_bench_c4_pmd$pmd.json 2>/dev/null; done
 SVX_BENCH_FORCE_DIST=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end > gpurun_out/${tag}_bench_c1_dist_path_1rank.json 2>/dev/null
-ls -la gpurun_out/${tag}_* | head -30
+bash tools/host_probe.sh > gpurun_out/${tag}_host_probe.txt 2>&1
+[ -x tools/micro/read_bw.bin ] || hipcc --offload-arch=gfx950 -O3 -o tools/micro/read_bw.bin tools/micro/read_bw.hip
+tools/micro/read_bw.bin > gpurun_out/${tag}_read_bw.txt 2>&1
+python tools/reader_scaling.py 60000 > gpurun_out/${tag}_reader_scaling.txt 2>&1
+ls -la gpurun_out/${tag}_* | head -40
