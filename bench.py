@@ -113,6 +113,13 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: everything libraries write to fd 1 (RCCL prints a version banner there) goes to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -136,10 +143,12 @@ def main():
     if args.bam:
         from svim_amd import harness
         out = harness.run_bam(args.bam, args.fasta, opts, rank=rank, world=world, device=local_rank, steps=args.steps, warmup=args.warmup)
-        if rank == 0:
-            print(json.dumps(out))
         if use_dist:
+            from svim_amd import multigpu
+            multigpu.barrier()
             dist.destroy_process_group()
+        if rank == 0:
+            emit(out)
         return
     t0 = time.perf_counter()
     if args.workload == "c1":
@@ -202,7 +211,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            MG.barrier()
         torch.cuda.synchronize()
 
     # the very first pass of a fresh context: includes every device allocation; the library keeps NO tuning state between calls
@@ -232,11 +241,11 @@ def main():
         cnt = torch.tensor([st["n_rec_used"], st["n_sig"], st["n_ops"]], dtype=torch.int64, device=dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         tot_used, tot_sig, tot_ops = (int(x) for x in cnt.tolist())
+        MG.barrier()
+        dist.destroy_process_group()                                  # all ranks together, before rank 0 goes on alone
     else:
         tot_used, tot_sig, tot_ops = st["n_rec_used"], st["n_sig"], st["n_ops"]
     if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
         return
     ms_per_step = 1e3 * elapsed / args.steps
     reads_per_s = tot_used * args.steps / elapsed
@@ -333,9 +342,7 @@ def main():
     if not args.no_cpu_baseline and world == 1 and not use_dist:           # the CPU baseline is a rank-0, N=1 measurement
         out["cpu_baseline"] = cpu_baseline(batch, g_off, genome, p, eng)
         out["speedup_vs_cpu_port"] = reads_per_s / world / out["cpu_baseline"]["value"]
-    print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
+    emit(out)
 
 
 if __name__ == "__main__":

@@ -574,71 +574,76 @@ int svx_pair_distances_impl(svx_ctx* c, const ClusterIn& in, int64_t n_pairs, co
 // ---------------------------------------------------------------------------------------------------------
 struct LinkLds {
     double* D;        // condensed distances, n(n-1)/2
-    double* Zh;       // merge heights [n-1] (unsorted), reused as sorted heights
-    double* MD;       // max height below [n-1]
-    int* Zx; int* Zy; // merge members (unsorted)
-    int* size; int* chain;
+    double* Zh;       // merge heights [n-1] in merge order
+    double* MD;       // max height below, per row of the height-sorted merge table
+    int* Zx; int* Zy; // merge members (slot indices, merge order)
+    int* chain;
     int* ord;         // merge order after the stable sort
-    int* L; int* Rr;  // relabelled children per sorted row
-    int* parent;      // union-find [2n-1]
-    int* stack; int* visited; int* labels;
+    int* labels;
 };
 
-// returns number of flat clusters; labels[0..n) in 1..ncl.  All 64 lanes must call.
+__device__ __forceinline__ int cidx24(int n, int i, int j) {        // cidx with full-rate 24-bit multiplies (n <= MAXN)
+    if (i > j) { const int t = i; i = j; j = t; }
+    return (int)__umul24((unsigned)n, (unsigned)i) - (int)(__umul24((unsigned)i, (unsigned)(i + 1)) >> 1) + (j - i - 1);
+}
+
+// returns number of flat clusters; labels[0..n) in 1..ncl.  All 64 lanes must call (one wave per problem, n <= 128).
+// Everything indexed by a cluster slot or a tree row that the serial parts of scipy's algorithm walk lives in REGISTERS spread over
+// the lanes (lane l: entries l and l + 64; lane_table_get = v_readlane with a wave-uniform index), only the distance matrix and
+// the merge table are in LDS; control flow is wave-uniform throughout.
 __device__ int linkage_fcluster_lds(int n, const LinkLds& w, double cutoff) {
     const int lane = lane_id();
     if (n == 1) { if (lane == 0) w.labels[0] = 1; __syncthreads(); return 1; }
-    for (int i = lane; i < n; i += 64) w.size[i] = 1;
-    __syncthreads();
+    int sz0 = lane < n ? 1 : 0, sz1 = lane + 64 < n ? 1 : 0;            // cluster sizes per slot, 0 = dead
     int chain_len = 0;
-    int y = 0;
     for (int k = 0; k < n - 1; k++) {
-        int x; double cur;
+        int x, yprev;
         if (chain_len == 0) {
             // first live cluster
-            const unsigned long long b0 = __ballot(lane < n && w.size[lane] > 0);
-            int first;
-            if (b0) first = __ffsll((long long)b0) - 1;
-            else { const unsigned long long b1 = __ballot(lane + 64 < n && w.size[lane + 64] > 0); first = 64 + __ffsll((long long)b1) - 1; }
-            if (lane == 0) w.chain[0] = first;
+            const unsigned long long b0 = __ballot(sz0 > 0);
+            if (b0) x = __ffsll((long long)b0) - 1;
+            else { const unsigned long long b1 = __ballot(sz1 > 0); x = 64 + __ffsll((long long)b1) - 1; }
+            if (lane == 0) w.chain[0] = x;
             chain_len = 1;
-            __syncthreads();
+            yprev = -1;
+        } else {
+            x = __builtin_amdgcn_readfirstlane(w.chain[chain_len - 1]);
+            yprev = chain_len > 1 ? __builtin_amdgcn_readfirstlane(w.chain[chain_len - 2]) : -1;
         }
+        int y; double cur;
         for (;;) {
-            x = w.chain[chain_len - 1];
-            if (chain_len > 1) { y = w.chain[chain_len - 2]; cur = w.D[cidx(n, x, y)]; }
-            else cur = __builtin_inf();
+            y = yprev;
+            cur = yprev >= 0 ? w.D[cidx24(n, x, yprev)] : __builtin_inf();
             // nearest live neighbour of x: strict '<' scanning i upward => lowest index wins ties, previous element kept on ties
             const int i0 = lane, i1 = lane + 64;
-            const bool v0 = i0 < n && i0 != x && w.size[i0] > 0, v1 = i1 < n && i1 != x && w.size[i1] > 0;
-            const double d0 = v0 ? w.D[cidx(n, x, i0)] : __builtin_inf();
-            const double d1 = v1 ? w.D[cidx(n, x, i1)] : __builtin_inf();
-            double m = d0 < d1 ? d0 : d1;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { const double t = __shfl_xor(m, o, 64); m = t < m ? t : m; }
+            const bool v0 = i0 < n && i0 != x && sz0 > 0, v1 = i1 < n && i1 != x && sz1 > 0;
+            const double d0 = v0 ? w.D[cidx24(n, x, i0)] : __builtin_inf();
+            const double d1 = v1 ? w.D[cidx24(n, x, i1)] : __builtin_inf();
+            const double m = wave_min_f64(d0 < d1 ? d0 : d1);
             if (m < cur) {
                 cur = m;
                 const unsigned long long b0 = __ballot(v0 && d0 == m);
                 if (b0) y = __ffsll((long long)b0) - 1;
                 else { const unsigned long long b1 = __ballot(v1 && d1 == m); y = 64 + __ffsll((long long)b1) - 1; }
             }
-            if (chain_len > 1 && y == w.chain[chain_len - 2]) break;
-            __syncthreads();
+            if (yprev >= 0 && y == yprev) break;
             if (lane == 0) w.chain[chain_len] = y;
             chain_len++;
-            __syncthreads();
+            yprev = x; x = y;
         }
         chain_len -= 2;
         if (x > y) { const int t = x; x = y; y = t; }
-        const int nx = w.size[x], ny = w.size[y];
-        __syncthreads();
-        if (lane == 0) { w.Zx[k] = x; w.Zy[k] = y; w.Zh[k] = cur; w.size[x] = 0; w.size[y] = nx + ny; }
+        const int nx = lane_table_get(sz0, sz1, x), ny = lane_table_get(sz0, sz1, y);
+        if (lane == 0) { w.Zx[k] = x; w.Zy[k] = y; w.Zh[k] = cur; }
+        lane_table_set(sz0, sz1, x, 0);
+        lane_table_set(sz0, sz1, y, nx + ny);
         // Lance-Williams update for average linkage, same expression as scipy
-        for (int i = lane; i < n; i += 64) {
-            if (i == y || i == x) continue;
-            if (w.size[i] == 0) continue;
-            const int iy = cidx(n, i, y);
-            w.D[iy] = ((double)nx * w.D[cidx(n, i, x)] + (double)ny * w.D[iy]) / (double)(nx + ny);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int i = lane + 64 * h;
+            if (i >= n || i == y || i == x || (h ? sz1 : sz0) == 0) continue;
+            const int iy = cidx24(n, i, y);
+            w.D[iy] = ((double)nx * w.D[cidx24(n, i, x)] + (double)ny * w.D[iy]) / (double)(nx + ny);
         }
         __syncthreads();
     }
@@ -649,41 +654,45 @@ __device__ int linkage_fcluster_lds(int n, const LinkLds& w, double cutoff) {
         for (int j = 0; j < nm; j++) { const double hj = w.Zh[j]; r += (hj < h) || (hj == h && j < i); }
         w.ord[r] = i;
     }
-    for (int i = lane; i < 2 * n - 1; i += 64) { w.parent[i] = i; w.visited[i] = 0; }
     __syncthreads();
-    // union-find relabel in sorted order + max-height-below (serial, <= 99 rows)
-    if (lane == 0) {
-        for (int r = 0; r < nm; r++) {
-            const int src = w.ord[r];
-            int a = w.Zx[src], b = w.Zy[src];
-            while (w.parent[a] != a) a = w.parent[a];
-            while (w.parent[b] != b) b = w.parent[b];
-            const int l = a < b ? a : b, rr = a < b ? b : a;
-            w.L[r] = l; w.Rr[r] = rr;
-            w.parent[a] = n + r; w.parent[b] = n + r;
-            double m = w.Zh[src];
-            if (l >= n && w.MD[l - n] > m) m = w.MD[l - n];
-            if (rr >= n && w.MD[rr - n] > m) m = w.MD[rr - n];
-            w.MD[r] = m;
-        }
-        // cluster_monocrit: DFS from the root, left child first
-        int k = 0, ncl = 0, leader = -1;
-        w.stack[0] = 2 * n - 2;
-        while (k >= 0) {
-            const int root = w.stack[k] - n;
-            const int lc = w.L[root], rc = w.Rr[root];
-            if (leader == -1 && w.MD[root] <= cutoff) { leader = root; ncl++; }
-            if (lc >= n && !w.visited[lc]) { w.visited[lc] = 1; w.stack[++k] = lc; continue; }
-            if (rc >= n && !w.visited[rc]) { w.visited[rc] = 1; w.stack[++k] = rc; continue; }
-            if (lc < n) { if (leader == -1) ncl++; w.labels[lc] = ncl; }
-            if (rc < n) { if (leader == -1) ncl++; w.labels[rc] = ncl; }
-            if (leader == root) leader = -1;
-            k--;
-        }
-        w.stack[0] = ncl;
+    // scipy's label(): the union-find over the sorted rows becomes "root node of every leaf" (one register pair), relabelled by all lanes at once;
+    // the sorted tree (children, max-height-below <= cutoff) goes into lane tables for the walk below
+    int root0 = lane, root1 = lane + 64 < n ? lane + 64 : -1;
+    int L0 = 0, L1 = 0, R0 = 0, R1 = 0, le0 = 0, le1 = 0;
+    for (int r = 0; r < nm; r++) {
+        const int src = __builtin_amdgcn_readfirstlane(w.ord[r]);
+        const int a0 = __builtin_amdgcn_readfirstlane(w.Zx[src]), b0 = __builtin_amdgcn_readfirstlane(w.Zy[src]);
+        const int a = lane_table_get(root0, root1, a0), b = lane_table_get(root0, root1, b0);
+        const int l = a < b ? a : b, rr = a < b ? b : a;
+        double m = w.Zh[src];
+        if (l >= n) { const double t = w.MD[l - n]; if (t > m) m = t; }
+        if (rr >= n) { const double t = w.MD[rr - n]; if (t > m) m = t; }
+        if (lane == 0) w.MD[r] = m;
+        lane_table_set(L0, L1, r, l);
+        lane_table_set(R0, R1, r, rr);
+        lane_table_set(le0, le1, r, m <= cutoff ? 1 : 0);
+        root0 = (root0 == a || root0 == b) ? n + r : root0;
+        root1 = (root1 == a || root1 == b) ? n + r : root1;
     }
+    // cluster_monocrit: DFS from the root, left child first (stack, visited flags and labels in lane tables; rows are node id - n)
+    int vis0 = 0, vis1 = 0, lab0 = 0, lab1 = 0, stk0 = 0, stk1 = 0;
+    int k = 0, ncl = 0, leader = -1;
+    lane_table_set(stk0, stk1, 0, nm - 1);
+    while (k >= 0) {
+        const int root = lane_table_get(stk0, stk1, k);
+        const int lc = lane_table_get(L0, L1, root), rc = lane_table_get(R0, R1, root);
+        if (leader == -1 && lane_table_get(le0, le1, root)) { leader = root; ncl++; }
+        if (lc >= n && !lane_table_get(vis0, vis1, lc - n)) { lane_table_set(vis0, vis1, lc - n, 1); k++; lane_table_set(stk0, stk1, k, lc - n); continue; }
+        if (rc >= n && !lane_table_get(vis0, vis1, rc - n)) { lane_table_set(vis0, vis1, rc - n, 1); k++; lane_table_set(stk0, stk1, k, rc - n); continue; }
+        if (lc < n) { if (leader == -1) ncl++; lane_table_set(lab0, lab1, lc, ncl); }
+        if (rc < n) { if (leader == -1) ncl++; lane_table_set(lab0, lab1, rc, ncl); }
+        if (leader == root) leader = -1;
+        k--;
+    }
+    if (lane < n) w.labels[lane] = lab0;
+    if (lane + 64 < n) w.labels[lane + 64] = lab1;
     __syncthreads();
-    return w.stack[0];
+    return ncl;
 }
 
 __device__ __forceinline__ LinkLds carve_link(char*& sm, int nmax) {
@@ -693,15 +702,13 @@ __device__ __forceinline__ LinkLds carve_link(char*& sm, int nmax) {
     w.Zh = reinterpret_cast<double*>(sm); sm += sizeof(double) * nmax;
     w.MD = reinterpret_cast<double*>(sm); sm += sizeof(double) * nmax;
     int* ip = reinterpret_cast<int*>(sm);
-    w.Zx = ip; ip += nmax; w.Zy = ip; ip += nmax; w.size = ip; ip += nmax; w.chain = ip; ip += nmax; w.ord = ip; ip += nmax;
-    w.L = ip; ip += nmax; w.Rr = ip; ip += nmax; w.parent = ip; ip += 2 * nmax; w.stack = ip; ip += nmax; w.visited = ip; ip += 2 * nmax;
-    w.labels = ip; ip += nmax;
+    w.Zx = ip; ip += nmax; w.Zy = ip; ip += nmax; w.chain = ip; ip += nmax; w.ord = ip; ip += nmax; w.labels = ip; ip += nmax;
     sm = reinterpret_cast<char*>(ip);
     return w;
 }
 static size_t link_lds_bytes(int nmax) {
     const int np = nmax * (nmax - 1) / 2;
-    return sizeof(double) * (size_t)(np > 0 ? np : 1) + 2 * sizeof(double) * nmax + sizeof(int) * 13 * (size_t)nmax + 16;
+    return sizeof(double) * (size_t)(np > 0 ? np : 1) + 2 * sizeof(double) * nmax + sizeof(int) * 5 * (size_t)nmax + 16;
 }
 
 // utility / test entry: batch of condensed matrices -> flat labels
@@ -848,8 +855,8 @@ __global__ __launch_bounds__(64) void k_cluster(long long n_part, const int64_t*
     // same-read duplicates (SVIM_clustering.py:141-151): j is dropped when ANY earlier i of the same read is within the cut
     if (t != SVX_INV && ns > 1) {
         const int npairs = ns * (ns - 1) / 2;
-        for (int k = lane; k < npairs; k += 64) {
-            int i = 0, rem = k;
+        int i = 0, rem = lane;                                                         // pair k = (i, i + 1 + rem), carried from k to k + 64
+        for (int k = lane; k < npairs; k += 64, rem += 64) {
             while (rem >= ns - 1 - i) { rem -= ns - 1 - i; i++; }
             const int j = i + 1 + rem;
             if (all[i].read == all[j].read) {
@@ -874,8 +881,8 @@ __global__ __launch_bounds__(64) void k_cluster(long long n_part, const int64_t*
     if (nm == 1) { if (lane == 0) w.labels[0] = 1; ncl = 1; __syncthreads(); }
     else {
         const int npairs = nm * (nm - 1) / 2;
-        for (int k = lane; k < npairs; k += 64) {
-            int i = 0, rem = k;
+        int i = 0, rem = lane;
+        for (int k = lane; k < npairs; k += 64, rem += 64) {
             while (rem >= nm - 1 - i) { rem -= nm - 1 - i; i++; }
             const int j = i + 1 + rem;
             double d;
@@ -1016,6 +1023,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     if (n >= (1ll << 31)) return svx_fail(SVX_E_ARG, "more than 2^31 signatures in one call", __FILE__, __LINE__, hipSuccess);
     const int T = 256;
     HIPCHK(hipEventRecord(c->ev[8], st));
+    SVXCHK(svx_edit_prepack_begin(c, in, p, c->ev[8]));     // haplotype store of the insertions, on a side stream beside everything up to the pair list
     // ---- sort by (type, contig ranks, coordinate), stable w.r.t. list order --------------------------------------
     SVXCHK(c->k_hi.reserve((size_t)n * 8)); SVXCHK(c->k_lo.reserve((size_t)n * 8)); SVXCHK(c->k_idx.reserve((size_t)n * 4));
     SVXCHK(c->k_hi2.reserve((size_t)n * 8)); SVXCHK(c->k_lo2.reserve((size_t)n * 8)); SVXCHK(c->k_idx2.reserve((size_t)n * 4));
@@ -1032,6 +1040,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     int64_t n_part = 0;
     HIPCHK(hipMemcpyAsync(&n_part, c->part_id.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    SVXCHK(svx_edit_prepack_pack(c, in));
     SVXCHK(c->part_start.reserve((size_t)(n_part + 1) * 8));
     k_part_starts<<<GRID(n + 1, T), T, 0, st>>>(c->part_flag.as<int64_t>(), c->part_id.as<int64_t>(), n, c->part_start.as<int64_t>(), n_part);
     // per-partition sizes -> sample base, large-partition slots, INS pair slots (5 arrays of n_part+1 int64 in part_meta)

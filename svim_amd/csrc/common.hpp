@@ -154,6 +154,10 @@ struct svx_ctx {
     // the length gap.  Chosen per call from a sample of that call's own pairs (k_edit_pilot, edit.hip) - no state survives a call;
     // 0.125 is only the fallback for calls too small to sample.  Routing only: results never depend on it.  SVX_EDIT_GUESS=<fraction> pins it.
     float edit_guess = 0.125f; bool edit_guess_pinned = false; float edit_guess_last = 0.125f;
+    // Packed haplotype store built AHEAD of the pair list, on a side stream beside the partition / sampling kernels (svx_edit_prepack_*):
+    // 0 = none, 1 = word counts + offsets enqueued, 2 = packed (ev[18] marks the end)
+    int prepack_state = 0; long long prepack_radius = 0, prepack_n = 0; DevBuf prepack_tmp;
+    int64_t* pinned = nullptr;       // 4 KB of pinned host memory for small asynchronous read-backs
     DevBuf e_hist;
     bool edit_force_full = false;  // debugging aid (env SVX_EDIT_FORCE_FULL=1): every pair through the full-matrix kernel
     bool no_seq_gather = false;   // svx_cigar_indel hook: positions only
@@ -165,11 +169,14 @@ struct svx_ctx {
 int svx_sort_pairs_u64(svx_ctx* c, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                        int64_t n, int begin_bit, int end_bit);
 int svx_exclusive_scan_i64(svx_ctx* c, const int64_t* in, int64_t* out, int64_t n);   // out[n] NOT written
+int svx_exclusive_scan_i64_on(svx_ctx* c, const int64_t* in, int64_t* out, int64_t n, hipStream_t stream, DevBuf& tmp);
 int svx_exclusive_scan_i32_to_i64(svx_ctx* c, const int32_t* in, int64_t* out, int64_t n);
 
 // ---- stage entry points ------------------------------------------------------------------------------------
 int svx_collect_impl(svx_ctx* c, const svx_batch* b_dev, const svx_params* p);
 int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const int32_t* rank_dev, const svx_params* p);
+int svx_edit_prepack_begin(svx_ctx* c, const ClusterIn& in, const svx_params& p, hipEvent_t input_ready);
+int svx_edit_prepack_pack(svx_ctx* c, const ClusterIn& in);
 int svx_pair_distances_impl(svx_ctx* c, const ClusterIn& in, int64_t n_pairs, const int64_t* ia_dev, const int64_t* ib_dev, const svx_params* p, double* out_dev);
 int svx_set_alignment_index_impl(svx_ctx* c, const svx_aln_index* h);
 int svx_genotype_impl(svx_ctx* c, int32_t mode, int64_t n_cand, const int32_t* tid, const int32_t* start, const int32_t* end, const int64_t* moff,
@@ -198,6 +205,34 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
     return s;
 }
 __device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i32(v), 63); }
+// minimum of a double over the 64 lanes, the same in every lane afterwards (same DPP ladder; a lane the shift does not reach keeps its own value)
+#define SVX_DPP_MIN_F64(s_, src_, ctrl_, row_, bank_)                                                                     \
+    {                                                                                                                     \
+        const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(src_), __double2loint(src_), ctrl_, row_, bank_, false); \
+        const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(src_), __double2hiint(src_), ctrl_, row_, bank_, false); \
+        const double t_ = __hiloint2double(hi_, lo_);                                                                     \
+        s_ = t_ < s_ ? t_ : s_;                                                                                           \
+    }
+__device__ __forceinline__ double wave_min_f64(double v) {
+    double s = v;
+    SVX_DPP_MIN_F64(s, v, 0x111, 0xf, 0xf);
+    SVX_DPP_MIN_F64(s, v, 0x112, 0xf, 0xf);
+    SVX_DPP_MIN_F64(s, v, 0x113, 0xf, 0xf);
+    { const double u = s; SVX_DPP_MIN_F64(s, u, 0x114, 0xf, 0xe); }
+    { const double u = s; SVX_DPP_MIN_F64(s, u, 0x118, 0xf, 0xc); }
+    { const double u = s; SVX_DPP_MIN_F64(s, u, 0x142, 0xa, 0xf); }
+    { const double u = s; SVX_DPP_MIN_F64(s, u, 0x143, 0xc, 0xf); }
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 63), __builtin_amdgcn_readlane(__double2loint(s), 63));
+}
+// entry i (wave-uniform, < 128) of a table kept in two registers across the lanes: lane l holds entries l and l + 64
+__device__ __forceinline__ int lane_table_get(int v0, int v1, int i) {
+    return i < 64 ? __builtin_amdgcn_readlane(v0, i) : __builtin_amdgcn_readlane(v1, i - 64);
+}
+__device__ __forceinline__ void lane_table_set(int& v0, int& v1, int i, int val) {
+    const int lane = (int)(threadIdx.x & 63);
+    if (lane == i) v0 = val;
+    if (lane + 64 == i) v1 = val;
+}
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1276,7 +1276,12 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     HIPCHK(hipMemsetAsync(cnt, 0, CNT_WORDS * 8, st));
     // 1. packed store: one record per string / signature
     src.radius = 0;
-    if (!src.plain) {
+    const bool prepacked = !src.plain && c->prepack_state == 2 && c->prepack_n == src.in.n;
+    c->prepack_state = 0;
+    if (prepacked) {
+        src.radius = c->prepack_radius;
+        HIPCHK(hipStreamWaitEvent(st, c->ev[18], 0));
+    } else if (!src.plain) {
         k_pair_span<<<(unsigned)(c->n_cu * 4), T, 0, st>>>(n_work, src, cnt);
         unsigned long long shard[16], span = 0;
         HIPCHK(hipMemcpyAsync(shard, cnt + 16, sizeof shard, hipMemcpyDeviceToHost, st));
@@ -1285,19 +1290,24 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         src.radius = (long long)span + 100;
     }
     const long long n_rec = src.plain ? 2 * n_work : src.in.n;
-    SVXCHK(c->e_words.reserve((size_t)(n_rec + 1) * 8));
-    SVXCHK(c->e_off.reserve((size_t)(n_rec + 1) * 8));
-    SVXCHK(c->e_rec.reserve((size_t)n_rec * sizeof(HapRec) + 64));
-    src.rec = c->e_rec.as<HapRec>();
-    k_hap_words<<<(unsigned)((n_rec + 1 + T - 1) / T), T, 0, st>>>(n_rec, src, c->e_words.as<int64_t>());
-    SVXCHK(svx_exclusive_scan_i64(c, c->e_words.as<int64_t>(), c->e_off.as<int64_t>(), n_rec + 1));
     int64_t total_words = 0;
-    HIPCHK(hipMemcpyAsync(&total_words, c->e_off.as<int64_t>() + n_rec, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    SVXCHK(c->e_scratch.reserve((size_t)(total_words + 64) * 4));
-    HIPCHK(hipMemsetAsync(c->e_scratch.p, 0, 4, st));                    // the leading pad word
-    k_hap_pack<<<(unsigned)((n_rec + 3) / 4), 256, 0, st>>>(n_rec, src, c->e_off.as<int64_t>(), c->e_scratch.as<uint32_t>(), c->e_rec.as<HapRec>());
-    HIPCHK(hipGetLastError());
+    if (prepacked) {
+        src.rec = c->e_rec.as<HapRec>();
+        total_words = c->pinned[0];
+    } else {
+        SVXCHK(c->e_words.reserve((size_t)(n_rec + 1) * 8));
+        SVXCHK(c->e_off.reserve((size_t)(n_rec + 1) * 8));
+        SVXCHK(c->e_rec.reserve((size_t)n_rec * sizeof(HapRec) + 64));
+        src.rec = c->e_rec.as<HapRec>();
+        k_hap_words<<<(unsigned)((n_rec + 1 + T - 1) / T), T, 0, st>>>(n_rec, src, c->e_words.as<int64_t>());
+        SVXCHK(svx_exclusive_scan_i64(c, c->e_words.as<int64_t>(), c->e_off.as<int64_t>(), n_rec + 1));
+        HIPCHK(hipMemcpyAsync(&total_words, c->e_off.as<int64_t>() + n_rec, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        SVXCHK(c->e_scratch.reserve((size_t)(total_words + 64) * 4));
+        HIPCHK(hipMemsetAsync(c->e_scratch.p, 0, 4, st));                    // the leading pad word
+        k_hap_pack<<<(unsigned)((n_rec + 3) / 4), 256, 0, st>>>(n_rec, src, c->e_off.as<int64_t>(), c->e_scratch.as<uint32_t>(), c->e_rec.as<HapRec>());
+        HIPCHK(hipGetLastError());
+    }
     SVXCHK(c->e_desc.reserve((size_t)n_work * sizeof(PairDesc)));
     SVXCHK(c->e_key.reserve((size_t)n_work * 8 * 2)); SVXCHK(c->e_val.reserve((size_t)n_work * 4 * 2));
     SVXCHK(c->e_slot.reserve((size_t)n_work * 8));
@@ -1503,6 +1513,53 @@ int svx_edit_distance_pairs(svx_ctx* c, int64_t n_pairs, const uint8_t* codes_de
     PairSource src; memset(&src, 0, sizeof src);
     src.plain = 1; src.codes = codes_dev; src.a_off = a_off_dev; src.b_off = b_off_dev; src.g_codes = codes_dev;
     return run_edit_pipeline(c, n_pairs, src, out_dev, nullptr);
+}
+
+// The packed store of a CLUSTER call does not depend on the pair list except through the flank radius, and every pair that needs an edit
+// distance has |start_a - start_b| <= 2 * cluster_max_distance * position_distance_normalizer (ins_needs_edit in cluster.hip): with that bound as
+// radius the store is built on a side stream while the main stream sorts, partitions and samples.  begin: word counts + offsets (enqueue only);
+// pack: called after the caller's next host synchronisation - reads the total, reserves, packs, records ev[18].
+static PairSource prepack_source(svx_ctx* c, const ClusterIn& in) {
+    PairSource src; memset(&src, 0, sizeof src);
+    src.plain = 0; src.in = in; src.g_off = c->g_off_p; src.g_codes = c->g_codes_p; src.radius = c->prepack_radius; src.rec = c->e_rec.as<HapRec>();
+    return src;
+}
+
+int svx_edit_prepack_begin(svx_ctx* c, const ClusterIn& in, const svx_params& p, hipEvent_t input_ready) {
+    c->prepack_state = 0;
+    if (!c->g_off_p || !c->pinned || in.n <= 0 || getenv("SVX_EDIT_NO_PREPACK")) return SVX_OK;
+    const double bound = 2.0 * p.cluster_max_distance * p.position_distance_normalizer;
+    if (!(bound >= 0) || !(bound < 16000.0)) return SVX_OK;                       // unusual parameters: the exact radius is found from the pair list
+    c->prepack_radius = (long long)(bound * (1.0 + 1e-9)) + 2 + 100;
+    c->prepack_n = in.n;
+    hipStream_t ps = c->aux[2];
+    const long long n_rec = in.n;
+    SVXCHK(c->e_words.reserve((size_t)(n_rec + 1) * 8));
+    SVXCHK(c->e_off.reserve((size_t)(n_rec + 1) * 8));
+    SVXCHK(c->e_rec.reserve((size_t)n_rec * sizeof(HapRec) + 64));
+    const PairSource src = prepack_source(c, in);
+    HIPCHK(hipStreamWaitEvent(ps, input_ready, 0));
+    k_hap_words<<<(unsigned)((n_rec + 1 + 255) / 256), 256, 0, ps>>>(n_rec, src, c->e_words.as<int64_t>());
+    SVXCHK(svx_exclusive_scan_i64_on(c, c->e_words.as<int64_t>(), c->e_off.as<int64_t>(), n_rec + 1, ps, c->prepack_tmp));
+    HIPCHK(hipMemcpyAsync(c->pinned, c->e_off.as<int64_t>() + n_rec, 8, hipMemcpyDeviceToHost, ps));
+    c->prepack_state = 1;
+    return SVX_OK;
+}
+
+int svx_edit_prepack_pack(svx_ctx* c, const ClusterIn& in) {
+    if (c->prepack_state != 1) return SVX_OK;
+    hipStream_t ps = c->aux[2];
+    HIPCHK(hipStreamSynchronize(ps));
+    const int64_t total_words = c->pinned[0];
+    SVXCHK(c->e_scratch.reserve((size_t)(total_words + 64) * 4));
+    const long long n_rec = in.n;
+    const PairSource src = prepack_source(c, in);
+    HIPCHK(hipMemsetAsync(c->e_scratch.p, 0, 4, ps));                    // the leading pad word
+    k_hap_pack<<<(unsigned)((n_rec + 3) / 4), 256, 0, ps>>>(n_rec, src, c->e_off.as<int64_t>(), c->e_scratch.as<uint32_t>(), c->e_rec.as<HapRec>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[18], ps));
+    c->prepack_state = 2;
+    return SVX_OK;
 }
 
 // used by cluster.hip

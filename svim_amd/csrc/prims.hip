@@ -25,6 +25,17 @@ int svx_exclusive_scan_i64(svx_ctx* c, const int64_t* in, int64_t* out, int64_t 
     return SVX_OK;
 }
 
+// the same on another stream with its own temporary storage (concurrent with the main stream's primitives)
+int svx_exclusive_scan_i64_on(svx_ctx* c, const int64_t* in, int64_t* out, int64_t n, hipStream_t stream, DevBuf& tmp) {
+    (void)c;
+    if (n <= 0) return SVX_OK;
+    size_t bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), stream));
+    SVXCHK(tmp.reserve(bytes));
+    HIPCHK(rocprim::exclusive_scan(tmp.p, bytes, in, out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), stream));
+    return SVX_OK;
+}
+
 struct I32ToI64 {
     __host__ __device__ int64_t operator()(int32_t v) const { return (int64_t)v; }
 };

@@ -423,10 +423,10 @@ def _run_bam_sharded(bam_path, fasta_path, opts, eng, rank, world, device, steps
     adapter = multigpu.SvxAdapter(eng, dev)
     best = None
     for it in range(warmup + steps):
-        torch.cuda.synchronize(); dist.barrier()
+        torch.cuda.synchronize(); multigpu.barrier()
         t0 = time.perf_counter()
         res, pipe, _ = collect_cluster_bam_sharded(bam_path, opts, eng, adapter, rank, world, threads=threads)
-        torch.cuda.synchronize(); dist.barrier()
+        torch.cuda.synchronize(); multigpu.barrier()
         wall = time.perf_counter() - t0
         n_local = pipe.stats["records"]
         pipe.close()

@@ -73,6 +73,16 @@ class ChainRelay(object):
                 dist.send(torch.tensor(words, dtype=torch.int64, device=self.device), dst=self.rank + 1)
 
 
+def barrier():
+    """dist.barrier that names this rank's device under RCCL (otherwise torch guesses it from the rank)"""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier()
+
+
 def _all_gather_counts(values, device):
     import torch
     import torch.distributed as dist

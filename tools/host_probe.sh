@@ -7,7 +7,7 @@ free -g | head -2
 python - <<'PY'
 import os, time, zlib, threading
 raw = os.urandom(1 << 16) * 4 + bytes(1 << 18) + (b"ACGTTGCA" * 8192)
-comp = [zlib.compress(raw[i:i + 65280], 1) for i in range(0, len(raw), 65280)] * 64
+comp = [zlib.compress(raw[i:i + 65280], 1) for i in range(0, len(raw), 65280)] * 1024
 tot = sum(len(zlib.decompress(c)) for c in comp[:8]) / 8 * len(comp)
 def work(lo, hi):
     for c in comp[lo:hi]:
