@@ -100,6 +100,94 @@ __device__ __forceinline__ uint4 load_chunk(const uint32_t* cig, unsigned long l
     return q;
 }
 
+// cursors of the operations [from, to) of a record that starts at off0 (lane partial sums): the chunks were streamed moments ago (L2); four
+// loads are issued before the first is decoded - the walk is latency, not bandwidth
+__device__ __forceinline__ void catch_up(const uint32_t* cig, unsigned long long from, unsigned long long to, unsigned long long off0, unsigned long long limit,
+                                         unsigned long long tot, int lane, int& acc_ref, int& acc_read) {
+    for (unsigned long long kk = from; kk < to; kk += 1024ull) {
+        uint4 r[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const unsigned long long kq = kk + 256ull * g;
+            r[g] = make_uint4(15u, 15u, 15u, 15u);
+            if (kq < to) r[g] = load_chunk(cig, kq + (unsigned long long)lane * 4, limit < to ? limit : to, tot);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const unsigned long long kq = kk + 256ull * g, kc = kq + (unsigned long long)lane * 4;
+            if (kq < off0) {
+                if (kc < off0) r[g].x = 15u;
+                if (kc + 1 < off0) r[g].y = 15u;
+                if (kc + 2 < off0) r[g].z = 15u;
+                if (kc + 3 < off0) r[g].w = 15u;
+            }
+            const uint32_t rv[4] = {r[g].x, r[g].y, r[g].z, r[g].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int op = (int)(rv[j] & 15u), l = (int)(rv[j] >> 4);
+                acc_ref += op_sel(MASK_REF, op, l);
+                acc_read += op_sel(MASK_READ, op, l);
+            }
+        }
+    }
+}
+
+// geometry record of one alignment from the sums over its CIGAR: {reference length, query_alignment_start, query_alignment_end, infer_read_length,
+// hard-clipped bases} with htslib's / pysam's rules; executed by ONE lane
+__device__ __forceinline__ void finish_geom(const uint32_t* c, long long n, int lseq, long long sum_ref, long long sum_read, long long sum_n, long long sum_h,
+                                            long long sum_s, int* geom_out) {
+    long long qstart = 0;
+    for (long long i = 0; i < n; i++) {                     // leading clips: hard skipped, soft summed
+        const int op = c[i] & 15;
+        if (op == 5) continue;
+        if (op == 4) qstart += c[i] >> 4; else break;
+    }
+    long long qend;
+    if (lseq == 0) {
+        // no stored sequence: M+I+=+X, plus a soft clip met while the running total is still zero
+        qend = sum_read - sum_s;
+        for (long long i = 0; i < n; i++) {
+            const int op = c[i] & 15; const long long l = c[i] >> 4;
+            if (l == 0) continue;
+            if (op == 4) { qend += l; break; }
+            if (op == 0 || op == 1 || op == 7 || op == 8) break;
+        }
+    } else {
+        qend = lseq;
+        for (long long i = n - 1; i >= 1; i--) {            // element 0 is never inspected (pysam getQueryEnd)
+            const int op = c[i] & 15;
+            if (op == 5) continue;
+            if (op == 4) qend -= c[i] >> 4; else break;
+        }
+    }
+    long long ref_len = sum_ref + sum_n;
+    if (ref_len == 0) ref_len = 1;                          // bam_endpos never returns pos itself
+    geom_out[0] = (int)ref_len; geom_out[1] = (int)qstart; geom_out[2] = (int)qend;
+    geom_out[3] = (n > 0) ? (int)(sum_read + sum_h) : 0; geom_out[4] = (int)sum_h;
+}
+
+// Segment rows come from SA tags and most aligners abbreviate their CIGARs to a handful of operations: a wave per row would spend its time on
+// latency (one trip, one serial epilogue), so rows of at most SEG_SMALL operations are done one per LANE here and k_cigar_scan skips them.
+#define SEG_SMALL 32
+__global__ __launch_bounds__(256) void k_seg_geom_small(ScanArgs b, int* seg_geom) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= b.n_seg) return;
+    const unsigned long long off0 = b.seg_cigar_off[s], off1 = b.seg_cigar_off[s + 1];
+    const long long n = (long long)(off1 - off0);
+    if (n > SEG_SMALL) return;
+    const uint32_t* c = b.seg_cigar + off0;
+    int sum_ref = 0, sum_read = 0, sum_n = 0, sum_h = 0, sum_s = 0;
+    for (long long i = 0; i < n; i++) {
+        const int op = (int)(c[i] & 15u), l = (int)(c[i] >> 4);
+        sum_ref += op_sel(MASK_REF, op, l);
+        sum_read += op_sel(MASK_READ, op, l);
+        sum_n += (op == 3) ? l : 0;
+        sum_h += (op == 5) ? l : 0;
+        sum_s += (op == 4) ? l : 0;
+    }
+    finish_geom(c, n, b.seg_lseq[s], sum_ref, sum_read, sum_n, sum_h, sum_s, seg_geom + 5 * s);
+}
+
 template <bool GEOM>
 __device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& out, long long w,
                                           const ItemMeta& mt, bool need_indel, int* geom_out, unsigned long long total_ops,
@@ -162,23 +250,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& ou
             for (int j = 0; j < 4; j++) any_emit |= (v[j] >= emit_floor) && (((v[j] - 1u) & 15u) < 2u);
             if (!__any(any_emit)) continue;
             // ... and catches up when one turns up: the operations of [done_k, k0) are decoded now (they were streamed moments ago: L2)
-            for (unsigned long long kk = done_k; kk < k0; kk += 256ull) {
-                const unsigned long long kc = kk + (unsigned long long)lane * 4;
-                uint4 r = load_chunk(cig, kc, off1, tot);
-                if (kk < off0) {
-                    if (kc < off0) r.x = 15u;
-                    if (kc + 1 < off0) r.y = 15u;
-                    if (kc + 2 < off0) r.z = 15u;
-                    if (kc + 3 < off0) r.w = 15u;
-                }
-                const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int op = (int)(rv[j] & 15u), l = (int)(rv[j] >> 4);
-                    acc_ref += op_sel(MASK_REF, op, l);
-                    acc_read += op_sel(MASK_READ, op, l);
-                }
-            }
+            catch_up(cig, done_k, k0, off0, off1, tot, lane, acc_ref, acc_read);
             done_k = k0 + 256ull;
         }
 #pragma unroll
@@ -222,47 +294,21 @@ __device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& ou
     if (!GEOM) return;
     const long long sum_ref = wave_sum_i32(acc_ref), sum_read = wave_sum_i32(acc_read);
     const long long sum_n = wave_sum_i32(acc_n), sum_h = wave_sum_i32(acc_h), sum_s = wave_sum_i32(acc_s);
-    if (lane == 0) {
-        const long long n = (long long)(off1 - off0);
-        const uint32_t* c = cig + off0;
-        const int lseq = mt.lseq;
-        long long qstart = 0;
-        for (long long i = 0; i < n; i++) {                     // leading clips: hard skipped, soft summed
-            const int op = c[i] & 15;
-            if (op == 5) continue;
-            if (op == 4) qstart += c[i] >> 4; else break;
-        }
-        long long qend;
-        if (lseq == 0) {
-            // no stored sequence: M+I+=+X, plus a soft clip met while the running total is still zero
-            qend = sum_read - sum_s;
-            for (long long i = 0; i < n; i++) {
-                const int op = c[i] & 15; const long long l = c[i] >> 4;
-                if (l == 0) continue;
-                if (op == 4) { qend += l; break; }
-                if (op == 0 || op == 1 || op == 7 || op == 8) break;
-            }
-        } else {
-            qend = lseq;
-            for (long long i = n - 1; i >= 1; i--) {            // element 0 is never inspected (pysam getQueryEnd)
-                const int op = c[i] & 15;
-                if (op == 5) continue;
-                if (op == 4) qend -= c[i] >> 4; else break;
-            }
-        }
-        long long ref_len = sum_ref + sum_n;
-        if (ref_len == 0) ref_len = 1;                          // bam_endpos never returns pos itself
-        geom_out[0] = (int)ref_len; geom_out[1] = (int)qstart; geom_out[2] = (int)qend;
-        geom_out[3] = (n > 0) ? (int)(sum_read + sum_h) : 0; geom_out[4] = (int)sum_h;
-    }
+    if (lane == 0) finish_geom(cig + off0, (long long)(off1 - off0), mt.lseq, sum_ref, sum_read, sum_n, sum_h, sum_s, geom_out);
 }
 
-__global__ __launch_bounds__(256) void k_cigar_scan(ScanArgs b, RawTarget out, int* rec_geom, int* seg_geom,
-                                                    unsigned long long total_ops, unsigned long long total_seg_ops, int map_mode) {
+// an item this kernel leaves alone: a filtered-out record, or a short segment row (k_seg_geom_small has those)
+__device__ __forceinline__ bool scan_skips(const ScanArgs& b, long long w, const ItemMeta& m) {
+    if (w >= b.n_rec) return m.off1 - m.off0 <= SEG_SMALL;
+    return (m.flag & SVX_FLAG_USED_MASK) || m.mapq < b.min_mapq;
+}
+
+__device__ __forceinline__ void scan_items(const ScanArgs& b, const RawTarget& out, int* rec_geom, int* seg_geom,
+                                           unsigned long long total_ops, unsigned long long total_seg_ops, int map_mode, long long block, long long n_blocks) {
     const long long n_items = b.n_rec + b.n_seg;
-    const long long n_waves = (long long)gridDim.x * 4;
+    const long long n_waves = n_blocks * 4;
     // the wave index is uniform: keep it (and everything derived from it: metadata, base pointers) in scalar registers
-    const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long wave = block * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int shard = (int)wave;                   // grid is capped at RAW_SHARDS waves
     int n_out = 0;                                 // records this wave has emitted (uniform)
     // map_mode 0: wave walks items wave, wave+W, ... ; 1: wave owns a contiguous run of items (sequential DRAM stream per wave)
@@ -274,7 +320,7 @@ __global__ __launch_bounds__(256) void k_cigar_scan(ScanArgs b, RawTarget out, i
     for (;; w += w_step) {
         if (w >= w_end) return;
         mt = load_meta(b, w);
-        if (!(w < b.n_rec && ((mt.flag & SVX_FLAG_USED_MASK) || mt.mapq < b.min_mapq))) break;
+        if (!scan_skips(b, w, mt)) break;
     }
     uint4 nx[SVX_SCAN_NU];
     {
@@ -291,7 +337,7 @@ __global__ __launch_bounds__(256) void k_cigar_scan(ScanArgs b, RawTarget out, i
         bool has_next = false;
         for (; wn < w_end; wn += w_step) {
             mtn = load_meta(b, wn);
-            if (!(wn < b.n_rec && ((mtn.flag & SVX_FLAG_USED_MASK) || mtn.mapq < b.min_mapq))) { has_next = true; break; }
+            if (!scan_skips(b, wn, mtn)) { has_next = true; break; }
         }
         const bool is_rec = w < b.n_rec;
         const bool need_geom = is_rec ? (!(mt.flag & 2048u) && mt.has_seg) : true;
@@ -304,7 +350,11 @@ __global__ __launch_bounds__(256) void k_cigar_scan(ScanArgs b, RawTarget out, i
     if (lane_id() == 0) out.shard_counter[shard] = (unsigned long long)n_out;
 }
 
-// exclusive prefix of the per-shard counts -> dense signature slots; also freezes the total in CNT_SIG / CNT_RAW
+__global__ __launch_bounds__(256) void k_cigar_scan(ScanArgs b, RawTarget out, int* rec_geom, int* seg_geom, unsigned long long total_ops,
+                                                    unsigned long long total_seg_ops, int map_mode) {
+    scan_items(b, out, rec_geom, seg_geom, total_ops, total_seg_ops, map_mode, blockIdx.x, gridDim.x);
+}
+
 __global__ __launch_bounds__(1024) void k_shard_prefix(const unsigned long long* shard_counter, long long shard_cap, long long* prefix,
                                                        unsigned long long* counters) {
     __shared__ long long s[1024];
@@ -695,6 +745,7 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
             HIPCHK(hipMemsetAsync(shard_counter, 0, RAW_SHARDS * 8, st));
             RawTarget rt{c->raw_indel.as<RawIndel>(), shard_cap, shard_counter};
             ScanArgs sa{b.n_rec, b.n_seg, b.flag, b.mapq, b.lseq, b.seg_off, b.cigar_off, b.cigar, b.seg_lseq, b.seg_cigar_off, b.seg_cigar, p->min_mapq, p->min_sv_size};
+            if (b.n_seg > 0) k_seg_geom_small<<<(unsigned)((b.n_seg + 255) / 256), 256, 0, st>>>(sa, c->seg_geom.as<int>());
             k_cigar_scan<<<(unsigned)blocks, 256, 0, st>>>(sa, rt, c->rec_geom.as<int>(), c->seg_geom.as<int>(), tot_ops, tot_seg_ops, scan_map);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev[5], st));

@@ -10,6 +10,14 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The torch wheel bundles its own HIP / HSA runtime and libsvx.so links the system one: whichever is initialised FIRST in a process is the
+    # one that sees the GPU.  Tests that use torch device tensors beside libsvx need torch to be first (bench.py imports torch first, too).
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")
