@@ -100,20 +100,22 @@ __device__ __forceinline__ uint4 load_chunk(const uint32_t* cig, unsigned long l
     return q;
 }
 
-// cursors of the operations [from, to) of a record that starts at off0 (lane partial sums): the chunks were streamed moments ago (L2); four
-// loads are issued before the first is decoded - the walk is latency, not bandwidth
+// cursors of the operations [from, to) of a record that starts at off0 (lane partial sums): the chunks were streamed moments ago (L2)
+#ifndef SVX_CATCHUP_G
+#define SVX_CATCHUP_G 1        /* chunks loaded per step of the catch-up walk: more in flight costs registers, and occupancy is worth more (measured) */
+#endif
 __device__ __forceinline__ void catch_up(const uint32_t* cig, unsigned long long from, unsigned long long to, unsigned long long off0, unsigned long long limit,
                                          unsigned long long tot, int lane, int& acc_ref, int& acc_read) {
-    for (unsigned long long kk = from; kk < to; kk += 1024ull) {
-        uint4 r[4];
+    for (unsigned long long kk = from; kk < to; kk += 256ull * SVX_CATCHUP_G) {
+        uint4 r[SVX_CATCHUP_G];
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < SVX_CATCHUP_G; g++) {
             const unsigned long long kq = kk + 256ull * g;
             r[g] = make_uint4(15u, 15u, 15u, 15u);
             if (kq < to) r[g] = load_chunk(cig, kq + (unsigned long long)lane * 4, limit < to ? limit : to, tot);
         }
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < SVX_CATCHUP_G; g++) {
             const unsigned long long kq = kk + 256ull * g, kc = kq + (unsigned long long)lane * 4;
             if (kq < off0) {
                 if (kc < off0) r[g].x = 15u;
@@ -350,7 +352,12 @@ __device__ __forceinline__ void scan_items(const ScanArgs& b, const RawTarget& o
     if (lane_id() == 0) out.shard_counter[shard] = (unsigned long long)n_out;
 }
 
-__global__ __launch_bounds__(256) void k_cigar_scan(ScanArgs b, RawTarget out, int* rec_geom, int* seg_geom, unsigned long long total_ops,
+#ifdef SVX_SCAN_WAVES
+#define SVX_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(SVX_SCAN_WAVES, SVX_SCAN_WAVES)))
+#else
+#define SVX_SCAN_ATTR
+#endif
+__global__ __launch_bounds__(256) SVX_SCAN_ATTR void k_cigar_scan(ScanArgs b, RawTarget out, int* rec_geom, int* seg_geom, unsigned long long total_ops,
                                                     unsigned long long total_seg_ops, int map_mode) {
     scan_items(b, out, rec_geom, seg_geom, total_ops, total_seg_ops, map_mode, blockIdx.x, gridDim.x);
 }
