@@ -298,8 +298,17 @@ __global__ void k_large_info(const int32_t* large_list, long long n_large, const
     info[2 * q + 1] = (int32_t)(part_start[p + 1] - part_start[p]);
 }
 
+// one thread per candidate start of a partition: how many stream words do its 100 draws consume from there?  The 256 starts of a block are
+// consecutive, so the words they will look at (a window of 256 + the ~130-250 a walk consumes) are staged in LDS once: the walk is a chain of
+// dependent reads, ~10x shorter from LDS than from L2; the rare walk that leaves the window continues in global memory.
+#define SAMPLE_WIN 1024
 __global__ __launch_bounds__(256) void k_sample_tables(const SampleMeta* meta, const uint32_t* stream, long long cap, uint16_t* table) {
+    __shared__ uint32_t win[SAMPLE_WIN];
     const SampleMeta m = meta[blockIdx.y];
+    if ((int)blockIdx.x * 256 >= m.width) return;
+    const long long base = m.lo + (long long)blockIdx.x * 256;
+    for (int i = threadIdx.x; i < SAMPLE_WIN; i += 256) { const long long q = base + i; win[i] = q < cap ? stream[q] : 0u; }
+    __syncthreads();
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= m.width) return;
     long long pos = m.lo + s;
@@ -310,8 +319,10 @@ __global__ __launch_bounds__(256) void k_sample_tables(const SampleMeta* meta, c
         const int k = 32 - __clz((int)bound);           // Random._randbelow_with_getrandbits: k = bound.bit_length()
         for (;;) {
             if (pos >= cap) { ok = false; break; }
-            const uint32_t r = stream[pos++] >> (32 - k);
-            if (r < bound) break;
+            const long long o = pos - base;
+            const uint32_t word = o < SAMPLE_WIN ? win[o] : stream[pos];
+            pos++;
+            if ((word >> (32 - k)) < bound) break;
         }
         if (!ok) break;
     }
@@ -1109,6 +1120,8 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
             HIPCHK(hipMemcpyAsync(info.data(), info_dev, (size_t)n_large * 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             std::vector<SampleMeta> meta((size_t)n_large);
+            static thread_local double moments_mean[1046], moments_var[1046];             // words one pool-method sample of a partition of n members consumes
+            static thread_local bool moments_have[1046];
             long long type_begin[SVX_NTYPES + 1];
             bool table_ok = true;
             long long slots = 0, q = 0;
@@ -1129,12 +1142,17 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
                     m.lo = lo; m.width = (int)(hi - lo + 1); m.n = n_q; m.off = slots;
                     slots += m.width;
                     if (m.width > max_width) max_width = m.width;
-                    for (int i = 0; i < 100; i++) {                                      // draw i accepts a word with probability (n-i) / 2^k
-                        const double bound = (double)(n_q - i);
-                        int k = 0; while ((1u << k) <= (unsigned)(n_q - i)) k++;
-                        const double pacc = bound / (double)(1u << k);
-                        mean += 1.0 / pacc; var += (1.0 - pacc) / (pacc * pacc);
+                    if (!moments_have[n_q]) {                                            // draw i accepts a word with probability (n-i) / 2^k
+                        double dm = 0, dv = 0;
+                        for (int i = 0; i < 100; i++) {
+                            const double bound = (double)(n_q - i);
+                            int k = 0; while ((1u << k) <= (unsigned)(n_q - i)) k++;
+                            const double pacc = bound / (double)(1u << k);
+                            dm += 1.0 / pacc; dv += (1.0 - pacc) / (pacc * pacc);
+                        }
+                        moments_mean[n_q] = dm; moments_var[n_q] = dv; moments_have[n_q] = true;
                     }
+                    mean += moments_mean[n_q]; var += moments_var[n_q];
                     least += 100;
                 }
             }

@@ -118,7 +118,7 @@ struct svx_ctx {
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[20];
+    hipEvent_t ev[24];
     hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] high priority (band classes), [2..3] low (full-matrix classes); [4] low: linkage of the partitions that need no edit distances
     // device copies of a host-resident batch
     std::vector<DevBuf> batch_bufs;

@@ -1368,35 +1368,13 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         unsigned long long* wc_band = cnt + WC_OFF + (size_t)(round * 2) * WC_PER_LAUNCH;
         unsigned long long* wc_full = wc_band + WC_PER_LAUNCH;
         bool band_used[2] = {false, false};
-        for (int generic = 0; generic <= 1; generic++) {
+        // full-matrix launch of one alphabet from per-class segments (lo / cn indexed by sort class) of `lst`
+        static const int order[14] = {CLS_FULL, CLS_WIDE0 + 3, CLS_WIDE12 + 3, CLS_WIDE0 + 2, CLS_WIDE12 + 2, CLS_WIDE0 + 1, CLS_WIDE12 + 1, CLS_WIDE0, CLS_WIDE12,
+                                      CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};     // longest serial chains first
+        auto launch_fulls = [&](int generic, const long long* lo, const long long* cn_of, const uint32_t* lst, hipStream_t fs, unsigned long long* wc, int label) -> int {
             const int base = GENERIC_BASE * generic;
-            FusedTab tb; memset(&tb, 0, sizeof tb);
-            unsigned nblk = 0;
-            for (int cls = NBAND - 1; cls >= 0; cls--) {                          // widest band first
-                const long long cn = seg_cn[base + cls];
-                if (cn <= 0) continue;
-                tb.kind[tb.n] = cls; tb.lo[tb.n] = seg_lo[base + cls]; tb.cn[tb.n] = cn; tb.first_block[tb.n] = nblk;
-                nblk += (unsigned)((cn + T - 1) / T); tb.n++;
-            }
-            tb.first_block[tb.n] = nblk;
-            if (tb.n) {
-                band_used[generic] = true;
-                if (serial) HIPCHK(hipEventRecord(c->ev[6], band_st[generic]));
-                if (generic) k_edit_bands<4><<<nblk, T, 0, band_st[1]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
-                else k_edit_bands<2><<<nblk, T, 0, band_st[0]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
-                HIPCHK(hipGetLastError());
-                if (serial) {                                                        // SVX_EDIT_SERIAL=1: stand-alone kernel durations for profiling
-                    HIPCHK(hipEventRecord(c->ev[7], band_st[generic]));
-                    HIPCHK(hipStreamSynchronize(band_st[generic]));
-                    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
-                    fprintf(stderr, "{\"edit_launch\": {\"round\": %d, \"kind\": \"bands\", \"generic\": %d, \"blocks\": %u, \"ms\": %.4f}}\n", round, generic, nblk, ms);
-                }
-            }
             FusedTab tf; memset(&tf, 0, sizeof tf);
-            nblk = 0;
-            // longest serial chains first: systolic (one wave per pair), 8/4/2 lanes per pair, then the lane classes
-            static const int order[14] = {CLS_FULL, CLS_WIDE0 + 3, CLS_WIDE12 + 3, CLS_WIDE0 + 2, CLS_WIDE12 + 2, CLS_WIDE0 + 1, CLS_WIDE12 + 1, CLS_WIDE0, CLS_WIDE12,
-                                          CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};
+            unsigned nblk = 0;
             auto class_threads = [&](int cls, long long cn) -> long long {
                 if (cls == CLS_FULL) return cn * 64;
                 if (cls >= CLS_WIDE12) return cn * (2 << (cls - CLS_WIDE12));
@@ -1412,7 +1390,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             };
             long long waves_normal = 0, waves_ll = 0;
             for (int k = 0; k < 14; k++) {
-                const long long cn = seg_cn[base + order[k]];
+                const long long cn = cn_of[base + order[k]];
                 if (cn <= 0) continue;
                 waves_normal += (class_threads(order[k], cn) + 63) / 64;
                 waves_ll += ll_kind(order[k]) ? cn : (class_threads(order[k], cn) + 63) / 64;
@@ -1420,27 +1398,80 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             const bool low_latency = !getenv("SVX_EDIT_NO_LL") && waves_normal <= 2 * 4 * (long long)c->n_cu && waves_ll <= 8 * 4 * (long long)c->n_cu;
             for (int k = 0; k < 14; k++) {
                 const int cls = order[k];
-                const long long cn = seg_cn[base + cls];
+                const long long cn = cn_of[base + cls];
                 if (cn <= 0) continue;
                 const int ll = low_latency ? ll_kind(cls) : 0;
                 const long long threads = ll ? cn * 64 : class_threads(cls, cn);
-                tf.kind[tf.n] = ll ? ll : cls; tf.lo[tf.n] = seg_lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
+                tf.kind[tf.n] = ll ? ll : cls; tf.lo[tf.n] = lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
                 nblk += (unsigned)((threads + T - 1) / T); tf.n++;
             }
             tf.first_block[tf.n] = nblk;
-            if (tf.n) {
-                hipStream_t fs = full_st[round & 1];
-                if (serial) HIPCHK(hipEventRecord(c->ev[6], fs));
-                if (generic) k_edit_fulls<4><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc_full);
-                else k_edit_fulls<2><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc_full);
+            if (!tf.n) return SVX_OK;
+            if (serial) HIPCHK(hipEventRecord(c->ev[6], fs));
+            if (generic) k_edit_fulls<4><<<nblk, T, 0, fs>>>(tf, lst, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc);
+            else k_edit_fulls<2><<<nblk, T, 0, fs>>>(tf, lst, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc);
+            HIPCHK(hipGetLastError());
+            if (serial) {
+                HIPCHK(hipEventRecord(c->ev[7], fs));
+                HIPCHK(hipStreamSynchronize(fs));
+                float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
+                fprintf(stderr, "{\"edit_launch\": {\"round\": %d, \"kind\": \"fulls\", \"generic\": %d, \"blocks\": %u, \"ms\": %.4f}}\n", label, generic, nblk, ms);
+            }
+            return SVX_OK;
+        };
+        // Round 0 launches its band classes in two parts, widest first: the pairs that fail the WIDEST bands are the long ones whose full matrices are
+        // the serial tail of the next round, and they are known as soon as the first part is through - their full-matrix retries start right then,
+        // beside the rest of the round (early_cn: what of every retry list has been launched already).
+        const int SPLIT_CLS = 6;
+        bool split_used[2] = {false, false};
+        for (int generic = 0; generic <= 1; generic++) {
+            const int base = GENERIC_BASE * generic;
+            bool any_wide = false, any_narrow = false;
+            for (int cls = 0; cls < NBAND; cls++) if (seg_cn[base + cls] > 0) { if (cls >= SPLIT_CLS) any_wide = true; else any_narrow = true; }
+            const bool split = round == 0 && !serial && any_wide && any_narrow && !getenv("SVX_EDIT_NO_EARLY");
+            for (int part = 0; part < (split ? 2 : 1); part++) {
+                FusedTab tb; memset(&tb, 0, sizeof tb);
+                unsigned nblk = 0;
+                for (int cls = NBAND - 1; cls >= 0; cls--) {                          // widest band first
+                    const long long cn = seg_cn[base + cls];
+                    if (cn <= 0) continue;
+                    if (split && (part == 0) != (cls >= SPLIT_CLS)) continue;
+                    tb.kind[tb.n] = cls; tb.lo[tb.n] = seg_lo[base + cls]; tb.cn[tb.n] = cn; tb.first_block[tb.n] = nblk;
+                    nblk += (unsigned)((cn + T - 1) / T); tb.n++;
+                }
+                tb.first_block[tb.n] = nblk;
+                if (!tb.n) continue;
+                band_used[generic] = true;
+                if (serial) HIPCHK(hipEventRecord(c->ev[6], band_st[generic]));
+                if (generic) k_edit_bands<4><<<nblk, T, 0, band_st[1]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
+                else k_edit_bands<2><<<nblk, T, 0, band_st[0]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
                 HIPCHK(hipGetLastError());
-                if (serial) {
-                    HIPCHK(hipEventRecord(c->ev[7], fs));
-                    HIPCHK(hipStreamSynchronize(fs));
+                if (split && part == 0) { HIPCHK(hipEventRecord(c->ev[20 + generic], band_st[generic])); split_used[generic] = true; }
+                if (serial) {                                                        // SVX_EDIT_SERIAL=1: stand-alone kernel durations for profiling
+                    HIPCHK(hipEventRecord(c->ev[7], band_st[generic]));
+                    HIPCHK(hipStreamSynchronize(band_st[generic]));
                     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
-                    fprintf(stderr, "{\"edit_launch\": {\"round\": %d, \"kind\": \"fulls\", \"generic\": %d, \"blocks\": %u, \"ms\": %.4f}}\n", round, generic, nblk, ms);
+                    fprintf(stderr, "{\"edit_launch\": {\"round\": %d, \"kind\": \"bands\", \"generic\": %d, \"blocks\": %u, \"ms\": %.4f}}\n", round, generic, nblk, ms);
                 }
             }
+            SVXCHK(launch_fulls(generic, seg_lo, seg_cn, list, full_st[round & 1], wc_full, round));
+        }
+        long long early_cn[N_SORT_CLASSES];
+        for (int sc = 0; sc < N_SORT_CLASSES; sc++) early_cn[sc] = 0;
+        if (split_used[0] || split_used[1]) {
+            for (int g = 0; g <= 1; g++) if (split_used[g]) HIPCHK(hipEventSynchronize(c->ev[20 + g]));
+            unsigned long long h[N_SORT_CLASSES];
+            HIPCHK(hipMemcpyAsync(h, fail_cnt, sizeof h, hipMemcpyDeviceToHost, st));         // the main stream is idle during the rounds
+            HIPCHK(hipStreamSynchronize(st));
+            long long e_lo[N_SORT_CLASSES];
+            for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
+                e_lo[sc] = (long long)sc * pending;
+                const int cls = sc % GENERIC_BASE;
+                early_cn[sc] = (cls >= NBAND && split_used[sc / GENERIC_BASE]) ? (long long)h[sc] : 0;      // full-matrix classes only; band retries wait for the round
+            }
+            hipStream_t fs = full_st[(round + 1) & 1];
+            unsigned long long* wc_next = cnt + WC_OFF + (size_t)((round + 1) * 2 + 1) * WC_PER_LAUNCH;
+            for (int generic = 0; generic <= 1; generic++) SVXCHK(launch_fulls(generic, e_lo, early_cn, fb.as<uint32_t>(), fs, wc_next, round + 1));
         }
         // only the band launches can hand pairs to the next round
         const long long cap = pending;
@@ -1451,7 +1482,11 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             unsigned long long h[N_SORT_CLASSES];
             HIPCHK(hipMemcpyAsync(h, fail_cnt, sizeof h, hipMemcpyDeviceToHost, band_st[0]));
             HIPCHK(hipStreamSynchronize(band_st[0]));
-            for (int sc = 0; sc < N_SORT_CLASSES; sc++) { seg_cn[sc] = (long long)h[sc]; pending += seg_cn[sc]; }
+            for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
+                seg_lo[sc] += early_cn[sc];                                       // that part of the list is running already
+                seg_cn[sc] = (long long)h[sc] - early_cn[sc];
+                pending += seg_cn[sc];
+            }
         }
         list = fb.as<uint32_t>();
     }
