@@ -56,6 +56,23 @@ class DeviceBatch(object):
         self._keep = b
         return b
 
+    def view_records(self, lo, hi):
+        """DeviceBatch of records [lo, hi) that SHARES this batch's arrays: per-record columns and the offset arrays start at record lo, the
+        flat arrays (CIGAR, SEQ, segment table) stay whole - offsets are absolute.  Emission slots, read ids and contig ids are unchanged."""
+        v = DeviceBatch()
+        v.n_rec, v.n_seg, v.n_contig = hi - lo, self.n_seg, self.n_contig
+        v.meta = self.meta
+        for k, t in self.t.items():
+            if k in ("flag", "tid", "pos", "mapq", "lseq", "read_id", "order", "seg_order"):
+                v.t[k] = t[lo:hi]
+            elif k in ("cigar_off", "seq_off", "seg_off"):
+                v.t[k] = t[lo:hi + 1]
+            else:
+                v.t[k] = t
+        if hasattr(self, "references"):
+            v.references = self.references
+        return v
+
     def nbytes(self):
         return sum(v.numel() * v.element_size() for v in self.t.values())
 

@@ -81,3 +81,79 @@ def test_c1_ont_quarter_scale_vs_oracle(eng, oracle):
     g_off = torch.tensor([0, genome.numel()], dtype=torch.int64, device="cuda:0")
     sig, ct, st = _both(eng, oracle, batch, g_off, genome, _options())
     assert sig.n > 150_000 and ct.n > 5_000 and st["n_large_partitions"] > 100
+
+
+@pytest.mark.skipif(os.environ.get("SVX_SKIP_SLOW") == "1", reason="SVX_SKIP_SLOW=1")
+def test_c1_full_bench_size_properties(eng):
+    """The configs[1] bench batch at FULL size (1 M reads, 1.5 G CIGAR operations) - too large for the oracle in a test, so the checks are the
+    size-independent properties of the path: ordering, membership and consolidation invariants of the reference's data model, determinism
+    (a second pass returns the same bits), and linearity of COLLECT (the file in two halves, accumulated in HBM, equals the file in one)."""
+    import torch
+    from svim_amd import devsynth
+    o = _options()
+    p = _abi.Params.from_options(o)
+    batch, genome, meta = devsynth.make_batch(n_reads=1_000_000, contig_len=250_000_000, seed=2, device="cuda:0")
+    g_off = torch.tensor([0, genome.numel()], dtype=torch.int64, device="cuda:0")
+    rank = batch.t["contig_rank"].cpu().numpy().astype(np.int32)
+    eng.set_genome(g_off, genome, on_device=True)
+    sig, bnd = eng.collect(batch.struct(), p)
+    ct = eng.cluster(p, rank, source=0)
+    st = eng.stats()
+    assert sig.n > 600_000 and ct.n > 20_000 and st["n_large_partitions"] > 500
+    # ---- COLLECT: list order = emission order (slot, phase, ordinal), every row well-formed
+    key = sig.key[:sig.n]
+    assert np.all(key[1:] > key[:-1])
+    slot = (key >> np.uint64(32)).astype(np.int64)
+    order = batch.t["order"].cpu().numpy().astype(np.int64)
+    assert np.all(np.isin(slot[sig.src[:sig.n] == 0], order))                      # a CIGAR indel sits in its record's own slot
+    typ, start, end = sig.type[:sig.n], sig.start[:sig.n].astype(np.int64), sig.end[:sig.n].astype(np.int64)
+    assert np.all(end >= start)
+    lens = np.diff(sig.seq_off[:sig.n + 1])
+    cig_ins = (typ == _abi.SVX_INS) & (sig.src[:sig.n] == 0)
+    assert np.array_equal(lens[cig_ins], (end - start)[cig_ins])                   # inserted bases of a CIGAR insertion: its length
+    assert np.all(lens[typ != _abi.SVX_INS] == 0)
+    assert np.all((end - start)[(typ == _abi.SVX_DEL) & (sig.src[:sig.n] == 0)] >= o.min_sv_size)
+    # ---- CLUSTER: type-major, inside a unilocal type by centre; members partition (a subset of) the signatures of their type
+    ctype = ct.type[:ct.n]
+    out_rank = np.array([0, 1, 2, 3, 5, 4])                                         # tuple order of cluster_sv_signatures: DEL INS INV DUP_TAN DUP_INT BND
+    assert np.all(np.diff(out_rank[ctype]) >= 0)
+    assert [int((ctype == k).sum()) for k in range(6)] == list(ct.type_count)
+    centre2 = ct.start[:ct.n].astype(np.int64) + ct.end[:ct.n].astype(np.int64)
+    for k in (_abi.SVX_DEL, _abi.SVX_INS, _abi.SVX_INV):
+        assert np.all(np.diff(centre2[ctype == k]) >= 0)
+    moff = ct.member_off[:ct.n + 1].astype(np.int64)
+    members = ct.members[:ct.n_members].astype(np.int64)
+    assert moff[0] == 0 and moff[-1] == ct.n_members and np.array_equal(np.diff(moff), ct.size[:ct.n])
+    assert len(np.unique(members)) == len(members)                                  # nobody is in two clusters
+    owner = np.repeat(np.arange(ct.n), np.diff(moff))
+    assert np.array_equal(typ[members], ctype[owner])
+    # consolidated coordinates: int(round(mean)) of the members' (SVIM_clustering.py:214-228), round-half-even
+    ssum = np.zeros(ct.n, dtype=np.int64); np.add.at(ssum, owner, start[members])
+    esum = np.zeros(ct.n, dtype=np.int64); np.add.at(esum, owner, end[members])
+    n_m = np.diff(moff).astype(np.float64)
+    uni = np.isin(ctype, (_abi.SVX_DEL, _abi.SVX_INS, _abi.SVX_INV))
+    assert np.array_equal(np.rint(ssum / n_m).astype(np.int64)[uni], ct.start[:ct.n].astype(np.int64)[uni])
+    assert np.array_equal(np.rint(esum / n_m).astype(np.int64)[uni], ct.end[:ct.n].astype(np.int64)[uni])
+    # two signatures of one read never share a DEL / INS cluster (same-read rules, SVIM_clustering.py:141-167)
+    rid = sig.read_id[:sig.n].astype(np.int64)
+    pair = owner * (int(rid.max()) + 1) + rid[members]
+    nodup = np.isin(ctype[owner], (_abi.SVX_DEL, _abi.SVX_INS))
+    assert len(np.unique(pair[nodup])) == int(nodup.sum())
+    # ---- determinism: the same call again returns the same bits
+    sig2, bnd2 = eng.collect(batch.struct(), p)
+    ct2 = eng.cluster(p, rank, source=0)
+    assert sig2.first_difference(sig) is None and bnd2.first_difference(bnd) is None
+    assert ct2.first_difference(ct, rtol=0.0) is None
+    # ---- linearity: two halves accumulated in HBM = the whole
+    half = batch.n_rec // 2
+    eng.accumulate(True)
+    try:
+        for lo, hi in ((0, half), (half, batch.n_rec)):
+            eng.set_slot_base(0)                                                     # the views keep the file's emission slots
+            eng.collect(batch.view_records(lo, hi).struct(), p, fetch=False)
+        sig3 = eng.fetch_signatures(0)
+        ct3 = eng.cluster(p, rank, source=0)
+    finally:
+        eng.accumulate(False)
+    assert sig3.first_difference(sig) is None
+    assert ct3.first_difference(ct, rtol=0.0) is None
