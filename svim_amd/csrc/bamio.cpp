@@ -276,7 +276,9 @@ static int default_threads() {
         char first[32] = {0};
         if (fscanf(f, "%31s %lld", first, &period) == 2 && strcmp(first, "max") != 0) quota = atoll(first);
         fclose(f);
-        if (quota > 0 && period > 0) { const unsigned q = (unsigned)((quota + period - 1) / period); if (q >= 1 && q < n) n = q; }
+        // a CPU quota (container): 4 threads per granted CPU - the quota is enforced per 100 ms period, and a pool as wide as the quota leaves
+        // granted time unused whenever a worker waits (measured on a 16-CPU grant: 16 threads 0.36, 64 threads 0.47 M records/s)
+        if (quota > 0 && period > 0) { const unsigned q = 4 * (unsigned)((quota + period - 1) / period); if (q >= 1 && q < n) n = q; }
     }
     return (int)n;
 }

@@ -28,5 +28,8 @@ SVX_BENCH_FORCE_DIST=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline -
 bash tools/host_probe.sh > gpurun_out/${tag}_host_probe.txt 2>&1
 [ -x tools/micro/read_bw.bin ] || hipcc --offload-arch=gfx950 -O3 -o tools/micro/read_bw.bin tools/micro/read_bw.hip
 tools/micro/read_bw.bin > gpurun_out/${tag}_read_bw.txt 2>&1
+# calibration of the FETCH_SIZE correction: the probe reads a known number of bytes per launch with the same 16 B / lane loads
+rm -rf /tmp/pmc_cal; (cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_cal -o p -- $R/tools/micro/read_bw.bin > /dev/null 2>&1)
+db=$(find /tmp/pmc_cal -name "*.db" | head -1); [ -n "$db" ] && python tools/pmc_summary.py $db gpurun_out/${tag}_pmc_FETCH_SIZE_read_bw_calibration.csv > /dev/null
 python tools/reader_scaling.py 60000 > gpurun_out/${tag}_reader_scaling.txt 2>&1
 ls -la gpurun_out/${tag}_* | head -40

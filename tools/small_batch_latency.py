@@ -11,7 +11,7 @@ o = types.SimpleNamespace(min_mapq=20, min_sv_size=40, max_sv_size=100000, segme
 p = _abi.Params.from_options(o)
 eng = _lib.Engine(0)
 for n in (1, 10, 100, 1000, 10000, 100000):
-    b, genome, meta = devsynth.make_batch(n_reads=n, contig_len=max(200_000, 250 * n), seed=2, device="cuda:0")
+    b, genome, meta = devsynth.make_batch(n_reads=n, contig_len=max(2_000_000, 250 * n), seed=2, device="cuda:0")
     g_off = torch.tensor([0, genome.numel()], dtype=torch.int64, device="cuda:0")
     eng.set_genome(g_off, genome, on_device=True)
     rank = b.t["contig_rank"].cpu().numpy().astype(np.int32)
