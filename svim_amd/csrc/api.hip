@@ -29,7 +29,7 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
     {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        for (int k = 0; k < SVX_N_AUX; k++) HIPCHK(hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, k < 2 ? greatest : least));
+        for (int k = 0; k < SVX_N_AUX; k++) HIPCHK(hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, (k < 2 || k == 5) ? greatest : least));
     }
     { void* hp = nullptr; HIPCHK(hipHostMalloc(&hp, 4096, hipHostMallocDefault)); c->pinned = (int64_t*)hp; }
     memset(&c->stats, 0, sizeof c->stats);

@@ -1280,10 +1280,10 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     const bool split = pair_total > 0;
     if (split) {
         HIPCHK(hipEventRecord(c->ev[13], st));
-        HIPCHK(hipStreamWaitEvent(c->aux[SVX_N_AUX - 1], c->ev[13], 0));
-        SVXCHK(launch_cluster(c->aux[SVX_N_AUX - 1], 1));
+        HIPCHK(hipStreamWaitEvent(c->aux[4], c->ev[13], 0));
+        SVXCHK(launch_cluster(c->aux[4], 1));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(c->ev[14], c->aux[SVX_N_AUX - 1]));
+        HIPCHK(hipEventRecord(c->ev[14], c->aux[4]));
     }
     // ---- INS haplotype edit distances -----------------------------------------------------------------------------
     unsigned long long h_cnt[16] = {0};

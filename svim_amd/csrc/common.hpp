@@ -112,14 +112,14 @@ struct DevClusters {
     DevBuf type, contig, start, end, contig2, start2, end2, aux, score, std_span, std_pos, size, member_off, members, part_index;
 };
 
-#define SVX_N_AUX 5
+#define SVX_N_AUX 6
 
 struct svx_ctx {
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev[24];
-    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] high priority (band classes), [2..3] low (full-matrix classes); [4] low: linkage of the partitions that need no edit distances
+    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] high priority (band classes), [2..3] low (full-matrix classes); [4] low: linkage of the partitions that need no edit distances; [5] high: the widest band classes of round 0
     // device copies of a host-resident batch
     std::vector<DevBuf> batch_bufs;
     // COLLECT results

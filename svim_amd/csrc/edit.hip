@@ -1395,7 +1395,9 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                 waves_normal += (class_threads(order[k], cn) + 63) / 64;
                 waves_ll += ll_kind(order[k]) ? cn : (class_threads(order[k], cn) + 63) / 64;
             }
-            const bool low_latency = !getenv("SVX_EDIT_NO_LL") && waves_normal <= 2 * 4 * (long long)c->n_cu && waves_ll <= 8 * 4 * (long long)c->n_cu;
+            static long long ll_waves = 0;                                       // waves per SIMD below which the launch counts as latency-bound
+            if (!ll_waves) { const char* e = getenv("SVX_EDIT_LL_WAVES"); ll_waves = e && atoi(e) > 0 ? atoi(e) : 2; }
+            const bool low_latency = !getenv("SVX_EDIT_NO_LL") && waves_normal <= ll_waves * 4 * (long long)c->n_cu && waves_ll <= 8 * 4 * (long long)c->n_cu;
             for (int k = 0; k < 14; k++) {
                 const int cls = order[k];
                 const long long cn = cn_of[base + cls];
@@ -1443,10 +1445,12 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                 if (!tb.n) continue;
                 band_used[generic] = true;
                 if (serial) HIPCHK(hipEventRecord(c->ev[6], band_st[generic]));
-                if (generic) k_edit_bands<4><<<nblk, T, 0, band_st[1]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
-                else k_edit_bands<2><<<nblk, T, 0, band_st[0]>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
+                // the first part (few, long pairs: latency) on a stream of its own, so that the second does not wait for it
+                hipStream_t bs = (split && part == 0) ? c->aux[5] : band_st[generic];
+                if (generic) k_edit_bands<4><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
+                else k_edit_bands<2><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
                 HIPCHK(hipGetLastError());
-                if (split && part == 0) { HIPCHK(hipEventRecord(c->ev[20 + generic], band_st[generic])); split_used[generic] = true; }
+                if (split && part == 0) { HIPCHK(hipEventRecord(c->ev[20 + generic], bs)); split_used[generic] = true; }
                 if (serial) {                                                        // SVX_EDIT_SERIAL=1: stand-alone kernel durations for profiling
                     HIPCHK(hipEventRecord(c->ev[7], band_st[generic]));
                     HIPCHK(hipStreamSynchronize(band_st[generic]));
@@ -1479,6 +1483,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         for (int sc = 0; sc < N_SORT_CLASSES; sc++) { seg_lo[sc] = (long long)sc * cap; seg_cn[sc] = 0; }
         if (band_used[0] || band_used[1]) {
             for (int g = 0; g <= 1; g++) if (band_used[g]) HIPCHK(hipStreamSynchronize(band_st[g]));
+            if (split_used[0] || split_used[1]) HIPCHK(hipStreamSynchronize(c->aux[5]));
             unsigned long long h[N_SORT_CLASSES];
             HIPCHK(hipMemcpyAsync(h, fail_cnt, sizeof h, hipMemcpyDeviceToHost, band_st[0]));
             HIPCHK(hipStreamSynchronize(band_st[0]));
