@@ -120,6 +120,31 @@ def _gather_to_root(t, counts, rank):
     return None
 
 
+def _gather_table_to_root(cols, names, counts, rank):
+    """One gather for a whole table: the columns `names` of `cols` (1-D tensors of this rank's row count, any dtypes) travel as ONE byte buffer
+    (column after column) instead of one collective per column.  Rank 0 gets {name: rank-major concatenation}, the others None."""
+    import torch
+    n = counts[rank]
+    parts = [cols[k].contiguous().view(torch.uint8) for k in names]
+    sizes = [cols[k].element_size() for k in names]
+    dtypes = [cols[k].dtype for k in names]
+    row = sum(sizes)
+    dev = cols[names[0]].device
+    mine = torch.cat(parts) if n else torch.zeros(0, dtype=torch.uint8, device=dev)
+    got = _gather_to_root(mine, [c * row for c in counts], rank)
+    if rank != 0:
+        return None
+    out = {k: [] for k in names}
+    base = 0
+    for c in counts:
+        off = base
+        for k, sz, dt in zip(names, sizes, dtypes):
+            out[k].append(got[off:off + c * sz].clone().view(dt))          # clone: a fresh, aligned buffer for the typed view
+            off += c * sz
+        base += c * row
+    return {k: torch.cat(v) for k, v in out.items()}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # engine adapters: the step below works on torch tensors; an adapter moves them in and out of an engine
 # ---------------------------------------------------------------------------------------------------------------------
@@ -420,13 +445,14 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
         g_mem = members
         g_sig = cols if gather_signatures else None
     else:
-        g = {k: _gather_to_root(c_cols[k], [c[0] for c in allc], rank) for k in CLU_DTYPES}
+        # three collectives: cluster records, member lists, signature columns (each table as one byte buffer)
+        g = _gather_table_to_root(c_cols, list(CLU_DTYPES), [c[0] for c in allc], rank)
         g_mem = _gather_to_root(members, [c[1] for c in allc], rank)
         g_sig = None
         if gather_signatures:
             empty = {k: torch.zeros(0, dtype=_tdtype(SIG_DTYPES[k]), device=dev) for k in SIG_COLS}
             src = cols if cols is not None else empty
-            g_sig = {k: _gather_to_root(src[k], sig_counts, rank) for k in SIG_COLS}
+            g_sig = _gather_table_to_root(src, list(SIG_COLS), sig_counts, rank)
     adapter.set_chain(None)
     if rank != 0:
         return None

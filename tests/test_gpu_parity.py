@@ -694,3 +694,35 @@ def test_edit_distance_routes_do_not_change_results(oracle, monkeypatch):
         results.append(first)
     assert all(r == results[0] for r in results)
     assert results[0][:400] == exp
+
+
+@pytest.mark.parametrize("env, normalizer", [({}, 900), ({"SVX_EDIT_NO_PREPACK": "1"}, 900), ({"SVX_EDIT_NO_EARLY": "1"}, 900), ({}, 40000), ({}, 5)])
+def test_cluster_scheduling_switches_do_not_change_results(oracle, monkeypatch, env, normalizer):
+    """The haplotype store packed ahead of the pair list (radius from the parameters; off when 2 * cluster_max_distance * normalizer is out of
+    range: normalizer 40000 -> the exact radius comes from the pair list) and the early full-matrix retries are scheduling choices: the tables
+    stay those of the oracle."""
+    from svim_amd._lib import Engine
+    for k in ("SVX_EDIT_NO_PREPACK", "SVX_EDIT_NO_EARLY"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    bam, refs, references = _planted_case(91, 3000, 80)
+    o = H.options({"min_mapq": 20, "min_sv_size": 40, "max_sv_size": 100000, "segment_gap_tolerance": 10,
+                   "segment_overlap_tolerance": 5, "partition_max_distance": 1000, "position_distance_normalizer": normalizer,
+                   "edit_distance_normalizer": 1.0, "cluster_max_distance": 0.5, "all_bnds": False})
+    hb = batch.build_batch(bam, o, mode="coordinate")
+    p = _abi.Params.from_options(o)
+    off, codes = convert.genome_arrays(refs, references)
+    e = Engine()
+    try:
+        e.set_genome(off, codes)
+        oracle.set_genome(off, codes)
+        sig, bnd = e.collect(hb, p)
+        osig, obnd = oracle.collect(hb, p)
+        assert sig.first_difference(osig) is None
+        ct = e.cluster(p, hb.contig_rank, source=0)
+        oc = oracle.cluster(p, hb.contig_rank, source=0)
+        assert ct.type_count[_abi.SVX_INS] > 0 and e.stats()["n_edit_pairs"] > 0
+        assert ct.first_difference(oc, rtol=1e-12) is None
+    finally:
+        e.close()
