@@ -173,12 +173,14 @@ class SvxAdapter(object):
         n, nseq, _ = self.eng.collect_counts()
         return n, nseq
 
-    def fetch_signatures(self):
-        """the COLLECT result as device tensors: columns dict, seq_off, seq"""
+    def fetch_signatures(self, with_seq=True):
+        """the COLLECT result as device tensors: columns dict, seq_off, seq (with_seq False: the inserted bases stay where they are, seq is empty)"""
         import ctypes as C
         import torch
         from ._lib import _check
         n, nseq = self.collect_counts()
+        if not with_seq:
+            nseq = 0
         cols = {k: torch.empty(max(1, n), dtype=_tdtype(SIG_DTYPES[k]), device=self.device) for k in SIG_COLS}
         seq_off = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
         seq = torch.zeros(max(1, nseq), dtype=torch.uint8, device=self.device)
@@ -186,7 +188,7 @@ class SvxAdapter(object):
         v.on_device, v.n = 1, n
         for k in SIG_COLS:
             setattr(v, k, _abi.ptr(cols[k]))
-        v.seq_off, v.seq = _abi.ptr(seq_off), _abi.ptr(seq)
+        v.seq_off, v.seq = _abi.ptr(seq_off), (_abi.ptr(seq) if with_seq else None)
         _check(self.eng.L.svx_collect_fetch(self.eng.ctx, 0, C.byref(v)), "svx_collect_fetch")
         return {k: c[:n] for k, c in cols.items()}, seq_off, seq[:nseq]
 
@@ -235,7 +237,7 @@ class HostAdapter(object):
     def collect_counts(self):
         return self.sig.n, int(self.sig.seq_off[self.sig.n])
 
-    def fetch_signatures(self):
+    def fetch_signatures(self, with_seq=True):
         import torch
         t = self.sig
         cols = {}
@@ -328,7 +330,7 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
     cols = seq_off = seq = None
     n_foreign = 0
     if world > 1 and n_own:
-        cols, seq_off, seq = adapter.fetch_signatures()
+        cols, seq_off, seq = adapter.fetch_signatures(with_seq=False)        # the columns decide who owns a row; sequences only travel with foreign rows
         own_c = owner_contig(cols["type"], gid[cols["contig"].long()], torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()], cols["contig2"].long()))
         foreign = owner_t[own_c] != rank
         n_foreign = int(foreign.sum().item())
@@ -340,7 +342,7 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
         adapter.cluster(params, local_rank_arr, table=None)
         n_sig = n_own
         if gather_signatures and cols is None and n_own:
-            cols, seq_off, seq = adapter.fetch_signatures()
+            cols, seq_off, seq = adapter.fetch_signatures(with_seq=False)
         if cols is not None:
             cols = dict(cols)
             cols["contig"] = gid[cols["contig"].long()].to(torch.int32)
@@ -352,6 +354,8 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
         if cols is None:
             cols, seq_off, seq = adapter.fetch_signatures()
             foreign = torch.zeros(0, dtype=torch.bool, device=dev)
+        else:
+            cols, seq_off, seq = adapter.fetch_signatures()                    # this time with the inserted bases (same rows, same order)
         # globalise ids, split off the foreign rows, exchange them (with their inserted sequences), keep the rows this rank owns
         cols = dict(cols)
         cols["contig"] = gid[cols["contig"].long()].to(torch.int32)
