@@ -726,3 +726,56 @@ def test_cluster_scheduling_switches_do_not_change_results(oracle, monkeypatch, 
         assert ct.first_difference(oc, rtol=1e-12) is None
     finally:
         e.close()
+
+
+def test_bench_harness_on_a_bam_and_fasta(tmp_path):
+    """`python bench.py --bam X --fasta Y` (the harness for real inputs): one JSON line on stdout and nothing else, counts equal to
+    the reference's configs[0] result."""
+    import json
+    import os
+    import subprocess
+    import sys
+    g, refs, recs = H.c1_case()
+    path = str(tmp_path / "c1.bam")
+    records.write_bam(path, ["chr1"], [2000000], recs)
+    fa = str(tmp_path / "c1.fa")
+    synth.write_fasta(fa, refs)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--bam", path, "--fasta", fa, "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["unit"] == "reads/s" and d["value"] > 0 and d["data"] == "file"
+    assert d["counts"]["records"] == len(recs)
+    assert d["counts"]["signatures"] == len(g["signatures"])
+    assert d["counts"]["clusters"] == sum(len(x) for x in g["clusters"])
+    assert d["end_to_end"]["bam_file_reads_per_s"] == d["value"]
+
+
+def test_bench_under_torchrun_multi_gpu_code_path_single_rank():
+    """The launch the driver uses for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), here with one rank and the multi-GPU code path
+    forced (RCCL process group from torchrun's environment, contig-sharded step, gathers): ONE JSON line on stdout, RCCL's banner and
+    everything else on stderr."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env["SVX_BENCH_FORCE_DIST"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--reads", "100000", "--contig-len", "25000000", "--no-cpu-baseline", "--no-end-to-end"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["counts"]["signatures"] > 10000 and d["counts"]["clusters"] > 1000
