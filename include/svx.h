@@ -255,6 +255,17 @@ int  svx_linkage_fcluster(svx_ctx* ctx, int64_t n_problems, const int32_t* n_hos
 int  svx_pair_distances(svx_ctx* ctx, const svx_sig_view* host_sigs, int64_t n_pairs, const int64_t* a, const int64_t* b, const svx_params* p,
                         double* out);
 
+/* ---- BGZF inflate on the GPU (first piece of a device-resident BAM front-end) ----------------------
+ * Replaces zlib's inflate() as htslib runs it under pysam.AlignmentFile (src/svim/SVIM_COLLECT.py:132-137): every BGZF block is an independent
+ * raw DEFLATE stream; one wavefront inflates one block (svim_amd/csrc/inflate_core.hpp, bit-identical to zlib).  The caller packs the payloads
+ * (the bytes between the block header and the CRC32/ISIZE trailer) into the pinned staging buffer at 8-byte aligned offsets. */
+typedef struct svx_inflater svx_inflater;
+int   svx_inflater_create(int device, svx_inflater** out);
+void  svx_inflater_destroy(svx_inflater* f);
+void* svx_inflater_staging(svx_inflater* f, uint64_t bytes);
+int   svx_inflater_run(svx_inflater* f, int64_t n, const uint64_t* in_off, const uint32_t* clen, const uint32_t* isize, const uint64_t* out_at,
+                       uint64_t staged_bytes, uint8_t* out, uint64_t out_bytes, int out_on_device, float* kernel_ms /* may be NULL */);
+
 /* ---- native BAM front-end (host side) --------------------------------------------------
  * Replaces pysam.AlignmentFile(bam).fetch(until_eof=True) + the per-record accessors + the SA-tag string handling of
  * src/svim/SVIM_COLLECT.py:8-41,44-85,133 for BAM inputs: multi-threaded BGZF inflate, records decoded straight into

@@ -23,7 +23,8 @@ SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version",
            "svx_cluster_set_shard_by_origin", "svx_cluster_remote_members", "svx_cluster_set_chain",
            "svx_set_alignment_index", "svx_genotype",
            "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster", "svx_pair_distances",
-           "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names", "svx_bam_set_seq_filter", "svx_bam_rewind", "svx_bam_seek"]
+           "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names", "svx_bam_set_seq_filter", "svx_bam_rewind", "svx_bam_seek",
+           "svx_inflater_create", "svx_inflater_destroy", "svx_inflater_staging", "svx_inflater_run"]
 
 
 class SvxError(RuntimeError):
@@ -260,3 +261,72 @@ def engine(device=None):
     if e is None:
         e = _ENGINES[device] = Engine(device)
     return e
+
+
+def bgzf_blocks(path):
+    """(payload bytes, ISIZE) of every BGZF block of a file: the raw DEFLATE stream between the block header and its CRC32 / ISIZE trailer"""
+    import struct
+    with open(path, "rb") as fh:
+        data = fh.read()
+    at, out = 0, []
+    while at + 18 <= len(data):
+        if data[at:at + 2] != b"\x1f\x8b":
+            raise ValueError("not a BGZF block at %d" % at)
+        xlen = struct.unpack_from("<H", data, at + 10)[0]
+        p, bsize = at + 12, None
+        while p + 4 <= at + 12 + xlen:
+            si, sl = data[p:p + 2], struct.unpack_from("<H", data, p + 2)[0]
+            if si == b"BC":
+                bsize = struct.unpack_from("<H", data, p + 4)[0]
+            p += 4 + sl
+        if bsize is None:
+            raise ValueError("no BC subfield")
+        blen = bsize + 1
+        out.append((data[at + 12 + xlen:at + blen - 8], struct.unpack_from("<I", data, at + blen - 4)[0]))
+        at += blen
+    return out
+
+
+class Inflater(object):
+    """svx_inflater: BGZF payloads inflated on the GPU, one wavefront per block (svim_amd/csrc/bgzf.hip).  No CPU fallback."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.L.svx_inflater_staging.restype = C.c_void_p
+        _check(self.L.svx_inflater_create(C.c_int(device), C.byref(self.h)), "svx_inflater_create")
+        self.kernel_ms = 0.0
+
+    def close(self):
+        if self.h:
+            self.L.svx_inflater_destroy(self.h)
+            self.h = None
+
+    def inflate(self, blocks):
+        """blocks: [(payload bytes, isize)] -> the inflated stream as a numpy uint8 array (host); self.kernel_ms = duration of the launch"""
+        n = len(blocks)
+        in_off = np.zeros(max(1, n), dtype=np.uint64)
+        clen = np.array([len(b) for b, _ in blocks] or [0], dtype=np.uint32)
+        isize = np.array([s for _, s in blocks] or [0], dtype=np.uint32)
+        out_at = np.zeros(max(1, n), dtype=np.uint64)
+        at = 0
+        for i, (b, _) in enumerate(blocks):
+            in_off[i] = at
+            at += (len(b) + 7) & ~7
+        if n > 1:
+            out_at[1:n] = np.cumsum(isize[:n - 1].astype(np.uint64))
+        total_out = int(isize[:n].astype(np.uint64).sum()) if n else 0
+        stage = self.L.svx_inflater_staging(self.h, C.c_uint64(max(at, 8)))
+        if not stage:
+            raise SvxError("svx_inflater_staging failed")
+        buf = (C.c_uint8 * max(at, 8)).from_address(stage)
+        view = np.frombuffer(buf, dtype=np.uint8)
+        for i, (b, _) in enumerate(blocks):
+            o = int(in_off[i])
+            view[o:o + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        out = np.zeros(max(1, total_out), dtype=np.uint8)
+        ms = C.c_float(0)
+        _check(self.L.svx_inflater_run(self.h, C.c_int64(n), ptr(in_off), ptr(clen), ptr(isize), ptr(out_at), C.c_uint64(at), ptr(out),
+                                       C.c_uint64(total_out), C.c_int(0), C.byref(ms)), "svx_inflater_run")
+        self.kernel_ms = float(ms.value)
+        return out[:total_out]

@@ -779,3 +779,37 @@ def test_bench_under_torchrun_multi_gpu_code_path_single_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["counts"]["signatures"] > 10000 and d["counts"]["clusters"] > 1000
+
+
+def test_bgzf_inflate_on_the_gpu_equals_zlib(tmp_path):
+    """svx_inflater (one wavefront per BGZF block, svim_amd/csrc/inflate_core.hpp) returns zlib's bytes: the blocks of a BAM the writer made at its
+    usual level, the same records at level 9 and level 1, stored blocks (level 0), an empty block (the EOF marker) and incompressible data."""
+    import gzip
+    import zlib
+    from svim_amd._lib import Inflater, bgzf_blocks
+    contigs = [("chr1", 150000)]
+    refs = synth.make_reference(3, contigs)
+    recs = synth.planted_reads(5, 500, refs, ["chr1"], [150000], n_sites=25, types=("DEL", "INS", "INV"))
+    path = str(tmp_path / "t.bam")
+    records.write_bam(path, ["chr1"], [150000], synth.coordinate_sort(recs))
+    blocks = bgzf_blocks(path)
+    assert len(blocks) > 20 and blocks[-1][1] == 0                               # the BGZF EOF marker is an empty block
+    with gzip.open(path, "rb") as fh:
+        whole = fh.read()
+    # the same content re-deflated at other levels, in 60 000-byte blocks, plus random bytes (stored / barely compressible)
+    rng = random.Random(3)
+    noise = bytes(rng.getrandbits(8) for _ in range(50000))
+    for level in (0, 1, 9):
+        for lo in range(0, min(len(whole), 600000), 60000):
+            raw = whole[lo:lo + 60000]
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            blocks.append((co.compress(raw) + co.flush(), len(raw)))
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        blocks.append((co.compress(noise) + co.flush(), len(noise)))
+    f = Inflater(0)
+    try:
+        got = f.inflate(blocks)
+    finally:
+        f.close()
+    expect = b"".join(zlib.decompress(b, -15) if s else b"" for b, s in blocks)
+    assert len(got) == len(expect) and got.tobytes() == expect

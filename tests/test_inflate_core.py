@@ -1,0 +1,35 @@
+"""The GPU's DEFLATE decoder (svim_amd/csrc/inflate_core.hpp) built for the host with its lane operations emulated (tools/inflate_host_test.cpp)
+and checked against zlib: random buffers at every level / strategy (stored, fixed and dynamic blocks) and the BGZF blocks of a BAM file."""
+import os
+import subprocess
+
+import pytest
+
+from svim_amd import records, synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host_binary(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("inflate") / "inflate_host_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DINF_HOST", "-I", os.path.join(REPO, "svim_amd", "csrc"),
+                           os.path.join(REPO, "tools", "inflate_host_test.cpp"), "-lz", "-o", out])
+    return out
+
+
+def test_inflate_core_fuzz_vs_zlib(host_binary):
+    out = subprocess.run([host_binary, "--fuzz", "1500"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "1500 buffers, 0 mismatches" in out.stdout
+
+
+def test_inflate_core_bam_blocks_vs_zlib(host_binary, tmp_path):
+    contigs = [("chr1", 200000)]
+    refs = synth.make_reference(3, contigs)
+    recs = synth.planted_reads(5, 600, refs, ["chr1"], [200000], n_sites=30, types=("DEL", "INS", "INV"))
+    path = str(tmp_path / "t.bam")
+    records.write_bam(path, ["chr1"], [200000], synth.coordinate_sort(recs))
+    out = subprocess.run([host_binary, path], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert " 0 mismatches" in out.stdout

@@ -1,0 +1,97 @@
+// Host build of svim_amd/csrc/inflate_core.hpp (the GPU's DEFLATE decoder with the lane operations emulated), checked against zlib:
+//   inflate_host_test <file.bam|file.gz-with-BGZF-blocks>   every BGZF block of the file: inflate_raw == zlib
+//   inflate_host_test --fuzz N                              N random buffers deflated at levels 0..9 / strategies, incl. stored and fixed blocks
+// Build: g++ -O2 -std=c++17 -DINF_HOST -I svim_amd/csrc tools/inflate_host_test.cpp -lz -o /tmp/inflate_host_test
+#include "inflate_core.hpp"
+#include <zlib.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static int check(const uint8_t* comp, size_t clen, const std::vector<uint8_t>& expect, const char* what) {
+    std::vector<uint32_t> in((clen + 3) / 4 + 4, 0);
+    memcpy(in.data(), comp, clen);
+    std::vector<uint8_t> out(expect.size() + 8, 0xAA);
+    InfScratch sc;
+    const int rc = inflate_raw(in.data(), (uint32_t)clen, out.data(), (uint32_t)expect.size(), sc);
+    if (rc != (int)expect.size() || memcmp(out.data(), expect.data(), expect.size()) != 0 || out[expect.size()] != 0xAA) {
+        size_t d = 0; while (d < expect.size() && out[d] == expect[d]) d++;
+        fprintf(stderr, "MISMATCH %s: rc %d expected %zu, first difference at %zu\n", what, rc, expect.size(), d);
+        return 1;
+    }
+    return 0;
+}
+
+static std::vector<uint8_t> deflate_raw(const std::vector<uint8_t>& src, int level, int strategy) {
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy);
+    std::vector<uint8_t> out(2 * src.size() + 4096);                      // fixed codes can expand incompressible data beyond deflateBound
+    zs.next_in = const_cast<Bytef*>(src.data()); zs.avail_in = (uInt)src.size(); zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { fprintf(stderr, "deflate did not finish\n"); exit(2); }
+    out.resize(zs.total_out);
+    deflateEnd(&zs);
+    return out;
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 3 && std::string(argv[1]) == "--fuzz") {
+        const int n = atoi(argv[2]);
+        unsigned long long x = 88172645463325252ull;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        int bad = 0, done = 0;
+        for (int it = 0; it < n; it++) {
+            const size_t len = (size_t)(rnd() % 65281);
+            std::vector<uint8_t> src(len);
+            const int kind = (int)(rnd() % 6);
+            for (size_t i = 0; i < len; i++) {
+                switch (kind) {
+                    case 0: src[i] = (uint8_t)rnd(); break;                                       // incompressible
+                    case 1: src[i] = (uint8_t)("ACGT"[rnd() & 3]); break;
+                    case 2: src[i] = (uint8_t)(i % 7 == 0 ? rnd() : 'I'); break;                  // long runs
+                    case 3: src[i] = (uint8_t)(i >= 300 && (rnd() % 5) ? src[i - 1 - rnd() % 299] : rnd()); break;   // many short matches
+                    case 4: src[i] = (uint8_t)(i & 1 ? 0 : rnd() % 3); break;
+                    default: src[i] = (uint8_t)(33 + rnd() % 40); break;                          // quality-like
+                }
+            }
+            const int level = (int)(rnd() % 10);
+            const int strategies[4] = {Z_DEFAULT_STRATEGY, Z_FIXED, Z_HUFFMAN_ONLY, Z_RLE};
+            const int strat = strategies[rnd() % 4];
+            const std::vector<uint8_t> comp = deflate_raw(src, level, strat);
+            char what[96]; snprintf(what, sizeof what, "fuzz %d kind %d level %d strategy %d len %zu", it, kind, level, strat, len);
+            bad += check(comp.data(), comp.size(), src, what); done++;
+        }
+        printf("fuzz: %d buffers, %d mismatches\n", done, bad);
+        return bad ? 1 : 0;
+    }
+    if (argc < 2) { fprintf(stderr, "usage\n"); return 2; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror("open"); return 2; }
+    std::vector<uint8_t> file;
+    { uint8_t buf[1 << 16]; size_t k; while ((k = fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + k); }
+    fclose(f);
+    size_t at = 0; int blocks = 0, bad = 0; size_t total = 0;
+    while (at + 18 <= file.size()) {
+        const uint8_t* hd = file.data() + at;
+        if (hd[0] != 31 || hd[1] != 139) { fprintf(stderr, "not a BGZF block at %zu\n", at); return 2; }
+        const unsigned xlen = hd[10] | (hd[11] << 8);
+        int bsize = -1;
+        for (size_t p = 0; p + 4 <= xlen;) { const uint8_t* e = hd + 12 + p; const unsigned sl = e[2] | (e[3] << 8); if (e[0] == 'B' && e[1] == 'C') bsize = e[4] | (e[5] << 8); p += 4 + sl; }
+        if (bsize < 0) { fprintf(stderr, "no BC field\n"); return 2; }
+        const size_t blen = (size_t)bsize + 1, cstart = 12 + xlen, clen = blen - cstart - 8;
+        const uint32_t isize = hd[blen - 4] | (hd[blen - 3] << 8) | (hd[blen - 2] << 16) | ((uint32_t)hd[blen - 1] << 24);
+        std::vector<uint8_t> expect(isize);
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        inflateInit2(&zs, -15);
+        zs.next_in = const_cast<Bytef*>(hd + cstart); zs.avail_in = (uInt)clen; zs.next_out = expect.data(); zs.avail_out = isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END && isize) { fprintf(stderr, "zlib failed on block %d\n", blocks); return 2; }
+        char what[64]; snprintf(what, sizeof what, "block %d", blocks);
+        bad += check(hd + cstart, clen, expect, what);
+        at += blen; blocks++; total += isize;
+    }
+    printf("%s: %d BGZF blocks, %zu bytes inflated, %d mismatches\n", argv[1], blocks, total, bad);
+    return bad ? 1 : 0;
+}
