@@ -262,7 +262,14 @@ int  svx_pair_distances(svx_ctx* ctx, const svx_sig_view* host_sigs, int64_t n_p
 typedef struct svx_inflater svx_inflater;
 int   svx_inflater_create(int device, svx_inflater** out);
 void  svx_inflater_destroy(svx_inflater* f);
-void* svx_inflater_staging(svx_inflater* f, uint64_t bytes);
+/* three slots (0..2), each with its own stream, device buffers and pinned staging buffer: while one sub-batch is inflated and copied back, the
+ * caller packs the next.  enqueue = H2D + inflate + copy of the inflated range to `out` (host, or device when out_on_device), asynchronous;
+ * wait = its completion (error if a block was not a sound DEFLATE stream of ISIZE bytes).  run = enqueue + wait on slot 0. */
+void* svx_inflater_staging(svx_inflater* f, int slot, uint64_t bytes);
+int   svx_inflater_pin(svx_inflater* f, void* host_buffer, uint64_t bytes);      /* page-lock a destination buffer: the copy back becomes one DMA */
+int   svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const uint64_t* in_off, const uint32_t* clen, const uint32_t* isize,
+                           const uint64_t* out_at, uint64_t staged_bytes, uint8_t* out, uint64_t out_bytes, int out_on_device);
+int   svx_inflater_wait(svx_inflater* f, int slot, float* kernel_ms /* may be NULL */);
 int   svx_inflater_run(svx_inflater* f, int64_t n, const uint64_t* in_off, const uint32_t* clen, const uint32_t* isize, const uint64_t* out_at,
                        uint64_t staged_bytes, uint8_t* out, uint64_t out_bytes, int out_on_device, float* kernel_ms /* may be NULL */);
 
@@ -286,6 +293,10 @@ int  svx_bam_rewind(svx_bam* h);
 /* contig-sharded ranks: continue at BGZF virtual offset `voff` (the .bai gives the first record of every contig) and report end-of-file at
  * the first record whose reference id exceeds last_tid or that is unplaced (-2: no limit) */
 int  svx_bam_seek(svx_bam* h, uint64_t voff, int32_t last_tid);
+/* BGZF inflate shared between the GPU (svx_inflater on `device`; < 0: off) and the host's cores: of every chunk of blocks the GPU takes sub-batches
+ * from the front while the worker threads take blocks from the back - whoever is faster inflates more.  stats: blocks inflated by either so far. */
+int  svx_bam_set_gpu_inflate(svx_bam* h, int device);
+int  svx_bam_gpu_inflate_stats(svx_bam* h, int64_t* gpu_blocks, int64_t* cpu_blocks, double* gpu_kernel_ms);
 int  svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** nul_separated, int64_t* blob_len);
 
 #ifdef __cplusplus

@@ -23,8 +23,9 @@ SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version",
            "svx_cluster_set_shard_by_origin", "svx_cluster_remote_members", "svx_cluster_set_chain",
            "svx_set_alignment_index", "svx_genotype",
            "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster", "svx_pair_distances",
-           "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names", "svx_bam_set_seq_filter", "svx_bam_rewind", "svx_bam_seek",
-           "svx_inflater_create", "svx_inflater_destroy", "svx_inflater_staging", "svx_inflater_run"]
+           "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names", "svx_bam_set_seq_filter", "svx_bam_rewind", "svx_bam_seek", "svx_bam_set_gpu_inflate", "svx_bam_gpu_inflate_stats",
+           "svx_inflater_create", "svx_inflater_destroy", "svx_inflater_staging", "svx_inflater_pin", "svx_inflater_enqueue", "svx_inflater_wait",
+           "svx_inflater_run"]
 
 
 class SvxError(RuntimeError):
@@ -316,7 +317,7 @@ class Inflater(object):
         if n > 1:
             out_at[1:n] = np.cumsum(isize[:n - 1].astype(np.uint64))
         total_out = int(isize[:n].astype(np.uint64).sum()) if n else 0
-        stage = self.L.svx_inflater_staging(self.h, C.c_uint64(max(at, 8)))
+        stage = self.L.svx_inflater_staging(self.h, C.c_int(0), C.c_uint64(max(at, 8)))
         if not stage:
             raise SvxError("svx_inflater_staging failed")
         buf = (C.c_uint8 * max(at, 8)).from_address(stage)

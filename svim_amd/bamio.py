@@ -49,6 +49,16 @@ class NativeBam(object):
         if rc != 0:
             raise SvxError("svx_bam_set_seq_filter failed")
 
+    def set_gpu_inflate(self, device):
+        """BGZF inflate shared between the GPU (device >= 0) and the host's cores (svx_bam_set_gpu_inflate); device < 0 switches it off"""
+        if self.L.svx_bam_set_gpu_inflate(self.h, C.c_int(int(device))) != 0:
+            raise SvxError("svx_bam_set_gpu_inflate failed: %s" % self.L.svx_last_error().decode())
+
+    def gpu_inflate_stats(self):
+        g, c, ms = C.c_int64(), C.c_int64(), C.c_double()
+        self.L.svx_bam_gpu_inflate_stats(self.h, C.byref(g), C.byref(c), C.byref(ms))
+        return {"gpu_blocks": g.value, "cpu_blocks": c.value, "gpu_kernel_ms": ms.value}
+
     def seek(self, voff, last_tid=-2):
         """continue at BGZF virtual offset `voff`; records beyond reference id `last_tid` end the reading (svx_bam_seek)"""
         if self.L.svx_bam_seek(self.h, C.c_uint64(int(voff)), C.c_int32(int(last_tid))) != 0:

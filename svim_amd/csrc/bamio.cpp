@@ -147,6 +147,9 @@ struct svx_bam {
     struct RecRef { const uint8_t* r; const uint8_t* end; const uint8_t* cig; uint32_t n_cig; };
     std::vector<RecRef> refs; std::vector<const char*> t_name, t_sa; std::vector<uint32_t> t_name_len, t_sa_len;
     int64_t total_records = 0;
+    // svx_bam_set_gpu_inflate: the GPU inflates sub-batches of blocks from the front of every chunk while the host's cores take blocks from its back
+    svx_inflater* gpu = nullptr; size_t gpu_sub = 4096;
+    int64_t gpu_blocks = 0, cpu_blocks = 0; double gpu_kernel_ms = 0;
 };
 
 // ---- BGZF ------------------------------------------------------------------------------------------------------------------
@@ -213,6 +216,69 @@ static void inflate_next_chunk(svx_bam* h) {
         }
         h->next.resize_uninit(WIN_HEAD + total);
         h->next_len = total;
+        if (h->gpu && !blocks.empty()) {
+            // Both ends against the middle: a feeder thread hands sub-batches from the FRONT of the chunk to the GPU (payloads packed into pinned staging,
+            // three sub-batches in flight: H2D, inflate and the copy back overlap), the worker threads inflate runs of 8 blocks from the BACK with zlib;
+            // whoever is faster takes more.  The window is page-locked so that the copy back is a DMA into place.
+            uint8_t* out_base = h->next.data() + WIN_HEAD;
+            (void)svx_inflater_pin(h->gpu, h->next.data(), h->next.cap);
+            std::mutex m;
+            size_t lo = 0, hi = blocks.size();
+            auto take = [&](bool front, size_t want, size_t& a, size_t& b) -> bool {
+                std::lock_guard<std::mutex> g(m);
+                if (lo >= hi) return false;
+                if (front) { a = lo; b = std::min(hi, lo + want); lo = b; }
+                else { b = hi; a = hi > lo + want ? hi - want : lo; hi = a; }
+                return true;
+            };
+            std::string gpu_err;
+            int64_t n_gpu = 0; double ms_gpu = 0;
+            std::thread feeder([&]() {
+                bool used[3] = {false, false, false};
+                auto wait_slot = [&](int sl) { float ms = 0; if (svx_inflater_wait(h->gpu, sl, &ms) != SVX_OK) throw std::string(svx_last_error()); ms_gpu += ms; used[sl] = false; };
+                try {
+                    std::vector<uint64_t> in_off, out_at; std::vector<uint32_t> clen, isize;
+                    size_t a, b; int slot = 0;
+                    while (take(true, h->gpu_sub, a, b)) {
+                        if (used[slot]) wait_slot(slot);
+                        const size_t n = b - a;
+                        in_off.resize(n); out_at.resize(n); clen.resize(n); isize.resize(n);
+                        uint64_t staged = 0;
+                        const size_t base = blocks[a].out_at;
+                        for (size_t i = 0; i < n; i++) {
+                            const RawBlock& rb = blocks[a + i];
+                            in_off[i] = staged; staged += ((uint64_t)rb.clen + 7) & ~7ull;
+                            clen[i] = (uint32_t)rb.clen; isize[i] = rb.isize; out_at[i] = rb.out_at - base;
+                        }
+                        uint8_t* stage = (uint8_t*)svx_inflater_staging(h->gpu, slot, staged + 8);
+                        if (!stage) throw std::string("no pinned staging memory");
+                        for (size_t i = 0; i < n; i++) memcpy(stage + in_off[i], blocks[a + i].comp, blocks[a + i].clen);
+                        const uint64_t out_bytes = blocks[b - 1].out_at + blocks[b - 1].isize - base;
+                        if (svx_inflater_enqueue(h->gpu, slot, (int64_t)n, in_off.data(), clen.data(), isize.data(), out_at.data(), staged, out_base + base, out_bytes, 0) != SVX_OK)
+                            throw std::string(svx_last_error());
+                        used[slot] = true; n_gpu += (int64_t)n;
+                        slot = (slot + 1) % 3;
+                    }
+                    for (int sl = 0; sl < 3; sl++) if (used[sl]) wait_slot(sl);
+                } catch (const std::string& e) {
+                    gpu_err = e;
+                    for (int sl = 0; sl < 3; sl++) if (used[sl]) (void)svx_inflater_wait(h->gpu, sl, nullptr);
+                }
+            });
+            const int n_workers = std::max(1, h->n_threads);
+            std::vector<std::string> errs((size_t)n_workers);
+            std::vector<int64_t> done((size_t)n_workers, 0);
+            h->pool_inflate->run(n_workers, [&](int t) {
+                try { size_t a, b; while (take(false, 8, a, b)) { for (size_t i = a; i < b; i++) inflate_block(blocks[i], out_base + blocks[i].out_at); done[(size_t)t] += (int64_t)(b - a); } }
+                catch (const std::string& e) { errs[(size_t)t] = e; }
+            });
+            feeder.join();
+            h->gpu_blocks += n_gpu; h->gpu_kernel_ms += ms_gpu;
+            for (auto d : done) h->cpu_blocks += d;
+            if (!gpu_err.empty()) throw gpu_err;
+            for (auto& e : errs) if (!e.empty()) throw e;
+            return;
+        }
         // blocks in runs of 8 per task: dynamic scheduling over the pool evens out the cost differences between blocks
         const int n_tasks = (int)((blocks.size() + 7) / 8);
         std::vector<std::string> errs((size_t)std::max(1, n_tasks));
@@ -283,6 +349,28 @@ static int default_threads() {
     return (int)n;
 }
 
+// BGZF inflate shared between the GPU (svx_inflater, device >= 0) and the host's cores; device < 0 switches it off again.  Larger chunks then:
+// the GPU wants thousands of blocks in flight.
+extern "C" int svx_bam_set_gpu_inflate(svx_bam* h, int device) {
+    if (!h) return bam_fail(SVX_E_ARG, "null handle");
+    if (h->prefetch_active) { h->prefetch.get(); h->prefetch_active = false; h->prefetch_err.clear(); }
+    if (h->gpu) { svx_inflater_destroy(h->gpu); h->gpu = nullptr; }
+    if (device < 0) return SVX_OK;
+    const int rc = svx_inflater_create(device, &h->gpu);
+    if (rc != SVX_OK) { h->gpu = nullptr; return rc; }
+    h->chunk_bytes = std::max<size_t>(h->chunk_bytes, (size_t)1536 << 20);
+    h->chunk_blocks = std::max<size_t>(h->chunk_blocks, 32768);
+    { const char* e = getenv("SVX_BAM_GPU_SUB"); if (e && atoll(e) > 0) h->gpu_sub = (size_t)atoll(e); }
+    return SVX_OK;
+}
+extern "C" int svx_bam_gpu_inflate_stats(svx_bam* h, int64_t* gpu_blocks, int64_t* cpu_blocks, double* gpu_kernel_ms) {
+    if (!h) return bam_fail(SVX_E_ARG, "null handle");
+    if (gpu_blocks) *gpu_blocks = h->gpu_blocks;
+    if (cpu_blocks) *cpu_blocks = h->cpu_blocks;
+    if (gpu_kernel_ms) *gpu_kernel_ms = h->gpu_kernel_ms;
+    return SVX_OK;
+}
+
 extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out) {
     svx_bam* h = new svx_bam();
     h->path = path;
@@ -351,6 +439,11 @@ extern "C" void svx_bam_close(svx_bam* h) {
     if (getenv("SVX_BAM_TIMING"))
         fprintf(stderr, "bamio %d threads: wait for inflate %.3f s, window copy %.3f, record walk %.3f, decode %.3f, names + SA %.3f\n", h->n_threads,
                 h->t_wait, h->t_copy, h->t_walk, h->t_decode, h->t_intern);
+    if (h->gpu) {
+        if (getenv("SVX_BAM_TIMING")) fprintf(stderr, "bamio inflate: %lld blocks on the GPU (kernels %.1f ms), %lld on the host\n", (long long)h->gpu_blocks, h->gpu_kernel_ms, (long long)h->cpu_blocks);
+        svx_inflater_destroy(h->gpu);                    // before the windows it page-locked are freed
+        h->gpu = nullptr;
+    }
     if (h->map) munmap((void*)h->map, h->map_len);
     if (h->fd >= 0) close(h->fd);
     delete h->pool; delete h->pool_inflate;

@@ -18,13 +18,19 @@ __global__ __launch_bounds__(256) void k_bgzf_inflate(const uint8_t* comp, const
     if (lane_id() == 0 && rc != (int)job.out_bytes) { status[0] = 1; status[1] = (int)j; status[2] = rc; }
 }
 
-struct svx_inflater {
-    int device = 0;
+#define INF_SLOTS 3
+struct InflaterSlot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[2];
     DevBuf comp, out, jobs, status;
-    void* staging = nullptr; size_t staging_cap = 0;      // pinned host memory the caller packs the payloads into
-    float last_kernel_ms = 0;
+    void* staging = nullptr; size_t staging_cap = 0;      // pinned host memory the caller packs this slot's payloads into
+    int host_status[4] = {0, 0, 0, 0};
+    bool busy = false;
+};
+struct svx_inflater {
+    int device = 0;
+    InflaterSlot slot[INF_SLOTS];
+    std::vector<std::pair<void*, size_t>> pinned;         // caller buffers registered for direct DMA
 };
 
 extern "C" int svx_inflater_create(int device, svx_inflater** out) {
@@ -34,8 +40,10 @@ extern "C" int svx_inflater_create(int device, svx_inflater** out) {
     HIPCHK(hipSetDevice(device));
     svx_inflater* f = new svx_inflater();
     f->device = device;
-    HIPCHK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
-    for (auto& e : f->ev) HIPCHK(hipEventCreate(&e));
+    for (auto& sl : f->slot) {
+        HIPCHK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        for (auto& e : sl.ev) HIPCHK(hipEventCreate(&e));
+    }
     *out = f;
     return SVX_OK;
 }
@@ -43,35 +51,62 @@ extern "C" int svx_inflater_create(int device, svx_inflater** out) {
 extern "C" void svx_inflater_destroy(svx_inflater* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
-    (void)hipStreamSynchronize(f->stream);
-    f->comp.release(); f->out.release(); f->jobs.release(); f->status.release();
-    if (f->staging) (void)hipHostFree(f->staging);
-    for (auto& e : f->ev) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(f->stream);
+    for (auto& sl : f->slot) {
+        (void)hipStreamSynchronize(sl.stream);
+        sl.comp.release(); sl.out.release(); sl.jobs.release(); sl.status.release();
+        if (sl.staging) (void)hipHostFree(sl.staging);
+        for (auto& e : sl.ev) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(sl.stream);
+    }
+    for (auto& pr : f->pinned) (void)hipHostUnregister(pr.first);
     delete f;
 }
 
-// pinned host buffer of at least `bytes` for the packed payloads (8-byte aligned start of every payload); valid until the next larger request
-extern "C" void* svx_inflater_staging(svx_inflater* f, uint64_t bytes) {
-    if (!f) return nullptr;
-    if (bytes > f->staging_cap) {
+// pinned host buffer of at least `bytes` for the packed payloads of one slot (8-byte aligned start of every payload); valid until the next larger
+// request for the same slot.  Three slots: while one sub-batch is inflated and copied back, the caller packs the next.
+extern "C" void* svx_inflater_staging(svx_inflater* f, int slot, uint64_t bytes) {
+    if (!f || slot < 0 || slot >= INF_SLOTS) return nullptr;
+    InflaterSlot& sl = f->slot[slot];
+    if (bytes > sl.staging_cap) {
         (void)hipSetDevice(f->device);
-        if (f->staging) (void)hipHostFree(f->staging);
-        f->staging = nullptr; f->staging_cap = 0;
+        if (sl.busy) { (void)hipStreamSynchronize(sl.stream); sl.busy = false; }
+        if (sl.staging) (void)hipHostFree(sl.staging);
+        sl.staging = nullptr; sl.staging_cap = 0;
         const size_t want = (size_t)bytes + (size_t)bytes / 4 + 4096;
-        if (hipHostMalloc(&f->staging, want, hipHostMallocDefault) != hipSuccess) return nullptr;
-        f->staging_cap = want;
+        if (hipHostMalloc(&sl.staging, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+        sl.staging_cap = want;
     }
-    return f->staging;
+    return sl.staging;
 }
 
-// n payloads packed in the staging buffer (in_off[i], 8-byte aligned, clen[i] bytes of raw DEFLATE) -> out_host + out_at[i] (isize[i] bytes each).
-// out_on_device != 0: out_host is device memory (the inflated stream stays in HBM).  kernel_ms (optional): duration of the inflate launch.
-extern "C" int svx_inflater_run(svx_inflater* f, int64_t n, const uint64_t* in_off, const uint32_t* clen, const uint32_t* isize, const uint64_t* out_at,
-                                uint64_t staged_bytes, uint8_t* out_host, uint64_t out_bytes, int out_on_device, float* kernel_ms) {
-    if (!f || n < 0 || (n && (!in_off || !clen || !isize || !out_at || !out_host))) return svx_fail(SVX_E_ARG, "null argument", __FILE__, __LINE__, hipSuccess);
-    if (staged_bytes > f->staging_cap) return svx_fail(SVX_E_ARG, "payloads are not in the staging buffer", __FILE__, __LINE__, hipSuccess);
-    if (kernel_ms) *kernel_ms = 0;
+// page-lock a caller buffer that receives inflated data, so that the copy back is one DMA (without it the runtime stages through its own buffers);
+// a buffer that moved or grew is registered again.  Failure to register is not an error - the copies just take the slow path.
+extern "C" int svx_inflater_pin(svx_inflater* f, void* p, uint64_t bytes) {
+    if (!f || !p || !bytes) return SVX_OK;
+    (void)hipSetDevice(f->device);
+    for (size_t i = 0; i < f->pinned.size(); i++) {
+        auto& pr = f->pinned[i];
+        if (pr.first == p && pr.second >= bytes) return SVX_OK;
+        const char* a = (const char*)pr.first; const char* b = (const char*)p;
+        if (b < a + pr.second && a < b + bytes) {                                   // overlaps an older registration: drop that one
+            for (auto& sl : f->slot) if (sl.busy) { (void)hipStreamSynchronize(sl.stream); }
+            (void)hipHostUnregister(pr.first);
+            f->pinned.erase(f->pinned.begin() + (long)i); i--;
+        }
+    }
+    if (hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) == hipSuccess) f->pinned.emplace_back(p, (size_t)bytes);
+    else (void)hipGetLastError();
+    return SVX_OK;
+}
+
+// n payloads packed in the slot's staging buffer (in_off[i], 8-byte aligned, clen[i] bytes of raw DEFLATE) -> out + out_at[i] (isize[i] bytes each),
+// asynchronously on the slot's stream: H2D, inflate, copy back.  out_on_device != 0: `out` is device memory (the inflated stream stays in HBM).
+extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const uint64_t* in_off, const uint32_t* clen, const uint32_t* isize, const uint64_t* out_at,
+                                    uint64_t staged_bytes, uint8_t* out, uint64_t out_bytes, int out_on_device) {
+    if (!f || slot < 0 || slot >= INF_SLOTS || n < 0 || (n && (!in_off || !clen || !isize || !out_at || !out))) return svx_fail(SVX_E_ARG, "bad argument", __FILE__, __LINE__, hipSuccess);
+    InflaterSlot& sl = f->slot[slot];
+    if (sl.busy) return svx_fail(SVX_E_STATE, "slot still busy: svx_inflater_wait first", __FILE__, __LINE__, hipSuccess);
+    if (staged_bytes > sl.staging_cap) return svx_fail(SVX_E_ARG, "payloads are not in the staging buffer", __FILE__, __LINE__, hipSuccess);
     if (n == 0) return SVX_OK;
     HIPCHK(hipSetDevice(f->device));
     std::vector<BgzfJob> jobs((size_t)n);
@@ -80,31 +115,46 @@ extern "C" int svx_inflater_run(svx_inflater* f, int64_t n, const uint64_t* in_o
             return svx_fail(SVX_E_ARG, "payload offset / size out of range", __FILE__, __LINE__, hipSuccess);
         jobs[(size_t)i] = BgzfJob{in_off[i], out_at[i], clen[i], isize[i]};
     }
-    SVXCHK(f->comp.reserve((size_t)staged_bytes + 64));
-    SVXCHK(f->jobs.reserve((size_t)n * sizeof(BgzfJob)));
-    SVXCHK(f->status.reserve(16));
-    uint8_t* out_dev = out_host;
-    if (!out_on_device) { SVXCHK(f->out.reserve((size_t)out_bytes + 64)); out_dev = f->out.as<uint8_t>(); }
-    hipStream_t st = f->stream;
-    HIPCHK(hipMemcpyAsync(f->comp.p, f->staging, (size_t)staged_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(f->jobs.p, jobs.data(), (size_t)n * sizeof(BgzfJob), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(f->status.p, 0, 16, st));
-    HIPCHK(hipEventRecord(f->ev[0], st));
-    k_bgzf_inflate<<<(unsigned)((n + 3) / 4), 256, 0, st>>>(f->comp.as<uint8_t>(), f->jobs.as<BgzfJob>(), (long long)n, out_dev, f->status.as<int>());
+    SVXCHK(sl.comp.reserve((size_t)staged_bytes + 64));
+    SVXCHK(sl.jobs.reserve((size_t)n * sizeof(BgzfJob)));
+    SVXCHK(sl.status.reserve(16));
+    uint8_t* out_dev = out;
+    if (!out_on_device) { SVXCHK(sl.out.reserve((size_t)out_bytes + 64)); out_dev = sl.out.as<uint8_t>(); }
+    hipStream_t st = sl.stream;
+    HIPCHK(hipMemcpyAsync(sl.comp.p, sl.staging, (size_t)staged_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sl.jobs.p, jobs.data(), (size_t)n * sizeof(BgzfJob), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));                                   // `jobs` is a local; the (small) uploads are through, the rest stays asynchronous
+    HIPCHK(hipMemsetAsync(sl.status.p, 0, 16, st));
+    HIPCHK(hipEventRecord(sl.ev[0], st));
+    k_bgzf_inflate<<<(unsigned)((n + 3) / 4), 256, 0, st>>>(sl.comp.as<uint8_t>(), sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.status.as<int>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(f->ev[1], st));
-    int status[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(status, f->status.p, 16, hipMemcpyDeviceToHost, st));
-    if (!out_on_device) HIPCHK(hipMemcpyAsync(out_host, out_dev, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, f->ev[0], f->ev[1]));
-    f->last_kernel_ms = ms;
-    if (kernel_ms) *kernel_ms = ms;
-    if (status[0]) {
+    HIPCHK(hipEventRecord(sl.ev[1], st));
+    HIPCHK(hipMemcpyAsync(sl.host_status, sl.status.p, 16, hipMemcpyDeviceToHost, st));
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, out_dev, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
+    sl.busy = true;
+    return SVX_OK;
+}
+
+extern "C" int svx_inflater_wait(svx_inflater* f, int slot, float* kernel_ms) {
+    if (!f || slot < 0 || slot >= INF_SLOTS) return svx_fail(SVX_E_ARG, "bad argument", __FILE__, __LINE__, hipSuccess);
+    InflaterSlot& sl = f->slot[slot];
+    if (kernel_ms) *kernel_ms = 0;
+    if (!sl.busy) return SVX_OK;
+    HIPCHK(hipSetDevice(f->device));
+    HIPCHK(hipStreamSynchronize(sl.stream));
+    sl.busy = false;
+    if (kernel_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1])); *kernel_ms = ms; }
+    if (sl.host_status[0]) {
         char msg[128];
-        snprintf(msg, sizeof msg, "BGZF inflate failed on block %d (code %d)", status[1], status[2]);
+        snprintf(msg, sizeof msg, "BGZF inflate failed on block %d of the sub-batch (code %d)", sl.host_status[1], sl.host_status[2]);
         return svx_fail(SVX_E_ARG, msg, __FILE__, __LINE__, hipSuccess);
     }
     return SVX_OK;
+}
+
+// one sub-batch, synchronously (slot 0)
+extern "C" int svx_inflater_run(svx_inflater* f, int64_t n, const uint64_t* in_off, const uint32_t* clen, const uint32_t* isize, const uint64_t* out_at,
+                                uint64_t staged_bytes, uint8_t* out, uint64_t out_bytes, int out_on_device, float* kernel_ms) {
+    SVXCHK(svx_inflater_enqueue(f, 0, n, in_off, clen, isize, out_at, staged_bytes, out, out_bytes, out_on_device));
+    return svx_inflater_wait(f, 0, kernel_ms);
 }

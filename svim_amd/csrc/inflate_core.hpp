@@ -24,11 +24,16 @@
 #define INF_E_INPUT (-8)
 
 // per-wave scratch (LDS on the device): code lengths while a dynamic header is read, then the symbols of both codes in canonical order
+#define INF_FAST_L 10          /* literal/length codes of up to 10 bits and distance codes of up to 8 bits are decoded by ONE table lookup; */
+#define INF_FAST_D 8           /* an entry is (code length << 9) | symbol, 0 = longer code: canonical walk                              */
 struct InfScratch {
     uint16_t len[INF_MAXL + INF_MAXD];
     uint16_t lsym[INF_MAXL];
     uint16_t dsym[INF_MAXD];
     uint16_t cnt[INF_MAXBITS + 1];
+    uint16_t code[INF_MAXL];                 // canonical code of every symbol (while a fast table is filled)
+    uint16_t fast_l[1 << INF_FAST_L];
+    uint16_t fast_d[1 << INF_FAST_D];
 };
 
 #ifdef INF_HOST
@@ -43,11 +48,13 @@ struct InfScratch {
 
 struct InfState {
     // input: 32-bit words (the block's payload starts at a 4-byte aligned address), bit buffer
-    const uint32_t* in; uint32_t in_words, in_at;
+    const uint32_t* in; uint32_t in_words, in_at;      // in_at: words handed to the bit buffer so far
+    uint32_t ahead;                                    // word in_at, loaded when word in_at - 1 was taken: its latency hides behind the symbols in between
     uint64_t bitbuf; int bitcnt;
     // output
     uint8_t* out; uint32_t out_cap, pos;      // pos: bytes produced (staged ones included)
     uint32_t staged;                           // literals waiting in the lanes (0..64); they belong to out[pos - staged, pos)
+    uint32_t clean;                            // every store to out[0, clean) is known to have completed (the last wait)
 #ifdef INF_HOST
     uint8_t stage[64];
 #else
@@ -57,8 +64,9 @@ struct InfState {
 
 INF_FN void inf_need(InfState& s, int n) {                 // n <= 32
     if (s.bitcnt < n) {
-        const uint32_t w = s.in_at < s.in_words ? (uint32_t)INF_UNI(s.in[s.in_at]) : 0u;       // reading past the end yields zeros; the caller notices by position
+        const uint32_t w = (uint32_t)INF_UNI(s.ahead);
         s.in_at++;
+        s.ahead = s.in_at < s.in_words ? s.in[s.in_at] : 0u;       // reading past the end yields zeros; the caller notices by position
         s.bitbuf |= (uint64_t)w << s.bitcnt;
         s.bitcnt += 32;
     }
@@ -97,12 +105,17 @@ INF_FN int inf_match(InfState& s, uint32_t dist, uint32_t len) {
     if (dist > s.pos) return INF_E_DIST;
     if (s.pos + len > s.out_cap) return INF_E_OUTPUT;
     inf_flush(s);
+    // the source may have been written by this wave a moment ago (by other lanes): only then wait for the stores (workgroup-scope fence)
+    if (s.pos - dist + (len < dist ? len : dist) > s.clean) {
+#ifndef INF_HOST
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+        s.clean = s.pos;
+    }
 #ifdef INF_HOST
     for (uint32_t i = 0; i < len; i++) s.out[s.pos + i] = s.out[s.pos - dist + i];
 #else
-    // the source may have been written by this wave a moment ago (by other lanes): workgroup-scope fence = wait for those stores
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint8_t* src = s.out + (s.pos - dist);
     uint8_t* dst = s.out + s.pos;
     for (uint32_t i = (uint32_t)INF_LANE; i < len; i += 64) dst[i] = src[dist >= len ? i : i % dist];
@@ -153,7 +166,41 @@ INF_FN int inf_construct(InfScratch& sc, const uint16_t* len, int n, InfCounts& 
     return left;
 }
 
-INF_FN int inf_codes(InfState& s, const InfCounts& lc, const uint16_t* lsym, const InfCounts& dc, const uint16_t* dsym) {
+// fast table of a code built by inf_construct: entry[bits] for every `fb`-bit window whose low bits are a complete code of at most fb bits
+INF_FN void inf_fast_table(InfScratch& sc, const uint16_t* len, int n, const InfCounts& h, uint16_t* fast, int fb) {
+    // canonical codes: first code of every length, then symbols in order (lane 0; a few hundred steps)
+    if (INF_LANE == 0) {
+        uint16_t* next = sc.cnt;                                    // free again after inf_construct
+        uint32_t code = 0;
+        next[0] = 0;
+#pragma unroll
+        for (int l = 1; l <= INF_MAXBITS; l++) { code = (code + (l > 1 ? (uint32_t)h.c[l - 1] : 0u)) << 1; next[l] = (uint16_t)code; }
+        for (int i = 0; i < n; i++) { const int l = len[i]; sc.code[i] = l ? next[l]++ : 0; }
+    }
+#ifdef INF_HOST
+    for (int k = 0; k < (1 << fb); k++) fast[k] = 0;
+    for (int i = 0; i < n; i++) {
+#else
+    for (int k = INF_LANE; k < (1 << fb); k += 64) fast[k] = 0;
+    for (int i = INF_LANE; i < n; i += 64) {
+#endif
+        const int l = len[i];
+        if (l == 0 || l > fb) continue;
+        uint32_t c = sc.code[i], r = 0;
+        for (int b = 0; b < l; b++) { r = (r << 1) | (c & 1u); c >>= 1; }          // the stream carries codes most significant bit first
+        const uint16_t e = (uint16_t)((l << 9) | i);
+        for (uint32_t k = r; k < (1u << fb); k += 1u << l) fast[k] = e;
+    }
+}
+
+INF_FN int inf_decode_fast(InfState& s, const InfCounts& h, const uint16_t* symbol, const uint16_t* fast, int fb) {
+    inf_need(s, INF_MAXBITS);
+    const uint32_t e = (uint32_t)INF_UNI(fast[(uint32_t)s.bitbuf & ((1u << fb) - 1u)]) & 0xffffu;
+    if (e) { const int l = (int)(e >> 9); s.bitbuf >>= l; s.bitcnt -= l; return (int)(e & 511u); }
+    return inf_decode(s, h, symbol);
+}
+
+INF_FN int inf_codes(InfState& s, const InfCounts& lc, const uint16_t* lsym, const InfCounts& dc, const uint16_t* dsym, const InfScratch& sc) {
     // length / distance bases and extra bits (RFC 1951 3.2.5), packed: base | extra << 16
     static const uint32_t lens[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11 | 1 << 16, 13 | 1 << 16, 15 | 1 << 16, 17 | 1 << 16, 19 | 2 << 16, 23 | 2 << 16, 27 | 2 << 16,
                                       31 | 2 << 16, 35 | 3 << 16, 43 | 3 << 16, 51 | 3 << 16, 59 | 3 << 16, 67 | 4 << 16, 83 | 4 << 16, 99 | 4 << 16, 115 | 4 << 16,
@@ -163,7 +210,7 @@ INF_FN int inf_codes(InfState& s, const InfCounts& lc, const uint16_t* lsym, con
                                        1025 | 9 << 16, 1537 | 9 << 16, 2049 | 10 << 16, 3073 | 10 << 16, 4097 | 11 << 16, 6145 | 11 << 16, 8193 | 12 << 16,
                                        12289 | 12 << 16, 16385 | 13 << 16, 24577 | 13 << 16};
     for (;;) {
-        int sym = inf_decode(s, lc, lsym);
+        int sym = inf_decode_fast(s, lc, lsym, sc.fast_l, INF_FAST_L);
         if (sym < 0) return sym;
         if (sym < 256) { const int rc = inf_literal(s, (uint32_t)sym); if (rc) return rc; continue; }
         if (sym == 256) return 0;
@@ -171,7 +218,7 @@ INF_FN int inf_codes(InfState& s, const InfCounts& lc, const uint16_t* lsym, con
         if (sym >= 29) return INF_E_SYMBOL;
         const uint32_t le = lens[sym];
         const uint32_t len = (le & 0xffffu) + inf_bits(s, (int)(le >> 16));
-        const int ds = inf_decode(s, dc, dsym);
+        const int ds = inf_decode_fast(s, dc, dsym, sc.fast_d, INF_FAST_D);
         if (ds < 0) return ds;
         if (ds >= 30) return INF_E_SYMBOL;
         const uint32_t de = dists[ds];
@@ -186,7 +233,8 @@ INF_FN int inf_codes(InfState& s, const InfCounts& lc, const uint16_t* lsym, con
 INF_FN int inflate_raw(const uint32_t* in, uint32_t in_bytes, uint8_t* out, uint32_t out_cap, InfScratch& sc) {
     InfState s;
     s.in = in; s.in_words = (in_bytes + 3u) / 4u; s.in_at = 0; s.bitbuf = 0; s.bitcnt = 0;
-    s.out = out; s.out_cap = out_cap; s.pos = 0; s.staged = 0;
+    s.ahead = s.in_words ? in[0] : 0u;
+    s.out = out; s.out_cap = out_cap; s.pos = 0; s.staged = 0; s.clean = 0;
 #ifndef INF_HOST
     s.stage = 0;
 #endif
@@ -214,6 +262,7 @@ INF_FN int inflate_raw(const uint32_t* in, uint32_t in_bytes, uint8_t* out, uint
             // restart the bit reader behind the stored bytes
             const uint32_t next = at + len;
             s.in_at = next / 4u; s.bitbuf = 0; s.bitcnt = 0;
+            s.ahead = s.in_at < s.in_words ? s.in[s.in_at] : 0u;
             if (next & 3u) (void)inf_bits(s, 8 * (int)(next & 3u));
         } else if (type == 1 || type == 2) {
             if (type == 1) {
@@ -225,7 +274,9 @@ INF_FN int inflate_raw(const uint32_t* in, uint32_t in_bytes, uint8_t* out, uint
                     for (int i = 0; i < 30; i++) sc.len[288 + i] = 5;
                 }
                 (void)inf_construct(sc, sc.len, 288, lc, sc.lsym);
+                inf_fast_table(sc, sc.len, 288, lc, sc.fast_l, INF_FAST_L);
                 (void)inf_construct(sc, sc.len + 288, 30, dc, sc.dsym);
+                inf_fast_table(sc, sc.len + 288, 30, dc, sc.fast_d, INF_FAST_D);
             } else {
                 static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
                 const int nlen = (int)inf_bits(s, 5) + 257, ndist = (int)inf_bits(s, 5) + 1, ncode = (int)inf_bits(s, 4) + 4;
@@ -257,10 +308,12 @@ INF_FN int inflate_raw(const uint32_t* in, uint32_t in_bytes, uint8_t* out, uint
                 // the distance lengths first (construct of the literal/length code overwrites lsym, where csym lived)
                 err = inf_construct(sc, sc.len + nlen, ndist, dc, sc.dsym);
                 if (err < 0 || (err > 0 && ndist - dc.c[0] != 1)) return INF_E_OVERSUB;   // incomplete only allowed for a single distance code
+                inf_fast_table(sc, sc.len + nlen, ndist, dc, sc.fast_d, INF_FAST_D);
                 err = inf_construct(sc, sc.len, nlen, lc, sc.lsym);
                 if (err < 0 || (err > 0 && nlen - lc.c[0] != 1)) return INF_E_OVERSUB;
+                inf_fast_table(sc, sc.len, nlen, lc, sc.fast_l, INF_FAST_L);
             }
-            const int rc = inf_codes(s, lc, sc.lsym, dc, sc.dsym);
+            const int rc = inf_codes(s, lc, sc.lsym, dc, sc.dsym, sc);
             if (rc) return rc;
         } else return INF_E_BLOCKTYPE;
         if (last) break;

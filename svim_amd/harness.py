@@ -38,9 +38,11 @@ def effective_cpus():
 class BamPipeline(object):
     """reader thread || GPU thread over one BAM file; results stay resident in the engine (accumulated lists)."""
 
-    def __init__(self, path, options, engine, threads=0, batch_records=200_000, mode="coordinate", sparse_seq=True, regions=None):
+    def __init__(self, path, options, engine, threads=0, batch_records=200_000, mode="coordinate", sparse_seq=True, regions=None, gpu_inflate=None):
         from .bamio import NativeBam
         self.bam = NativeBam(path, threads=threads)
+        if gpu_inflate is not None:
+            self.bam.set_gpu_inflate(int(gpu_inflate))          # BGZF inflate shared between that GPU and the host's cores
         self.options, self.eng, self.mode, self.batch_records = options, engine, mode, batch_records
         self.params = _abi.Params.from_options(options)
         if sparse_seq and mode == "coordinate":
@@ -232,10 +234,10 @@ def write_bam_from_batch(path, hb, references, lengths, name_fmt="r%08d", thread
 # ---------------------------------------------------------------------------------------------------------------------
 # measurements
 # ---------------------------------------------------------------------------------------------------------------------
-def _timed_bam_passes(path, opts, eng, genome, passes=1, threads=0, batch_records=200_000, sparse_seq=True):
+def _timed_bam_passes(path, opts, eng, genome, passes=1, threads=0, batch_records=200_000, sparse_seq=True, gpu_inflate=None):
     """-> list of (records, wall seconds, pipeline stats, engine stats, (n_sig, n_seq, n_bnd)) per pass over ONE reader: the first pass
     pays every first-touch allocation (host buffers, device buffers), later passes are the steady state of a long file."""
-    pipe = BamPipeline(path, opts, eng, threads=threads, batch_records=batch_records, sparse_seq=sparse_seq)
+    pipe = BamPipeline(path, opts, eng, threads=threads, batch_records=batch_records, sparse_seq=sparse_seq, gpu_inflate=gpu_inflate)
     out = []
     try:
         for k in range(passes):
