@@ -239,20 +239,34 @@ static void inflate_next_chunk(svx_bam* h) {
                 try {
                     std::vector<uint64_t> in_off, out_at; std::vector<uint32_t> clen, isize;
                     size_t a, b; int slot = 0;
-                    while (take(true, h->gpu_sub, a, b)) {
+                    // sub-batch: as large as possible for the GPU's sake (thousands of wavefronts), at most half of the chunk so that the cores get their share
+                    const size_t sub = std::min(h->gpu_sub, std::max<size_t>(2048, blocks.size() / 2));
+                    while (take(true, sub, a, b)) {
                         if (used[slot]) wait_slot(slot);
                         const size_t n = b - a;
                         in_off.resize(n); out_at.resize(n); clen.resize(n); isize.resize(n);
-                        uint64_t staged = 0;
+                        // the blocks of a sub-batch are one contiguous slice of the file: it goes to the pinned staging buffer as it is (headers and
+                        // trailers included), in four concurrent copies
+                        const uint8_t* f0 = blocks[a].comp;
+                        const uint64_t staged = (uint64_t)(blocks[b - 1].comp + blocks[b - 1].clen - f0);
                         const size_t base = blocks[a].out_at;
                         for (size_t i = 0; i < n; i++) {
                             const RawBlock& rb = blocks[a + i];
-                            in_off[i] = staged; staged += ((uint64_t)rb.clen + 7) & ~7ull;
+                            in_off[i] = (uint64_t)(rb.comp - f0);
                             clen[i] = (uint32_t)rb.clen; isize[i] = rb.isize; out_at[i] = rb.out_at - base;
                         }
                         uint8_t* stage = (uint8_t*)svx_inflater_staging(h->gpu, slot, staged + 8);
                         if (!stage) throw std::string("no pinned staging memory");
-                        for (size_t i = 0; i < n; i++) memcpy(stage + in_off[i], blocks[a + i].comp, blocks[a + i].clen);
+                        {
+                            const int parts = staged > ((uint64_t)8 << 20) ? 4 : 1;
+                            std::vector<std::thread> cp;
+                            for (int q = 1; q < parts; q++) {
+                                const uint64_t lo_b = staged * (uint64_t)q / parts, hi_b = staged * (uint64_t)(q + 1) / parts;
+                                cp.emplace_back([=]() { memcpy(stage + lo_b, f0 + lo_b, (size_t)(hi_b - lo_b)); });
+                            }
+                            memcpy(stage, f0, (size_t)(staged / parts));
+                            for (auto& t : cp) t.join();
+                        }
                         const uint64_t out_bytes = blocks[b - 1].out_at + blocks[b - 1].isize - base;
                         if (svx_inflater_enqueue(h->gpu, slot, (int64_t)n, in_off.data(), clen.data(), isize.data(), out_at.data(), staged, out_base + base, out_bytes, 0) != SVX_OK)
                             throw std::string(svx_last_error());
@@ -353,14 +367,16 @@ static int default_threads() {
 // the GPU wants thousands of blocks in flight.
 extern "C" int svx_bam_set_gpu_inflate(svx_bam* h, int device) {
     if (!h) return bam_fail(SVX_E_ARG, "null handle");
-    if (h->prefetch_active) { h->prefetch.get(); h->prefetch_active = false; h->prefetch_err.clear(); }
+    if (h->prefetch_active) h->prefetch.wait();          // the chunk being inflated stays what it is; the next one sees the new setting
     if (h->gpu) { svx_inflater_destroy(h->gpu); h->gpu = nullptr; }
     if (device < 0) return SVX_OK;
     const int rc = svx_inflater_create(device, &h->gpu);
     if (rc != SVX_OK) { h->gpu = nullptr; return rc; }
-    h->chunk_bytes = std::max<size_t>(h->chunk_bytes, (size_t)1536 << 20);
-    h->chunk_blocks = std::max<size_t>(h->chunk_blocks, 32768);
+    h->chunk_bytes = std::max<size_t>(h->chunk_bytes, (size_t)3072 << 20);
+    h->chunk_blocks = std::max<size_t>(h->chunk_blocks, 65536);
+    h->gpu_sub = 32768;
     { const char* e = getenv("SVX_BAM_GPU_SUB"); if (e && atoll(e) > 0) h->gpu_sub = (size_t)atoll(e); }
+    { const char* e = getenv("SVX_BAM_GPU_CHUNK_MB"); if (e && atoll(e) > 0) { h->chunk_bytes = (size_t)atoll(e) << 20; h->chunk_blocks = h->chunk_bytes / 30000; } }
     return SVX_OK;
 }
 extern "C" int svx_bam_gpu_inflate_stats(svx_bam* h, int64_t* gpu_blocks, int64_t* cpu_blocks, double* gpu_kernel_ms) {

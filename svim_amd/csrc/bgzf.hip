@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void k_bgzf_inflate(const uint8_t* comp, const
     const long long j = (long long)blockIdx.x * 4 + wave;
     if (j >= n_jobs) return;
     const BgzfJob job = jobs[j];
-    const int rc = inflate_raw(reinterpret_cast<const uint32_t*>(comp + job.in_off), job.in_bytes, out + job.out_off, job.out_bytes, scratch[wave]);
+    const int rc = inflate_raw(comp + job.in_off, job.in_bytes, out + job.out_off, job.out_bytes, scratch[wave]);
     if (lane_id() == 0 && rc != (int)job.out_bytes) { status[0] = 1; status[1] = (int)j; status[2] = rc; }
 }
 
@@ -62,7 +62,7 @@ extern "C" void svx_inflater_destroy(svx_inflater* f) {
     delete f;
 }
 
-// pinned host buffer of at least `bytes` for the packed payloads of one slot (8-byte aligned start of every payload); valid until the next larger
+// pinned host buffer of at least `bytes` for the payloads of one slot (a slice of the file as it is, or payloads packed one by one); valid until the next larger
 // request for the same slot.  Three slots: while one sub-batch is inflated and copied back, the caller packs the next.
 extern "C" void* svx_inflater_staging(svx_inflater* f, int slot, uint64_t bytes) {
     if (!f || slot < 0 || slot >= INF_SLOTS) return nullptr;
@@ -99,7 +99,7 @@ extern "C" int svx_inflater_pin(svx_inflater* f, void* p, uint64_t bytes) {
     return SVX_OK;
 }
 
-// n payloads packed in the slot's staging buffer (in_off[i], 8-byte aligned, clen[i] bytes of raw DEFLATE) -> out + out_at[i] (isize[i] bytes each),
+// n payloads in the slot's staging buffer (in_off[i], any alignment, clen[i] bytes of raw DEFLATE) -> out + out_at[i] (isize[i] bytes each),
 // asynchronously on the slot's stream: H2D, inflate, copy back.  out_on_device != 0: `out` is device memory (the inflated stream stays in HBM).
 extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const uint64_t* in_off, const uint32_t* clen, const uint32_t* isize, const uint64_t* out_at,
                                     uint64_t staged_bytes, uint8_t* out, uint64_t out_bytes, int out_on_device) {
@@ -111,7 +111,7 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
     HIPCHK(hipSetDevice(f->device));
     std::vector<BgzfJob> jobs((size_t)n);
     for (int64_t i = 0; i < n; i++) {
-        if ((in_off[i] & 7ull) || in_off[i] + clen[i] > staged_bytes || out_at[i] + isize[i] > out_bytes)
+        if (in_off[i] + clen[i] > staged_bytes || out_at[i] + isize[i] > out_bytes)
             return svx_fail(SVX_E_ARG, "payload offset / size out of range", __FILE__, __LINE__, hipSuccess);
         jobs[(size_t)i] = BgzfJob{in_off[i], out_at[i], clen[i], isize[i]};
     }

@@ -228,16 +228,20 @@ INF_FN int inf_codes(InfState& s, const InfCounts& lc, const uint16_t* lsym, con
     }
 }
 
-// one raw DEFLATE stream: `in` = payload (4-byte aligned, in_bytes long), out_cap = ISIZE.  Returns the number of bytes produced (== ISIZE for a
+// one raw DEFLATE stream: `payload` (any alignment, in_bytes long), out_cap = ISIZE.  Returns the number of bytes produced (== ISIZE for a
 // sound block) or a negative INF_E_*.  Device: every lane of the wave must call, with wave-uniform arguments.
-INF_FN int inflate_raw(const uint32_t* in, uint32_t in_bytes, uint8_t* out, uint32_t out_cap, InfScratch& sc) {
+INF_FN int inflate_raw(const uint8_t* payload, uint32_t in_bytes, uint8_t* out, uint32_t out_cap, InfScratch& sc) {
     InfState s;
-    s.in = in; s.in_words = (in_bytes + 3u) / 4u; s.in_at = 0; s.bitbuf = 0; s.bitcnt = 0;
-    s.ahead = s.in_words ? in[0] : 0u;
+    // the bit reader works on aligned 32-bit words: the up to 3 bytes in front of the payload are read and dropped
+    const uint32_t skip = (uint32_t)(reinterpret_cast<uintptr_t>(payload) & 3u);
+    in_bytes += skip;
+    s.in = reinterpret_cast<const uint32_t*>(payload - skip); s.in_words = (in_bytes + 3u) / 4u; s.in_at = 0; s.bitbuf = 0; s.bitcnt = 0;
+    s.ahead = s.in_words ? s.in[0] : 0u;
     s.out = out; s.out_cap = out_cap; s.pos = 0; s.staged = 0; s.clean = 0;
 #ifndef INF_HOST
     s.stage = 0;
 #endif
+    if (skip) (void)inf_bits(s, 8 * (int)skip);
     InfCounts lc, dc;
     for (;;) {
         const uint32_t last = inf_bits(s, 1), type = inf_bits(s, 2);

@@ -41,7 +41,9 @@ class BamPipeline(object):
     def __init__(self, path, options, engine, threads=0, batch_records=200_000, mode="coordinate", sparse_seq=True, regions=None, gpu_inflate=None):
         from .bamio import NativeBam
         self.bam = NativeBam(path, threads=threads)
-        if gpu_inflate is not None:
+        if gpu_inflate is None and os.environ.get("SVX_BAM_GPU_INFLATE", "1") != "0":
+            gpu_inflate = getattr(engine, "device", None)          # default: the engine's GPU helps with the inflate (SVX_BAM_GPU_INFLATE=0: host only)
+        if gpu_inflate is not None and gpu_inflate is not False:
             self.bam.set_gpu_inflate(int(gpu_inflate))          # BGZF inflate shared between that GPU and the host's cores
         self.options, self.eng, self.mode, self.batch_records = options, engine, mode, batch_records
         self.params = _abi.Params.from_options(options)
@@ -115,6 +117,10 @@ class BamPipeline(object):
         t_collect_done = time.perf_counter()
         self.stats = dict(records=n_rec, batches=n_batches, t_collect_wall=t_collect_done - t_start, t_reader_busy=t_read[0], t_gpu_collect=t_gpu,
                           t_gpu_waits_for_reader=t_wait)
+        try:
+            self.stats["inflate"] = self.bam.gpu_inflate_stats()       # cumulative over the passes of this reader
+        except Exception:
+            self.stats["inflate"] = None
         return n_rec
 
     def cluster(self, genome=None):
@@ -253,7 +259,7 @@ def _timed_bam_passes(path, opts, eng, genome, passes=1, threads=0, batch_record
     return out
 
 
-def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s=None, n_records=60_000, tmp_dir=None):
+def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s=None, n_records=180_000, tmp_dir=None):
     """bench.py's `end_to_end` block: the first n_records of the synthetic batch (coordinate order) written as a BAM file, then
     (a) BAM file -> reader -> pipeline -> CLUSTER, wall clock including inflate, decode, H2D; (b) the same records handed over as host
     arrays (H2D included, no file); next to (c) the resident rate of the headline.  One untimed pass warms allocations."""
@@ -284,7 +290,11 @@ def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s
         out["bam_file"] = {"records": n_read, "wall_s": wall, "bam_MB_per_s": size / wall / 1e6, "inflated_MB_per_s": raw_bytes / wall / 1e6,
                            "batches": ps["batches"], "reader_busy_s": ps["t_reader_busy"], "gpu_collect_s": ps["t_gpu_collect"],
                            "gpu_waits_for_reader_s": ps["t_gpu_waits_for_reader"], "cluster_s": ps["t_cluster_wall"],
-                           "signatures": counts[0], "bound_by": "reader (BGZF inflate + decode on the granted host CPUs)" if ps["t_gpu_waits_for_reader"] > 0.5 * wall else "GPU"}
+                           "signatures": counts[0], "inflate": ps.get("inflate"),
+                           "bound_by": "reader (BGZF inflate shared between the GPU and the granted host CPUs, record decode on the CPUs)" if ps["t_gpu_waits_for_reader"] > 0.5 * wall else "GPU"}
+        # the same with the inflate on the host's cores alone (SVX_BAM_GPU_INFLATE=0)
+        r = min(_timed_bam_passes(path, opts, eng, gen, passes=3, batch_records=per_batch, gpu_inflate=False)[1:], key=lambda x: x[1])
+        out["bam_file_host_inflate_only_reads_per_s"] = r[0] / r[1]
         # dense SEQ for comparison: what the sparse filter saves on PCIe and in the decoder
         r = min(_timed_bam_passes(path, opts, eng, gen, passes=3, batch_records=per_batch, sparse_seq=False)[1:], key=lambda x: x[1])
         out["bam_file_dense_seq_reads_per_s"] = r[0] / r[1]

@@ -11,11 +11,13 @@
 #include <vector>
 
 static int check(const uint8_t* comp, size_t clen, const std::vector<uint8_t>& expect, const char* what) {
+    static unsigned shift = 0;                                          // every alignment of the payload gets its turn
     std::vector<uint32_t> in((clen + 3) / 4 + 4, 0);
-    memcpy(in.data(), comp, clen);
+    uint8_t* payload = reinterpret_cast<uint8_t*>(in.data()) + (shift++ & 3u);
+    memcpy(payload, comp, clen);
     std::vector<uint8_t> out(expect.size() + 8, 0xAA);
     InfScratch sc;
-    const int rc = inflate_raw(in.data(), (uint32_t)clen, out.data(), (uint32_t)expect.size(), sc);
+    const int rc = inflate_raw(payload, (uint32_t)clen, out.data(), (uint32_t)expect.size(), sc);
     if (rc != (int)expect.size() || memcmp(out.data(), expect.data(), expect.size()) != 0 || out[expect.size()] != 0xAA) {
         size_t d = 0; while (d < expect.size() && out[d] == expect[d]) d++;
         fprintf(stderr, "MISMATCH %s: rc %d expected %zu, first difference at %zu\n", what, rc, expect.size(), d);

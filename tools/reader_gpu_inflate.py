@@ -58,7 +58,7 @@ def run(gpu, threads=0, sub=None, passes=3, checksum=False):
 
 tot, t_cpu, _, s_cpu = run(False, checksum=True)
 print("host only              : %.3f s  %.2f M records/s  %.2f GB/s inflated" % (t_cpu, tot / t_cpu / 1e6, raw / t_cpu / 1e9))
-for sub in (2048, 4096, 8192):
+for sub in (8192, 16384, 32768):
     tot2, t_gpu, st, s_gpu = run(True, sub=sub, checksum=True)
     share = st["gpu_blocks"] / max(1, st["gpu_blocks"] + st["cpu_blocks"])
     print("GPU + host, sub %5d   : %.3f s  %.2f M records/s  %.2f GB/s inflated   GPU took %.0f %% of the blocks (kernels %.0f ms over all passes)  same arrays: %s" % (
