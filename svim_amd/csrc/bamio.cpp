@@ -148,7 +148,7 @@ struct svx_bam {
     std::vector<RecRef> refs; std::vector<const char*> t_name, t_sa; std::vector<uint32_t> t_name_len, t_sa_len;
     int64_t total_records = 0;
     // svx_bam_set_gpu_inflate: the GPU inflates sub-batches of blocks from the front of every chunk while the host's cores take blocks from its back
-    svx_inflater* gpu = nullptr; size_t gpu_sub = 4096;
+    svx_inflater* gpu = nullptr; size_t gpu_sub = 4096; bool gpu_sub_forced = false;       // SVX_BAM_GPU_SUB: exact sub-batch size (tests)
     int64_t gpu_blocks = 0, cpu_blocks = 0; double gpu_kernel_ms = 0;
 };
 
@@ -240,7 +240,7 @@ static void inflate_next_chunk(svx_bam* h) {
                     std::vector<uint64_t> in_off, out_at; std::vector<uint32_t> clen, isize;
                     size_t a, b; int slot = 0;
                     // sub-batch: as large as possible for the GPU's sake (thousands of wavefronts), at most half of the chunk so that the cores get their share
-                    const size_t sub = std::min(h->gpu_sub, std::max<size_t>(2048, blocks.size() / 2));
+                    const size_t sub = h->gpu_sub_forced ? h->gpu_sub : std::min(h->gpu_sub, std::max<size_t>(2048, blocks.size() / 2));
                     while (take(true, sub, a, b)) {
                         if (used[slot]) wait_slot(slot);
                         const size_t n = b - a;
@@ -372,10 +372,13 @@ extern "C" int svx_bam_set_gpu_inflate(svx_bam* h, int device) {
     if (device < 0) return SVX_OK;
     const int rc = svx_inflater_create(device, &h->gpu);
     if (rc != SVX_OK) { h->gpu = nullptr; return rc; }
-    h->chunk_bytes = std::max<size_t>(h->chunk_bytes, (size_t)3072 << 20);
-    h->chunk_blocks = std::max<size_t>(h->chunk_blocks, 65536);
+    if (!getenv("SVX_BAM_CHUNK_BLOCKS")) {                   // (the test hook keeps its small chunks)
+        h->chunk_bytes = std::max<size_t>(h->chunk_bytes, (size_t)3072 << 20);
+        h->chunk_blocks = std::max<size_t>(h->chunk_blocks, 65536);
+    }
     h->gpu_sub = 32768;
-    { const char* e = getenv("SVX_BAM_GPU_SUB"); if (e && atoll(e) > 0) h->gpu_sub = (size_t)atoll(e); }
+    h->gpu_sub_forced = false;
+    { const char* e = getenv("SVX_BAM_GPU_SUB"); if (e && atoll(e) > 0) { h->gpu_sub = (size_t)atoll(e); h->gpu_sub_forced = true; } }
     { const char* e = getenv("SVX_BAM_GPU_CHUNK_MB"); if (e && atoll(e) > 0) { h->chunk_bytes = (size_t)atoll(e) << 20; h->chunk_blocks = h->chunk_bytes / 30000; } }
     return SVX_OK;
 }

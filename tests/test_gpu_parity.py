@@ -813,3 +813,51 @@ def test_bgzf_inflate_on_the_gpu_equals_zlib(tmp_path):
         f.close()
     expect = b"".join(zlib.decompress(b, -15) if s else b"" for b, s in blocks)
     assert len(got) == len(expect) and got.tobytes() == expect
+
+
+@pytest.mark.parametrize("sub", ["16", "40", None])
+def test_reader_with_gpu_inflate_delivers_the_same_batches(tmp_path, monkeypatch, sub):
+    """svx_bam_set_gpu_inflate: the GPU inflates sub-batches from the front of every chunk, the host's cores blocks from its back (sub-batches of
+    16 / 40 blocks here so that both sides work on one small file and the three slots rotate; None = the default sizing).  Every array of every
+    batch equals what the host-only reader delivers, in both SEQ modes."""
+    from svim_amd.bamio import NativeBam
+    if sub is None:
+        monkeypatch.delenv("SVX_BAM_GPU_SUB", raising=False)
+    else:
+        monkeypatch.setenv("SVX_BAM_GPU_SUB", sub)
+    monkeypatch.setenv("SVX_BAM_CHUNK_BLOCKS", "120")                    # several chunks: the window switch happens with page-locked buffers
+    contigs = [("chr1", 200000), ("chr2", 80000)]
+    refs = synth.make_reference(3, contigs)
+    references, lengths = [c[0] for c in contigs], [c[1] for c in contigs]
+    recs = synth.planted_reads(5, 1500, refs, references, lengths, n_sites=60, types=("DEL", "INS", "INV"))
+    recs += synth.fuzz_split_reads(6, 150, references, lengths)
+    path = str(tmp_path / "t.bam")
+    records.write_bam(path, references, lengths, synth.coordinate_sort(recs))
+
+    def read_all(gpu, seq_filter):
+        nb = NativeBam(path, threads=4)
+        if seq_filter:
+            nb.set_seq_filter(40)
+        if gpu:
+            nb.set_gpu_inflate(0)
+        out = []
+        for _ in range(2):                                                 # second pass after rewind: buffers reused
+            while True:
+                b, k = nb.read_batch(700, 20, "coordinate")
+                if k == 0:
+                    break
+                out.append(nb.batch_arrays(b))
+            nb.rewind()
+        st = nb.gpu_inflate_stats()
+        nb.close()
+        return out, st
+
+    for seq_filter in (False, True):
+        host, _ = read_all(False, seq_filter)
+        both, st = read_all(True, seq_filter)
+        assert st["gpu_blocks"] > 0 and (sub is None or st["cpu_blocks"] > 0), st
+        assert len(host) == len(both) and len(host) > 4
+        for a, b in zip(host, both):
+            assert a.keys() == b.keys()
+            for k in a:
+                assert np.array_equal(a[k], b[k]), k
