@@ -117,6 +117,54 @@ struct BatchArrays {
     std::string sa_blob; std::vector<uint64_t> sa_at; std::vector<uint32_t> sa_len;
 };
 
+// Read names -> dense ids in first-seen order.  Interning is the serial part of the reader (ids must follow record order), so it is made
+// short: the 64-bit hashes are computed in the parallel decode phase, the table is open addressing over (hash, id) pairs with the slot of
+// a later record prefetched, and a hit is confirmed against the name blob (ids are exact, the hash only finds the slot).
+static inline uint64_t name_hash(const char* p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+    while (n >= 8) { uint64_t w; memcpy(&w, p, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32; p += 8; n -= 8; }
+    uint64_t w = 0; memcpy(&w, p, n);
+    h = (h ^ w) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29;
+    return h | 1ull;                                       // 0 marks an empty slot
+}
+struct NameTable {
+    struct Slot { uint64_t hash; int32_t id; int32_t len; };
+    std::vector<Slot> slots; size_t mask = 0, used = 0;
+    std::string blob;                       // NUL-separated, id order
+    std::vector<uint64_t> off;              // start of name id in blob
+    void grow() {
+        const size_t cap = slots.empty() ? (size_t)1 << 16 : slots.size() * 2;
+        std::vector<Slot> old; old.swap(slots);
+        slots.assign(cap, Slot{0, 0, 0}); mask = cap - 1;
+        for (const Slot& e : old) if (e.hash) { size_t i = (size_t)e.hash & mask; while (slots[i].hash) i = (i + 1) & mask; slots[i] = e; }
+    }
+    void prefetch(uint64_t hash) const { if (mask) __builtin_prefetch(&slots[(size_t)hash & mask]); }
+    int32_t find(const char* p, size_t n, uint64_t hash) const {
+        if (!mask) return -1;
+        for (size_t i = (size_t)hash & mask;; i = (i + 1) & mask) {
+            const Slot& e = slots[i];
+            if (!e.hash) return -1;
+            if (e.hash == hash && (size_t)e.len == n && memcmp(blob.data() + off[(size_t)e.id], p, n) == 0) return e.id;
+        }
+    }
+    int32_t intern(const char* p, size_t n, uint64_t hash) {
+        if ((used + 1) * 10 > slots.size() * 6) grow();
+        size_t i = (size_t)hash & mask;
+        for (;; i = (i + 1) & mask) {
+            const Slot& e = slots[i];
+            if (!e.hash) break;
+            if (e.hash == hash && (size_t)e.len == n && memcmp(blob.data() + off[(size_t)e.id], p, n) == 0) return e.id;
+        }
+        const int32_t id = (int32_t)off.size();
+        off.push_back(blob.size());
+        blob.append(p, n); blob.push_back('\0');
+        slots[i] = Slot{hash, id, (int32_t)n};
+        used++;
+        return id;
+    }
+    size_t size() const { return off.size(); }
+};
+
 struct svx_bam {
     // the file is memory-mapped: finding the BGZF block boundaries is a serial walk over 18-byte headers, the compressed payload is read
     // (page-faulted in) by the inflating threads themselves - a serial fread of every block capped the reader at ~2 GB/s of BAM
@@ -124,9 +172,8 @@ struct svx_bam {
     std::string path, sort_order, names_blob;
     std::vector<std::string> ref_names;
     std::vector<int32_t> ref_len, contig_rank;
-    std::unordered_map<std::string, int32_t> tid_of, read_id_of;
-    std::string read_names_blob;          // NUL-separated, id order
-    std::vector<uint64_t> read_name_off;
+    std::unordered_map<std::string, int32_t> tid_of;
+    NameTable names;                      // read names -> ids
     // uncompressed stream window + the chunk a background thread is inflating meanwhile
     RawVec<uint8_t> buf; size_t pos = 0; bool file_eof = false;
     // The background thread inflates the next chunk into `next` BEHIND `WIN_HEAD` bytes of headroom: switching windows then only moves
@@ -145,7 +192,7 @@ struct svx_bam {
     std::vector<uint32_t> t_rng_cnt; std::vector<uint64_t> t_seq_bytes;
     std::vector<uint32_t> name_id_tmp;
     struct RecRef { const uint8_t* r; const uint8_t* end; const uint8_t* cig; uint32_t n_cig; };
-    std::vector<RecRef> refs; std::vector<const char*> t_name, t_sa; std::vector<uint32_t> t_name_len, t_sa_len;
+    std::vector<RecRef> refs; std::vector<const char*> t_name, t_sa; std::vector<uint32_t> t_name_len, t_sa_len; std::vector<uint64_t> t_name_hash;
     int64_t total_records = 0;
     // svx_bam_set_gpu_inflate: the GPU inflates sub-batches of blocks from the front of every chunk while the host's cores take blocks from its back
     svx_inflater* gpu = nullptr; size_t gpu_sub = 4096; bool gpu_sub_forced = false;       // SVX_BAM_GPU_SUB: exact sub-batch size (tests)
@@ -648,7 +695,7 @@ static int64_t decode_run(svx_bam* h, int64_t max_count, bool sparse) {
     const size_t base = B.flag.size();
     B.flag.resize(base + n); B.tid.resize(base + n); B.bpos.resize(base + n); B.mapq.resize(base + n); B.lseq.resize(base + n);
     B.read_id.resize(base + n); B.sa_at.resize(base + n); B.sa_len.resize(base + n);
-    h->t_name.resize(n); h->t_name_len.resize(n); h->t_sa.resize(n); h->t_sa_len.resize(n);
+    h->t_name.resize(n); h->t_name_len.resize(n); h->t_sa.resize(n); h->t_sa_len.resize(n); h->t_name_hash.resize(n);
     B.cigar.resize_uninit(cig_total);
     const size_t RUN = 256;
     const int n_tasks = (int)((n + RUN - 1) / RUN);
@@ -669,6 +716,7 @@ static int64_t decode_run(svx_bam* h, int64_t max_count, bool sparse) {
                 B.tid[k] = (int32_t)rd32(r); B.bpos[k] = (int32_t)rd32(r + 4); B.mapq[k] = r[9];
                 B.flag[k] = (uint16_t)(rd16(r + 14) & 0x0fff); B.lseq[k] = (int32_t)l_seq;
                 h->t_name[i] = (const char*)r + 32; h->t_name_len[i] = l_name ? l_name - 1 : 0;
+                h->t_name_hash[i] = name_hash(h->t_name[i], h->t_name_len[i]);
                 const uint8_t* q = r + 32 + l_name + 4 * (size_t)rd16(r + 12);       // the record's own CIGAR field, CG or not
                 const char* sa; size_t sa_n; const uint8_t* cg; uint32_t cg_n;
                 scan_aux(q + (l_seq + 1) / 2 + l_seq, rr.end, sa, sa_n, cg, cg_n);
@@ -726,16 +774,8 @@ static int64_t decode_run(svx_bam* h, int64_t max_count, bool sparse) {
     });
     h->t_decode += now_s() - t0; t0 = now_s();
     for (size_t i = 0; i < n; i++) {
-        const std::string name(h->t_name[i], h->t_name_len[i]);
-        auto it = h->read_id_of.find(name);
-        int32_t rid;
-        if (it == h->read_id_of.end()) {
-            rid = (int32_t)h->read_name_off.size();
-            h->read_id_of.emplace(name, rid);
-            h->read_name_off.push_back(h->read_names_blob.size());
-            h->read_names_blob += name; h->read_names_blob.push_back('\0');
-        } else rid = it->second;
-        B.read_id[base + i] = rid;
+        if (i + 12 < n) h->names.prefetch(h->t_name_hash[i + 12]);
+        B.read_id[base + i] = h->names.intern(h->t_name[i], h->t_name_len[i], h->t_name_hash[i]);
         B.sa_at[base + i] = B.sa_blob.size(); B.sa_len[base + i] = h->t_sa_len[i];
         if (h->t_sa_len[i]) B.sa_blob.append(h->t_sa[i], h->t_sa_len[i]);
     }
@@ -766,14 +806,7 @@ static int parse_record(svx_bam* h) {
     scan_aux(q, end, sa, sa_n, cg, cg_n);
     // long CIGARs (> 65535 ops) live in CG:B,I behind a <l_seq>S<ref_len>N placeholder
     if (cg && n_cig == 2 && (rd32(cig) & 15) == 4 && (rd32(cig) >> 4) == l_seq && (rd32(cig + 4) & 15) == 3) { cig = cg; n_cig = cg_n; }
-    auto it = h->read_id_of.find(name);
-    int32_t rid;
-    if (it == h->read_id_of.end()) {
-        rid = (int32_t)h->read_name_off.size();
-        h->read_id_of.emplace(name, rid);
-        h->read_name_off.push_back(h->read_names_blob.size());
-        h->read_names_blob += name; h->read_names_blob.push_back('\0');
-    } else rid = it->second;
+    const int32_t rid = h->names.intern(name.data(), name.size(), name_hash(name.data(), name.size()));
     h->b->flag.push_back((uint16_t)(flag & 0x0fff)); h->b->tid.push_back(tid); h->b->bpos.push_back(pos); h->b->mapq.push_back((uint8_t)mq);
     h->b->lseq.push_back((int32_t)l_seq); h->b->read_id.push_back(rid);
     const size_t c0 = h->b->cigar.size();
@@ -822,8 +855,8 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
                 if (!ensure(h, 4 + (size_t)bs)) throw std::string("truncated BAM record");
                 const uint8_t* r = h->buf.data() + h->pos + 4;
                 const std::string name((const char*)r + 32, r[8] ? r[8] - 1 : 0);
-                auto it = h->read_id_of.find(name);
-                if (it == h->read_id_of.end() || it->second != h->b->read_id[(size_t)n - 1]) { h->pos = save_pos; break; }
+                const int32_t known = h->names.find(name.data(), name.size(), name_hash(name.data(), name.size()));
+                if (known < 0 || known != h->b->read_id[(size_t)n - 1]) { h->pos = save_pos; break; }
                 parse_record(h); n++;
             }
         }
@@ -901,6 +934,6 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
 
 // read names interned so far: NUL-separated blob in id order
 extern "C" int svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** blob, int64_t* blob_len) {
-    *n_names = (int64_t)h->read_name_off.size(); *blob = h->read_names_blob.data(); *blob_len = (int64_t)h->read_names_blob.size();
+    *n_names = (int64_t)h->names.size(); *blob = h->names.blob.data(); *blob_len = (int64_t)h->names.blob.size();
     return SVX_OK;
 }
