@@ -113,6 +113,14 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
+    # a GPU fault must end the run, not write a multi-GB GPU core dump first
+    os.environ.setdefault("HSA_DISABLE_COREDUMP_ON_EXCEPTION", "1")
+    try:
+        import resource
+        resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
+    except Exception:
+        pass
+
     # stdout carries the ONE JSON line and nothing else: everything libraries write to fd 1 (RCCL prints a version banner there) goes to stderr
     json_fd = os.dup(1)
     os.dup2(2, 1)

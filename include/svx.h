@@ -267,6 +267,7 @@ void  svx_inflater_destroy(svx_inflater* f);
  * wait = its completion (error if a block was not a sound DEFLATE stream of ISIZE bytes).  run = enqueue + wait on slot 0. */
 void* svx_inflater_staging(svx_inflater* f, int slot, uint64_t bytes);
 int   svx_inflater_pin(svx_inflater* f, void* host_buffer, uint64_t bytes);      /* page-lock a destination buffer: the copy back becomes one DMA */
+int   svx_inflater_unpin(svx_inflater* f, void* host_buffer);                    /* MUST precede freeing / reallocating a pinned buffer */
 int   svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const uint64_t* in_off, const uint32_t* clen, const uint32_t* isize,
                            const uint64_t* out_at, uint64_t staged_bytes, uint8_t* out, uint64_t out_bytes, int out_on_device);
 int   svx_inflater_wait(svx_inflater* f, int slot, float* kernel_ms /* may be NULL */);

@@ -261,6 +261,7 @@ static void inflate_next_chunk(svx_bam* h) {
             b.out_at = total; total += b.isize;
             blocks.push_back(b);
         }
+        if (h->gpu && WIN_HEAD + total > h->next.cap) (void)svx_inflater_unpin(h->gpu, h->next.data());      // the window is about to move
         h->next.resize_uninit(WIN_HEAD + total);
         h->next_len = total;
         if (h->gpu && !blocks.empty()) {
@@ -380,6 +381,7 @@ static bool ensure(svx_bam* h, size_t need) {
         } else {
             // a record longer than the headroom straddles the chunks: fall back to appending
             if (h->pos) { memmove(h->buf.data(), h->buf.data() + h->pos, keep); h->buf.n = keep; h->pos = 0; }
+            if (h->gpu && h->buf.n + h->next_len > h->buf.cap) (void)svx_inflater_unpin(h->gpu, h->buf.data());
             h->buf.append(h->next.data() + WIN_HEAD, h->next_len);
         }
         if (h->next_eof) h->file_eof = true;

@@ -99,6 +99,21 @@ extern "C" int svx_inflater_pin(svx_inflater* f, void* p, uint64_t bytes) {
     return SVX_OK;
 }
 
+// a page-locked destination is about to be freed or reallocated: its registration must go first (a stale one would make the runtime treat
+// whatever lives at that address later as page-locked memory with the OLD physical pages)
+extern "C" int svx_inflater_unpin(svx_inflater* f, void* p) {
+    if (!f || !p) return SVX_OK;
+    (void)hipSetDevice(f->device);
+    for (size_t i = 0; i < f->pinned.size(); i++) {
+        if (f->pinned[i].first != p) continue;
+        for (auto& sl : f->slot) if (sl.busy) (void)hipStreamSynchronize(sl.stream);
+        if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+        f->pinned.erase(f->pinned.begin() + (long)i);
+        break;
+    }
+    return SVX_OK;
+}
+
 // n payloads in the slot's staging buffer (in_off[i], any alignment, clen[i] bytes of raw DEFLATE) -> out + out_at[i] (isize[i] bytes each),
 // asynchronously on the slot's stream: H2D, inflate, copy back.  out_on_device != 0: `out` is device memory (the inflated stream stays in HBM).
 extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const uint64_t* in_off, const uint32_t* clen, const uint32_t* isize, const uint64_t* out_at,

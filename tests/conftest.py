@@ -10,6 +10,12 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    os.environ.setdefault("HSA_DISABLE_COREDUMP_ON_EXCEPTION", "1")      # a GPU fault should fail the test, not write a multi-GB core dump first
+    try:
+        import resource
+        resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
+    except Exception:
+        pass
     # The torch wheel bundles its own HIP / HSA runtime and libsvx.so links the system one: whichever is initialised FIRST in a process is the
     # one that sees the GPU.  Tests that use torch device tensors beside libsvx need torch to be first (bench.py imports torch first, too).
     try:
