@@ -3,6 +3,7 @@
 # WRITE_SIZE in separate passes), the per-class edit profile, bench lines of every workload.  Usage: tools/gpu_profiles.sh <tag>
 tag=${1:-r02}
 export TMPDIR=/tmp
+export HSA_DISABLE_COREDUMP_ON_EXCEPTION=1; ulimit -c 0
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 cd /tmp
@@ -31,5 +32,8 @@ tools/micro/read_bw.bin > gpurun_out/${tag}_read_bw.txt 2>&1
 # calibration of the FETCH_SIZE correction: the probe reads a known number of bytes per launch with the same 16 B / lane loads
 rm -rf /tmp/pmc_cal; (cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_cal -o p -- $R/tools/micro/read_bw.bin > /dev/null 2>&1)
 db=$(find /tmp/pmc_cal -name "*.db" | head -1); [ -n "$db" ] && python tools/pmc_summary.py $db gpurun_out/${tag}_pmc_FETCH_SIZE_read_bw_calibration.csv > /dev/null
-python tools/reader_scaling.py 60000 > gpurun_out/${tag}_reader_scaling.txt 2>&1
+SVX_BAM_GPU_INFLATE=0 python tools/reader_scaling.py 60000 > gpurun_out/${tag}_reader_scaling.txt 2>&1
+python tools/bgzf_inflate_rate.py 60000 > gpurun_out/${tag}_bgzf_inflate_rate.txt 2>&1
+python tools/bgzf_symbol_cost.py > gpurun_out/${tag}_bgzf_symbol_cost.txt 2>&1
+python tools/reader_gpu_inflate.py 240000 > gpurun_out/${tag}_reader_gpu_inflate.txt 2>&1
 ls -la gpurun_out/${tag}_* | head -40
