@@ -36,9 +36,11 @@ static inline double now_s() { return std::chrono::duration<double>(std::chrono:
 // the decoder threads; std::vector::resize would first zero them (a memset of every batch)
 template <class T> struct RawVec {
     T* p = nullptr; size_t n = 0, cap = 0;
+    // a buffer that is page-locked for DMA (svx_inflater_pin) must lose its registration BEFORE its memory is freed or moved
+    void (*before_move)(void* user, void* old_ptr) = nullptr; void* bm_user = nullptr;
     RawVec() = default;
     RawVec(const RawVec&) = delete; RawVec& operator=(const RawVec&) = delete;
-    ~RawVec() { free(p); }
+    ~RawVec() { if (before_move && p) before_move(bm_user, p); free(p); }
     // Large buffers (inflate windows, CIGAR words, packed bases: hundreds of MB that 100+ threads write for the first time at once) are
     // 2 MB aligned and marked for transparent huge pages: first-touch page faults on 4 KB pages serialise the threads in the kernel.
     void reserve(size_t c) {
@@ -52,10 +54,12 @@ template <class T> struct RawVec {
             if (posix_memalign(&q, huge, rounded) != 0 || !q) throw std::string("out of host memory");
             (void)madvise(q, rounded, MADV_HUGEPAGE);
             if (p && n) memcpy(q, p, (n < cap ? n : cap) * sizeof(T));
+            if (before_move && p) before_move(bm_user, p);
             free(p);
             p = (T*)q; cap = rounded / sizeof(T);
             return;
         }
+        if (before_move && p) before_move(bm_user, p);
         T* q = (T*)realloc(p, bytes);
         if (!q) throw std::string("out of host memory");
         p = q; cap = nc;
@@ -414,13 +418,28 @@ static int default_threads() {
 
 // BGZF inflate shared between the GPU (svx_inflater, device >= 0) and the host's cores; device < 0 switches it off again.  Larger chunks then:
 // the GPU wants thousands of blocks in flight.
+// the buffers the GPU reads from / writes to by DMA: both inflate windows and the two big arrays of either batch set (CIGAR words, packed bases)
+static void unpin_hook(void* user, void* p) { svx_bam* h = (svx_bam*)user; if (h->gpu) (void)svx_inflater_unpin(h->gpu, p); }
+static void set_pin_hooks(svx_bam* h, bool on) {
+    auto set = [&](auto& v) { v.before_move = on ? unpin_hook : nullptr; v.bm_user = on ? h : nullptr; };
+    set(h->buf); set(h->next);
+    for (auto& b : h->ba) { set(b.cigar); set(b.seq); }
+}
+static void drop_gpu(svx_bam* h) {
+    if (!h->gpu) return;
+    set_pin_hooks(h, false);
+    svx_inflater_destroy(h->gpu);                        // unregisters everything it page-locked
+    h->gpu = nullptr;
+}
+
 extern "C" int svx_bam_set_gpu_inflate(svx_bam* h, int device) {
     if (!h) return bam_fail(SVX_E_ARG, "null handle");
     if (h->prefetch_active) h->prefetch.wait();          // the chunk being inflated stays what it is; the next one sees the new setting
-    if (h->gpu) { svx_inflater_destroy(h->gpu); h->gpu = nullptr; }
+    drop_gpu(h);
     if (device < 0) return SVX_OK;
     const int rc = svx_inflater_create(device, &h->gpu);
     if (rc != SVX_OK) { h->gpu = nullptr; return rc; }
+    set_pin_hooks(h, true);
     if (!getenv("SVX_BAM_CHUNK_BLOCKS")) {                   // (the test hook keeps its small chunks)
         h->chunk_bytes = std::max<size_t>(h->chunk_bytes, (size_t)3072 << 20);
         h->chunk_blocks = std::max<size_t>(h->chunk_blocks, 65536);
@@ -509,8 +528,7 @@ extern "C" void svx_bam_close(svx_bam* h) {
                 h->t_wait, h->t_copy, h->t_walk, h->t_decode, h->t_intern);
     if (h->gpu) {
         if (getenv("SVX_BAM_TIMING")) fprintf(stderr, "bamio inflate: %lld blocks on the GPU (kernels %.1f ms), %lld on the host\n", (long long)h->gpu_blocks, h->gpu_kernel_ms, (long long)h->cpu_blocks);
-        svx_inflater_destroy(h->gpu);                    // before the windows it page-locked are freed
-        h->gpu = nullptr;
+        drop_gpu(h);                                     // before the buffers it page-locked are freed
     }
     if (h->map) munmap((void*)h->map, h->map_len);
     if (h->fd >= 0) close(h->fd);
@@ -930,6 +948,11 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
             out->seq_rng_byte = h->b->rng_byte.data(); out->n_seq_rng = (int64_t)h->b->rng_off[(size_t)n];
         }
         h->total_records += n;
+        // the consumer uploads these arrays to the GPU: page-locked, the upload is one DMA each (the registration lasts until the array moves)
+        if (h->gpu && n > 0) {
+            (void)svx_inflater_pin(h->gpu, h->b->cigar.data(), h->b->cigar.cap * sizeof(uint32_t));
+            (void)svx_inflater_pin(h->gpu, h->b->seq.data(), h->b->seq.cap);
+        }
     } catch (const std::string& e) { return bam_fail(SVX_E_ARG, e); }
     return SVX_OK;
 }

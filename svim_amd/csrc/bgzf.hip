@@ -5,6 +5,7 @@
 // Replaces: zlib inflate() under htslib's bgzf_read_block (the reference reads BAM through pysam.AlignmentFile, SVIM_COLLECT.py:132-137).
 #include "common.hpp"
 #include "inflate_core.hpp"
+#include <mutex>
 
 struct BgzfJob { unsigned long long in_off; unsigned long long out_off; uint32_t in_bytes; uint32_t out_bytes; };
 
@@ -31,6 +32,7 @@ struct svx_inflater {
     int device = 0;
     InflaterSlot slot[INF_SLOTS];
     std::vector<std::pair<void*, size_t>> pinned;         // caller buffers registered for direct DMA
+    std::mutex pin_mutex;                                 // pin / unpin come from the reader's threads
 };
 
 extern "C" int svx_inflater_create(int device, svx_inflater** out) {
@@ -83,6 +85,7 @@ extern "C" void* svx_inflater_staging(svx_inflater* f, int slot, uint64_t bytes)
 // a buffer that moved or grew is registered again.  Failure to register is not an error - the copies just take the slow path.
 extern "C" int svx_inflater_pin(svx_inflater* f, void* p, uint64_t bytes) {
     if (!f || !p || !bytes) return SVX_OK;
+    std::lock_guard<std::mutex> guard(f->pin_mutex);
     (void)hipSetDevice(f->device);
     for (size_t i = 0; i < f->pinned.size(); i++) {
         auto& pr = f->pinned[i];
@@ -103,6 +106,7 @@ extern "C" int svx_inflater_pin(svx_inflater* f, void* p, uint64_t bytes) {
 // whatever lives at that address later as page-locked memory with the OLD physical pages)
 extern "C" int svx_inflater_unpin(svx_inflater* f, void* p) {
     if (!f || !p) return SVX_OK;
+    std::lock_guard<std::mutex> guard(f->pin_mutex);
     (void)hipSetDevice(f->device);
     for (size_t i = 0; i < f->pinned.size(); i++) {
         if (f->pinned[i].first != p) continue;
