@@ -570,6 +570,10 @@ extern "C" int svx_bam_rewind(svx_bam* h) {
     if (!h) return bam_fail(SVX_E_ARG, "null reader");
     if (h->prefetch_active) { h->prefetch.wait(); h->prefetch_active = false; }
     h->prefetch_err.clear();
+    if (getenv("SVX_BAM_TIMING")) {                      // per pass: the stages of the pass that just ended
+        fprintf(stderr, "bamio pass: wait for inflate %.3f s, window copy %.3f, record walk %.3f, decode %.3f, names + SA %.3f\n", h->t_wait, h->t_copy, h->t_walk, h->t_decode, h->t_intern);
+        h->t_wait = h->t_copy = h->t_walk = h->t_decode = h->t_intern = 0;
+    }
     h->fpos = 0; h->file_eof = false; h->buf.clear(); h->pos = 0; h->next_len = 0; h->next_eof = false;
     try {
         if (!ensure(h, 12)) throw std::string("not a BAM file");
