@@ -1,6 +1,6 @@
 """GPU vs oracle on a device-generated batch (bench-like data at reduced size): full table comparison."""
 import sys, time, types
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from svim_amd import _abi, _lib, devsynth
 from oracle import oracle as om
