@@ -296,3 +296,13 @@ def test_two_ranks_indexed_bam_contig_runs(tmp_path):
     ret = dict(ret)
     assert [ret[r] for r in range(2)] == ["ok"] * 2, ret
     assert ret["regions0"] == 2 and ret["regions1"] == 2 and ret["batches0"] >= 3
+
+
+def test_eight_ranks_five_of_them_empty():
+    """The node the scaling bench runs on has eight GPUs: eight ranks over three contigs - five ranks own nothing, take part in every exchange and
+    relay the stream positions untouched - still reproduce the single-process result on rank 0."""
+    ret = _run(_worker_signatures, world=8)
+    assert [ret[r] for r in range(8)] == ["ok"] * 8, ret
+    assert sum(1 for r in range(8) if ret["owned%d" % r] > 0) == 3
+    ends = [ret["chain%d" % r] for r in range(8)]
+    assert ends == sorted(ends) and ends[-1] > 1500
