@@ -13,7 +13,7 @@ objects.  Building 7*10^5 objects costs seconds of interpreter time; the GPU nee
   * the six cluster lists are ClusterList views of the cluster table; a cluster's `members` resolve to signature objects on
     first access.
 """
-from collections.abc import Sequence
+from collections.abc import MutableSequence, Sequence
 
 from . import convert
 
@@ -78,15 +78,20 @@ class SignatureList(Sequence):
         return {TYPE_NAMES[k]: int(c[k]) for k in range(6)}
 
 
-class ClusterList(Sequence):
-    """The clusters of ONE type (one slot of cluster_sv_signatures' 6-tuple) as a view of rows [lo, hi) of the cluster table."""
+class ClusterList(MutableSequence):
+    """The clusters of ONE type (one slot of cluster_sv_signatures' 6-tuple) as a view of rows [lo, hi) of the cluster table.
+
+    The reference hands out plain lists and its COMBINE step MUTATES them (`del insertion_signature_clusters[i]`,
+    src/svim/SVIM_COMBINE.py:455-457; `translocation_signature_clusters.extend(...)`, src/svim/SVIM_merging.py:106;
+    `insertion_from_signature_clusters.extend(...)`, SVIM_COMBINE.py:392), so this is a MutableSequence: the first mutation builds
+    the objects and from then on the view behaves like the list it stands for (the table itself is never changed)."""
 
     def __init__(self, ct, lo, hi, signatures, references):
         self.ct, self.lo, self.hi, self.signatures, self.references = ct, lo, hi, signatures, references
         self._objs = None
 
     def __len__(self):
-        return self.hi - self.lo
+        return self.hi - self.lo if self._objs is None else len(self._objs)
 
     def materialise(self):
         if self._objs is None:
@@ -99,10 +104,27 @@ class ClusterList(Sequence):
     def __getitem__(self, i):
         return self.materialise()[i]
 
+    def __setitem__(self, i, value):
+        self.materialise()[i] = value
+
+    def __delitem__(self, i):
+        del self.materialise()[i]
+
+    def insert(self, i, value):
+        self.materialise().insert(i, value)
+
+    def extend(self, values):                       # (MutableSequence.extend appends one by one; `x.extend(x)` must not loop forever)
+        self.materialise().extend(list(values))
+
+    def sort(self, key=None, reverse=False):
+        self.materialise().sort(key=key, reverse=reverse)
+
     def __eq__(self, other):
         if isinstance(other, (list, tuple, ClusterList)):
             return list(self) == list(other)
         return NotImplemented
+
+    __hash__ = None
 
     def __add__(self, other):
         return list(self) + list(other)

@@ -672,6 +672,157 @@ def gen_writers():
                                          "clusters; the same writers driven by svim_amd's objects produced the same text at generation time"})
 
 
+# ------------------------------------------------------------------ COMBINE-side consumers of the cluster lists
+def cand_row(c, idx):
+    """Candidate object (src/svim/SVCandidate.py) -> plain row: every data attribute by name, members as signature indices."""
+    d = {k: v for k, v in vars(c).items() if k not in ("members", "complement")}
+    d["members"] = [idx[id(m)] for m in c.members]
+    d["class"] = type(c).__name__
+    return d
+
+
+def combine_signature_rows(seed):
+    """A signature list whose clusters drive every branch of merge_translocations_at_insertions / flag_cutpaste_candidates /
+    combine_clusters: insertions flanked by fwd-fwd + rev-rev breakends whose destinations are one insertion length apart (both
+    for an insertion on the canonically first contig and on the second one, where only the REVERSED breakend clusters match), a
+    flanked insertion with the wrong destination distance, an insertion on a contig without rev-rev breakends (the KeyError path),
+    interspersed duplications with and without a deletion of their source, insertions that coincide with an interspersed /
+    a tandem duplication, plus ordinary deletions, inversions and breakends."""
+    rng = random.Random(seed)
+    rows, rid = [], [0]
+
+    def read():
+        rid[0] += 1
+        return "q%d" % rid[0]
+
+    def j(x, k=3):
+        return x + rng.randint(-k, k)
+
+    def ins(contig, pos, length, n, reads=None):
+        base = synth.random_seq(rng, length + 8)
+        out = []
+        for k in range(n):
+            rd = reads[k] if reads else read()
+            s = j(pos)
+            ln = max(40, j(length, 2))
+            seq = "".join(ch if rng.random() > 0.03 else rng.choice("ACGT") for ch in base[:ln])
+            rows.append(["INS", contig, s, s + ln, "cigar", rd, seq])
+            out.append(rd)
+        return out
+
+    def bnd(c1, p1, d1, c2, p2, d2, n, reads=None):
+        for k in range(n):
+            rows.append(["BND", c1, j(p1), d1, c2, j(p2), d2, "suppl", reads[k] if reads else read()])
+
+    # A: chr1:30000, 300 bp inserted, copied from chr2:10000-10300
+    bnd("chr1", 30000, "fwd", "chr2", 10000, "fwd", 6)
+    bnd("chr2", 10300, "fwd", "chr1", 30000, "fwd", 6)
+    ins("chr1", 30000, 300, 8)
+    # B: chr2:40000, 200 bp inserted, copied from chr1:90000-90200 (the matching breakend clusters exist only reversed)
+    bnd("chr2", 40000, "fwd", "chr1", 90000, "fwd", 5)
+    bnd("chr1", 90200, "fwd", "chr2", 40000, "fwd", 5)
+    ins("chr2", 40000, 200, 7)
+    # C: flanked, but the destinations are 900 bp apart for a 250 bp insertion
+    bnd("chr1", 60000, "fwd", "chr2", 25000, "fwd", 5)
+    bnd("chr2", 25900, "fwd", "chr1", 60000, "fwd", 5)
+    ins("chr1", 60000, 250, 6)
+    # D: chr10 carries fwd-fwd breakends only
+    bnd("chr10", 20000, "fwd", "chr2", 50000, "fwd", 5)
+    ins("chr10", 20000, 150, 6)
+    # E: breakends too far from the insertion (> trans_sv_max_distance)
+    bnd("chr1", 120000, "fwd", "chr2", 30000, "fwd", 4)
+    bnd("chr2", 30180, "fwd", "chr1", 120000, "fwd", 4)
+    ins("chr1", 121000, 180, 6)
+    # interspersed duplications from split reads: F with its source deleted (cut & paste), G without
+    for k in range(6):
+        s = j(50000)
+        rows.append(["DUP_INT", "chr1", s, s + j(500, 2), "suppl", read(), "chr2", j(20000)])
+    for k in range(6):
+        s = j(50000)
+        rows.append(["DEL", "chr1", s, s + j(500, 2), "cigar", read()])
+    for k in range(5):
+        s = j(140000)
+        rows.append(["DUP_INT", "chr1", s, s + j(700, 2), "suppl", read(), "chr10", j(30000)])
+    # an insertion where duplication F was pasted (same length): removed from the insertion list
+    ins("chr2", 20000, 500, 6)
+    # a tandem duplication and an insertion that is really that duplication
+    for k in range(6):
+        s = j(100000)
+        rows.append(["DUP_TAN", "chr1", s, s + j(400, 2), "suppl", read(), 1, rng.random() < 0.5])
+    ins("chr1", 100400, 400, 5)
+    # ordinary calls
+    for k in range(7):
+        s = j(15000)
+        rows.append(["DEL", "chr2", s, s + j(800, 3), rng.choice(("cigar", "suppl")), read()])
+    for k in range(6):
+        s = j(150000)
+        rows.append(["INV", "chr1", s, s + j(2000, 3), "suppl", read(), ("left_fwd", "right_fwd", "left_rev", "right_rev")[k % 4]])
+    ins("chr10", 45000, 90, 9)
+    bnd("chr1", 170000, "fwd", "chr10", 55000, "rev", 5)
+    bnd("chr2", 5000, "rev", "chr10", 5000, "fwd", 3)
+    rng.shuffle(rows)
+    return rows
+
+
+def gen_combine():
+    """The reference's COMBINE-side consumers of the six cluster lists - merge_translocations_at_insertions and
+    flag_cutpaste_candidates (src/svim/SVIM_merging.py:93-159, :12-29) and the whole combine_clusters (src/svim/SVIM_COMBINE.py:332-478,
+    --skip_consensus: no spoa) - on the reference's own clusters; and, as a check at generation time, THE SAME reference functions
+    driven by svim_amd's lazy ClusterLists (CPU path: oracle tables), which must give the same candidates although the functions
+    delete from / extend the lists they are handed."""
+    for name in ("spoa", "cpuinfo"):
+        stub = types.ModuleType(name)
+        stub.poa = stub.get_cpu_info = None                     # never called with skip_consensus
+        sys.modules.setdefault(name, stub)
+    from svim import SVIM_COMBINE, SVIM_merging
+    from svim_amd import _abi, batch as sbatch, convert
+    from oracle import oracle as om
+    import helpers as H
+    references = ["chr1", "chr2", "chr10"]
+    rows = combine_signature_rows(4711)
+    o = options(trans_sv_max_distance=500, del_ins_dup_max_distance=1.0, skip_consensus=True)
+    sigs = [row_sig(r) for r in rows]
+    idx = {id(s): i for i, s in enumerate(sigs)}
+    res = SVIM_CLUSTER.cluster_sv_signatures(sigs, o)
+    clusters = cluster_rows(res, sigs)
+
+    def run(c6, idx):
+        dele, insr, inv, tan, dint, bnd = [list(x) if isinstance(x, list) else x for x in c6]
+        if isinstance(bnd, list):
+            b2, i2 = list(bnd), list(insr)
+        else:
+            import copy
+            b2, i2 = copy.copy(bnd), copy.copy(insr)
+        new_from, to_remove = SVIM_merging.merge_translocations_at_insertions(b2, i2, o)
+        merged = [[c.source_contig, c.source_start, c.source_end, c.dest_contig, c.dest_start, c.dest_end, c.score, c.size,
+                   [idx[id(m)] for m in c.members], c.type, c.std_span, c.std_pos] for c in new_from]
+        flagged = [cand_row(c, idx) for c in SVIM_merging.flag_cutpaste_candidates(list(dint) + new_from, dele, o)]
+        n_ins_before = len(insr)
+        out = SVIM_COMBINE.combine_clusters((dele, insr, inv, tan, dint, bnd), o)
+        return {"merged_insertion_from_clusters": merged, "inserted_regions_to_remove": to_remove, "n_bnd_after_merge": len(b2),
+                "flag_cutpaste": flagged, "n_ins_before": n_ins_before, "n_ins_after": len(insr), "n_dup_int_after": len(dint),
+                "combine": [[cand_row(c, idx) for c in lst] for lst in out]}
+    exp = run(res, idx)
+    assert len(exp["merged_insertion_from_clusters"]) >= 2 and exp["inserted_regions_to_remove"], exp["merged_insertion_from_clusters"]
+    assert {r["cutpaste"] for r in exp["flag_cutpaste"]} == {True, False}
+    assert exp["n_ins_before"] - exp["n_ins_after"] > len(exp["inserted_regions_to_remove"])          # the overlap rules removed some too
+    # the same reference code on OUR lists
+    ours_sigs = [H.row_sig(r) for r in rows]
+    oidx = {id(s): i for i, s in enumerate(ours_sigs)}
+    tab, contigs, reads = convert.sigtable_from_objects(ours_sigs, convert.Interner(references))
+    orc = om.Oracle()
+    off, codes = convert.genome_arrays(os.path.join(HERE, "ref.fa.gz"), contigs.names)
+    orc.set_genome(off, codes)
+    ct = orc.cluster(_abi.Params.from_options(o), sbatch.contig_ranks(contigs.names), table=tab)
+    got = run(convert.cluster_objects(ct, ours_sigs, contigs.names), oidx)
+    diff = H.first_json_difference(got, exp)
+    assert diff is None, diff
+    dump("g_combine.json.gz", {"references": references, "signatures": rows, "options": opt_dict(o), "clusters": clusters, "expected": exp,
+                               "source": "svim.SVIM_merging.merge_translocations_at_insertions / flag_cutpaste_candidates (src/svim/SVIM_merging.py:93-159, "
+                                         ":12-29) and svim.SVIM_COMBINE.combine_clusters (src/svim/SVIM_COMBINE.py:332-478, skip_consensus) on the "
+                                         "reference's clusters; the same functions driven by svim_amd's ClusterLists gave the same rows at generation time"})
+
+
 def main():
     contigs = [("chr1", 180000), ("chr2", 60000), ("chr10", 60000)]   # tid order != Python string order
     refs = synth.make_reference(1, contigs)
@@ -692,6 +843,7 @@ def main():
     gen_c1()
     gen_genotype()
     gen_writers()
+    gen_combine()
 
 
 if __name__ == "__main__":
@@ -699,5 +851,7 @@ if __name__ == "__main__":
         gen_genotype()                 # this fixture only (the others are untouched)
     elif len(sys.argv) > 1 and sys.argv[1] == "writers":
         gen_writers()
+    elif len(sys.argv) > 1 and sys.argv[1] == "combine":
+        gen_combine()
     else:
         main()

@@ -191,3 +191,28 @@ def long_cigar_records():
     short.query_name, short.flag, short.reference_id, short.reference_start, short.mapping_quality = "short", 0, 0, 500, 60
     short.cigartuples, short.query_sequence = [(0, 50)], synth.random_seq(rng, 50)
     return short, a, cig
+
+
+def first_json_difference(got, exp, rtol=1e-9, path="$"):
+    """Two JSON-like trees: equal except that floats may differ by rtol.  None when equal, else a description of the first difference."""
+    if isinstance(exp, float) or isinstance(got, float):
+        if got is None or exp is None or isinstance(got, (str, bool)) or isinstance(exp, (str, bool)):
+            return None if got == exp else "%s: %r != %r" % (path, got, exp)
+        return None if close(got, exp, rtol) else "%s: %r != %r" % (path, got, exp)
+    if isinstance(exp, dict):
+        if not isinstance(got, dict) or sorted(got) != sorted(exp):
+            return "%s: keys %r != %r" % (path, sorted(got) if isinstance(got, dict) else got, sorted(exp))
+        for k in exp:
+            d = first_json_difference(got[k], exp[k], rtol, "%s.%s" % (path, k))
+            if d:
+                return d
+        return None
+    if isinstance(exp, (list, tuple)):
+        if not isinstance(got, (list, tuple)) or len(got) != len(exp):
+            return "%s: %r != %r" % (path, got if not isinstance(got, (list, tuple)) else len(got), len(exp))
+        for i, (a, b) in enumerate(zip(got, exp)):
+            d = first_json_difference(a, b, rtol, "%s[%d]" % (path, i))
+            if d:
+                return d
+        return None
+    return None if got == exp else "%s: %r != %r" % (path, got, exp)

@@ -861,3 +861,70 @@ def test_reader_with_gpu_inflate_delivers_the_same_batches(tmp_path, monkeypatch
             assert a.keys() == b.keys()
             for k in a:
                 assert np.array_equal(a[k], b[k]), k
+
+
+def test_combine_consumers_on_gpu_cluster_lists(eng):
+    """SURVEY 8f row 4 on the GPU: cluster_sv_signatures (drop-in name -> svx_cluster) hands out lazy ClusterLists; the COMBINE-side consumers
+    (src/svim/SVIM_merging.py:12-29,93-159, SVIM_COMBINE.py:332-478 - replayed by tests/combine_consumer.py) delete from / extend them and must
+    arrive at the candidates the reference's own functions computed (tests/golden/g_combine.json.gz)."""
+    import combine_consumer as cc
+    import svim_amd
+    from svim_amd.lazy import ClusterList
+    g = H.load("g_combine.json.gz")
+    o = H.options(g["options"])
+    sigs = [H.row_sig(r) for r in g["signatures"]]
+    clusters = svim_amd.cluster_sv_signatures(sigs, o)
+    assert all(isinstance(c, ClusterList) and c._objs is None for c in clusters)
+    idx = {id(s): i for i, s in enumerate(sigs)}
+    got_rows = []
+    for k, lst in enumerate(clusters):
+        rows = []
+        for c in lst:
+            mem = [idx[id(m)] for m in c.members]
+            if k < 3:
+                rows.append([c.contig, c.start, c.end, c.score, c.size, c.std_span, c.std_pos, mem])
+            else:
+                rows.append([c.source_contig, c.source_start, c.source_end, c.dest_contig, c.dest_start, c.dest_end, c.score, c.size, c.std_span, c.std_pos, mem]
+                            + ([c.direction1, c.direction2] if c.type == "BND" else []))
+        got_rows.append(rows)
+    H.compare_cluster_rows(got_rows, g["clusters"])
+    got = cc.consume(clusters, o, idx)
+    diff = H.first_json_difference(got, g["expected"])
+    assert diff is None, diff
+    assert len(clusters[1]) == g["expected"]["n_ins_after"] and len(clusters[5]) == g["expected"]["n_bnd_after_merge"]
+
+
+def test_writers_on_gpu_fetched_clusters(eng, tmp_path):
+    """write_signature_clusters_bed / _vcf (src/svim/SVIM_CLUSTER.py:29-106) on clusters FETCHED FROM THE GPU (the drop-in cluster_sv_signatures) ==
+    the files the reference's writers produced for the reference's clusters (tests/golden/g_writers.json.gz); FP columns within 1e-9."""
+    import os
+    import svim_amd
+    from svim_amd import SVIM_CLUSTER
+    gold = H.load("g_writers.json.gz")
+    g5 = H.load("g5_cluster.json.gz")
+    case = [c for c in g5["cases"] if c["name"] == "stress31"][0]
+    sigs = [H.row_sig(r) for r in case["signatures"]]
+    clusters = svim_amd.cluster_sv_signatures(sigs, H.options(case["options"]))
+    SVIM_CLUSTER.write_signature_clusters_bed(str(tmp_path), clusters)
+    SVIM_CLUSTER.write_signature_clusters_vcf(str(tmp_path), clusters, gold["version"])
+    for name, exp in gold["files"].items():
+        with open(os.path.join(str(tmp_path), name)) as fh:
+            got = fh.read()
+        assert H.text_close(got, exp) is None, (name, H.text_close(got, exp))
+    # and after a COLLECT -> CLUSTER that stayed resident (lazy SignatureList in, lazy ClusterLists out): the writers read members lazily
+    g = H.load("g2_collect.json.gz")
+    ccase = [c for c in g["cases"] if c["name"] == "fuzzA" and c["mode"] == "coordinate" and not c["options"]["all_bnds"]][0]
+    o = H.options(ccase["options"])
+    lazy_sigs, _ = svim_amd.analyze_alignment_file_coordsorted(records.AlignmentFile(text=ccase["sam"]), o)
+    res = svim_amd.cluster_sv_signatures(lazy_sigs, o)
+    d2 = tmp_path / "resident"
+    d2.mkdir()
+    SVIM_CLUSTER.write_signature_clusters_bed(str(d2), res)
+    SVIM_CLUSTER.write_signature_clusters_vcf(str(d2), res, gold["version"])
+    listed = sorted(os.path.relpath(os.path.join(r, f), str(d2)) for r, _, fs in os.walk(str(d2)) for f in fs)
+    assert listed == sorted(gold["files"])
+    n_lines = 0
+    for name in listed:
+        with open(os.path.join(str(d2), name)) as fh:
+            n_lines += sum(1 for line in fh if not line.startswith("#"))
+    assert n_lines >= sum(len(x) for x in res)

@@ -442,3 +442,63 @@ def test_native_bam_reader_rewind_repeats_the_file(tmp_path):
         for x, y in zip(passes[0], other):
             for k in x:
                 assert np.array_equal(x[k], y[k]), k
+
+
+def _combine_case(engine_like):
+    """g_combine's signatures -> (golden, options, our signature objects, the lazy 6-tuple) through `engine_like`.cluster"""
+    g = H.load("g_combine.json.gz")
+    o = H.options(g["options"])
+    sigs = [H.row_sig(r) for r in g["signatures"]]
+    tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(g["references"]))
+    off, codes = convert.genome_arrays(o.genome, contigs.names)
+    engine_like.set_genome(off, codes)
+    ct = engine_like.cluster(_abi.Params.from_options(o), batch.contig_ranks(contigs.names), table=tab)
+    return g, o, sigs, ct, contigs
+
+
+def test_combine_consumers_on_lazy_cluster_lists(oracle, monkeypatch):
+    """the COMBINE-side consumers (merge_translocations_at_insertions, flag_cutpaste_candidates, combine_clusters -
+    src/svim/SVIM_merging.py:12-29,93-159, SVIM_COMBINE.py:332-478) on our lazy ClusterLists: expected rows from the reference's own functions
+    (tests/golden/g_combine.json.gz); the consumer here replays their list / attribute protocol, including `del`, `extend` and `+`."""
+    import combine_consumer as cc
+    from svim_amd import _lib
+    from svim_amd.lazy import ClusterList
+
+    class LinkageOnly(object):                     # partition_and_cluster_candidates asks the process-wide engine for the linkage batch
+        def linkage_fcluster(self, problems, cutoff):
+            return [np.asarray(oracle.linkage_fcluster(n, np.asarray(d, dtype=np.float64), cutoff)) for n, d in problems]
+    monkeypatch.setattr(_lib, "engine", lambda device=None: LinkageOnly())
+    g, o, sigs, ct, contigs = _combine_case(oracle)
+    H.compare_cluster_rows(H.cluster_rows(ct, contigs.names), g["clusters"])
+    clusters = convert.cluster_objects(ct, sigs, contigs.names)
+    assert all(isinstance(c, ClusterList) and c._objs is None for c in clusters)
+    got = cc.consume(clusters, o, {id(s): i for i, s in enumerate(sigs)})
+    diff = H.first_json_difference(got, g["expected"])
+    assert diff is None, diff
+    # the lists were mutated in place like the plain lists they stand for
+    assert len(clusters[1]) == g["expected"]["n_ins_after"] and len(clusters[4]) == g["expected"]["n_dup_int_after"]
+    assert len(clusters[5]) == g["expected"]["n_bnd_after_merge"]
+
+
+def test_cluster_list_is_a_mutable_sequence(oracle):
+    from svim_amd.lazy import ClusterList
+    g, o, sigs, ct, contigs = _combine_case(oracle)
+    dele, insr, inv, tan, dint, bnd = convert.cluster_objects(ct, sigs, contigs.names)
+    n = len(insr)
+    first, last = insr[0], insr[-1]
+    del insr[0]
+    assert len(insr) == n - 1 and insr[0] is not first and insr[-1] is last
+    insr.extend(insr)                                                      # must terminate
+    assert len(insr) == 2 * (n - 1)
+    bnd.append(first)
+    assert bnd[-1] is first and first in bnd
+    joined = dele + inv
+    assert isinstance(joined, list) and len(joined) == len(dele) + len(inv)
+    dint.insert(0, last)
+    assert dint[0] is last
+    tan[0] = first
+    assert tan[0] is first
+    assert sorted(dele, key=lambda c: c.get_key()) == list(dele)
+    with pytest.raises(TypeError):
+        hash(dele)
+    assert isinstance(reversed(dele).__next__(), type(dele[0]))
