@@ -120,8 +120,10 @@ def _lognormal_lengths(gen, n, n50, device, lo=500, hi=200000):
 
 def make_batch(n_reads=10000, n50=20000, contig_len=250_000_000, n_sites=None, seed=2, device="cuda",
                frac_del=0.45, frac_ins=0.45, size_lo=50, size_hi=5000, inv_read_frac=0.12, ins_err=0.03,
-               max_sites_per_read=6):
-    """Returns (DeviceBatch, genome_codes uint8 tensor [contig_len], info dict)."""
+               max_sites_per_read=6, lengths=None):
+    """Returns (DeviceBatch, genome_codes uint8 tensor [contig_len], info dict).
+    lengths: None = log-normal with N50 `n50`; ("triangular", lo, hi, mode) = the read-length law of the reference's own test generator
+    (src/tests/test_Collect.py:71)."""
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
@@ -141,7 +143,14 @@ def make_batch(n_reads=10000, n50=20000, contig_len=250_000_000, n_sites=None, s
     site_seq = (1 << torch.randint(0, 4, (S, max_ins), generator=gen, device=dev, dtype=i64)).to(torch.uint8)
     inv_sites = torch.nonzero(site_type == 2).flatten()
     # ---- reads -----------------------------------------------------------------------------------------
-    L = _lognormal_lengths(gen, R, n50, dev)                       # aligned query length of the primary (before clips)
+    if lengths is not None and lengths[0] == "triangular":
+        _, t_lo, t_hi, t_mode = lengths
+        uu = torch.rand(R, generator=gen, device=dev, dtype=torch.float64)
+        fc = (t_mode - t_lo) / (t_hi - t_lo)
+        L = torch.where(uu < fc, t_lo + torch.sqrt(uu * (t_hi - t_lo) * (t_mode - t_lo)),
+                        t_hi - torch.sqrt((1 - uu) * (t_hi - t_lo) * (t_hi - t_mode))).to(torch.int64).clamp_min(40)
+    else:
+        L = _lognormal_lengths(gen, R, n50, dev)                   # aligned query length of the primary (before clips)
     start = torch.randint(1000, contig_len - 210000, (R,), generator=gen, device=dev, dtype=i64)
     is_inv = (torch.rand(R, generator=gen, device=dev) < inv_read_frac) & (inv_sites.numel() > 0)
     inv_pick = inv_sites[torch.randint(0, max(1, inv_sites.numel()), (R,), generator=gen, device=dev)] if inv_sites.numel() else torch.zeros(R, dtype=i64, device=dev)

@@ -533,6 +533,71 @@ def gen_c1():
                           "source": "svim.SVIM_COLLECT.analyze_alignment_file_coordsorted + svim.SVIM_CLUSTER.cluster_sv_signatures"})
 
 
+def records_from_hostbatch(hb, name_fmt="r%08d"):
+    """HostBatch (numpy SoA) -> record objects with pysam's attribute names (primaries without SA tags: what C1 holds)"""
+    A = hb.arrays
+    lut = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+    out = []
+    co, so = A["cigar_off"].astype(np.int64), A["seq_off"].astype(np.int64)
+    for i in range(hb.n_rec):
+        a = records.AlignedSegment()
+        a.query_name = name_fmt % int(A["read_id"][i])
+        a.flag = int(A["flag"][i]) & 0x0fff
+        a.reference_id, a.reference_start, a.mapping_quality = int(A["tid"][i]), int(A["pos"][i]), int(A["mapq"][i])
+        w = A["cigar"][co[i]:co[i + 1]].astype(np.int64)
+        a.cigartuples = list(zip((w & 15).tolist(), (w >> 4).tolist()))
+        sb = A["seq"][so[i]:so[i + 1]]
+        nib = np.empty(2 * sb.shape[0], dtype=np.uint8)
+        nib[0::2], nib[1::2] = sb >> 4, sb & 15
+        a.query_sequence = lut[nib[:int(A["lseq"][i])]].tobytes().decode("ascii")
+        out.append(a)
+    return out
+
+
+def gen_c1_full():
+    """BASELINE.json configs[0] AT ITS STATED SIZE: 250 Mb contig, 10 000 reads of length
+    ~ triangular(100, 20000, 15000), ~1.2*10^7 CIGAR operations, 300 planted DEL/INS sites - through the reference's CPU path, timed.  The
+    input is regenerated from its seed by the tests (tests/helpers.py:c1_full_case); only the reference's outputs are stored."""
+    import time
+    import helpers as H
+
+    class BamStub(object):                                 # the duck type analyze_alignment_file_coordsorted needs (src/svim/SVIM_COLLECT.py:132-167)
+        def __init__(self, recs):
+            self.recs, self.references = recs, ["chr1"]
+
+        def fetch(self, until_eof=True):
+            return iter(self.recs)
+
+        def getrname(self, tid):
+            return self.references[tid]
+
+        get_reference_name = getrname
+
+        def get_tid(self, name):
+            return self.references.index(name)
+    hb, genome, meta = H.c1_full_case()
+    recs = records_from_hostbatch(hb)
+    fa = os.path.join(HERE, "_c1_full.fa")
+    H.write_fasta_from_codes(fa, "chr1", genome)
+    o = options(genome=fa)
+    t0 = time.perf_counter()
+    sigs, bnds = SVIM_COLLECT.analyze_alignment_file_coordsorted(BamStub(recs), o)
+    t1 = time.perf_counter()
+    res = SVIM_CLUSTER.cluster_sv_signatures(sigs, o)
+    t2 = time.perf_counter()
+    os.remove(fa)
+    print("C1 full: %d records, %d ops, %d signatures, %d clusters, collect %.2fs cluster %.2fs" % (len(recs), meta["n_ops"], len(sigs), sum(len(x) for x in res), t1 - t0, t2 - t1))
+    dump("g_c1_full.json.gz", {"note": "BASELINE.json configs[0] at the size SURVEY.md section 8(d) C1 states (250 Mb contig, reads ~ triangular(100, 20000, 15000), "
+                                       "300 planted DEL/INS sites of 50-5000 bp)",
+                               "generator": "tests/helpers.py:c1_full_case = svim_amd.devsynth.make_batch(device='cpu', **%r)" % (H.C1_FULL,),
+                               "n_records": len(recs), "n_ops": int(meta["n_ops"]), "options": opt_dict(options()),
+                               "signatures": [sig_row(s) for s in sigs], "n_bnds": len(bnds), "clusters": cluster_rows(res, sigs),
+                               "reference_seconds": {"collect": t1 - t0, "cluster": t2 - t1, "records_per_s": len(recs) / (t2 - t0),
+                                                     "note": "the reference's Python functions in the build container, 1 core, pysam/edlib stubbed (edlib = pure-Python "
+                                                             "bit-vector Levenshtein: cluster time is an upper bound)"},
+                               "source": "svim.SVIM_COLLECT.analyze_alignment_file_coordsorted + svim.SVIM_CLUSTER.cluster_sv_signatures"})
+
+
 def gen_entrypoints(collect_cases):
     """Per-read entry points (analyze_alignment_indel, analyze_read_segments) and the COMBINE-side re-clustering
     (partition_and_cluster_candidates) as the reference computes them."""
@@ -841,6 +906,7 @@ def main():
     gen_rng()
     gen_edit()
     gen_c1()
+    gen_c1_full()
     gen_genotype()
     gen_writers()
     gen_combine()
@@ -851,6 +917,8 @@ if __name__ == "__main__":
         gen_genotype()                 # this fixture only (the others are untouched)
     elif len(sys.argv) > 1 and sys.argv[1] == "writers":
         gen_writers()
+    elif len(sys.argv) > 1 and sys.argv[1] == "c1_full":
+        gen_c1_full()
     elif len(sys.argv) > 1 and sys.argv[1] == "combine":
         gen_combine()
     else:

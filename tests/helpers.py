@@ -138,6 +138,36 @@ def c1_case():
     return _C1["g"], _C1["refs"], _C1["recs"]
 
 
+C1_FULL = dict(n_reads=10000, contig_len=250_000_000, n_sites=300, seed=1, frac_del=0.5, frac_ins=0.5, inv_read_frac=0.0,
+               lengths=("triangular", 100, 20000, 15000))
+
+
+def c1_full_case():
+    """BASELINE.json configs[0] at the size SURVEY.md section 8(d) C1 states: 10 000 primaries of length ~ triangular(100, 20000, 15000) on one
+    250 Mb contig, CIGAR = M-runs U[5,30] alternating with 1-3 bp I/D, 300 planted DEL / INS sites (log-uniform 50-5000 bp) - generated with the
+    vectorised generator on the CPU (seeded torch CPU stream: the same arrays here and on the GPU box).
+    -> (HostBatch, genome codes numpy uint8 [250 Mb], meta)"""
+    from svim_amd import devsynth
+    b, genome, meta = devsynth.make_batch(device="cpu", **C1_FULL)
+    b.references = ["chr1"]
+    return b.slice_records(0, b.n_rec), genome.numpy(), meta
+
+
+def write_fasta_from_codes(path, name, codes, width=100):
+    """one contig of 4-bit codes (1 2 4 8 15 = A C G T N) -> FASTA"""
+    lut = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+    n = codes.shape[0]
+    rows = n // width
+    with open(path, "wb") as fh:
+        fh.write((">%s\n" % name).encode())
+        body = np.empty((rows, width + 1), dtype=np.uint8)
+        body[:, :width] = lut[codes[:rows * width]].reshape(rows, width)
+        body[:, width] = 10
+        fh.write(body.tobytes())
+        if n > rows * width:
+            fh.write(lut[codes[rows * width:]].tobytes() + b"\n")
+
+
 def text_close(got, exp, rtol=1e-9):
     """Two writer outputs token by token: identical except that tokens which parse as floats may differ by rtol (the FP columns:
     score, std_span, std_pos).  Returns None when equal, else a description of the first difference."""

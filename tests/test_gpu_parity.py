@@ -928,3 +928,26 @@ def test_writers_on_gpu_fetched_clusters(eng, tmp_path):
         with open(os.path.join(str(d2), name)) as fh:
             n_lines += sum(1 for line in fh if not line.startswith("#"))
     assert n_lines >= sum(len(x) for x in res)
+
+
+def test_c1_config0_full_size_through_bam_file(eng, tmp_path):
+    """BASELINE.json configs[0] AT ITS STATED SIZE (250 Mb contig, 10 000 reads ~ triangular(100, 20000, 15000), 1.2*10^7 CIGAR
+    operations) end to end through the drop-in entry points: BAM file + FASTA on disk -> native reader (GPU inflate) -> analyze_alignment_file_coordsorted
+    -> cluster_sv_signatures == what the reference's CPU path returned (tests/golden/g_c1_full.json.gz)."""
+    import svim_amd
+    from svim_amd import harness
+    g = H.load("g_c1_full.json.gz")
+    hb, genome, meta = H.c1_full_case()
+    assert hb.n_rec == g["n_records"] and int(meta["n_ops"]) == g["n_ops"]
+    path, fa = str(tmp_path / "c1_full.bam"), str(tmp_path / "c1_full.fa")
+    harness.write_bam_from_batch(path, hb, ["chr1"], [int(genome.shape[0])])
+    H.write_fasta_from_codes(fa, "chr1", genome)
+    o = H.options(g["options"])
+    o.genome = fa
+    sigs, bnds = svim_amd.analyze_alignment_file_coordsorted(path, o)
+    assert [H.sig_row(s) for s in sigs] == g["signatures"] and len(bnds) == g["n_bnds"]
+    res = svim_amd.cluster_sv_signatures(sigs, o)
+    idx = {id(s): i for i, s in enumerate(sigs)}
+    got = [[[c.contig, c.start, c.end, c.score, c.size, c.std_span, c.std_pos, [idx[id(m)] for m in c.members]] for c in lst] if k < 3 else [] for k, lst in enumerate(res)]
+    assert all(len(lst) == 0 for lst in res[3:])
+    H.compare_cluster_rows(got, g["clusters"])

@@ -124,3 +124,18 @@ def test_c1_config0_end_to_end(oracle):
     oracle.set_genome(off, codes)
     ct = oracle.cluster(p, hb.contig_rank, source=0)
     H.compare_cluster_rows(H.cluster_rows(ct, ["chr1"]), g["clusters"])
+
+
+def test_c1_config0_full_size_end_to_end(oracle):
+    """BASELINE.json configs[0] at the size SURVEY.md section 8(d) C1 states (250 Mb contig, reads ~ triangular(100, 20000, 15000), 1.2*10^7 CIGAR
+    operations): the oracle reproduces what the reference's CPU path returned (tests/golden/g_c1_full.json.gz)."""
+    g = H.load("g_c1_full.json.gz")
+    hb, genome, meta = H.c1_full_case()
+    assert hb.n_rec == g["n_records"] and int(meta["n_ops"]) == g["n_ops"]
+    names = ["r%08d" % i for i in range(int(hb.arrays["read_id"].max()) + 1)]
+    p = _abi.Params.from_options(H.options(g["options"]))
+    sig, bnd = oracle.collect(hb, p)
+    assert H.table_rows(sig, ["chr1"], names) == g["signatures"] and bnd.n == g["n_bnds"]
+    oracle.set_genome(np.array([0, genome.shape[0]], dtype=np.int64), genome)
+    ct = oracle.cluster(p, hb.contig_rank, source=0)
+    H.compare_cluster_rows(H.cluster_rows(ct, ["chr1"]), g["clusters"])
