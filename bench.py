@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--sites", type=int, default=None)
     ap.add_argument("--bam", default=None, help="coordinate-sorted BAM instead of a synthetic workload (needs --fasta)")
     ap.add_argument("--fasta", default=None)
+    ap.add_argument("--foreign-frac", type=float, default=0.0, help="--gpus N, c2 / c4: this fraction of the cross-contig split-read segments points at a contig of "
+                    "ANOTHER rank, so that BND signatures owned by other ranks (foreign rows) cross the fabric in the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--end-to-end-child", action="store_true", help=argparse.SUPPRESS)
@@ -136,6 +138,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if os.environ.get("SVX_BENCH_ONE_GPU") == "1":        # tests: every rank on cuda:0 (with SVX_BENCH_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if args.end_to_end_child:
@@ -151,7 +155,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # SVX_BENCH_BACKEND=gloo: several ranks on ONE GPU (tests; RCCL refuses two ranks on the same device)
+        dist.init_process_group(os.environ.get("SVX_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from svim_amd import _abi, _lib, devsynth
     opts = options(args.partition_max_distance)
@@ -201,6 +206,19 @@ def main():
         owner = np.repeat(np.arange(world, dtype=np.int32), n_local)
         base = rank * n_local
         batch.t["tid"] = batch.t["tid"] + base
+        n_foreign_planted = 0
+        if args.foreign_frac > 0 and world > 1 and batch.n_seg:
+            # a cross-contig segment row (the partner of a BND) moves to the same-named contig of another rank: the signature then belongs to
+            # whichever rank owns its canonical first end (src/svim/SVSignature.py:194) - a foreign row for one of the two
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(77 + rank)
+            counts = (batch.t["seg_off"][1:] - batch.t["seg_off"][:-1]).to(torch.int64)
+            prim_tid = torch.repeat_interleave(batch.t["tid"].to(torch.int64), counts)
+            st_local = batch.t["seg_tid"][:batch.n_seg].to(torch.int64)
+            cross = (st_local != prim_tid) & (torch.rand(batch.n_seg, generator=gen, device=dev) < args.foreign_frac)
+            other = (rank + 1 + torch.randint(0, world - 1, (batch.n_seg,), generator=gen, device=dev)) % world
+            batch.t["seg_tid"][:batch.n_seg] = torch.where(cross, other * n_local + st_local - base, st_local - base).to(batch.t["seg_tid"].dtype)
+            n_foreign_planted = int(cross.sum().item())
         batch.t["seg_tid"] = batch.t["seg_tid"] + base
         batch.t["contig_rank"] = torch.as_tensor(crank_global, device=dev)
         batch.n_contig = n_global
@@ -218,10 +236,13 @@ def main():
         eng.set_genome(g_off, genome, on_device=True)
     bstruct = batch.struct()
 
+    last = {}
+
     def step():
         eng.collect(bstruct, p, fetch=False)
         if use_dist:
-            return MG.cluster_step(adapter, p, rank, world, gid, crank_global, owner, key_base=key_base, read_base=read_base)
+            last["res"] = MG.cluster_step(adapter, p, rank, world, gid, crank_global, owner, key_base=key_base, read_base=read_base)
+            return
         eng.cluster(p, rank_arr, source=0, fetch=False)
 
     def barrier():
@@ -324,9 +345,10 @@ def main():
         "edit_guess": st.get("edit_guess"),
     }
     cfg = {"workload": label, "records_per_gpu": meta["n_records"], "cigar_ops_per_gpu": meta["n_ops"], "planted_sites": meta["n_sites"],
-           "parallelism": "1 process/GPU; contigs sharded over ranks, every partition local; per step over xGMI: foreign signatures (none "
-                          "here), 48 B of random.sample stream positions rank to rank, final gather of clusters + members + fixed-width "
-                          "signature columns to rank 0 (svim_amd/multigpu.py)",
+           "parallelism": "1 process/GPU; contigs sharded over ranks, every partition local; per step over xGMI: foreign signatures (%s), "
+                          "the random.sample stream positions by all-gathers only (sizes of the large partitions + per-rank transfer tables, no "
+                          "rank waits for another rank's sampling), final gather of clusters + members + fixed-width signature columns to rank 0 "
+                          "(svim_amd/multigpu.py)" % ("--foreign-frac %g" % args.foreign_frac if use_dist and args.foreign_frac > 0 else "none here"),
            "options": "SVIM alignment-mode defaults" + ("" if args.partition_max_distance == 1000 else ", partition_max_distance %d" % args.partition_max_distance)}
     if "reads_by_layout" in meta:
         cfg["reads_by_layout"] = meta["reads_by_layout"]
@@ -344,6 +366,11 @@ def main():
                    "large_partitions": st["n_large_partitions"], "clusters": st["n_clusters"], "ins_bases": n_ins},
         "roofline": roofline, "roofline_edit": roofline_edit, "kernels": kernels, "synth_seconds": t_gen,
     }
+    if use_dist:
+        res = last.get("res")
+        out["multi_gpu"] = {"foreign_segments_planted_rank0": n_foreign_planted, "signatures_per_rank": list(res.sig_counts) if res is not None else None,
+                            "clusters_gathered": res.n if res is not None else None, "stream_end_rank0": res.chain_end if res is not None else None,
+                            "rank_exchange_allgathers_last_step": getattr(getattr(adapter, "transport", None), "calls", 0)}
     if world == 1 and not use_dist:
         fetch = getattr(eng, "fetch_clusters", None)
         if fetch is not None:

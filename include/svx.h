@@ -191,26 +191,24 @@ int  svx_cluster(svx_ctx* ctx, int source, const svx_sig_view* sigs, int32_t n_c
 int  svx_cluster_count(svx_ctx* ctx, int64_t* n_clusters, int64_t* n_members);
 int  svx_cluster_fetch(svx_ctx* ctx, svx_cluster_view* out);  /* destination arrays: host or device memory */
 
-/* multi-GPU: cluster only partitions with (global partition index % world) == rank; the caller gathers
- * the per-rank cluster tables (RCCL) and merges them by partition index (returned in part_index) */
-int  svx_cluster_set_shard(svx_ctx* ctx, int rank, int world);
-int  svx_cluster_fetch_part_index(svx_ctx* ctx, int64_t* out /* [n_clusters], host or device memory */);
-/* alternative ownership for contig-sharded input: the table passed to svx_cluster is the rank-major concatenation of the
- * per-rank tables, origin_prefix[r] = first global index of rank r; a partition belongs to the rank that produced its first
- * sorted member, so its inserted sequences are already local (only that rank's seq ranges need to be non-empty).
- * svx_cluster_remote_members reports how many members of this rank's insertion partitions came from another rank
- * (non-zero: the caller must supply all sequences and use svx_cluster_set_shard instead). */
-int  svx_cluster_set_shard_by_origin(svx_ctx* ctx, int rank, int world, const int64_t* origin_prefix_host /* [world+1] */);
-/* multi-GPU, contig-sharded ranks (each rank clusters ONLY the signatures of the contigs it owns - every partition is local): what
- * still couples the ranks is the random.sample word stream, which a signature type's > 100-member partitions consume in global
- * sorted order without re-seeding (src/svim/SVIM_clustering.py:129-134).  When ranks own consecutive ranges of the name-sorted
- * contig list that order is rank-major: rank r continues each type's stream where rank r-1 stopped.  svx_cluster calls
- * fn(user, 0, words) before sampling to OBTAIN the 6 start positions (32-bit words already consumed, SVX_* type order; rank 0
- * fills zeros) and fn(user, 1, words) after it to HAND ON the 6 end positions.  fn == NULL (default): streams start at 0.
- * 48 bytes per rank and step cross the fabric for this. */
-typedef int (*svx_chain_fn)(void* user, int phase, int64_t* words /* [SVX_NTYPES] */);
-int  svx_cluster_set_chain(svx_ctx* ctx, svx_chain_fn fn, void* user);
-int  svx_cluster_remote_members(svx_ctx* ctx, int64_t* out);
+/* multi-GPU, contig-sharded ranks: each rank clusters ONLY the signatures of the contigs it owns - every partition of
+ * src/svim/SVIM_clustering.py:17-29 is local to one rank.  What still couples the ranks is the random.sample word stream, which a signature type's
+ * > 100-member partitions consume in global sorted order without re-seeding (src/svim/SVIM_clustering.py:129-134).  When ranks own consecutive ranges
+ * of the name-sorted contig list that order is rank-major: rank r continues each type's stream where the partitions of ranks 0..r-1 stop.
+ * svx_cluster finds those positions itself, with ALL-GATHERS ONLY (no rank waits for another rank's sampling): (1) the sizes of everybody's large
+ * partitions (4 B each); (2) every rank builds, concurrently, its transfer table "stream position before my partitions -> position after them" for a
+ * 6-sigma window around the start it expects from (1) (a few thousand 8 B entries per type), the tables are all-gathered and composed.  Only when a
+ * partition beyond 1045 members exists somewhere (random.sample's set method: its consumption depends on the values drawn) or a start leaves its
+ * window do the ranks fall back to publishing exact end positions rank after rank (world all-gathers of 128 B).
+ * The transport is injected: `fn` must all-gather `bytes` bytes of host memory per rank into `recv` (rank-major, world * bytes) and return 0 - e.g. one
+ * torch.distributed.all_gather_into_tensor over RCCL.  Every rank must call svx_cluster once per step (a rank without signatures takes part with an
+ * empty table); a rank that fails sends a poison header so that the others fail instead of hanging (svx_cluster_abort_ranks: the same for a failure
+ * before the call).  fn == NULL or world <= 1: single rank, every stream starts at 0. */
+typedef int (*svx_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes);
+int  svx_cluster_set_ranks(svx_ctx* ctx, int rank, int world, svx_allgather_fn fn, void* user);
+int  svx_cluster_abort_ranks(svx_ctx* ctx);
+/* where each type's stream started / stopped on this rank in the last svx_cluster (32-bit words after seed(1524), SVX_* type order) */
+int  svx_cluster_stream_positions(svx_ctx* ctx, int64_t* start /* [SVX_NTYPES] */, int64_t* end /* [SVX_NTYPES] */);
 
 /* ---- GENOTYPE: replaces the per-candidate BAM re-fetch of genotype() (src/svim/SVIM_genotyping.py:34-93) --------
  * by an interval join over the alignment records, resident in HBM.  Records are in file order of a coordinate-sorted BAM

@@ -63,7 +63,8 @@ class Oracle(object):
         self.L.svo_set_genome(self.ctx, C.byref(g))
 
     def set_chain(self, fn):
-        """same contract as svim_amd._lib.Engine.set_chain (svx_cluster_set_chain)"""
+        """fn(phase, words): phase 0 fills the six per-type stream start positions into `words` (list of 6 ints, in place), phase 1 receives the six
+        end positions - the checker's stand-in for the rank exchange the product does inside svx_cluster (svx_cluster_set_ranks)"""
         if fn is None:
             self._chain_cb = None
             self.L.svo_cluster_set_chain(self.ctx, None, None)
@@ -87,12 +88,7 @@ class Oracle(object):
         self._chain_cb = proto(tramp)
         self.L.svo_cluster_set_chain(self.ctx, self._chain_cb, None)
 
-    def cluster(self, params, contig_rank, table=None, source=2, shard=None, origin_prefix=None):
-        if shard is not None and origin_prefix is not None:
-            pre = np.ascontiguousarray(origin_prefix, dtype=np.int64)
-            assert self.L.svo_cluster_set_shard_by_origin(self.ctx, shard[0], shard[1], ptr(pre)) == 0
-        elif shard is not None:
-            self.L.svo_cluster_set_shard(self.ctx, shard[0], shard[1])
+    def cluster(self, params, contig_rank, table=None, source=2):
         v = table.view() if table is not None else _abi.SigView()
         rank = np.ascontiguousarray(contig_rank, dtype=np.int32)
         rc = self.L.svo_cluster(self.ctx, source, C.byref(v), len(rank), ptr(rank), C.byref(params))
@@ -103,9 +99,6 @@ class Oracle(object):
         cv = ct.view()
         self.L.svo_cluster_fetch(self.ctx, C.byref(cv))
         ct.finish(cv)
-        pi = np.zeros(max(1, n.value), dtype=np.int64)
-        self.L.svo_cluster_fetch_part_index(self.ctx, ptr(pi))
-        ct.part_index = pi[:n.value]
         return ct
 
     def stats(self):
@@ -125,11 +118,6 @@ class Oracle(object):
         self.L.svo_cigar_indel(ptr(c), C.c_int64(n), C.c_int32(min_length), ptr(o_ref), ptr(o_read), ptr(o_len),
                                ptr(o_del), C.byref(m))
         return [(int(o_ref[i]), int(o_read[i]), int(o_len[i]), "DEL" if o_del[i] else "INS") for i in range(m.value)]
-
-    def remote_members(self):
-        n = C.c_int64()
-        self.L.svo_cluster_remote_members(self.ctx, C.byref(n))
-        return n.value
 
     def set_alignment_index(self, index):
         self._index = index                      # the C side borrows the arrays

@@ -57,6 +57,7 @@ static int64_t st_push(sigtab* t, uint64_t key, int type, int src, int aux, int3
     return i;
 }
 
+typedef int (*svo_chain_fn)(void* user, int phase, int64_t* words /* [SVX_NTYPES] */);
 typedef struct svo_ctx {
     sigtab sig, bnd;                 /* results of the last collect */
     int64_t* sig_seq_off; uint8_t* sig_seq;     /* INS sequences of `sig`, per signature */
@@ -64,15 +65,13 @@ typedef struct svo_ctx {
     int32_t g_n; int64_t* g_off; uint8_t* g_codes;
     /* cluster results */
     svx_cluster_view clu; int64_t clu_cap, mem_cap; int64_t* part_index;
-    int shard_rank, shard_world;
-    int shard_mode;                 /* 0: partition index % world, 1: origin rank of the first sorted member */
-    int64_t shard_prefix[65];       /* mode 1: first global index of every rank */
-    int64_t n_remote_members;
-    svx_chain_fn chain_fn; void* chain_user;      /* svo_cluster_set_chain (same contract as svx_cluster_set_chain) */
+    /* svo_cluster_set_chain: the checker's stand-in for the rank exchange of svx_cluster_set_ranks - fn(user, 0, words) OBTAINS the 6 stream start
+     * positions of this rank (words earlier ranks' partitions consumed), fn(user, 1, words) REPORTS the 6 end positions */
+    svo_chain_fn chain_fn; void* chain_user;
     svx_stats stats;
 } svo_ctx;
 
-int svo_ctx_create(svo_ctx** out) { *out = calloc(1, sizeof(svo_ctx)); (*out)->shard_world = 1; return 0; }
+int svo_ctx_create(svo_ctx** out) { *out = calloc(1, sizeof(svo_ctx)); return 0; }
 static void clu_free(svo_ctx* c) {
     svx_cluster_view* v = &c->clu;
     free(v->type); free(v->contig); free(v->start); free(v->end); free(v->contig2); free(v->start2); free(v->end2);
@@ -882,7 +881,7 @@ int svo_cluster(svo_ctx* c, int source, const svx_sig_view* sigs_in, int32_t n_c
     out->n = 0; out->n_members = 0; memset(out->type_count, 0, sizeof out->type_count);
     clu_reserve(c, 1, 1); out->member_off[0] = 0;
     int64_t e_pairs0 = c->stats.n_edit_pairs; (void)e_pairs0;
-    c->stats.n_partitions = c->stats.n_large_partitions = c->stats.n_pairs = 0; c->stats.n_edit_pairs = c->stats.n_edit_cells = 0; c->n_remote_members = 0;
+    c->stats.n_partitions = c->stats.n_large_partitions = c->stats.n_pairs = 0; c->stats.n_edit_pairs = c->stats.n_edit_cells = 0;
     skey* keys = malloc(sizeof(skey) * (size_t)(n ? n : 1));
     for (int64_t i = 0; i < n; i++) {
         skey k; k.type = v->type[i]; k.idx = i; k.r2 = 0;
@@ -925,17 +924,7 @@ int svo_cluster(svo_ctx* c, int source, const svx_sig_view* sigs_in, int32_t n_c
             c->stats.n_partitions++;
             if (psize > 100) { mt_sample100(&rng, psize, sample); ns = 100; c->stats.n_large_partitions++; }
             else { ns = (int)psize; for (int k = 0; k < ns; k++) sample[k] = k; }
-            int mine = (global_part % c->shard_world) == c->shard_rank;
-            if (c->shard_mode == 1) {
-                /* svx_cluster_set_shard_by_origin: the table is the rank-major concatenation, a partition belongs to the rank that
-                 * produced its first sorted member; members from other ranks are counted (the caller must then fall back) */
-                int owner = 0; int64_t g0 = keys[ps].idx;
-                while (owner + 1 < c->shard_world && g0 >= c->shard_prefix[owner + 1]) owner++;
-                mine = owner == c->shard_rank;
-                if (mine && type == SVX_INS)
-                    for (int k = 0; k < ns; k++) { int64_t g = keys[ps + sample[k]].idx;
-                        if (g < c->shard_prefix[owner] || g >= c->shard_prefix[owner + 1]) c->n_remote_members++; }
-            }
+            const int mine = 1;
             if (mine) {
                 csig m[100]; int32_t midx[100];
                 for (int k = 0; k < ns; k++) { midx[k] = (int32_t)keys[ps + sample[k]].idx; m[k] = get_sig(v, midx[k]); }
@@ -1011,15 +1000,7 @@ int svo_cluster(svo_ctx* c, int source, const svx_sig_view* sigs_in, int32_t n_c
     if (c->chain_fn && c->chain_fn(c->chain_user, 1, chain_end) != 0) return -5;
     return 0;
 }
-int svo_cluster_set_chain(svo_ctx* c, svx_chain_fn fn, void* user) { c->chain_fn = fn; c->chain_user = user; return 0; }
-int svo_cluster_set_shard(svo_ctx* c, int rank, int world) { c->shard_rank = rank; c->shard_world = world; c->shard_mode = 0; return 0; }
-int svo_cluster_set_shard_by_origin(svo_ctx* c, int rank, int world, const int64_t* prefix) {
-    if (world > 64) return -1;
-    c->shard_rank = rank; c->shard_world = world; c->shard_mode = 1;
-    for (int r = 0; r <= world; r++) c->shard_prefix[r] = prefix[r];
-    return 0;
-}
-int svo_cluster_remote_members(svo_ctx* c, int64_t* out) { *out = c->n_remote_members; return 0; }
+int svo_cluster_set_chain(svo_ctx* c, svo_chain_fn fn, void* user) { c->chain_fn = fn; c->chain_user = user; return 0; }
 int svo_cluster_count(svo_ctx* c, int64_t* ncl, int64_t* nmem) { *ncl = c->clu.n; *nmem = c->clu.n_members; return 0; }
 int svo_cluster_fetch(svo_ctx* c, svx_cluster_view* o) {
     svx_cluster_view* v = &c->clu; size_t n = (size_t)v->n;

@@ -182,7 +182,7 @@ class SigTable(object):
 
 
 class ClusterTable(object):
-    __slots__ = tuple(CLU_DTYPES) + ("member_off", "members", "n", "n_members", "type_count", "part_index")
+    __slots__ = tuple(CLU_DTYPES) + ("member_off", "members", "n", "n_members", "type_count")
 
     def __init__(self, n, n_members):
         self.n, self.n_members = n, n_members
@@ -191,7 +191,6 @@ class ClusterTable(object):
         self.member_off = np.zeros(n + 1, dtype=np.int64)
         self.members = np.zeros(max(1, n_members), dtype=np.int32)
         self.type_count = [0] * 6
-        self.part_index = None
 
     def view(self):
         v = ClusterView()

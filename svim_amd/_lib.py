@@ -19,8 +19,7 @@ _ENGINES = {}
 
 SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream",
            "svx_collect", "svx_collect_count", "svx_collect_fetch", "svx_collect_accumulate", "svx_collect_set_slot_base", "svx_set_genome", "svx_cluster",
-           "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_shard", "svx_cluster_fetch_part_index",
-           "svx_cluster_set_shard_by_origin", "svx_cluster_remote_members", "svx_cluster_set_chain",
+           "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_ranks", "svx_cluster_abort_ranks", "svx_cluster_stream_positions",
            "svx_set_alignment_index", "svx_genotype",
            "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster", "svx_pair_distances",
            "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names", "svx_bam_set_seq_filter", "svx_bam_rewind", "svx_bam_seek", "svx_bam_set_gpu_inflate", "svx_bam_gpu_inflate_stats",
@@ -116,12 +115,7 @@ class Engine(object):
         self._keep = [off, codes]
         _check(self.L.svx_set_genome(self.ctx, C.byref(g)), "svx_set_genome")
 
-    def cluster(self, params, contig_rank, table=None, source=2, shard=None, fetch=True, origin_prefix=None):
-        if shard is not None and origin_prefix is not None:
-            pre = np.ascontiguousarray(origin_prefix, dtype=np.int64)
-            _check(self.L.svx_cluster_set_shard_by_origin(self.ctx, shard[0], shard[1], ptr(pre)), "svx_cluster_set_shard_by_origin")
-        elif shard is not None:
-            _check(self.L.svx_cluster_set_shard(self.ctx, shard[0], shard[1]), "svx_cluster_set_shard")
+    def cluster(self, params, contig_rank, table=None, source=2, fetch=True):
         v = table.view() if (table is not None and hasattr(table, "view")) else (table if table is not None else _abi.SigView())
         rank = np.ascontiguousarray(contig_rank, dtype=np.int32)
         _check(self.L.svx_cluster(self.ctx, source, C.byref(v), len(rank), ptr(rank), C.byref(params)), "svx_cluster")
@@ -136,9 +130,6 @@ class Engine(object):
         cv = ct.view()
         _check(self.L.svx_cluster_fetch(self.ctx, C.byref(cv)), "svx_cluster_fetch")
         ct.finish(cv)
-        pi = np.zeros(max(1, n.value), dtype=np.int64)
-        _check(self.L.svx_cluster_fetch_part_index(self.ctx, ptr(pi)), "svx_cluster_fetch_part_index")
-        ct.part_index = pi[:n.value]
         return ct
 
     def set_alignment_index(self, index):
@@ -156,34 +147,38 @@ class Engine(object):
                                    ptr(member_names if member_names.size else np.zeros(1, np.int32)), C.c_int32(min_mapq), ptr(out)), "svx_genotype")
         return out[:n]
 
-    def set_chain(self, fn):
-        """fn(phase, words) -> None: phase 0 fills the six per-type stream start positions into `words` (a list of 6 ints,
-        modified in place), phase 1 receives the six end positions (svx_cluster_set_chain); None switches it off."""
-        if fn is None:
-            self._chain_cb = None
-            _check(self.L.svx_cluster_set_chain(self.ctx, None, None), "svx_cluster_set_chain")
+    def set_ranks(self, rank, world, allgather=None):
+        """Contig-sharded ranks (svx_cluster_set_ranks): this engine is rank `rank` of `world`; allgather(send: bytes) -> bytes of all ranks, rank-major
+        (len(send) * world) is the transport svx_cluster uses to find where its random.sample streams start.  allgather None / world 1: single rank."""
+        if allgather is None or world <= 1:
+            self._ag_cb = None
+            _check(self.L.svx_cluster_set_ranks(self.ctx, 0, 1, None, None), "svx_cluster_set_ranks")
             return
-        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int64))
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 
-        def tramp(user, phase, words):
+        def tramp(user, send, recv, nbytes):
             try:
-                w = [int(words[i]) for i in range(6)]
-                fn(int(phase), w)
-                if phase == 0:
-                    for i in range(6):
-                        words[i] = int(w[i])
+                got = allgather(C.string_at(send, nbytes))
+                if len(got) != nbytes * world:
+                    raise ValueError("all-gather callback returned %d bytes, expected %d" % (len(got), nbytes * world))
+                C.memmove(recv, got, len(got))
                 return 0
             except Exception:                       # an exception must not unwind through the C frames
                 import traceback
                 traceback.print_exc()
                 return 1
-        self._chain_cb = proto(tramp)
-        _check(self.L.svx_cluster_set_chain(self.ctx, self._chain_cb, None), "svx_cluster_set_chain")
+        self._ag_cb = proto(tramp)
+        _check(self.L.svx_cluster_set_ranks(self.ctx, int(rank), int(world), self._ag_cb, None), "svx_cluster_set_ranks")
 
-    def remote_members(self):
-        n = C.c_int64()
-        _check(self.L.svx_cluster_remote_members(self.ctx, C.byref(n)), "svx_cluster_remote_members")
-        return n.value
+    def abort_ranks(self):
+        """tell the other ranks this one will not reach svx_cluster (they fail instead of waiting in the rank exchange)"""
+        _check(self.L.svx_cluster_abort_ranks(self.ctx), "svx_cluster_abort_ranks")
+
+    def stream_positions(self):
+        """(start[6], end[6]): where each type's random.sample stream started / stopped on this rank in the last cluster call"""
+        a, b = (C.c_int64 * 6)(), (C.c_int64 * 6)()
+        _check(self.L.svx_cluster_stream_positions(self.ctx, a, b), "svx_cluster_stream_positions")
+        return list(a), list(b)
 
     def stats(self):
         s = _abi.Stats()

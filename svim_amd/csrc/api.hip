@@ -47,7 +47,7 @@ extern "C" void svx_ctx_destroy(svx_ctx* c) {
     c->sig.release(); c->bnd.release(); c->raw_sig.release(); c->raw_bnd.release();
     DevBuf* bufs[] = {&c->counters, &c->raw_indel, &c->shard_cnt, &c->rec_geom, &c->seg_geom, &c->seg_ws, &c->tmp0, &c->tmp1, &c->tmp2, &c->tmp3, &c->tmp4, &c->tmp5, &c->sort_tmp,
                       &c->g_off, &c->g_codes, &c->c_rank, &c->k_hi, &c->k_lo, &c->k_idx, &c->k_hi2, &c->k_lo2, &c->k_idx2, &c->part_flag, &c->part_id,
-                      &c->part_start, &c->part_meta, &c->shard_prefix, &c->samp_idx, &c->large_list, &c->samp_stream, &c->cell_shards, &c->mt_words, &c->samp_meta, &c->samp_table, &c->samp_runs, &c->pair_off, &c->ed, &c->work, &c->stage, &c->stage_members, &c->labels, &c->e_words, &c->e_off, &c->e_scratch, &c->e_rec, &c->e_hist, &c->e_desc, &c->e_key, &c->e_val, &c->e_slot, &c->e_fail, &c->e_big_list, &c->e_big_state, &c->e_big_off, &c->e_retry[0], &c->e_retry[1], &c->e_retry[2], &c->prepack_tmp,
+                      &c->part_start, &c->part_meta, &c->samp_chain, &c->samp_idx, &c->large_list, &c->samp_stream, &c->cell_shards, &c->mt_words, &c->samp_meta, &c->samp_table, &c->samp_runs, &c->pair_off, &c->ed, &c->work, &c->stage, &c->stage_members, &c->labels, &c->e_words, &c->e_off, &c->e_scratch, &c->e_rec, &c->e_hist, &c->e_desc, &c->e_key, &c->e_val, &c->e_slot, &c->e_fail, &c->e_big_list, &c->e_big_state, &c->e_big_off, &c->e_retry[0], &c->e_retry[1], &c->e_retry[2], &c->prepack_tmp,
                       &c->clu.type, &c->clu.contig, &c->clu.start, &c->clu.end, &c->clu.contig2, &c->clu.start2, &c->clu.end2, &c->clu.aux, &c->clu.score,
                       &c->clu.std_span, &c->clu.std_pos, &c->clu.size, &c->clu.member_off, &c->clu.members, &c->clu.part_index};
     for (auto* b : bufs) b->release();
@@ -283,29 +283,24 @@ extern "C" int svx_pair_distances(svx_ctx* c, const svx_sig_view* sigs, int64_t 
     return SVX_OK;
 }
 
-extern "C" int svx_cluster_set_shard(svx_ctx* c, int rank, int world) {
-    if (world < 1 || rank < 0 || rank >= world) return svx_fail(SVX_E_ARG, "bad shard", __FILE__, __LINE__, hipSuccess);
-    c->shard_rank = rank; c->shard_world = world; c->shard_mode = 0;
+// contig-sharded ranks: this context is rank `rank` of `world`; `fn` all-gathers small host buffers among them (NULL / world <= 1: single rank)
+extern "C" int svx_cluster_set_ranks(svx_ctx* c, int rank, int world, svx_allgather_fn fn, void* user) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return svx_fail(SVX_E_ARG, "bad rank / world", __FILE__, __LINE__, hipSuccess);
+    c->xr_rank = rank; c->xr_world = world; c->xr_fn = fn; c->xr_user = user; c->xr_pending = false;
     return SVX_OK;
 }
-
-extern "C" int svx_cluster_set_chain(svx_ctx* c, svx_chain_fn fn, void* user) {
+extern "C" int svx_cluster_stream_positions(svx_ctx* c, int64_t* start, int64_t* end) {
     if (!c) return svx_fail(SVX_E_ARG, "null context", __FILE__, __LINE__, hipSuccess);
-    c->chain_fn = fn; c->chain_user = user;
+    for (int t = 0; t < SVX_NTYPES; t++) { if (start) start[t] = c->stream_start[t]; if (end) end[t] = c->stream_end[t]; }
     return SVX_OK;
 }
-
-extern "C" int svx_cluster_set_shard_by_origin(svx_ctx* c, int rank, int world, const int64_t* origin_prefix_host) {
-    if (world < 1 || rank < 0 || rank >= world || !origin_prefix_host) return svx_fail(SVX_E_ARG, "bad shard", __FILE__, __LINE__, hipSuccess);
-    HIPCHK(hipSetDevice(c->device));
-    SVXCHK(c->shard_prefix.reserve((size_t)(world + 1) * 8));
-    HIPCHK(hipMemcpyAsync(c->shard_prefix.p, origin_prefix_host, (size_t)(world + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->shard_rank = rank; c->shard_world = world; c->shard_mode = 1;
+// a rank that cannot reach its svx_cluster (an error before the call) tells the others, who would otherwise wait for it in the rank exchange
+extern "C" int svx_cluster_abort_ranks(svx_ctx* c) {
+    if (!c) return svx_fail(SVX_E_ARG, "null context", __FILE__, __LINE__, hipSuccess);
+    c->xr_pending = c->xr_world > 1 && c->xr_fn;
+    svx_exchange_poison(c);
     return SVX_OK;
 }
-
-extern "C" int svx_cluster_remote_members(svx_ctx* c, int64_t* out) { *out = c->n_remote_members; return SVX_OK; }
 
 extern "C" int svx_cluster_count(svx_ctx* c, int64_t* n_clusters, int64_t* n_members) {
     if (n_clusters) *n_clusters = c->clu.n;
@@ -330,13 +325,6 @@ extern "C" int svx_cluster_fetch(svx_ctx* c, svx_cluster_view* o) {
     HIPCHK(hipStreamSynchronize(st));
     o->n = v.n; o->n_members = v.n_members;
     for (int t = 0; t < SVX_NTYPES; t++) o->type_count[t] = v.type_count[t];
-    return SVX_OK;
-}
-
-extern "C" int svx_cluster_fetch_part_index(svx_ctx* c, int64_t* host_out) {
-    HIPCHK(hipSetDevice(c->device));
-    if (c->clu.n) HIPCHK(hipMemcpyAsync(host_out, c->clu.part_index.p, (size_t)c->clu.n * 8, hipMemcpyDefault, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
     return SVX_OK;
 }
 

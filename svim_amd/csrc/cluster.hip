@@ -16,6 +16,7 @@
 // (<= 4950 doubles = 39.6 KB) and the whole dendrogram live in LDS; nothing is re-read from HBM.
 // FP64 throughout with the reference's operation order (-ffp-contract=off), so labels are bit-exact.
 #include "common.hpp"
+#include <cstdlib>
 
 int svx_launch_edit_pairs(svx_ctx* c, int64_t n_work, const void* work_dev, const ClusterIn& in, int32_t* ed_dev,
                           unsigned long long* cells_dev);
@@ -23,21 +24,6 @@ int svx_launch_edit_pairs(svx_ctx* c, int64_t n_work, const void* work_dev, cons
 struct EditWork { uint32_t a, b; long long slot; };
 
 #define MAXN 100
-
-// Which rank clusters a partition.  mode 0: partition index modulo world.  mode 1 ("by origin"): the rank whose COLLECT
-// produced the partition's first sorted member (the signature table is the rank-major concatenation, origin_prefix[r] =
-// first global index of rank r): with contig-sharded input every member - and every inserted sequence - is already local.
-struct Shard { int mode, rank, world; const int64_t* origin_prefix; };
-__device__ __forceinline__ int origin_of(const Shard& sh, uint32_t sig) {
-    int r = 0;
-    while (r + 1 < sh.world && (int64_t)sig >= sh.origin_prefix[r + 1]) r++;
-    return r;
-}
-__device__ __forceinline__ bool shard_mine(const Shard& sh, long long pt, uint32_t first_member) {
-    if (sh.world <= 1) return true;
-    if (sh.mode == 0) return (pt % sh.world) == sh.rank;
-    return origin_of(sh, first_member) == sh.rank;
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // sort keys (get_key): hi = type | rank1 | rank2, lo = biased coordinate
@@ -94,7 +80,7 @@ __global__ void k_part_starts(const int64_t* flag, const int64_t* pid_excl, long
 }
 
 // per-partition derived sizes: ns = min(size, 100); large flag; INS pair slots
-__global__ void k_part_sizes(const int64_t* part_start, long long n_part, const uint8_t* type, const uint32_t* sidx, Shard sh,
+__global__ void k_part_sizes(const int64_t* part_start, long long n_part, const uint8_t* type, const uint32_t* sidx,
                              int64_t* ns, int64_t* large, int64_t* pairs) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n_part) return;
@@ -103,8 +89,7 @@ __global__ void k_part_sizes(const int64_t* part_start, long long n_part, const 
     const long long m = size > MAXN ? MAXN : size;
     ns[p] = m;
     large[p] = size > MAXN;
-    const bool mine = shard_mine(sh, p, sidx[part_start[p]]);
-    pairs[p] = (mine && type[sidx[part_start[p]]] == SVX_INS) ? m * (m - 1) / 2 : 0;
+    pairs[p] = type[sidx[part_start[p]]] == SVX_INS ? m * (m - 1) / 2 : 0;
 }
 
 __global__ void k_large_list(const int64_t* large, const int64_t* large_excl, long long n_part, int32_t* list) {
@@ -476,11 +461,10 @@ __device__ __forceinline__ uint32_t member_gidx(long long pstart, long long size
     return sidx[pstart + q];
 }
 
-// enumerate the INS pairs that need an edit distance (one wave per INS partition of this shard)
+// enumerate the INS pairs that need an edit distance (one wave per INS partition)
 __global__ __launch_bounds__(64) void k_ins_pairs(long long n_part, const int64_t* part_start, const uint32_t* sidx, const int32_t* sample_idx,
                                                   const int64_t* large_excl, const int64_t* pair_cnt, const int64_t* pair_off, ClusterIn in,
-                                                  svx_params p, EditWork* work, unsigned long long* n_work, long long work_cap, Shard sh,
-                                                  unsigned long long* n_remote) {
+                                                  svx_params p, EditWork* work, unsigned long long* n_work, long long work_cap) {
     const long long pt = blockIdx.x;
     if (pt >= n_part || pair_cnt[pt] == 0) return;
     __shared__ int m_start[MAXN]; __shared__ uint32_t m_g[MAXN];
@@ -488,8 +472,6 @@ __global__ __launch_bounds__(64) void k_ins_pairs(long long n_part, const int64_
     const int ns = size > MAXN ? MAXN : (int)size;
     for (int q = lane_id(); q < ns; q += 64) {
         const uint32_t g = member_gidx(ps, size, q, sidx, sample_idx, large_excl, pt); m_g[q] = g; m_start[q] = in.start[g];
-        // by-origin sharding promises that the inserted sequences of an owned partition are local: count the exceptions
-        if (sh.world > 1 && sh.mode == 1 && origin_of(sh, g) != sh.rank) atomicAdd(n_remote, 1ull);
     }
     __syncthreads();
     const int npairs = ns * (ns - 1) / 2;
@@ -831,14 +813,13 @@ __device__ void consolidate_one(int t, int contig, const Member* mem, const int*
 template <int CAP, int LO>
 __global__ __launch_bounds__(64) void k_cluster(long long n_part, const int64_t* part_start, const uint32_t* sidx, const int32_t* sample_idx,
                                                 const int64_t* large_excl, const int64_t* samp_base, const int64_t* pair_off, const int32_t* ed,
-                                                ClusterIn in, svx_params p, Shard sh, Stage st, int32_t* ncl_out, int32_t* nmem_out,
+                                                ClusterIn in, svx_params p, Stage st, int32_t* ncl_out, int32_t* nmem_out,
                                                 unsigned long long* n_pairs_stat, int phase) {
     // phase 0: every partition; 1: all but insertions (they need no edit distances and run beside the edit-distance rounds); 2: insertions
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const long long pt = blockIdx.x;
     if (pt >= n_part) return;
     const int lane = lane_id();
-    if (!shard_mine(sh, pt, sidx[part_start[pt]])) { if (lane == 0 && LO == 0) { ncl_out[pt] = 0; nmem_out[pt] = 0; } return; }
     const long long ps = part_start[pt], size = part_start[pt + 1] - ps;
     const int ns = size > MAXN ? MAXN : (int)size;
     if (ns > CAP || ns <= LO) return;                                               // the other size class owns this partition
@@ -1011,7 +992,210 @@ static void mt_seed_state(uint32_t key0, uint32_t* s) {
 
 #define GRID(n, t) (unsigned)(((n) + (t) - 1) / (t))
 
-int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const int32_t* rank, const svx_params* pp) {
+// host-side plan of the consumption tables (k_sample_tables .. k_chase_*)
+struct SamplePlan {
+    std::vector<int32_t> info;                      // [2 n_large]: type, size of every large partition (sorted order)
+    std::vector<SampleMeta> meta; std::vector<ChaseRun> runs;
+    long long type_begin[SVX_NTYPES + 1], type_run_begin[SVX_NTYPES + 1];
+    long long slots = 0, end_slots = 0, n_runs = 0; int max_width = 0;
+    bool ok = false;
+    SampleMeta* meta_dev = nullptr; ChaseRun* runs_dev = nullptr; long long* run_start_dev = nullptr; long long* trb_dev = nullptr; long long* ends_dev = nullptr;
+};
+
+// words one pool-method sample of a partition of n members (101..1045) consumes: draw i accepts a word with probability (n-i) / 2^k
+static void sample_moments(int n_q, double* mean, double* var) {
+    static thread_local double moments_mean[1046], moments_var[1046];
+    static thread_local bool moments_have[1046];
+    if (!moments_have[n_q]) {
+        double dm = 0, dv = 0;
+        for (int i = 0; i < 100; i++) {
+            const double bound = (double)(n_q - i);
+            int k = 0; while ((1u << k) <= (unsigned)(n_q - i)) k++;
+            const double pacc = bound / (double)(1u << k);
+            dm += 1.0 / pacc; dv += (1.0 - pacc) / (pacc * pacc);
+        }
+        moments_mean[n_q] = dm; moments_var[n_q] = dv; moments_have[n_q] = true;
+    }
+    *mean = moments_mean[n_q]; *var = moments_var[n_q];
+}
+
+// windows (expected start -+ 6 sigma) of every large partition, given mean / variance / lower bound of each type's first start
+static void plan_sample_tables(SamplePlan& P, long long n_large, const double* mean0, const double* var0, const long long* least0) {
+    P.meta.assign((size_t)n_large, SampleMeta{0, 0, 0, 0});
+    P.runs.clear();
+    P.slots = 0; P.end_slots = 0; P.max_width = 0; P.ok = true;
+    const std::vector<int32_t>& info = P.info;
+    long long q = 0;
+    for (int t = 0; t <= SVX_NTYPES; t++) P.type_begin[t] = n_large;
+    for (int t = 0; t < SVX_NTYPES && P.ok; t++) {
+        while (q < n_large && info[(size_t)q * 2] < t) q++;
+        P.type_begin[t] = q;
+        double mean = mean0[t], var = var0[t];
+        long long least = least0[t];
+        for (; q < n_large && info[(size_t)q * 2] == t; q++) {
+            const int n_q = info[(size_t)q * 2 + 1];
+            if (n_q > 1045) { P.ok = false; break; }                       // set method: the walk depends on the values drawn
+            const double sd = sqrt(var);
+            long long lo = (long long)floor(mean - 6.0 * sd) - 32, hi = (long long)ceil(mean + 6.0 * sd) + 32;
+            if (lo < least) lo = least;
+            SampleMeta& m = P.meta[(size_t)q];
+            m.lo = lo; m.width = (int)(hi - lo + 1); m.n = n_q; m.off = P.slots;
+            P.slots += m.width;
+            if (m.width > P.max_width) P.max_width = m.width;
+            double dm, dv;
+            sample_moments(n_q, &dm, &dv);
+            mean += dm; var += dv;
+            least += 100;
+        }
+    }
+    P.type_begin[SVX_NTYPES] = n_large;
+    for (int t = SVX_NTYPES - 1; t >= 0; t--) if (P.type_begin[t] > P.type_begin[t + 1]) P.type_begin[t] = P.type_begin[t + 1];
+    if (!(P.ok && P.slots > 0 && P.slots < (1ll << 31) && n_large <= 65535)) { P.ok = false; return; }
+    // runs of CHASE_RUN partitions, never across a type boundary
+    for (int t = 0; t < SVX_NTYPES; t++) {
+        P.type_run_begin[t] = (long long)P.runs.size();
+        for (long long f = P.type_begin[t]; f < P.type_begin[t + 1]; f += CHASE_RUN) {
+            ChaseRun r; r.first = f; r.last = f + CHASE_RUN < P.type_begin[t + 1] ? f + CHASE_RUN : P.type_begin[t + 1];
+            r.eoff = P.end_slots; r.type = t; r.pad = 0;
+            P.end_slots += P.meta[(size_t)f].width;
+            P.runs.push_back(r);
+        }
+    }
+    P.type_run_begin[SVX_NTYPES] = (long long)P.runs.size();
+    P.n_runs = (long long)P.runs.size();
+}
+
+// transfer table of one rank: for every candidate start of each type's first window, the stream position after ALL of this rank's large
+// partitions of that type (-1: the walk left a window)
+__global__ __launch_bounds__(256) void k_chase_span(const SampleMeta* meta, const ChaseRun* runs, const long long* type_run_begin, const long long* ends,
+                                                    const long long* f_off /* [NTYPES + 1] */, long long* f) {
+    const int t = blockIdx.y;
+    const long long b0 = type_run_begin[t], b1 = type_run_begin[t + 1];
+    if (b0 >= b1) return;
+    const SampleMeta m0 = meta[runs[b0].first];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= m0.width) return;
+    long long pos = m0.lo + s;
+    for (long long b = b0; b < b1; b++) {
+        const ChaseRun r = runs[b];
+        const SampleMeta m = meta[r.first];
+        const long long idx = pos - m.lo;
+        if (idx < 0 || idx >= m.width) { pos = -1; break; }
+        pos = ends[r.eoff + idx];
+        if (pos < 0) break;
+    }
+    f[f_off[t] + s] = pos;
+}
+
+// ---- contig-sharded ranks: where do this rank's sample streams start? ------------------------------------------------------------------------
+// All communication is an all-gather of small host buffers through the callback of svx_cluster_set_ranks; every logical message is a 128-byte header
+// (status, payload size, inline values) followed by an optional payload padded to the largest one.  A rank that fails sends a header with a
+// negative status instead of its next header, so the others fail too instead of waiting for it.
+struct XHdr { int64_t status, payload, a[14]; };
+
+static int xchg_headers(svx_ctx* c, const XHdr& mine, std::vector<XHdr>& all) {
+    all.assign((size_t)c->xr_world, XHdr{});
+    if (c->xr_fn(c->xr_user, &mine, all.data(), (int64_t)sizeof(XHdr)) != 0) { c->xr_pending = false; return svx_fail(SVX_E_STATE, "rank exchange: the all-gather callback failed", __FILE__, __LINE__, hipSuccess); }
+    for (int r = 0; r < c->xr_world; r++)
+        if (all[(size_t)r].status < 0) { c->xr_pending = false; return svx_fail(SVX_E_STATE, "rank exchange: another rank reported a failure", __FILE__, __LINE__, hipSuccess); }
+    return SVX_OK;
+}
+static int xchg_payload(svx_ctx* c, const void* mine, size_t my_bytes, size_t each, std::vector<char>& all) {
+    std::vector<char> send(each, 0);
+    if (my_bytes) memcpy(send.data(), mine, my_bytes);
+    all.assign(each * (size_t)c->xr_world, 0);
+    if (c->xr_fn(c->xr_user, send.data(), all.data(), (int64_t)each) != 0) { c->xr_pending = false; return svx_fail(SVX_E_STATE, "rank exchange: the all-gather callback failed", __FILE__, __LINE__, hipSuccess); }
+    return SVX_OK;
+}
+// the other ranks are (or will be) waiting in a header exchange: tell them this rank gave up
+void svx_exchange_poison(svx_ctx* c) {
+    if (!c->xr_pending || c->xr_world <= 1 || !c->xr_fn) return;
+    c->xr_pending = false;
+    XHdr h{}; h.status = -1;
+    std::vector<XHdr> all((size_t)c->xr_world);
+    (void)c->xr_fn(c->xr_user, &h, all.data(), (int64_t)sizeof(XHdr));
+}
+
+template <class SpecTables, class SpecFinish, class ExactFrom>
+static int svx_sampling_exchange(svx_ctx* c, long long n_large, const int32_t* info, SpecTables spec_tables, SpecFinish spec_finish, ExactFrom exact_from) {
+    const int W = c->xr_world, R = c->xr_rank;
+    // (1) sizes of everybody's large partitions, per type
+    XHdr h{}; h.status = 0; h.payload = n_large * 4; h.a[0] = n_large;
+    std::vector<int32_t> mine((size_t)n_large + 1);
+    for (long long q = 0; q < n_large; q++) { h.a[1 + info[2 * q]]++; mine[(size_t)q] = info[2 * q + 1]; }
+    std::vector<XHdr> H;
+    SVXCHK(xchg_headers(c, h, H));
+    size_t each = 0;
+    for (auto& x : H) each = (size_t)x.payload > each ? (size_t)x.payload : each;
+    std::vector<char> sizes_all;
+    if (each) SVXCHK(xchg_payload(c, mine.data(), (size_t)n_large * 4, each, sizes_all));
+    bool spec = true;
+    double mean0[SVX_NTYPES], var0[SVX_NTYPES]; long long least0[SVX_NTYPES];
+    for (int t = 0; t < SVX_NTYPES; t++) { mean0[t] = 0; var0[t] = 0; least0[t] = 0; }
+    for (int r = 0; r < W; r++) {
+        const int32_t* sz = each ? reinterpret_cast<const int32_t*>(sizes_all.data() + each * (size_t)r) : nullptr;
+        if (H[(size_t)r].a[0] > 65535) spec = false;
+        long long at = 0;
+        for (int t = 0; t < SVX_NTYPES; t++)
+            for (long long k = 0; k < H[(size_t)r].a[1 + t]; k++, at++) {
+                const int n_q = sz[at];
+                if (n_q > 1045) { spec = false; continue; }                 // set method somewhere: its consumption depends on the values drawn
+                if (r < R) { double dm, dv; sample_moments(n_q, &dm, &dv); mean0[t] += dm; var0[t] += dv; least0[t] += 100; }
+            }
+    }
+    if (getenv("SVX_RANKS_EXACT")) spec = false;              // test hook (set for every rank alike): always the exact rounds
+    long long start[SVX_NTYPES] = {0, 0, 0, 0, 0, 0};
+    if (spec) {
+        // (2) every rank's transfer tables around its expected starts, built concurrently
+        long long lo[SVX_NTYPES], width[SVX_NTYPES]; const long long* f = nullptr; bool ok = true;
+        SVXCHK(spec_tables(mean0, var0, least0, lo, width, &f, &ok));
+        XHdr h2{}; h2.status = 0; h2.a[0] = ok ? 0 : 1;
+        long long tot = 0;
+        for (int t = 0; t < SVX_NTYPES; t++) { h2.a[1 + t] = lo[t]; h2.a[7 + t] = ok ? width[t] : 0; tot += ok ? width[t] : 0; }
+        h2.payload = tot * 8;
+        SVXCHK(xchg_headers(c, h2, H));
+        each = 0;
+        for (auto& x : H) { each = (size_t)x.payload > each ? (size_t)x.payload : each; if (x.a[0]) spec = false; }
+        std::vector<char> f_all;
+        if (each) SVXCHK(xchg_payload(c, f, (size_t)tot * 8, each, f_all));
+        if (spec) {
+            // (3) compose: rank r starts where the chain through ranks 0..r-1 ends (every rank computes every rank's start: the same verdict everywhere)
+            long long pos[SVX_NTYPES] = {0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < W && spec; r++) {
+                if (r == R) for (int t = 0; t < SVX_NTYPES; t++) start[t] = pos[t];
+                const long long* fr = each ? reinterpret_cast<const long long*>(f_all.data() + each * (size_t)r) : nullptr;
+                long long off = 0;
+                for (int t = 0; t < SVX_NTYPES; t++) {
+                    const long long w = H[(size_t)r].a[7 + t];
+                    if (H[(size_t)r].a[0] == 0 && w > 0) {
+                        const long long idx = pos[t] - H[(size_t)r].a[1 + t];
+                        if (idx < 0 || idx >= w || fr[off + idx] < 0) { spec = false; break; }
+                        pos[t] = fr[off + idx];
+                    }
+                    off += w;
+                }
+            }
+        }
+        if (spec) { c->xr_pending = false; return spec_finish(start); }
+    }
+    // (4) the exact chain, rank after rank (set-method partitions, > 65535 large partitions on a rank, or a start outside its 6-sigma window):
+    // round j publishes rank j's end positions
+    long long cur[SVX_NTYPES] = {0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < W; j++) {
+        XHdr h5{}; h5.status = 0;
+        if (j == R) {
+            long long end[SVX_NTYPES];
+            SVXCHK(exact_from(cur, end));
+            for (int t = 0; t < SVX_NTYPES; t++) h5.a[t] = end[t];
+        }
+        SVXCHK(xchg_headers(c, h5, H));
+        for (int t = 0; t < SVX_NTYPES; t++) cur[t] = H[(size_t)j].a[t];
+    }
+    c->xr_pending = false;
+    return SVX_OK;
+}
+
+static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const int32_t* rank, const svx_params* pp) {
     hipStream_t st = c->stream;
     const svx_params p = *pp;
     const int64_t n = in.n;
@@ -1022,12 +1206,19 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     S.n_partitions = S.n_large_partitions = S.n_pairs = S.n_edit_pairs = S.n_edit_cells = S.n_clusters = S.n_hap_bytes = 0;
     S.n_edit_wordcols_issued = S.n_edit_wordcols_useful = S.n_edit_wordcols_retry = S.n_edit_wordcols_band = 0; S.edit_guess = 0;
     S.t_cluster_ms = S.t_partition_ms = S.t_edit_ms = S.t_linkage_ms = 0;
-    c->n_remote_members = 0;
+    for (int t = 0; t < SVX_NTYPES; t++) c->stream_start[t] = c->stream_end[t] = 0;
     if (n == 0) {
-        if (c->chain_fn) {                                   // an empty rank still relays the stream positions
-            int64_t w[SVX_NTYPES] = {0, 0, 0, 0, 0, 0};
-            if (c->chain_fn(c->chain_user, 0, w) != 0 || c->chain_fn(c->chain_user, 1, w) != 0)
-                return svx_fail(SVX_E_STATE, "chain callback failed", __FILE__, __LINE__, hipSuccess);
+        if (c->xr_world > 1 && c->xr_fn) {                  // a rank without signatures still takes part in the exchange (its streams pass through)
+            long long pass[SVX_NTYPES] = {0, 0, 0, 0, 0, 0};
+            auto spec_tables = [&](const double*, const double*, const long long*, long long* lo, long long* width, const long long** f, bool* ok) -> int {
+                for (int t = 0; t < SVX_NTYPES; t++) { lo[t] = 0; width[t] = 0; }
+                *f = nullptr; *ok = true;
+                return SVX_OK;
+            };
+            auto spec_finish = [&](const long long* start) -> int { for (int t = 0; t < SVX_NTYPES; t++) pass[t] = start[t]; return SVX_OK; };
+            auto exact_from = [&](const long long* start, long long* end) -> int { for (int t = 0; t < SVX_NTYPES; t++) pass[t] = end[t] = start[t]; return SVX_OK; };
+            SVXCHK(svx_sampling_exchange(c, 0, nullptr, spec_tables, spec_finish, exact_from));
+            for (int t = 0; t < SVX_NTYPES; t++) c->stream_start[t] = c->stream_end[t] = pass[t];
         }
         return SVX_OK;
     }
@@ -1060,8 +1251,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     int64_t* ns_a = c->part_meta.as<int64_t>(); int64_t* large_a = ns_a + PM; int64_t* pairs_a = large_a + PM;
     int64_t* samp_base = pairs_a + PM; int64_t* large_excl = samp_base + PM; int64_t* pair_off = large_excl + PM;
     int64_t* clu_off = pair_off + PM; int64_t* mem_off = clu_off + PM;
-    Shard sh{c->shard_mode, c->shard_rank, c->shard_world, c->shard_prefix.as<int64_t>()};
-    k_part_sizes<<<GRID(n_part + 1, T), T, 0, st>>>(c->part_start.as<int64_t>(), n_part, in.type, sidx, sh, ns_a, large_a, pairs_a);
+    k_part_sizes<<<GRID(n_part + 1, T), T, 0, st>>>(c->part_start.as<int64_t>(), n_part, in.type, sidx, ns_a, large_a, pairs_a);
     SVXCHK(svx_exclusive_scan_i64(c, ns_a, samp_base, n_part + 1));
     SVXCHK(svx_exclusive_scan_i64(c, large_a, large_excl, n_part + 1));
     SVXCHK(svx_exclusive_scan_i64(c, pairs_a, pair_off, n_part + 1));
@@ -1075,133 +1265,99 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     unsigned long long* cnt = c->counters.as<unsigned long long>();
     HIPCHK(hipMemsetAsync(cnt, 0, 16 * 8, st));
     // ---- sampling ----------------------------------------------------------------------------------------------------
-    // multi-GPU (svx_cluster_set_chain): the word stream of every type continues where the previous rank's partitions left it
+    // The word stream of a signature type is consumed by its > 100-member partitions in global order without re-seeding
+    // (src/svim/SVIM_clustering.py:129-134).  Single rank: every stream starts at 0.  Contig-sharded ranks (svx_cluster_set_ranks): the global
+    // order is rank-major, so a rank's streams continue where the partitions of the ranks before it stop - sampling_exchange() finds those
+    // positions with all-gathers only (no rank waits for another rank's sampling).
     long long chain[2 * SVX_NTYPES];
     for (int t = 0; t < 2 * SVX_NTYPES; t++) chain[t] = 0;
-    if (c->chain_fn) {
-        int64_t w[SVX_NTYPES] = {0, 0, 0, 0, 0, 0};
-        if (c->chain_fn(c->chain_user, 0, w) != 0) return svx_fail(SVX_E_STATE, "chain callback (start positions) failed", __FILE__, __LINE__, hipSuccess);
-        for (int t = 0; t < SVX_NTYPES; t++) { if (w[t] < 0) return svx_fail(SVX_E_ARG, "negative stream position", __FILE__, __LINE__, hipSuccess); chain[t] = chain[SVX_NTYPES + t] = w[t]; }
-    }
-    long long chain_max = 0;
-    for (int t = 0; t < SVX_NTYPES; t++) chain_max = chain[t] > chain_max ? chain[t] : chain_max;
     SVXCHK(c->samp_idx.reserve((size_t)(n_large + 1) * 100 * 4));
+    SVXCHK(c->samp_chain.reserve(2 * SVX_NTYPES * 8));
+    long long* chain_dev = c->samp_chain.as<long long>();
+    int* err = reinterpret_cast<int*>(cnt + 15);
+    long long* samp_start = nullptr;
+    SamplePlan plan;
+    auto ensure_stream = [&](long long want) -> int {
+        if (c->mt_have >= want) return SVX_OK;
+        // (re)generate the prefix of the seed(1524) word stream this context keeps
+        const long long blocks = (2 * want + 623) / 624;
+        SVXCHK(c->mt_words.reserve((size_t)blocks * 624 * 4 + 624 * 4 + 64));
+        uint32_t* mt_dev = c->mt_words.as<uint32_t>() + blocks * 624;
+        uint32_t mt_host[624];
+        mt_seed_state(1524u, mt_host);
+        HIPCHK(hipMemcpyAsync(mt_dev, mt_host, sizeof mt_host, hipMemcpyHostToDevice, st));
+        k_mt_generate<<<1, 64, 0, st>>>(mt_dev, c->mt_words.as<uint32_t>(), blocks);
+        HIPCHK(hipStreamSynchronize(st));       // mt_host is a stack buffer
+        c->mt_have = blocks * 624;
+        return SVX_OK;
+    };
     if (n_large > 0) {
         SVXCHK(c->large_list.reserve((size_t)n_large * 4 + 64));
         k_large_list<<<GRID(n_part, T), T, 0, st>>>(large_a, large_excl, n_part, c->large_list.as<int32_t>());
-        long long cap = chain_max + n_large * 512 + 4 * 624;           // expected use: <= ~200 words per partition
-        SVXCHK(c->samp_chain.reserve(2 * SVX_NTYPES * 8));
-        long long* chain_dev = c->samp_chain.as<long long>();
-        HIPCHK(hipMemcpyAsync(chain_dev, chain, sizeof chain, hipMemcpyHostToDevice, st));
-        auto ensure_stream = [&](long long want) -> int {
-            if (c->mt_have >= want) return SVX_OK;
-            // (re)generate the prefix of the seed(1524) word stream this context keeps
-            const long long blocks = (2 * want + 623) / 624;
-            SVXCHK(c->mt_words.reserve((size_t)blocks * 624 * 4 + 624 * 4 + 64));
-            uint32_t* mt_dev = c->mt_words.as<uint32_t>() + blocks * 624;
-            uint32_t mt_host[624];
-            mt_seed_state(1524u, mt_host);
-            HIPCHK(hipMemcpyAsync(mt_dev, mt_host, sizeof mt_host, hipMemcpyHostToDevice, st));
-            k_mt_generate<<<1, 64, 0, st>>>(mt_dev, c->mt_words.as<uint32_t>(), blocks);
-            HIPCHK(hipStreamSynchronize(st));       // mt_host is a stack buffer
-            c->mt_have = blocks * 624;
-            return SVX_OK;
-        };
-        SVXCHK(ensure_stream(cap));
         SVXCHK(c->samp_stream.reserve((size_t)n_large * 8 + 64));
-        long long* samp_start = c->samp_stream.as<long long>();
-        int* err = reinterpret_cast<int*>(cnt + 15);
+        samp_start = c->samp_stream.as<long long>();
+        SVXCHK(c->samp_meta.reserve((size_t)n_large * (8 + sizeof(SampleMeta)) + (SVX_NTYPES + 1) * 8 + 64));
+        int32_t* info_dev = c->samp_meta.as<int32_t>();
+        k_large_info<<<GRID(n_large, T), T, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, info_dev);
+        plan.info.resize((size_t)n_large * 2);
+        HIPCHK(hipMemcpyAsync(plan.info.data(), info_dev, (size_t)n_large * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    // consumption tables for windows around the given expected start of every type (mean0 / var0; least0 = lower bound), launched up to k_chase_runs
+    auto build_tables = [&](const double* mean0, const double* var0, const long long* least0, long long reach) -> int {
+        plan_sample_tables(plan, n_large, mean0, var0, least0);
+        if (!plan.ok) return SVX_OK;
+        SVXCHK(ensure_stream(reach + n_large * 512 + 4 * 624));           // expected use: <= ~200 words per partition
+        SVXCHK(c->samp_table.reserve((size_t)plan.slots * 2 + 64));
+        SVXCHK(c->samp_runs.reserve((size_t)plan.n_runs * (sizeof(ChaseRun) + 8) + (size_t)plan.end_slots * 8 + (SVX_NTYPES + 1) * 8 + 64));
+        plan.meta_dev = reinterpret_cast<SampleMeta*>(c->samp_meta.as<char>() + (size_t)n_large * 8);
+        plan.runs_dev = c->samp_runs.as<ChaseRun>();
+        plan.run_start_dev = reinterpret_cast<long long*>(plan.runs_dev + plan.n_runs);
+        plan.trb_dev = plan.run_start_dev + plan.n_runs;
+        plan.ends_dev = plan.trb_dev + (SVX_NTYPES + 1);
+        HIPCHK(hipMemcpyAsync(plan.meta_dev, plan.meta.data(), (size_t)n_large * sizeof(SampleMeta), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(plan.runs_dev, plan.runs.data(), (size_t)plan.n_runs * sizeof(ChaseRun), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(plan.trb_dev, plan.type_run_begin, sizeof plan.type_run_begin, hipMemcpyHostToDevice, st));
+        k_sample_tables<<<dim3((unsigned)((plan.max_width + 255) / 256), (unsigned)n_large), 256, 0, st>>>(plan.meta_dev, c->mt_words.as<uint32_t>(), c->mt_have,
+                                                                                                         c->samp_table.as<uint16_t>());
+        k_chase_runs<<<dim3((unsigned)((plan.max_width + 255) / 256), (unsigned)plan.n_runs), 256, 0, st>>>(plan.meta_dev, plan.runs_dev, c->samp_table.as<uint16_t>(), plan.ends_dev);
+        HIPCHK(hipGetLastError());
+        return SVX_OK;
+    };
+    // with the tables built: follow the chain from the exact starts in chain[0..5], sample; *done = false when a start left its window
+    auto finish_tables = [&](bool* done) -> int {
+        HIPCHK(hipMemcpyAsync(chain_dev, chain, sizeof chain, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(err, 0, 8, st));
+        k_chase_top<<<SVX_NTYPES, 64, 0, st>>>(plan.meta_dev, plan.runs_dev, plan.trb_dev, plan.ends_dev, plan.run_start_dev, err, chain_dev);
+        k_chase_fill<<<GRID(plan.n_runs, 64), 64, 0, st>>>(plan.meta_dev, plan.runs_dev, plan.n_runs, c->samp_table.as<uint16_t>(), plan.run_start_dev, samp_start);
+        k_sample_apply<<<(unsigned)n_large, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
+                                                        c->mt_words.as<uint32_t>(), c->mt_have, samp_start, c->samp_idx.as<int32_t>());
+        HIPCHK(hipGetLastError());
+        int h_err = 0;
+        HIPCHK(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(chain, chain_dev, sizeof chain, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));       // also covers the plan's host vectors
+        *done = !h_err;
+        return SVX_OK;
+    };
+    // this rank's sampling from the exact stream positions chain[0..5]; leaves the end positions in chain[6..11]
+    auto exact_sampling = [&]() -> int {
+        for (int t = 0; t < SVX_NTYPES; t++) chain[SVX_NTYPES + t] = chain[t];
+        if (n_large == 0) return SVX_OK;
+        long long chain_max = 0;
+        for (int t = 0; t < SVX_NTYPES; t++) chain_max = chain[t] > chain_max ? chain[t] : chain_max;
+        long long cap = chain_max + n_large * 512 + 4 * 624;
         bool done = false;
-        {   // table path
-            SVXCHK(c->samp_meta.reserve((size_t)n_large * (8 + sizeof(SampleMeta)) + (SVX_NTYPES + 1) * 8 + 64));
-            int32_t* info_dev = c->samp_meta.as<int32_t>();
-            k_large_info<<<GRID(n_large, T), T, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, info_dev);
-            std::vector<int32_t> info((size_t)n_large * 2);
-            HIPCHK(hipMemcpyAsync(info.data(), info_dev, (size_t)n_large * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            std::vector<SampleMeta> meta((size_t)n_large);
-            static thread_local double moments_mean[1046], moments_var[1046];             // words one pool-method sample of a partition of n members consumes
-            static thread_local bool moments_have[1046];
-            long long type_begin[SVX_NTYPES + 1];
-            bool table_ok = true;
-            long long slots = 0, q = 0;
-            int max_width = 0;
-            for (int t = 0; t <= SVX_NTYPES; t++) type_begin[t] = n_large;
-            for (int t = 0; t < SVX_NTYPES && table_ok; t++) {
-                while (q < n_large && info[(size_t)q * 2] < t) q++;
-                type_begin[t] = q;
-                double mean = (double)chain[t], var = 0;
-                long long least = chain[t];
-                for (; q < n_large && info[(size_t)q * 2] == t; q++) {
-                    const int n_q = info[(size_t)q * 2 + 1];
-                    if (n_q > 1045) { table_ok = false; break; }                       // set method: the walk depends on the values drawn
-                    const double sd = sqrt(var);
-                    long long lo = (long long)floor(mean - 6.0 * sd) - 32, hi = (long long)ceil(mean + 6.0 * sd) + 32;
-                    if (lo < least) lo = least;
-                    SampleMeta& m = meta[(size_t)q];
-                    m.lo = lo; m.width = (int)(hi - lo + 1); m.n = n_q; m.off = slots;
-                    slots += m.width;
-                    if (m.width > max_width) max_width = m.width;
-                    if (!moments_have[n_q]) {                                            // draw i accepts a word with probability (n-i) / 2^k
-                        double dm = 0, dv = 0;
-                        for (int i = 0; i < 100; i++) {
-                            const double bound = (double)(n_q - i);
-                            int k = 0; while ((1u << k) <= (unsigned)(n_q - i)) k++;
-                            const double pacc = bound / (double)(1u << k);
-                            dm += 1.0 / pacc; dv += (1.0 - pacc) / (pacc * pacc);
-                        }
-                        moments_mean[n_q] = dm; moments_var[n_q] = dv; moments_have[n_q] = true;
-                    }
-                    mean += moments_mean[n_q]; var += moments_var[n_q];
-                    least += 100;
-                }
-            }
-            type_begin[SVX_NTYPES] = n_large;
-            for (int t = SVX_NTYPES - 1; t >= 0; t--) if (type_begin[t] > type_begin[t + 1]) type_begin[t] = type_begin[t + 1];
-            if (table_ok && slots > 0 && slots < (1ll << 31) && n_large <= 65535) {
-                // runs of CHASE_RUN partitions, never across a type boundary
-                std::vector<ChaseRun> runs;
-                long long type_run_begin[SVX_NTYPES + 1];
-                long long end_slots = 0;
-                for (int t = 0; t < SVX_NTYPES; t++) {
-                    type_run_begin[t] = (long long)runs.size();
-                    for (long long f = type_begin[t]; f < type_begin[t + 1]; f += CHASE_RUN) {
-                        ChaseRun r; r.first = f; r.last = f + CHASE_RUN < type_begin[t + 1] ? f + CHASE_RUN : type_begin[t + 1];
-                        r.eoff = end_slots; r.type = t; r.pad = 0;
-                        end_slots += meta[(size_t)f].width;
-                        runs.push_back(r);
-                    }
-                }
-                type_run_begin[SVX_NTYPES] = (long long)runs.size();
-                const long long n_runs = (long long)runs.size();
-                SVXCHK(c->samp_table.reserve((size_t)slots * 2 + 64));
-                SVXCHK(c->samp_runs.reserve((size_t)n_runs * (sizeof(ChaseRun) + 8) + (size_t)end_slots * 8 + (SVX_NTYPES + 1) * 8 + 64));
-                SampleMeta* meta_dev = reinterpret_cast<SampleMeta*>(c->samp_meta.as<char>() + (size_t)n_large * 8);
-                ChaseRun* runs_dev = c->samp_runs.as<ChaseRun>();
-                long long* run_start_dev = reinterpret_cast<long long*>(runs_dev + n_runs);
-                long long* trb_dev = run_start_dev + n_runs;
-                long long* ends_dev = trb_dev + (SVX_NTYPES + 1);
-                HIPCHK(hipMemcpyAsync(meta_dev, meta.data(), (size_t)n_large * sizeof(SampleMeta), hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(runs_dev, runs.data(), (size_t)n_runs * sizeof(ChaseRun), hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(trb_dev, type_run_begin, sizeof type_run_begin, hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemsetAsync(err, 0, 8, st));
-                k_sample_tables<<<dim3((unsigned)((max_width + 255) / 256), (unsigned)n_large), 256, 0, st>>>(meta_dev, c->mt_words.as<uint32_t>(), c->mt_have,
-                                                                                                             c->samp_table.as<uint16_t>());
-                k_chase_runs<<<dim3((unsigned)((max_width + 255) / 256), (unsigned)n_runs), 256, 0, st>>>(meta_dev, runs_dev, c->samp_table.as<uint16_t>(), ends_dev);
-                k_chase_top<<<SVX_NTYPES, 64, 0, st>>>(meta_dev, runs_dev, trb_dev, ends_dev, run_start_dev, err, chain_dev);
-                k_chase_fill<<<GRID(n_runs, 64), 64, 0, st>>>(meta_dev, runs_dev, n_runs, c->samp_table.as<uint16_t>(), run_start_dev, samp_start);
-                k_sample_apply<<<(unsigned)n_large, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
-                                                                c->mt_words.as<uint32_t>(), c->mt_have, samp_start, c->samp_idx.as<int32_t>());
-                HIPCHK(hipGetLastError());
-                int h_err = 0;
-                HIPCHK(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));       // also covers the host vectors
-                done = !h_err;
-            }
+        {
+            double mean0[SVX_NTYPES], var0[SVX_NTYPES]; long long least0[SVX_NTYPES];
+            for (int t = 0; t < SVX_NTYPES; t++) { mean0[t] = (double)chain[t]; var0[t] = 0; least0[t] = chain[t]; }
+            SVXCHK(build_tables(mean0, var0, least0, chain_max));
+            if (plan.ok) SVXCHK(finish_tables(&done));
         }
         for (int attempt = 0; !done && attempt < 6; attempt++) {
             SVXCHK(ensure_stream(cap));
             const uint32_t* stream = c->mt_words.as<uint32_t>();
+            HIPCHK(hipMemcpyAsync(chain_dev, chain, sizeof chain, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemsetAsync(err, 0, 8, st));
             k_sample_scan<<<SVX_NTYPES, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
                                                     stream, c->mt_have, samp_start, c->samp_idx.as<int32_t>(), err, chain_dev);
@@ -1210,21 +1366,63 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
             HIPCHK(hipGetLastError());
             int h_err = 0;
             HIPCHK(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(chain + SVX_NTYPES, chain_dev + SVX_NTYPES, SVX_NTYPES * 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             if (!h_err) break;
             if (attempt == 5) return svx_fail(SVX_E_CAPACITY, "random word stream", __FILE__, __LINE__, hipSuccess);
             cap = c->mt_have * 4;
         }
-        if (c->chain_fn) {
-            HIPCHK(hipMemcpyAsync(chain, chain_dev, sizeof chain, hipMemcpyDeviceToHost, st));
+        return SVX_OK;
+    };
+    if (c->xr_world <= 1 || !c->xr_fn) {
+        SVXCHK(exact_sampling());
+    } else {
+        // speculation: tables around the EXPECTED starts (from the sizes of the earlier ranks' partitions); F = end position of this rank's chain for
+        // every candidate start of each type's first window
+        std::vector<long long> f_host;
+        auto spec_tables = [&](const double* mean0, const double* var0, const long long* least0, long long* lo, long long* width, const long long** f, bool* ok) -> int {
+            for (int t = 0; t < SVX_NTYPES; t++) { lo[t] = 0; width[t] = 0; }
+            *ok = true; *f = nullptr;
+            if (n_large == 0) return SVX_OK;
+            double mx = 0;
+            for (int t = 0; t < SVX_NTYPES; t++) mx = mean0[t] + 6.0 * sqrt(var0[t]) > mx ? mean0[t] + 6.0 * sqrt(var0[t]) : mx;
+            SVXCHK(build_tables(mean0, var0, least0, (long long)mx + 64));
+            if (!plan.ok) { *ok = false; return SVX_OK; }
+            long long f_off[SVX_NTYPES + 1]; f_off[0] = 0;
+            int wmax = 1;
+            for (int t = 0; t < SVX_NTYPES; t++) {
+                const bool has = plan.type_begin[t] < plan.type_begin[t + 1];
+                if (has) { const SampleMeta& m0 = plan.meta[(size_t)plan.type_begin[t]]; lo[t] = m0.lo; width[t] = m0.width; if (m0.width > wmax) wmax = m0.width; }
+                f_off[t + 1] = f_off[t] + width[t];
+            }
+            SVXCHK(c->tmp5.reserve((size_t)(f_off[SVX_NTYPES] + SVX_NTYPES + 2) * 8));
+            long long* f_dev = c->tmp5.as<long long>(); long long* foff_dev = f_dev + f_off[SVX_NTYPES];
+            HIPCHK(hipMemcpyAsync(foff_dev, f_off, sizeof f_off, hipMemcpyHostToDevice, st));
+            k_chase_span<<<dim3((unsigned)((wmax + 255) / 256), SVX_NTYPES), 256, 0, st>>>(plan.meta_dev, plan.runs_dev, plan.trb_dev, plan.ends_dev, foff_dev, f_dev);
+            HIPCHK(hipGetLastError());
+            f_host.resize((size_t)f_off[SVX_NTYPES] + 1);
+            HIPCHK(hipMemcpyAsync(f_host.data(), f_dev, (size_t)f_off[SVX_NTYPES] * 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-        }
+            *f = f_host.data();
+            return SVX_OK;
+        };
+        auto spec_finish = [&](const long long* start) -> int {
+            for (int t = 0; t < SVX_NTYPES; t++) chain[t] = chain[SVX_NTYPES + t] = start[t];
+            if (n_large == 0) return SVX_OK;
+            bool done = false;
+            SVXCHK(finish_tables(&done));
+            if (!done) return svx_fail(SVX_E_STATE, "stream positions left the windows their own transfer table covered", __FILE__, __LINE__, hipSuccess);
+            return SVX_OK;
+        };
+        auto exact_from = [&](const long long* start, long long* end) -> int {
+            for (int t = 0; t < SVX_NTYPES; t++) chain[t] = start[t];
+            SVXCHK(exact_sampling());
+            for (int t = 0; t < SVX_NTYPES; t++) end[t] = chain[SVX_NTYPES + t];
+            return SVX_OK;
+        };
+        SVXCHK(svx_sampling_exchange(c, n_large, plan.info.data(), spec_tables, spec_finish, exact_from));
     }
-    if (c->chain_fn) {
-        int64_t w[SVX_NTYPES];
-        for (int t = 0; t < SVX_NTYPES; t++) w[t] = chain[SVX_NTYPES + t];
-        if (c->chain_fn(c->chain_user, 1, w) != 0) return svx_fail(SVX_E_STATE, "chain callback (end positions) failed", __FILE__, __LINE__, hipSuccess);
-    }
+    for (int t = 0; t < SVX_NTYPES; t++) { c->stream_start[t] = chain[t]; c->stream_end[t] = chain[SVX_NTYPES + t]; }
     HIPCHK(hipEventRecord(c->ev[9], st));
     // ---- staging area of the per-partition clustering --------------------------------------------------------------
     const size_t SN = (size_t)(samp_total + 1);
@@ -1260,13 +1458,13 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
             s_mid = c->aux[0]; s_small = c->aux[1];
         }
         k_cluster<MAXN, MID><<<(unsigned)n_part, 64, cluster_lds(MAXN), ks>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
-                                                                          samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
+                                                                          samp_base, pair_off, c->ed.as<int32_t>(), in, p, stg,
                                                                           ncl_a, nmem_a, cnt + 10, phase);
         k_cluster<MID, SMALL><<<(unsigned)n_part, 64, cluster_lds(MID), s_mid>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
-                                                                             samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
+                                                                             samp_base, pair_off, c->ed.as<int32_t>(), in, p, stg,
                                                                              ncl_a, nmem_a, cnt + 10, phase);
         k_cluster<SMALL, 0><<<(unsigned)n_part, 64, cluster_lds(SMALL), s_small>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl,
-                                                                               samp_base, pair_off, c->ed.as<int32_t>(), in, p, sh, stg,
+                                                                               samp_base, pair_off, c->ed.as<int32_t>(), in, p, stg,
                                                                                ncl_a, nmem_a, cnt + 10, phase);
         HIPCHK(hipGetLastError());
         if (fork) {
@@ -1291,12 +1489,11 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
         if (!c->g_off_p) return svx_fail(SVX_E_STATE, "svx_set_genome must precede clustering of insertions", __FILE__, __LINE__, hipSuccess);
         SVXCHK(c->work.reserve((size_t)pair_total * sizeof(EditWork)));
         k_ins_pairs<<<(unsigned)n_part, 64, 0, st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl, pairs_a, pair_off, in, p,
-                                                    c->work.as<EditWork>(), cnt + 8, pair_total, sh, cnt + 11);
+                                                    c->work.as<EditWork>(), cnt + 8, pair_total);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_cnt, cnt, 16 * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         const int64_t n_work = (int64_t)h_cnt[8];
-        c->n_remote_members = (int64_t)h_cnt[11];
         SVXCHK(c->cell_shards.reserve(1024 * 8));
         HIPCHK(hipMemsetAsync(c->cell_shards.p, 0, 1024 * 8, st));
         SVXCHK(svx_launch_edit_pairs(c, n_work, c->work.p, in, c->ed.as<int32_t>(), c->cell_shards.as<unsigned long long>()));
@@ -1381,4 +1578,16 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
         S.n_edit_cells = (int64_t)tot;
     }
     return SVX_OK;
+}
+
+int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const int32_t* rank, const svx_params* pp) {
+    c->xr_pending = c->xr_world > 1 && c->xr_fn;
+    const int rc = svx_cluster_body(c, in, n_contig, rank, pp);
+    if (rc != SVX_OK && c->xr_pending) {                    // the other ranks wait in a header exchange this rank will never reach
+        const std::string keep = g_svx_err;
+        svx_exchange_poison(c);
+        g_svx_err = keep;
+    }
+    c->xr_pending = false;
+    return rc;
 }

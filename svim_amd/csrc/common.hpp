@@ -141,15 +141,13 @@ struct svx_ctx {
     DevBuf cell_shards;
     DevBuf geno[11]; int64_t geno_n = 0; int32_t geno_contigs = -1;      // GENOTYPE: resident alignment index + per-call candidate buffers
     DevBuf samp_meta, samp_table, samp_runs, samp_chain;    // consumption tables of the sampling walk; per-type stream positions
-    svx_chain_fn chain_fn = nullptr; void* chain_user = nullptr;      // svx_cluster_set_chain
+    int xr_rank = 0, xr_world = 1; svx_allgather_fn xr_fn = nullptr; void* xr_user = nullptr; bool xr_pending = false;   // svx_cluster_set_ranks
+    long long stream_start[SVX_NTYPES] = {0, 0, 0, 0, 0, 0}, stream_end[SVX_NTYPES] = {0, 0, 0, 0, 0, 0};              // of the last svx_cluster
     DevBuf mt_words; long long mt_have = 0;      // tempered MT19937 words after seed(1524), kept across calls
     DevBuf pair_off, ed, work, stage, stage_members, labels;
     DevBuf e_words, e_off, e_scratch, e_rec, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off;
     DevBuf e_retry[3];              // per-class retry lists of the edit-distance rounds (rotating)     // edit-distance pipeline
     DevClusters clu;
-    int shard_rank = 0, shard_world = 1, shard_mode = 0;
-    DevBuf shard_prefix;            // origin prefix (world+1 int64) for by-origin sharding
-    int64_t n_remote_members = 0;   // members of owned INS partitions produced by another rank (by-origin mode)
     // Band speculation: a pair without a useful distance bound starts in the band sized for edit_guess * (core length) differences beyond
     // the length gap.  Chosen per call from a sample of that call's own pairs (k_edit_pilot, edit.hip) - no state survives a call;
     // 0.125 is only the fallback for calls too small to sample.  Routing only: results never depend on it.  SVX_EDIT_GUESS=<fraction> pins it.
@@ -175,6 +173,7 @@ int svx_exclusive_scan_i32_to_i64(svx_ctx* c, const int32_t* in, int64_t* out, i
 // ---- stage entry points ------------------------------------------------------------------------------------
 int svx_collect_impl(svx_ctx* c, const svx_batch* b_dev, const svx_params* p);
 int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const int32_t* rank_dev, const svx_params* p);
+void svx_exchange_poison(svx_ctx* c);
 int svx_edit_prepack_begin(svx_ctx* c, const ClusterIn& in, const svx_params& p, hipEvent_t input_ready);
 int svx_edit_prepack_pack(svx_ctx* c, const ClusterIn& in);
 int svx_pair_distances_impl(svx_ctx* c, const ClusterIn& in, int64_t n_pairs, const int64_t* ia_dev, const int64_t* ib_dev, const svx_params* p, double* out_dev);

@@ -11,12 +11,14 @@ What crosses the fabric per step
      signature that belongs to another contig's owner (a BND whose canonical first end lies elsewhere, a DUP_INT inserted
      elsewhere, a DEL between two supplementary segments on another contig).  Those rows - typically none to a few per
      thousand - are exchanged (one count exchange; nothing else when every count is zero).
-  2. the random.sample stream positions: 6 x int64 from rank r to rank r+1 (ChainRelay; svx_cluster_set_chain).  The stream of
-     a type is consumed by its > 100-member partitions in global order without re-seeding (SVIM_clustering.py:129-134).
+  2. the random.sample stream positions.  The stream of a type is consumed by its > 100-member partitions in global order without
+     re-seeding (SVIM_clustering.py:129-134): rank r continues where ranks 0..r-1 stop.  svx_cluster finds its start positions itself
+     with all-gathers only (svx_cluster_set_ranks; TorchAllGather is the transport): the sizes of everybody's large partitions, then every
+     rank's transfer table "position before my partitions -> position after them" - no rank waits for another rank's sampling.
   3. the final candidate gather to rank 0: cluster records, member lists, and the fixed-width signature columns.
 Signature columns of ordinary (non-foreign) signatures and inserted sequences never leave their rank before the final gather.
 
-The same code runs on CPU tensors over gloo with the oracle as stand-in engine (tests/test_distributed_gloo.py).
+The same code runs on CPU tensors over gloo with the oracle as stand-in engine (tests/test_multigpu_gloo.py).
 """
 import numpy as np
 
@@ -51,26 +53,42 @@ def owner_contig(typ, contig, contig2):
     return torch.where(is_dup_int, contig2, contig)
 
 
-class ChainRelay(object):
-    """The callback of svx_cluster_set_chain: receive the six stream start positions from rank-1, hand the six end positions to
-    rank+1 (48 bytes each way per step)."""
+class TorchAllGather(object):
+    """The transport svx_cluster_set_ranks asks for: all-gather of a small byte string over torch.distributed (one all_gather_into_tensor;
+    "nccl" = RCCL on device tensors, gloo on CPU tensors)."""
 
-    def __init__(self, rank, world, device="cpu"):
-        self.rank, self.world, self.device = rank, world, device
-        self.last = None
+    def __init__(self, world, device="cpu"):
+        self.world, self.device = world, device
+        self.calls, self.bytes = 0, 0
 
-    def __call__(self, phase, words):
+    def __call__(self, send):
         import torch
         import torch.distributed as dist
-        if phase == 0:
-            if self.rank > 0:
-                t = torch.zeros(6, dtype=torch.int64, device=self.device)
-                dist.recv(t, src=self.rank - 1)
-                words[:] = [int(x) for x in t.tolist()]
-        else:
-            self.last = list(words)
-            if self.rank + 1 < self.world:
-                dist.send(torch.tensor(words, dtype=torch.int64, device=self.device), dst=self.rank + 1)
+        n = len(send)
+        dev = self.device if dist.get_backend() == "nccl" else "cpu"
+        t = torch.frombuffer(bytearray(send), dtype=torch.uint8).to(dev)
+        out = torch.empty(n * self.world, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out, t)
+        self.calls += 1
+        self.bytes += n * self.world
+        return out.cpu().numpy().tobytes()
+
+
+class _CountingRandom(__import__("random").Random):
+    """CPython's own generator (the one the reference uses) counting the 32-bit words it hands out: every getrandbits(k <= 32) is one word"""
+    words = 0
+
+    def getrandbits(self, k):
+        self.words += 1
+        return super().getrandbits(k)
+
+
+def stream_words_after(sizes):
+    """32-bit words random.seed(1524) ... random.sample(range(n), 100) for n in sizes ... has consumed (src/svim/SVIM_clustering.py:129-134)"""
+    r = _CountingRandom(1524)
+    for n in sizes:
+        r.sample(range(int(n)), 100)
+    return r.words
 
 
 def barrier():
@@ -83,12 +101,19 @@ def barrier():
         dist.barrier()
 
 
+def _wire(device):
+    """device the collectives run on: the tensors' own under RCCL; the host under gloo (a two-process test on one GPU stages through it)"""
+    import torch.distributed as dist
+    return device if dist.get_backend() == "nccl" else "cpu"
+
+
 def _all_gather_counts(values, device):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
-    t = torch.tensor(values, dtype=torch.int64, device=device)
-    out = torch.zeros(world * len(values), dtype=torch.int64, device=device)
+    w = _wire(device)
+    t = torch.tensor(values, dtype=torch.int64, device=w)
+    out = torch.zeros(world * len(values), dtype=torch.int64, device=w)
     dist.all_gather_into_tensor(out, t)
     return out.view(world, len(values)).tolist()
 
@@ -98,10 +123,12 @@ def _all_gather_rows(t, counts):
     import torch
     import torch.distributed as dist
     mx = max(max(counts), 1)
-    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    w = _wire(t.device)
+    pad = torch.zeros(mx, dtype=t.dtype, device=w)
     pad[:t.numel()] = t
-    out = torch.empty(mx * len(counts), dtype=t.dtype, device=t.device)
+    out = torch.empty(mx * len(counts), dtype=t.dtype, device=w)
     dist.all_gather_into_tensor(out, pad)
+    out = out.to(t.device)
     return [out[r * mx:r * mx + c] for r, c in enumerate(counts)]
 
 
@@ -110,12 +137,13 @@ def _gather_to_root(t, counts, rank):
     import torch
     import torch.distributed as dist
     mx = max(max(counts), 1)
-    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    w = _wire(t.device)
+    pad = torch.zeros(mx, dtype=t.dtype, device=w)
     pad[:t.numel()] = t
     if rank == 0:
-        bufs = [torch.empty(mx, dtype=t.dtype, device=t.device) for _ in counts]
+        bufs = [torch.empty(mx, dtype=t.dtype, device=w) for _ in counts]
         dist.gather(pad, bufs, dst=0)
-        return torch.cat([b[:c] for b, c in zip(bufs, counts)])
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)]).to(t.device)
     dist.gather(pad, None, dst=0)
     return None
 
@@ -166,8 +194,21 @@ class SvxAdapter(object):
         import torch
         torch.cuda.synchronize()
 
-    def set_chain(self, relay):
-        self.eng.set_chain(relay)
+    def begin_step(self, rank, world):
+        """the engine finds its stream start positions inside svx_cluster, over this transport"""
+        self.transport = TorchAllGather(world, self.device) if world > 1 else None
+        self._entered = False
+        self.eng.set_ranks(rank, world, self.transport)
+
+    def end_step(self):
+        self.eng.set_ranks(0, 1, None)
+
+    def abort(self):
+        if not self._entered:           # svx_cluster itself tells the others when it fails; after it nobody waits in the exchange any more
+            self.eng.abort_ranks()
+
+    def stream_end(self):
+        return self.eng.stream_positions()[1]
 
     def collect_counts(self):
         n, nseq, _ = self.eng.collect_counts()
@@ -195,6 +236,7 @@ class SvxAdapter(object):
     def cluster(self, params, contig_rank, table=None):
         """table None: the resident COLLECT result (source 0); else (cols, seq_off, seq) device tensors (source 2)"""
         import torch
+        self._entered = True
         if table is None:
             self.eng.cluster(params, contig_rank, source=0, fetch=False)
             return
@@ -216,9 +258,24 @@ class SvxAdapter(object):
         self._keep = keep
 
     def fetch_clusters(self):
-        from .distributed import fetch_clusters_device
-        cols, members, part_index = fetch_clusters_device(self.eng, self.device)
-        return cols, members
+        """this rank's cluster table as device tensors (svx_cluster_fetch with device destinations): (cols, members)"""
+        import ctypes as C
+        import torch
+        from ._lib import _check
+        eng, dev = self.eng, self.device
+        n, nm = C.c_int64(), C.c_int64()
+        _check(eng.L.svx_cluster_count(eng.ctx, C.byref(n), C.byref(nm)), "svx_cluster_count")
+        n, nm = n.value, nm.value
+        cols = {k: torch.empty(max(1, n), dtype=_tdtype(dt), device=dev) for k, dt in CLU_DTYPES.items()}
+        member_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        members = torch.empty(max(1, nm), dtype=torch.int32, device=dev)
+        cv = _abi.ClusterView()
+        cv.n = n
+        for k in CLU_DTYPES:
+            setattr(cv, k, _abi.ptr(cols[k]))
+        cv.member_off, cv.members = _abi.ptr(member_off), _abi.ptr(members)
+        _check(eng.L.svx_cluster_fetch(eng.ctx, C.byref(cv)), "svx_cluster_fetch")
+        return {k: v[:n] for k, v in cols.items()}, members[:nm]
 
 
 class HostAdapter(object):
@@ -231,8 +288,41 @@ class HostAdapter(object):
     def sync(self):
         pass
 
-    def set_chain(self, relay):
-        self.engine.set_chain(relay)
+    def begin_step(self, rank, world):
+        self.rank, self.world = rank, world
+        self._ends = None
+
+    def end_step(self):
+        self.engine.set_chain(None)
+
+    def abort(self):
+        pass
+
+    def stream_end(self):
+        return self._ends
+
+    def _chain(self, phase, words):
+        if phase == 0:
+            words[:] = self._starts
+        else:
+            self._ends = list(words)
+
+    def _exchange_stream_starts(self, tab, params, contig_rank):
+        """The checker's version of what svx_cluster does internally: all ranks publish the sizes of their > 100-member partitions per type
+        (sorted order), and every rank replays the consumption of the ranks before it with CPython's own generator."""
+        import torch.distributed as dist
+        sizes = [[] for _ in range(6)]
+        if tab.n:
+            sidx, pid = self.engine.form_partitions(tab, contig_rank, int(params.partition_max_distance))
+            typ = tab.type[:tab.n][sidx]
+            cut = np.nonzero(np.diff(pid))[0] + 1
+            for a, b in zip(np.concatenate([[0], cut]), np.concatenate([cut, [tab.n]])):
+                if b - a > 100:
+                    sizes[int(typ[a])].append(int(b - a))
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, sizes)
+        self._starts = [stream_words_after([n for r in range(self.rank) for n in everyone[r][t]]) for t in range(6)]
+        self.engine.set_chain(self._chain)
 
     def collect_counts(self):
         return self.sig.n, int(self.sig.seq_off[self.sig.n])
@@ -260,6 +350,11 @@ class HostAdapter(object):
             tab.seq_off[:] = seq_off.numpy()
             if seq.numel():
                 tab.seq[:seq.numel()] = seq.numpy()
+        if getattr(self, "world", 1) > 1:
+            self._exchange_stream_starts(tab, params, contig_rank)
+        else:
+            self._starts = [0] * 6
+            self.engine.set_chain(self._chain)
         self.ct = self.engine.cluster(params, contig_rank, table=tab)
 
     def fetch_clusters(self):
@@ -323,8 +418,21 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
         run = (torch.searchsorted(kr_local, key >> 32, right=True) - 1).clamp_min(0)
         return key + (kr_delta[run] << 32)
 
-    relay = ChainRelay(rank, world, dev)
-    adapter.set_chain(relay)
+    adapter.begin_step(rank, world)
+    try:
+        return _cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, owner_of_contig, gather_signatures, names_of, ids_of,
+                             read_base, gid, owner_t, global_keys, dev)
+    except BaseException:
+        adapter.abort()               # the other ranks must not wait for this one in the rank exchange of svx_cluster
+        raise
+    finally:
+        adapter.end_step()
+
+
+def _cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, owner_of_contig, gather_signatures, names_of, ids_of, read_base, gid,
+                  owner_t, global_keys, dev):
+    import torch
+    import torch.distributed as dist
     n_own, _ = adapter.collect_counts()
     # ---- 1. foreign signatures --------------------------------------------------------------------------------------------
     cols = seq_off = seq = None
@@ -457,7 +565,7 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
             empty = {k: torch.zeros(0, dtype=_tdtype(SIG_DTYPES[k]), device=dev) for k in SIG_COLS}
             src = cols if cols is not None else empty
             g_sig = _gather_table_to_root(src, list(SIG_COLS), sig_counts, rank)
-    adapter.set_chain(None)
+    chain_end = adapter.stream_end()
     if rank != 0:
         return None
     # rank-major concatenation -> type-major: a stable sort by type keeps, inside a type, rank order and each rank's own order -
@@ -472,4 +580,4 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
     torch.cumsum(out_sizes, 0, out=member_off[1:])
     nm = int(g_mem.numel())
     src_idx = torch.repeat_interleave(src_off[order] - member_off[:-1], out_sizes) + torch.arange(nm, dtype=torch.int64, device=dev)
-    return StepResult(out_cols, member_off, g_mem[src_idx], g_sig, sig_counts, relay.last)
+    return StepResult(out_cols, member_off, g_mem[src_idx], g_sig, sig_counts, chain_end)

@@ -246,3 +246,27 @@ def first_json_difference(got, exp, rtol=1e-9, path="$"):
                 return d
         return None
     return None if got == exp else "%s: %r != %r" % (path, got, exp)
+
+
+class ThreadAllGather(object):
+    """In-process stand-in for the all-gather transport of svx_cluster_set_ranks: `world` threads meet at a barrier."""
+
+    def __init__(self, world, timeout=120):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world, timeout=timeout)
+        self.slots = [None] * world
+        self.calls = 0
+
+    def for_rank(self, r):
+        def allgather(send):
+            self.slots[r] = bytes(send)
+            self.barrier.wait()
+            out = b"".join(self.slots)
+            self.barrier.wait()
+            self.calls += 1
+            return out
+        return allgather
+
+    def abort(self):
+        self.barrier.abort()

@@ -144,7 +144,6 @@ def test_cluster_golden_and_oracle(eng, oracle, idx):
     oracle.set_genome(off, codes)
     oc = oracle.cluster(p, rank, table=tab)
     assert ct.first_difference(oc, rtol=1e-12) is None
-    assert np.array_equal(ct.part_index, oc.part_index)
 
 
 def test_sampling_many_partition_sizes_vs_oracle(eng, oracle):
@@ -213,13 +212,7 @@ def test_collect_then_cluster_resident_vs_oracle(eng, oracle):
         oc = oracle.cluster(p, hb.contig_rank, source=source)
         assert ct.n > 0
         assert ct.first_difference(oc, rtol=1e-12) is None
-    # sharded (world 2): the union of both shards, merged by partition index, is the unsharded result
-    full = eng.cluster(p, hb.contig_rank, source=0, shard=(0, 1))
-    parts = [eng.cluster(p, hb.contig_rank, source=0, shard=(r, 2)) for r in range(2)]
-    eng.cluster(p, hb.contig_rank, source=0, shard=(0, 1), fetch=False)
-    from svim_amd.distributed import merge_cluster_tables
-    merged = merge_cluster_tables(parts, hb.contig_rank)
-    assert merged.first_difference(full) is None
+
 
 
 def test_dropin_api_matches_reference_golden(eng):
@@ -258,7 +251,7 @@ def test_dropin_api_matches_reference_golden(eng):
 def test_multigpu_step_single_rank_device_path(eng, oracle):
     """bench.py's multi-GPU step (svim_amd/multigpu.py: SvxAdapter, everything device-resident, RCCL process group of one rank) must
     reproduce the plain single-GPU result, both when it clusters the resident table (no foreign rows: the bench layout) and when it
-    is handed a table of device tensors (the route taken after an exchange of foreign rows); the stream relay hook reports where the
+    is handed a table of device tensors (the route taken after an exchange of foreign rows); svx_cluster_stream_positions reports where the
     random.sample streams ended."""
     import os
     import socket
@@ -295,20 +288,12 @@ def test_multigpu_step_single_rank_device_path(eng, oracle):
         assert np.array_equal(res.sig_cols["key"].cpu().numpy().view(np.uint64), sig.key[:sig.n])
         # the table route: the same signatures handed over as device tensors
         cols, seq_off, seq = ad.fetch_signatures()
-        relay_log = []
-        eng.set_chain(lambda phase, w: relay_log.append((phase, list(w))))
         ad.cluster(p, crank, table=(cols, seq_off, seq))
-        eng.set_chain(None)
         again = eng.fetch_clusters()
         assert again.first_difference(direct) is None
-        assert [ph for ph, _ in relay_log] == [0, 1] and relay_log[0][1] == [0] * 6
-        # continuing every stream from an offset changes the samples of the large partitions - and only because of that offset
-        eng.set_chain(lambda phase, w: w.__setitem__(slice(None), [1000] * 6) if phase == 0 else relay_log.append((2, list(w))))
-        eng.cluster(p, crank, source=0, fetch=False)
-        eng.set_chain(None)
-        ends0, ends1 = relay_log[1][1], relay_log[2][1]
-        assert all((e1 == 1000 and e0 == 0) or e1 > 1000 for e0, e1 in zip(ends0, ends1))
-        # and the device-generated batch agrees with the oracle, relay included
+        starts0, ends0 = eng.stream_positions()
+        assert starts0 == [0] * 6 and max(ends0) > 100                     # large partitions consumed the seed(1524) streams from their beginning
+        # and the device-generated batch agrees with the oracle, stream positions included
         oracle.set_genome(g_off.cpu().numpy().astype(np.int64), genome.cpu().numpy())
         hb = b.slice_records(0, b.n_rec)
         osig, _ = oracle.collect(hb, p)
@@ -590,50 +575,6 @@ def test_partition_and_cluster_candidates_matches_reference(eng):
     for a, b in zip(got, g["merged_candidates"]):
         assert a[:7] == b[:7] and a[9:] == b[9:], (a, b)
         assert H.close(a[7], b[7]) and H.close(a[8], b[8])
-
-
-def test_shard_by_origin_two_virtual_ranks(eng, oracle):
-    """By-origin ownership (contig-sharded multi-GPU fast path), emulated on one GPU: rank 0 'collected' the chr1 records,
-    rank 1 the rest; each virtual rank sees the rank-major table with ONLY ITS OWN inserted sequences and clusters the
-    partitions it owns; the merged result equals the unsharded run."""
-    from svim_amd.distributed import concat_sig_tables, merge_cluster_tables
-    bam, refs, references = _planted_case(91, 1500, 40)
-    recs = list(bam.fetch(until_eof=True))
-    o = H.options({"min_mapq": 20, "min_sv_size": 40, "max_sv_size": 100000, "segment_gap_tolerance": 10, "segment_overlap_tolerance": 5,
-                   "partition_max_distance": 1000, "position_distance_normalizer": 900, "edit_distance_normalizer": 1.0,
-                   "cluster_max_distance": 0.5, "all_bnds": False})
-    p = _abi.Params.from_options(o)
-    off, codes = convert.genome_arrays(refs, references)
-    eng.set_genome(off, codes)
-    groups = [[a for a in recs if a.reference_id == 0], [a for a in recs if a.reference_id != 0]]
-    tabs, names = [], []
-    for grp in groups:
-        hb = batch.build_batch(bam, o, mode="coordinate", records=grp)
-        sig, _ = eng.collect(hb, p)
-        # keep only signatures that live entirely on this rank's contigs (split reads may bridge contigs)
-        sig.read_id = sig.read_id + len(names)
-        names += hb.read_names
-        tabs.append(sig)
-    full_tab = concat_sig_tables(tabs)
-    rank_arr = batch.contig_ranks(references)
-    full = eng.cluster(p, rank_arr, table=full_tab, shard=(0, 1))
-    prefix = np.array([0, tabs[0].n, tabs[0].n + tabs[1].n], dtype=np.int64)
-    parts, remote = [], []
-    for r in range(2):
-        local = concat_sig_tables(tabs)
-        lens = np.diff(local.seq_off)
-        lo, hi = int(prefix[r]), int(prefix[r + 1])
-        lens[:lo] = 0
-        lens[hi:] = 0                                   # remote sequences are NOT available on this rank
-        own = tabs[r]
-        local.seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        local.seq = own.seq[:max(1, int(own.seq_off[own.n]))].copy()
-        parts.append(eng.cluster(p, rank_arr, table=local, shard=(r, 2), origin_prefix=prefix))
-        remote.append(eng.remote_members())
-    eng.cluster(p, rank_arr, table=full_tab, shard=(0, 1), fetch=False)
-    assert remote == [0, 0]
-    merged = merge_cluster_tables(parts, rank_arr)
-    assert merged.first_difference(full) is None
 
 
 def test_edit_distance_full_matrix_classes_vs_oracle(eng, oracle):
@@ -951,3 +892,159 @@ def test_c1_config0_full_size_through_bam_file(eng, tmp_path):
     got = [[[c.contig, c.start, c.end, c.score, c.size, c.std_span, c.std_pos, [idx[id(m)] for m in c.members]] for c in lst] if k < 3 else [] for k, lst in enumerate(res)]
     assert all(len(lst) == 0 for lst in res[3:])
     H.compare_cluster_rows(got, g["clusters"])
+
+
+def _large_partition_table(drop_set_method):
+    """g5's 'stress31' signature list (3 contigs, 35 partitions beyond 100 members, all six types; three DEL partitions of 1045 / 1046 / 3000 members);
+    drop_set_method: without the two partitions beyond 1045 members (random.sample's set method)"""
+    g5 = H.load("g5_cluster.json.gz")
+    case = [c for c in g5["cases"] if c["name"] == "stress31"][0]
+    rows = case["signatures"]
+    if drop_set_method:
+        rows = [r for r in rows if not (r[0] == "DEL" and r[1] == g5["references"][0] and (39000 <= r[2] <= 41500 or 59000 <= r[2] <= 61500))]
+    sigs = [H.row_sig(r) for r in rows]
+    tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(g5["references"]))
+    return g5, H.options(case["options"]), tab, contigs
+
+
+def _split_by_owner(tab, owner):
+    """per-rank tables holding the rows whose partition key contig belongs to the rank (no foreign rows), emission order kept"""
+    from svim_amd import multigpu
+    n = tab.n
+    own = owner[multigpu.owner_contig(tab.type[:n], tab.contig[:n], np.where(tab.contig2[:n] >= 0, tab.contig2[:n], tab.contig[:n]))]
+    out = []
+    for r in range(int(owner.max()) + 1):
+        idx = np.nonzero(own == r)[0]
+        ln = tab.seq_off[idx + 1] - tab.seq_off[idx]
+        t = _abi.SigTable(len(idx), int(ln.sum()))
+        for k in _abi.SIG_DTYPES:
+            getattr(t, k)[:] = getattr(tab, k)[idx]
+        t.seq_off[1:] = np.cumsum(ln)
+        pos = 0
+        for i, l in zip(idx, ln):
+            t.seq[pos:pos + l] = tab.seq[tab.seq_off[i]:tab.seq_off[i] + l]
+            pos += int(l)
+        out.append(t)
+    return out
+
+
+@pytest.mark.parametrize("mode", ["transfer tables", "forced exact rounds", "set-method partitions"])
+def test_rank_exchange_three_contexts_on_one_gpu(oracle, monkeypatch, mode):
+    """svx_cluster_set_ranks: three contexts on cuda:0, one thread each, stand for three contig-sharded ranks; the all-gather
+    transport is an in-process barrier.  Every rank must find - with all-gathers only - the stream positions the serial order implies
+    (src/svim/SVIM_clustering.py:129-134), i.e. produce the clusters the oracle produces when it is TOLD those positions (computed here with CPython's
+    own generator), and all ranks together the single-process result.  Three protocol paths: composed transfer tables (no partition beyond 1045
+    members), the exact rank-after-rank rounds forced on the same input, and the rounds chosen because set-method partitions exist.  A fourth rank
+    without signatures takes part with an empty table."""
+    import threading
+    from svim_amd import _lib, multigpu
+    g5, o, tab, contigs = _large_partition_table(drop_set_method=(mode != "set-method partitions"))
+    if mode == "forced exact rounds":
+        monkeypatch.setenv("SVX_RANKS_EXACT", "1")
+    world = 4
+    p = _abi.Params.from_options(o)
+    crank = batch.contig_ranks(contigs.names)
+    off, codes = convert.genome_arrays(o.genome, contigs.names)
+    owner = np.asarray([0, 2, 1], dtype=np.int32)                          # name order chr1 < chr10 < chr2: ranks own consecutive ranges of it; rank 3 owns nothing
+    assert [contigs.names[i] for i in np.argsort(crank)] == sorted(contigs.names) and list(owner[np.argsort(crank)]) == [0, 1, 2]
+    locals_ = _split_by_owner(tab, owner) + [_abi.SigTable(0, 0)]
+    ag = H.ThreadAllGather(world)
+    results, errors = [None] * world, []
+
+    def work(r):
+        try:
+            eng = _lib.Engine(0)
+            eng.set_genome(off, codes)
+            eng.set_ranks(r, world, ag.for_rank(r))
+            ct = eng.cluster(p, crank, table=locals_[r])
+            results[r] = (ct, eng.stream_positions())
+            eng.set_ranks(0, 1, None)
+            eng.close()
+        except BaseException as e:                                         # noqa: B902
+            errors.append((r, e))
+            ag.abort()
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    # expected: the oracle on every rank's table, told the start positions the serial order implies
+    oracle.set_genome(off, codes)
+    sizes = []
+    for r in range(world):
+        per_type = [[] for _ in range(6)]
+        t = locals_[r]
+        if t.n:
+            sidx, pid = oracle.form_partitions(t, crank, int(p.partition_max_distance))
+            typ = t.type[:t.n][sidx]
+            cut = np.nonzero(np.diff(pid))[0] + 1
+            for a, b in zip(np.concatenate([[0], cut]), np.concatenate([cut, [t.n]])):
+                if b - a > 100:
+                    per_type[int(typ[a])].append(int(b - a))
+        sizes.append(per_type)
+    assert sum(len(x) for per_type in sizes for x in per_type) >= 25 and sum(1 for per_type in sizes if any(per_type)) >= 3
+    total = 0
+    for r in range(world):
+        starts = [multigpu.stream_words_after([n for q in range(r) for n in sizes[q][t]]) for t in range(6)]
+        log = []
+        oracle.set_chain(lambda phase, w, starts=starts: w.__setitem__(slice(None), starts) if phase == 0 else log.append(list(w)))
+        oc = oracle.cluster(p, crank, table=locals_[r])
+        oracle.set_chain(None)
+        ct, (got_start, got_end) = results[r]
+        assert got_start == starts, (r, got_start, starts)
+        assert got_end == (log[0] if log else starts), (r, got_end, log)
+        assert ct.first_difference(oc, rtol=1e-12) is None, r
+        total += ct.n
+    # and all ranks together: the single-process result (no partition spans ranks)
+    full = oracle.cluster(p, crank, table=tab)
+    assert total == full.n
+    assert ag.calls >= 2 * world
+
+
+def test_two_ranks_share_one_gpu_over_gloo():
+    """N > 1 on hardware within the one-GPU box: two processes (torch.distributed.run, backend gloo - RCCL refuses two ranks on one device) both on
+    cuda:0 run the contig-sharded step with the real engine and device tensors: foreign BND rows cross the ranks, svx_cluster's rank exchange
+    (svx_cluster_set_ranks) runs over the process group, rank 0 gathers; checked against the oracle on the union of both inputs
+    (tests/mp_two_ranks_one_gpu.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(here, "mp_two_ranks_one_gpu.py")],
+                         capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("TWO_RANKS_")]
+    assert out.returncode == 0 and lines, (out.stdout[-1500:], out.stderr[-3000:])
+    assert lines[-1].startswith("TWO_RANKS_OK"), lines[-1]
+    _, n_clusters, n_cross, n_foreign = lines[-1].split()
+    assert int(n_clusters) > 100 and int(n_cross) > 5 and int(n_foreign) > 0
+
+
+def test_bench_two_ranks_one_gpu_with_foreign_rows():
+    """bench.py --gpus 2 --workload c2 --foreign-frac 0.5 as the driver launches it, but with both ranks on cuda:0 over gloo (SVX_BENCH_BACKEND): the
+    timed step carries foreign rows and the rank exchange; ONE JSON line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SVX_BENCH_BACKEND="gloo", SVX_BENCH_ONE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--workload", "c2", "--scale", "0.02", "--foreign-frac", "0.5", "--partition-max-distance", "5000"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["multi_gpu"]["foreign_segments_planted_rank0"] > 0
+    assert d["multi_gpu"]["clusters_gathered"] > 100 and len(d["multi_gpu"]["signatures_per_rank"]) == 2

@@ -156,26 +156,6 @@ def test_table_object_roundtrip():
         convert.sigtable_from_objects([SignatureInsertion("chr1", 10, 20, "cigar", "r", "ACGU")])
 
 
-def test_shard_merge_equals_unsharded(oracle):
-    """Multi-GPU decomposition checked with the oracle as the stand-in compute engine."""
-    from svim_amd.distributed import merge_cluster_tables
-    g = H.load("g5_cluster.json.gz")
-    case = g["cases"][-1]
-    o = H.options(case["options"])
-    sigs = [H.row_sig(r) for r in case["signatures"]]
-    tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(H.REFS))
-    off, codes = convert.genome_arrays(o.genome, contigs.names)
-    oracle.set_genome(off, codes)
-    rank = batch.contig_ranks(contigs.names)
-    p = _abi.Params.from_options(o)
-    full = oracle.cluster(p, rank, table=tab, shard=(0, 1))
-    for world in (2, 3):
-        parts = [oracle.cluster(p, rank, table=tab, shard=(r, world)) for r in range(world)]
-        merged = merge_cluster_tables(parts, rank)
-        assert merged.first_difference(full) is None
-    oracle.cluster(p, rank, table=tab, shard=(0, 1))
-
-
 @pytest.mark.parametrize("mode", ["coordinate", "queryname"])
 def test_native_bam_reader_matches_python_batcher(tmp_path, mode):
     """The C++ BAM front-end (BGZF inflate + record decode + SA / grouping rules) builds the same record batch as the

@@ -1,6 +1,6 @@
 """world_size-4 gloo tests of the contig-sharded multi-GPU step (svim_amd/multigpu.py) on CPU tensors, the oracle standing in for the
-GPU engine: contig ownership, the exchange of foreign signatures, the random.sample stream relay across ranks (svx_cluster_set_chain
-contract, implemented by the oracle as svo_cluster_set_chain) and the final gather must reproduce the single-process result - cluster
+GPU engine: contig ownership, the exchange of foreign signatures, the random.sample stream positions across ranks (the product finds them inside
+svx_cluster - svx_cluster_set_ranks -, the oracle is told them through svo_cluster_set_chain by HostAdapter, which replays CPython's generator) and the final gather must reproduce the single-process result - cluster
 records bit-identical, member lists identical as sets of emission keys in order."""
 import os
 import socket
@@ -85,7 +85,7 @@ def _worker_signatures(rank, world, port, ret):
         n_foreign = int((owner[multigpu.owner_contig(local.type, local.contig, local.contig2)] != rank).sum()) if local.n else 0
         ad = multigpu.HostAdapter(orc, local)
         res = multigpu.cluster_step(ad, p, rank, world, np.arange(len(contigs.names)), crank, owner)
-        ret["chain%d" % rank] = max(ad.engine._last_chain_end) if getattr(ad.engine, "_last_chain_end", None) else -1
+        ret["chain%d" % rank] = max(ad.stream_end()) if ad.stream_end() else -1
         if rank == 0:
             verdict = _compare(res, full, tab.key[:n].astype(np.int64))
             ret[0] = verdict if verdict != "ok" else ("ok" if sum(res.sig_counts) == n and orc.stats()["n_large_partitions"] >= 0 else "counts")
