@@ -13,6 +13,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <exception>
 #include <chrono>
 #include <cstdlib>
 #include <future>
@@ -329,6 +330,9 @@ static void inflate_next_chunk(svx_bam* h) {
                 } catch (const std::string& e) {
                     gpu_err = e;
                     for (int sl = 0; sl < 3; sl++) if (used[sl]) (void)svx_inflater_wait(h->gpu, sl, nullptr);
+                } catch (const std::exception& e) {
+                    gpu_err = std::string("GPU inflate feeder: ") + e.what();
+                    for (int sl = 0; sl < 3; sl++) if (used[sl]) (void)svx_inflater_wait(h->gpu, sl, nullptr);
                 }
             });
             const int n_workers = std::max(1, h->n_threads);
@@ -337,6 +341,7 @@ static void inflate_next_chunk(svx_bam* h) {
             h->pool_inflate->run(n_workers, [&](int t) {
                 try { size_t a, b; while (take(false, 8, a, b)) { for (size_t i = a; i < b; i++) inflate_block(blocks[i], out_base + blocks[i].out_at); done[(size_t)t] += (int64_t)(b - a); } }
                 catch (const std::string& e) { errs[(size_t)t] = e; }
+                catch (const std::exception& e) { errs[(size_t)t] = std::string("inflate worker: ") + e.what(); }
             });
             feeder.join();
             h->gpu_blocks += n_gpu; h->gpu_kernel_ms += ms_gpu;
@@ -351,9 +356,11 @@ static void inflate_next_chunk(svx_bam* h) {
         h->pool_inflate->run(n_tasks, [&](int t) {
             try { for (size_t i = (size_t)t * 8; i < blocks.size() && i < (size_t)(t + 1) * 8; i++) inflate_block(blocks[i], h->next.data() + WIN_HEAD + blocks[i].out_at); }
             catch (const std::string& e) { errs[(size_t)t] = e; }
+            catch (const std::exception& e) { errs[(size_t)t] = std::string("inflate worker: ") + e.what(); }
         });
         for (auto& e : errs) if (!e.empty()) throw e;
     } catch (const std::string& e) { h->prefetch_err = e; }
+      catch (const std::exception& e) { h->prefetch_err = std::string("inflate: ") + e.what(); }
 }
 
 static void start_prefetch(svx_bam* h) {
@@ -660,16 +667,21 @@ static void scan_aux(const uint8_t* q, const uint8_t* end, const char*& sa, size
     while (q + 3 <= end) {
         const char t0 = (char)q[0], t1 = (char)q[1], ty = (char)q[2]; q += 3;
         size_t sz = 0;
+        const size_t left = (size_t)(end - q);
         switch (ty) {
             case 'A': case 'c': case 'C': sz = 1; break;
             case 's': case 'S': sz = 2; break;
             case 'i': case 'I': case 'f': sz = 4; break;
             case 'Z': case 'H': { const uint8_t* z = (const uint8_t*)memchr(q, 0, (size_t)(end - q)); if (!z) throw std::string("unterminated aux string");
                 if (t0 == 'S' && t1 == 'A' && ty == 'Z') { sa = (const char*)q; sa_n = (size_t)(z - q); } sz = (size_t)(z - q) + 1; break; }
-            case 'B': { const char sub = (char)q[0]; const uint32_t cnt = rd32(q + 1); const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                if (t0 == 'C' && t1 == 'G' && sub == 'I') { cg = q + 5; cg_n = cnt; } sz = 5 + es * cnt; break; }
+            case 'B': { if (left < 5) throw std::string("truncated BAM aux array");
+                const char sub = (char)q[0]; const uint32_t cnt = rd32(q + 1); const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                sz = 5 + es * (size_t)cnt;
+                if (sz > left) throw std::string("BAM aux array runs past the end of its record");
+                if (t0 == 'C' && t1 == 'G' && sub == 'I') { cg = q + 5; cg_n = cnt; } break; }
             default: throw std::string("unknown BAM aux type");
         }
+        if (sz > left) throw std::string("BAM aux field runs past the end of its record");
         q += sz;
     }
 }
@@ -706,7 +718,7 @@ static int64_t decode_run(svx_bam* h, int64_t max_count, bool sparse) {
         if (rr.n_cig == 2 && (rd32(rr.cig) & 15) == 4 && (rd32(rr.cig) >> 4) == l_seq && (rd32(rr.cig + 4) & 15) == 3) {
             const char* sa; size_t sa_n; const uint8_t* cg; uint32_t cg_n;
             scan_aux(rr.cig + 8 + (l_seq + 1) / 2 + l_seq, rr.end, sa, sa_n, cg, cg_n);
-            if (cg) { rr.cig = cg; rr.n_cig = cg_n; }
+            if (cg) { if (cg + 4 * (size_t)cg_n > rr.end) throw std::string("corrupt CG tag"); rr.cig = cg; rr.n_cig = cg_n; }
         }
         cig_total += rr.n_cig;
         B.cigar_off.push_back(cig_total);
@@ -767,6 +779,7 @@ static int64_t decode_run(svx_bam* h, int64_t max_count, bool sparse) {
                 }
             }
         } catch (const std::string& e) { errs[(size_t)t] = e; }
+          catch (const std::exception& e) { errs[(size_t)t] = std::string("decode worker: ") + e.what(); }
     });
     for (auto& e : errs) if (!e.empty()) throw e;
     // (3) offsets of the kept ranges and their bytes
@@ -857,6 +870,7 @@ static void clear_batch(svx_bam* h) {
 // arrays stay valid until the next call.  *n_out = 0 at end of file.  mode 0 = coordinate-sorted rules
 // (src/svim/SVIM_COLLECT.py:132-167), 1 = query-name-sorted rules (:96-129).
 extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int min_mapq, svx_batch* out, int64_t* n_out) {
+    BatchArrays* const handed_out = h->b;                                                 // the set the previous call handed out: the caller may still upload from it
     try {
         h->b = &h->ba[h->b == &h->ba[0] ? 1 : 0];                                        // the previous batch stays valid during this read
         clear_batch(h);
@@ -885,6 +899,13 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
             }
         }
         *n_out = n;
+        if (n == 0) {
+            // end of a region / of the file: nothing is handed out, so the sets must NOT alternate - the next read (after svx_bam_seek to another
+            // region) has to fill THIS set again, not the one that still holds the last batch of the region that just ended
+            memset(out, 0, sizeof *out);
+            h->b = handed_out;
+            return SVX_OK;
+        }
         h->b->order.assign((size_t)n, 0); h->b->seg_order.assign((size_t)n, 0); h->b->seg_off.assign((size_t)n + 1, 0);
         if (mode == 0) {
             for (int64_t i = 0; i < n; i++) {
@@ -957,7 +978,8 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
             (void)svx_inflater_pin(h->gpu, h->b->cigar.data(), h->b->cigar.cap * sizeof(uint32_t));
             (void)svx_inflater_pin(h->gpu, h->b->seq.data(), h->b->seq.cap);
         }
-    } catch (const std::string& e) { return bam_fail(SVX_E_ARG, e); }
+    } catch (const std::string& e) { h->b = handed_out; return bam_fail(SVX_E_ARG, e); }
+      catch (const std::exception& e) { h->b = handed_out; return bam_fail(SVX_E_ARG, std::string("reader: ") + e.what()); }
     return SVX_OK;
 }
 

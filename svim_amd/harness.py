@@ -59,14 +59,19 @@ class BamPipeline(object):
         free = threading.Semaphore(2)                 # the reader owns two array sets: at most one batch ahead of the GPU thread
         ready, box, err = threading.Semaphore(0), [], []
         t_read = [0.0]
+        stop = threading.Event()                      # set when the GPU thread gives up: the reader must leave libsvx before the handle is closed
 
         def reader():
             try:
                 for region in (self.regions if self.regions is not None else [None]):
+                    if stop.is_set():
+                        break
                     if region is not None:
                         bam.seek(region[0], region[1])
                     while True:
                         free.acquire()
+                        if stop.is_set():
+                            break
                         t0 = time.perf_counter()
                         b, n = bam.read_batch(self.batch_records, min_mapq, self.mode)
                         t_read[0] += time.perf_counter() - t0
@@ -75,10 +80,11 @@ class BamPipeline(object):
                             break
                         box.append((b, n, region))
                         ready.release()
-                free.acquire()
+                if not stop.is_set():
+                    free.acquire()
                 box.append((None, 0, None))
                 ready.release()
-            except Exception as e:                     # surfaces in the GPU thread
+            except BaseException as e:                 # surfaces in the GPU thread
                 err.append(e)
                 box.append((None, 0, None))
                 ready.release()
@@ -91,29 +97,35 @@ class BamPipeline(object):
         k = 0
         self.region_slots = []
         cur_region = object()
-        while True:
-            t0 = time.perf_counter()
-            ready.acquire()
-            t_wait += time.perf_counter() - t0
-            b, n, region = box[k]
-            k += 1
-            if err:
-                raise err[0]
-            if n == 0:
-                break
-            if region is not cur_region:
-                cur_region = region
-                self.region_slots.append([slot_base, 0])
-            self.region_slots[-1][1] += n
-            t0 = time.perf_counter()
-            eng.set_slot_base(slot_base)
-            eng.collect(b, p, fetch=False)
-            t_gpu += time.perf_counter() - t0
-            slot_base += 2 * n + 2
-            n_rec += n
-            n_batches += 1
+        try:
+            while True:
+                t0 = time.perf_counter()
+                ready.acquire()
+                t_wait += time.perf_counter() - t0
+                b, n, region = box[k]
+                k += 1
+                if err:
+                    raise err[0]
+                if n == 0:
+                    break
+                if region is not cur_region:
+                    cur_region = region
+                    self.region_slots.append([slot_base, 0])
+                self.region_slots[-1][1] += n
+                t0 = time.perf_counter()
+                eng.set_slot_base(slot_base)
+                eng.collect(b, p, fetch=False)
+                t_gpu += time.perf_counter() - t0
+                slot_base += 2 * n + 2
+                n_rec += n
+                n_batches += 1
+                free.release()
+        finally:
+            # whatever happened (a failing collect, an interrupt): the reader thread leaves libsvx BEFORE anyone may close the handle it reads from
+            stop.set()
             free.release()
-        th.join()
+            free.release()
+            th.join()
         t_collect_done = time.perf_counter()
         self.stats = dict(records=n_rec, batches=n_batches, t_collect_wall=t_collect_done - t_start, t_reader_busy=t_read[0], t_gpu_collect=t_gpu,
                           t_gpu_waits_for_reader=t_wait)
@@ -247,9 +259,9 @@ def _timed_bam_passes(path, opts, eng, genome, passes=1, threads=0, batch_record
     out = []
     try:
         for k in range(passes):
-            if k:
-                pipe.rewind()
             t0 = time.perf_counter()
+            if k:
+                pipe.rewind()                       # INSIDE the clock: rewinding inflates the first chunk of the file (svx_bam_rewind -> ensure)
             n = pipe.run()
             pipe.cluster(genome if k == 0 else None)
             wall = time.perf_counter() - t0
@@ -341,7 +353,7 @@ def shard_plan(references, lengths, bai, rank, world):
     return owner, runs
 
 
-def collect_cluster_bam_sharded(bam_path, opts, engine, adapter, rank, world, threads=0, batch_records=200_000, bai_path=None):
+def collect_cluster_bam_sharded(bam_path, opts, engine, adapter, rank, world, threads=0, batch_records=200_000, bai_path=None, gather_names=True):
     """One rank of a contig-sharded run over an indexed, coordinate-sorted BAM: read this rank's contig runs (svx_bam_seek), COLLECT
     them batch by batch (accumulating), exchange the region sizes so that emission slots are global, then multigpu.cluster_step.
     Returns (StepResult or None, pipeline, read-name list of this rank)."""
@@ -385,8 +397,20 @@ def collect_cluster_bam_sharded(bam_path, opts, engine, adapter, rank, world, th
                 names.append(nm)
             out.append(i)
         return out
+    # read ids are rank-local numbers (each rank interns the names of the records IT read, plus the names foreign rows arrive with): in the gathered
+    # table rank r's ids are shifted by r * stride, and rank 0 receives every rank's name list - StepResult.read_name(id) resolves any member
+    stride = (2 ** 31 - 1) // max(1, world)
+    if len(names) >= stride:
+        raise OverflowError("more than %d read names on one rank" % stride)
     res = multigpu.cluster_step(adapter, pipe.params, rank, world, np.arange(len(refs)), contig_ranks(refs), owner, key_runs=key_runs,
-                                names_of=names_of, ids_of=ids_of)
+                                names_of=names_of, ids_of=ids_of, read_base=rank * stride)
+    if gather_names and world > 1:
+        everyone = [None] * world if rank == 0 else None
+        dist.gather_object(list(names), everyone, dst=0)
+        if rank == 0:
+            res.set_read_names(everyone, stride)
+    elif res is not None:
+        res.set_read_names([list(names)], stride)
     pipe.stats["records"] = n_rec
     return res, pipe, names
 

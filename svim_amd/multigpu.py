@@ -40,7 +40,7 @@ def assign_contigs(names, lengths, world):
         mid = acc + lengths[i] / 2.0
         owner[i] = min(world - 1, int(mid * world / total))
         acc += lengths[i]
-    # ranges must be monotone in name order (midpoints are), and no rank may be skipped when there are enough contigs
+    # ranges are monotone in name order (midpoints are); a rank whose range holds no contig midpoint owns nothing and only takes part in the exchanges
     return owner
 
 
@@ -372,6 +372,15 @@ class StepResult(object):
         self.clusters, self.member_off, self.members = clusters, member_off, members
         self.sig_cols, self.sig_counts, self.chain_end = sig_cols, sig_counts, chain_end
         self.n = int(clusters["type"].numel()) if clusters is not None else 0
+
+    def set_read_names(self, names_by_rank, stride):
+        """names_by_rank[r][i]: the read rank r numbered i; the gathered table carries rank r's ids shifted by r * stride"""
+        self.names_by_rank, self.name_stride = names_by_rank, stride
+
+    def read_name(self, read_id):
+        """query name behind a read_id of the gathered signature table (sig_cols["read_id"])"""
+        r, i = divmod(int(read_id), self.name_stride)
+        return self.names_by_rank[r][i]
 
     def to_host(self):
         out = _abi.ClusterTable(self.n, int(self.members.numel()))

@@ -482,3 +482,69 @@ def test_cluster_list_is_a_mutable_sequence(oracle):
     with pytest.raises(TypeError):
         hash(dele)
     assert isinstance(reversed(dele).__next__(), type(dele[0]))
+
+
+def test_reader_keeps_the_last_batch_of_a_region_alive_across_a_seek(tmp_path):
+    """a read that ends a region returns n = 0 - the two batch array sets must not alternate on it, or the first batch of the NEXT
+    region (after svx_bam_seek) is decoded into the set that still holds the last batch of the region before, which the consumer may still be
+    uploading.  Here the consumer is deliberately slow: it looks at a batch only after the reader has already produced the next one."""
+    import threading
+    import time
+    from svim_amd import harness
+    from svim_amd.bamio import NativeBam
+    refs, lens = ["chr1", "chr2", "chr10", "chr3"], [100000, 80000, 80000, 60000]
+    ref = synth.make_reference(61, list(zip(refs, lens)))
+    recs = synth.coordinate_sort(synth.fuzz_split_reads(62, 200, refs, lens, max_sv_size=20000) +
+                                 synth.planted_reads(63, 240, ref, refs, lens, n_sites=25, types=("DEL", "INS")))
+    path = str(tmp_path / "regions.bam")
+    records.write_bam(path, refs, lens, recs)
+    bai = records.read_bai(path + ".bai")
+    regions = [(bai[t][0], t) for t in (0, 2, 1, 3) if bai[t] is not None]          # four regions, visited out of file order
+    o = H.options({"min_mapq": 20, "min_sv_size": 40, "max_sv_size": 100000, "segment_gap_tolerance": 10, "segment_overlap_tolerance": 5,
+                   "partition_max_distance": 1000, "position_distance_normalizer": 900, "edit_distance_normalizer": 1.0, "cluster_max_distance": 0.5,
+                   "all_bnds": False})
+
+    def digest(nb, b):
+        A = nb.batch_arrays(b)
+        return tuple(int(A[k].astype(np.int64).sum()) for k in ("tid", "pos", "lseq", "read_id", "cigar", "seg_pos", "cigar_off")) + (int(b.n_rec),)
+    # sequential reference: every batch looked at right away
+    nb = NativeBam(path, threads=2)
+    want = []
+    for voff, last in regions:
+        nb.seek(voff, last)
+        while True:
+            b, n = nb.read_batch(37, 20, "coordinate")
+            if n == 0:
+                break
+            want.append(digest(nb, b))
+    nb.close()
+
+    class SlowEngine(object):
+        def __init__(self):
+            self.seen = []
+
+        def accumulate(self, on):
+            pass
+
+        def set_slot_base(self, base):
+            pass
+
+        def collect(self, b, p, fetch=False):
+            time.sleep(0.03)                         # the reader runs ahead: next read (and, at a region end, the n = 0 read + seek + read) happens now
+            self.seen.append(digest(pipe.bam, b))
+    eng = SlowEngine()
+    pipe = harness.BamPipeline(path, o, eng, threads=2, batch_records=37, regions=regions, gpu_inflate=False, sparse_seq=False)
+    n = pipe.run()
+    pipe.bam.close()
+    assert n == sum(w[-1] for w in want) and len(want) > 8
+    assert eng.seen == want
+    # a failing consumer: run() joins the reader before the error leaves (no thread left inside the handle that is about to be closed)
+    class Failing(SlowEngine):
+        def collect(self, b, p, fetch=False):
+            raise RuntimeError("collect failed")
+    pipe = harness.BamPipeline(path, o, Failing(), threads=2, batch_records=37, regions=regions, gpu_inflate=False, sparse_seq=False)
+    before = threading.active_count()
+    with pytest.raises(RuntimeError):
+        pipe.run()
+    pipe.bam.close()
+    assert threading.active_count() <= before

@@ -270,6 +270,14 @@ def _worker_bam(rank, world, port, ret, bam_path, fasta_path):
         pipe.bam.close()
         if rank == 0:
             verdict = _compare(res, full, None)
+            if verdict == "ok":
+                # every member signature of the gathered result resolves to its read NAME on rank 0 (ids are rank-local numbers shifted per rank)
+                keys = res.sig_cols["key"].numpy()
+                order = np.argsort(keys, kind="stable")
+                got = [res.read_name(i) for i in res.sig_cols["read_id"].numpy()[order]]
+                want = [hb_all.read_names[i] for i in sig_all.read_id[:sig_all.n]]
+                if got != want:
+                    verdict = "read names of the gathered signatures differ"
             ret[0] = verdict
         else:
             ret[rank] = "ok"
