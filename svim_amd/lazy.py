@@ -98,6 +98,13 @@ class ClusterList(MutableSequence):
             self._objs = convert.cluster_objects_range(self.ct, self.lo, self.hi, self.signatures, self.references)
         return self._objs
 
+    def __copy__(self):                             # copy.copy(list) is a new list of the same objects: mutating the copy leaves the original alone
+        c = ClusterList(self.ct, self.lo, self.hi, self.signatures, self.references)
+        c._objs = list(self.materialise())
+        return c
+
+    copy = __copy__
+
     def __iter__(self):
         return iter(self.materialise())
 

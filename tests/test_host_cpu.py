@@ -482,6 +482,11 @@ def test_cluster_list_is_a_mutable_sequence(oracle):
     with pytest.raises(TypeError):
         hash(dele)
     assert isinstance(reversed(dele).__next__(), type(dele[0]))
+    import copy
+    n_inv = len(inv)
+    twin = copy.copy(inv)                                                  # built or not, a copy is a list of its own
+    twin.append(first)
+    assert len(inv) == n_inv and len(twin) == n_inv + 1 and twin[0] is inv[0]
 
 
 def test_reader_keeps_the_last_batch_of_a_region_alive_across_a_seek(tmp_path):
