@@ -167,6 +167,7 @@ const char* svx_last_error(void);
 int  svx_version(void);
 int  svx_get_stats(svx_ctx* ctx, svx_stats* out);
 void* svx_stream(svx_ctx* ctx);                              /* hipStream_t the kernels run on */
+int  svx_memcpy_d2h(void* host_dst, const void* device_src, uint64_t bytes);   /* inspection of device-resident results (tests) */
 
 /* ---- COLLECT: replaces analyze_alignment_file_* (src/svim/SVIM_COLLECT.py:96-167) -------------- */
 int  svx_collect(svx_ctx* ctx, const svx_batch* batch, const svx_params* p);
@@ -297,6 +298,13 @@ int  svx_bam_seek(svx_bam* h, uint64_t voff, int32_t last_tid);
 int  svx_bam_set_gpu_inflate(svx_bam* h, int device);
 int  svx_bam_gpu_inflate_stats(svx_bam* h, int64_t* gpu_blocks, int64_t* cpu_blocks, double* gpu_kernel_ms);
 int  svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** nul_separated, int64_t* blob_len);
+/* Device-resident front-end (coordinate mode): the compressed file slice is the only thing that crosses PCIe.  Every chunk of BGZF blocks (2 GB of inflated
+ * data) is inflated by the GPU into HBM (one wavefront per block), the record boundaries are found there (BGZF blocks are the restart points of the
+ * block_size chain: a speculative record start per block, verified by linking the chains), and fixed fields, CIGAR (CG tag included), the SA tag -> segment
+ * table and the read names (interned by 2 x 64-bit hashes) are decoded by kernels.  svx_bam_read_batch then returns an svx_batch whose pointers are DEVICE
+ * memory (on_device = 1; seq points into the inflated stream - no bases are copied); arrays stay valid until the THIRD next chunk is loaded.  device < 0:
+ * back to the host reader. */
+int  svx_bam_set_device_decode(svx_bam* h, int device);
 
 #ifdef __cplusplus
 }

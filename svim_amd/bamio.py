@@ -54,6 +54,13 @@ class NativeBam(object):
         if self.L.svx_bam_set_gpu_inflate(self.h, C.c_int(int(device))) != 0:
             raise SvxError("svx_bam_set_gpu_inflate failed: %s" % self.L.svx_last_error().decode())
 
+    def set_device_decode(self, device):
+        """coordinate mode: BGZF inflate, record discovery and decode on GPU `device` (svx_bam_set_device_decode); read_batch then returns
+        batches whose arrays live in HBM.  device < 0: back to the host reader"""
+        if self.L.svx_bam_set_device_decode(self.h, C.c_int(int(device))) != 0:
+            raise SvxError("svx_bam_set_device_decode failed: %s" % self.L.svx_last_error().decode())
+        self.device_decode = int(device) >= 0
+
     def gpu_inflate_stats(self):
         g, c, ms = C.c_int64(), C.c_int64(), C.c_double()
         self.L.svx_bam_gpu_inflate_stats(self.h, C.byref(g), C.byref(c), C.byref(ms))
@@ -82,6 +89,8 @@ class NativeBam(object):
     def batch_arrays(self, b):
         """numpy copies of a batch returned by read_batch (tests / inspection)."""
         n, ns = b.n_rec, b.n_seg
+        if b.on_device:
+            return self._device_batch_arrays(b)
 
         def arr(ptr, count, dt):
             if count == 0:
@@ -105,6 +114,44 @@ class NativeBam(object):
             A["seq_rng_off"] = arr(b.seq_rng_off, n + 1, np.uint32)
             A["seq_rng_q0"], A["seq_rng_len"] = arr(b.seq_rng_q0, nr, np.int32), arr(b.seq_rng_len, nr, np.int32)
             A["seq_rng_byte"] = arr(b.seq_rng_byte, nr, np.uint64)
+        return A
+
+    def _device_batch_arrays(self, b):
+        """a device-resident batch (svx_bam_set_device_decode) copied to the host in the layout of a host batch: offsets rebased to the batch, one
+        packed SEQ per record (the device batch points into the inflated stream instead)"""
+        n, ns = int(b.n_rec), int(b.n_seg)
+
+        def arr(ptr, count, dt, skip=0):
+            out = np.zeros(count, dtype=dt)
+            if count:
+                src = C.c_void_p(C.cast(ptr, C.c_void_p).value + skip * np.dtype(dt).itemsize)
+                if self.L.svx_memcpy_d2h(out.ctypes.data_as(C.c_void_p), src, C.c_uint64(out.nbytes)) != 0:
+                    raise SvxError("svx_memcpy_d2h failed: %s" % self.L.svx_last_error().decode())
+            return out
+        A = {}
+        for k in ("flag", "tid", "pos", "mapq", "lseq", "read_id", "order", "seg_order"):
+            A[k] = arr(getattr(b, k), n, _abi.BATCH_DTYPES[k])
+        co = arr(b.cigar_off, n + 1, np.uint64)
+        A["cigar"] = arr(b.cigar, int(co[-1] - co[0]) if n else 0, np.uint32, skip=int(co[0]) if n else 0)
+        A["cigar_off"] = (co - co[0]).astype(np.uint64) if n else np.zeros(1, np.uint64)
+        so = arr(b.seq_off, n + 1, np.uint64)
+        nb = (A["lseq"].astype(np.int64) + 1) // 2
+        parts = []
+        if n:
+            lo, hi = int(so[0]), int(so[n - 1] + nb[n - 1])
+            raw = arr(b.seq, hi - lo, np.uint8, skip=lo)
+            parts = [raw[int(so[i]) - lo:int(so[i]) - lo + int(nb[i])] for i in range(n)]
+        A["seq"] = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+        A["seq_off"] = np.concatenate([[0], np.cumsum(nb)]).astype(np.uint64)
+        sg = arr(b.seg_off, n + 1, np.uint32)
+        s0, s1 = (int(sg[0]), int(sg[-1])) if n else (0, 0)
+        A["seg_off"] = (sg - sg[0]).astype(np.uint32) if n else np.zeros(1, np.uint32)
+        for k in ("seg_tid", "seg_pos", "seg_rev", "seg_mapq", "seg_lseq"):
+            A[k] = arr(getattr(b, k), s1 - s0, _abi.BATCH_DTYPES[k], skip=s0)
+        sc = arr(b.seg_cigar_off, s1 - s0 + 1, np.uint64, skip=s0) if ns else np.zeros(1, np.uint64)
+        A["seg_cigar"] = arr(b.seg_cigar, int(sc[-1] - sc[0]), np.uint32, skip=int(sc[0]))
+        A["seg_cigar_off"] = (sc - sc[0]).astype(np.uint64)
+        A["contig_rank"] = arr(b.contig_rank, b.n_contig, np.int32)
         return A
 
     def read_names(self):

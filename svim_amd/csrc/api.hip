@@ -61,6 +61,11 @@ extern "C" void svx_ctx_destroy(svx_ctx* c) {
 }
 
 extern "C" void* svx_stream(svx_ctx* c) { return (void*)c->stream; }
+// test / inspection helper: device memory -> host (a device-resident svx_batch handed out by the BAM reader can be looked at without torch)
+extern "C" int svx_memcpy_d2h(void* host_dst, const void* device_src, uint64_t bytes) {
+    if (bytes) HIPCHK(hipMemcpy(host_dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return SVX_OK;
+}
 extern "C" int svx_get_stats(svx_ctx* c, svx_stats* out) { *out = c->stats; return SVX_OK; }
 
 static int upload(svx_ctx* c, DevBuf& d, const void* host, size_t bytes, size_t pad = 64) {

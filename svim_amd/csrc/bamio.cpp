@@ -28,6 +28,7 @@
 #include <functional>
 #include <mutex>
 #include "../../include/svx.h"
+#include "devdec.hpp"
 
 extern thread_local std::string g_svx_err;
 static int bam_fail(int code, const std::string& what) { g_svx_err = what; return code; }
@@ -202,6 +203,13 @@ struct svx_bam {
     // svx_bam_set_gpu_inflate: the GPU inflates sub-batches of blocks from the front of every chunk while the host's cores take blocks from its back
     svx_inflater* gpu = nullptr; size_t gpu_sub = 4096; bool gpu_sub_forced = false;       // SVX_BAM_GPU_SUB: exact sub-batch size (tests)
     int64_t gpu_blocks = 0, cpu_blocks = 0; double gpu_kernel_ms = 0;
+    // svx_bam_set_device_decode: inflate, record discovery and decode on the GPU (bamdev.hip); batches come back with device pointers
+    svx_devdec* dev = nullptr; int dev_device = -1;
+    size_t header_bytes = 0;                  // length of the BAM header in the inflated stream
+    size_t dev_fpos = 0; uint64_t dev_skip = 0; bool dev_file_done = false, dev_region_done = false;
+    int dev_cur = -1; int64_t dev_first = 0, dev_valid = 0; bool dev_have_carry = false;
+    size_t dev_chunk_bytes = (size_t)2048 << 20, dev_chunk_blocks = (size_t)1 << 30;      // test hooks: SVX_BAM_DEV_CHUNK_MB, SVX_BAM_DEV_CHUNK_BLOCKS
+    std::string dev_names_blob;
 };
 
 // ---- BGZF ------------------------------------------------------------------------------------------------------------------
@@ -409,6 +417,15 @@ static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] <
 
 // CPUs this process may actually use: the visible cores capped by the cgroup CPU quota (a container that shows 256 cores but is granted
 // 16 CPUs' worth of time gets throttled for the rest of every scheduler period once 100+ busy threads have burnt the quota)
+static int granted_cpus() {                                 // CPUs the cgroup quota grants (the visible cores when there is none)
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long period = 0; char first[32] = {0};
+        if (fscanf(f, "%31s %lld", first, &period) == 2 && strcmp(first, "max") != 0 && period > 0) { const long long q = (atoll(first) + period - 1) / period; if (q >= 1 && (unsigned)q < n) n = (unsigned)q; }
+        fclose(f);
+    }
+    return (int)n;
+}
 static int default_threads() {
     unsigned n = std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -459,6 +476,13 @@ extern "C" int svx_bam_set_gpu_inflate(svx_bam* h, int device) {
 }
 extern "C" int svx_bam_gpu_inflate_stats(svx_bam* h, int64_t* gpu_blocks, int64_t* cpu_blocks, double* gpu_kernel_ms) {
     if (!h) return bam_fail(SVX_E_ARG, "null handle");
+    if (h->dev) {                                            // device decode: every block is inflated by the GPU
+        DevDecStats ds; devdec_stats(h->dev, &ds);
+        if (gpu_blocks) *gpu_blocks = ds.gpu_blocks;
+        if (cpu_blocks) *cpu_blocks = ds.cpu_blocks;
+        if (gpu_kernel_ms) *gpu_kernel_ms = ds.inflate_kernel_ms;
+        return SVX_OK;
+    }
     if (gpu_blocks) *gpu_blocks = h->gpu_blocks;
     if (cpu_blocks) *cpu_blocks = h->cpu_blocks;
     if (gpu_kernel_ms) *gpu_kernel_ms = h->gpu_kernel_ms;
@@ -517,6 +541,7 @@ extern "C" int svx_bam_open(const char* path, int n_threads, svx_bam** out) {
         std::sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return h->ref_names[(size_t)a] < h->ref_names[(size_t)b]; });
         h->contig_rank.assign(n_ref ? n_ref : 1, 0);
         for (uint32_t r = 0; r < n_ref; r++) h->contig_rank[(size_t)idx[r]] = (int32_t)r;
+        h->header_bytes = h->pos - h->win_head;                      // (the header sits in the first window, which starts at win_head)
     } catch (const std::string& e) {
         if (h->prefetch_active) h->prefetch.wait();
         if (h->map) munmap((void*)h->map, h->map_len);
@@ -536,6 +561,15 @@ extern "C" void svx_bam_close(svx_bam* h) {
     if (h->gpu) {
         if (getenv("SVX_BAM_TIMING")) fprintf(stderr, "bamio inflate: %lld blocks on the GPU (kernels %.1f ms), %lld on the host\n", (long long)h->gpu_blocks, h->gpu_kernel_ms, (long long)h->cpu_blocks);
         drop_gpu(h);                                     // before the buffers it page-locked are freed
+    }
+    if (h->dev) {
+        if (getenv("SVX_BAM_TIMING")) {
+            DevDecStats ds; devdec_stats(h->dev, &ds);
+            fprintf(stderr, "bamio device decode: %lld blocks (%lld GPU, %lld host), %.1f MB inflated, %lld records; staging + enqueue %.3f s, waiting for the inflate %.3f (kernels %.1f ms), "
+                            "record discovery %.3f, decode %.3f, names %.3f; %lld serial fallbacks\n", (long long)ds.blocks, (long long)ds.gpu_blocks, (long long)ds.cpu_blocks, ds.bytes / 1e6, (long long)ds.records, ds.t_stage,
+                    ds.t_inflate_wait, ds.inflate_kernel_ms, ds.t_discover, ds.t_decode, ds.t_names, (long long)ds.fallbacks);
+        }
+        devdec_destroy(h->dev); h->dev = nullptr;
     }
     if (h->map) munmap((void*)h->map, h->map_len);
     if (h->fd >= 0) close(h->fd);
@@ -564,6 +598,10 @@ extern "C" int svx_bam_seek(svx_bam* h, uint64_t voff, int32_t last_tid) {
     if (coff > h->map_len) return bam_fail(SVX_E_ARG, "virtual offset beyond the end of the file");
     h->fpos = coff; h->file_eof = false; h->buf.clear(); h->pos = 0; h->next_len = 0; h->next_eof = false;
     h->tid_limit = last_tid; h->region_done = false;
+    if (h->dev) {                                          // device decode: the next chunk starts at that block, `uoff` bytes into its data
+        h->dev_fpos = coff; h->dev_skip = uoff; h->dev_file_done = false; h->dev_region_done = false; h->dev_cur = -1; h->dev_first = h->dev_valid = 0; h->dev_have_carry = false;
+        return SVX_OK;
+    }
     try {
         if (uoff && !ensure(h, uoff)) throw std::string("virtual offset beyond its block");
         h->pos += uoff;
@@ -580,6 +618,11 @@ extern "C" int svx_bam_rewind(svx_bam* h) {
     if (getenv("SVX_BAM_TIMING")) {                      // per pass: the stages of the pass that just ended
         fprintf(stderr, "bamio pass: wait for inflate %.3f s, window copy %.3f, record walk %.3f, decode %.3f, names + SA %.3f\n", h->t_wait, h->t_copy, h->t_walk, h->t_decode, h->t_intern);
         h->t_wait = h->t_copy = h->t_walk = h->t_decode = h->t_intern = 0;
+    }
+    if (h->dev) {                                          // device decode: nothing to inflate here - the first chunk is loaded by the first read
+        h->dev_fpos = 0; h->dev_skip = h->header_bytes; h->dev_file_done = false; h->dev_region_done = false; h->dev_cur = -1; h->dev_first = h->dev_valid = 0; h->dev_have_carry = false;
+        h->total_records = 0; h->tid_limit = -2; h->region_done = false;
+        return SVX_OK;
     }
     h->fpos = 0; h->file_eof = false; h->buf.clear(); h->pos = 0; h->next_len = 0; h->next_eof = false;
     try {
@@ -869,7 +912,68 @@ static void clear_batch(svx_bam* h) {
 // Read up to max_records records (query-name mode: never splits a read's group) and lay them out as an svx_batch whose
 // arrays stay valid until the next call.  *n_out = 0 at end of file.  mode 0 = coordinate-sorted rules
 // (src/svim/SVIM_COLLECT.py:132-167), 1 = query-name-sorted rules (:96-129).
+// device decode: the next chunk of BGZF blocks -> bamdev.hip (inflate + record discovery + decode in HBM); batches are views of the chunk's arrays
+static int read_batch_device(svx_bam* h, int64_t max_records, int min_mapq, svx_batch* out, int64_t* n_out) {
+    *n_out = 0;
+    memset(out, 0, sizeof *out);
+    for (;;) {
+        if (h->dev_cur >= 0 && h->dev_first < h->dev_valid) {
+            const int64_t count = std::min<int64_t>(max_records, h->dev_valid - h->dev_first);
+            const int rc = devdec_batch(h->dev, h->dev_cur, h->dev_first, count, out);
+            if (rc != SVX_OK) return rc;
+            h->dev_first += count; h->total_records += count; *n_out = count;
+            return SVX_OK;
+        }
+        if (h->dev_region_done || (h->dev_file_done && h->dev_cur >= 0)) return SVX_OK;          // end of the region / of the file
+        // the next chunk: whole BGZF blocks up to dev_chunk_bytes of inflated data
+        std::vector<DevDecBlock> blocks;
+        size_t total = 0;
+        try {
+            const size_t save = h->fpos;
+            h->fpos = h->dev_fpos;
+            while (total < h->dev_chunk_bytes && blocks.size() < h->dev_chunk_blocks) {
+                RawBlock b;
+                if (!read_block(h, b)) { h->dev_file_done = true; break; }
+                blocks.push_back(DevDecBlock{b.comp, (uint32_t)b.clen, b.isize});
+                total += b.isize;
+            }
+            h->dev_fpos = h->fpos;
+            h->fpos = save;
+        } catch (const std::string& e) { return bam_fail(SVX_E_ARG, e); }
+        if (blocks.empty() && !h->dev_have_carry) { h->dev_file_done = true; if (h->dev_cur < 0) h->dev_cur = 0; h->dev_first = h->dev_valid = 0; return SVX_OK; }
+        const int slot = h->dev_cur < 0 ? 0 : (h->dev_cur + 1) % 3;
+        int rc = devdec_load(h->dev, slot, blocks.data(), blocks.size(), h->dev_have_carry ? h->dev_cur : -1, h->dev_skip, h->dev_file_done, min_mapq);
+        if (rc != SVX_OK) return rc;
+        h->dev_skip = 0;
+        int64_t n_rec = 0, n_valid = 0;
+        rc = devdec_count(h->dev, slot, h->tid_limit, &n_rec, &n_valid);
+        if (rc != SVX_OK) return rc;
+        h->dev_cur = slot; h->dev_first = 0; h->dev_valid = n_valid; h->dev_have_carry = true;
+        if (n_valid < n_rec) h->dev_region_done = true;                 // contig-range reading: the range ends where the next contig (or the unplaced tail) begins
+        // (a chunk without one complete record is carried over whole into the next load; devdec_load refuses when a record outgrows its carry-over room)
+        if (n_valid == 0 && (h->dev_file_done || h->dev_region_done)) return SVX_OK;
+    }
+}
+
+extern "C" int svx_bam_set_device_decode(svx_bam* h, int device) {
+    if (!h) return bam_fail(SVX_E_ARG, "null handle");
+    if (h->dev) { devdec_destroy(h->dev); h->dev = nullptr; }
+    if (device < 0) return SVX_OK;
+    const int rc = devdec_create(device, granted_cpus(), (int32_t)h->ref_names.size(), h->ref_len.data(), h->names_blob.c_str(), h->contig_rank.data(), &h->dev);
+    if (rc != SVX_OK) { h->dev = nullptr; return rc; }
+    h->dev_device = device;
+    { const char* e = getenv("SVX_BAM_DEV_CHUNK_MB"); if (e && atoll(e) > 0) h->dev_chunk_bytes = (size_t)atoll(e) << 20; }
+    { const char* e = getenv("SVX_BAM_DEV_CHUNK_BLOCKS"); if (e && atoll(e) > 0) h->dev_chunk_blocks = (size_t)atoll(e); }
+    if (h->prefetch_active) { h->prefetch.wait(); h->prefetch_active = false; }
+    h->dev_fpos = 0; h->dev_skip = h->header_bytes; h->dev_file_done = false; h->dev_region_done = false; h->dev_cur = -1; h->dev_first = h->dev_valid = 0; h->dev_have_carry = false;
+    return SVX_OK;
+}
+
 extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int min_mapq, svx_batch* out, int64_t* n_out) {
+    if (h->dev) {
+        if (mode != 0) return bam_fail(SVX_E_ARG, "the device BAM decode reads coordinate-sorted input only (query-name grouping stays on the host reader)");
+        return read_batch_device(h, max_records, min_mapq, out, n_out);
+    }
     BatchArrays* const handed_out = h->b;                                                 // the set the previous call handed out: the caller may still upload from it
     try {
         h->b = &h->ba[h->b == &h->ba[0] ? 1 : 0];                                        // the previous batch stays valid during this read
@@ -985,6 +1089,13 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
 
 // read names interned so far: NUL-separated blob in id order
 extern "C" int svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** blob, int64_t* blob_len) {
+    if (h->dev) {
+        const std::vector<std::string>& nm = devdec_names(h->dev);
+        h->dev_names_blob.clear();
+        for (const auto& x : nm) { h->dev_names_blob += x; h->dev_names_blob.push_back('\0'); }
+        *n_names = (int64_t)nm.size(); *blob = h->dev_names_blob.data(); *blob_len = (int64_t)h->dev_names_blob.size();
+        return SVX_OK;
+    }
     *n_names = (int64_t)h->names.size(); *blob = h->names.blob.data(); *blob_len = (int64_t)h->names.blob.size();
     return SVX_OK;
 }

@@ -6,16 +6,17 @@
 #include "common.hpp"
 #include "inflate_core.hpp"
 #include <mutex>
+#include <cstdlib>
 
 struct BgzfJob { unsigned long long in_off; unsigned long long out_off; uint32_t in_bytes; uint32_t out_bytes; };
 
-__global__ __launch_bounds__(256) void k_bgzf_inflate(const uint8_t* comp, const BgzfJob* jobs, long long n_jobs, uint8_t* out, int* status) {
-    __shared__ InfScratch scratch[4];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long j = (long long)blockIdx.x * 4 + wave;
+// one wavefront = one workgroup = one BGZF block (the waves share nothing, so they are scheduled one by one; ~8 KB of LDS each: 20 per CU)
+__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* comp, const BgzfJob* jobs, long long n_jobs, uint8_t* out, int* status) {
+    __shared__ InfScratch scratch;
+    const long long j = (long long)blockIdx.x;
     if (j >= n_jobs) return;
     const BgzfJob job = jobs[j];
-    const int rc = inflate_raw(comp + job.in_off, job.in_bytes, out + job.out_off, job.out_bytes, scratch[wave]);
+    const int rc = inflate_raw(comp + job.in_off, job.in_bytes, out + job.out_off, job.out_bytes, scratch);
     if (lane_id() == 0 && rc != (int)job.out_bytes) { status[0] = 1; status[1] = (int)j; status[2] = rc; }
 }
 
@@ -26,6 +27,7 @@ struct InflaterSlot {
     DevBuf comp, out, jobs, status;
     void* staging = nullptr; size_t staging_cap = 0;      // pinned host memory the caller packs this slot's payloads into
     int host_status[4] = {0, 0, 0, 0};
+    std::vector<BgzfJob> host_jobs;                       // alive until the slot's wait: its upload is asynchronous
     bool busy = false;
 };
 struct svx_inflater {
@@ -128,7 +130,8 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
     if (staged_bytes > sl.staging_cap) return svx_fail(SVX_E_ARG, "payloads are not in the staging buffer", __FILE__, __LINE__, hipSuccess);
     if (n == 0) return SVX_OK;
     HIPCHK(hipSetDevice(f->device));
-    std::vector<BgzfJob> jobs((size_t)n);
+    std::vector<BgzfJob>& jobs = sl.host_jobs;
+    jobs.resize((size_t)n);
     for (int64_t i = 0; i < n; i++) {
         if (in_off[i] + clen[i] > staged_bytes || out_at[i] + isize[i] > out_bytes)
             return svx_fail(SVX_E_ARG, "payload offset / size out of range", __FILE__, __LINE__, hipSuccess);
@@ -142,10 +145,10 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
     hipStream_t st = sl.stream;
     HIPCHK(hipMemcpyAsync(sl.comp.p, sl.staging, (size_t)staged_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sl.jobs.p, jobs.data(), (size_t)n * sizeof(BgzfJob), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));                                   // `jobs` is a local; the (small) uploads are through, the rest stays asynchronous
     HIPCHK(hipMemsetAsync(sl.status.p, 0, 16, st));
     HIPCHK(hipEventRecord(sl.ev[0], st));
-    k_bgzf_inflate<<<(unsigned)((n + 3) / 4), 256, 0, st>>>(sl.comp.as<uint8_t>(), sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.status.as<int>());
+    static const unsigned lds_pad = []() { const char* e = getenv("SVX_INFLATE_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();      // experiment: fewer resident waves per CU
+    k_bgzf_inflate<<<(unsigned)n, 64, lds_pad, st>>>(sl.comp.as<uint8_t>(), sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.status.as<int>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.ev[1], st));
     HIPCHK(hipMemcpyAsync(sl.host_status, sl.status.p, 16, hipMemcpyDeviceToHost, st));

@@ -1,14 +1,21 @@
-// inflate_core.hpp - raw DEFLATE (RFC 1951) decoder for one BGZF block, written once for two executors:
-//   * the GPU: one 64-lane wavefront per block (bgzf.hip).  Huffman decoding is inherently serial, so the decode state (bit buffer, canonical
-//     code counts) is WAVE-UNIFORM - the compiler keeps it in scalar registers and the scalar unit does the decoding - while the vector lanes do
-//     what is parallel: literals are staged one per lane and leave as 64-byte stores, matches and stored blocks are copied 64 bytes per step.
-//   * the host (INF_HOST, tests/test_inflate_core.py through tools/inflate_host_test.cpp): the same algorithm with the lane operations
-//     emulated, checked against zlib on real BGZF blocks.
+// inflate_core.hpp - raw DEFLATE (RFC 1951) decoder for one BGZF block, written for a 64-lane wavefront (one wave per block, bgzf.hip) and, with the
+// lane operations emulated, for the host (INF_HOST: tests/test_inflate_core.py through tools/inflate_host_test.cpp, fuzzed against zlib).
 // Replaces: zlib's inflate() as htslib / pysam use it under pysam.AlignmentFile (the reference reads BAM through them, SVIM_COLLECT.py:132-137).
+//
+// Huffman decoding is a serial chain (a code's length decides where the next one starts), but only THAT is serial.  Per step the wave
+//   1. looks up, in ONE LDS gather, the table entry of the code that would start at each of the next 64 bit offsets (lane l: offset l);
+//   2. follows the chain of real code starts through those 64 entries with v_readlane - a few scalar instructions per symbol and no memory
+//      round trip - as long as the symbols are literals, collecting their offsets in a 64-bit mask;
+//   3. writes all literals of the step with one predicated LDS byte store (lane = code start, position = rank of its bit in the mask).
+// A length symbol ends the run: extra bits and the distance code are peeked from registers (the compressed input lives in two VGPRs, 256 bytes
+// each, refilled 2048 bits ahead), and the match is copied inside an LDS RING holding the most recent output (4 KiB: what BAM matches mostly
+// reach for); only a source farther back is read from global memory, behind a fence.  The ring is the write buffer as well: output leaves as
+// aligned 16-byte-per-lane stores, 1 KiB per instruction.  Code tables are built by all lanes (ballot ranks instead of a serial counting pass).
 // Canonical decoding after Mark Adler's description of the format (count of codes per length + symbols in code order); nothing else is shared.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <string.h>
 
 #define INF_MAXBITS 15
 #define INF_MAXL 288
@@ -23,122 +30,225 @@
 #define INF_E_OUTPUT (-7)
 #define INF_E_INPUT (-8)
 
-// per-wave scratch (LDS on the device): code lengths while a dynamic header is read, then the symbols of both codes in canonical order
-#define INF_FAST_L 10          /* literal/length codes of up to 10 bits and distance codes of up to 8 bits are decoded by ONE table lookup; */
-#define INF_FAST_D 8           /* an entry is (code length << 9) | symbol, 0 = longer code: canonical walk                              */
+#ifndef INF_FAST_L
+#define INF_FAST_L 10          /* literal/length codes of up to 10 bits, distance codes of up to 8 and code-length codes of up to 7 are decoded by ONE lookup */
+#endif
+#define INF_FAST_D 8
+#define INF_FAST_C 7
+#ifndef INF_RING
+#define INF_RING 4096u         /* bytes of recent output kept in LDS (power of two, multiple of 16) */
+#endif
+#define INF_RMASK (INF_RING - 1u)
+#define INF_FLUSH_AT 1039u     /* pending bytes that trigger a flush: 1 KiB + what alignment may hold back */
+/* table entry: code length << 10 | flag 0x200 ("simple": a literal / a plain code length) | symbol; 0 = code longer than the table: canonical walk */
+#define INF_SIMPLE 0x200u
+
+// per-wave scratch (LDS on the device)
 struct InfScratch {
-    uint16_t len[INF_MAXL + INF_MAXD];
-    uint16_t lsym[INF_MAXL];
-    uint16_t dsym[INF_MAXD];
-    uint16_t cnt[INF_MAXBITS + 1];
-    uint16_t code[INF_MAXL];                 // canonical code of every symbol (while a fast table is filled)
+    alignas(16) uint8_t ring[INF_RING];
     uint16_t fast_l[1 << INF_FAST_L];
     uint16_t fast_d[1 << INF_FAST_D];
+    uint16_t fast_c[1 << INF_FAST_C];
+    uint16_t lsym[INF_MAXL];                 // symbols in canonical order (codes longer than the fast tables)
+    uint16_t dsym[INF_MAXD];
+    uint16_t csym[20];
+    uint16_t cnt_l[16], cnt_d[16], cnt_c[16];   // codes per length (canonical walk of the long codes)
+    uint8_t len[INF_MAXL + INF_MAXD + 16];   // code lengths while a header is read
 };
 
+// ---- lane abstraction: the device executes a "vector" statement in every lane; the host runs the 64 lanes in a loop ------------------------------
 #ifdef INF_HOST
 #define INF_FN static inline
-#define INF_LANE 0
-#define INF_UNI(x) (x)
+#define W_VEC(T, name) T name[64]
+#define W_VEC2(T, name, k) T name[k][64]
+#define W_FOR for (int lane_ = 0; lane_ < 64; lane_++)
+#define V(name) name[lane_]
+#define V2(name, r) name[r][lane_]
+#define W_LANE lane_
+#define W_READLANE(name, idx) ((uint32_t)name[(idx)])
+#define W_BALLOT(dst, expr) do { dst = 0; for (int lane_ = 0; lane_ < 64; lane_++) if (expr) dst |= 1ull << lane_; } while (0)
+#define W_RANK(mask) ((uint32_t)__builtin_popcountll((mask) & ((1ull << lane_) - 1ull)))
+#define W_FENCE() do { } while (0)
+static inline uint32_t inf_bitrev(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (x & 1u); x >>= 1; } return r; }
 #else
 #define INF_FN __device__ __forceinline__
-#define INF_LANE ((int)(threadIdx.x & 63))
-#define INF_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
+#define W_VEC(T, name) T name
+#define W_VEC2(T, name, k) T name[k]
+#define W_FOR
+#define V(name) name
+#define V2(name, r) name[r]
+#define W_LANE ((int)(threadIdx.x & 63))
+#define W_READLANE(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx)))
+#define W_BALLOT(dst, expr) dst = __ballot(expr)
+#define W_RANK(mask) ((uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u)))
+#define W_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+static __device__ __forceinline__ uint32_t inf_bitrev(uint32_t x) { return __builtin_bitreverse32(x); }
 #endif
+
+
+// exclusive prefix sum of a per-lane value over the 64 lanes (dst) and the sum of all lanes (total, wave-uniform)
+#ifdef INF_HOST
+#define W_EXCL_SCAN(dst, src, total) do { uint32_t run_ = 0; for (int lane_ = 0; lane_ < 64; lane_++) { const uint32_t v_ = src[lane_]; dst[lane_] = run_; run_ += v_; } total = run_; } while (0)
+#else
+#define INF_DPP_ADD(d_, s_, ctrl_, row_, bank_) d_ += __builtin_amdgcn_update_dpp(0, s_, ctrl_, row_, bank_, true)
+#define W_EXCL_SCAN(dst, src, total) do { int i_ = (int)(src), v_ = i_;                                                  \
+        INF_DPP_ADD(i_, v_, 0x111, 0xf, 0xf); INF_DPP_ADD(i_, v_, 0x112, 0xf, 0xf); INF_DPP_ADD(i_, v_, 0x113, 0xf, 0xf);   \
+        INF_DPP_ADD(i_, i_, 0x114, 0xf, 0xe); INF_DPP_ADD(i_, i_, 0x118, 0xf, 0xc);                                         \
+        INF_DPP_ADD(i_, i_, 0x142, 0xa, 0xf); INF_DPP_ADD(i_, i_, 0x143, 0xc, 0xf);                                         \
+        dst = (uint32_t)(i_ - v_); total = (uint32_t)__builtin_amdgcn_readlane(i_, 63); } while (0)
+#endif
+/* a token (literal, or length + distance) that would start at a bit offset: bits it takes | output bytes << 8 | flags */
+#define INF_T_MATCH (1u << 20)
+#define INF_T_STOP  (1u << 21)
+#ifndef INF_STEP_CAP
+#define INF_STEP_CAP 1024u
+#endif
+/* INF_STEP_CAP: output bytes one step may produce: its literals are written before its matches are copied, so a match of the step must not
+                                  reach back farther than ring size - this (a later literal of the same step would already sit on its source) */
 
 struct InfState {
-    // input: 32-bit words (the block's payload starts at a 4-byte aligned address), bit buffer
-    const uint32_t* in; uint32_t in_words, in_at;      // in_at: words handed to the bit buffer so far
-    uint32_t ahead;                                    // word in_at, loaded when word in_at - 1 was taken: its latency hides behind the symbols in between
-    uint64_t bitbuf; int bitcnt;
+    // input: aligned 32-bit words; lane l of cA holds word cbase + l, of cB word cbase + 64 + l; bp = bit position from the aligned base
+    const uint32_t* in; uint32_t in_words, cbase, bp;
+    W_VEC(uint32_t, cA); W_VEC(uint32_t, cB);
     // output
-    uint8_t* out; uint32_t out_cap, pos;      // pos: bytes produced (staged ones included)
-    uint32_t staged;                           // literals waiting in the lanes (0..64); they belong to out[pos - staged, pos)
-    uint32_t clean;                            // every store to out[0, clean) is known to have completed (the last wait)
-#ifdef INF_HOST
-    uint8_t stage[64];
-#else
-    uint32_t stage;                            // this lane's staged byte
-#endif
+    uint8_t* out; uint32_t out_cap, pos, flushed, clean, mis;      // mis: (address of out) & 15 - ring index of output byte p is (p + mis) & INF_RMASK
+    InfScratch* sc;
 };
 
-INF_FN void inf_need(InfState& s, int n) {                 // n <= 32
-    if (s.bitcnt < n) {
-        const uint32_t w = (uint32_t)INF_UNI(s.ahead);
-        s.in_at++;
-        s.ahead = s.in_at < s.in_words ? s.in[s.in_at] : 0u;       // reading past the end yields zeros; the caller notices by position
-        s.bitbuf |= (uint64_t)w << s.bitcnt;
-        s.bitcnt += 32;
+// ---- input ----------------------------------------------------------------------------------------------------------------------------------------
+INF_FN void inf_load_chunks(InfState& s, uint32_t cbase) {
+    s.cbase = cbase;
+    W_FOR { const uint32_t k = cbase + (uint32_t)W_LANE; V(s.cA) = k < s.in_words ? s.in[k] : 0u; }
+    W_FOR { const uint32_t k = cbase + 64u + (uint32_t)W_LANE; V(s.cB) = k < s.in_words ? s.in[k] : 0u; }
+}
+// called at the top of every decode step: the word holding bit bp sits in cA (every step reads less than 64 words ahead)
+INF_FN void inf_sync_input(InfState& s) {
+    if ((s.bp >> 5) - s.cbase >= 64u) {
+        if ((s.bp >> 5) - s.cbase >= 128u) { inf_load_chunks(s, (s.bp >> 5) & ~63u); return; }
+        s.cbase += 64u;
+        W_FOR { V(s.cA) = V(s.cB); }
+        W_FOR { const uint32_t k = s.cbase + 64u + (uint32_t)W_LANE; V(s.cB) = k < s.in_words ? s.in[k] : 0u; }
     }
 }
-INF_FN uint32_t inf_bits(InfState& s, int n) {             // n <= 24
-    inf_need(s, n);
-    const uint32_t v = (uint32_t)s.bitbuf & ((1u << n) - 1u);
-    s.bitbuf >>= n; s.bitcnt -= n;
+INF_FN uint32_t inf_word(const InfState& s, uint32_t d) {             // word d, cbase <= d < cbase + 128
+    const uint32_t j = d - s.cbase;
+    const uint32_t a = W_READLANE(s.cA, j & 63u), b = W_READLANE(s.cB, j & 63u);       // both, then a select: no branch
+    return j < 64u ? a : b;
+}
+INF_FN uint32_t inf_peek(const InfState& s, uint32_t bp) {            // the 32 bits from bit position bp on
+    const uint32_t d = bp >> 5, sh = bp & 31u;
+    const uint64_t two = (uint64_t)inf_word(s, d) | ((uint64_t)inf_word(s, d + 1u) << 32);
+    return (uint32_t)(two >> sh);
+}
+INF_FN uint32_t inf_bits(InfState& s, int n) {                        // n <= 24
+    const uint32_t v = inf_peek(s, s.bp) & ((1u << n) - 1u);
+    s.bp += (uint32_t)n;
     return v;
 }
 
-// ---- output -----------------------------------------------------------------------------------------------------------------
-INF_FN void inf_flush(InfState& s) {
-    if (!s.staged) return;
-    const uint32_t base = s.pos - s.staged;
+// ---- output ---------------------------------------------------------------------------------------------------------------------------------------
+INF_FN uint32_t inf_ridx(const InfState& s, uint32_t p) { return (p + s.mis) & INF_RMASK; }
+
+// ring -> global for output bytes [flushed, upto): bytes up to the first 16-byte boundary of the destination, then 16 bytes per lane
+INF_FN void inf_flush(InfState& s, uint32_t upto) {
+    while (s.flushed < upto) {
+        const uint32_t a = (s.flushed + s.mis) & 15u, left = upto - s.flushed;
+        if (a != 0u || left < 16u) {
+            uint32_t n = a ? 16u - a : left;
+            if (n > left) n = left;
+            W_VEC(uint32_t, v);
+            W_FOR { if ((uint32_t)W_LANE < n) V(v) = s.sc->ring[inf_ridx(s, s.flushed + (uint32_t)W_LANE)]; }
+            W_FOR { if ((uint32_t)W_LANE < n) s.out[s.flushed + (uint32_t)W_LANE] = (uint8_t)V(v); }
+            s.flushed += n;
+        } else {
+            uint32_t n16 = left >> 4;
+            if (n16 > 64u) n16 = 64u;
 #ifdef INF_HOST
-    for (uint32_t i = 0; i < s.staged; i++) s.out[base + i] = s.stage[i];
+            for (uint32_t i = 0; i < n16; i++) memcpy(s.out + s.flushed + 16u * i, s.sc->ring + inf_ridx(s, s.flushed + 16u * i), 16);
 #else
-    if ((uint32_t)INF_LANE < s.staged) s.out[base + INF_LANE] = (uint8_t)s.stage;
+            if ((uint32_t)W_LANE < n16) {
+                const uint4 q = *reinterpret_cast<const uint4*>(s.sc->ring + inf_ridx(s, s.flushed + 16u * (uint32_t)W_LANE));
+                *reinterpret_cast<uint4*>(s.out + s.flushed + 16u * (uint32_t)W_LANE) = q;
+            }
 #endif
-    s.staged = 0;
+            s.flushed += 16u * n16;
+        }
+    }
 }
-INF_FN int inf_literal(InfState& s, uint32_t byte) {
-    if (s.pos >= s.out_cap) return INF_E_OUTPUT;
-#ifdef INF_HOST
-    s.stage[s.staged] = (uint8_t)byte;
-#else
-    if ((uint32_t)INF_LANE == s.staged) s.stage = byte;
-#endif
-    s.staged++; s.pos++;
-    if (s.staged == 64) inf_flush(s);
-    return 0;
+INF_FN void inf_maybe_flush(InfState& s) {
+    if (s.pos - s.flushed >= INF_FLUSH_AT) inf_flush(s, s.pos - ((s.pos + s.mis) & 15u));       // up to the last 16-byte boundary of the destination
 }
-// out[pos, pos + len) = out[pos - dist ...] with the overlap rule of LZ77 (a distance shorter than the length repeats the pattern)
+
+// ring[op, op + len) = ring[op - dist ...] with the overlap rule of LZ77 (a distance shorter than the length repeats the pattern); dist + len <= INF_RING.
+// Chunks of `step` bytes never read what they write: step = 64 for dist >= 64, else the largest multiple of dist below 65 (the first chunk lays
+// the pattern out from the source, the others copy from one step back)
+INF_FN void inf_copy_near(InfState& s, uint32_t op, uint32_t dist, uint32_t len) {
+    uint8_t* ring = s.sc->ring;
+    W_VEC(uint32_t, v);
+    if (len <= 64u && dist >= len) {                                      // the common case (CIGAR words, tags): one gather, one scatter
+        W_FOR { if ((uint32_t)W_LANE < len) V(v) = ring[inf_ridx(s, op + (uint32_t)W_LANE - dist)]; }
+        W_FOR { if ((uint32_t)W_LANE < len) ring[inf_ridx(s, op + (uint32_t)W_LANE)] = (uint8_t)V(v); }
+        return;
+    }
+    if (dist >= 64u || dist >= len) {
+        for (uint32_t done = 0; done < len; done += 64u) {
+            const uint32_t n = len - done < 64u ? len - done : 64u;
+            W_FOR { if ((uint32_t)W_LANE < n) V(v) = ring[inf_ridx(s, op + done + (uint32_t)W_LANE - dist)]; }
+            W_FOR { if ((uint32_t)W_LANE < n) ring[inf_ridx(s, op + done + (uint32_t)W_LANE)] = (uint8_t)V(v); }
+        }
+    } else {
+        const uint32_t step = dist * (64u / dist);
+        uint32_t n = len < step ? len : step;
+        W_FOR { if ((uint32_t)W_LANE < n) V(v) = ring[inf_ridx(s, op - dist + (dist == 1u ? 0u : (uint32_t)W_LANE % dist))]; }
+        W_FOR { if ((uint32_t)W_LANE < n) ring[inf_ridx(s, op + (uint32_t)W_LANE)] = (uint8_t)V(v); }
+        // a step is a whole number of periods: every later chunk repeats, lane by lane, the bytes of the first one - writes only
+        for (uint32_t done = n; done < len; done += step) {
+            n = len - done < step ? len - done : step;
+            W_FOR { if ((uint32_t)W_LANE < n) ring[inf_ridx(s, op + done + (uint32_t)W_LANE)] = (uint8_t)V(v); }
+        }
+    }
+}
+
+// out[pos, pos + len) = out[pos - dist ...]: inside the ring, or - a source that left the ring - from global memory
 INF_FN int inf_match(InfState& s, uint32_t dist, uint32_t len) {
     if (dist > s.pos) return INF_E_DIST;
     if (s.pos + len > s.out_cap) return INF_E_OUTPUT;
-    inf_flush(s);
-    // the source may have been written by this wave a moment ago (by other lanes): only then wait for the stores (workgroup-scope fence)
-    if (s.pos - dist + (len < dist ? len : dist) > s.clean) {
-#ifndef INF_HOST
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
-        s.clean = s.pos;
+    if (dist + len <= INF_RING) inf_copy_near(s, s.pos, dist, len);
+    else {
+        // the source was flushed long ago (pending output is far shorter than the ring); wait for those stores only if they may still be in flight
+        uint8_t* ring = s.sc->ring;
+        W_VEC(uint32_t, v);
+        if (s.pos - dist + len > s.clean) { W_FENCE(); s.clean = s.flushed; }
+        for (uint32_t done = 0; done < len; done += 64u) {
+            const uint32_t n = len - done < 64u ? len - done : 64u;
+            W_FOR { if ((uint32_t)W_LANE < n) V(v) = s.out[s.pos + done + (uint32_t)W_LANE - dist]; }
+            W_FOR { if ((uint32_t)W_LANE < n) ring[inf_ridx(s, s.pos + done + (uint32_t)W_LANE)] = (uint8_t)V(v); }
+        }
     }
-#ifdef INF_HOST
-    for (uint32_t i = 0; i < len; i++) s.out[s.pos + i] = s.out[s.pos - dist + i];
-#else
-    const uint8_t* src = s.out + (s.pos - dist);
-    uint8_t* dst = s.out + s.pos;
-    for (uint32_t i = (uint32_t)INF_LANE; i < len; i += 64) dst[i] = src[dist >= len ? i : i % dist];
-#endif
     s.pos += len;
     return 0;
 }
 
-// ---- canonical Huffman ------------------------------------------------------------------------------------------------------
-// counts per code length live in registers (constant indices after unrolling); the symbols in canonical order in scratch
-struct InfCounts { uint16_t c[INF_MAXBITS + 1]; };
-
-INF_FN int inf_decode(InfState& s, const InfCounts& h, const uint16_t* symbol) {
-    inf_need(s, INF_MAXBITS);
-    uint32_t bits = (uint32_t)s.bitbuf;
+// ---- canonical Huffman ----------------------------------------------------------------------------------------------------------------------------
+// slow path: a code longer than its fast table (counts per length in registers, symbols in canonical order in scratch)
+INF_FN int inf_decode_slow(InfState& s, const uint16_t* counts, const uint16_t* symbol) {
+    uint32_t bits = inf_peek(s, s.bp);
     int code = 0, first = 0, index = 0;
-#pragma unroll
+#pragma unroll 1
     for (int len = 1; len <= INF_MAXBITS; len++) {
         code |= (int)(bits & 1u); bits >>= 1;
-        const int count = h.c[len];
+#ifdef INF_HOST
+        const int count = counts[len];
+#else
+        const int count = __builtin_amdgcn_readfirstlane((int)counts[len]);
+#endif
         if (code - count < first) {
-            s.bitbuf >>= len; s.bitcnt -= len;
-            return (int)INF_UNI(symbol[index + (code - first)]);
+            s.bp += (uint32_t)len;
+#ifdef INF_HOST
+            return (int)symbol[index + (code - first)];
+#else
+            return __builtin_amdgcn_readfirstlane((int)symbol[index + (code - first)]);
+#endif
         }
         index += count; first += count;
         first <<= 1; code <<= 1;
@@ -146,182 +256,326 @@ INF_FN int inf_decode(InfState& s, const InfCounts& h, const uint16_t* symbol) {
     return INF_E_SYMBOL;
 }
 
-// lengths len[0..n) -> counts (registers) + symbols in canonical order; returns 0 for a complete code, > 0 incomplete, < 0 over-subscribed
-INF_FN int inf_construct(InfScratch& sc, const uint16_t* len, int n, InfCounts& h, uint16_t* symbol) {
-    const bool writer = INF_LANE == 0;
-    if (writer) for (int l = 0; l <= INF_MAXBITS; l++) sc.cnt[l] = 0;
-    if (writer) for (int i = 0; i < n; i++) sc.cnt[len[i]]++;
+// Code lengths len[0..n) (scratch) -> counts per length, symbols in canonical order, fast table of `fb` bits; simple_below: symbols below it carry
+// INF_SIMPLE.  All lanes work: lane l owns symbols l, l + 64, ...; the rank of a symbol among those of its length comes from ballots.
+// Returns 0 for a complete code, > 0 incomplete, < 0 over-subscribed; *used = symbols with a code.
+INF_FN int inf_build(InfState& s, const uint8_t* len, int n, uint16_t* counts, uint16_t* symbol, uint16_t* fast, int fb, int simple_below, int* used) {
+    W_VEC2(uint32_t, L, 5);
 #pragma unroll
-    for (int l = 0; l <= INF_MAXBITS; l++) h.c[l] = (uint16_t)INF_UNI(sc.cnt[l]);
-    if (h.c[0] == n) return 0;                                 // no codes: complete, but decoding with it fails
+    for (int r = 0; r < 5; r++) { W_FOR { const int i = r * 64 + W_LANE; V2(L, r) = i < n ? (uint32_t)len[i] : 0u; } }
+    W_FOR { for (int k = W_LANE; k < (1 << (fb - 1)); k += 64) reinterpret_cast<uint32_t*>(fast)[k] = 0u; }
     int left = 1;
+    uint32_t code = 0, base = 0;
+#pragma unroll 1
+    for (int l = 1; l <= INF_MAXBITS; l++) {
+        uint32_t cnt = 0;
 #pragma unroll
-    for (int l = 1; l <= INF_MAXBITS; l++) { left <<= 1; left -= h.c[l]; if (left < 0) return left; }
-    // offsets of each length in the symbol table (sc.cnt is reused as the running offsets)
-    if (writer) {
-        uint16_t off = 0;
-        for (int l = 1; l <= INF_MAXBITS; l++) { const uint16_t c = sc.cnt[l]; sc.cnt[l] = off; off = (uint16_t)(off + c); }
-        for (int i = 0; i < n; i++) if (len[i] != 0) symbol[sc.cnt[len[i]]++] = (uint16_t)i;
+        for (int r = 0; r < 5; r++) {
+            if (r * 64 >= n) break;
+            uint64_t m;
+            W_BALLOT(m, V2(L, r) == (uint32_t)l);
+            if (m) {
+                W_FOR {
+                    if (V2(L, r) == (uint32_t)l) {
+                        const uint32_t rank = cnt + W_RANK(m), sym = (uint32_t)(r * 64 + W_LANE);
+                        symbol[base + rank] = (uint16_t)sym;
+                        if (l <= fb) {
+                            const uint32_t rev = inf_bitrev(code + rank) >> (32 - l);
+                            const uint16_t e = (uint16_t)(((uint32_t)l << 10) | ((int)sym < simple_below ? INF_SIMPLE : 0u) | sym);
+                            for (uint32_t k = rev; k < (1u << fb); k += 1u << l) fast[k] = e;
+                        }
+                    }
+                }
+                cnt += (uint32_t)__builtin_popcountll(m);
+            }
+        }
+        W_FOR { if (W_LANE == 0) counts[l] = (uint16_t)cnt; }
+        left <<= 1; left -= (int)cnt;
+        if (left < 0) return left;
+        base += cnt;
+        code = (code + cnt) << 1;
     }
+    *used = (int)base;
     return left;
 }
 
-// fast table of a code built by inf_construct: entry[bits] for every `fb`-bit window whose low bits are a complete code of at most fb bits
-INF_FN void inf_fast_table(InfScratch& sc, const uint16_t* len, int n, const InfCounts& h, uint16_t* fast, int fb) {
-    // canonical codes: first code of every length, then symbols in order (lane 0; a few hundred steps)
-    if (INF_LANE == 0) {
-        uint16_t* next = sc.cnt;                                    // free again after inf_construct
-        uint32_t code = 0;
-        next[0] = 0;
-#pragma unroll
-        for (int l = 1; l <= INF_MAXBITS; l++) { code = (code + (l > 1 ? (uint32_t)h.c[l - 1] : 0u)) << 1; next[l] = (uint16_t)code; }
-        for (int i = 0; i < n; i++) { const int l = len[i]; sc.code[i] = l ? next[l]++ : 0; }
+// one 64-offset lookup step: entry of the code that would start at bit bp + lane, for a table of fb bits
+#define INF_WINDOW(s, fast, fb, E)                                                                                                         \
+    {                                                                                                                                      \
+        const uint32_t d0_ = (s).bp >> 5, sh_ = (s).bp & 31u;                                                                              \
+        const uint32_t w0_ = inf_word(s, d0_), w1_ = inf_word(s, d0_ + 1u), w2_ = inf_word(s, d0_ + 2u), w3_ = inf_word(s, d0_ + 3u);      \
+        W_FOR {                                                                                                                            \
+            const uint32_t b_ = sh_ + (uint32_t)W_LANE, i_ = b_ >> 5, f_ = b_ & 31u;                                                       \
+            const uint32_t lo_ = i_ == 0u ? w0_ : (i_ == 1u ? w1_ : w2_), hi_ = i_ == 0u ? w1_ : (i_ == 1u ? w2_ : w3_);                   \
+            const uint32_t bits_ = (uint32_t)((((uint64_t)hi_ << 32) | lo_) >> f_);                                                        \
+            V(E) = (fast)[bits_ & ((1u << (fb)) - 1u)];                                                                                    \
+        }                                                                                                                                  \
     }
-#ifdef INF_HOST
-    for (int k = 0; k < (1 << fb); k++) fast[k] = 0;
-    for (int i = 0; i < n; i++) {
-#else
-    for (int k = INF_LANE; k < (1 << fb); k += 64) fast[k] = 0;
-    for (int i = INF_LANE; i < n; i += 64) {
-#endif
-        const int l = len[i];
-        if (l == 0 || l > fb) continue;
-        uint32_t c = sc.code[i], r = 0;
-        for (int b = 0; b < l; b++) { r = (r << 1) | (c & 1u); c >>= 1; }          // the stream carries codes most significant bit first
-        const uint16_t e = (uint16_t)((l << 9) | i);
-        for (uint32_t k = r; k < (1u << fb); k += 1u << l) fast[k] = e;
-    }
-}
 
-INF_FN int inf_decode_fast(InfState& s, const InfCounts& h, const uint16_t* symbol, const uint16_t* fast, int fb) {
-    inf_need(s, INF_MAXBITS);
-    const uint32_t e = (uint32_t)INF_UNI(fast[(uint32_t)s.bitbuf & ((1u << fb) - 1u)]) & 0xffffu;
-    if (e) { const int l = (int)(e >> 9); s.bitbuf >>= l; s.bitcnt -= l; return (int)(e & 511u); }
-    return inf_decode(s, h, symbol);
-}
+// length symbol (257 + i) -> base length and extra bits; distance symbol -> base distance and extra bits (RFC 1951 3.2.5 in closed form)
+INF_FN uint32_t inf_len_extra(uint32_t i) { return i < 8u || i >= 28u ? 0u : (i - 4u) >> 2; }
+INF_FN uint32_t inf_len_base(uint32_t i, uint32_t xb) { return i < 8u ? 3u + i : (i >= 28u ? 258u : 3u + ((4u + (i & 3u)) << xb)); }
+INF_FN uint32_t inf_dist_extra(uint32_t ds) { return ds < 4u ? 0u : (ds - 2u) >> 1; }
+INF_FN uint32_t inf_dist_base(uint32_t ds, uint32_t xb) { return ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << xb); }
 
-INF_FN int inf_codes(InfState& s, const InfCounts& lc, const uint16_t* lsym, const InfCounts& dc, const uint16_t* dsym, const InfScratch& sc) {
-    // length / distance bases and extra bits (RFC 1951 3.2.5), packed: base | extra << 16
-    static const uint32_t lens[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11 | 1 << 16, 13 | 1 << 16, 15 | 1 << 16, 17 | 1 << 16, 19 | 2 << 16, 23 | 2 << 16, 27 | 2 << 16,
-                                      31 | 2 << 16, 35 | 3 << 16, 43 | 3 << 16, 51 | 3 << 16, 59 | 3 << 16, 67 | 4 << 16, 83 | 4 << 16, 99 | 4 << 16, 115 | 4 << 16,
-                                      131 | 5 << 16, 163 | 5 << 16, 195 | 5 << 16, 227 | 5 << 16, 258};
-    static const uint32_t dists[30] = {1, 2, 3, 4, 5 | 1 << 16, 7 | 1 << 16, 9 | 2 << 16, 13 | 2 << 16, 17 | 3 << 16, 25 | 3 << 16, 33 | 4 << 16, 49 | 4 << 16,
-                                       65 | 5 << 16, 97 | 5 << 16, 129 | 6 << 16, 193 | 6 << 16, 257 | 7 << 16, 385 | 7 << 16, 513 | 8 << 16, 769 | 8 << 16,
-                                       1025 | 9 << 16, 1537 | 9 << 16, 2049 | 10 << 16, 3073 | 10 << 16, 4097 | 11 << 16, 6145 | 11 << 16, 8193 | 12 << 16,
-                                       12289 | 12 << 16, 16385 | 13 << 16, 24577 | 13 << 16};
+INF_FN int inf_codes(InfState& s) {
+    InfScratch& sc = *s.sc;
     for (;;) {
-        int sym = inf_decode_fast(s, lc, lsym, sc.fast_l, INF_FAST_L);
-        if (sym < 0) return sym;
-        if (sym < 256) { const int rc = inf_literal(s, (uint32_t)sym); if (rc) return rc; continue; }
+        if (s.bp > 32u * s.in_words + 64u) return INF_E_INPUT;
+        inf_sync_input(s);
+        inf_maybe_flush(s);
+        // every lane: the 32 input bits from its offset on, and the literal/length entry of the code that would start there
+        W_VEC(uint32_t, XL); W_VEC(uint32_t, E);
+        {
+            const uint32_t d0 = s.bp >> 5, sh = s.bp & 31u, j0 = d0 - s.cbase;
+            uint32_t w0, w1, w2, w3;
+            if (j0 < 61u) { w0 = W_READLANE(s.cA, j0); w1 = W_READLANE(s.cA, j0 + 1u); w2 = W_READLANE(s.cA, j0 + 2u); w3 = W_READLANE(s.cA, j0 + 3u); }   // (the usual case)
+            else { w0 = inf_word(s, d0); w1 = inf_word(s, d0 + 1u); w2 = inf_word(s, d0 + 2u); w3 = inf_word(s, d0 + 3u); }
+            W_FOR {
+                const uint32_t b = sh + (uint32_t)W_LANE, i = b >> 5, f = b & 31u;
+                const uint32_t a0 = i == 0u ? w0 : (i == 1u ? w1 : w2), a1 = i == 0u ? w1 : (i == 1u ? w2 : w3);
+                V(XL) = (uint32_t)((((uint64_t)a1 << 32) | a0) >> f);
+                V(E) = sc.fast_l[V(XL) & ((1u << INF_FAST_L) - 1u)];
+            }
+        }
+        // phase A: follow the code starts through the 64 entries while they are literals
+        uint64_t M = 0;
+        uint32_t o = 0, e;
+#define INF_HOP_A                                                                                                           \
+        e = W_READLANE(E, o);                                                                                               \
+        if (!(e & INF_SIMPLE)) break;                                                                                       \
+        M |= 1ull << o;                                                                                                     \
+        o += e >> 10;                                                                                                       \
+        if (o >= 64u) { e = INF_SIMPLE; break; }                  /* window used up; the next step continues at bp + o */
+        for (;;) { INF_HOP_A INF_HOP_A INF_HOP_A INF_HOP_A }            // (four hops per taken branch)
+#undef INF_HOP_A
+        const uint32_t nlit = (uint32_t)__builtin_popcountll(M);
+        if (nlit) {
+            if (s.pos + nlit > s.out_cap) return INF_E_OUTPUT;
+            W_FOR { if ((M >> W_LANE) & 1ull) sc.ring[inf_ridx(s, s.pos + W_RANK(M))] = (uint8_t)V(E); }
+            s.pos += nlit;
+        }
+        if (e & INF_SIMPLE) { s.bp += o; continue; }
+        if (e != 0u && (e & 511u) >= 257u && (e & 511u) <= 285u) {
+            // phase B: a length code.  Every lane decodes the WHOLE token that would start at its offset (literal, or length + extra bits +
+            // distance code + extra bits: one more table gather), then the chain runs on over literals and matches alike
+            W_VEC(uint32_t, T); W_VEC(uint32_t, DV);
+            W_FOR {
+                // 32-bit arithmetic on the low word: a token of more than 32 bits (long distance codes with many extra bits) is left to the serial path
+                const uint32_t x = V(XL);
+                const uint32_t ee = V(E), cl = ee >> 10;
+                uint32_t t, dv = 0;
+                if (ee & INF_SIMPLE) t = cl | (1u << 8);
+                else {
+                    const uint32_t i = (ee & 511u) - 257u;                                   // 0..28 for a length symbol
+                    const uint32_t xb = inf_len_extra(i);
+                    const uint32_t len = inf_len_base(i, xb) + ((x >> cl) & ((1u << xb) - 1u));
+                    const uint32_t p2 = cl + xb;                                             // <= 15
+                    const uint32_t de = sc.fast_d[(x >> p2) & ((1u << INF_FAST_D) - 1u)];
+                    const uint32_t dcl = de >> 10, ds = (de & 511u) < 30u ? (de & 511u) : 0u;
+                    const uint32_t dxb = inf_dist_extra(ds), p3 = p2 + dcl;                    // p3 <= 23
+                    dv = inf_dist_base(ds, dxb) + ((x >> p3) & ((1u << dxb) - 1u));
+                    const bool ok = ee != 0u && i <= 28u && de != 0u && (de & 511u) < 30u && p3 + dxb <= 32u && dv + len + INF_STEP_CAP <= INF_RING;
+                    t = ok ? ((p3 + dxb) | (len << 8) | INF_T_MATCH) : INF_T_STOP;
+                }
+                V(T) = t; V(DV) = dv;
+            }
+            uint64_t MT = 0;
+            uint32_t o2 = o, acc = 0, t = 0;
+#define INF_HOP_B                                                                                                           \
+            t = W_READLANE(T, o2);                                                                                          \
+            if (t & INF_T_STOP) break;                                                                                      \
+            if (acc + ((t >> 8) & 511u) > INF_STEP_CAP) break;                                                              \
+            acc += (t >> 8) & 511u;                                                                                         \
+            MT |= 1ull << o2;                                                                                               \
+            o2 += t & 63u;                                                                                                  \
+            if (o2 >= 64u) break;
+            for (;;) { INF_HOP_B INF_HOP_B INF_HOP_B INF_HOP_B }
+#undef INF_HOP_B
+            if (MT) {
+                if (s.pos + acc > s.out_cap) return INF_E_OUTPUT;
+                W_VEC(uint32_t, OL); W_VEC(uint32_t, EX);
+                W_FOR { V(OL) = ((MT >> W_LANE) & 1ull) ? (V(T) >> 8) & 511u : 0u; }
+                uint32_t total;
+                W_EXCL_SCAN(EX, OL, total);
+                (void)total;
+                W_FOR { if (((MT >> W_LANE) & 1ull) && !(V(T) & INF_T_MATCH)) sc.ring[inf_ridx(s, s.pos + V(EX))] = (uint8_t)V(E); }
+                uint64_t MM;
+                W_BALLOT(MM, ((MT >> W_LANE) & 1ull) && (V(T) & INF_T_MATCH));
+                while (MM) {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(MM);
+                    MM &= MM - 1ull;
+                    const uint32_t len = (W_READLANE(T, k) >> 8) & 511u, dist = W_READLANE(DV, k), op = s.pos + W_READLANE(EX, k);
+                    if (dist > op) return INF_E_DIST;
+                    inf_copy_near(s, op, dist, len);
+                }
+                s.pos += acc;
+                s.bp += o2;
+                continue;                                               // (a token the chain stopped at starts the next step)
+            }
+            // the very first token is not a plain near match: the serial path below decodes it
+        }
+        s.bp += o;
+        int sym;
+        if (e) { sym = (int)(e & 511u); s.bp += e >> 10; }
+        else {
+            sym = inf_decode_slow(s, sc.cnt_l, sc.lsym);
+            if (sym < 0) return sym;
+            if (sym < 256) {
+                if (s.pos >= s.out_cap) return INF_E_OUTPUT;
+                W_FOR { if (W_LANE == 0) sc.ring[inf_ridx(s, s.pos)] = (uint8_t)sym; }
+                s.pos++;
+                continue;
+            }
+        }
         if (sym == 256) return 0;
         sym -= 257;
         if (sym >= 29) return INF_E_SYMBOL;
-        const uint32_t le = lens[sym];
-        const uint32_t len = (le & 0xffffu) + inf_bits(s, (int)(le >> 16));
-        const int ds = inf_decode_fast(s, dc, dsym, sc.fast_d, INF_FAST_D);
-        if (ds < 0) return ds;
+        const uint32_t lxb = inf_len_extra((uint32_t)sym);
+        const uint32_t len = inf_len_base((uint32_t)sym, lxb) + inf_bits(s, (int)lxb);
+        int ds;
+        {
+            const uint32_t idx = inf_peek(s, s.bp) & ((1u << INF_FAST_D) - 1u);
+#ifdef INF_HOST
+            const uint32_t de = sc.fast_d[idx];
+#else
+            const uint32_t de = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.fast_d[idx]);
+#endif
+            if (de) { ds = (int)(de & 511u); s.bp += de >> 10; }
+            else { ds = inf_decode_slow(s, sc.cnt_d, sc.dsym); if (ds < 0) return ds; }
+        }
         if (ds >= 30) return INF_E_SYMBOL;
-        const uint32_t de = dists[ds];
-        const uint32_t dist = (de & 0xffffu) + inf_bits(s, (int)(de >> 16));
+        const uint32_t dxb = inf_dist_extra((uint32_t)ds);
+        const uint32_t dist = inf_dist_base((uint32_t)ds, dxb) + inf_bits(s, (int)dxb);
         const int rc = inf_match(s, dist, len);
         if (rc) return rc;
     }
 }
 
+// the code lengths of a dynamic block: nlen + ndist values coded with the code-length code (RFC 1951 3.2.7) -> sc.len[0 .. nlen + ndist)
+INF_FN int inf_code_lengths(InfState& s, int total) {
+    InfScratch& sc = *s.sc;
+    int index = 0;
+    while (index < total) {
+        if (s.bp > 32u * s.in_words + 64u) return INF_E_INPUT;
+        inf_sync_input(s);
+        W_VEC(uint32_t, E);
+        INF_WINDOW(s, sc.fast_c, INF_FAST_C, E);
+        uint64_t M = 0;
+        uint32_t o = 0, e;
+        int room = total - index;
+        for (;;) {
+            e = W_READLANE(E, o);
+            if (!(e & INF_SIMPLE) || room == 0) break;
+            M |= 1ull << o; room--;
+            o += e >> 10;
+            if (o >= 64u) { e = INF_SIMPLE; break; }
+        }
+        const int k = __builtin_popcountll(M);
+        if (k) { W_FOR { if ((M >> W_LANE) & 1ull) sc.len[index + (int)W_RANK(M)] = (uint8_t)(V(E) & 31u); } index += k; }
+        s.bp += o;
+        if ((e & INF_SIMPLE) || index >= total) continue;
+        int sym;
+        if (e) { sym = (int)(e & 511u); s.bp += e >> 10; }
+        else { sym = inf_decode_slow(s, sc.cnt_c, sc.csym); if (sym < 0) return sym; }
+        if (sym < 16) { W_FOR { if (W_LANE == 0) sc.len[index] = (uint8_t)sym; } index++; continue; }
+        uint32_t prev = 0, rep;
+        if (sym == 16) {
+            if (index == 0) return INF_E_CODELEN;
+#ifdef INF_HOST
+            prev = sc.len[index - 1];
+#else
+            prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.len[index - 1]);
+#endif
+            rep = 3u + inf_bits(s, 2);
+        } else if (sym == 17) rep = 3u + inf_bits(s, 3);
+        else rep = 11u + inf_bits(s, 7);
+        if (index + (int)rep > total) return INF_E_CODELEN;
+        W_FOR { for (uint32_t r = (uint32_t)W_LANE; r < rep; r += 64u) sc.len[index + (int)r] = (uint8_t)prev; }
+        index += (int)rep;
+    }
+    return 0;
+}
+
 // one raw DEFLATE stream: `payload` (any alignment, in_bytes long), out_cap = ISIZE.  Returns the number of bytes produced (== ISIZE for a
-// sound block) or a negative INF_E_*.  Device: every lane of the wave must call, with wave-uniform arguments.
+// sound block) or a negative INF_E_*.  Device: every lane of the wave must call, with wave-uniform arguments; `sc` is that wave's own scratch.
 INF_FN int inflate_raw(const uint8_t* payload, uint32_t in_bytes, uint8_t* out, uint32_t out_cap, InfScratch& sc) {
     InfState s;
-    // the bit reader works on aligned 32-bit words: the up to 3 bytes in front of the payload are read and dropped
+    // the bit reader works on aligned 32-bit words: the up to 3 bytes in front of the payload are skipped
     const uint32_t skip = (uint32_t)(reinterpret_cast<uintptr_t>(payload) & 3u);
     in_bytes += skip;
-    s.in = reinterpret_cast<const uint32_t*>(payload - skip); s.in_words = (in_bytes + 3u) / 4u; s.in_at = 0; s.bitbuf = 0; s.bitcnt = 0;
-    s.ahead = s.in_words ? s.in[0] : 0u;
-    s.out = out; s.out_cap = out_cap; s.pos = 0; s.staged = 0; s.clean = 0;
-#ifndef INF_HOST
-    s.stage = 0;
-#endif
-    if (skip) (void)inf_bits(s, 8 * (int)skip);
-    InfCounts lc, dc;
+    s.in = reinterpret_cast<const uint32_t*>(payload - skip); s.in_words = (in_bytes + 3u) / 4u; s.bp = 8u * skip;
+    s.out = out; s.out_cap = out_cap; s.pos = 0; s.flushed = 0; s.clean = 0; s.mis = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15u);
+    s.sc = &sc;
+    inf_load_chunks(s, 0);
+    int used = 0;
     for (;;) {
+        if (s.bp > 32u * s.in_words + 64u) return INF_E_INPUT;
+        inf_sync_input(s);
         const uint32_t last = inf_bits(s, 1), type = inf_bits(s, 2);
         if (type == 0) {
             // stored: skip to the byte boundary, LEN, ~LEN, LEN bytes
-            const int drop = s.bitcnt & 7;
-            s.bitbuf >>= drop; s.bitcnt -= drop;
+            s.bp = (s.bp + 7u) & ~7u;
             const uint32_t len = inf_bits(s, 16), nlen = inf_bits(s, 16);
             if (len != (~nlen & 0xffffu)) return INF_E_STORED;
             if (s.pos + len > s.out_cap) return INF_E_OUTPUT;
-            inf_flush(s);
-            // byte position of the data in the input: words consumed * 4 - bytes still in the bit buffer
-            const uint32_t at = s.in_at * 4u - (uint32_t)(s.bitcnt >> 3);
+            const uint32_t at = s.bp >> 3;
             if (at + len > in_bytes) return INF_E_INPUT;
             const uint8_t* src = reinterpret_cast<const uint8_t*>(s.in) + at;
-#ifdef INF_HOST
-            for (uint32_t i = 0; i < len; i++) s.out[s.pos + i] = src[i];
-#else
-            for (uint32_t i = (uint32_t)INF_LANE; i < len; i += 64) s.out[s.pos + i] = src[i];
-#endif
-            s.pos += len;
-            // restart the bit reader behind the stored bytes
-            const uint32_t next = at + len;
-            s.in_at = next / 4u; s.bitbuf = 0; s.bitcnt = 0;
-            s.ahead = s.in_at < s.in_words ? s.in[s.in_at] : 0u;
-            if (next & 3u) (void)inf_bits(s, 8 * (int)(next & 3u));
+            for (uint32_t done = 0; done < len; done += 64u) {
+                const uint32_t n = len - done < 64u ? len - done : 64u;
+                W_VEC(uint32_t, v);
+                W_FOR { if ((uint32_t)W_LANE < n) V(v) = src[done + (uint32_t)W_LANE]; }
+                W_FOR { if ((uint32_t)W_LANE < n) sc.ring[inf_ridx(s, s.pos + (uint32_t)W_LANE)] = (uint8_t)V(v); }
+                s.pos += n;
+                inf_maybe_flush(s);
+            }
+            s.bp += 8u * len;
         } else if (type == 1 || type == 2) {
             if (type == 1) {
-                if (INF_LANE == 0) {
-                    for (int i = 0; i < 144; i++) sc.len[i] = 8;
-                    for (int i = 144; i < 256; i++) sc.len[i] = 9;
-                    for (int i = 256; i < 280; i++) sc.len[i] = 7;
-                    for (int i = 280; i < 288; i++) sc.len[i] = 8;
-                    for (int i = 0; i < 30; i++) sc.len[288 + i] = 5;
+                W_FOR {
+                    for (int i = W_LANE; i < 288; i += 64) sc.len[i] = (uint8_t)(i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
+                    if (W_LANE < 30) sc.len[288 + W_LANE] = 5;
                 }
-                (void)inf_construct(sc, sc.len, 288, lc, sc.lsym);
-                inf_fast_table(sc, sc.len, 288, lc, sc.fast_l, INF_FAST_L);
-                (void)inf_construct(sc, sc.len + 288, 30, dc, sc.dsym);
-                inf_fast_table(sc, sc.len + 288, 30, dc, sc.fast_d, INF_FAST_D);
+                (void)inf_build(s, sc.len, 288, sc.cnt_l, sc.lsym, sc.fast_l, INF_FAST_L, 256, &used);
+                (void)inf_build(s, sc.len + 288, 30, sc.cnt_d, sc.dsym, sc.fast_d, INF_FAST_D, 0, &used);
             } else {
                 static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
                 const int nlen = (int)inf_bits(s, 5) + 257, ndist = (int)inf_bits(s, 5) + 1, ncode = (int)inf_bits(s, 4) + 4;
                 if (nlen > 286 || ndist > 30) return INF_E_CODELEN;
-                // the code-length code: 19 symbols of up to 7 bits; its lengths go through sc.len as well (lane 0 writes, everybody reads)
-                for (int i = 0; i < 19; i++) { const uint32_t v = i < ncode ? inf_bits(s, 3) : 0u; if (INF_LANE == 0) sc.len[order[i]] = (uint16_t)v; }
-                InfCounts cc;
-                int err = inf_construct(sc, sc.len, 19, cc, sc.lsym);
-                if (err != 0) return INF_E_CODELEN;                      // complete code required here
-                // cc's symbols sit in sc.lsym[0..19); move them out of the way of the real table: the tail of dsym's neighbour is free until then
-                uint16_t* csym = sc.lsym + 256;                           // lsym[256..275): overwritten only when the literal/length table is built
-                if (INF_LANE == 0) for (int i = 0; i < 19; i++) csym[i] = sc.lsym[i];
-                int index = 0;
-                while (index < nlen + ndist) {
-                    int sym = inf_decode(s, cc, csym);
-                    if (sym < 0) return sym;
-                    if (sym < 16) { if (INF_LANE == 0) sc.len[index] = (uint16_t)sym; index++; }
-                    else {
-                        uint32_t prev = 0, rep;
-                        if (sym == 16) { if (index == 0) return INF_E_CODELEN; prev = (uint32_t)INF_UNI(sc.len[index - 1]); rep = 3 + inf_bits(s, 2); }
-                        else if (sym == 17) rep = 3 + inf_bits(s, 3);
-                        else rep = 11 + inf_bits(s, 7);
-                        if (index + (int)rep > nlen + ndist) return INF_E_CODELEN;
-                        if (INF_LANE == 0) for (uint32_t r = 0; r < rep; r++) sc.len[index + (int)r] = (uint16_t)prev;
-                        index += (int)rep;
+                // the code-length code: 19 symbols of up to 7 bits, 3 bits each in the header (57 bits: two peeks)
+                W_FOR { if (W_LANE < 19) sc.len[W_LANE] = 0; }
+                {
+                    const uint32_t a = inf_peek(s, s.bp), b = inf_peek(s, s.bp + 30u);
+                    W_FOR {
+                        if (W_LANE < ncode) {
+                            const uint32_t v3 = W_LANE < 10 ? (a >> (3 * W_LANE)) & 7u : (b >> (3 * (W_LANE - 10))) & 7u;
+                            sc.len[order[W_LANE]] = (uint8_t)v3;
+                        }
                     }
+                    s.bp += 3u * (uint32_t)ncode;
                 }
-                if ((int)INF_UNI(sc.len[256]) == 0) return INF_E_CODELEN;           // no end-of-block code
-                // the distance lengths first (construct of the literal/length code overwrites lsym, where csym lived)
-                err = inf_construct(sc, sc.len + nlen, ndist, dc, sc.dsym);
-                if (err < 0 || (err > 0 && ndist - dc.c[0] != 1)) return INF_E_OVERSUB;   // incomplete only allowed for a single distance code
-                inf_fast_table(sc, sc.len + nlen, ndist, dc, sc.fast_d, INF_FAST_D);
-                err = inf_construct(sc, sc.len, nlen, lc, sc.lsym);
-                if (err < 0 || (err > 0 && nlen - lc.c[0] != 1)) return INF_E_OVERSUB;
-                inf_fast_table(sc, sc.len, nlen, lc, sc.fast_l, INF_FAST_L);
+                int err = inf_build(s, sc.len, 19, sc.cnt_c, sc.csym, sc.fast_c, INF_FAST_C, 16, &used);
+                if (err != 0) return INF_E_CODELEN;                      // complete code required here
+                err = inf_code_lengths(s, nlen + ndist);
+                if (err) return err;
+#ifdef INF_HOST
+                const int eob_len = sc.len[256];
+#else
+                const int eob_len = __builtin_amdgcn_readfirstlane((int)sc.len[256]);
+#endif
+                if (eob_len == 0) return INF_E_CODELEN;                  // no end-of-block code
+                err = inf_build(s, sc.len + nlen, ndist, sc.cnt_d, sc.dsym, sc.fast_d, INF_FAST_D, 0, &used);
+                if (err < 0 || (err > 0 && used != 1)) return INF_E_OVERSUB;   // incomplete only allowed for a single distance code
+                err = inf_build(s, sc.len, nlen, sc.cnt_l, sc.lsym, sc.fast_l, INF_FAST_L, 256, &used);
+                if (err < 0 || (err > 0 && used != 1)) return INF_E_OVERSUB;
             }
-            const int rc = inf_codes(s, lc, sc.lsym, dc, sc.dsym, sc);
+            const int rc = inf_codes(s);
             if (rc) return rc;
         } else return INF_E_BLOCKTYPE;
         if (last) break;
     }
-    inf_flush(s);
+    if ((s.bp + 7u) / 8u > in_bytes) return INF_E_INPUT;
+    inf_flush(s, s.pos);
     return (int)s.pos;
 }

@@ -38,17 +38,26 @@ def effective_cpus():
 class BamPipeline(object):
     """reader thread || GPU thread over one BAM file; results stay resident in the engine (accumulated lists)."""
 
-    def __init__(self, path, options, engine, threads=0, batch_records=200_000, mode="coordinate", sparse_seq=True, regions=None, gpu_inflate=None):
+    def __init__(self, path, options, engine, threads=0, batch_records=200_000, mode="coordinate", sparse_seq=True, regions=None, gpu_inflate=None,
+                 device_decode=None):
         from .bamio import NativeBam
         self.bam = NativeBam(path, threads=threads)
-        if gpu_inflate is None and os.environ.get("SVX_BAM_GPU_INFLATE", "1") != "0":
-            gpu_inflate = getattr(engine, "device", None)          # default: the engine's GPU helps with the inflate (SVX_BAM_GPU_INFLATE=0: host only)
-        if gpu_inflate is not None and gpu_inflate is not False:
-            self.bam.set_gpu_inflate(int(gpu_inflate))          # BGZF inflate shared between that GPU and the host's cores
+        dev = getattr(engine, "device", None)
+        if device_decode is None:                                   # default for coordinate-sorted input on a GPU engine (SVX_BAM_DEVICE_DECODE=0: host reader)
+            device_decode = dev is not None and mode == "coordinate" and gpu_inflate is not False and os.environ.get("SVX_BAM_DEVICE_DECODE", "1") != "0"
+        self.device_decode = bool(device_decode)
         self.options, self.eng, self.mode, self.batch_records = options, engine, mode, batch_records
         self.params = _abi.Params.from_options(options)
-        if sparse_seq and mode == "coordinate":
-            self.bam.set_seq_filter(int(getattr(options, "min_sv_size", 40)))
+        if self.device_decode:
+            # inflate, record discovery and decode on the engine's GPU: batches arrive device-resident, only the compressed file crosses PCIe
+            self.bam.set_device_decode(int(dev))
+        else:
+            if gpu_inflate is None and os.environ.get("SVX_BAM_GPU_INFLATE", "1") != "0":
+                gpu_inflate = dev                                   # the engine's GPU helps with the inflate (SVX_BAM_GPU_INFLATE=0: host only)
+            if gpu_inflate is not None and gpu_inflate is not False:
+                self.bam.set_gpu_inflate(int(gpu_inflate))          # BGZF inflate shared between that GPU and the host's cores
+            if sparse_seq and mode == "coordinate":
+                self.bam.set_seq_filter(int(getattr(options, "min_sv_size", 40)))
         self.regions = regions            # [(virtual offset, last reference id)]: the contig runs this rank reads (None: the whole file)
         self.region_slots = []            # per region: (first local emission slot, records)
         self.stats = {}

@@ -454,22 +454,25 @@ def test_bam_pipeline_accumulates_batches_on_device(oracle, tmp_path):
     osig, obnd = oracle.collect(whole, p)
     oracle.set_genome(g_off.cpu().numpy().astype(np.int64), genome.cpu().numpy())
     oct_ = oracle.cluster(p, crank, source=0)
+    one_names = nb.read_names()
     nb.close()
     assert one_sig.first_difference(osig) is None and one_bnd.first_difference(obnd) is None
     assert one_ct.first_difference(oct_, rtol=1e-12) is None
-    # many batches through the pipeline
+    # many batches through the pipeline (the device-resident reader: read ids are numbered in another order - compared through the names)
     pipe = harness.BamPipeline(path, o, e, threads=4, batch_records=max(64, n // 7))
     assert pipe.run() == n and pipe.stats["batches"] >= 7
     pipe.cluster()
     many_ct = e.fetch_clusters()
     counts = e.collect_counts()
+    many_names = pipe.bam.read_names()
     pipe.close()
     assert e.collect_counts() == counts == (one_sig.n, int(one_sig.seq_off[one_sig.n]), one_bnd.n)     # still resident after accumulation ends
     many_sig, many_bnd = e.fetch_signatures(0), e.fetch_signatures(1)
     for a, c in ((many_sig, one_sig), (many_bnd, one_bnd)):
         for k in _abi.SIG_DTYPES:
-            if k != "key":
+            if k not in ("key", "read_id"):
                 assert np.array_equal(getattr(a, k)[:a.n], getattr(c, k)[:c.n]), k
+        assert [many_names[int(i)] for i in a.read_id[:a.n]] == [one_names[int(i)] for i in c.read_id[:c.n]]
         assert np.all(np.diff(a.key[:a.n].astype(np.int64)) > 0)                                       # one global emission order
         assert np.array_equal(a.seq_off, c.seq_off) and np.array_equal(a.seq[:int(a.seq_off[a.n])], c.seq[:int(c.seq_off[c.n])])
     assert many_ct.first_difference(one_ct) is None
@@ -1048,3 +1051,118 @@ def test_bench_two_ranks_one_gpu_with_foreign_rows():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["multi_gpu"]["foreign_segments_planted_rank0"] > 0
     assert d["multi_gpu"]["clusters_gathered"] > 100 and len(d["multi_gpu"]["signatures_per_rank"]) == 2
+
+
+def _read_all_batches(nb, batch_records, regions=None):
+    """every batch of a reader (host or device-resident) as host arrays + read names per record"""
+    out, names_per_rec = [], []
+    for region in (regions or [None]):
+        if region is not None:
+            nb.seek(region[0], region[1])
+        while True:
+            b, n = nb.read_batch(batch_records, 20, "coordinate")
+            if n == 0:
+                break
+            A = nb.batch_arrays(b)
+            names = nb.read_names()
+            names_per_rec += [names[int(i)] for i in A["read_id"]]
+            out.append(A)
+    return out, names_per_rec
+
+
+def _concat_batches(batches):
+    """record-level view that does not depend on how the records were cut into batches: per-record CIGARs, bases, segment rows"""
+    rows = []
+    for A in batches:
+        n = len(A["flag"])
+        co, so, sg, sc = A["cigar_off"].astype(np.int64), A["seq_off"].astype(np.int64), A["seg_off"].astype(np.int64), A["seg_cigar_off"].astype(np.int64)
+        for i in range(n):
+            nbytes = (int(A["lseq"][i]) + 1) // 2
+            segs = []
+            for r in range(int(sg[i]), int(sg[i + 1])):
+                segs.append((int(A["seg_tid"][r]), int(A["seg_pos"][r]), int(A["seg_rev"][r]), int(A["seg_mapq"][r]), int(A["seg_lseq"][r]),
+                             A["seg_cigar"][sc[r]:sc[r + 1]].tobytes()))
+            rows.append((int(A["flag"][i]), int(A["tid"][i]), int(A["pos"][i]), int(A["mapq"][i]), int(A["lseq"][i]), A["cigar"][co[i]:co[i + 1]].tobytes(),
+                         A["seq"][so[i]:so[i] + nbytes].tobytes(), tuple(segs)))
+        # emission slots are per batch (the caller adds its slot base): 2 i for the record's indels, 2 i + 1 for its read's split-alignment signatures
+        assert np.array_equal(A["order"], 2 * np.arange(n, dtype=np.uint32)) and np.array_equal(A["seg_order"], 2 * np.arange(n, dtype=np.uint32) + 1)
+    return rows
+
+
+@pytest.mark.parametrize("chunk_blocks", [None, "1", "3"])
+def test_device_bam_decode_equals_host_reader(tmp_path, monkeypatch, chunk_blocks):
+    """BGZF inflate + record discovery + field / CIGAR / SA / name decode ON THE GPU (svx_bam_set_device_decode, csrc/bamdev.hip) hands
+    out the records the host reader (bamio.cpp) decodes - flag, tid, pos, mapq, l_seq, packed CIGAR, packed bases, the SA-derived segment table, read names -
+    on configs[0] (small geometry), a multi-contig split-read file with SA tags to known and unknown contigs, and a record whose 67 000-operation CIGAR
+    lives in the CG tag; also with chunks of one / three BGZF blocks (records and even record HEADERS straddle chunk boundaries)."""
+    from svim_amd.bamio import NativeBam
+    if chunk_blocks:
+        monkeypatch.setenv("SVX_BAM_DEV_CHUNK_BLOCKS", chunk_blocks)
+    files = []
+    g, refs, recs = H.c1_case()
+    p1 = str(tmp_path / "c1.bam")
+    records.write_bam(p1, ["chr1"], [2000000], recs[:3000])
+    files.append((p1, 777))
+    refs3, lens3 = ["chr1", "chr2", "chr10"], [180000, 60000, 60000]
+    ref = synth.make_reference(21, list(zip(refs3, lens3)))
+    rr = synth.coordinate_sort(synth.fuzz_split_reads(22, 300, refs3, lens3) + synth.planted_reads(23, 400, ref, refs3, lens3, n_sites=30, types=("DEL", "INS", "INV")))
+    p2 = str(tmp_path / "split.bam")
+    records.write_bam(p2, refs3, lens3, rr)
+    files.append((p2, 97))
+    short, long_rec, cig = H.long_cigar_records()
+    p3 = str(tmp_path / "cg.bam")
+    records.write_bam(p3, ["chr1"], [2000000], [short, long_rec, short])
+    files.append((p3, 5))
+    for path, per_batch in files:
+        host = NativeBam(path, threads=2)
+        want, want_names = _read_all_batches(host, per_batch)
+        host.close()
+        dev = NativeBam(path, threads=2)
+        dev.set_device_decode(0)
+        for rep in range(2):                                               # a second pass after rewind: same records, same ids
+            got, got_names = _read_all_batches(dev, per_batch)
+            assert got_names == want_names, path
+            a, b = _concat_batches(got), _concat_batches(want)
+            assert len(a) == len(b) and len(a) > 2, path
+            for k, (x, y) in enumerate(zip(a, b)):
+                assert x == y, (path, k, [i for i, (u, v) in enumerate(zip(x, y)) if u != v])
+            dev.rewind()
+        dev.close()
+
+
+def test_device_bam_decode_regions_and_pipeline(eng, tmp_path, monkeypatch):
+    """contig-range reading (svx_bam_seek + reference id limit) in device mode == host mode, out of file order; and BamPipeline on the device reader
+    accumulates the same signature list as on the host reader."""
+    from svim_amd import harness
+    from svim_amd.bamio import NativeBam
+    refs, lens = ["chr1", "chr2", "chr10", "chr3"], [100000, 80000, 80000, 60000]
+    ref = synth.make_reference(61, list(zip(refs, lens)))
+    recs = synth.coordinate_sort(synth.fuzz_split_reads(62, 260, refs, lens, max_sv_size=20000) + synth.planted_reads(63, 300, ref, refs, lens, n_sites=25, types=("DEL", "INS", "INV")))
+    path = str(tmp_path / "m.bam")
+    records.write_bam(path, refs, lens, recs)
+    bai = records.read_bai(path + ".bai")
+    regions = [(bai[t][0], t) for t in (2, 0, 3, 1) if bai[t] is not None]
+    host = NativeBam(path, threads=2)
+    want, want_names = _read_all_batches(host, 41, regions)
+    host.close()
+    monkeypatch.setenv("SVX_BAM_DEV_CHUNK_BLOCKS", "2")
+    dev = NativeBam(path, threads=2)
+    dev.set_device_decode(0)
+    got, got_names = _read_all_batches(dev, 41, regions)
+    dev.close()
+    assert got_names == want_names
+    assert _concat_batches(got) == _concat_batches(want)
+    o = H.options({"min_mapq": 20, "min_sv_size": 40, "max_sv_size": 20000, "segment_gap_tolerance": 10, "segment_overlap_tolerance": 5, "partition_max_distance": 1000,
+                   "position_distance_normalizer": 900, "edit_distance_normalizer": 1.0, "cluster_max_distance": 0.5, "all_bnds": False})
+    tabs = []
+    for device_decode in (True, False):
+        pipe = harness.BamPipeline(path, o, eng, threads=2, batch_records=53, device_decode=device_decode)
+        assert pipe.device_decode is device_decode
+        n = pipe.run()
+        assert n == len(recs)
+        names = pipe.bam.read_names()
+        sig = eng.fetch_signatures(0)
+        pipe.close()
+        tabs.append([(int(sig.type[i]), int(sig.contig[i]), int(sig.start[i]), int(sig.end[i]), int(sig.contig2[i]), int(sig.pos2[i]), names[int(sig.read_id[i])], sig.sequence(i))
+                     for i in range(sig.n)])
+    assert tabs[0] == tabs[1] and len(tabs[0]) > 100
