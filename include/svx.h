@@ -298,7 +298,7 @@ int  svx_bam_seek(svx_bam* h, uint64_t voff, int32_t last_tid);
 int  svx_bam_set_gpu_inflate(svx_bam* h, int device);
 int  svx_bam_gpu_inflate_stats(svx_bam* h, int64_t* gpu_blocks, int64_t* cpu_blocks, double* gpu_kernel_ms);
 int  svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** nul_separated, int64_t* blob_len);
-/* Device-resident front-end (coordinate mode): the compressed file slice is the only thing that crosses PCIe.  Every chunk of BGZF blocks (2 GB of inflated
+/* Device-resident front-end (coordinate mode): the compressed file slice is the only thing that crosses PCIe.  Every chunk of BGZF blocks (8 GB of inflated
  * data) is inflated by the GPU into HBM (one wavefront per block), the record boundaries are found there (BGZF blocks are the restart points of the
  * block_size chain: a speculative record start per block, verified by linking the chains), and fixed fields, CIGAR (CG tag included), the SA tag -> segment
  * table and the read names (interned by 2 x 64-bit hashes) are decoded by kernels.  svx_bam_read_batch then returns an svx_batch whose pointers are DEVICE

@@ -18,6 +18,7 @@
 #define DD_NONE (~0ull)
 #define DD_HEAD ((size_t)32 << 20)            // room in front of a chunk's inflated data for the unconsumed tail of the chunk before
 #define DD_MAX_REC (1u << 28)
+#define DD_HBUF ((size_t)2048 << 20)           // pinned host memory for the host cores' share of a chunk's inflate
 #define DD_E_CORRUPT 1
 #define DD_E_AUX 2
 #define DD_E_SA 3
@@ -514,30 +515,39 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
     {
         const size_t sub_env = []() { const char* e = getenv("SVX_BAM_DEV_SUB"); return e && atoll(e) > 0 ? (size_t)atoll(e) : (size_t)0; }();       // (experiments)
         const int cpu_env = []() { const char* e = getenv("SVX_BAM_DEV_CPU"); return e ? atoi(e) : -1; }();
-        const size_t SUB = sub_env ? sub_env : 12288;
-        int n_cpu = cpu_env >= 0 ? cpu_env : (d->n_threads > 3 ? d->n_threads - 3 : 0);
+        const size_t SUB = sub_env ? sub_env : 32768;                  // a launch of >= ~25 k blocks runs at the kernel's best rate (a 12 k one at 0.8 of it: its tail)
+        int n_cpu = cpu_env >= 0 ? cpu_env : (d->n_threads > 8 ? d->n_threads - 6 : (d->n_threads > 3 ? d->n_threads - 3 : 0));      // (the staging copies want cores, too)
         if (nb_in < 4 * SUB / 3) n_cpu = 0;                            // a small chunk: one launch does it
         std::mutex m;
         size_t lo = 0, hi = nb_in;
+        size_t h_first_v = 0;                                              // (set below, before any worker runs)
         auto take = [&](bool front, size_t want, size_t& a, size_t& b) -> bool {
             std::lock_guard<std::mutex> g(m);
             if (lo >= hi) return false;
             if (front) { a = lo; b = hi < lo + want ? hi : lo + want; lo = b; }
-            else { b = hi; a = hi > lo + want ? hi - want : lo; hi = a; }
+            else {
+                const size_t floor_ = lo > h_first_v ? lo : h_first_v;
+                if (hi <= floor_) return false;
+                b = hi; a = hi > floor_ + want ? hi - want : floor_; hi = a;
+            }
             return true;
         };
         std::vector<std::string> errs((size_t)(n_cpu > 0 ? n_cpu : 1));
         std::vector<int64_t> cpu_done((size_t)(n_cpu > 0 ? n_cpu : 1), 0);
         std::vector<std::thread> workers;
-        if (n_cpu > 0) {
-            if (d->hbuf_cap < (size_t)total + 64) {
-                if (d->hbuf) (void)hipHostFree(d->hbuf);
-                d->hbuf = nullptr; d->hbuf_cap = 0;
-                void* p = nullptr;
-                if (hipHostMalloc(&p, (size_t)total + ((size_t)total >> 3) + 4096, hipHostMallocDefault) == hipSuccess) { d->hbuf = (uint8_t*)p; d->hbuf_cap = (size_t)total + ((size_t)total >> 3) + 4096; }
-                else { (void)hipGetLastError(); n_cpu = 0; }
-            }
+        // the host's share lands in pinned memory first: room for the BACK of the chunk (the cores take a quarter or so; at most DD_HBUF of it)
+        const size_t want_h = (size_t)total < DD_HBUF ? (size_t)total : DD_HBUF;
+        if (n_cpu > 0 && d->hbuf_cap < want_h) {
+            if (d->hbuf) (void)hipHostFree(d->hbuf);
+            d->hbuf = nullptr; d->hbuf_cap = 0;
+            void* p = nullptr;
+            if (hipHostMalloc(&p, want_h + 4096, hipHostMallocDefault) == hipSuccess) { d->hbuf = (uint8_t*)p; d->hbuf_cap = want_h; }
+            else { (void)hipGetLastError(); n_cpu = 0; }
         }
+        const uint64_t h_base = total > d->hbuf_cap ? total - d->hbuf_cap : 0;          // inflated offsets at or above this may go through the host buffer
+        size_t h_first = 0;                                                               // first block the cores may take
+        while (h_first < nb_in && out_at[h_first] < h_base) h_first++;
+        h_first_v = h_first;
         for (int w = 0; w < n_cpu; w++) workers.emplace_back([&, w]() {
             (void)hipSetDevice(d->device);
             z_stream zs; memset(&zs, 0, sizeof zs);
@@ -548,11 +558,11 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
                     if (!blocks[k].isize) continue;
                     if (inflateReset(&zs) != Z_OK) { errs[(size_t)w] = "inflateReset failed"; break; }
                     zs.next_in = const_cast<Bytef*>(blocks[k].comp); zs.avail_in = blocks[k].clen;
-                    zs.next_out = d->hbuf + out_at[k]; zs.avail_out = blocks[k].isize;
+                    zs.next_out = d->hbuf + (out_at[k] - h_base); zs.avail_out = blocks[k].isize;
                     if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) { errs[(size_t)w] = "BGZF inflate failed (host share of the device reader)"; break; }
                 }
                 if (!errs[(size_t)w].empty()) break;
-                if (out_at[b] > out_at[a] && hipMemcpyAsync(sp + DD_HEAD + out_at[a], d->hbuf + out_at[a], (size_t)(out_at[b] - out_at[a]), hipMemcpyHostToDevice, d->copy_stream) != hipSuccess) {
+                if (out_at[b] > out_at[a] && hipMemcpyAsync(sp + DD_HEAD + out_at[a], d->hbuf + (out_at[a] - h_base), (size_t)(out_at[b] - out_at[a]), hipMemcpyHostToDevice, d->copy_stream) != hipSuccess) {
                     errs[(size_t)w] = "upload of host-inflated blocks failed"; break;
                 }
                 cpu_done[(size_t)w] += (int64_t)(b - a);
@@ -565,7 +575,9 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
             int sl = 0;
             std::vector<uint64_t> in_off, o_at; std::vector<uint32_t> clen, isz;
             size_t a, b;
-            while (rc_gpu == SVX_OK && take(true, SUB, a, b)) {
+            size_t ramp = sub_env ? SUB : 4096;                            // the first sub-batches are small: the GPU starts after 4 k blocks are staged, not 32 k
+            while (rc_gpu == SVX_OK && take(true, ramp, a, b)) {
+                if (ramp < SUB) ramp *= 2;
                 const size_t mm = b - a;
                 if (used[sl]) { float ms = 0; rc_gpu = svx_inflater_wait(d->inf, sl, &ms); d->stats.inflate_kernel_ms += ms; used[sl] = false; if (rc_gpu != SVX_OK) break; }
                 const uint8_t* f0 = blocks[a].comp;

@@ -208,9 +208,13 @@ struct svx_bam {
     size_t header_bytes = 0;                  // length of the BAM header in the inflated stream
     size_t dev_fpos = 0; uint64_t dev_skip = 0; bool dev_file_done = false, dev_region_done = false;
     int dev_cur = -1; int64_t dev_first = 0, dev_valid = 0; bool dev_have_carry = false;
-    size_t dev_chunk_bytes = (size_t)2048 << 20, dev_chunk_blocks = (size_t)1 << 30;      // test hooks: SVX_BAM_DEV_CHUNK_MB, SVX_BAM_DEV_CHUNK_BLOCKS
+    size_t dev_chunk_bytes = (size_t)8192 << 20, dev_chunk_blocks = (size_t)1 << 30;      // test hooks: SVX_BAM_DEV_CHUNK_MB, SVX_BAM_DEV_CHUNK_BLOCKS
     std::string dev_names_blob;
+    struct DevLoad { int slot = 0, rc = SVX_OK; std::string err; int64_t n_rec = 0, n_valid = 0; bool file_done = false, empty = false; };
+    std::future<DevLoad> dev_future; bool dev_prefetching = false;
 };
+
+static void dev_drop_prefetch(svx_bam* h);
 
 // ---- BGZF ------------------------------------------------------------------------------------------------------------------
 struct RawBlock { const uint8_t* comp; size_t clen; uint32_t isize; size_t out_at; };
@@ -563,6 +567,7 @@ extern "C" void svx_bam_close(svx_bam* h) {
         drop_gpu(h);                                     // before the buffers it page-locked are freed
     }
     if (h->dev) {
+        dev_drop_prefetch(h);
         if (getenv("SVX_BAM_TIMING")) {
             DevDecStats ds; devdec_stats(h->dev, &ds);
             fprintf(stderr, "bamio device decode: %lld blocks (%lld GPU, %lld host), %.1f MB inflated, %lld records; staging + enqueue %.3f s, waiting for the inflate %.3f (kernels %.1f ms), "
@@ -599,6 +604,7 @@ extern "C" int svx_bam_seek(svx_bam* h, uint64_t voff, int32_t last_tid) {
     h->fpos = coff; h->file_eof = false; h->buf.clear(); h->pos = 0; h->next_len = 0; h->next_eof = false;
     h->tid_limit = last_tid; h->region_done = false;
     if (h->dev) {                                          // device decode: the next chunk starts at that block, `uoff` bytes into its data
+        dev_drop_prefetch(h);
         h->dev_fpos = coff; h->dev_skip = uoff; h->dev_file_done = false; h->dev_region_done = false; h->dev_cur = -1; h->dev_first = h->dev_valid = 0; h->dev_have_carry = false;
         return SVX_OK;
     }
@@ -620,6 +626,7 @@ extern "C" int svx_bam_rewind(svx_bam* h) {
         h->t_wait = h->t_copy = h->t_walk = h->t_decode = h->t_intern = 0;
     }
     if (h->dev) {                                          // device decode: nothing to inflate here - the first chunk is loaded by the first read
+        dev_drop_prefetch(h);
         h->dev_fpos = 0; h->dev_skip = h->header_bytes; h->dev_file_done = false; h->dev_region_done = false; h->dev_cur = -1; h->dev_first = h->dev_valid = 0; h->dev_have_carry = false;
         h->total_records = 0; h->tid_limit = -2; h->region_done = false;
         return SVX_OK;
@@ -912,7 +919,40 @@ static void clear_batch(svx_bam* h) {
 // Read up to max_records records (query-name mode: never splits a read's group) and lay them out as an svx_batch whose
 // arrays stay valid until the next call.  *n_out = 0 at end of file.  mode 0 = coordinate-sorted rules
 // (src/svim/SVIM_COLLECT.py:132-167), 1 = query-name-sorted rules (:96-129).
-// device decode: the next chunk of BGZF blocks -> bamdev.hip (inflate + record discovery + decode in HBM); batches are views of the chunk's arrays
+// one chunk of the device reader: whole BGZF blocks up to dev_chunk_bytes of inflated data -> slot `slot` (runs on a background thread while the
+// batches of the chunk before it are handed out; only this function advances dev_fpos)
+static svx_bam::DevLoad dev_load_chunk(svx_bam* h, int slot, int carry_slot, uint64_t skip, int min_mapq) {
+    svx_bam::DevLoad r;
+    r.slot = slot;
+    std::vector<DevDecBlock> blocks;
+    size_t total = 0;
+    try {
+        size_t fp = h->dev_fpos;
+        std::swap(fp, h->fpos);                                   // (read_block walks h->fpos; the host reader is idle in device mode)
+        while (total < h->dev_chunk_bytes && blocks.size() < h->dev_chunk_blocks) {
+            RawBlock b;
+            if (!read_block(h, b)) { r.file_done = true; break; }
+            blocks.push_back(DevDecBlock{b.comp, (uint32_t)b.clen, b.isize});
+            total += b.isize;
+        }
+        std::swap(fp, h->fpos);
+        h->dev_fpos = fp;
+    } catch (const std::string& e) { r.rc = SVX_E_ARG; r.err = e; return r; }
+    if (blocks.empty() && carry_slot < 0) { r.file_done = true; r.empty = true; return r; }
+    r.rc = devdec_load(h->dev, slot, blocks.data(), blocks.size(), carry_slot, skip, r.file_done, min_mapq);
+    if (r.rc == SVX_OK) r.rc = devdec_count(h->dev, slot, h->tid_limit, &r.n_rec, &r.n_valid);
+    if (r.rc != SVX_OK) r.err = svx_last_error();
+    return r;
+}
+static void dev_start_prefetch(svx_bam* h, int slot, int carry_slot, uint64_t skip, int min_mapq) {
+    h->dev_future = std::async(std::launch::async, dev_load_chunk, h, slot, carry_slot, skip, min_mapq);
+    h->dev_prefetching = true;
+}
+static void dev_drop_prefetch(svx_bam* h) {
+    if (h->dev_prefetching) { (void)h->dev_future.get(); h->dev_prefetching = false; }
+}
+
+// device decode: batches are views of the current chunk's arrays; the next chunk is inflated and decoded meanwhile
 static int read_batch_device(svx_bam* h, int64_t max_records, int min_mapq, svx_batch* out, int64_t* n_out) {
     *n_out = 0;
     memset(out, 0, sizeof *out);
@@ -924,40 +964,24 @@ static int read_batch_device(svx_bam* h, int64_t max_records, int min_mapq, svx_
             h->dev_first += count; h->total_records += count; *n_out = count;
             return SVX_OK;
         }
-        if (h->dev_region_done || (h->dev_file_done && h->dev_cur >= 0)) return SVX_OK;          // end of the region / of the file
-        // the next chunk: whole BGZF blocks up to dev_chunk_bytes of inflated data
-        std::vector<DevDecBlock> blocks;
-        size_t total = 0;
-        try {
-            const size_t save = h->fpos;
-            h->fpos = h->dev_fpos;
-            while (total < h->dev_chunk_bytes && blocks.size() < h->dev_chunk_blocks) {
-                RawBlock b;
-                if (!read_block(h, b)) { h->dev_file_done = true; break; }
-                blocks.push_back(DevDecBlock{b.comp, (uint32_t)b.clen, b.isize});
-                total += b.isize;
-            }
-            h->dev_fpos = h->fpos;
-            h->fpos = save;
-        } catch (const std::string& e) { return bam_fail(SVX_E_ARG, e); }
-        if (blocks.empty() && !h->dev_have_carry) { h->dev_file_done = true; if (h->dev_cur < 0) h->dev_cur = 0; h->dev_first = h->dev_valid = 0; return SVX_OK; }
-        const int slot = h->dev_cur < 0 ? 0 : (h->dev_cur + 1) % 3;
-        int rc = devdec_load(h->dev, slot, blocks.data(), blocks.size(), h->dev_have_carry ? h->dev_cur : -1, h->dev_skip, h->dev_file_done, min_mapq);
-        if (rc != SVX_OK) return rc;
+        if (h->dev_region_done || h->dev_file_done) return SVX_OK;          // end of the region / of the file
+        if (!h->dev_prefetching) dev_start_prefetch(h, h->dev_cur < 0 ? 0 : (h->dev_cur + 1) % 3, h->dev_have_carry ? h->dev_cur : -1, h->dev_skip, min_mapq);
+        svx_bam::DevLoad r = h->dev_future.get();
+        h->dev_prefetching = false;
         h->dev_skip = 0;
-        int64_t n_rec = 0, n_valid = 0;
-        rc = devdec_count(h->dev, slot, h->tid_limit, &n_rec, &n_valid);
-        if (rc != SVX_OK) return rc;
-        h->dev_cur = slot; h->dev_first = 0; h->dev_valid = n_valid; h->dev_have_carry = true;
-        if (n_valid < n_rec) h->dev_region_done = true;                 // contig-range reading: the range ends where the next contig (or the unplaced tail) begins
+        if (r.rc != SVX_OK) return bam_fail(r.rc, r.err);
+        if (r.empty) { h->dev_file_done = true; return SVX_OK; }
+        h->dev_cur = r.slot; h->dev_first = 0; h->dev_valid = r.n_valid; h->dev_have_carry = true;
+        h->dev_file_done = r.file_done;                                     // (the records of this last chunk are still to be handed out: checked after them)
+        if (r.n_valid < r.n_rec) h->dev_region_done = true;                 // contig-range reading: the range ends where the next contig (or the unplaced tail) begins
         // (a chunk without one complete record is carried over whole into the next load; devdec_load refuses when a record outgrows its carry-over room)
-        if (n_valid == 0 && (h->dev_file_done || h->dev_region_done)) return SVX_OK;
+        if (!h->dev_file_done && !h->dev_region_done) dev_start_prefetch(h, (h->dev_cur + 1) % 3, h->dev_cur, 0, min_mapq);
     }
 }
 
 extern "C" int svx_bam_set_device_decode(svx_bam* h, int device) {
     if (!h) return bam_fail(SVX_E_ARG, "null handle");
-    if (h->dev) { devdec_destroy(h->dev); h->dev = nullptr; }
+    if (h->dev) { dev_drop_prefetch(h); devdec_destroy(h->dev); h->dev = nullptr; }
     if (device < 0) return SVX_OK;
     const int rc = devdec_create(device, granted_cpus(), (int32_t)h->ref_names.size(), h->ref_len.data(), h->names_blob.c_str(), h->contig_rank.data(), &h->dev);
     if (rc != SVX_OK) { h->dev = nullptr; return rc; }
@@ -1090,6 +1114,7 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
 // read names interned so far: NUL-separated blob in id order
 extern "C" int svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** blob, int64_t* blob_len) {
     if (h->dev) {
+        if (h->dev_prefetching) h->dev_future.wait();          // (the loader appends the names of the chunk it decodes)
         const std::vector<std::string>& nm = devdec_names(h->dev);
         h->dev_names_blob.clear();
         for (const auto& x : nm) { h->dev_names_blob += x; h->dev_names_blob.push_back('\0'); }

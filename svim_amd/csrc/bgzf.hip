@@ -137,18 +137,24 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
             return svx_fail(SVX_E_ARG, "payload offset / size out of range", __FILE__, __LINE__, hipSuccess);
         jobs[(size_t)i] = BgzfJob{in_off[i], out_at[i], clen[i], isize[i]};
     }
-    SVXCHK(sl.comp.reserve((size_t)staged_bytes + 64));
+    // the compressed payloads: read by the kernel straight from the pinned staging buffer over PCIe (each byte is read once, 256 B at a time per wave and far
+    // ahead of its use - and the copy engine's H2D would not overlap the kernel of the sub-batch before: it starts when that kernel ends), or copied to HBM first
+    // (SVX_INFLATE_ZEROCOPY=0)
+    static const bool zero_copy = []() { const char* e = getenv("SVX_INFLATE_ZEROCOPY"); return !(e && e[0] == '0'); }();
+    const uint8_t* comp_dev = nullptr;
+    if (zero_copy) { void* dp = nullptr; if (hipHostGetDevicePointer(&dp, sl.staging, 0) == hipSuccess) comp_dev = (const uint8_t*)dp; else (void)hipGetLastError(); }
+    if (!comp_dev) SVXCHK(sl.comp.reserve((size_t)staged_bytes + 64));
     SVXCHK(sl.jobs.reserve((size_t)n * sizeof(BgzfJob)));
     SVXCHK(sl.status.reserve(16));
     uint8_t* out_dev = out;
     if (!out_on_device) { SVXCHK(sl.out.reserve((size_t)out_bytes + 64)); out_dev = sl.out.as<uint8_t>(); }
     hipStream_t st = sl.stream;
-    HIPCHK(hipMemcpyAsync(sl.comp.p, sl.staging, (size_t)staged_bytes, hipMemcpyHostToDevice, st));
+    if (!comp_dev) { HIPCHK(hipMemcpyAsync(sl.comp.p, sl.staging, (size_t)staged_bytes, hipMemcpyHostToDevice, st)); comp_dev = sl.comp.as<uint8_t>(); }
     HIPCHK(hipMemcpyAsync(sl.jobs.p, jobs.data(), (size_t)n * sizeof(BgzfJob), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(sl.status.p, 0, 16, st));
     HIPCHK(hipEventRecord(sl.ev[0], st));
     static const unsigned lds_pad = []() { const char* e = getenv("SVX_INFLATE_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();      // experiment: fewer resident waves per CU
-    k_bgzf_inflate<<<(unsigned)n, 64, lds_pad, st>>>(sl.comp.as<uint8_t>(), sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.status.as<int>());
+    k_bgzf_inflate<<<(unsigned)n, 64, lds_pad, st>>>(comp_dev, sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.status.as<int>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.ev[1], st));
     HIPCHK(hipMemcpyAsync(sl.host_status, sl.status.p, 16, hipMemcpyDeviceToHost, st));

@@ -43,7 +43,10 @@ def passes(nb, k=3):
 
 
 variants = [("GPU + host cores (default)", {}), ("GPU only, sub-batches of 12288", {"SVX_BAM_DEV_CPU": "0"}), ("GPU only, sub-batches of 4096", {"SVX_BAM_DEV_CPU": "0", "SVX_BAM_DEV_SUB": "4096"}),
-            ("GPU only, sub-batches of 40000", {"SVX_BAM_DEV_CPU": "0", "SVX_BAM_DEV_SUB": "40000"}), ("GPU + 8 host threads", {"SVX_BAM_DEV_CPU": "8"})]
+            ("GPU only, sub-batches of 40000", {"SVX_BAM_DEV_CPU": "0", "SVX_BAM_DEV_SUB": "40000"}), ("GPU + 8 host threads", {"SVX_BAM_DEV_CPU": "8"}),
+            ("GPU + 6 host threads, sub-batches of 24576", {"SVX_BAM_DEV_CPU": "6", "SVX_BAM_DEV_SUB": "24576"})]
+if os.environ.get("SVX_READER_ONE"):                  # (profiling runs: the GPU-only reader with mid-size sub-batches, nothing else)
+    variants = [("GPU only, sub-batches of 12288", {"SVX_BAM_DEV_CPU": "0", "SVX_BAM_DEV_SUB": "12288"})]
 for mb in chunks:
     for label, env in variants if mb == chunks[0] else variants[:1]:
         os.environ["SVX_BAM_DEV_CHUNK_MB"] = str(mb)
@@ -58,6 +61,8 @@ for mb in chunks:
         nb.close()                                        # (prints the stage times of all passes to stderr)
 for k in ("SVX_BAM_DEV_CPU", "SVX_BAM_DEV_SUB"):
     os.environ.pop(k, None)
+if os.environ.get("SVX_READER_ONE"):
+    sys.exit(0)
 nb = NativeBam(path)
 nb.set_seq_filter(40)
 nb.set_gpu_inflate(0)
