@@ -217,7 +217,7 @@ struct svx_bam {
 static void dev_drop_prefetch(svx_bam* h);
 
 // ---- BGZF ------------------------------------------------------------------------------------------------------------------
-struct RawBlock { const uint8_t* comp; size_t clen; uint32_t isize; size_t out_at; };
+struct RawBlock { const uint8_t* comp; size_t clen; uint32_t isize; size_t out_at; uint32_t crc; };
 
 static bool read_block(svx_bam* h, RawBlock& b) {
     if (h->fpos >= h->map_len) return false;
@@ -240,6 +240,7 @@ static bool read_block(svx_bam* h, RawBlock& b) {
     b.comp = hd + 12 + xlen; b.clen = clen;
     const uint8_t* tail = b.comp + clen;
     b.isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+    b.crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
     h->fpos += (size_t)bsize + 1;
     return true;
 }
@@ -261,6 +262,10 @@ static void inflate_block(const RawBlock& b, uint8_t* out) {
     t.zs.next_out = out; t.zs.avail_out = b.isize;
     const int rc = inflate(&t.zs, Z_FINISH);
     if (rc != Z_STREAM_END || t.zs.avail_out != 0) throw std::string("BGZF inflate failed");
+    // SVX_BAM_VERIFY_CRC=1: the CRC32 of the block trailer, as htslib checks it (off by default: it costs about as much as a third of the inflate;
+    // blocks the GPU inflates are checked for their length and for a sound DEFLATE stream only)
+    static const bool verify = []() { const char* e = getenv("SVX_BAM_VERIFY_CRC"); return e && e[0] == '1'; }();
+    if (verify && (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, b.isize) != b.crc) throw std::string("BGZF block fails its CRC32");
 }
 
 // Inflate the next chunk of BGZF blocks (<= 1024 blocks / 48 MB) into h->next: n_threads workers, runs on a background thread while the

@@ -553,3 +553,35 @@ def test_reader_keeps_the_last_batch_of_a_region_alive_across_a_seek(tmp_path):
         pipe.run()
     pipe.bam.close()
     assert threading.active_count() <= before
+
+
+def test_reader_verifies_block_crc_on_request(tmp_path, monkeypatch):
+    """with SVX_BAM_VERIFY_CRC=1 the host reader checks the CRC32 of every BGZF block it inflates (htslib does): a block whose trailer
+    CRC was altered is refused; without the switch the (still sound) DEFLATE stream is accepted."""
+    import subprocess
+    import sys
+    from svim_amd._lib import SvxError
+    refs, lens = ["chr1"], [200000]
+    ref = synth.make_reference(5, list(zip(refs, lens)))
+    recs = synth.coordinate_sort(synth.planted_reads(6, 300, ref, refs, lens, n_sites=10, types=("DEL", "INS")))
+    good = str(tmp_path / "good.bam")
+    records.write_bam(good, refs, lens, recs)
+    raw = bytearray(open(good, "rb").read())
+    # second block: flip one bit of its CRC32 (the 8 bytes before the next block header are CRC32 + ISIZE)
+    bsize0 = raw[16] | (raw[17] << 8)
+    at = bsize0 + 1
+    bsize1 = raw[at + 16] | (raw[at + 17] << 8)
+    raw[at + bsize1 + 1 - 8] ^= 1
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(raw))
+    code = ("import sys; sys.path.insert(0, %r)\nfrom svim_amd.bamio import NativeBam\nnb = NativeBam(sys.argv[1], threads=2)\nn = 0\n"
+            "while True:\n    b, k = nb.read_batch(1000, 20, 'coordinate')\n    if k == 0: break\n    n += k\nprint('READ', n)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ)
+    env.pop("SVX_BAM_VERIFY_CRC", None)
+    out = subprocess.run([sys.executable, "-c", code, bad], capture_output=True, text=True, env=env, timeout=300)
+    assert "READ %d" % len(recs) in out.stdout, out.stderr[-500:]
+    env["SVX_BAM_VERIFY_CRC"] = "1"
+    out = subprocess.run([sys.executable, "-c", code, good], capture_output=True, text=True, env=env, timeout=300)
+    assert "READ %d" % len(recs) in out.stdout, out.stderr[-500:]
+    out = subprocess.run([sys.executable, "-c", code, bad], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0 and "CRC32" in out.stderr, (out.stdout, out.stderr[-500:])
