@@ -991,6 +991,7 @@ extern "C" int svx_bam_set_device_decode(svx_bam* h, int device) {
     const int rc = devdec_create(device, granted_cpus(), (int32_t)h->ref_names.size(), h->ref_len.data(), h->names_blob.c_str(), h->contig_rank.data(), &h->dev);
     if (rc != SVX_OK) { h->dev = nullptr; return rc; }
     h->dev_device = device;
+    if (h->map && h->map_len) devdec_set_file(h->dev, h->map, h->map_len);
     { const char* e = getenv("SVX_BAM_DEV_CHUNK_MB"); if (e && atoll(e) > 0) h->dev_chunk_bytes = (size_t)atoll(e) << 20; }
     { const char* e = getenv("SVX_BAM_DEV_CHUNK_BLOCKS"); if (e && atoll(e) > 0) h->dev_chunk_blocks = (size_t)atoll(e); }
     if (h->prefetch_active) { h->prefetch.wait(); h->prefetch_active = false; }

@@ -163,6 +163,50 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
     return SVX_OK;
 }
 
+// the same with the payloads already in device-visible memory (`comp_dev` + in_off[i]: HBM, or host memory registered with the GPU - the memory-mapped BAM
+// file itself, svx_inflater_map_file): nothing is staged or copied, the launch follows at once.  Output to device memory only.
+extern "C" int svx_inflater_enqueue_mapped(svx_inflater* f, int slot, int64_t n, const uint8_t* comp_dev, uint64_t comp_bytes, const uint64_t* in_off, const uint32_t* clen,
+                                           const uint32_t* isize, const uint64_t* out_at, uint8_t* out_dev, uint64_t out_bytes) {
+    if (!f || slot < 0 || slot >= INF_SLOTS || n < 0 || (n && (!comp_dev || !in_off || !clen || !isize || !out_at || !out_dev))) return svx_fail(SVX_E_ARG, "bad argument", __FILE__, __LINE__, hipSuccess);
+    InflaterSlot& sl = f->slot[slot];
+    if (sl.busy) return svx_fail(SVX_E_STATE, "slot still busy: svx_inflater_wait first", __FILE__, __LINE__, hipSuccess);
+    if (n == 0) return SVX_OK;
+    HIPCHK(hipSetDevice(f->device));
+    std::vector<BgzfJob>& jobs = sl.host_jobs;
+    jobs.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        if (in_off[i] + clen[i] > comp_bytes || out_at[i] + isize[i] > out_bytes) return svx_fail(SVX_E_ARG, "payload offset / size out of range", __FILE__, __LINE__, hipSuccess);
+        jobs[(size_t)i] = BgzfJob{in_off[i], out_at[i], clen[i], isize[i]};
+    }
+    SVXCHK(sl.jobs.reserve((size_t)n * sizeof(BgzfJob)));
+    SVXCHK(sl.status.reserve(16));
+    hipStream_t st = sl.stream;
+    HIPCHK(hipMemcpyAsync(sl.jobs.p, jobs.data(), (size_t)n * sizeof(BgzfJob), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(sl.status.p, 0, 16, st));
+    HIPCHK(hipEventRecord(sl.ev[0], st));
+    k_bgzf_inflate<<<(unsigned)n, 64, 0, st>>>(comp_dev, sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.status.as<int>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(sl.ev[1], st));
+    HIPCHK(hipMemcpyAsync(sl.host_status, sl.status.p, 16, hipMemcpyDeviceToHost, st));
+    sl.busy = true;
+    return SVX_OK;
+}
+// register a read-only host mapping (the memory-mapped BAM file) with the GPU: *dev_ptr is its address for kernels.  Returns SVX_E_HIP when the runtime refuses
+// (the caller stages through pinned buffers instead)
+extern "C" int svx_inflater_map_file(svx_inflater* f, const void* base, uint64_t bytes, const uint8_t** dev_ptr) {
+    if (!f || !base || !bytes || !dev_ptr) return svx_fail(SVX_E_ARG, "bad argument", __FILE__, __LINE__, hipSuccess);
+    (void)hipSetDevice(f->device);
+    void* p = const_cast<void*>(base);
+    hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterReadOnly);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostRegister(p, (size_t)bytes, hipHostRegisterMapped); }
+    if (e != hipSuccess) { (void)hipGetLastError(); return svx_fail(SVX_E_HIP, "the runtime does not register the file mapping", __FILE__, __LINE__, e); }
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || !dp) { (void)hipGetLastError(); (void)hipHostUnregister(p); return svx_fail(SVX_E_HIP, "no device address for the file mapping", __FILE__, __LINE__, hipSuccess); }
+    { std::lock_guard<std::mutex> guard(f->pin_mutex); f->pinned.emplace_back(p, (size_t)bytes); }
+    *dev_ptr = (const uint8_t*)dp;
+    return SVX_OK;
+}
+
 extern "C" int svx_inflater_wait(svx_inflater* f, int slot, float* kernel_ms) {
     if (!f || slot < 0 || slot >= INF_SLOTS) return svx_fail(SVX_E_ARG, "bad argument", __FILE__, __LINE__, hipSuccess);
     InflaterSlot& sl = f->slot[slot];

@@ -521,14 +521,33 @@ INF_FN int inflate_raw(const uint8_t* payload, uint32_t in_bytes, uint8_t* out, 
             if (s.pos + len > s.out_cap) return INF_E_OUTPUT;
             const uint32_t at = s.bp >> 3;
             if (at + len > in_bytes) return INF_E_INPUT;
-            const uint8_t* src = reinterpret_cast<const uint8_t*>(s.in) + at;
-            for (uint32_t done = 0; done < len; done += 64u) {
-                const uint32_t n = len - done < 64u ? len - done : 64u;
-                W_VEC(uint32_t, v);
-                W_FOR { if ((uint32_t)W_LANE < n) V(v) = src[done + (uint32_t)W_LANE]; }
-                W_FOR { if ((uint32_t)W_LANE < n) sc.ring[inf_ridx(s, s.pos + (uint32_t)W_LANE)] = (uint8_t)V(v); }
+            // 1 KiB per trip: every lane assembles 4 x 4 bytes from aligned input words, all loads issued before the first is used (the input may be host
+            // memory behind PCIe: one round trip per trip)
+            const uint32_t sh8 = (at & 3u) * 8u;
+            const uint32_t* wsrc = s.in + (at >> 2);
+            for (uint32_t done = 0; done < len; done += 1024u) {
+                const uint32_t n = len - done < 1024u ? len - done : 1024u;
+                W_VEC2(uint32_t, v, 4);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    W_FOR {
+                        const uint32_t i4 = 256u * (uint32_t)r + 4u * (uint32_t)W_LANE;            // first of this lane's 4 bytes in the trip
+                        if (i4 < n) {
+                            const uint32_t wi = (done + i4) >> 2;
+                            const uint32_t lo = wsrc[wi], hi = sh8 ? wsrc[wi + 1u] : 0u;                 // (in_words covers at + len: the word behind the last byte may be padding)
+                            V2(v, r) = sh8 ? (lo >> sh8) | (hi << (32u - sh8)) : lo;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    W_FOR {
+                        const uint32_t i4 = 256u * (uint32_t)r + 4u * (uint32_t)W_LANE;
+                        for (uint32_t k = 0; k < 4u; k++) if (i4 + k < n) sc.ring[inf_ridx(s, s.pos + i4 + k)] = (uint8_t)(V2(v, r) >> (8u * k));
+                    }
+                }
                 s.pos += n;
-                inf_maybe_flush(s);
+                inf_flush(s, s.pos - ((s.pos + s.mis) & 15u));
             }
             s.bp += 8u * len;
         } else if (type == 1 || type == 2) {
