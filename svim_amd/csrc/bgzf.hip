@@ -20,6 +20,16 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* comp, const 
     if (lane_id() == 0 && rc != (int)job.out_bytes) { status[0] = 1; status[1] = (int)j; status[2] = rc; }
 }
 
+#ifdef INF_PROFILE
+// cycle accounting of the decode loop, summed over every block inflated since the last reset (experiment builds only; tools/inflate_profile.py)
+extern "C" int svx_inflate_profile(unsigned long long* out16, int reset) {
+    HIPCHK(hipDeviceSynchronize());
+    if (out16) HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_inf_prof), 16 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_inf_prof), z, sizeof(z))); }
+    return SVX_OK;
+}
+#endif
+
 #define INF_SLOTS 3
 struct InflaterSlot {
     hipStream_t stream = nullptr;

@@ -53,7 +53,14 @@ struct InfScratch {
     uint16_t dsym[INF_MAXD];
     uint16_t csym[20];
     uint16_t cnt_l[16], cnt_d[16], cnt_c[16];   // codes per length (canonical walk of the long codes)
-    uint8_t len[INF_MAXL + INF_MAXD + 16];   // code lengths while a header is read
+    union {
+        uint8_t len[INF_MAXL + INF_MAXD + 16];  // code lengths while a header is read
+        struct {                                // ... and, once the tables are built, what the token decode of the block needs:
+            uint32_t dist_lut[32];              // distance symbol -> base | extra bits << 16 (0: not a symbol)
+            uint16_t len_lut[32];               // length symbol - 257 -> base | extra bits << 9 (0: not a symbol)
+            uint8_t tokmap[64];                 // output byte of a step -> lane of the token that produces it
+        };
+    };
 };
 
 // ---- lane abstraction: the device executes a "vector" statement in every lane; the host runs the 64 lanes in a loop ------------------------------
@@ -97,9 +104,23 @@ static __device__ __forceinline__ uint32_t inf_bitrev(uint32_t x) { return __bui
         INF_DPP_ADD(i_, i_, 0x142, 0xa, 0xf); INF_DPP_ADD(i_, i_, 0x143, 0xc, 0xf);                                         \
         dst = (uint32_t)(i_ - v_); total = (uint32_t)__builtin_amdgcn_readlane(i_, 63); } while (0)
 #endif
+// dst[lane] = src[idx[lane]] (idx < 64), and an inclusive running maximum over the lanes (values >= 0)
+#ifdef INF_HOST
+#define W_BPERMUTE(dst, src, idx) do { uint32_t t_[64]; for (int l_ = 0; l_ < 64; l_++) t_[l_] = src[(idx[l_]) & 63u]; for (int l_ = 0; l_ < 64; l_++) dst[l_] = t_[l_]; } while (0)
+#define W_INCL_MAX_SCAN(v) do { uint32_t run_ = 0; for (int l_ = 0; l_ < 64; l_++) { if (v[l_] > run_) run_ = v[l_]; v[l_] = run_; } } while (0)
+#else
+#define W_BPERMUTE(dst, src, idx) dst = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx) << 2), (int)(src))
+#define INF_DPP_MAX(d_, s_, ctrl_, row_, bank_) { const int t_ = __builtin_amdgcn_update_dpp(0, s_, ctrl_, row_, bank_, true); d_ = t_ > d_ ? t_ : d_; }
+#define W_INCL_MAX_SCAN(v) do { int i_ = (int)(v), v_ = i_;                                                            \
+        INF_DPP_MAX(i_, v_, 0x111, 0xf, 0xf) INF_DPP_MAX(i_, v_, 0x112, 0xf, 0xf) INF_DPP_MAX(i_, v_, 0x113, 0xf, 0xf)   \
+        { const int u_ = i_; INF_DPP_MAX(i_, u_, 0x114, 0xf, 0xe) } { const int u_ = i_; INF_DPP_MAX(i_, u_, 0x118, 0xf, 0xc) }  \
+        { const int u_ = i_; INF_DPP_MAX(i_, u_, 0x142, 0xa, 0xf) } { const int u_ = i_; INF_DPP_MAX(i_, u_, 0x143, 0xc, 0xf) }  \
+        v = (uint32_t)i_; } while (0)
+#endif
 /* a token (literal, or length + distance) that would start at a bit offset: bits it takes | output bytes << 8 | flags */
 #define INF_T_MATCH (1u << 20)
 #define INF_T_STOP  (1u << 21)
+#define INF_T_FAR   (1u << 22)   /* a match whose source is no longer (safely) in the ring: read back from the flushed output */
 #ifndef INF_STEP_CAP
 #define INF_STEP_CAP 1024u
 #endif
@@ -113,7 +134,24 @@ struct InfState {
     // output
     uint8_t* out; uint32_t out_cap, pos, flushed, clean, mis;      // mis: (address of out) & 15 - ring index of output byte p is (p + mis) & INF_RMASK
     InfScratch* sc;
+#ifdef INF_PROFILE
+    uint32_t prof[16]; uint64_t t_last;
+#endif
 };
+
+// optional cycle accounting of the decode loop (build with -DINF_PROFILE; tools/inflate_profile.py reads the totals): INF_PROF charges the cycles since the
+// previous mark to a slot, INF_COUNT adds to a counter
+#if defined(INF_PROFILE) && !defined(INF_HOST)
+__device__ unsigned long long g_inf_prof[16];
+#define INF_PROF(s, slot) { const uint64_t now_ = __builtin_readcyclecounter(); (s).prof[slot] += (uint32_t)(now_ - (s).t_last); (s).t_last = now_; }
+#define INF_COUNT(s, slot, n) { (s).prof[slot] += (uint32_t)(n); }
+#else
+#define INF_PROF(s, slot)
+#define INF_COUNT(s, slot, n)
+#endif
+#ifndef INF_STAT
+#define INF_STAT(path, len, dist)       // host-side token statistics (tools/inflate_host_test.cpp --stats)
+#endif
 
 // ---- input ----------------------------------------------------------------------------------------------------------------------------------------
 INF_FN void inf_load_chunks(InfState& s, uint32_t cbase) {
@@ -210,21 +248,23 @@ INF_FN void inf_copy_near(InfState& s, uint32_t op, uint32_t dist, uint32_t len)
 }
 
 // out[pos, pos + len) = out[pos - dist ...]: inside the ring, or - a source that left the ring - from global memory
+// ring[op, op + len) from the flushed output: dist + len > INF_RING - INF_STEP_CAP, so the source ends in front of everything still pending (at most
+// INF_FLUSH_AT + INF_STEP_CAP bytes); the stores of earlier flushes are waited for only if they may still be in flight
+INF_FN void inf_copy_far(InfState& s, uint32_t op, uint32_t dist, uint32_t len) {
+    uint8_t* ring = s.sc->ring;
+    W_VEC(uint32_t, v);
+    if (op - dist + len > s.clean) { W_FENCE(); s.clean = s.flushed; }
+    for (uint32_t done = 0; done < len; done += 64u) {
+        const uint32_t n = len - done < 64u ? len - done : 64u;
+        W_FOR { if ((uint32_t)W_LANE < n) V(v) = s.out[op + done + (uint32_t)W_LANE - dist]; }
+        W_FOR { if ((uint32_t)W_LANE < n) ring[inf_ridx(s, op + done + (uint32_t)W_LANE)] = (uint8_t)V(v); }
+    }
+}
 INF_FN int inf_match(InfState& s, uint32_t dist, uint32_t len) {
     if (dist > s.pos) return INF_E_DIST;
     if (s.pos + len > s.out_cap) return INF_E_OUTPUT;
-    if (dist + len <= INF_RING) inf_copy_near(s, s.pos, dist, len);
-    else {
-        // the source was flushed long ago (pending output is far shorter than the ring); wait for those stores only if they may still be in flight
-        uint8_t* ring = s.sc->ring;
-        W_VEC(uint32_t, v);
-        if (s.pos - dist + len > s.clean) { W_FENCE(); s.clean = s.flushed; }
-        for (uint32_t done = 0; done < len; done += 64u) {
-            const uint32_t n = len - done < 64u ? len - done : 64u;
-            W_FOR { if ((uint32_t)W_LANE < n) V(v) = s.out[s.pos + done + (uint32_t)W_LANE - dist]; }
-            W_FOR { if ((uint32_t)W_LANE < n) ring[inf_ridx(s, s.pos + done + (uint32_t)W_LANE)] = (uint8_t)V(v); }
-        }
-    }
+    if (dist + len + INF_STEP_CAP <= INF_RING) inf_copy_near(s, s.pos, dist, len);
+    else inf_copy_far(s, s.pos, dist, len);
     s.pos += len;
     return 0;
 }
@@ -318,12 +358,75 @@ INF_FN uint32_t inf_len_base(uint32_t i, uint32_t xb) { return i < 8u ? 3u + i :
 INF_FN uint32_t inf_dist_extra(uint32_t ds) { return ds < 4u ? 0u : (ds - 2u) >> 1; }
 INF_FN uint32_t inf_dist_base(uint32_t ds, uint32_t xb) { return ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << xb); }
 
+// base values and extra-bit counts of the length / distance symbols (RFC 1951 3.2.5) as two LDS tables: they share their bytes with the code lengths of the
+// header, so they are written again after the tables of every block are built
+INF_FN void inf_token_luts(InfState& s) {
+    InfScratch& sc = *s.sc;
+    W_FOR {
+        if (W_LANE < 32) {
+            const uint32_t i = (uint32_t)W_LANE, lx = inf_len_extra(i), dx = inf_dist_extra(i);
+            sc.len_lut[i] = (uint16_t)(i <= 28u ? inf_len_base(i, lx) | (lx << 9) : 0u);
+            sc.dist_lut[i] = i < 30u ? inf_dist_base(i, dx) | (dx << 16) : 0u;
+        }
+    }
+}
+
+// emission of one step's tokens (mask MT over the lanes; T / DV / E per token lane; EX = output offset of each token inside the step, acc = bytes of the step)
+// one output byte per lane when the step produces at most 64 bytes: which token a byte belongs to comes from a scatter + running maximum, a match byte whose
+// source lies before the step is gathered from the ring, one whose source is a byte of this very step follows it by pointer doubling
+template <class VecT>
+INF_FN int inf_emit_bytes(InfState& s, uint64_t MT, const VecT& T, const VecT& DV, const VecT& E, const VecT& EX, uint32_t acc) {
+    InfScratch& sc = *s.sc;
+    W_VEC(uint32_t, tk); W_VEC(uint32_t, PK); W_VEC(uint32_t, pk); W_VEC(uint32_t, val); W_VEC(uint32_t, ref); W_VEC(uint32_t, un); W_VEC(uint32_t, idx);
+    W_FOR { if (W_LANE < 16) reinterpret_cast<uint32_t*>(sc.tokmap)[W_LANE] = 0u; }
+    W_FOR { if ((MT >> W_LANE) & 1ull) sc.tokmap[V(EX)] = (uint8_t)(W_LANE + 1); }
+    W_FOR { V(tk) = (uint32_t)W_LANE < acc ? (uint32_t)sc.tokmap[W_LANE] : 0u; }
+    W_INCL_MAX_SCAN(tk);
+    W_FOR {
+        V(PK) = (V(DV) & 0xffffu) | (V(EX) << 16) | ((V(T) & INF_T_MATCH) ? 1u << 22 : 0u) | ((V(T) & INF_T_FAR) ? 1u << 23 : 0u) | ((V(E) & 255u) << 24);
+        V(idx) = (V(tk) - 1u) & 63u;
+    }
+    W_BPERMUTE(pk, PK, idx);
+    uint64_t bad, wait;
+    W_BALLOT(bad, (uint32_t)W_LANE < acc && ((V(pk) >> 22) & 1u) && (V(pk) & 0xffffu) > s.pos + ((V(pk) >> 16) & 63u));
+    if (bad) return INF_E_DIST;                                   // a distance reaching in front of the output
+    // far sources come back from the flushed output (their distance puts them in front of everything pending): wait for those stores if they may be in flight
+    W_BALLOT(wait, (uint32_t)W_LANE < acc && ((V(pk) >> 23) & 1u) && s.pos + (uint32_t)W_LANE - (V(pk) & 0xffffu) >= s.clean);
+    if (wait) { W_FENCE(); s.clean = s.flushed; }
+    W_FOR {
+        const uint32_t dist = V(pk) & 0xffffu;
+        const bool m = (uint32_t)W_LANE < acc && ((V(pk) >> 22) & 1u);
+        V(val) = V(pk) >> 24;
+        V(un) = 0u; V(ref) = 0u;
+        if (m) {
+            if (dist > (uint32_t)W_LANE) {                                                                    // source in front of the step
+                if ((V(pk) >> 23) & 1u) V(val) = s.out[s.pos + (uint32_t)W_LANE - dist];
+                else V(val) = sc.ring[inf_ridx(s, s.pos + (uint32_t)W_LANE - dist)];
+            } else { V(un) = 1u; V(ref) = (uint32_t)W_LANE - dist; }                                          // source is a byte of this step
+        }
+    }
+    for (;;) {
+        uint64_t U;
+        W_BALLOT(U, V(un) != 0u);
+        if (!U) break;
+        W_VEC(uint32_t, vv); W_VEC(uint32_t, v2); W_VEC(uint32_t, r2);
+        W_FOR { V(vv) = V(val) | (V(un) << 8); }
+        W_BPERMUTE(v2, vv, ref);
+        W_BPERMUTE(r2, ref, ref);
+        W_FOR { if (V(un)) { if (!((V(v2) >> 8) & 1u)) { V(val) = V(v2) & 255u; V(un) = 0u; } else V(ref) = V(r2); } }
+    }
+    W_FOR { if ((uint32_t)W_LANE < acc) sc.ring[inf_ridx(s, s.pos + (uint32_t)W_LANE)] = (uint8_t)V(val); }
+    return 0;
+}
+
 INF_FN int inf_codes(InfState& s) {
     InfScratch& sc = *s.sc;
+    bool match_mode = false;                                       // the step before produced matches: decode whole tokens right away
     for (;;) {
         if (s.bp > 32u * s.in_words + 64u) return INF_E_INPUT;
         inf_sync_input(s);
         inf_maybe_flush(s);
+        INF_PROF(s, 8)
         // every lane: the 32 input bits from its offset on, and the literal/length entry of the code that would start there
         W_VEC(uint32_t, XL); W_VEC(uint32_t, E);
         {
@@ -338,27 +441,31 @@ INF_FN int inf_codes(InfState& s) {
                 V(E) = sc.fast_l[V(XL) & ((1u << INF_FAST_L) - 1u)];
             }
         }
-        // phase A: follow the code starts through the 64 entries while they are literals
-        uint64_t M = 0;
+        INF_PROF(s, 0) INF_COUNT(s, 9, 1)
         uint32_t o = 0, e;
+        if (!match_mode) {
+            // phase A: follow the code starts through the 64 entries while they are literals
+            uint64_t M = 0;
 #define INF_HOP_A                                                                                                           \
-        e = W_READLANE(E, o);                                                                                               \
-        if (!(e & INF_SIMPLE)) break;                                                                                       \
-        M |= 1ull << o;                                                                                                     \
-        o += e >> 10;                                                                                                       \
-        if (o >= 64u) { e = INF_SIMPLE; break; }                  /* window used up; the next step continues at bp + o */
-        for (;;) { INF_HOP_A INF_HOP_A INF_HOP_A INF_HOP_A }            // (four hops per taken branch)
+            e = W_READLANE(E, o);                                                                                           \
+            if (!(e & INF_SIMPLE)) break;                                                                                   \
+            M |= 1ull << o;                                                                                                 \
+            o += e >> 10;                                                                                                   \
+            if (o >= 64u) { e = INF_SIMPLE; break; }              /* window used up; the next step continues at bp + o */
+            for (;;) { INF_HOP_A INF_HOP_A INF_HOP_A INF_HOP_A }        // (four hops per taken branch)
 #undef INF_HOP_A
-        const uint32_t nlit = (uint32_t)__builtin_popcountll(M);
-        if (nlit) {
-            if (s.pos + nlit > s.out_cap) return INF_E_OUTPUT;
-            W_FOR { if ((M >> W_LANE) & 1ull) sc.ring[inf_ridx(s, s.pos + W_RANK(M))] = (uint8_t)V(E); }
-            s.pos += nlit;
-        }
-        if (e & INF_SIMPLE) { s.bp += o; continue; }
-        if (e != 0u && (e & 511u) >= 257u && (e & 511u) <= 285u) {
-            // phase B: a length code.  Every lane decodes the WHOLE token that would start at its offset (literal, or length + extra bits +
-            // distance code + extra bits: one more table gather), then the chain runs on over literals and matches alike
+            const uint32_t nlit = (uint32_t)__builtin_popcountll(M);
+            if (nlit) {
+                if (s.pos + nlit > s.out_cap) return INF_E_OUTPUT;
+                W_FOR { if ((M >> W_LANE) & 1ull) sc.ring[inf_ridx(s, s.pos + W_RANK(M))] = (uint8_t)V(E); }
+                s.pos += nlit;
+            }
+            INF_PROF(s, 1) INF_COUNT(s, 13, nlit)
+            if (e & INF_SIMPLE) { s.bp += o; continue; }
+        } else e = W_READLANE(E, 0u);
+        if (match_mode || (e != 0u && (e & 511u) >= 257u && (e & 511u) <= 285u)) {
+            // phase B: every lane decodes the WHOLE token that would start at its offset (literal, or length + extra bits + distance code + extra bits: base
+            // values and extra-bit counts come from two small LDS tables), then the chain runs on over literals and matches alike
             W_VEC(uint32_t, T); W_VEC(uint32_t, DV);
             W_FOR {
                 // 32-bit arithmetic on the low word: a token of more than 32 bits (long distance codes with many extra bits) is left to the serial path
@@ -368,65 +475,90 @@ INF_FN int inf_codes(InfState& s) {
                 if (ee & INF_SIMPLE) t = cl | (1u << 8);
                 else {
                     const uint32_t i = (ee & 511u) - 257u;                                   // 0..28 for a length symbol
-                    const uint32_t xb = inf_len_extra(i);
-                    const uint32_t len = inf_len_base(i, xb) + ((x >> cl) & ((1u << xb) - 1u));
+                    const uint32_t ll = sc.len_lut[i & 31u];
+                    const uint32_t xb = ll >> 9;
+                    const uint32_t len = (ll & 511u) + ((x >> cl) & ((1u << xb) - 1u));
                     const uint32_t p2 = cl + xb;                                             // <= 15
                     const uint32_t de = sc.fast_d[(x >> p2) & ((1u << INF_FAST_D) - 1u)];
-                    const uint32_t dcl = de >> 10, ds = (de & 511u) < 30u ? (de & 511u) : 0u;
-                    const uint32_t dxb = inf_dist_extra(ds), p3 = p2 + dcl;                    // p3 <= 23
-                    dv = inf_dist_base(ds, dxb) + ((x >> p3) & ((1u << dxb) - 1u));
-                    const bool ok = ee != 0u && i <= 28u && de != 0u && (de & 511u) < 30u && p3 + dxb <= 32u && dv + len + INF_STEP_CAP <= INF_RING;
-                    t = ok ? ((p3 + dxb) | (len << 8) | INF_T_MATCH) : INF_T_STOP;
+                    const uint32_t dl = sc.dist_lut[de & 31u];
+                    const uint32_t dxb = dl >> 16, p3 = p2 + (de >> 10);                       // p3 <= 23
+                    dv = (dl & 0xffffu) + ((x >> p3) & ((1u << dxb) - 1u));
+                    const bool ok = ee != 0u && i <= 28u && de != 0u && (de & 511u) < 30u && p3 + dxb <= 32u;
+                    t = ok ? ((p3 + dxb) | (len << 8) | INF_T_MATCH | (dv + len + INF_STEP_CAP <= INF_RING ? 0u : INF_T_FAR)) : INF_T_STOP;
                 }
                 V(T) = t; V(DV) = dv;
             }
+            INF_PROF(s, 2) INF_COUNT(s, 10, 1)
             uint64_t MT = 0;
-            uint32_t o2 = o, acc = 0, t = 0;
+            uint32_t o2 = o, t = 0;
 #define INF_HOP_B                                                                                                           \
             t = W_READLANE(T, o2);                                                                                          \
             if (t & INF_T_STOP) break;                                                                                      \
-            if (acc + ((t >> 8) & 511u) > INF_STEP_CAP) break;                                                              \
-            acc += (t >> 8) & 511u;                                                                                         \
             MT |= 1ull << o2;                                                                                               \
             o2 += t & 63u;                                                                                                  \
             if (o2 >= 64u) break;
             for (;;) { INF_HOP_B INF_HOP_B INF_HOP_B INF_HOP_B }
 #undef INF_HOP_B
+            INF_PROF(s, 3)
             if (MT) {
-                if (s.pos + acc > s.out_cap) return INF_E_OUTPUT;
                 W_VEC(uint32_t, OL); W_VEC(uint32_t, EX);
                 W_FOR { V(OL) = ((MT >> W_LANE) & 1ull) ? (V(T) >> 8) & 511u : 0u; }
-                uint32_t total;
-                W_EXCL_SCAN(EX, OL, total);
-                (void)total;
-                W_FOR { if (((MT >> W_LANE) & 1ull) && !(V(T) & INF_T_MATCH)) sc.ring[inf_ridx(s, s.pos + V(EX))] = (uint8_t)V(E); }
+                uint32_t acc;
+                W_EXCL_SCAN(EX, OL, acc);
+                if (acc > INF_STEP_CAP) {
+                    // too much output for one step (a window of maximal matches): keep the tokens that fit - a prefix of the chain
+                    uint64_t keep;
+                    W_BALLOT(keep, ((MT >> W_LANE) & 1ull) && V(EX) + V(OL) <= INF_STEP_CAP);
+                    const uint64_t dropped = MT & ~keep;
+                    o2 = (uint32_t)__builtin_ctzll(dropped);
+                    MT = keep;
+                    W_FOR { if (!((MT >> W_LANE) & 1ull)) V(OL) = 0u; }
+                    W_EXCL_SCAN(EX, OL, acc);
+                }
+                if (s.pos + acc > s.out_cap) return INF_E_OUTPUT;
                 uint64_t MM;
                 W_BALLOT(MM, ((MT >> W_LANE) & 1ull) && (V(T) & INF_T_MATCH));
-                while (MM) {
-                    const uint32_t k = (uint32_t)__builtin_ctzll(MM);
-                    MM &= MM - 1ull;
-                    const uint32_t len = (W_READLANE(T, k) >> 8) & 511u, dist = W_READLANE(DV, k), op = s.pos + W_READLANE(EX, k);
-                    if (dist > op) return INF_E_DIST;
-                    inf_copy_near(s, op, dist, len);
+                if (acc <= 64u) {
+                    const int rc = inf_emit_bytes(s, MT, T, DV, E, EX, acc);
+                    if (rc) return rc;
+                    INF_PROF(s, 4)
+                } else {
+                    W_FOR { if (((MT >> W_LANE) & 1ull) && !(V(T) & INF_T_MATCH)) sc.ring[inf_ridx(s, s.pos + V(EX))] = (uint8_t)V(E); }
+                    uint64_t mm = MM;
+                    while (mm) {
+                        const uint32_t k = (uint32_t)__builtin_ctzll(mm);
+                        mm &= mm - 1ull;
+                        const uint32_t len = (W_READLANE(T, k) >> 8) & 511u, dist = W_READLANE(DV, k), op = s.pos + W_READLANE(EX, k);
+                        if (dist > op) return INF_E_DIST;
+                        if (W_READLANE(T, k) & INF_T_FAR) inf_copy_far(s, op, dist, len); else inf_copy_near(s, op, dist, len);
+                    }
+                    INF_PROF(s, 5) INF_COUNT(s, 12, 1)
                 }
                 s.pos += acc;
                 s.bp += o2;
+                match_mode = MM != 0ull;
+                W_FOR { if ((MT >> W_LANE) & 1ull) INF_STAT(0, (V(T) & INF_T_MATCH) ? (V(T) >> 8) & 511u : 0u, V(DV)); }
+                INF_COUNT(s, 14, __builtin_popcountll(MT))
                 continue;                                               // (a token the chain stopped at starts the next step)
             }
             // the very first token is not a plain near match: the serial path below decodes it
+            e = W_READLANE(E, o);
         }
+        match_mode = false;
         s.bp += o;
         int sym;
         if (e) { sym = (int)(e & 511u); s.bp += e >> 10; }
         else {
             sym = inf_decode_slow(s, sc.cnt_l, sc.lsym);
             if (sym < 0) return sym;
-            if (sym < 256) {
-                if (s.pos >= s.out_cap) return INF_E_OUTPUT;
-                W_FOR { if (W_LANE == 0) sc.ring[inf_ridx(s, s.pos)] = (uint8_t)sym; }
-                s.pos++;
-                continue;
-            }
+        }
+        INF_COUNT(s, 11, 1)
+        if (sym < 256) {
+            if (s.pos >= s.out_cap) return INF_E_OUTPUT;
+            W_FOR { if (W_LANE == 0) sc.ring[inf_ridx(s, s.pos)] = (uint8_t)sym; }
+            s.pos++;
+            INF_PROF(s, 6)
+            continue;
         }
         if (sym == 256) return 0;
         sym -= 257;
@@ -447,8 +579,10 @@ INF_FN int inf_codes(InfState& s) {
         if (ds >= 30) return INF_E_SYMBOL;
         const uint32_t dxb = inf_dist_extra((uint32_t)ds);
         const uint32_t dist = inf_dist_base((uint32_t)ds, dxb) + inf_bits(s, (int)dxb);
+        INF_STAT(1, len, dist);
         const int rc = inf_match(s, dist, len);
         if (rc) return rc;
+        INF_PROF(s, 6)
     }
 }
 
@@ -507,6 +641,10 @@ INF_FN int inflate_raw(const uint8_t* payload, uint32_t in_bytes, uint8_t* out, 
     s.in = reinterpret_cast<const uint32_t*>(payload - skip); s.in_words = (in_bytes + 3u) / 4u; s.bp = 8u * skip;
     s.out = out; s.out_cap = out_cap; s.pos = 0; s.flushed = 0; s.clean = 0; s.mis = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15u);
     s.sc = &sc;
+#if defined(INF_PROFILE) && !defined(INF_HOST)
+    for (int i = 0; i < 16; i++) s.prof[i] = 0;
+    s.t_last = __builtin_readcyclecounter();
+#endif
     inf_load_chunks(s, 0);
     int used = 0;
     for (;;) {
@@ -589,6 +727,8 @@ INF_FN int inflate_raw(const uint8_t* payload, uint32_t in_bytes, uint8_t* out, 
                 err = inf_build(s, sc.len, nlen, sc.cnt_l, sc.lsym, sc.fast_l, INF_FAST_L, 256, &used);
                 if (err < 0 || (err > 0 && used != 1)) return INF_E_OVERSUB;
             }
+            inf_token_luts(s);
+            INF_PROF(s, 7)
             const int rc = inf_codes(s);
             if (rc) return rc;
         } else return INF_E_BLOCKTYPE;
@@ -596,5 +736,10 @@ INF_FN int inflate_raw(const uint8_t* payload, uint32_t in_bytes, uint8_t* out, 
     }
     if ((s.bp + 7u) / 8u > in_bytes) return INF_E_INPUT;
     inf_flush(s, s.pos);
+#if defined(INF_PROFILE) && !defined(INF_HOST)
+    INF_PROF(s, 8)
+    s.prof[15] = s.pos;
+    if (W_LANE == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_inf_prof[i], (unsigned long long)s.prof[i]);
+#endif
     return (int)s.pos;
 }

@@ -2,6 +2,17 @@
 //   inflate_host_test <file.bam|file.gz-with-BGZF-blocks>   every BGZF block of the file: inflate_raw == zlib
 //   inflate_host_test --fuzz N                              N random buffers deflated at levels 0..9 / strategies, incl. stored and fixed blocks
 // Build: g++ -O2 -std=c++17 -DINF_HOST -I svim_amd/csrc tools/inflate_host_test.cpp -lz -o /tmp/inflate_host_test
+#include <cstdint>
+static unsigned long long g_tok[2][3], g_len[2][10], g_dist[2][17], g_bytes[2];      // [path: 0 token chain, 1 serial][...]
+static inline void stat_token(int path, unsigned len, unsigned dist) {
+    g_tok[path][len ? 1 : 0]++;
+    g_bytes[path] += len ? len : 1;
+    if (!len) return;
+    int lb = 0; while ((1u << (lb + 1)) <= len && lb < 9) lb++;
+    int db = 0; while ((1u << (db + 1)) <= dist && db < 16) db++;
+    g_len[path][lb]++; g_dist[path][db]++;
+}
+#define INF_STAT(path, len, dist) stat_token(path, len, dist)
 #include "inflate_core.hpp"
 #include <zlib.h>
 #include <cstdio>
@@ -95,5 +106,12 @@ int main(int argc, char** argv) {
         at += blen; blocks++; total += isize;
     }
     printf("%s: %d BGZF blocks, %zu bytes inflated, %d mismatches\n", argv[1], blocks, total, bad);
+    for (int p = 0; p < 2; p++) {
+        printf("%s: %llu literals, %llu matches, %llu bytes\n  match length (log2 bins from 2):", p ? "serial tokens" : "token chain", g_tok[p][0], g_tok[p][1], g_bytes[p]);
+        for (int i = 1; i < 10; i++) printf(" %llu", g_len[p][i]);
+        printf("\n  distance (log2 bins from 1):");
+        for (int i = 0; i < 17; i++) printf(" %llu", g_dist[p][i]);
+        printf("\n");
+    }
     return bad ? 1 : 0;
 }
