@@ -1323,6 +1323,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     k_edit_prep<PREP_LANES><<<(unsigned)((n_work + 4 * (64 / PREP_LANES) - 1) / (4 * (64 / PREP_LANES))), 256, 0, st>>>(n_work, src, scratch, desc, key_a, val_a, ed_dev, cells_dev);
     HIPCHK(hipGetLastError());
     const bool profile = getenv("SVX_EDIT_PROFILE") != nullptr, serial = getenv("SVX_EDIT_SERIAL") != nullptr;
+    std::vector<PairDesc> first_desc;                       // SVX_EDIT_PROFILE: the descriptors as round 0 saw them (first class of every pair)
     // 2a. band speculation of THIS call from a strided sample of its own pairs (k_edit_pilot); SVX_EDIT_GUESS pins it instead
     float guess = c->edit_guess;
     if (!c->edit_guess_pinned && !c->edit_force_full && n_work >= 4096) {
@@ -1359,6 +1360,11 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     for (int round = 0; pending > 0; round++) {
         if (round >= MAX_ROUNDS) return svx_fail(SVX_E_STATE, "edit-distance retry loop did not converge", __FILE__, __LINE__, hipSuccess);
         if (profile) profile_round(c, round, seg_lo, seg_cn, list, desc, n_work);
+        if (profile && round == 0) {
+            first_desc.resize((size_t)n_work);
+            HIPCHK(hipMemcpyAsync(first_desc.data(), desc, (size_t)n_work * sizeof(PairDesc), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
         // retry lists this round's band launch appends to: one list of `pending` slots per sort class.  Three buffers rotate; the one reused now was
         // last read by round-2's launches
         DevBuf& fb = c->e_retry[round % 3];
@@ -1496,6 +1502,38 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         list = fb.as<uint32_t>();
     }
     for (int k = 0; k < 2; k++) HIPCHK(hipStreamSynchronize(full_st[k]));
+    if (profile && !first_desc.empty()) {
+        // how much wider than necessary was the first band of every pair?  (needed = narrowest band class that certifies the distance found in the end)
+        std::vector<long long> slot((size_t)n_work);
+        long long n_slot = n_work;
+        if (slot_of) {
+            HIPCHK(hipMemcpy(slot.data(), slot_of, (size_t)n_work * 8, hipMemcpyDeviceToHost));
+            for (long long w = 0; w < n_work; w++) if (slot[(size_t)w] + 1 > n_slot) n_slot = slot[(size_t)w] + 1;
+        }
+        std::vector<int32_t> ed((size_t)n_slot);
+        HIPCHK(hipMemcpy(ed.data(), ed_dev, (size_t)n_slot * 4, hipMemcpyDeviceToHost));
+        double used[N_CLASSES] = {0}, need[N_CLASSES] = {0}, failed[N_CLASSES] = {0}; long long cnt_c[N_CLASSES] = {0};
+        double ratio_hist[8] = {0};
+        auto h_need_class = [](int m, int n, int d) { int x = (d - (n - m)) / 2; if (x < 0) x = 0; const int nw = (n - m) + 2 * x + 1;
+            for (int b = 0; b < NBAND; b++) if (nw + (b <= 2 ? 14 : 46) <= 32 * band_words(b)) return b; return (int)CLS_FULL; };
+        for (long long w = 0; w < n_work; w++) {
+            const PairDesc& pd = first_desc[(size_t)w];
+            if (pd.cls == -1) continue;
+            const int cls = pd.cls & 0xff;
+            if (cls >= NBAND) continue;
+            const int d = ed[(size_t)(slot_of ? slot[(size_t)w] : w)];
+            const int nc = h_need_class(pd.m, pd.n, d);
+            const double u = (double)pd.n * band_words(cls), nd = (double)pd.n * (nc < NBAND ? band_words(nc) : (pd.m + 31) / 32);
+            cnt_c[cls]++; used[cls] += u;
+            if (nc <= cls) { need[cls] += nd; int r = band_words(cls) * 4 / band_words(nc) - 4; if (r > 7) r = 7; ratio_hist[r] += u; }
+            else failed[cls] += u;
+        }
+        for (int b = 0; b < NBAND; b++) if (cnt_c[b])
+            fprintf(stderr, "{\"edit_band_fit\": {\"first_cls\": %d, \"words\": %d, \"pairs\": %lld, \"word_cols_first_band\": %.4g, \"of_which_failed\": %.4g, \"word_cols_narrowest_sufficient\": %.4g}}\n",
+                    b, band_words(b), cnt_c[b], used[b], failed[b], need[b]);
+        fprintf(stderr, "{\"edit_band_fit_ratio_hist\": {\"bins\": \"first band / narrowest sufficient band in [1, 1.25), [1.25, 1.5) ... >= 2.75, weighted by word-columns\", \"h\": [%.4g, %.4g, %.4g, %.4g, %.4g, %.4g, %.4g, %.4g]}}\n",
+                ratio_hist[0], ratio_hist[1], ratio_hist[2], ratio_hist[3], ratio_hist[4], ratio_hist[5], ratio_hist[6], ratio_hist[7]);
+    }
     {
         std::vector<unsigned long long> wch((size_t)MAX_ROUNDS * 2 * WC_PER_LAUNCH);
         unsigned long long nb = 0;

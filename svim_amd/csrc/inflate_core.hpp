@@ -76,6 +76,7 @@ struct InfScratch {
 #define W_BALLOT(dst, expr) do { dst = 0; for (int lane_ = 0; lane_ < 64; lane_++) if (expr) dst |= 1ull << lane_; } while (0)
 #define W_RANK(mask) ((uint32_t)__builtin_popcountll((mask) & ((1ull << lane_) - 1ull)))
 #define W_FENCE() do { } while (0)
+#define W_WAIT_LOADS() do { } while (0)
 static inline uint32_t inf_bitrev(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (x & 1u); x >>= 1; } return r; }
 #else
 #define INF_FN __device__ __forceinline__
@@ -88,6 +89,7 @@ static inline uint32_t inf_bitrev(uint32_t x) { uint32_t r = 0; for (int i = 0; 
 #define W_READLANE(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx)))
 #define W_BALLOT(dst, expr) dst = __ballot(expr)
 #define W_RANK(mask) ((uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u)))
+#define W_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)      /* s_waitcnt vmcnt(0) */
 #define W_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 static __device__ __forceinline__ uint32_t inf_bitrev(uint32_t x) { return __builtin_bitreverse32(x); }
 #endif
@@ -128,9 +130,9 @@ static __device__ __forceinline__ uint32_t inf_bitrev(uint32_t x) { return __bui
                                   reach back farther than ring size - this (a later literal of the same step would already sit on its source) */
 
 struct InfState {
-    // input: aligned 32-bit words; lane l of cA holds word cbase + l, of cB word cbase + 64 + l; bp = bit position from the aligned base
+    // input: aligned 32-bit words, 256 of them in four registers: lane l of c[r] holds word cbase + 4 l + r; bp = bit position from the aligned base
     const uint32_t* in; uint32_t in_words, cbase, bp;
-    W_VEC(uint32_t, cA); W_VEC(uint32_t, cB);
+    W_VEC2(uint32_t, c, 4);
     // output
     uint8_t* out; uint32_t out_cap, pos, flushed, clean, mis;      // mis: (address of out) & 15 - ring index of output byte p is (p + mis) & INF_RMASK
     InfScratch* sc;
@@ -154,25 +156,39 @@ __device__ unsigned long long g_inf_prof[16];
 #endif
 
 // ---- input ----------------------------------------------------------------------------------------------------------------------------------------
+// 1 KiB of input per refill, 16 bytes per lane, loaded when a step starts in the last words of the buffer.  No prefetch register: a register with a load
+// in flight makes the compiler wait (for every memory operation of the wave) wherever that register could be read, i.e. at every step; one exposed round
+// trip per KiB costs less, also when the input sits behind PCIe
+#define INF_IN_WORDS 256u
+#define INF_IN_SLACK 16u           /* words a step may read beyond its first one */
 INF_FN void inf_load_chunks(InfState& s, uint32_t cbase) {
     s.cbase = cbase;
-    W_FOR { const uint32_t k = cbase + (uint32_t)W_LANE; V(s.cA) = k < s.in_words ? s.in[k] : 0u; }
-    W_FOR { const uint32_t k = cbase + 64u + (uint32_t)W_LANE; V(s.cB) = k < s.in_words ? s.in[k] : 0u; }
-}
-// called at the top of every decode step: the word holding bit bp sits in cA (every step reads less than 64 words ahead)
-INF_FN void inf_sync_input(InfState& s) {
-    if ((s.bp >> 5) - s.cbase >= 64u) {
-        if ((s.bp >> 5) - s.cbase >= 128u) { inf_load_chunks(s, (s.bp >> 5) & ~63u); return; }
-        s.cbase += 64u;
-        W_FOR { V(s.cA) = V(s.cB); }
-        W_FOR { const uint32_t k = s.cbase + 64u + (uint32_t)W_LANE; V(s.cB) = k < s.in_words ? s.in[k] : 0u; }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        W_FOR { const uint32_t k = cbase + 4u * (uint32_t)W_LANE + (uint32_t)r; V2(s.c, r) = k < s.in_words ? s.in[k] : 0u; }
     }
+    W_WAIT_LOADS();                    // here, once per KiB - otherwise every step has to assume that the four registers may still be on their way
 }
-INF_FN uint32_t inf_word(const InfState& s, uint32_t d) {             // word d, cbase <= d < cbase + 128
-    const uint32_t j = d - s.cbase;
-    const uint32_t a = W_READLANE(s.cA, j & 63u), b = W_READLANE(s.cB, j & 63u);       // both, then a select: no branch
-    return j < 64u ? a : b;
+// called at the top of every decode step: the words the step reads (bp >> 5 and INF_IN_SLACK more) are in the buffer
+INF_FN void inf_sync_input(InfState& s) {
+    if ((s.bp >> 5) - s.cbase > INF_IN_WORDS - INF_IN_SLACK) inf_load_chunks(s, (s.bp >> 5) & ~3u);
 }
+INF_FN uint32_t inf_word(const InfState& s, uint32_t d) {             // word d, cbase <= d < cbase + 256
+    const uint32_t j = d - s.cbase, q = (j >> 2) & 63u, r = j & 3u;
+    const uint32_t a = W_READLANE(s.c[0], q), b = W_READLANE(s.c[1], q), c = W_READLANE(s.c[2], q), e = W_READLANE(s.c[3], q);       // all four, then selects: no branch
+    return r == 0u ? a : (r == 1u ? b : (r == 2u ? c : e));
+}
+// words d .. d + 3 (cbase <= d, d + 3 < cbase + 256): four lane reads, which registers they come from depends on d & 3 only (cbase is a multiple of 4)
+#define INF_WORDS4(s, d, w0, w1, w2, w3)                                                                                                   \
+    {                                                                                                                                      \
+        const uint32_t j_ = (d) - (s).cbase, q_ = j_ >> 2;                                                                                 \
+        switch (j_ & 3u) {                                                                                                                 \
+        case 0u: w0 = W_READLANE((s).c[0], q_); w1 = W_READLANE((s).c[1], q_); w2 = W_READLANE((s).c[2], q_); w3 = W_READLANE((s).c[3], q_); break;            \
+        case 1u: w0 = W_READLANE((s).c[1], q_); w1 = W_READLANE((s).c[2], q_); w2 = W_READLANE((s).c[3], q_); w3 = W_READLANE((s).c[0], q_ + 1u); break;       \
+        case 2u: w0 = W_READLANE((s).c[2], q_); w1 = W_READLANE((s).c[3], q_); w2 = W_READLANE((s).c[0], q_ + 1u); w3 = W_READLANE((s).c[1], q_ + 1u); break;  \
+        default: w0 = W_READLANE((s).c[3], q_); w1 = W_READLANE((s).c[0], q_ + 1u); w2 = W_READLANE((s).c[1], q_ + 1u); w3 = W_READLANE((s).c[2], q_ + 1u); break; \
+        }                                                                                                                                  \
+    }
 INF_FN uint32_t inf_peek(const InfState& s, uint32_t bp) {            // the 32 bits from bit position bp on
     const uint32_t d = bp >> 5, sh = bp & 31u;
     const uint64_t two = (uint64_t)inf_word(s, d) | ((uint64_t)inf_word(s, d + 1u) << 32);
@@ -343,7 +359,8 @@ INF_FN int inf_build(InfState& s, const uint8_t* len, int n, uint16_t* counts, u
 #define INF_WINDOW(s, fast, fb, E)                                                                                                         \
     {                                                                                                                                      \
         const uint32_t d0_ = (s).bp >> 5, sh_ = (s).bp & 31u;                                                                              \
-        const uint32_t w0_ = inf_word(s, d0_), w1_ = inf_word(s, d0_ + 1u), w2_ = inf_word(s, d0_ + 2u), w3_ = inf_word(s, d0_ + 3u);      \
+        uint32_t w0_, w1_, w2_, w3_;                                                                                                       \
+        INF_WORDS4(s, d0_, w0_, w1_, w2_, w3_)                                                                                             \
         W_FOR {                                                                                                                            \
             const uint32_t b_ = sh_ + (uint32_t)W_LANE, i_ = b_ >> 5, f_ = b_ & 31u;                                                       \
             const uint32_t lo_ = i_ == 0u ? w0_ : (i_ == 1u ? w1_ : w2_), hi_ = i_ == 0u ? w1_ : (i_ == 1u ? w2_ : w3_);                   \
@@ -430,10 +447,9 @@ INF_FN int inf_codes(InfState& s) {
         // every lane: the 32 input bits from its offset on, and the literal/length entry of the code that would start there
         W_VEC(uint32_t, XL); W_VEC(uint32_t, E);
         {
-            const uint32_t d0 = s.bp >> 5, sh = s.bp & 31u, j0 = d0 - s.cbase;
+            const uint32_t d0 = s.bp >> 5, sh = s.bp & 31u;
             uint32_t w0, w1, w2, w3;
-            if (j0 < 61u) { w0 = W_READLANE(s.cA, j0); w1 = W_READLANE(s.cA, j0 + 1u); w2 = W_READLANE(s.cA, j0 + 2u); w3 = W_READLANE(s.cA, j0 + 3u); }   // (the usual case)
-            else { w0 = inf_word(s, d0); w1 = inf_word(s, d0 + 1u); w2 = inf_word(s, d0 + 2u); w3 = inf_word(s, d0 + 3u); }
+            INF_WORDS4(s, d0, w0, w1, w2, w3)
             W_FOR {
                 const uint32_t b = sh + (uint32_t)W_LANE, i = b >> 5, f = b & 31u;
                 const uint32_t a0 = i == 0u ? w0 : (i == 1u ? w1 : w2), a1 = i == 0u ? w1 : (i == 1u ? w2 : w3);
