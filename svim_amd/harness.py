@@ -176,8 +176,9 @@ def _bgzf_block(payload, level=1):
     return head + comp + (zlib.crc32(payload) & 0xffffffff).to_bytes(4, "little") + len(payload).to_bytes(4, "little")
 
 
-def write_bam_from_batch(path, hb, references, lengths, name_fmt="r%08d", threads=None):
-    """HostBatch (numpy SoA; e.g. DeviceBatch.slice_records) -> coordinate-sorted BAM file: fixed fields, CIGAR, SEQ, QUAL 0xff, and an
+def write_bam_from_batch(path, hb, references, lengths, name_fmt="r%08d", threads=None, qual_seed=None):
+    """HostBatch (numpy SoA; e.g. DeviceBatch.slice_records) -> coordinate-sorted BAM file: fixed fields, CIGAR, SEQ, QUAL 0xff (= absent; with
+    qual_seed: random Phred values, normal(18, 8) clipped to 1..50 - a file that deflates like one with base qualities), and an
     SA tag rebuilt from the segment rows of every primary that has them.  Returns (n_records, uncompressed bytes)."""
     from concurrent.futures import ThreadPoolExecutor
     A = hb.arrays
@@ -213,7 +214,10 @@ def write_bam_from_batch(path, hb, references, lengths, name_fmt="r%08d", thread
     for r, l in zip(references, lengths):
         nm = r.encode() + b"\0"
         head += len(nm).to_bytes(4, "little") + nm + int(l).to_bytes(4, "little")
-    buf = np.full(len(head) + int(off[n]), 0xff, dtype=np.uint8)           # QUAL bytes are 0xff: pre-filled
+    if qual_seed is None:
+        buf = np.full(len(head) + int(off[n]), 0xff, dtype=np.uint8)       # QUAL bytes are 0xff: pre-filled
+    else:                                                                 # (everything but QUAL is overwritten below)
+        buf = np.clip(np.rint(np.random.default_rng(qual_seed).normal(18.0, 8.0, len(head) + int(off[n]))), 1, 50).astype(np.uint8)
     buf[:len(head)] = np.frombuffer(head, dtype=np.uint8)
     base = len(head)
     core = np.zeros((n, 9), dtype="<i4")                                  # block_size, refID, pos, (l_name|mapq|bin), (n_cig|flag), l_seq, next refID, next pos, tlen
