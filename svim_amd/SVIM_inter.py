@@ -50,3 +50,42 @@ def analyze_read_segments(primary, supplementaries, bam, options):
     keep = [i for i in range(sig.n) if sig.src[i] == 1]
     keep_b = [i for i in range(bnd.n) if bnd.src[i] == 1]
     return [sigs[i] for i in keep], [bnds[i] for i in keep_b]
+
+
+def analyze_read_segments_batch(reads, bam, options):
+    """analyze_read_segments for MANY reads with one launch: reads = [(primary, supplementaries)] -> [(sv_signatures, all_bnds side list)]
+    in the same order, equal to the one-by-one calls (src/svim/SVIM_inter.py:24-302)."""
+    import copy
+    reads = list(reads)
+    if not reads:
+        return []
+    o = types.SimpleNamespace(**vars(options))
+    o.min_mapq = 0
+    recs, real_names = [], []
+    for i, (primary, supplementaries) in enumerate(reads):
+        token = "\x01%d" % i                             # one query-name group per read, whatever the records are called
+        real_names.append(primary.query_name)
+        prim = copy.copy(primary)
+        prim.flag = primary.flag & ~(4 | 256 | 2048)
+        prim.query_name = token
+        recs.append(prim)
+        for s in supplementaries:
+            c = copy.copy(s)
+            c.query_name = token
+            c.flag = (s.flag & 16) | 2048
+            recs.append(c)
+    view = _ReadFile(recs, bam)
+    hb = batch.build_batch(view, o, mode="queryname")
+    sig, bnd = _lib.engine().collect(hb, _abi.Params.from_options(o))
+    read_of_id = [int(nm[1:]) for nm in hb.read_names]
+    names = [real_names[i] for i in read_of_id]
+    sigs = convert.objects_from_sigtable(sig, view.references, names)
+    bnds = convert.objects_from_sigtable(bnd, view.references, names)
+    out = [([], []) for _ in reads]
+    for k in range(sig.n):
+        if sig.src[k] == 1:                              # split-read signatures only (CIGAR indels belong to analyze_alignment_indel)
+            out[read_of_id[int(sig.read_id[k])]][0].append(sigs[k])
+    for k in range(bnd.n):
+        if bnd.src[k] == 1:
+            out[read_of_id[int(bnd.read_id[k])]][1].append(bnds[k])
+    return out

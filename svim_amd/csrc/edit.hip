@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
 }
 
 // first class of every pair + its sort key (one thread per pair)
-__global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort_key, uint32_t* sort_val, int force_full, float guess_frac) {
+__global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort_key, uint32_t* sort_val, int force_full, float guess_frac, int few_pairs) {
     const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_work) return;
     const PairDesc pd = desc[w];
@@ -433,6 +433,10 @@ __global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort
         // short patterns: the whole column fits one lane (k_edit_lane), nothing to speculate about
         if (cls > 0 && cls < NBAND && pd.m <= 512 && (1 << lane_class_for(pd.m)) <= band_words(cls)) cls = CLS_LANE0 + lane_class_for(pd.m);
         else if (cls == CLS_FULL) cls = full_class_for(pd.m);
+        // A call with few pairs is bound by the LATENCY of its longest pair, not by throughput: a band kernel walks a pair's columns in one lane
+        // (4000 columns x 12 words x 40 cycles = 0.9 ms), the 64-lane full-matrix forms (d_edit_wide<64, Q>, chosen by the launch when few
+        // waves are in flight) finish the same pair in a quarter of that while most of the chip idles either way
+        else if (few_pairs && cls < NBAND && pd.m > 512) cls = pd.m <= 4096 ? CLS_WIDE0 + 2 : (pd.m <= 6144 ? CLS_WIDE12 + 3 : (pd.m <= 8192 ? CLS_WIDE0 + 3 : CLS_FULL));
     }
     const int flagged = cls | (pd.cls & ~0xff);
     desc[w].cls = flagged;
@@ -1338,7 +1342,9 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         c->edit_guess_last = guess;
         if (profile) fprintf(stderr, "{\"edit_guess_pilot\": %.4f, \"sampled_pairs\": %lld}\n", guess, n_samp);
     }
-    k_edit_classify<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, desc, key_a, val_a, c->edit_force_full ? 1 : 0, guess);
+    long long few_pairs = 2048;                             // SVX_EDIT_FEW_PAIRS: calls with at most this many pairs take the low-latency route (0 = never)
+    if (const char* e = getenv("SVX_EDIT_FEW_PAIRS")) few_pairs = atoll(e);
+    k_edit_classify<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, desc, key_a, val_a, c->edit_force_full ? 1 : 0, guess, n_work <= few_pairs ? 1 : 0);
     HIPCHK(hipGetLastError());
     // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
     SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, 40));      // 32 bits of cost order + 6 bits of class (+2 spare)

@@ -34,8 +34,10 @@ def test_edit_distance_golden(eng):
     assert eng.edit_distances(pairs) == exp
 
 
+@pytest.mark.parametrize("few_pairs", ["0", "2048"])
 @pytest.mark.parametrize("alphabet", ["ACGTN", "ACGT"])      # generic 4-plane kernels / 2-plane A,C,G,T kernels
-def test_edit_distance_long_vs_oracle(eng, oracle, alphabet):
+def test_edit_distance_long_vs_oracle(eng, oracle, alphabet, few_pairs, monkeypatch):
+    monkeypatch.setenv("SVX_EDIT_FEW_PAIRS", few_pairs)
     rng = random.Random(3)
     pairs = []
     for la, lb, sim in ((2047, 2049, True), (2100, 2300, True), (4000, 4100, False), (5000, 300, False),
@@ -63,10 +65,12 @@ def test_edit_distance_long_vs_oracle(eng, oracle, alphabet):
     assert got == exp
 
 
+@pytest.mark.parametrize("few_pairs", ["0", "2048"])            # band route as in a large call / low-latency route of a call with few pairs
 @pytest.mark.parametrize("alphabet", ["ACGTN", "ACGT"])
-def test_edit_distance_banded_classes_vs_oracle(eng, oracle, alphabet):
+def test_edit_distance_banded_classes_vs_oracle(eng, oracle, alphabet, few_pairs, monkeypatch):
     """Similar pairs with substitutions AND indels at several divergences / lengths / length differences: drives every
     band class (32..512 diagonals), the failed-band retry and the full-matrix fallback; also the '=' symbol (code 0)."""
+    monkeypatch.setenv("SVX_EDIT_FEW_PAIRS", few_pairs)
     rng = random.Random(11)
     pairs = []
     for it in range(700):
@@ -540,6 +544,37 @@ def test_per_read_entry_points_match_reference(eng):
                 s2, b2 = svim_amd.analyze_read_segments(a, sup, bam, o)
                 assert [H.sig_row(s) for s in s2] == e["segments"], e["rec"]
                 assert [H.sig_row(s) for s in b2] == e["segments_bnd"], e["rec"]
+
+
+def test_batched_per_read_entry_points_match_reference(eng):
+    """analyze_alignment_indel_batch / analyze_read_segments_batch: many reads, ONE launch - per record exactly what the reference's per-read
+    functions returned (src/svim/SVIM_intra.py:33-51, src/svim/SVIM_inter.py:24-302; g_entrypoints.json.gz)."""
+    import svim_amd
+    g = H.load("g_entrypoints.json.gz")
+    g2 = H.load("g2_collect.json.gz")
+    text = [c for c in g2["cases"] if c["name"] == "fuzzA" and c["mode"] == "coordinate" and c.get("sam")][0]["sam"]
+    bam = records.AlignmentFile(text=text)
+    recs = list(bam.fetch(until_eof=True))
+    for run in g["runs"]:
+        o = H.options(run["options"])
+        per = run["per_record"]
+        alns = [recs[e["rec"]] for e in per]
+        res = svim_amd.analyze_alignment_indel_batch(alns, bam, [a.query_name for a in alns], o)
+        assert len(res) == len(per)
+        for e, (s1, b1) in zip(per, res):
+            assert [H.sig_row(s) for s in s1] == e["indel"], e["rec"]
+            assert [H.sig_row(s) for s in b1] == e["indel_bnd"], e["rec"]
+        seg = [e for e in per if "segments" in e]
+        reads = []
+        for e in seg:
+            a = recs[e["rec"]]
+            reads.append((a, [x for x in svim_amd.retrieve_other_alignments(a, bam) if x.mapping_quality >= o.min_mapq]))
+        res2 = svim_amd.analyze_read_segments_batch(reads, bam, o)
+        assert len(res2) == len(seg) and len(seg) > 0
+        for e, (s2, b2) in zip(seg, res2):
+            assert [H.sig_row(s) for s in s2] == e["segments"], e["rec"]
+            assert [H.sig_row(s) for s in b2] == e["segments_bnd"], e["rec"]
+    assert svim_amd.analyze_alignment_indel_batch([], bam, [], o) == [] and svim_amd.analyze_read_segments_batch([], bam, o) == []
 
 
 class _Cand(object):

@@ -17,7 +17,7 @@ def test_abi_library_exports_every_declared_symbol():
     assert os.path.exists(_lib._LIB_PATH)
     L = ctypes.CDLL(_lib._LIB_PATH)
     header = open(os.path.join(os.path.dirname(_lib._HERE), "include", "svx.h")).read()
-    declared = sorted(set(re.findall(r"\b(svx_[a-z_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(svx_[a-z0-9_]+)\s*\(", header)))
     assert set(declared) == set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name

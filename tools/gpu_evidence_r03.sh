@@ -24,7 +24,7 @@ for pass in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_AC
 done
 cd $R
 SVX_EDIT_SERIAL=1 SVX_EDIT_PROFILE=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2> gpurun_out/${tag}_edit_profile_raw.txt
-grep -E "edit_profile|edit_launch|edit_guess" gpurun_out/${tag}_edit_profile_raw.txt > gpurun_out/${tag}_edit_class_profile.jsonl; rm -f gpurun_out/${tag}_edit_profile_raw.txt
+grep -E "edit_profile|edit_launch|edit_guess|edit_band_fit" gpurun_out/${tag}_edit_profile_raw.txt > gpurun_out/${tag}_edit_class_profile.jsonl; rm -f gpurun_out/${tag}_edit_profile_raw.txt
 python bench.py --steps 10 --warmup 3 --workload c2 --no-cpu-baseline > gpurun_out/${tag}_bench_c2.json 2>/dev/null
 for pmd in 1000 5000 20000 100000; do python bench.py --steps 5 --warmup 2 --workload c4 --partition-max-distance $pmd --no-cpu-baseline > gpurun_out/${tag}_bench_c4_pmd$pmd.json 2>/dev/null; done
 SVX_BENCH_FORCE_DIST=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end > gpurun_out/${tag}_bench_c1_dist_path_1rank.json 2>/dev/null
@@ -32,6 +32,7 @@ port=29577
 SVX_BENCH_BACKEND=gloo SVX_BENCH_ONE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $port bench.py --gpus 2 --steps 5 --warmup 2 --workload c2 --scale 0.25 --foreign-frac 0.5 --partition-max-distance 5000 > gpurun_out/${tag}_bench_c2_two_ranks_one_gpu_foreign.json 2>/dev/null
 bash tools/host_probe.sh > gpurun_out/${tag}_host_probe.txt 2>&1
 python tools/bgzf_inflate_rate.py 60000 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_bgzf_inflate_rate.txt
+[ -f svim_amd/variants/libsvx_prof.so ] && SVX_LIB=svim_amd/variants/libsvx_prof.so python tools/inflate_profile.py 60000 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_inflate_profile.txt
 python tools/bgzf_symbol_cost.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_bgzf_symbol_cost.txt
 python tools/device_reader_rate.py 180000 8192 2>&1 | grep -v "amdgpu.ids\|bamio pass\|   pass\|bamio 64" > gpurun_out/${tag}_device_reader_rate.txt
 cd /tmp; rm -rf /tmp/rt
@@ -39,4 +40,7 @@ SVX_READER_ONE=1 timeout 600 rocprofv3 --kernel-trace -d /tmp/rt -o p -- python 
 db=$(find /tmp/rt -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/reader_timeline.py $db | tail -14 > $R/gpurun_out/${tag}_reader_timeline.txt
 cd $R
 python tools/small_batch_latency.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_small_batch_latency.txt
+cd /tmp; rm -rf /tmp/sb; rocprofv3 --kernel-trace -d /tmp/sb -o p -- python $R/tools/small_batch_trace.py run 1000 > /tmp/sb.out 2>&1
+db=$(find /tmp/sb -name "*.db" | head -1); [ -n "$db" ] && (grep "last cluster" /tmp/sb.out; python $R/tools/small_batch_trace.py show $db) > $R/gpurun_out/${tag}_small_batch_trace.txt
+cd $R
 ls -la gpurun_out/${tag}_* | head -50

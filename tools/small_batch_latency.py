@@ -30,3 +30,22 @@ for n in (1, 10, 100, 1000, 10000, 100000):
     st = eng.stats()
     print("%7d reads (%d records, %d signatures, %d clusters): collect %.3f ms/call, cluster %.3f ms/call" % (
         n, b.n_rec, st["n_sig"], st["n_clusters"], 1e3 * (t1 - t0) / reps, 1e3 * (t2 - t1) / reps))
+
+# the per-read entry points of the drop-in, one call per record against one batched call (tests/golden: the fuzzA SAM text)
+from tests import helpers as H                             # noqa: E402
+import svim_amd                                           # noqa: E402
+from svim_amd import records                              # noqa: E402
+g2 = H.load("g2_collect.json.gz")
+text = [c for c in g2["cases"] if c["name"] == "fuzzA" and c["mode"] == "coordinate" and c.get("sam")][0]["sam"]
+bam = records.AlignmentFile(text=text)
+recs = list(bam.fetch(until_eof=True))[:200]
+oo = H.options({})
+svim_amd.analyze_alignment_indel(recs[0], bam, recs[0].query_name, oo)
+t0 = time.perf_counter()
+one = [svim_amd.analyze_alignment_indel(a, bam, a.query_name, oo) for a in recs]
+t1 = time.perf_counter()
+many = svim_amd.analyze_alignment_indel_batch(recs, bam, [a.query_name for a in recs], oo)
+t2 = time.perf_counter()
+assert [[s.as_string() if hasattr(s, "as_string") else repr(s) for s in x[0]] for x in one] == [[s.as_string() if hasattr(s, "as_string") else repr(s) for s in x[0]] for x in many]
+print("analyze_alignment_indel, %d records: %.2f ms per call one by one (%.1f ms in all), %.1f ms for ONE analyze_alignment_indel_batch call" % (
+    len(recs), 1e3 * (t1 - t0) / len(recs), 1e3 * (t1 - t0), 1e3 * (t2 - t1)))
