@@ -433,11 +433,13 @@ __global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort
         // short patterns: the whole column fits one lane (k_edit_lane), nothing to speculate about
         if (cls > 0 && cls < NBAND && pd.m <= 512 && (1 << lane_class_for(pd.m)) <= band_words(cls)) cls = CLS_LANE0 + lane_class_for(pd.m);
         else if (cls == CLS_FULL) cls = full_class_for(pd.m);
-        // A call with few pairs is bound by the LATENCY of its longest pair, not by throughput: a band kernel walks a pair's columns in one lane
-        // (4000 columns x 12 words x 40 cycles = 0.9 ms), the 64-lane full-matrix forms (d_edit_wide<64, Q>, chosen by the launch when few
-        // waves are in flight) finish the same pair in a quarter of that while most of the chip idles either way
-        else if (few_pairs && cls < NBAND && pd.m > 512) cls = pd.m <= 4096 ? CLS_WIDE0 + 2 : (pd.m <= 6144 ? CLS_WIDE12 + 3 : (pd.m <= 8192 ? CLS_WIDE0 + 3 : CLS_FULL));
     }
+    // A call with few pairs is bound by the LATENCY of its longest pair, not by throughput: a lane-per-pair kernel walks a pair's columns in one
+    // lane (4000 columns x 12 band words x 40 cycles = 0.9 ms; 1700 columns x 16 words of a 400-row pattern = 0.45 ms), the 64-lane full-matrix forms
+    // (d_edit_wide<64, Q>, 2-4 words per lane, chosen by the launch when few waves are in flight) finish the same pair in a fraction of that while
+    // most of the chip idles either way.  Short patterns and narrow bands of short pairs stay where they are (one or two words per column already).
+    if (few_pairs && !force_full && pd.m > 64 && !(cls < NBAND && pd.m <= 512))
+        cls = pd.m <= 4096 ? CLS_WIDE0 + 2 : (pd.m <= 6144 ? CLS_WIDE12 + 3 : (pd.m <= 8192 ? CLS_WIDE0 + 3 : CLS_FULL));
     const int flagged = cls | (pd.cls & ~0xff);
     desc[w].cls = flagged;
     sort_key[w] = (sort_class(flagged) << 32) | work_key(cls, pd.m, pd.n);
