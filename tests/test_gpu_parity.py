@@ -1201,3 +1201,78 @@ def test_device_bam_decode_regions_and_pipeline(eng, tmp_path, monkeypatch):
         tabs.append([(int(sig.type[i]), int(sig.contig[i]), int(sig.start[i]), int(sig.end[i]), int(sig.contig2[i]), int(sig.pos2[i]), names[int(sig.read_id[i])], sig.sequence(i))
                      for i in range(sig.n)])
     assert tabs[0] == tabs[1] and len(tabs[0]) > 100
+
+
+def _bgzf_offsets(raw):
+    """(offset, total size) of every BGZF block of a file image (SAM spec 4.1: BSIZE at byte 16 of a block with the standard 6-byte extra field)"""
+    out, at = [], 0
+    while at + 18 <= len(raw):
+        size = int.from_bytes(raw[at + 16:at + 18], "little") + 1
+        out.append((at, size))
+        at += size
+    return out
+
+
+def test_device_bam_decode_edge_cases_and_damaged_files(tmp_path, monkeypatch):
+    """The device-resident reader on inputs at the edges: a file with a header and no record, unmapped records behind the mapped ones (the coordinate-sorted
+    pass ends at the first of them in both readers), a file cut in the middle of a BGZF block, a block whose DEFLATE stream is damaged, a block whose
+    ISIZE lies - errors are raised (SvxError), nothing hangs, nothing is handed out silently."""
+    from svim_amd import _lib
+    from svim_amd.bamio import NativeBam
+    g, refs, recs = H.c1_case()
+    # (a) header only
+    p0 = str(tmp_path / "empty.bam")
+    records.write_bam(p0, ["chr1"], [2000000], [])
+    for device in (False, True):
+        nb = NativeBam(p0, threads=2)
+        if device:
+            nb.set_device_decode(0)
+        b, n = nb.read_batch(100, 20, "coordinate")
+        assert n == 0
+        nb.close()
+    # (b) unmapped records at the end
+    import copy
+    tail = []
+    for r in recs[:5]:
+        u = copy.copy(r)
+        u.reference_id, u.reference_start, u.flag, u.cigartuples, u.mapping_quality = -1, -1, 4, [], 0
+        u.query_name = "unmapped_" + r.query_name
+        tail.append(u)
+    p1 = str(tmp_path / "tail.bam")
+    records.write_bam(p1, ["chr1"], [2000000], recs[:400] + tail)
+    host = NativeBam(p1, threads=2)
+    want, want_names = _read_all_batches(host, 150)
+    host.close()
+    dev = NativeBam(p1, threads=2)
+    dev.set_device_decode(0)
+    got, got_names = _read_all_batches(dev, 150)
+    dev.close()
+    assert got_names == want_names and _concat_batches(got) == _concat_batches(want) and len(want_names) == 400
+    # (c) (d) (e) damaged files
+    p2 = str(tmp_path / "good.bam")
+    records.write_bam(p2, ["chr1"], [2000000], recs[:1500])
+    raw = open(p2, "rb").read()
+    blocks = _bgzf_offsets(raw)
+    assert len(blocks) > 6
+    mid_at, mid_size = blocks[len(blocks) // 2]
+    cut = raw[:mid_at + mid_size // 2]
+    bad_type = bytearray(raw)
+    bad_type[mid_at + 18] |= 0x06                                        # BTYPE = 3 (reserved) in the block's first DEFLATE header
+    bad_isize = bytearray(raw)
+    bad_isize[mid_at + mid_size - 4:mid_at + mid_size] = (int.from_bytes(raw[mid_at + mid_size - 4:mid_at + mid_size], "little") - 7).to_bytes(4, "little")
+    for name, image in (("cut", cut), ("btype", bytes(bad_type)), ("isize", bytes(bad_isize))):
+        path = str(tmp_path / (name + ".bam"))
+        with open(path, "wb") as fh:
+            fh.write(image)
+        for device in (True, False):
+            nb = NativeBam(path, threads=2)
+            if device:
+                nb.set_device_decode(0)
+            with pytest.raises(_lib.SvxError):
+                total = 0
+                while True:
+                    b, n = nb.read_batch(200, 20, "coordinate")
+                    if n == 0:
+                        break
+                    total += n
+            nb.close()
