@@ -339,6 +339,20 @@ def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s
         out["bam_file"]["sanity"] = {"inflated_MB_per_s": raw_bytes / wall / 1e6, "gpu_kernel_MB_per_s_while_running": gpu_rate, "host_only_reader_MB_per_s": host_only_rate,
                                      "ok": raw_bytes / wall / 1e6 <= gpu_rate + host_only_rate}
         assert out["bam_file"]["sanity"]["ok"], out["bam_file"]["sanity"]
+        # the same path on a file that carries base qualities (the sample above has QUAL 0xff = absent): a third of the records, random Phred values.
+        # Such a file deflates ~1.5 : 1 instead of ~4 : 1; the decoder's rate follows the compressed bits, so records/s drop accordingly
+        try:
+            nq = max(1000, n // 3)
+            qpath = os.path.join(d, "sample_q.bam")
+            _, q_raw = write_bam_from_batch(qpath, batch.slice_records(0, nq), refs, lens, qual_seed=7)
+            q_size = os.path.getsize(qpath)
+            rq = min(_timed_bam_passes(qpath, opts, eng, gen, passes=3, batch_records=max(1000, nq // 4))[1:], key=lambda x: x[1])
+            out["bam_file_with_base_qualities"] = {"records": rq[0], "reads_per_s": rq[0] / rq[1], "bam_MB": q_size / 1e6, "inflated_MB": q_raw / 1e6,
+                                                   "deflate_ratio": q_raw / max(1, q_size), "inflated_MB_per_s": q_raw / rq[1] / 1e6, "bam_MB_per_s": q_size / rq[1] / 1e6,
+                                                   "qualities": "random Phred values, normal(18, 8) clipped to 1..50"}
+            os.remove(qpath)
+        except OSError:
+            pass
         # (b) host arrays in, no file
         eng.accumulate(False)
         eng.set_genome(*gen)
