@@ -945,9 +945,11 @@ static svx_bam::DevLoad dev_load_chunk(svx_bam* h, int slot, int carry_slot, uin
     } catch (const std::string& e) { r.rc = SVX_E_ARG; r.err = e; return r; }
     catch (const std::exception& e) { r.rc = SVX_E_ARG; r.err = e.what(); return r; }      // (this runs on a std::async thread: nothing may escape into future::get of a C entry point)
     if (blocks.empty() && carry_slot < 0) { r.file_done = true; r.empty = true; return r; }
-    r.rc = devdec_load(h->dev, slot, blocks.data(), blocks.size(), carry_slot, skip, r.file_done, min_mapq);
-    if (r.rc == SVX_OK) r.rc = devdec_count(h->dev, slot, h->tid_limit, &r.n_rec, &r.n_valid);
-    if (r.rc != SVX_OK) r.err = svx_last_error();
+    try {
+        r.rc = devdec_load(h->dev, slot, blocks.data(), blocks.size(), carry_slot, skip, r.file_done, min_mapq);
+        if (r.rc == SVX_OK) r.rc = devdec_count(h->dev, slot, h->tid_limit, &r.n_rec, &r.n_valid);
+        if (r.rc != SVX_OK) r.err = svx_last_error();
+    } catch (const std::exception& e) { r.rc = SVX_E_ARG; r.err = e.what(); }
     return r;
 }
 static void dev_start_prefetch(svx_bam* h, int slot, int carry_slot, uint64_t skip, int min_mapq) {
