@@ -168,6 +168,9 @@ int  svx_version(void);
 int  svx_get_stats(svx_ctx* ctx, svx_stats* out);
 void* svx_stream(svx_ctx* ctx);                              /* hipStream_t the kernels run on */
 int  svx_memcpy_d2h(void* host_dst, const void* device_src, uint64_t bytes);   /* inspection of device-resident results (tests) */
+/* self-test of the library's own radix sort (64-bit keys + 32-bit values, key bits [begin_bit, end_bit), stable) and exclusive scan on n pseudo-random
+   elements, checked on the host against std::stable_sort / a serial sum: 0 = identical (tests) */
+int  svx_selftest_prims(svx_ctx* ctx, int64_t n, int32_t begin_bit, int32_t end_bit, uint64_t seed);
 
 /* ---- COLLECT: replaces analyze_alignment_file_* (src/svim/SVIM_COLLECT.py:96-167) -------------- */
 int  svx_collect(svx_ctx* ctx, const svx_batch* batch, const svx_params* p);

@@ -17,7 +17,7 @@ _LIB_PATH = os.environ.get("SVX_LIB") or os.path.join(_HERE, "libsvx.so")      #
 _LIB = None
 _ENGINES = {}
 
-SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream", "svx_memcpy_d2h", "svx_bam_set_device_decode",
+SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream", "svx_memcpy_d2h", "svx_selftest_prims", "svx_bam_set_device_decode",
            "svx_collect", "svx_collect_count", "svx_collect_fetch", "svx_collect_accumulate", "svx_collect_set_slot_base", "svx_set_genome", "svx_cluster",
            "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_ranks", "svx_cluster_abort_ranks", "svx_cluster_stream_positions",
            "svx_set_alignment_index", "svx_genotype",
@@ -187,6 +187,10 @@ class Engine(object):
 
     def stream(self):
         return self.L.svx_stream(self.ctx)
+
+    def selftest_prims(self, n, begin_bit=0, end_bit=64, seed=1):
+        """the library's own radix sort + exclusive scan on n pseudo-random elements against std::stable_sort / a serial sum (raises on a difference)"""
+        _check(self.L.svx_selftest_prims(self.ctx, C.c_int64(n), C.c_int32(begin_bit), C.c_int32(end_bit), C.c_uint64(seed)), "svx_selftest_prims")
 
     # ---- single-function entry points ----
     def cigar_indel(self, tuples, min_length):

@@ -8,7 +8,7 @@
 // src/svim/SVIM_COLLECT.py:44-93,132-167 (what bamio.cpp's decode_run / append_sa do on the host's cores).
 #include "common.hpp"
 #include "devdec.hpp"
-#include <rocprim/rocprim.hpp>
+#include "scan.hpp"
 #include <zlib.h>
 #include <chrono>
 #include <mutex>
@@ -476,11 +476,7 @@ void devdec_stats(svx_devdec* d, DevDecStats* out) { *out = d->stats; }
 void devdec_reset_names(svx_devdec* d) { (void)d; }
 
 template <class T> static int dd_scan(svx_devdec* d, DevChunk& c, const T* in, T* out, size_t n) {           // exclusive; out[n] NOT written
-    size_t bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), d->stream));
-    SVXCHK(c.scan_tmp.reserve(bytes + 64));
-    HIPCHK(rocprim::exclusive_scan(c.scan_tmp.p, bytes, in, out, T(0), n, rocprim::plus<T>(), d->stream));
-    return SVX_OK;
+    return svx_exclusive_scan<T, T>(in, out, (long long)n, d->stream, c.scan_tmp);
 }
 
 static int dd_check(svx_devdec* d, const char* where) {

@@ -132,7 +132,7 @@ struct svx_ctx {
     DevBuf raw_indel;               // RawIndel records written by the scan kernel
     DevBuf rec_geom, seg_geom;      // int32 x 5 per record / per segment row
     DevBuf seg_ws;                  // segment analysis workspace
-    DevBuf tmp0, tmp1, tmp2, tmp3, tmp4, tmp5, sort_tmp;
+    DevBuf tmp0, tmp1, tmp2, tmp3, tmp4, tmp5, sort_tmp, scan_tmp;
     // genome
     DevBuf g_off, g_codes; int32_t g_n = 0; bool g_borrowed = false; const int64_t* g_off_p = nullptr; const uint8_t* g_codes_p = nullptr;
     // CLUSTER workspace + results
@@ -163,7 +163,7 @@ struct svx_ctx {
     int64_t last_cluster_source_n = 0;
 };
 
-// ---- primitives (prims.hip) ---------------------------------------------------------------------------
+// ---- primitives (prims.hip, scan.hpp: hand-written radix sort and scan) -------------------------------
 int svx_sort_pairs_u64(svx_ctx* c, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                        int64_t n, int begin_bit, int end_bit);
 int svx_exclusive_scan_i64(svx_ctx* c, const int64_t* in, int64_t* out, int64_t n);   // out[n] NOT written

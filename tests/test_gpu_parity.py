@@ -1278,3 +1278,17 @@ def test_device_bam_decode_edge_cases_and_damaged_files(tmp_path, monkeypatch):
                         break
             if nb is not None:
                 nb.close()
+
+
+def test_own_radix_sort_and_scan(eng):
+    """csrc/prims.hip, csrc/scan.hpp (hand-written; rocPRIM in rounds 1-2): stable LSD radix sort of (u64 key, u32 value) pairs over a bit range and the
+    exclusive scan, against std::stable_sort / a serial sum - sizes around every path switch (one workgroup <= 16384 pairs, tiles of 2048; scan: one
+    launch <= 8192), the bit ranges the path uses (0..32, 0..40, 0..64) and ragged ones; seeds with bit 8 set make every key narrow (passes over a
+    constant digit are skipped in the one-workgroup form)."""
+    for n in (0, 1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 8191, 8192, 8193, 10000, 16383, 16384, 16385, 32767, 32768, 32769, 100003, 1 << 20, 3333333):
+        for b0, b1 in ((0, 64), (0, 32), (0, 40)):
+            eng.selftest_prims(n, b0, b1, seed=(n + b1) & ~0x100)
+            eng.selftest_prims(n, b0, b1, seed=(n + b1) | 0x100)
+    for b0, b1 in ((3, 17), (8, 9), (60, 64), (31, 33), (0, 1), (5, 64)):
+        for n in (100, 5000, 8192, 70001):
+            eng.selftest_prims(n, b0, b1, seed=7 * n + b0)
