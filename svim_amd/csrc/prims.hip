@@ -266,25 +266,27 @@ extern "C" int svx_selftest_prims(svx_ctx* c, int64_t n, int32_t begin_bit, int3
     }
     s[(size_t)n] = 0;
     DevBuf dk, dk2, dv, dv2, ds, ds2;
-    SVXCHK(dk.reserve((size_t)n * 8 + 8)); SVXCHK(dk2.reserve((size_t)n * 8 + 8)); SVXCHK(dv.reserve((size_t)n * 4 + 8)); SVXCHK(dv2.reserve((size_t)n * 4 + 8));
-    SVXCHK(ds.reserve((size_t)(n + 1) * 8)); SVXCHK(ds2.reserve((size_t)(n + 1) * 8));
-    int rc = SVX_OK;
     auto done = [&](int r) { dk.release(); dk2.release(); dv.release(); dv2.release(); ds.release(); ds2.release(); return r; };
-    if (n) {
-        HIPCHK(hipMemcpy(dk.p, k.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dv.p, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    }
-    HIPCHK(hipMemcpy(ds.p, s.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
-    rc = svx_sort_pairs_u64(c, dk.as<uint64_t>(), dk2.as<uint64_t>(), dv.as<uint32_t>(), dv2.as<uint32_t>(), n, begin_bit, end_bit);
+    auto on_device = [&]() -> int {                                // (HIPCHK / SVXCHK return from here; the buffers are released by the caller below)
+        SVXCHK(dk.reserve((size_t)n * 8 + 8)); SVXCHK(dk2.reserve((size_t)n * 8 + 8)); SVXCHK(dv.reserve((size_t)n * 4 + 8)); SVXCHK(dv2.reserve((size_t)n * 4 + 8));
+        SVXCHK(ds.reserve((size_t)(n + 1) * 8)); SVXCHK(ds2.reserve((size_t)(n + 1) * 8));
+        if (n) {
+            HIPCHK(hipMemcpy(dk.p, k.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(dv.p, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        }
+        HIPCHK(hipMemcpy(ds.p, s.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+        SVXCHK(svx_sort_pairs_u64(c, dk.as<uint64_t>(), dk2.as<uint64_t>(), dv.as<uint32_t>(), dv2.as<uint32_t>(), n, begin_bit, end_bit));
+        SVXCHK(svx_exclusive_scan_i64(c, ds.as<int64_t>(), ds2.as<int64_t>(), n + 1));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (n) {
+            HIPCHK(hipMemcpy(k2.data(), dk2.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(v2.data(), dv2.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        }
+        HIPCHK(hipMemcpy(s2.data(), ds2.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+        return SVX_OK;
+    };
+    const int rc = on_device();
     if (rc != SVX_OK) return done(rc);
-    rc = svx_exclusive_scan_i64(c, ds.as<int64_t>(), ds2.as<int64_t>(), n + 1);
-    if (rc != SVX_OK) return done(rc);
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (n) {
-        HIPCHK(hipMemcpy(k2.data(), dk2.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(v2.data(), dv2.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    }
-    HIPCHK(hipMemcpy(s2.data(), ds2.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
     const uint64_t m = (end_bit - begin_bit >= 64 ? ~0ull : ((1ull << (end_bit - begin_bit)) - 1ull)) << begin_bit;
     std::vector<uint32_t> order((size_t)n);
     for (int64_t i = 0; i < n; i++) order[(size_t)i] = (uint32_t)i;
