@@ -33,6 +33,7 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
     }
     { void* hp = nullptr; HIPCHK(hipHostMalloc(&hp, 4096, hipHostMallocDefault)); c->pinned = (int64_t*)hp; }
     memset(&c->stats, 0, sizeof c->stats);
+    svx_preload_collect(); svx_preload_cluster(); svx_preload_edit(); svx_preload_prims();       // code objects now, not inside the first call
     { const char* e = getenv("SVX_EDIT_FORCE_FULL"); c->edit_force_full = e && e[0] == '1'; }
     { const char* e = getenv("SVX_EDIT_GUESS"); if (e && atof(e) > 0) { c->edit_guess = (float)atof(e); c->edit_guess_pinned = true; } }
     *out = c;
@@ -40,6 +41,7 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
 }
 
 extern "C" void svx_ctx_destroy(svx_ctx* c) {
+    if (getenv("SVX_ALLOC_STATS")) fprintf(stderr, "svx allocations: %lld hipMalloc calls, %.1f MB, %.2f ms\n", svx_alloc_calls(), svx_alloc_bytes() / 1e6, 1e3 * svx_alloc_seconds());
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);

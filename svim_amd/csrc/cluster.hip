@@ -1591,3 +1591,7 @@ int svx_cluster_impl(svx_ctx* c, const ClusterIn& in, int32_t n_contig, const in
     c->xr_pending = false;
     return rc;
 }
+
+// loads this translation unit's code object (HIP does it lazily, at the first launch): called by svx_ctx_create so that the first COLLECT / CLUSTER call
+// of a context does not pay for it
+void svx_preload_cluster() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_part_starts)); (void)hipGetLastError(); }

@@ -842,3 +842,7 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
     s.n_sig = n_sig; s.n_bnd_side = n_bnd; s.n_ins_bases = n_seq;
     return SVX_OK;
 }
+
+// loads this translation unit's code object (HIP does it lazily, at the first launch): called by svx_ctx_create so that the first COLLECT / CLUSTER call
+// of a context does not pay for it
+void svx_preload_collect() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_shard_prefix)); (void)hipGetLastError(); }

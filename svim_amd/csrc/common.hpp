@@ -1,5 +1,6 @@
 // common.hpp - context, device buffers and wave helpers shared by the libsvx translation units (gfx950 only).
 #pragma once
+#include <chrono>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -25,6 +26,10 @@ int svx_fail(int code, const char* what, const char* file, int line, hipError_t 
     } while (0)
 
 // Growable device allocation (never shrinks; contents are NOT preserved on growth unless asked).
+// time spent in hipMalloc / number of calls / bytes (SVX_ALLOC_STATS=1 prints them when a context is destroyed)
+inline double& svx_alloc_seconds() { static double v = 0; return v; }
+inline long long& svx_alloc_calls() { static long long v = 0; return v; }
+inline size_t& svx_alloc_bytes() { static size_t v = 0; return v; }
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -32,7 +37,9 @@ struct DevBuf {
         if (bytes <= cap) return SVX_OK;
         size_t ncap = bytes + bytes / 8 + 256;
         void* np = nullptr;
+        const auto t0_ = std::chrono::steady_clock::now();
         HIPCHK(hipMalloc(&np, ncap));
+        svx_alloc_seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(); svx_alloc_calls()++; svx_alloc_bytes() += ncap;
         if (keep && p && cap) {
             HIPCHK(hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -169,6 +176,8 @@ int svx_sort_pairs_u64(svx_ctx* c, const uint64_t* keys_in, uint64_t* keys_out, 
 int svx_exclusive_scan_i64(svx_ctx* c, const int64_t* in, int64_t* out, int64_t n);   // out[n] NOT written
 int svx_exclusive_scan_i64_on(svx_ctx* c, const int64_t* in, int64_t* out, int64_t n, hipStream_t stream, DevBuf& tmp);
 int svx_exclusive_scan_i32_to_i64(svx_ctx* c, const int32_t* in, int64_t* out, int64_t n);
+
+void svx_preload_collect(); void svx_preload_cluster(); void svx_preload_edit(); void svx_preload_prims();      // code objects loaded at context creation
 
 // ---- stage entry points ------------------------------------------------------------------------------------
 int svx_collect_impl(svx_ctx* c, const svx_batch* b_dev, const svx_params* p);

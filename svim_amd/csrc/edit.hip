@@ -1655,3 +1655,7 @@ int svx_launch_edit_pairs(svx_ctx* c, int64_t n_work, const void* work_dev, cons
     src.plain = 0; src.work = (const EditWork*)work_dev; src.in = in; src.g_off = c->g_off_p; src.g_codes = c->g_codes_p;
     return run_edit_pipeline(c, n_work, src, ed_dev, cells_dev);
 }
+
+// loads this translation unit's code object (HIP does it lazily, at the first launch): called by svx_ctx_create so that the first COLLECT / CLUSTER call
+// of a context does not pay for it
+void svx_preload_edit() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_edit_classify)); (void)hipGetLastError(); }

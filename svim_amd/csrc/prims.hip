@@ -300,3 +300,7 @@ extern "C" int svx_selftest_prims(svx_ctx* c, int64_t n, int32_t begin_bit, int3
     }
     return done(SVX_OK);
 }
+
+// loads this translation unit's code object (HIP does it lazily, at the first launch): called by svx_ctx_create so that the first COLLECT / CLUSTER call
+// of a context does not pay for it
+void svx_preload_prims() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_radix_offsets)); (void)hipGetLastError(); }
