@@ -76,6 +76,80 @@ __device__ bool dd_validate(const uint8_t* st, uint64_t q, uint64_t data_end, in
     return true;
 }
 
+// ---- CRC32 of every inflated block against its BGZF trailer (htslib verifies it in bgzf_read_block; SVX_BAM_VERIFY_CRC=0 switches the check off) ---------------
+// One wavefront per block, 4 KiB per round: lane l runs the table-driven byte recurrence over its 64 bytes of the round from register 0 (the lanes of a
+// wave read one contiguous 4 KiB), the 64 registers are combined pairwise in six levels - register(A || B) = shift(register(A), |B|) ^ register(B), the
+// shift by 2^j zero bytes being a fixed 32 x 32 matrix over GF(2) - and the rounds are chained the same way.  The block is right-aligned in its rounds
+// (leading zero bytes leave a zero register alone); the initial value 0xffffffff enters at the end as shift(0xffffffff, len).
+struct CrcJob { unsigned long long at; uint32_t len, crc; };
+#define CRC_POW 17                                  /* shift matrices for 2^0 .. 2^16 zero bytes */
+typedef uint32_t __attribute__((aligned(1))) crc_u32_unaligned;
+__device__ __forceinline__ uint32_t crc_apply(const uint32_t* __restrict__ m, uint32_t x) {       // m: 32 words, wave-uniform address
+    uint32_t o = 0;
+#pragma unroll
+    for (int bit = 0; bit < 32; bit++) o ^= m[bit] & (0u - ((x >> bit) & 1u));
+    return o;
+}
+__global__ __launch_bounds__(64) void k_crc32(const uint8_t* st, const CrcJob* jobs, long long nb, const uint32_t* __restrict__ shift, int* err) {
+    __shared__ uint32_t T[256], T1[256], T2[256], T3[256];        // T: one byte; T1..T3: the same byte followed by 1..3 zero bytes (a word takes one round of look-ups)
+    const int lane = lane_id();
+    for (int e = lane; e < 256; e += 64) {
+        uint32_t c = (uint32_t)e;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        T[e] = c;
+    }
+    __syncthreads();
+    for (int e = lane; e < 256; e += 64) {
+        const uint32_t c1 = T[T[e] & 255u] ^ (T[e] >> 8), c2 = T[c1 & 255u] ^ (c1 >> 8), c3 = T[c2 & 255u] ^ (c2 >> 8);
+        T1[e] = c1; T2[e] = c2; T3[e] = c3;
+    }
+    __syncthreads();
+    const long long b = blockIdx.x;
+    if (b >= nb) return;
+    const CrcJob job = jobs[b];
+    const uint8_t* base = st + job.at;
+    const long long len = job.len, rounds = (len + 4095) >> 12, pad = (rounds << 12) - len;
+    uint32_t acc = 0;
+    for (long long r = 0; r < rounds; r++) {
+        const long long off = (r << 12) + (long long)lane * 64 - pad;            // where my 64 bytes start in the block (negative: virtual zero bytes)
+        uint32_t reg = 0;
+        if (off >= 0) {
+            const crc_u32_unaligned* w = reinterpret_cast<const crc_u32_unaligned*>(base + off);
+            uint32_t x[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = w[k];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                reg ^= x[k];
+                reg = T3[reg & 255u] ^ T2[(reg >> 8) & 255u] ^ T1[(reg >> 16) & 255u] ^ T[reg >> 24];
+            }
+        } else if (off > -64) {
+            for (long long i = 0; i < off + 64; i++) reg = T[(reg ^ base[i]) & 255u] ^ (reg >> 8);
+        }
+        // six levels: the last lane of every group of 2, 4, ... 64 holds the register of its group's bytes
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const uint32_t left = (uint32_t)__shfl_up((int)reg, 1 << j, 64);
+            const uint32_t joined = crc_apply(shift + 32 * (6 + j), left) ^ reg;
+            if ((lane & ((2 << j) - 1)) == (2 << j) - 1) reg = joined;
+        }
+        acc = crc_apply(shift + 32 * 12, acc) ^ (uint32_t)__builtin_amdgcn_readlane((int)reg, 63);
+    }
+    uint32_t init = 0xffffffffu;
+    for (int j = 0; j < CRC_POW; j++) if ((len >> j) & 1) init = crc_apply(shift + 32 * j, init);
+    const uint32_t crc = ~(acc ^ init);
+    if (lane == 0 && crc != job.crc) { if (atomicCAS(err, 0, 1) == 0) err[1] = (int)b; }
+}
+// the shift matrices: column `bit` of matrix j = the register that 1 << bit becomes after 2^j zero bytes
+static void crc_shift_matrices(uint32_t (*m)[32]) {
+    uint32_t T[256];
+    for (uint32_t e = 0; e < 256; e++) { uint32_t c = e; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; T[e] = c; }
+    for (int bit = 0; bit < 32; bit++) { const uint32_t r = 1u << bit; m[0][bit] = T[r & 255u] ^ (r >> 8); }
+    for (int j = 1; j < CRC_POW; j++)
+        for (int bit = 0; bit < 32; bit++) { uint32_t o = 0; for (int k = 0; k < 32; k++) if ((m[j - 1][bit] >> k) & 1u) o ^= m[j - 1][k]; m[j][bit] = o; }
+}
+
 // first record start at or after the start of every BGZF block (one wavefront per block; lanes test 64 consecutive byte offsets at a time)
 __global__ __launch_bounds__(64) void k_anchor(const uint8_t* st, const uint64_t* blk_off, long long nb, uint64_t data_end, int32_t n_ref, const int32_t* ref_len,
                                                 uint64_t* anchor) {
@@ -363,14 +437,15 @@ __global__ void k_widen_u32(long long n, const uint32_t* in, uint64_t* out) {
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
 struct DevChunk {
     DevBuf stream; size_t data_begin = 0, data_end = 0, tail_start = 0;            // offsets into stream
-    DevBuf blk_off, anchor, cnt, exit_at, base, rec_off, desc, n_cig, n_seg, n_segop, scan_tmp;
+    DevBuf blk_off, anchor, cnt, exit_at, base, rec_off, desc, n_cig, n_seg, n_segop, scan_tmp, crc_jobs;
+    std::vector<CrcJob> crc_host;          // (alive until the chunk is loaded again: its upload is asynchronous)
     DevBuf flag, tid, pos, mapq, lseq, read_id, cigar_off, cigar, seq_off, seg_off, segop_off, seg_tid, seg_pos, seg_rev, seg_mapq, seg_lseq, seg_cigar_off, seg_cigar;
     DevBuf slot_of, new_rec, name_len, name_at, name_blob;
     DevBuf order[2], seg_order[2]; int order_flip = 0;
     int64_t n_rec = 0, tot_seg = 0, tot_ops = 0, tot_segops = 0;
     bool loaded = false;
     void release() {
-        DevBuf* all[] = {&stream, &blk_off, &anchor, &cnt, &exit_at, &base, &rec_off, &desc, &n_cig, &n_seg, &n_segop, &scan_tmp, &flag, &tid, &pos, &mapq, &lseq, &read_id,
+        DevBuf* all[] = {&stream, &blk_off, &anchor, &cnt, &exit_at, &base, &rec_off, &desc, &n_cig, &n_seg, &n_segop, &scan_tmp, &crc_jobs, &flag, &tid, &pos, &mapq, &lseq, &read_id,
                          &cigar_off, &cigar, &seq_off, &seg_off, &segop_off, &seg_tid, &seg_pos, &seg_rev, &seg_mapq, &seg_lseq, &seg_cigar_off, &seg_cigar, &slot_of,
                          &new_rec, &name_len, &name_at, &name_blob, &order[0], &order[1], &seg_order[0], &seg_order[1]};
         for (auto* b : all) b->release();
@@ -382,7 +457,7 @@ struct svx_devdec {
     hipStream_t stream = nullptr;
     svx_inflater* inf = nullptr;
     int32_t n_ref = 0;
-    DevBuf ref_len, contig_rank, ct_key, ct_tid, ct_names, ct_name_off, err, counters;
+    DevBuf ref_len, contig_rank, ct_key, ct_tid, ct_names, ct_name_off, err, counters, crc_shift;
     uint32_t ct_mask = 0;
     DevBuf nt_key, nt_check, nt_id; uint32_t nt_cap = 0;
     std::vector<std::string> names;
@@ -453,7 +528,7 @@ void devdec_destroy(svx_devdec* d) {
     (void)hipStreamSynchronize(d->stream);
     if (d->inf) svx_inflater_destroy(d->inf);
     for (auto& c : d->chunk) c.release();
-    DevBuf* all[] = {&d->ref_len, &d->contig_rank, &d->ct_key, &d->ct_tid, &d->ct_names, &d->ct_name_off, &d->err, &d->counters, &d->nt_key, &d->nt_check, &d->nt_id};
+    DevBuf* all[] = {&d->ref_len, &d->contig_rank, &d->ct_key, &d->ct_tid, &d->ct_names, &d->ct_name_off, &d->err, &d->counters, &d->crc_shift, &d->nt_key, &d->nt_check, &d->nt_id};
     for (auto* b : all) b->release();
     if (d->h_err) (void)hipHostFree(d->h_err);
     if (d->hbuf) (void)hipHostFree(d->hbuf);
@@ -655,6 +730,20 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
     SVXCHK(c.exit_at.reserve((size_t)nb * 8)); SVXCHK(c.base.reserve((size_t)(nb + 1) * 8));
     HIPCHK(hipMemcpyAsync(c.blk_off.p, blk.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d->err.p, 0, 64, st));
+    static const bool verify_crc = []() { const char* e = getenv("SVX_BAM_VERIFY_CRC"); return !(e && e[0] == '0'); }();
+    if (verify_crc && nb_in) {
+        if (!d->crc_shift.p) {
+            uint32_t m[CRC_POW][32];
+            crc_shift_matrices(m);
+            SVXCHK(d->crc_shift.reserve(sizeof m));
+            HIPCHK(hipMemcpy(d->crc_shift.p, m, sizeof m, hipMemcpyHostToDevice));
+        }
+        c.crc_host.resize(nb_in);
+        for (size_t k = 0; k < nb_in; k++) c.crc_host[k] = CrcJob{(unsigned long long)(DD_HEAD + out_at[k]), blocks[k].isize, blocks[k].crc};
+        SVXCHK(c.crc_jobs.reserve(nb_in * sizeof(CrcJob)));
+        HIPCHK(hipMemcpyAsync(c.crc_jobs.p, c.crc_host.data(), nb_in * sizeof(CrcJob), hipMemcpyHostToDevice, st));
+        k_crc32<<<(unsigned)nb_in, 64, 0, st>>>(sp, c.crc_jobs.as<CrcJob>(), (long long)nb_in, d->crc_shift.as<uint32_t>(), d->err.as<int>() + 8);
+    }
     k_anchor<<<(unsigned)nb, 64, 0, st>>>(sp, c.blk_off.as<uint64_t>(), nb, c.data_end, d->n_ref, d->ref_len.as<int32_t>(), c.anchor.as<uint64_t>());
     k_walk<<<GRIDB(nb, 64), 64, 0, st>>>(sp, c.blk_off.as<uint64_t>(), nb, c.data_end, c.anchor.as<uint64_t>(), c.cnt.as<uint32_t>(), c.exit_at.as<uint64_t>(), nullptr, nullptr);
     HIPCHK(hipGetLastError());
@@ -662,8 +751,11 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
     std::vector<uint32_t> cnt((size_t)nb);
     HIPCHK(hipMemcpyAsync(anchor.data(), c.anchor.p, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(exit_at.data(), c.exit_at.p, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
+    int crc_err[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(cnt.data(), c.cnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(crc_err, d->err.as<int>() + 8, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (crc_err[0]) { char msg[96]; snprintf(msg, sizeof msg, "BGZF block %d of the chunk fails its CRC32", crc_err[1]); return svx_fail(SVX_E_ARG, msg, __FILE__, __LINE__, hipSuccess); }
     // the anchors are right iff they link up: the walk that leaves a block must arrive exactly at the next anchor, and the first anchor is the known start
     bool linked = anchor[0] == c.data_begin;
     uint64_t n_rec = 0, tail = c.data_begin;

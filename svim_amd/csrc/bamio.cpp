@@ -937,7 +937,7 @@ static svx_bam::DevLoad dev_load_chunk(svx_bam* h, int slot, int carry_slot, uin
         while (total < h->dev_chunk_bytes && blocks.size() < h->dev_chunk_blocks) {
             RawBlock b;
             if (!read_block(h, b)) { r.file_done = true; break; }
-            blocks.push_back(DevDecBlock{b.comp, (uint32_t)b.clen, b.isize});
+            blocks.push_back(DevDecBlock{b.comp, (uint32_t)b.clen, b.isize, b.crc});
             total += b.isize;
         }
         std::swap(fp, h->fpos);

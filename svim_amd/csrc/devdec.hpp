@@ -7,7 +7,7 @@
 #include <vector>
 #include "../../include/svx.h"
 
-struct DevDecBlock { const uint8_t* comp; uint32_t clen, isize; };      // one BGZF block: raw DEFLATE payload in the memory-mapped file, inflated size
+struct DevDecBlock { const uint8_t* comp; uint32_t clen, isize, crc; };   // one BGZF block: raw DEFLATE payload in the memory-mapped file, inflated size, CRC32 of the inflated bytes
 
 struct svx_devdec;
 // names_blob: the reference names NUL-separated in header order (SA tags name contigs)

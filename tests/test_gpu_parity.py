@@ -1216,7 +1216,7 @@ def _bgzf_offsets(raw):
 def test_device_bam_decode_edge_cases_and_damaged_files(tmp_path, monkeypatch):
     """The device-resident reader on inputs at the edges: a file with a header and no record, unmapped records behind the mapped ones (both readers hand them out, COLLECT
     skips them by their flag), a file cut in the middle of a BGZF block, a block whose DEFLATE stream is damaged, a block whose
-    ISIZE lies - errors are raised (SvxError), nothing hangs, nothing is handed out silently."""
+    ISIZE lies, a block that inflates to the wrong bytes (only its CRC32 tells) - errors are raised (SvxError), nothing hangs, nothing is handed out silently."""
     from svim_amd import _lib
     from svim_amd.bamio import NativeBam
     g, refs, recs = H.c1_case()
@@ -1262,11 +1262,23 @@ def test_device_bam_decode_edge_cases_and_damaged_files(tmp_path, monkeypatch):
     bad_type[mid_at + 18] |= 0x06                                        # BTYPE = 3 (reserved) in the block's first DEFLATE header
     bad_isize = bytearray(raw)
     bad_isize[mid_at + mid_size - 4:mid_at + mid_size] = (int.from_bytes(raw[mid_at + mid_size - 4:mid_at + mid_size], "little") - 7).to_bytes(4, "little")
-    for name, image in (("cut", cut), ("btype", bytes(bad_type)), ("isize", bytes(bad_isize))):
+    # a block that inflates without complaint to the right length but to the wrong bytes: one quality byte changed, the trailer's CRC32 kept
+    import zlib
+    pay = zlib.decompress(raw[mid_at + 18:mid_at + mid_size - 8], -15)
+    run = pay.find(b"\xff" * 40)
+    assert run > 0
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = co.compress(pay[:run + 20] + b"\xfe" + pay[run + 21:]) + co.flush()
+    wrong = bytearray(raw[mid_at:mid_at + 18]) + body + raw[mid_at + mid_size - 8:mid_at + mid_size]
+    wrong[16:18] = (len(wrong) - 1).to_bytes(2, "little")
+    bad_crc = raw[:mid_at] + bytes(wrong) + raw[mid_at + mid_size:]
+    for name, image in (("cut", cut), ("btype", bytes(bad_type)), ("isize", bytes(bad_isize)), ("crc", bad_crc)):
         path = str(tmp_path / (name + ".bam"))
         with open(path, "wb") as fh:
             fh.write(image)
         for device in (True, False):
+            if name == "crc" and not device:
+                continue                                                   # (the host reader verifies CRCs only with SVX_BAM_VERIFY_CRC=1: tests/test_host_cpu.py)
             nb = None
             with pytest.raises(_lib.SvxError):                             # (a cut file is refused when it is opened already)
                 nb = NativeBam(path, threads=2)
