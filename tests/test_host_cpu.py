@@ -585,3 +585,29 @@ def test_reader_verifies_block_crc_on_request(tmp_path, monkeypatch):
     assert "READ %d" % len(recs) in out.stdout, out.stderr[-500:]
     out = subprocess.run([sys.executable, "-c", code, bad], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode != 0 and "CRC32" in out.stderr, (out.stdout, out.stderr[-500:])
+
+
+def test_sample_bam_with_base_qualities_is_the_same_file_but_for_qual(tmp_path):
+    """harness.write_bam_from_batch(qual_seed=...) - the literal-heavy sample of the inflate / end-to-end measurements: the records are the ones of the
+    QUAL-less file (our Python BAM reader on both), only the quality bytes differ (Phred 1..50 instead of 0xff = absent), and the file deflates far worse."""
+    import gzip
+    from svim_amd import devsynth, harness
+    b, genome, meta = devsynth.make_batch(n_reads=300, n50=3000, contig_len=400_000, seed=5, device="cpu")
+    hb = b.slice_records(0, b.n_rec)
+    p0, p1 = str(tmp_path / "plain.bam"), str(tmp_path / "qual.bam")
+    n0, raw0 = harness.write_bam_from_batch(p0, hb, ["chr1"], [int(genome.numel())])
+    n1, raw1 = harness.write_bam_from_batch(p1, hb, ["chr1"], [int(genome.numel())], qual_seed=3)
+    assert n0 == n1 == b.n_rec and raw0 == raw1
+    a0 = list(records.AlignmentFile(p0).fetch(until_eof=True))
+    a1 = list(records.AlignmentFile(p1).fetch(until_eof=True))
+    assert len(a0) == len(a1) == b.n_rec
+    for x, y in zip(a0, a1):
+        assert (x.query_name, x.flag, x.reference_id, x.reference_start, x.mapping_quality, x.cigartuples, x.query_sequence) == \
+               (y.query_name, y.flag, y.reference_id, y.reference_start, y.mapping_quality, y.cigartuples, y.query_sequence)
+    r0, r1 = gzip.open(p0).read(), gzip.open(p1).read()
+    assert len(r0) == len(r1) == raw0
+    diff = np.frombuffer(r0, dtype=np.uint8) != np.frombuffer(r1, dtype=np.uint8)
+    q1 = np.frombuffer(r1, dtype=np.uint8)[diff]
+    assert diff.any() and (np.frombuffer(r0, dtype=np.uint8)[diff] == 0xff).all() and q1.min() >= 1 and q1.max() <= 50
+    import os
+    assert os.path.getsize(p1) > 1.5 * os.path.getsize(p0)
