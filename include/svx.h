@@ -309,8 +309,9 @@ int  svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** nul_separated
  * data) is inflated by the GPU into HBM (one wavefront per block), the record boundaries are found there (BGZF blocks are the restart points of the
  * block_size chain: a speculative record start per block, verified by linking the chains), and fixed fields, CIGAR (CG tag included), the SA tag -> segment
  * table and the read names (interned by 2 x 64-bit hashes) are decoded by kernels.  svx_bam_read_batch then returns an svx_batch whose pointers are DEVICE
- * memory (on_device = 1; seq points into the inflated stream - no bases are copied); arrays stay valid until the THIRD next chunk is loaded.  device < 0:
- * back to the host reader. */
+ * memory (on_device = 1; seq points into the inflated stream - no bases are copied); arrays stay valid until the THIRD next chunk is loaded.  Every
+ * inflated block is checked against the CRC32 of its BGZF trailer on the device (as htslib's bgzf_read_block does; environment SVX_BAM_VERIFY_CRC=0: off);
+ * a damaged block fails the svx_bam_read_batch that would have handed out its records.  device < 0: back to the host reader. */
 int  svx_bam_set_device_decode(svx_bam* h, int device);
 
 #ifdef __cplusplus
