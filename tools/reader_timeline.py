@@ -13,7 +13,7 @@ def main(db_path):
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     for n, s, e in cur.execute("select %s, start, end from kernels" % name_col):
-        if "k_bgzf_inflate" in n or "k_anchor" in n or "k_measure" in n or "k_cigar_copy" in n:
+        if any(k in n for k in ("k_bgzf_inflate", "k_crc32", "k_anchor", "k_walk", "k_measure", "k_fields", "k_cigar_copy", "k_name_")):
             ev.append((s, e, n.split("(")[0].replace("void ", "")))
     mc = [t for t in tables if "memory_cop" in t]
     for t in mc[:1]:
