@@ -62,6 +62,10 @@ class Oracle(object):
         self._keep = [off, codes]
         self.L.svo_set_genome(self.ctx, C.byref(g))
 
+    def set_threads(self, n):
+        """worker threads for the pair distances of cluster() (test infrastructure: full-size parity runs; the results do not depend on n)"""
+        self.L.svo_set_threads(self.ctx, int(n))
+
     def set_chain(self, fn):
         """fn(phase, words): phase 0 fills the six per-type stream start positions into `words` (list of 6 ints, in place), phase 1 receives the six
         end positions - the checker's stand-in for the rank exchange the product does inside svx_cluster (svx_cluster_set_ranks)"""

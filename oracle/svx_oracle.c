@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <pthread.h>
 #include "../include/svx.h"
 
 /* ---------------------------------------------------------------- growable signature table ---- */
@@ -69,6 +70,7 @@ typedef struct svo_ctx {
      * positions of this rank (words earlier ranks' partitions consumed), fn(user, 1, words) REPORTS the 6 end positions */
     svo_chain_fn chain_fn; void* chain_user;
     svx_stats stats;
+    int n_threads;                   /* svo_set_threads: worker threads for the pair distances of svo_cluster (default 1) */
 } svo_ctx;
 
 int svo_ctx_create(svo_ctx** out) { *out = calloc(1, sizeof(svo_ctx)); return 0; }
@@ -690,7 +692,7 @@ static int64_t haplotype_edit_distance(svo_ctx* c, const csig* s1, const csig* s
     memcpy(h2 + l2, s2->seq, (size_t)s2->seq_len); l2 += s2->seq_len;
     l2 += fetch(c, s2->contig, s2->start, we, h2 + l2);
     int64_t d = svo_edit_distance(h1, l1, h2, l2);
-    c->stats.n_edit_pairs++; c->stats.n_edit_cells += l1 * l2;
+    __atomic_fetch_add(&c->stats.n_edit_pairs, 1, __ATOMIC_RELAXED); __atomic_fetch_add(&c->stats.n_edit_cells, l1 * l2, __ATOMIC_RELAXED);      /* (svo_set_threads) */
     free(h1); free(h2);
     return d;
 }
@@ -865,6 +867,53 @@ static void consolidate(svo_ctx* c, const csig* m, const int32_t* midx, int n, i
 
 /* cluster_sv_signatures -> partition_and_cluster x6 (src/svim/SVIM_CLUSTER.py:7-26, SVIM_clustering.py:375-385,
  * form_partitions :17-29, clusters_from_partitions :122-180) */
+/* one partition's sample (pass 1), its same-read duplicates removed and its condensed distance matrix (pass 2) */
+typedef struct {
+    int type, ns, nm;
+    int32_t midx[100];              /* sampled members: indices into the signature table, sample order */
+    int32_t mmidx[100];             /* ... without the same-read duplicates */
+    double* cd;                     /* nm (nm - 1) / 2 distances, scipy's condensed order */
+} part_job;
+typedef struct { svo_ctx* c; const svx_sig_view* v; const svx_params* p; part_job* jobs; int64_t n; int64_t next; } part_work;
+
+static void part_distances(svo_ctx* c, const svx_sig_view* v, const svx_params* p, part_job* J) {
+    const int ns = J->ns, type = J->type;
+    csig m[100];
+    for (int k = 0; k < ns; k++) m[k] = get_sig(v, J->midx[k]);
+    /* same-read duplicate removal (:141-151); INV exempt */
+    unsigned char dup[100]; memset(dup, 0, sizeof dup);
+    if (type != SVX_INV) {
+        for (int i = 0; i < ns - 1; i++) for (int j = i + 1; j < ns; j++)
+            if (m[i].read_id == m[j].read_id) {
+                double d = span_position_distance(c, &m[i], &m[j], p);
+                if (d <= p->cluster_max_distance) dup[j] = 1;
+            }
+    }
+    csig mm[100]; int nm = 0;
+    for (int k = 0; k < ns; k++) if (!dup[k]) { mm[nm] = m[k]; J->mmidx[nm] = J->midx[k]; nm++; }
+    J->nm = nm; J->cd = NULL;
+    if (nm > 1) {
+        double* cd = malloc(sizeof(double) * (size_t)(nm * (nm - 1) / 2));
+        int64_t q = 0;
+        for (int i = 0; i < nm - 1; i++) for (int j = i + 1; j < nm; j++) {
+            if (type != SVX_INV && mm[i].read_id == mm[j].read_id) cd[q++] = 99999.0;
+            else cd[q++] = span_position_distance(c, &mm[i], &mm[j], p);
+        }
+        J->cd = cd;
+    }
+}
+static void* part_worker(void* arg) {
+    part_work* W = arg;
+    for (;;) {
+        const int64_t i = __atomic_fetch_add(&W->next, 1, __ATOMIC_RELAXED);
+        if (i >= W->n) break;
+        part_distances(W->c, W->v, W->p, &W->jobs[i]);
+    }
+    return NULL;
+}
+/* test infrastructure only: the pair distances of svo_cluster on n worker threads (results do not depend on n) */
+int svo_set_threads(svo_ctx* c, int n) { c->n_threads = n < 1 ? 1 : n; return 0; }
+
 int svo_cluster(svo_ctx* c, int source, const svx_sig_view* sigs_in, int32_t n_contig, const int32_t* rank, const svx_params* p) {
     (void)n_contig;
     svx_sig_view local; const svx_sig_view* v = sigs_in;
@@ -905,6 +954,11 @@ int svo_cluster(svo_ctx* c, int source, const svx_sig_view* sigs_in, int32_t n_c
         int64_t first_cluster = out->n;
         mt rng; mt_seed_int(&rng, 1524u);                     /* seed(1524) once per type call, :129 */
         for (int64_t w = 0; w < chain_words[type]; w++) (void)mt_u32(&rng);     /* svo_cluster_set_chain: words earlier ranks consumed */
+        /* Three passes over the type's partitions.  (1) boundaries + random.sample, in order (the generator is one stream per type);
+         * (2) the pair distances of every partition - independent of each other, the only expensive part (edit distances): spread over
+         * svo_set_threads worker threads, results the same whatever the thread count; (3) linkage + consolidation, in order. */
+        int64_t np_cap = 1024, np = 0;
+        part_job* jobs = malloc(sizeof(part_job) * (size_t)np_cap);
         int64_t ps = t_begin;
         while (ps < t_end) {
             /* grow the partition while downstream_distance_to(prev, cur) <= max_distance */
@@ -920,53 +974,52 @@ int svo_cluster(svo_ctx* c, int source, const svx_sig_view* sigs_in, int32_t n_c
                 pe++;
             }
             int64_t psize = pe - ps;
-            int32_t sample[100]; int ns;
+            if (np == np_cap) { np_cap *= 2; jobs = realloc(jobs, sizeof(part_job) * (size_t)np_cap); }
+            part_job* J = &jobs[np++];
+            memset(J, 0, sizeof *J);
             c->stats.n_partitions++;
-            if (psize > 100) { mt_sample100(&rng, psize, sample); ns = 100; c->stats.n_large_partitions++; }
-            else { ns = (int)psize; for (int k = 0; k < ns; k++) sample[k] = k; }
-            const int mine = 1;
-            if (mine) {
-                csig m[100]; int32_t midx[100];
-                for (int k = 0; k < ns; k++) { midx[k] = (int32_t)keys[ps + sample[k]].idx; m[k] = get_sig(v, midx[k]); }
-                /* same-read duplicate removal (:141-151); INV exempt */
-                unsigned char dup[100]; memset(dup, 0, sizeof dup);
-                double* dm = malloc(sizeof(double) * 100 * 100);     /* distances computed during dedupe, reused below */
-                unsigned char* have = calloc(100 * 100, 1);
-                if (type != SVX_INV) {
-                    for (int i = 0; i < ns - 1; i++) for (int j = i + 1; j < ns; j++)
-                        if (m[i].read_id == m[j].read_id) {
-                            double d = span_position_distance(c, &m[i], &m[j], p);
-                            dm[i * 100 + j] = d; have[i * 100 + j] = 1;
-                            if (d <= p->cluster_max_distance) dup[j] = 1;
-                        }
-                }
-                csig mm[100]; int32_t mmidx[100]; int orig[100]; int nm = 0;
-                for (int k = 0; k < ns; k++) if (!dup[k]) { mm[nm] = m[k]; mmidx[nm] = midx[k]; orig[nm] = k; nm++; }
-                if (nm == 1) consolidate(c, mm, mmidx, 1, global_part);
-                else {
-                    double* cd = malloc(sizeof(double) * (size_t)(nm * (nm - 1) / 2));
-                    int64_t q = 0;
-                    for (int i = 0; i < nm - 1; i++) for (int j = i + 1; j < nm; j++) {
-                        if (type != SVX_INV && mm[i].read_id == mm[j].read_id) cd[q++] = 99999.0;
-                        else cd[q++] = span_position_distance(c, &mm[i], &mm[j], p);
-                        c->stats.n_pairs++;
-                    }
-                    (void)orig;
-                    int32_t lab[100];
-                    svo_linkage_fcluster(nm, cd, p->cluster_max_distance, lab, NULL);
-                    int maxl = 0; for (int k = 0; k < nm; k++) if (lab[k] > maxl) maxl = lab[k];
-                    for (int l = 1; l <= maxl; l++) {
-                        csig cm[100]; int32_t cidx_[100]; int cn = 0;
-                        for (int k = 0; k < nm; k++) if (lab[k] == l) { cm[cn] = mm[k]; cidx_[cn] = mmidx[k]; cn++; }
-                        if (cn) consolidate(c, cm, cidx_, cn, global_part);
-                    }
-                    free(cd);
-                }
-                free(dm); free(have);
-            }
-            global_part++;
+            int32_t sample[100];
+            if (psize > 100) { mt_sample100(&rng, psize, sample); J->ns = 100; c->stats.n_large_partitions++; }
+            else { J->ns = (int)psize; for (int k = 0; k < J->ns; k++) sample[k] = k; }
+            for (int k = 0; k < J->ns; k++) J->midx[k] = (int32_t)keys[ps + sample[k]].idx;
+            J->type = type;
             ps = pe;
         }
+        {
+            part_work W; W.c = c; W.v = v; W.p = p; W.jobs = jobs; W.n = np; W.next = 0;
+            int nt = c->n_threads > 1 ? c->n_threads : 1;
+            if (nt > np) nt = (int)(np ? np : 1);
+            if (nt <= 1) part_worker(&W);
+            else {
+                pthread_t* th = malloc(sizeof(pthread_t) * (size_t)nt);
+                int started = 0;
+                for (int k = 0; k < nt - 1; k++) if (pthread_create(&th[started], NULL, part_worker, &W) == 0) started++;
+                part_worker(&W);
+                for (int k = 0; k < started; k++) pthread_join(th[k], NULL);
+                free(th);
+            }
+        }
+        for (int64_t pi = 0; pi < np; pi++) {
+            part_job* J = &jobs[pi];
+            const int nm = J->nm;
+            csig mm[100];
+            for (int k = 0; k < nm; k++) mm[k] = get_sig(v, J->mmidx[k]);
+            if (nm == 1) consolidate(c, mm, J->mmidx, 1, global_part);
+            else {
+                c->stats.n_pairs += (int64_t)nm * (nm - 1) / 2;
+                int32_t lab[100];
+                svo_linkage_fcluster(nm, J->cd, p->cluster_max_distance, lab, NULL);
+                int maxl = 0; for (int k = 0; k < nm; k++) if (lab[k] > maxl) maxl = lab[k];
+                for (int l = 1; l <= maxl; l++) {
+                    csig cm[100]; int32_t cidx_[100]; int cn = 0;
+                    for (int k = 0; k < nm; k++) if (lab[k] == l) { cm[cn] = mm[k]; cidx_[cn] = J->mmidx[k]; cn++; }
+                    if (cn) consolidate(c, cm, cidx_, cn, global_part);
+                }
+                free(J->cd);
+            }
+            global_part++;
+        }
+        free(jobs);
         /* unilocal types: sorted(key=(contig, (end+start)/2)) - stable (:381) */
         int64_t ncl = out->n - first_cluster;
         if (type <= SVX_INV && ncl > 1) {

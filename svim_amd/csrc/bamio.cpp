@@ -210,7 +210,14 @@ struct svx_bam {
     int dev_cur = -1; int64_t dev_first = 0, dev_valid = 0; bool dev_have_carry = false;
     size_t dev_chunk_bytes = (size_t)8192 << 20, dev_chunk_blocks = (size_t)1 << 30;      // test hooks: SVX_BAM_DEV_CHUNK_MB, SVX_BAM_DEV_CHUNK_BLOCKS
     std::string dev_names_blob;
-    struct DevLoad { int slot = 0, rc = SVX_OK; std::string err; int64_t n_rec = 0, n_valid = 0; bool file_done = false, empty = false; };
+    struct DevLoad { int slot = 0, carry_slot = -1, rc = SVX_OK; std::string err; int64_t n_rec = 0, n_valid = 0; bool file_done = false, empty = false;
+                     size_t fpos_start = 0; uint64_t skip = 0; };
+    // Chunk slots rotate 0 -> 1 -> 2 -> 0 over the whole life of the reader - ALSO across svx_bam_seek / svx_bam_rewind: the batch handed out last (and the
+    // one before it) may still be read by the consumer's stream when the next region's first chunk is loaded (include/svx.h: arrays stay valid until the
+    // third next chunk is loaded).  dev_last_slot = the slot that was loaded last.
+    int dev_last_slot = -1, dev_handed_slot = -1;      // dev_handed_slot: the slot the last batch was handed out from
+    int dev_grow = 0;                         // a chunk without one complete record is loaded again, into the same slot, with 2^dev_grow times the budget
+    size_t dev_region_bytes = 0;              // contig-range reading: budget of the next chunk (small after a seek, x4 per chunk: a range is not read 8 GB beyond its end)
     std::future<DevLoad> dev_future; bool dev_prefetching = false;
 };
 
@@ -611,6 +618,7 @@ extern "C" int svx_bam_seek(svx_bam* h, uint64_t voff, int32_t last_tid) {
     if (h->dev) {                                          // device decode: the next chunk starts at that block, `uoff` bytes into its data
         dev_drop_prefetch(h);
         h->dev_fpos = coff; h->dev_skip = uoff; h->dev_file_done = false; h->dev_region_done = false; h->dev_cur = -1; h->dev_first = h->dev_valid = 0; h->dev_have_carry = false;
+        h->dev_grow = 0; h->dev_region_bytes = last_tid != -2 ? (size_t)256 << 20 : 0;
         return SVX_OK;
     }
     try {
@@ -633,6 +641,7 @@ extern "C" int svx_bam_rewind(svx_bam* h) {
     if (h->dev) {                                          // device decode: nothing to inflate here - the first chunk is loaded by the first read
         dev_drop_prefetch(h);
         h->dev_fpos = 0; h->dev_skip = h->header_bytes; h->dev_file_done = false; h->dev_region_done = false; h->dev_cur = -1; h->dev_first = h->dev_valid = 0; h->dev_have_carry = false;
+        h->dev_grow = 0; h->dev_region_bytes = 0;
         h->total_records = 0; h->tid_limit = -2; h->region_done = false;
         return SVX_OK;
     }
@@ -926,15 +935,15 @@ static void clear_batch(svx_bam* h) {
 // (src/svim/SVIM_COLLECT.py:132-167), 1 = query-name-sorted rules (:96-129).
 // one chunk of the device reader: whole BGZF blocks up to dev_chunk_bytes of inflated data -> slot `slot` (runs on a background thread while the
 // batches of the chunk before it are handed out; only this function advances dev_fpos)
-static svx_bam::DevLoad dev_load_chunk(svx_bam* h, int slot, int carry_slot, uint64_t skip, int min_mapq) {
+static svx_bam::DevLoad dev_load_chunk(svx_bam* h, int slot, int carry_slot, uint64_t skip, int min_mapq, size_t budget_bytes, size_t budget_blocks) {
     svx_bam::DevLoad r;
-    r.slot = slot;
+    r.slot = slot; r.carry_slot = carry_slot; r.skip = skip; r.fpos_start = h->dev_fpos;
     std::vector<DevDecBlock> blocks;
     size_t total = 0;
     try {
         size_t fp = h->dev_fpos;
         std::swap(fp, h->fpos);                                   // (read_block walks h->fpos; the host reader is idle in device mode)
-        while (total < h->dev_chunk_bytes && blocks.size() < h->dev_chunk_blocks) {
+        while (total < budget_bytes && blocks.size() < budget_blocks) {
             RawBlock b;
             if (!read_block(h, b)) { r.file_done = true; break; }
             blocks.push_back(DevDecBlock{b.comp, (uint32_t)b.clen, b.isize, b.crc});
@@ -953,11 +962,20 @@ static svx_bam::DevLoad dev_load_chunk(svx_bam* h, int slot, int carry_slot, uin
     return r;
 }
 static void dev_start_prefetch(svx_bam* h, int slot, int carry_slot, uint64_t skip, int min_mapq) {
-    h->dev_future = std::async(std::launch::async, dev_load_chunk, h, slot, carry_slot, skip, min_mapq);
+    // budgets are fixed here, on the caller's thread (the loader runs beside the consumer)
+    size_t bytes = h->dev_chunk_bytes, blocks = h->dev_chunk_blocks;
+    if (h->dev_region_bytes && h->dev_region_bytes < bytes) bytes = h->dev_region_bytes;
+    for (int g = 0; g < h->dev_grow; g++) { if (bytes < ((size_t)1 << 62)) bytes *= 2; if (blocks < ((size_t)1 << 62)) blocks *= 2; }
+    if (h->dev_region_bytes && !h->dev_grow) h->dev_region_bytes = std::min(h->dev_region_bytes * 4, h->dev_chunk_bytes);
+    h->dev_last_slot = slot;
+    h->dev_future = std::async(std::launch::async, dev_load_chunk, h, slot, carry_slot, skip, min_mapq, bytes, blocks);
     h->dev_prefetching = true;
 }
+// the slot after the one loaded last - never restarted at 0: see dev_last_slot
+static int dev_next_slot(const svx_bam* h) { return h->dev_last_slot < 0 ? 0 : (h->dev_last_slot + 1) % 3; }
 static void dev_drop_prefetch(svx_bam* h) {
     if (h->dev_prefetching) { (void)h->dev_future.get(); h->dev_prefetching = false; }
+    h->dev_last_slot = h->dev_handed_slot;                // whatever was loaded beyond the last handed-out chunk is discarded: the rotation goes on behind that chunk
 }
 
 // device decode: batches are views of the current chunk's arrays; the next chunk is inflated and decoded meanwhile
@@ -970,20 +988,31 @@ static int read_batch_device(svx_bam* h, int64_t max_records, int min_mapq, svx_
             const int rc = devdec_batch(h->dev, h->dev_cur, h->dev_first, count, out);
             if (rc != SVX_OK) return rc;
             h->dev_first += count; h->total_records += count; *n_out = count;
+            h->dev_handed_slot = h->dev_cur;
             return SVX_OK;
         }
         if (h->dev_region_done || h->dev_file_done) return SVX_OK;          // end of the region / of the file
-        if (!h->dev_prefetching) dev_start_prefetch(h, h->dev_cur < 0 ? 0 : (h->dev_cur + 1) % 3, h->dev_have_carry ? h->dev_cur : -1, h->dev_skip, min_mapq);
+        if (!h->dev_prefetching) dev_start_prefetch(h, dev_next_slot(h), h->dev_have_carry ? h->dev_cur : -1, h->dev_skip, min_mapq);
         svx_bam::DevLoad r = h->dev_future.get();
         h->dev_prefetching = false;
         h->dev_skip = 0;
         if (r.rc != SVX_OK) return bam_fail(r.rc, r.err);
         if (r.empty) { h->dev_file_done = true; return SVX_OK; }
+        if (r.n_rec == 0 && !r.file_done) {
+            // not one complete record in the chunk (a header or a record longer than the chunk: only with the small chunks of the test hooks).  The rotation
+            // must not advance for it - the slot after this one may still be in use - so the SAME slot is loaded again from the same place with twice the budget
+            if (h->dev_grow >= 24) return bam_fail(SVX_E_ARG, "device BAM decode: no complete record within the largest chunk");
+            h->dev_grow++;
+            h->dev_fpos = r.fpos_start;
+            dev_start_prefetch(h, r.slot, r.carry_slot, r.skip, min_mapq);
+            continue;
+        }
+        h->dev_grow = 0;
         h->dev_cur = r.slot; h->dev_first = 0; h->dev_valid = r.n_valid; h->dev_have_carry = true;
         h->dev_file_done = r.file_done;                                     // (the records of this last chunk are still to be handed out: checked after them)
         if (r.n_valid < r.n_rec) h->dev_region_done = true;                 // contig-range reading: the range ends where the next contig (or the unplaced tail) begins
         // (a chunk without one complete record is carried over whole into the next load; devdec_load refuses when a record outgrows its carry-over room)
-        if (!h->dev_file_done && !h->dev_region_done) dev_start_prefetch(h, (h->dev_cur + 1) % 3, h->dev_cur, 0, min_mapq);
+        if (!h->dev_file_done && !h->dev_region_done) dev_start_prefetch(h, dev_next_slot(h), h->dev_cur, 0, min_mapq);
     }
 }
 
@@ -999,6 +1028,7 @@ extern "C" int svx_bam_set_device_decode(svx_bam* h, int device) {
     { const char* e = getenv("SVX_BAM_DEV_CHUNK_BLOCKS"); if (e && atoll(e) > 0) h->dev_chunk_blocks = (size_t)atoll(e); }
     if (h->prefetch_active) { h->prefetch.wait(); h->prefetch_active = false; }
     h->dev_fpos = 0; h->dev_skip = h->header_bytes; h->dev_file_done = false; h->dev_region_done = false; h->dev_cur = -1; h->dev_first = h->dev_valid = 0; h->dev_have_carry = false;
+    h->dev_last_slot = h->dev_handed_slot = -1; h->dev_grow = 0; h->dev_region_bytes = 0;                      // a fresh decoder: nothing handed out from its slots yet
     return SVX_OK;
 }
 

@@ -664,37 +664,203 @@ __device__ __forceinline__ void planes8(uint32_t w, uint32_t (&out)[P]) {       
 // bit-plane words of 32 rows given as 4 packed words.  Deliberately NOT inlined: unrolled into the Q-word set-up loops it drives the
 // kernels' register allocation up (155 -> fewer waves per SIMD) for code that runs once per pair / once per 32 columns.
 template <int P>
-__device__ __attribute__((noinline)) void planes32(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t (&out)[P]) {
+__device__ __forceinline__ void planes32(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t (&out)[P]) {
     uint32_t e0[P], e1[P], e2[P], e3[P];
     planes8<P>(w0, e0); planes8<P>(w1, e1); planes8<P>(w2, e2); planes8<P>(w3, e3);
 #pragma unroll
     for (int b = 0; b < P; b++) out[b] = e0[b] | (e1[b] << 8) | (e2[b] << 16) | (e3[b] << 24);
 }
 
+// The staircase window NARROWS while it runs (Ukkonen's cut-off, as edlib applies it to its block range): with kcap = the largest distance this
+// attempt can certify (what the static window guarantees, or a smaller upper bound known beforehand), a cell whose value plus the
+// remaining diagonal distance |(n - j) - (m - i)| exceeds kcap lies on no alignment of cost <= kcap.  At every drop (each 32 columns) the wave
+// asks two questions about the column it has just finished (j1):
+//   top:    would the last row r of the SECOND window word be such a cell?  (value = top + deltas of words 0 and 1, on diagonal j1 - r >= n - m).
+//           Values never decrease along a diagonal and lose at most 1 per step towards the corridor, so every later cell on or above
+//           that diagonal is such a cell too: both words leave instead of one.
+//   bottom: is the last row of the second-to-last word such a cell (diagonal <= n - m)?  Then so is everything below it in the next 32
+//           columns: no new word enters.  (Also when the window already reaches below row m.)
+// Either answer must hold for every pair of the wave that still has columns (one __all each): the number of live words Q is wave-uniform and
+// selects the unrolled column code.  A pair is answered iff its result is <= kcap - exactly the acceptance rule of the static window
+// (d <= delta + 2 margin + 1), so narrowing changes what is computed, never what is accepted.  SVX_EDIT_NARROW=0 keeps the window static.
+#define STAIR_QMAX 16
+#define STAIR_QMIN 3
+
+template <int Q, int P, bool PRED>
+__device__ __forceinline__ void stair_columns8(uint32_t (&pv)[STAIR_QMAX], uint32_t (&mv)[STAIR_QMAX], uint32_t (&pl)[P][STAIR_QMAX], const uint32_t tword,
+                                               const int j0, const int n, int& top) {
+    uint32_t tp[P];
+    planes8<P>(tword, tp);                                          // bit k of tp[b]: plane b of the word's k-th symbol
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (!PRED || j0 + k + 1 <= n) {
+            uint32_t nk[P];
+#pragma unroll
+            for (int b = 0; b < P; b++) nk[b] = ((tp[b] >> k) & 1u) - 1u;
+            top += 1;
+            unsigned carry = 0;
+            uint32_t ph_prev = 0x80000000u, mh_prev = 0u;          // the row above the window steps +1
+            MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
+        }
+    }
+}
+
+// per-lane bookkeeping of the staircase kernel
+struct StairLane {
+    int top;                    // D[row above the window][current column]
+    int trow;                   // pattern row held by bit 0 of the window
+    int kcap;                   // largest distance this attempt certifies
+    int m, n, delta;
+    int d;                      // the result, taken when the lane's last column is through (-1: row m was not inside the window)
+    bool live;
+    long long useful;           // word-columns the lane's pair needed
+};
+
+// Block kb (columns 32 kb + 1 .. 32 kb + 32) with Q live words, then the drop that prepares block kb + 1.  Returns the new Q.
+// The window state is moved for ALL lanes alike (a lane-dependent move would make the compiler keep whole copies of the register arrays):
+// a lane whose last column lies in this block takes its result here, before the drop.
 template <int Q, int P>
-__device__ __forceinline__ void d_edit_stair(long long blk, long long count, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
-                                             const long long* slot_of, int32_t* ed, unsigned long long* fail_cnt, uint32_t* fail_lists,
+__device__ __forceinline__ int stair_block(uint32_t (&pv)[STAIR_QMAX], uint32_t (&mv)[STAIR_QMAX], uint32_t (&pl)[P][STAIR_QMAX], uint32_t (&tq)[4],
+                                           const uint32_t (&pw_next)[4], StairLane& L, const int kb, const int nmin, const int nmax, const bool narrow,
+                                           long long& issued) {
+    const int n = L.n;
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+        const int j0 = kb * 32 + i * 8;
+        if (j0 >= nmax) break;
+        const uint32_t tword = tq[0];
+        tq[0] = tq[1]; tq[1] = tq[2]; tq[2] = tq[3];
+        if (j0 + 8 <= nmin) stair_columns8<Q, P, false>(pv, mv, pl, tword, j0, n, L.top);
+        else stair_columns8<Q, P, true>(pv, mv, pl, tword, j0, n, L.top);
+    }
+    {
+        const int cols = nmax - kb * 32 >= 32 ? 32 : nmax - kb * 32;
+        issued += (long long)cols * Q * 64;
+        int mine = n - kb * 32; mine = mine > 32 ? 32 : (mine < 0 ? 0 : mine);
+        L.useful += (long long)mine * Q;
+    }
+    const int j1 = 32 * (kb + 1);                                  // last column of the block
+    const bool fin = L.live && n > 32 * kb && n <= j1;             // this lane's last column lies in this block
+    if (__any(fin)) {
+        // D[m][n] = D[row above the window][n] + vertical deltas of window bits 0 .. (m - first row of the window)
+        const int bm = L.m - L.trow;
+        int d = L.top;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int hi_bit = bm - 32 * q;
+            const uint32_t mask = hi_bit >= 31 ? 0xffffffffu : (hi_bit < 0 ? 0u : ((2u << hi_bit) - 1u));
+            d += __popc(pv[q] & mask) - __popc(mv[q] & mask);
+        }
+        if (fin) L.d = (bm >= 0 && bm < 32 * Q) ? d : -1;
+    }
+    if (j1 >= nmax) return Q;                                      // no lane has another block
+    const bool active = L.live && j1 < n;
+    const int t1 = L.top + __popc(pv[0]) - __popc(mv[0]);           // D[last row of word 0][j1]
+    int t2 = t1;
+    bool et = false, eb = false;
+    if (narrow && Q > STAIR_QMIN) {
+        t2 = t1 + __popc(pv[1]) - __popc(mv[1]);                    // D[last row of word 1][j1]
+        const int oc_t = j1 - (L.trow + 63);                        // its diagonal
+        const bool ok_t = !active || (oc_t >= L.delta && t2 + (oc_t - L.delta) > L.kcap);
+        int sb = L.top;
+#pragma unroll
+        for (int q = 0; q < Q - 1; q++) sb += __popc(pv[q]) - __popc(mv[q]);          // D[last row of word Q-2][j1]
+        const int bot = L.trow + 32 * Q;                            // first row below the window
+        const int oc_b = j1 - (bot - 33);
+        const bool ok_b = !active || bot > L.m || (oc_b <= L.delta && sb + (L.delta - oc_b) > L.kcap);
+        et = __all(ok_t); eb = __all(ok_b);
+        if (et && eb && Q - 2 < STAIR_QMIN) eb = false;
+    }
+    uint32_t acc[P];
+    planes32<P>(pw_next[0], pw_next[1], pw_next[2], pw_next[3], acc);       // the word below the window (enters unless eb)
+    if (et) {
+        L.top = t2; L.trow += 64;
+#pragma unroll
+        for (int q = 0; q + 2 < Q; q++) {
+            pv[q] = pv[q + 2]; mv[q] = mv[q + 2];
+#pragma unroll
+            for (int b = 0; b < P; b++) pl[b][q] = pl[b][q + 2];
+        }
+        if (!eb) {                                                  // a word that enters steps +1 per row
+            pv[Q - 2] = 0xffffffffu; mv[Q - 2] = 0u;
+#pragma unroll
+            for (int b = 0; b < P; b++) pl[b][Q - 2] = acc[b];
+        }
+    } else {
+        L.top = t1; L.trow += 32;
+#pragma unroll
+        for (int q = 0; q + 1 < Q; q++) {
+            pv[q] = pv[q + 1]; mv[q] = mv[q + 1];
+#pragma unroll
+            for (int b = 0; b < P; b++) pl[b][q] = pl[b][q + 1];
+        }
+        if (!eb) {
+            pv[Q - 1] = 0xffffffffu; mv[Q - 1] = 0u;
+#pragma unroll
+            for (int b = 0; b < P; b++) pl[b][Q - 1] = acc[b];
+        }
+    }
+    return Q - (et ? 1 : 0) - (eb ? 1 : 0);
+}
+
+// wave-uniform state of a staircase run
+struct StairRun {
+    int Q, kb, n_blocks, nmin, nmax, txt_words, pat_words;
+    bool narrow, live;
+    long long issued;
+};
+
+// The number of live words only ever decreases: the run is a cascade of plain loops, one per Q, each entered when the window has that many
+// words (a single loop around a switch over Q makes every register array a 14-way merge at its header).
+template <int Q, int P>
+__device__ __forceinline__ void stair_run(uint32_t (&pv)[STAIR_QMAX], uint32_t (&mv)[STAIR_QMAX], uint32_t (&pl)[P][STAIR_QMAX], uint32_t (&tq)[4],
+                                          uint32_t (&tw_next)[4], uint32_t (&pw_next)[4], StairLane& L, StairRun& R, const Packed& pat, const Packed& txt) {
+    if (R.Q == Q && R.kb < R.n_blocks) {
+#pragma unroll 1
+        do {
+            R.Q = stair_block<Q, P>(pv, mv, pl, tq, pw_next, L, R.kb, R.nmin, R.nmax, R.narrow, R.issued);
+            // text words of block kb + 1 (fetched a block ahead), then the fetches for block kb + 2 and for the pattern rows below the new window
+            const int below = (L.trow + 32 * R.Q - 1) >> 3;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                tq[i] = tw_next[i];
+                const int ti = 4 * (R.kb + 2) + i;
+                tw_next[i] = (R.live && ti < R.txt_words) ? txt.word(ti) : 0u;
+                const int pi = below + i;
+                pw_next[i] = (R.live && pi >= 0 && pi < R.pat_words) ? pat.word(pi) : 0u;
+            }
+            R.kb++;
+        } while (R.Q == Q && R.kb < R.n_blocks);
+    }
+    if constexpr (Q > STAIR_QMIN) stair_run<Q - 1, P>(pv, mv, pl, tq, tw_next, pw_next, L, R, pat, txt);
+}
+
+template <int P>
+__device__ __forceinline__ void d_edit_stair(const int Q0, const bool narrow, long long blk, long long count, const uint32_t* list, const uint32_t* scratch,
+                                             PairDesc* desc, const long long* slot_of, int32_t* ed, unsigned long long* fail_cnt, uint32_t* fail_lists,
                                              long long fail_cap, unsigned long long* wc) {
     const long long t = blk * 256 + threadIdx.x;
     const bool live = t < count;
     uint32_t widx = 0;
     PairDesc pd; pd.m = 1; pd.n = 0; pd.pat = 0; pd.txt = 0; pd.ub = 0; pd.cls = 0;
     if (live) { widx = list[t]; pd = desc[widx]; }
-    const int W = 32 * Q;
+    const int W0 = 32 * Q0;
     const int m = pd.m, n = live ? pd.n : 0;
     const int delta = n - m;
-    int off = (W - 34 + delta) / 2;
+    int off = (W0 - 34 + delta) / 2;
     if (off < 7) off = 7;
     off -= ((off - 7) & 7);
-    const int margin_lo = W - off - 33, margin_up = off + 1 - delta;
+    const int margin_lo = W0 - off - 33, margin_up = off + 1 - delta;
     const int margin = margin_lo < margin_up ? margin_lo : margin_up;
     const Packed pat{scratch + pd.pat, CLS_PAT_SH(pd.cls)}, txt{scratch + pd.txt, CLS_TXT_SH(pd.cls)};
     const int pat_words = (m + 7) >> 3, txt_words = (n + 7) >> 3;
     const int w0 = -((off + 1) >> 3);                   // packed pattern word that holds bit 0 of the window (row -off)
     auto pat_word = [&](int idx) -> uint32_t { return (live && idx >= 0 && idx < pat_words) ? pat.word(idx) : 0u; };
-    uint32_t pv[Q], mv[Q], pl[P][Q];
+    // all STAIR_QMAX words are set up, whatever Q0 is (the words beyond Q0 are never looked at): a set-up that depends on Q0 would make every
+    // register array a union of its variants
+    uint32_t pv[STAIR_QMAX], mv[STAIR_QMAX], pl[P][STAIR_QMAX];
 #pragma unroll
-    for (int q = 0; q < Q; q++) {
+    for (int q = 0; q < STAIR_QMAX; q++) {
         const int nvirt = off + 1 - 32 * q;             // bits of this word that are rows <= 0: vertical delta -1
         const uint32_t mlow = nvirt >= 32 ? 0xffffffffu : (nvirt <= 0 ? 0u : ((1u << nvirt) - 1u));
         mv[q] = mlow; pv[q] = ~mlow;
@@ -703,13 +869,18 @@ __device__ __forceinline__ void d_edit_stair(long long blk, long long count, con
 #pragma unroll
         for (int b = 0; b < P; b++) pl[b][q] = acc[b];
     }
-    int top = off + 1;                                   // D[row above the window][column]
+    StairLane L;
+    L.top = off + 1;                                     // D[row above the window][column]
+    L.trow = -off; L.m = m; L.n = n; L.delta = delta; L.live = live; L.useful = 0; L.d = -1;
+    // what the static window certifies: d <= delta + 2 margin + 1 (x = floor((d - delta) / 2) <= margin); an upper bound known beforehand
+    // (trivial alignments, an earlier band's path) is never exceeded by the true distance, so it may stand in when it is smaller
+    L.kcap = margin >= 0 ? delta + 2 * margin + 1 : -1;
+    if (live && pd.ub < L.kcap) L.kcap = pd.ub;
     int nmax = n;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
-    // Columns are processed one packed text word (8 columns) per loop trip - the unrolled body of a whole 32-column block is 18-45 KB
-    // of code per class, which several classes resident on one CU pair do not keep in the instruction cache.  The pairs of a wave are
-    // sorted by text length, so all but the last few trips run without the per-column `j <= n` test (PRED = false).
+    // Columns are processed one packed text word (8 columns) per loop trip; the pairs of a wave are sorted by text length, so all but the
+    // last few trips run without the per-column `j <= n` test (PRED = false).
     int nmin = live ? n : 0x7fffffff;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(nmin, o, 64); nmin = v < nmin ? v : nmin; }
@@ -719,71 +890,18 @@ __device__ __forceinline__ void d_edit_stair(long long blk, long long count, con
     for (int i = 0; i < 4; i++) {
         tq[i] = (live && i < txt_words) ? txt.word(i) : 0u;
         tw_next[i] = (live && 4 + i < txt_words) ? txt.word(4 + i) : 0u;
-        pw_next[i] = pat_word(w0 + 4 * Q + i);
+        pw_next[i] = pat_word(w0 + 4 * Q0 + i);                         // rows just below the window
     }
-    auto columns8 = [&](const uint32_t tword, const int j0, auto pred_tag) {
-        constexpr bool PRED = decltype(pred_tag)::value;
-        uint32_t tp[P];
-        planes8<P>(tword, tp);                                          // bit k of tp[b]: plane b of the word's k-th symbol
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (!PRED || j0 + k + 1 <= n) {
-                uint32_t nk[P];
-#pragma unroll
-                for (int b = 0; b < P; b++) nk[b] = ((tp[b] >> k) & 1u) - 1u;
-                top += 1;
-                unsigned carry = 0;
-                uint32_t ph_prev = 0x80000000u, mh_prev = 0u;          // the row above the window steps +1
-                MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
-            }
-        }
-    };
-#pragma unroll 1
-    for (int jb = 0; jb * 8 < nmax; jb++) {
-        if ((jb & 3) == 0 && jb > 0) {
-            const int kb = jb >> 2;
-            if (kb * 32 < n) {
-                // the window drops 32 rows: word 0 leaves (its deltas move into `top`), a fresh word enters at the bottom
-                top += __popc(pv[0]) - __popc(mv[0]);
-#pragma unroll
-                for (int q = 0; q < Q - 1; q++) {
-                    pv[q] = pv[q + 1]; mv[q] = mv[q + 1];
-#pragma unroll
-                    for (int b = 0; b < P; b++) pl[b][q] = pl[b][q + 1];
-                }
-                pv[Q - 1] = 0xffffffffu; mv[Q - 1] = 0u;
-                uint32_t acc[P];
-                planes32<P>(pw_next[0], pw_next[1], pw_next[2], pw_next[3], acc);
-#pragma unroll
-                for (int b = 0; b < P; b++) pl[b][Q - 1] = acc[b];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                tq[i] = tw_next[i];
-                const int ti = 4 * (kb + 1) + i;
-                tw_next[i] = (live && ti < txt_words) ? txt.word(ti) : 0u;
-                pw_next[i] = pat_word(w0 + 4 * (kb + Q) + i);           // enters when the window drops into block kb + 1
-            }
-        }
-        const uint32_t tword = tq[0];
-        tq[0] = tq[1]; tq[1] = tq[2]; tq[2] = tq[3];
-        if (jb * 8 + 8 <= nmin) columns8(tword, jb * 8, std::false_type{});
-        else columns8(tword, jb * 8, std::true_type{});
-    }
-    wc_account(wc, (long long)nmax * Q * 64, (long long)n * Q);
+    StairRun R;
+    R.Q = Q0; R.kb = 0; R.n_blocks = (nmax + 31) >> 5; R.nmin = nmin; R.nmax = nmax; R.narrow = narrow; R.issued = 0;
+    R.live = live; R.txt_words = txt_words; R.pat_words = pat_words;
+    stair_run<STAIR_QMAX, P>(pv, mv, pl, tq, tw_next, pw_next, L, R, pat, txt);
+    const long long issued = R.issued;
+    wc_account(wc, issued, L.useful);
     if (!live) return;
-    // D[m][n] = D[row above the window][n] + vertical deltas of window bits 0 .. (m - first row of the last block)
-    const int bm = m - (((n - 1) >> 5) * 32 - off);
-    int d = top;
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-        const int hi_bit = bm - 32 * q;
-        const uint32_t mask = hi_bit >= 31 ? 0xffffffffu : (hi_bit < 0 ? 0u : ((2u << hi_bit) - 1u));
-        d += __popc(pv[q] & mask) - __popc(mv[q] & mask);
-    }
-    const int x = (d - delta) >> 1;
-    if (margin >= 0 && bm >= 0 && bm < W && x >= 0 && x <= margin) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
-    else band_retry(pd, widx, m, n, (margin >= 0 && bm >= 0 && bm < W) ? d : pd.ub, desc, fail_cnt, fail_lists, fail_cap);
+    const int d = L.d;
+    if (margin >= 0 && d >= 0 && d <= L.kcap) ed[slot_of ? slot_of[widx] : (long long)widx] = d;
+    else band_retry(pd, widx, m, n, d >= 0 ? d : pd.ub, desc, fail_cnt, fail_lists, fail_cap);
 }
 
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
@@ -1111,6 +1229,7 @@ __device__ __forceinline__ void d_edit_full(long long blk, long long count, cons
 #define KIND_LL 32
 struct FusedTab {
     int n;
+    int narrow;                            // band launches: the staircase windows narrow as they run (d_edit_stair)
     int kind[SEG_MAX];                     // class id (0..13)
     unsigned first_block[SEG_MAX + 1];
     long long lo[SEG_MAX], cn[SEG_MAX];    // range of the class in the sorted list
@@ -1128,12 +1247,7 @@ __global__ __launch_bounds__(256) void k_edit_bands(FusedTab tab, const uint32_t
         case 0: d_edit_band<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
         case 1: d_edit_band<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
         case 2: d_edit_band<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
-        case 3: d_edit_stair<6, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
-        case 4: d_edit_stair<8, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
-        case 5: d_edit_stair<10, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
-        case 6: d_edit_stair<12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
-        case 7: d_edit_stair<14, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
-        default: d_edit_stair<16, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
+                                                default: d_edit_stair<P>(band_words(tab.kind[s]), tab.narrow != 0, blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
     }
 }
 
@@ -1344,6 +1458,8 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         c->edit_guess_last = guess;
         if (profile) fprintf(stderr, "{\"edit_guess_pilot\": %.4f, \"sampled_pairs\": %lld}\n", guess, n_samp);
     }
+    int narrow_windows = 1;                                 // SVX_EDIT_NARROW=0: static staircase windows (A/B switch; results are the same either way)
+    if (const char* e = getenv("SVX_EDIT_NARROW")) narrow_windows = atoi(e) == 0 ? 0 : 1;
     long long few_pairs = 2048;                             // SVX_EDIT_FEW_PAIRS: calls with at most this many pairs take the low-latency route (0 = never)
     if (const char* e = getenv("SVX_EDIT_FEW_PAIRS")) few_pairs = atoll(e);
     k_edit_classify<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, desc, key_a, val_a, c->edit_force_full ? 1 : 0, guess, n_work <= few_pairs ? 1 : 0);
@@ -1447,6 +1563,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             const bool split = round == 0 && !serial && any_wide && any_narrow && !getenv("SVX_EDIT_NO_EARLY");
             for (int part = 0; part < (split ? 2 : 1); part++) {
                 FusedTab tb; memset(&tb, 0, sizeof tb);
+                tb.narrow = narrow_windows;
                 unsigned nblk = 0;
                 for (int cls = NBAND - 1; cls >= 0; cls--) {                          // widest band first
                     const long long cn = seg_cn[base + cls];

@@ -23,7 +23,10 @@
             else { _Pragma("unroll") for (int b = 1; b < P_; b++) e &= pl_[b][q0 + g] ^ nk_[b]; }               \
             eq_[g] = e;                                                                                         \
         }                                                                                                       \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) { xv_[g] = eq_[g] | mv_[q0 + g]; sum_[g] = eq_[g] & pv_[q0 + g]; } \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
+            xv_[g] = eq_[g] | mv_[q0 + g]; sum_[g] = eq_[g] & pv_[q0 + g];                                      \
+            asm("" : "+v"(xv_[g]));     /* opaque: keeps `phs & xv` a two-operand v_and (2 cycles) - the compiler would fold it into a three-operand v_bitop3 (4) */ \
+        }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
             unsigned carry_out;                                                                                 \

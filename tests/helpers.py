@@ -270,3 +270,16 @@ class ThreadAllGather(object):
 
     def abort(self):
         self.barrier.abort()
+
+
+def granted_cpus():
+    """CPUs this process may really use: the cgroup quota when there is one (the GPU boxes show 256 cores and grant 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))

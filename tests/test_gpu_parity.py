@@ -22,7 +22,7 @@ def eng():
 
 def test_cigar_indel_golden(eng):
     g = H.load("g1_cigar_indel.json.gz")
-    for c in g["cases"][:400]:
+    for c in g["cases"]:
         got = eng.cigar_indel([tuple(t) for t in c["tuples"]], c["min_length"])
         assert got == [tuple(x) for x in c["expect"]], c["tuples"]
 
@@ -631,6 +631,98 @@ def test_edit_distance_full_matrix_classes_vs_oracle(eng, oracle):
     assert got == exp
 
 
+_NARROW_CACHE = {}
+
+
+@pytest.mark.parametrize("guess", ["pilot", "0.03", "0.12", "0.3"])
+def test_edit_distance_narrowing_windows_vs_oracle(oracle, monkeypatch, guess):
+    """The staircase windows narrow while they run (d_edit_stair: Ukkonen cut-off per 32-column block, wave-uniform).  Pairs built to sit where a
+    wrong cut would show: the cheap alignment runs tens of diagonals away from the corridor for most of its length (a deletion near the start
+    paid back by an insertion near the end, either side), differences bunched at the start / at the end / in the middle, long clean stretches
+    (nothing may be cut there), noise as substitutions only and as indels, equal and unequal lengths; enough pairs that whole waves share a class,
+    and ragged lengths so that lanes of one wave finish in different blocks.  Every distance must be the oracle's, whatever the speculation."""
+    from svim_amd._lib import Engine
+    monkeypatch.delenv("SVX_EDIT_NARROW", raising=False)
+    monkeypatch.delenv("SVX_EDIT_FORCE_FULL", raising=False)
+    if guess == "pilot":
+        monkeypatch.delenv("SVX_EDIT_GUESS", raising=False)
+    else:
+        monkeypatch.setenv("SVX_EDIT_GUESS", guess)
+    monkeypatch.setenv("SVX_EDIT_FEW_PAIRS", "0")
+    rng = random.Random(29)
+
+    def noisy(s, rate, lo, hi, indels):
+        b = list(s)
+        k = int(rate * (hi - lo))
+        for _ in range(k):
+            p = rng.randrange(lo, max(lo + 1, min(hi, len(b))))
+            r = rng.random() if indels else 0.0
+            if r < 0.5:
+                b[p] = rng.choice("ACGT")
+            elif r < 0.75:
+                del b[p]
+            else:
+                b.insert(p, rng.choice("ACGT"))
+        return "".join(b)
+
+    pairs = []
+    for it in range(4600):
+        la = rng.choice((900, 1700, 2500, 3300, 4300, 5200)) + rng.randrange(0, 90)
+        a = synth.random_seq(rng, la)
+        kind = it % 8
+        rate = rng.choice((0.01, 0.03, 0.05, 0.08))
+        indels = rng.random() < 0.5
+        if kind == 0:                                   # uniform noise
+            b = noisy(a, rate, 0, la, indels)
+        elif kind == 1:                                 # all differences in the last fifth
+            b = noisy(a, 4 * rate, la - la // 5, la, indels)
+        elif kind == 2:                                 # all in the first fifth
+            b = noisy(a, 4 * rate, 0, la // 5, indels)
+        elif kind == 3:                                 # a block missing near the start, another one inserted near the end: the path runs off the corridor in between
+            k = rng.choice((10, 25, 45, 70))
+            b = noisy(a, rate * 0.5, 0, la, indels)
+            b = b[:30] + b[30 + k:]
+            b = b[:len(b) - 40] + synth.random_seq(rng, k) + b[len(b) - 40:]
+        elif kind == 4:                                 # the other side
+            k = rng.choice((10, 25, 45, 70))
+            b = noisy(a, rate * 0.5, 0, la, indels)
+            b = b[:30] + synth.random_seq(rng, k) + b[30:]
+            b = b[:len(b) - 40 - k] + b[len(b) - 40:]
+        elif kind == 5:                                 # clean halves around a noisy middle
+            b = noisy(a, 6 * rate, 2 * la // 5, 3 * la // 5, indels)
+        elif kind == 6:                                 # unequal lengths: the corridor itself is wide
+            b = noisy(a, rate, 0, la, indels) + synth.random_seq(rng, rng.choice((20, 60, 150)))
+        else:                                           # shifted copy (what insertion pairs at different positions look like)
+            k = rng.choice((5, 20, 40))
+            b = synth.random_seq(rng, k) + noisy(a, rate, 0, la, indels)[:la - k]
+        if rng.random() < 0.5:
+            a, b = b, a
+        pairs.append((a, b))
+    e = Engine()
+    try:
+        got = e.edit_distances(pairs)
+        st = e.stats()
+    finally:
+        e.close()
+    idx = range(len(pairs))
+    if "exp" not in _NARROW_CACHE:
+        _NARROW_CACHE["exp"] = {i: oracle.edit_distance(*pairs[i]) for i in idx}          # the pairs do not depend on the parameter
+    exp = _NARROW_CACHE["exp"]
+    bad = [(i, got[i], exp[i], len(pairs[i][0]), len(pairs[i][1]), i % 8) for i in idx if got[i] != exp[i]]
+    assert not bad, bad[:10]
+    assert st["n_edit_wordcols_band"] > 0
+    # the switch only changes the work, never a result
+    monkeypatch.setenv("SVX_EDIT_NARROW", "0")
+    e = Engine()
+    try:
+        wide = e.edit_distances(pairs)
+        st0 = e.stats()
+    finally:
+        e.close()
+    assert wide == got
+    assert st["n_edit_wordcols_band"] < st0["n_edit_wordcols_band"]          # narrowing did happen
+
+
 def test_edit_distance_routes_do_not_change_results(oracle, monkeypatch):
     """The band speculation (SVX_EDIT_GUESS pinned tiny / huge, or chosen by the per-call pilot from a sample of the call's own
     pairs) and the forced full-matrix route are performance choices only: every route must return the oracle's distances."""
@@ -658,8 +750,9 @@ def test_edit_distance_routes_do_not_change_results(oracle, monkeypatch):
         pairs.append((a, b))
     exp = [oracle.edit_distance(a, b) for a, b in pairs[:400]]
     results = []
-    for env in ({"SVX_EDIT_GUESS": "0.004"}, {"SVX_EDIT_GUESS": "0.45"}, {"SVX_EDIT_FORCE_FULL": "1"}, {}):
-        for k in ("SVX_EDIT_GUESS", "SVX_EDIT_FORCE_FULL"):
+    for env in ({"SVX_EDIT_GUESS": "0.004"}, {"SVX_EDIT_GUESS": "0.45"}, {"SVX_EDIT_FORCE_FULL": "1"}, {"SVX_EDIT_NARROW": "0"},
+                {"SVX_EDIT_NARROW": "0", "SVX_EDIT_GUESS": "0.2"}, {"SVX_EDIT_GUESS": "0.2"}, {}):
+        for k in ("SVX_EDIT_GUESS", "SVX_EDIT_FORCE_FULL", "SVX_EDIT_NARROW"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

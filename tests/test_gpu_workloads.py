@@ -84,10 +84,12 @@ def test_c1_ont_quarter_scale_vs_oracle(eng, oracle):
 
 
 @pytest.mark.skipif(os.environ.get("SVX_SKIP_SLOW") == "1", reason="SVX_SKIP_SLOW=1")
-def test_c1_full_bench_size_properties(eng):
-    """The configs[1] bench batch at FULL size (1 M reads, 1.5 G CIGAR operations) - too large for the oracle in a test, so the checks are the
-    size-independent properties of the path: ordering, membership and consolidation invariants of the reference's data model, determinism
-    (a second pass returns the same bits), and linearity of COLLECT (the file in two halves, accumulated in HBM, equals the file in one)."""
+def test_c1_full_bench_size_vs_oracle_and_properties(eng, oracle):
+    """The configs[1] bench batch at FULL size (1 M reads, 1.5 G CIGAR operations, the batch `bench.py` times): signature and cluster tables
+    bit-identical with the oracle's (its pair distances spread over the granted CPUs: oracle.set_threads, results independent of the thread
+    count - tests/test_oracle_golden.py), then the size-independent properties of the path: ordering, membership and consolidation invariants
+    of the reference's data model, determinism (a second pass returns the same bits), and linearity of COLLECT (the file in two halves,
+    accumulated in HBM, equals the file in one)."""
     import torch
     from svim_amd import devsynth
     o = _options()
@@ -100,6 +102,23 @@ def test_c1_full_bench_size_properties(eng):
     ct = eng.cluster(p, rank, source=0)
     st = eng.stats()
     assert sig.n > 600_000 and ct.n > 20_000 and st["n_large_partitions"] > 500
+    # ---- the oracle on the same records
+    import time
+    from helpers import granted_cpus
+    t0 = time.time()
+    oracle.set_threads(granted_cpus())
+    try:
+        oracle.set_genome(g_off.cpu().numpy().astype(np.int64), genome.cpu().numpy())
+        hb = batch.slice_records(0, batch.n_rec)
+        osig, obnd = oracle.collect(hb, p)
+        oct_ = oracle.cluster(p, hb.contig_rank, source=0)
+    finally:
+        oracle.set_threads(1)
+    print("oracle at bench size: %.1f s on %d threads; %d signatures, %d clusters" % (time.time() - t0, granted_cpus(), osig.n, oct_.n))
+    assert sig.first_difference(osig) is None
+    assert bnd.first_difference(obnd) is None
+    assert ct.first_difference(oct_, rtol=1e-12) is None
+    del hb, osig, obnd, oct_
     # ---- COLLECT: list order = emission order (slot, phase, ordinal), every row well-formed
     key = sig.key[:sig.n]
     assert np.all(key[1:] > key[:-1])

@@ -139,3 +139,28 @@ def test_c1_config0_full_size_end_to_end(oracle):
     oracle.set_genome(np.array([0, genome.shape[0]], dtype=np.int64), genome)
     ct = oracle.cluster(p, hb.contig_rank, source=0)
     H.compare_cluster_rows(H.cluster_rows(ct, ["chr1"]), g["clusters"])
+
+
+def test_threaded_pair_distances_do_not_change_the_oracle():
+    """svo_set_threads (used by the full-size GPU parity test so that the checker finishes in a minute): the pair distances of svo_cluster on
+    worker threads - the tables stay those of the single-threaded run AND of the reference (configs[0] golden, all of its partitions)."""
+    from oracle import oracle as om
+    from svim_amd import synth
+    g, refs, recs = H.c1_case()
+    bam = H.records.AlignmentFile(text=synth.sam_text(["chr1"], [2000000], recs))
+    o = H.options(g["options"])
+    hb = batch.build_batch(bam, o, mode="coordinate")
+    p = _abi.Params.from_options(o)
+    off, codes = convert.genome_arrays(refs, ["chr1"])
+    tables = []
+    for threads in (1, 5, 16):
+        oc = om.Oracle()
+        oc.set_threads(threads)
+        oc.set_genome(off, codes)
+        oc.collect(hb, p)
+        ct = oc.cluster(p, hb.contig_rank, source=0)
+        tables.append((ct, oc.stats()))
+    H.compare_cluster_rows(H.cluster_rows(tables[1][0], ["chr1"]), g["clusters"])
+    for ct, st in tables[1:]:
+        assert tables[0][0].first_difference(ct, rtol=0.0) is None
+        assert st["n_edit_pairs"] == tables[0][1]["n_edit_pairs"] and st["n_pairs"] == tables[0][1]["n_pairs"]
