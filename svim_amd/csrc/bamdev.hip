@@ -222,7 +222,9 @@ __global__ void k_measure(const uint8_t* st, const uint64_t* rec_off, long long 
     if (end - r < 32 || d.seq_at + ((uint64_t)l_seq + 1) / 2 + l_seq > end) { atomicExch(err, DD_E_CORRUPT); d.n_cig = 0; d.name_len = 0; }
     d.h1 = dd_fnv(st + r + 32, d.name_len, 0) | 1ull;                  // 0 marks an empty slot
     d.h2 = dd_fnv(st + r + 32, d.name_len, 0x9E3779B97F4A7C15ull);
-    const bool want_cg = ncf == 2u && (ld32(st, d.cig_at) & 15u) == 4u && (ld32(st, d.cig_at) >> 4) == l_seq && (ld32(st, d.cig_at + 4) & 15u) == 3u;
+    // htslib's bam_tag2cigar (what pysam hands the reference): a mapped record (tid, pos >= 0) whose FIRST operation is a soft clip of the whole read carries
+    // its real CIGAR in CG:B,I (or B,i) - whatever the rest of the placeholder looks like
+    const bool want_cg = ncf >= 1u && (int32_t)ld32(st, r) >= 0 && (int32_t)ld32(st, r + 4) >= 0 && d.n_cig == ncf && (ld32(st, d.cig_at) & 15u) == 4u && (ld32(st, d.cig_at) >> 4) == l_seq;
     const bool primary_ok = !(flag & (4u | 256u | 2048u)) && (int)mapq >= min_mapq;
     uint32_t segs = 0, ops = 0;
     if ((want_cg || primary_ok) && d.n_cig == ncf) {
@@ -248,7 +250,7 @@ __global__ void k_measure(const uint8_t* st, const uint64_t* rec_off, long long 
                 const uint32_t c = ld32(st, q + 1);
                 const uint64_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
                 sz = 5 + es * (uint64_t)c;
-                if (sz <= left && t0 == 'C' && t1 == 'G' && sub == 'I') { cg_at = q + 5; cg_n = c; have_cg = true; }
+                if (sz <= left && t0 == 'C' && t1 == 'G' && (sub == 'I' || sub == 'i') && c > 0u) { cg_at = q + 5; cg_n = c; have_cg = true; }
             } else { atomicExch(err, DD_E_AUX); break; }
             if (sz > left) { atomicExch(err, DD_E_AUX); break; }
             q += sz;
@@ -259,13 +261,13 @@ __global__ void k_measure(const uint8_t* st, const uint64_t* rec_off, long long 
             d.flags = 1u;
             uint64_t a = d.sa_at; const uint64_t e = d.sa_at + d.sa_len;
             while (a < e) {
-                uint64_t z = a; uint32_t commas = 0, o = 0; bool star = false;
+                uint64_t z = a; uint32_t commas = 0, o = 0, flen = 0; bool star = false;
                 for (; z < e && st[z] != ';'; z++) {
                     const uint8_t ch = st[z];
                     if (ch == ',') commas++;
-                    else if (commas == 3u) { if (ch == '*') star = true; else if (!dd_digit(ch)) o++; }
+                    else if (commas == 3u) { flen++; if (ch == '*') star = true; else if (!dd_digit(ch)) o++; }
                 }
-                if (z > a && commas == 5u) { segs++; ops += star ? 0u : o; }
+                if (z > a && commas == 5u) { segs++; ops += (star && flen == 1u) ? 0u : o + (star ? 1u : 0u); }      // "*" alone = no operations (k_fields: the same test); a '*' inside a CIGAR is a bad operation there
                 a = z + 1;
             }
         }

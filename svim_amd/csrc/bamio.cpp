@@ -725,6 +725,11 @@ static int append_sa(svx_bam* h, const char* sa, size_t len, int32_t primary_lse
     return SVX_OK;
 }
 
+// does the record's CIGAR field stand in for a real CIGAR kept in the CG tag?  (htslib sam.c bam_tag2cigar)
+static inline bool cg_placeholder(const uint8_t* rec, const uint8_t* cig, uint32_t n_cig, uint32_t l_seq) {
+    return n_cig >= 1 && (int32_t)rd32(rec) >= 0 && (int32_t)rd32(rec + 4) >= 0 && (rd32(cig) & 15) == 4 && (rd32(cig) >> 4) == l_seq;
+}
+
 // aux fields of one record: SA (Z) and CG (B,I)
 static void scan_aux(const uint8_t* q, const uint8_t* end, const char*& sa, size_t& sa_n, const uint8_t*& cg, uint32_t& cg_n) {
     sa = nullptr; sa_n = 0; cg = nullptr; cg_n = 0;
@@ -742,7 +747,7 @@ static void scan_aux(const uint8_t* q, const uint8_t* end, const char*& sa, size
                 const char sub = (char)q[0]; const uint32_t cnt = rd32(q + 1); const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
                 sz = 5 + es * (size_t)cnt;
                 if (sz > left) throw std::string("BAM aux array runs past the end of its record");
-                if (t0 == 'C' && t1 == 'G' && sub == 'I') { cg = q + 5; cg_n = cnt; } break; }
+                if (t0 == 'C' && t1 == 'G' && (sub == 'I' || sub == 'i') && cnt > 0) { cg = q + 5; cg_n = cnt; } break; }
             default: throw std::string("unknown BAM aux type");
         }
         if (sz > left) throw std::string("BAM aux field runs past the end of its record");
@@ -778,10 +783,11 @@ static int64_t decode_run(svx_bam* h, int64_t max_count, bool sparse) {
             const int32_t t = (int32_t)rd32(rr.r);
             if (t < 0 || t > h->tid_limit) { h->region_done = true; break; }
         }
-        // long CIGARs (> 65535 ops) live in CG:B,I behind a <l_seq>S<ref_len>N placeholder
-        if (rr.n_cig == 2 && (rd32(rr.cig) & 15) == 4 && (rd32(rr.cig) >> 4) == l_seq && (rd32(rr.cig + 4) & 15) == 3) {
+        // long CIGARs (> 65535 ops) live in CG:B,I behind a placeholder whose first operation clips the whole read - htslib's bam_tag2cigar rule: mapped
+        // record (tid, pos >= 0), first operation <l_seq>S, CG of type B,I / B,i with at least one word; the rest of the placeholder does not matter
+        if (cg_placeholder(rr.r, rr.cig, rr.n_cig, l_seq)) {
             const char* sa; size_t sa_n; const uint8_t* cg; uint32_t cg_n;
-            scan_aux(rr.cig + 8 + (l_seq + 1) / 2 + l_seq, rr.end, sa, sa_n, cg, cg_n);
+            scan_aux(rr.cig + 4 * (size_t)rr.n_cig + (l_seq + 1) / 2 + l_seq, rr.end, sa, sa_n, cg, cg_n);
             if (cg) { if (cg + 4 * (size_t)cg_n > rr.end) throw std::string("corrupt CG tag"); rr.cig = cg; rr.n_cig = cg_n; }
         }
         cig_total += rr.n_cig;
@@ -905,8 +911,7 @@ static int parse_record(svx_bam* h) {
     q += l_seq;
     const char* sa; size_t sa_n; const uint8_t* cg; uint32_t cg_n;
     scan_aux(q, end, sa, sa_n, cg, cg_n);
-    // long CIGARs (> 65535 ops) live in CG:B,I behind a <l_seq>S<ref_len>N placeholder
-    if (cg && n_cig == 2 && (rd32(cig) & 15) == 4 && (rd32(cig) >> 4) == l_seq && (rd32(cig + 4) & 15) == 3) { cig = cg; n_cig = cg_n; }
+    if (cg && cg_placeholder(r, cig, n_cig, l_seq)) { cig = cg; n_cig = cg_n; }          // long CIGARs (> 65535 ops): see decode_run
     const int32_t rid = h->names.intern(name.data(), name.size(), name_hash(name.data(), name.size()));
     h->b->flag.push_back((uint16_t)(flag & 0x0fff)); h->b->tid.push_back(tid); h->b->bpos.push_back(pos); h->b->mapq.push_back((uint8_t)mq);
     h->b->lseq.push_back((int32_t)l_seq); h->b->read_id.push_back(rid);

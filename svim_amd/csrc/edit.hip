@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_hap_pack(long long n_rec, PairSource sr
 // pairs in flight, not the symbols compared per step
 template <int G>
 __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource src, const uint32_t* packed, PairDesc* desc,
-                                                   uint64_t* sort_key, uint32_t* sort_val, int32_t* ed, unsigned long long* cells) {
+                                                   uint64_t* sort_key, uint32_t* sort_val, int32_t* ed, unsigned long long* cells, int shift_bounds) {
     const int wave_lane = lane_id();
     const int sg = wave_lane / G, lane = wave_lane % G;                   // sub-group of the wave / lane inside it
     const unsigned long long sg_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (sg * G);
@@ -374,34 +374,49 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
         if (lane == 0) { ed[src.slot(w)] = pd.n; pd.ub = pd.n; pd.cls = -1; desc[w] = pd; sort_key[w] = 0xffull << 32; sort_val[w] = (uint32_t)w; }
         return;
     }
-    // mismatches of the trivial left-justified alignment
+    // Upper bounds from trivial alignments: substitutions only, the pattern pushed `a` and the text `b` symbols to the right
+    //   cost = a + b + mismatches over the overlap + what is left of either core behind it.
+    // (0, 0) is the left-justified one.  Two insertions at DIFFERENT positions carry `shift` reference bases on opposite sides of their inserted
+    // sequences (PairSource::views): their inserted sequences line up at (0, shift) or (shift, 0), whichever core belongs to the earlier
+    // insertion - both are tried when (0, 0) is useless.  A bound is only worth its pass over the cores when it is SMALL: after the first 8 G
+    // symbols an alignment with more than 25 % mismatches is given up (three quarters of the positions of unrelated or misaligned sequences
+    // mismatch from the first symbols on).  A tight bound does two things: the pair starts in the narrowest band that certifies it, and the
+    // staircase window narrows against the bound instead of against the window's own capacity (d_edit_stair).
     const uint32_t* wp = packed + P.word_off; const uint32_t* wt = packed + T.word_off;
-    // The bound is only worth its pass over the cores when it is SMALL (aligned copies of one sequence).  Most pairs are shifted against
-    // each other or unrelated: three quarters of their positions mismatch from the first symbols on.  After the first 8 G symbols a pair
-    // with more than 25 % mismatches gives up on the bound (ub = n: substitute the shorter core, insert the rest) and skips the pass.
-    int ham_l = 0;
-    bool useless = false;
-    for (int base = 0; base < pd.m; base += 8 * G) {
-        const int i0 = base + lane * 8;
-        if (i0 < pd.m) {
-            const int v = pd.m - i0 >= 8 ? 8 : pd.m - i0;
-            const uint32_t vmask = v >= 8 ? 0xffffffffu : ((1u << (4 * v)) - 1u);
-            const uint32_t x = (fetch8(wp, p0 + i0) ^ fetch8(wt, t0 + i0)) & vmask;
-            ham_l += __popc((x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u);
-        }
-        if (base == 0 && pd.m > 8 * G) {
-            int first = ham_l;
+    auto bound_at = [&](const int a, const int b) -> int {                  // every lane of the sub-group returns the same value; m + n = useless
+        const int L = (pd.m - a) < (pd.n - b) ? (pd.m - a) : (pd.n - b);
+        if (L <= 0) return pd.m + pd.n;
+        int ham_l = 0;
+        bool useless = false;
+        for (int base = 0; base < L; base += 8 * G) {
+            const int i0 = base + lane * 8;
+            if (i0 < L) {
+                const int v = L - i0 >= 8 ? 8 : L - i0;
+                const uint32_t vmask = v >= 8 ? 0xffffffffu : ((1u << (4 * v)) - 1u);
+                const uint32_t x = (fetch8(wp, p0 + a + i0) ^ fetch8(wt, t0 + b + i0)) & vmask;
+                ham_l += __popc((x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u);
+            }
+            if (base == 0 && L > 8 * G) {
+                int first = ham_l;
 #pragma unroll
-            for (int o = G / 2; o >= 1; o >>= 1) first += __shfl_xor(first, o, 64);
-            if (first > 2 * G) { useless = true; break; }
+                for (int o = G / 2; o >= 1; o >>= 1) first += __shfl_xor(first, o, 64);
+                if (first > 2 * G) { useless = true; break; }
+            }
         }
+#pragma unroll
+        for (int o = G / 2; o >= 1; o >>= 1) ham_l += __shfl_xor(ham_l, o, 64);          // sum over the sub-group
+        if (useless) return pd.m + pd.n;
+        return a + b + ham_l + (pd.m - a - L) + (pd.n - b - L);
+    };
+    int ub = bound_at(0, 0);
+    if (ub > pd.n) ub = pd.n;                                               // substitute the shorter core, insert the rest
+    if (shift_bounds && shift > 0 && 4 * ub > pd.n) {           // (0, 0) says little: try the two shifted alignments
+        if (shift < pd.n) { const int u = bound_at(0, shift); ub = u < ub ? u : ub; }
+        if (shift < pd.m && 4 * ub > pd.n) { const int u = bound_at(shift, 0); ub = u < ub ? u : ub; }
     }
-#pragma unroll
-    for (int o = G / 2; o >= 1; o >>= 1) ham_l += __shfl_xor(ham_l, o, 64);          // sum over the sub-group
-    if (useless) ham_l = pd.m;
     const int zero = (A.flags | B.flags) & HAP_ZERO, other = (A.flags | B.flags) & HAP_OTHER;      // of the whole records: conservative
     if (lane == 0) {
-        pd.ub = ham_l + (pd.n - pd.m);
+        pd.ub = ub;
         pd.cls = (other ? CLS_GENERIC : 0) | (zero ? CLS_ZERO : 0) | sh_bits;       // the class itself: k_edit_classify
         desc[w] = pd;
         if (cells) atomicAdd(cells + (w & 1023), (unsigned long long)pd.m * (unsigned long long)pd.n);      // 1024 shards: no same-address pile-up
@@ -683,11 +698,11 @@ __device__ __forceinline__ void planes32(uint32_t w0, uint32_t w1, uint32_t w2, 
 // Either answer must hold for every pair of the wave that still has columns (one __all each): the number of live words Q is wave-uniform and
 // selects the unrolled column code.  A pair is answered iff its result is <= kcap - exactly the acceptance rule of the static window
 // (d <= delta + 2 margin + 1), so narrowing changes what is computed, never what is accepted.  SVX_EDIT_NARROW=0 keeps the window static.
-#define STAIR_QMAX 16
+#define STAIR_QMAX 16            /* widest class; a launch without the two widest classes runs the kernel built for 12 words (more waves per SIMD) */
 #define STAIR_QMIN 3
 
-template <int Q, int P, bool PRED>
-__device__ __forceinline__ void stair_columns8(uint32_t (&pv)[STAIR_QMAX], uint32_t (&mv)[STAIR_QMAX], uint32_t (&pl)[P][STAIR_QMAX], const uint32_t tword,
+template <int Q, int P, bool PRED, int QM>
+__device__ __forceinline__ void stair_columns8(uint32_t (&pv)[QM], uint32_t (&mv)[QM], uint32_t (&pl)[P][QM], const uint32_t tword,
                                                const int j0, const int n, int& top) {
     uint32_t tp[P];
     planes8<P>(tword, tp);                                          // bit k of tp[b]: plane b of the word's k-th symbol
@@ -719,8 +734,8 @@ struct StairLane {
 // Block kb (columns 32 kb + 1 .. 32 kb + 32) with Q live words, then the drop that prepares block kb + 1.  Returns the new Q.
 // The window state is moved for ALL lanes alike (a lane-dependent move would make the compiler keep whole copies of the register arrays):
 // a lane whose last column lies in this block takes its result here, before the drop.
-template <int Q, int P>
-__device__ __forceinline__ int stair_block(uint32_t (&pv)[STAIR_QMAX], uint32_t (&mv)[STAIR_QMAX], uint32_t (&pl)[P][STAIR_QMAX], uint32_t (&tq)[4],
+template <int Q, int P, int QM>
+__device__ __forceinline__ int stair_block(uint32_t (&pv)[QM], uint32_t (&mv)[QM], uint32_t (&pl)[P][QM], uint32_t (&tq)[4],
                                            const uint32_t (&pw_next)[4], StairLane& L, const int kb, const int nmin, const int nmax, const bool narrow,
                                            long long& issued) {
     const int n = L.n;
@@ -730,8 +745,8 @@ __device__ __forceinline__ int stair_block(uint32_t (&pv)[STAIR_QMAX], uint32_t 
         if (j0 >= nmax) break;
         const uint32_t tword = tq[0];
         tq[0] = tq[1]; tq[1] = tq[2]; tq[2] = tq[3];
-        if (j0 + 8 <= nmin) stair_columns8<Q, P, false>(pv, mv, pl, tword, j0, n, L.top);
-        else stair_columns8<Q, P, true>(pv, mv, pl, tword, j0, n, L.top);
+        if (j0 + 8 <= nmin) stair_columns8<Q, P, false, QM>(pv, mv, pl, tword, j0, n, L.top);
+        else stair_columns8<Q, P, true, QM>(pv, mv, pl, tword, j0, n, L.top);
     }
     {
         const int cols = nmax - kb * 32 >= 32 ? 32 : nmax - kb * 32;
@@ -812,13 +827,13 @@ struct StairRun {
 
 // The number of live words only ever decreases: the run is a cascade of plain loops, one per Q, each entered when the window has that many
 // words (a single loop around a switch over Q makes every register array a 14-way merge at its header).
-template <int Q, int P>
-__device__ __forceinline__ void stair_run(uint32_t (&pv)[STAIR_QMAX], uint32_t (&mv)[STAIR_QMAX], uint32_t (&pl)[P][STAIR_QMAX], uint32_t (&tq)[4],
+template <int Q, int P, int QM>
+__device__ __forceinline__ void stair_run(uint32_t (&pv)[QM], uint32_t (&mv)[QM], uint32_t (&pl)[P][QM], uint32_t (&tq)[4],
                                           uint32_t (&tw_next)[4], uint32_t (&pw_next)[4], StairLane& L, StairRun& R, const Packed& pat, const Packed& txt) {
     if (R.Q == Q && R.kb < R.n_blocks) {
 #pragma unroll 1
         do {
-            R.Q = stair_block<Q, P>(pv, mv, pl, tq, pw_next, L, R.kb, R.nmin, R.nmax, R.narrow, R.issued);
+            R.Q = stair_block<Q, P, QM>(pv, mv, pl, tq, pw_next, L, R.kb, R.nmin, R.nmax, R.narrow, R.issued);
             // text words of block kb + 1 (fetched a block ahead), then the fetches for block kb + 2 and for the pattern rows below the new window
             const int below = (L.trow + 32 * R.Q - 1) >> 3;
 #pragma unroll
@@ -832,10 +847,10 @@ __device__ __forceinline__ void stair_run(uint32_t (&pv)[STAIR_QMAX], uint32_t (
             R.kb++;
         } while (R.Q == Q && R.kb < R.n_blocks);
     }
-    if constexpr (Q > STAIR_QMIN) stair_run<Q - 1, P>(pv, mv, pl, tq, tw_next, pw_next, L, R, pat, txt);
+    if constexpr (Q > STAIR_QMIN) stair_run<Q - 1, P, QM>(pv, mv, pl, tq, tw_next, pw_next, L, R, pat, txt);
 }
 
-template <int P>
+template <int P, int QM>
 __device__ __forceinline__ void d_edit_stair(const int Q0, const bool narrow, long long blk, long long count, const uint32_t* list, const uint32_t* scratch,
                                              PairDesc* desc, const long long* slot_of, int32_t* ed, unsigned long long* fail_cnt, uint32_t* fail_lists,
                                              long long fail_cap, unsigned long long* wc) {
@@ -856,11 +871,11 @@ __device__ __forceinline__ void d_edit_stair(const int Q0, const bool narrow, lo
     const int pat_words = (m + 7) >> 3, txt_words = (n + 7) >> 3;
     const int w0 = -((off + 1) >> 3);                   // packed pattern word that holds bit 0 of the window (row -off)
     auto pat_word = [&](int idx) -> uint32_t { return (live && idx >= 0 && idx < pat_words) ? pat.word(idx) : 0u; };
-    // all STAIR_QMAX words are set up, whatever Q0 is (the words beyond Q0 are never looked at): a set-up that depends on Q0 would make every
+    // all QM words are set up, whatever Q0 is (the words beyond Q0 are never looked at): a set-up that depends on Q0 would make every
     // register array a union of its variants
-    uint32_t pv[STAIR_QMAX], mv[STAIR_QMAX], pl[P][STAIR_QMAX];
+    uint32_t pv[QM], mv[QM], pl[P][QM];
 #pragma unroll
-    for (int q = 0; q < STAIR_QMAX; q++) {
+    for (int q = 0; q < QM; q++) {
         const int nvirt = off + 1 - 32 * q;             // bits of this word that are rows <= 0: vertical delta -1
         const uint32_t mlow = nvirt >= 32 ? 0xffffffffu : (nvirt <= 0 ? 0u : ((1u << nvirt) - 1u));
         mv[q] = mlow; pv[q] = ~mlow;
@@ -895,7 +910,7 @@ __device__ __forceinline__ void d_edit_stair(const int Q0, const bool narrow, lo
     StairRun R;
     R.Q = Q0; R.kb = 0; R.n_blocks = (nmax + 31) >> 5; R.nmin = nmin; R.nmax = nmax; R.narrow = narrow; R.issued = 0;
     R.live = live; R.txt_words = txt_words; R.pat_words = pat_words;
-    stair_run<STAIR_QMAX, P>(pv, mv, pl, tq, tw_next, pw_next, L, R, pat, txt);
+    stair_run<QM, P, QM>(pv, mv, pl, tq, tw_next, pw_next, L, R, pat, txt);
     const long long issued = R.issued;
     wc_account(wc, issued, L.useful);
     if (!live) return;
@@ -1235,7 +1250,7 @@ struct FusedTab {
     long long lo[SEG_MAX], cn[SEG_MAX];    // range of the class in the sorted list
 };
 
-template <int P>
+template <int P, int QM>
 __global__ __launch_bounds__(256) void k_edit_bands(FusedTab tab, const uint32_t* list, const uint32_t* scratch, PairDesc* desc,
                                                     const long long* slot_of, int32_t* ed, unsigned long long* fail_cnt, uint32_t* fail_lists,
                                                     long long fail_cap, unsigned long long* wc) {
@@ -1247,7 +1262,7 @@ __global__ __launch_bounds__(256) void k_edit_bands(FusedTab tab, const uint32_t
         case 0: d_edit_band<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
         case 1: d_edit_band<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
         case 2: d_edit_band<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
-                                                default: d_edit_stair<P>(band_words(tab.kind[s]), tab.narrow != 0, blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
+                                                default: d_edit_stair<P, QM>(band_words(tab.kind[s]), tab.narrow != 0, blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
     }
 }
 
@@ -1439,8 +1454,10 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     uint32_t* scratch = c->e_scratch.as<uint32_t>();
     c->stats.n_hap_bytes += total_words * 4;
     // 2. trim + classify
+    int shift_bounds = 1;                                   // SVX_EDIT_SHIFT_BOUNDS=0: upper bounds from the left-justified alignment only (A/B switch)
+    if (const char* e = getenv("SVX_EDIT_SHIFT_BOUNDS")) shift_bounds = atoi(e) == 0 ? 0 : 1;
     k_slots<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, src, slot_of);
-    k_edit_prep<PREP_LANES><<<(unsigned)((n_work + 4 * (64 / PREP_LANES) - 1) / (4 * (64 / PREP_LANES))), 256, 0, st>>>(n_work, src, scratch, desc, key_a, val_a, ed_dev, cells_dev);
+    k_edit_prep<PREP_LANES><<<(unsigned)((n_work + 4 * (64 / PREP_LANES) - 1) / (4 * (64 / PREP_LANES))), 256, 0, st>>>(n_work, src, scratch, desc, key_a, val_a, ed_dev, cells_dev, shift_bounds);
     HIPCHK(hipGetLastError());
     const bool profile = getenv("SVX_EDIT_PROFILE") != nullptr, serial = getenv("SVX_EDIT_SERIAL") != nullptr;
     std::vector<PairDesc> first_desc;                       // SVX_EDIT_PROFILE: the descriptors as round 0 saw them (first class of every pair)
@@ -1554,7 +1571,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         // Round 0 launches its band classes in two parts, widest first: the pairs that fail the WIDEST bands are the long ones whose full matrices are
         // the serial tail of the next round, and they are known as soon as the first part is through - their full-matrix retries start right then,
         // beside the rest of the round (early_cn: what of every retry list has been launched already).
-        const int SPLIT_CLS = 6;
+        const int SPLIT_CLS = 7;                              // classes 7, 8 (14 / 16 words): the first part, and the only ones that need the 16-word kernel
         bool split_used[2] = {false, false};
         for (int generic = 0; generic <= 1; generic++) {
             const int base = GENERIC_BASE * generic;
@@ -1578,8 +1595,16 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                 if (serial) HIPCHK(hipEventRecord(c->ev[6], band_st[generic]));
                 // the first part (few, long pairs: latency) on a stream of its own, so that the second does not wait for it
                 hipStream_t bs = (split && part == 0) ? c->aux[5] : band_st[generic];
-                if (generic) k_edit_bands<4><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
-                else k_edit_bands<2><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
+                // the kernel built for 12 state words keeps more waves per SIMD: every launch without the two widest classes takes it
+                bool wide16 = false;
+                for (int k = 0; k < tb.n; k++) if (band_words(tb.kind[k]) > 12) wide16 = true;
+                if (generic) {
+                    if (wide16) k_edit_bands<4, 16><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
+                    else k_edit_bands<4, 12><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
+                } else {
+                    if (wide16) k_edit_bands<2, 16><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
+                    else k_edit_bands<2, 12><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
+                }
                 HIPCHK(hipGetLastError());
                 if (split && part == 0) { HIPCHK(hipEventRecord(c->ev[20 + generic], bs)); split_used[generic] = true; }
                 if (serial) {                                                        // SVX_EDIT_SERIAL=1: stand-alone kernel durations for profiling

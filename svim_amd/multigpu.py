@@ -197,14 +197,18 @@ class SvxAdapter(object):
     def begin_step(self, rank, world):
         """the engine finds its stream start positions inside svx_cluster, over this transport"""
         self.transport = TorchAllGather(world, self.device) if world > 1 else None
-        self._entered = False
+        self._at_exchange = False
         self.eng.set_ranks(rank, world, self.transport)
 
     def end_step(self):
         self.eng.set_ranks(0, 1, None)
 
     def abort(self):
-        if not self._entered:           # svx_cluster itself tells the others when it fails; after it nobody waits in the exchange any more
+        """Poison the rank exchange of svx_cluster - ONLY while every peer is known to be entering it: the phases of the step agree on a status
+        word before they go on (_agree), so a failure anywhere else is seen by all ranks in the same collective and nobody waits; the one window
+        left is between that agreement and svx_cluster itself (which reports its own failures through the exchange)."""
+        if self._at_exchange:
+            self._at_exchange = False
             self.eng.abort_ranks()
 
     def stream_end(self):
@@ -236,8 +240,9 @@ class SvxAdapter(object):
     def cluster(self, params, contig_rank, table=None):
         """table None: the resident COLLECT result (source 0); else (cols, seq_off, seq) device tensors (source 2)"""
         import torch
-        self._entered = True
+        self._at_exchange = True              # the caller has agreed with every rank that all of them call this now
         if table is None:
+            self._at_exchange = False
             self.eng.cluster(params, contig_rank, source=0, fetch=False)
             return
         cols, seq_off, seq = table
@@ -254,6 +259,7 @@ class SvxAdapter(object):
         keep += [so, sq]
         v.seq_off, v.seq = _abi.ptr(so), _abi.ptr(sq)
         torch.cuda.synchronize()              # the tensors were produced on torch's / RCCL's streams; libsvx runs on its own
+        self._at_exchange = False             # from here on svx_cluster tells the others itself when it fails
         self.eng.cluster(params, contig_rank, table=v, source=2, fetch=False)
         self._keep = keep
 
@@ -393,6 +399,40 @@ class StepResult(object):
         return out
 
 
+class RankFailed(RuntimeError):
+    """another rank failed in a phase of the step (its own exception is raised there)"""
+
+
+class _Phase(object):
+    """Local work of one phase of the step.  A failure is kept, the rank still takes part in the phase's count exchange (_agree) and all ranks raise
+    together right after it - a rank that simply stopped would leave the others waiting in their next collective."""
+
+    def __init__(self):
+        self.err = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if ev is not None and isinstance(ev, Exception):
+            self.err = ev
+            return True
+        return False
+
+
+def _agree(phase, values, dev, world):
+    """count exchange of a phase + one status word per rank"""
+    st = 0 if phase.err is None else 1
+    mine = [int(x) for x in values] + [st] if st == 0 else [0] * len(values) + [1]
+    got = _all_gather_counts(mine, dev) if world > 1 else [mine]
+    if phase.err is not None:
+        raise phase.err
+    bad = [r for r, c in enumerate(got) if c[-1]]
+    if bad:
+        raise RankFailed("rank(s) %s failed in this phase of the multi-GPU step" % bad)
+    return [c[:-1] for c in got]
+
+
 def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, owner_of_contig, key_base=0, read_base=0,
                  gather_signatures=True, names_of=None, ids_of=None, key_runs=None):
     """One multi-GPU CLUSTER step after this rank's COLLECT.
@@ -432,7 +472,7 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
         return _cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, owner_of_contig, gather_signatures, names_of, ids_of,
                              read_base, gid, owner_t, global_keys, dev)
     except BaseException:
-        adapter.abort()               # the other ranks must not wait for this one in the rank exchange of svx_cluster
+        adapter.abort()               # (only does something between the last agreement of the ranks and svx_cluster: see SvxAdapter.abort)
         raise
     finally:
         adapter.end_step()
@@ -442,122 +482,132 @@ def _cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, 
                   owner_t, global_keys, dev):
     import torch
     import torch.distributed as dist
-    n_own, _ = adapter.collect_counts()
     # ---- 1. foreign signatures --------------------------------------------------------------------------------------------
     cols = seq_off = seq = None
-    n_foreign = 0
-    if world > 1 and n_own:
-        cols, seq_off, seq = adapter.fetch_signatures(with_seq=False)        # the columns decide who owns a row; sequences only travel with foreign rows
-        own_c = owner_contig(cols["type"], gid[cols["contig"].long()], torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()], cols["contig2"].long()))
-        foreign = owner_t[own_c] != rank
-        n_foreign = int(foreign.sum().item())
-    counts = _all_gather_counts([n_foreign], dev) if world > 1 else [[0]]
+    n_foreign = n_own = 0
+    with _Phase() as ph:
+        n_own, _ = adapter.collect_counts()
+        if world > 1 and n_own:
+            cols, seq_off, seq = adapter.fetch_signatures(with_seq=False)        # the columns decide who owns a row; sequences only travel with foreign rows
+            own_c = owner_contig(cols["type"], gid[cols["contig"].long()], torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()], cols["contig2"].long()))
+            foreign = owner_t[own_c] != rank
+            n_foreign = int(foreign.sum().item())
+    counts = _agree(ph, [n_foreign], dev, world)
     any_foreign = any(c[0] for c in counts)
     local_rank_arr = np.asarray(contig_rank_global, dtype=np.int32)[np.asarray(contig_gid, dtype=np.int64)]
     if not any_foreign:
         # the common case: every signature stays where it was collected; cluster the resident table as it is (local contig ids)
         adapter.cluster(params, local_rank_arr, table=None)
         n_sig = n_own
-        if gather_signatures and cols is None and n_own:
-            cols, seq_off, seq = adapter.fetch_signatures(with_seq=False)
-        if cols is not None:
+        local_to_global_contig = gid
+    else:
+        # ---- 2a. what this rank sends (local work), agreed sizes, then the rows travel
+        fidx = f_cols = f_len = f_seq = lens = mine_names = None
+        n_send = f_bytes = 0
+        with _Phase() as ph:
+            if cols is None:
+                cols, seq_off, seq = adapter.fetch_signatures()
+                foreign = torch.zeros(0, dtype=torch.bool, device=dev)
+            else:
+                cols, seq_off, seq = adapter.fetch_signatures()                    # this time with the inserted bases (same rows, same order)
+            # globalise ids, split off the foreign rows, exchange them (with their inserted sequences), keep the rows this rank owns
             cols = dict(cols)
             cols["contig"] = gid[cols["contig"].long()].to(torch.int32)
             cols["contig2"] = torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()].to(torch.int32), cols["contig2"])
             cols["read_id"] = cols["read_id"] + read_base
             cols["key"] = global_keys(cols["key"])
-        local_to_global_contig = gid
-    else:
-        if cols is None:
-            cols, seq_off, seq = adapter.fetch_signatures()
-            foreign = torch.zeros(0, dtype=torch.bool, device=dev)
-        else:
-            cols, seq_off, seq = adapter.fetch_signatures()                    # this time with the inserted bases (same rows, same order)
-        # globalise ids, split off the foreign rows, exchange them (with their inserted sequences), keep the rows this rank owns
-        cols = dict(cols)
-        cols["contig"] = gid[cols["contig"].long()].to(torch.int32)
-        cols["contig2"] = torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()].to(torch.int32), cols["contig2"])
-        cols["read_id"] = cols["read_id"] + read_base
-        cols["key"] = global_keys(cols["key"])
-        lens = seq_off[1:] - seq_off[:-1]
-        fidx = torch.nonzero(foreign).flatten()
-        f_cols = {k: cols[k][fidx] for k in SIG_COLS}
-        f_len = lens[fidx]
+            lens = seq_off[1:] - seq_off[:-1]
+            fidx = torch.nonzero(foreign).flatten()
+            f_cols = {k: cols[k][fidx] for k in SIG_COLS}
+            f_len = lens[fidx]
+            if names_of is not None:
+                mine_names = list(names_of((f_cols["read_id"] - read_base).cpu().numpy()))
+            # inserted sequences of the foreign rows (rare: an INS between supplementary segments of another contig)
+            f_bytes = int(f_len.sum().item())
+            if f_bytes:
+                src = torch.repeat_interleave(seq_off[:-1][fidx] - (torch.cumsum(f_len, 0) - f_len), f_len) + torch.arange(f_bytes, device=dev)
+                f_seq = seq[src]
+            else:
+                f_seq = torch.zeros(0, dtype=torch.uint8, device=dev)
+            n_send = int(fidx.numel())
+        cnt2 = _agree(ph, [n_send, f_bytes], dev, world)
         g_names = None
         if names_of is not None:
-            mine_names = names_of((f_cols["read_id"] - read_base).cpu().numpy())
             g_names = [None] * world
-            dist.all_gather_object(g_names, list(mine_names))
-        # inserted sequences of the foreign rows (rare: an INS between supplementary segments of another contig)
-        f_bytes = int(f_len.sum().item())
-        if f_bytes:
-            src = torch.repeat_interleave(seq_off[:-1][fidx] - (torch.cumsum(f_len, 0) - f_len), f_len) + torch.arange(f_bytes, device=dev)
-            f_seq = seq[src]
-        else:
-            f_seq = torch.zeros(0, dtype=torch.uint8, device=dev)
-        cnt2 = _all_gather_counts([int(fidx.numel()), f_bytes], dev)
+            dist.all_gather_object(g_names, mine_names)
         rows = [c[0] for c in cnt2]
         g_cols = {k: _all_gather_rows(f_cols[k], rows) for k in SIG_COLS}
         g_len = _all_gather_rows(f_len, rows)
         g_seq = _all_gather_rows(f_seq, [c[1] for c in cnt2])
-        keep = ~foreign
-        parts_cols = {k: [cols[k][keep]] for k in SIG_COLS}
-        parts_len, parts_seq = [lens[keep]], []
-        kidx = torch.nonzero(keep).flatten()
-        k_bytes = int(lens[keep].sum().item())
-        if k_bytes:
-            kl = lens[kidx]
-            src = torch.repeat_interleave(seq_off[:-1][kidx] - (torch.cumsum(kl, 0) - kl), kl) + torch.arange(k_bytes, device=dev)
-            parts_seq.append(seq[src])
-        for r in range(world):
-            if r == rank or rows[r] == 0:
-                continue
-            oc = owner_contig(g_cols["type"][r], g_cols["contig"][r].long(), g_cols["contig2"][r].long())
-            take = owner_t[oc] == rank
-            if not bool(take.any()):
-                continue
-            tidx = torch.nonzero(take).flatten()
-            for k in SIG_COLS:
-                if k == "read_id" and g_names is not None:
-                    got = [g_names[r][int(i)] for i in tidx.tolist()]
-                    parts_cols[k].append(torch.as_tensor(np.asarray(ids_of(got), dtype=np.int32), device=dev) + read_base)
-                else:
-                    parts_cols[k].append(g_cols[k][r][tidx])
-            tl = g_len[r][tidx]
-            parts_len.append(tl)
-            tb = int(tl.sum().item())
-            if tb:
-                starts = torch.cumsum(g_len[r], 0) - g_len[r]
-                src = torch.repeat_interleave(starts[tidx] - (torch.cumsum(tl, 0) - tl), tl) + torch.arange(tb, device=dev)
-                parts_seq.append(g_seq[r][src])
-        cols = {k: torch.cat(v) for k, v in parts_cols.items()}
-        lens = torch.cat(parts_len)
-        seq = torch.cat(parts_seq) if parts_seq else torch.zeros(0, dtype=torch.uint8, device=dev)
-        # list order = emission order (the partition sort is stable with respect to it): sort by the global key
-        order = torch.sort(cols["key"], stable=True).indices
-        starts = torch.cumsum(lens, 0) - lens
-        cols = {k: v[order] for k, v in cols.items()}
-        ol = lens[order]
-        tot = int(ol.sum().item())
-        if tot:
-            src = torch.repeat_interleave(starts[order] - (torch.cumsum(ol, 0) - ol), ol) + torch.arange(tot, device=dev)
-            seq = seq[src]
-        seq_off = torch.zeros(ol.numel() + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(ol, 0, out=seq_off[1:])
-        n_sig = int(ol.numel())
+        # ---- 2b. this rank's table: its own rows + the rows it received (local work), then all ranks enter svx_cluster together
+        with _Phase() as ph:
+            keep = ~foreign
+            parts_cols = {k: [cols[k][keep]] for k in SIG_COLS}
+            parts_len, parts_seq = [lens[keep]], []
+            kidx = torch.nonzero(keep).flatten()
+            k_bytes = int(lens[keep].sum().item())
+            if k_bytes:
+                kl = lens[kidx]
+                src = torch.repeat_interleave(seq_off[:-1][kidx] - (torch.cumsum(kl, 0) - kl), kl) + torch.arange(k_bytes, device=dev)
+                parts_seq.append(seq[src])
+            for r in range(world):
+                if r == rank or rows[r] == 0:
+                    continue
+                oc = owner_contig(g_cols["type"][r], g_cols["contig"][r].long(), g_cols["contig2"][r].long())
+                take = owner_t[oc] == rank
+                if not bool(take.any()):
+                    continue
+                tidx = torch.nonzero(take).flatten()
+                for k in SIG_COLS:
+                    if k == "read_id" and g_names is not None:
+                        got = [g_names[r][int(i)] for i in tidx.tolist()]
+                        parts_cols[k].append(torch.as_tensor(np.asarray(ids_of(got), dtype=np.int32), device=dev) + read_base)
+                    else:
+                        parts_cols[k].append(g_cols[k][r][tidx])
+                tl = g_len[r][tidx]
+                parts_len.append(tl)
+                tb = int(tl.sum().item())
+                if tb:
+                    starts = torch.cumsum(g_len[r], 0) - g_len[r]
+                    src = torch.repeat_interleave(starts[tidx] - (torch.cumsum(tl, 0) - tl), tl) + torch.arange(tb, device=dev)
+                    parts_seq.append(g_seq[r][src])
+            cols = {k: torch.cat(v) for k, v in parts_cols.items()}
+            lens = torch.cat(parts_len)
+            seq = torch.cat(parts_seq) if parts_seq else torch.zeros(0, dtype=torch.uint8, device=dev)
+            # list order = emission order (the partition sort is stable with respect to it): sort by the global key
+            order = torch.sort(cols["key"], stable=True).indices
+            starts = torch.cumsum(lens, 0) - lens
+            cols = {k: v[order] for k, v in cols.items()}
+            ol = lens[order]
+            tot = int(ol.sum().item())
+            if tot:
+                src = torch.repeat_interleave(starts[order] - (torch.cumsum(ol, 0) - ol), ol) + torch.arange(tot, device=dev)
+                seq = seq[src]
+            seq_off = torch.zeros(ol.numel() + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(ol, 0, out=seq_off[1:])
+            n_sig = int(ol.numel())
+        _agree(ph, [], dev, world)
         adapter.cluster(params, np.asarray(contig_rank_global, dtype=np.int32), table=(cols, seq_off, seq))
         local_to_global_contig = None
     # ---- 3. final candidate gather to rank 0 ----------------------------------------------------------------------------
-    c_cols, members = adapter.fetch_clusters()
-    if local_to_global_contig is not None and int(c_cols["type"].numel()):
-        c_cols = dict(c_cols)
-        c_cols["contig"] = local_to_global_contig[c_cols["contig"].long()].to(torch.int32)
-        c_cols["contig2"] = torch.where(c_cols["contig2"] >= 0, local_to_global_contig[c_cols["contig2"].clamp_min(0).long()].to(torch.int32), c_cols["contig2"])
-    ncl, nmem = int(c_cols["type"].numel()), int(members.numel())
-    if world == 1:
-        allc = [[ncl, nmem, n_sig]]
-    else:
-        allc = _all_gather_counts([ncl, nmem, n_sig], dev)
+    ncl = nmem = 0
+    with _Phase() as ph:
+        if local_to_global_contig is not None:                                # the resident table was clustered: its columns, globalised for the gather
+            if gather_signatures and cols is None and n_own:
+                cols, seq_off, seq = adapter.fetch_signatures(with_seq=False)
+            if cols is not None:
+                cols = dict(cols)
+                cols["contig"] = gid[cols["contig"].long()].to(torch.int32)
+                cols["contig2"] = torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()].to(torch.int32), cols["contig2"])
+                cols["read_id"] = cols["read_id"] + read_base
+                cols["key"] = global_keys(cols["key"])
+        c_cols, members = adapter.fetch_clusters()
+        if local_to_global_contig is not None and int(c_cols["type"].numel()):
+            c_cols = dict(c_cols)
+            c_cols["contig"] = local_to_global_contig[c_cols["contig"].long()].to(torch.int32)
+            c_cols["contig2"] = torch.where(c_cols["contig2"] >= 0, local_to_global_contig[c_cols["contig2"].clamp_min(0).long()].to(torch.int32), c_cols["contig2"])
+        ncl, nmem = int(c_cols["type"].numel()), int(members.numel())
+    allc = _agree(ph, [ncl, nmem, n_sig], dev, world)
     sig_counts = [c[2] for c in allc]
     sig_base = int(sum(sig_counts[:rank]))
     members = members.to(torch.int64) + sig_base                           # indices into the rank-major gathered signature table

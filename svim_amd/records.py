@@ -454,7 +454,8 @@ class AlignmentFile(object):
             tags = {}
             _decode_bam_aux(data, q, end, tags)
             # long CIGARs (> 65535 ops) live in the CG:B,I tag with a placeholder kSmN CIGAR
-            if "CG" in tags and n_cigar == 2 and a._cigar[0] == (4, l_seq) and a._cigar[1][0] == 3:
+            # (htslib's bam_tag2cigar rule: a mapped record whose first operation soft-clips the whole read; CG of type B,I or B,i)
+            if "CG" in tags and tags.get("__B_CG") in ("I", "i") and len(tags["CG"]) > 0 and n_cigar >= 1 and a._cigar[0] == (4, l_seq) and tid >= 0 and pos >= 0:
                 a._cigar = [(c & 0xF, c >> 4) for c in tags.pop("CG")]
                 tags.pop("__B_CG", None)
             a._tags = {k: v for k, v in tags.items() if not k.startswith("__B_")}

@@ -283,3 +283,21 @@ def granted_cpus():
     except (OSError, ValueError):
         pass
     return max(1, min(n, 64))
+
+
+def concat_batch_rows(batches):
+    """record-level view of record batches (dicts of arrays in the svx_batch layout) that does not depend on how the records were cut into
+    batches: (flag, tid, pos, mapq, l_seq, CIGAR bytes, packed bases, segment rows) per record"""
+    rows = []
+    for A in batches:
+        n = len(A["flag"])
+        co, so, sg, sc = A["cigar_off"].astype(np.int64), A["seq_off"].astype(np.int64), A["seg_off"].astype(np.int64), A["seg_cigar_off"].astype(np.int64)
+        for i in range(n):
+            nbytes = (int(A["lseq"][i]) + 1) // 2
+            segs = []
+            for r in range(int(sg[i]), int(sg[i + 1])):
+                segs.append((int(A["seg_tid"][r]), int(A["seg_pos"][r]), int(A["seg_rev"][r]), int(A["seg_mapq"][r]), int(A["seg_lseq"][r]),
+                             A["seg_cigar"][sc[r]:sc[r + 1]].tobytes()))
+            rows.append((int(A["flag"][i]), int(A["tid"][i]), int(A["pos"][i]), int(A["mapq"][i]), int(A["lseq"][i]), A["cigar"][co[i]:co[i + 1]].tobytes(),
+                         A["seq"][so[i]:so[i] + nbytes].tobytes(), tuple(segs)))
+    return rows

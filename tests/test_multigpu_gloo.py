@@ -314,3 +314,72 @@ def test_eight_ranks_five_of_them_empty():
     assert sum(1 for r in range(8) if ret["owned%d" % r] > 0) == 3
     ends = [ret["chain%d" % r] for r in range(8)]
     assert ends == sorted(ends) and ends[-1] > 1500
+
+
+def _worker_failing_rank(rank, world, port, ret, where):
+    """One rank fails in the local work of a phase (the adapter's fetch raises): every rank must leave cluster_step with an exception -
+    the failing one with its own, the others with RankFailed - instead of waiting in a collective the failed rank never enters."""
+    _setup(rank, world, port)
+    try:
+        import helpers as H
+        from oracle import oracle as om
+        from svim_amd import _abi, batch, convert, multigpu
+        g5 = H.load("g5_cluster.json.gz")
+        case = [c for c in g5["cases"] if c["name"] == "stress31"][0]
+        o = H.options(case["options"])
+        sigs = [H.row_sig(r) for r in case["signatures"]]
+        tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(g5["references"]))
+        orc = om.Oracle()
+        off, codes = convert.genome_arrays(o.genome, contigs.names)
+        orc.set_genome(off, codes)
+        p = _abi.Params.from_options(o)
+        crank = batch.contig_ranks(contigs.names)
+        owner = multigpu.assign_contigs(contigs.names, g5["lengths"], world)
+        n = tab.n
+        other = np.where(tab.type[:n] == _abi.SVX_DUP_INT, tab.contig[:n], np.where(tab.contig2[:n] >= 0, tab.contig2[:n], tab.contig[:n]))
+        idx = np.nonzero(owner[other] == rank)[0]
+        local = _abi.SigTable(len(idx), int((tab.seq_off[idx + 1] - tab.seq_off[idx]).sum()))
+        for k in _abi.SIG_DTYPES:
+            getattr(local, k)[:] = getattr(tab, k)[idx]
+        ln = tab.seq_off[idx + 1] - tab.seq_off[idx]
+        local.seq_off[1:] = np.cumsum(ln)
+        pos = 0
+        for i, l in zip(idx, ln):
+            local.seq[pos:pos + l] = tab.seq[tab.seq_off[i]:tab.seq_off[i] + l]
+            pos += int(l)
+
+        class Failing(multigpu.HostAdapter):
+            calls = 0
+
+            def fetch_signatures(self, with_seq=True):
+                Failing.calls += 1
+                if rank == 1 and where == "fetch%d" % Failing.calls:
+                    raise ValueError("planted failure on rank 1")
+                return multigpu.HostAdapter.fetch_signatures(self, with_seq)
+
+            def fetch_clusters(self):
+                if rank == 1 and where == "clusters":
+                    raise ValueError("planted failure on rank 1")
+                return multigpu.HostAdapter.fetch_clusters(self)
+        try:
+            multigpu.cluster_step(Failing(orc, local), p, rank, world, np.arange(len(contigs.names)), crank, owner)
+            ret[rank] = "returned"
+        except ValueError as e:
+            ret[rank] = "own: %s" % e
+        except multigpu.RankFailed as e:
+            ret[rank] = "peer"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_takes_every_rank_out_of_the_step():
+    import pytest
+    for where in ("fetch1", "clusters"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(_worker_failing_rank, args=(3, port, ret, where), nprocs=3, join=True)
+        ret = dict(ret)
+        assert ret[1].startswith("own:") and ret[0] == "peer" and ret[2] == "peer", (where, ret)
