@@ -29,7 +29,14 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
     {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        for (int k = 0; k < SVX_N_AUX; k++) HIPCHK(hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, (k < 2 || k == 5) ? greatest : least));
+        // SVX_EDIT_PRIO: which kind of edit-distance launch gets the high-priority streams - "band" (default), "full", "equal" (A/B switch)
+        const char* pe = getenv("SVX_EDIT_PRIO");
+        const int mode = pe && !strcmp(pe, "full") ? 1 : (pe && !strcmp(pe, "equal") ? 2 : 0);
+        for (int k = 0; k < SVX_N_AUX; k++) {
+            const bool band_stream = k < 2 || k == 5;
+            const int prio = mode == 2 ? least : ((band_stream == (mode == 0)) ? greatest : least);
+            HIPCHK(hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, prio));
+        }
     }
     { void* hp = nullptr; HIPCHK(hipHostMalloc(&hp, 4096, hipHostMallocDefault)); c->pinned = (int64_t*)hp; }
     memset(&c->stats, 0, sizeof c->stats);

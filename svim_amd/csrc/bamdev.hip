@@ -439,6 +439,7 @@ __global__ void k_widen_u32(long long n, const uint32_t* in, uint64_t* out) {
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
 struct DevChunk {
     DevBuf stream; size_t data_begin = 0, data_end = 0, tail_start = 0;            // offsets into stream
+    uint64_t seq_end_host = 0;
     DevBuf blk_off, anchor, cnt, exit_at, base, rec_off, desc, n_cig, n_seg, n_segop, scan_tmp, crc_jobs;
     std::vector<CrcJob> crc_host;          // (alive until the chunk is loaded again: its upload is asynchronous)
     DevBuf flag, tid, pos, mapq, lseq, read_id, cigar_off, cigar, seq_off, seg_off, segop_off, seg_tid, seg_pos, seg_rev, seg_mapq, seg_lseq, seg_cigar_off, seg_cigar;
@@ -832,7 +833,8 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
                                            c.tid.as<int32_t>(), c.pos.as<int32_t>(), c.mapq.as<uint8_t>(), c.lseq.as<int32_t>(), c.seq_off.as<uint64_t>(), c.seg_tid.as<int32_t>(),
                                            c.seg_pos.as<int32_t>(), c.seg_rev.as<uint8_t>(), c.seg_mapq.as<uint8_t>(), c.seg_lseq.as<int32_t>(), c.seg_cigar_off.as<uint64_t>(),
                                            c.seg_cigar.as<uint32_t>(), d->err.as<int>(), d->counters.as<unsigned long long>() + 4);
-    { const uint64_t se = c.data_end; HIPCHK(hipMemcpyAsync(c.seq_off.as<uint64_t>() + n, &se, 8, hipMemcpyHostToDevice, st)); }
+    c.seq_end_host = c.data_end;                                            // (the source of an asynchronous copy must outlive it: a member, not a local)
+    HIPCHK(hipMemcpyAsync(c.seq_off.as<uint64_t>() + n, &c.seq_end_host, 8, hipMemcpyHostToDevice, st));
     k_cigar_copy<<<GRIDB(n, 4), 256, 0, st>>>(sp, n, c.desc.as<RecDesc>(), c.cigar_off.as<uint64_t>(), c.cigar.as<uint32_t>());
     HIPCHK(hipGetLastError());
     d->stats.t_decode += dd_now() - t0; t0 = dd_now();

@@ -141,6 +141,7 @@ struct PairSource {
     // compute_haplotype_edit_distance (src/svim/SVIM_clustering.py:32-45): window = min/max start -+ 100
     // shift = |start_a - start_b|: the haplotype of the later insertion carries that many reference bases in FRONT of its inserted
     // sequence which the other one carries BEHIND it, i.e. the alignment leaves the main diagonal by `shift` whatever the sequences are
+    // shift > 0: A is the earlier insertion (A's inserted sequence lines up with B's `shift` symbols further right in B), < 0: B is
     __device__ __forceinline__ void views(long long w, HapView& A, HapView& B, int& shift) const {
         shift = 0;
         if (plain) {
@@ -151,7 +152,7 @@ struct PairSource {
             const EditWork wk = work[w];
             const long long s1 = in.start[wk.a], s2 = in.start[wk.b];
             const long long ws = (s1 < s2 ? s1 : s2) - 100, we = (s1 > s2 ? s1 : s2) + 100;
-            shift = (int)(s1 < s2 ? s2 - s1 : s1 - s2);
+            shift = (int)(s2 - s1);
             const int c1 = in.contig[wk.a], c2 = in.contig[wk.b];
             const long long l1 = g_off[c1 + 1] - g_off[c1], l2 = g_off[c2 + 1] - g_off[c2];
             const HapRec ra = rec[wk.a], rb = rec[wk.b];
@@ -329,8 +330,9 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     const long long w = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + sg;
     if (w >= n_work) return;
     HapView A, B;
-    int shift;
-    src.views(w, A, B, shift);
+    int sshift;
+    src.views(w, A, B, sshift);
+    const int shift = sshift < 0 ? -sshift : sshift;
     const uint32_t* wa = packed + A.word_off; const uint32_t* wb = packed + B.word_off;
     const int la = A.len, lb = B.len;
     const int mn = la < lb ? la : lb;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     //   cost = a + b + mismatches over the overlap + what is left of either core behind it.
     // (0, 0) is the left-justified one.  Two insertions at DIFFERENT positions carry `shift` reference bases on opposite sides of their inserted
     // sequences (PairSource::views): their inserted sequences line up at (0, shift) or (shift, 0), whichever core belongs to the earlier
-    // insertion - both are tried when (0, 0) is useless.  A bound is only worth its pass over the cores when it is SMALL: after the first 8 G
+    // insertion - tried first for such a pair, (0, 0) only when that says little.  A bound is only worth its pass over the cores when it is SMALL: after the first 8 G
     // symbols an alignment with more than 25 % mismatches is given up (three quarters of the positions of unrelated or misaligned sequences
     // mismatch from the first symbols on).  A tight bound does two things: the pair starts in the narrowest band that certifies it, and the
     // staircase window narrows against the bound instead of against the window's own capacity (d_edit_stair).
@@ -408,12 +410,12 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
         if (useless) return pd.m + pd.n;
         return a + b + ham_l + (pd.m - a - L) + (pd.n - b - L);
     };
-    int ub = bound_at(0, 0);
-    if (ub > pd.n) ub = pd.n;                                               // substitute the shorter core, insert the rest
-    if (shift_bounds && shift > 0 && 4 * ub > pd.n) {           // (0, 0) says little: try the two shifted alignments
-        if (shift < pd.n) { const int u = bound_at(0, shift); ub = u < ub ? u : ub; }
-        if (shift < pd.m && 4 * ub > pd.n) { const int u = bound_at(shift, 0); ub = u < ub ? u : ub; }
-    }
+    // the core of the EARLIER insertion is the one whose inserted sequence comes first: its symbols line up with the other core's `shift` further right
+    const bool pat_earlier = (sshift > 0) == a_short;
+    int ub = pd.n;                                                          // substitute the shorter core, insert the rest
+    if (shift_bounds && shift > 0 && shift < (pat_earlier ? pd.n : pd.m)) ub = pat_earlier ? bound_at(0, shift) : bound_at(shift, 0);
+    if (ub > pd.n) ub = pd.n;
+    if (4 * ub > pd.n) { const int u = bound_at(0, 0); ub = u < ub ? u : ub; }         // (also the only one tried for insertions at the same position)
     const int zero = (A.flags | B.flags) & HAP_ZERO, other = (A.flags | B.flags) & HAP_OTHER;      // of the whole records: conservative
     if (lane == 0) {
         pd.ub = ub;
@@ -707,11 +709,13 @@ __device__ __forceinline__ void stair_columns8(uint32_t (&pv)[QM], uint32_t (&mv
     uint32_t tp[P];
     planes8<P>(tword, tp);                                          // bit k of tp[b]: plane b of the word's k-th symbol
 #pragma unroll
+    for (int b = 0; b < P; b++) tp[b] = ~tp[b];
+#pragma unroll
     for (int k = 0; k < 8; k++) {
         if (!PRED || j0 + k + 1 <= n) {
             uint32_t nk[P];
 #pragma unroll
-            for (int b = 0; b < P; b++) nk[b] = ((tp[b] >> k) & 1u) - 1u;
+            for (int b = 0; b < P; b++) nk[b] = (uint32_t)__builtin_amdgcn_sbfe((int)tp[b], k, 1);      // bit set -> 0, clear -> all ones: one v_bfe_i32
             top += 1;
             unsigned carry = 0;
             uint32_t ph_prev = 0x80000000u, mh_prev = 0u;          // the row above the window steps +1

@@ -262,6 +262,145 @@ def write_bam_from_batch(path, hb, references, lengths, name_fmt="r%08d", thread
     return n, len(raw)
 
 
+def write_bam_from_device_batch(path, batch, references, lengths, lo=0, hi=None, name_prefix="r", name_digits=8, threads=None, qual_seed=None,
+                                slab_bytes=384 << 20, level=1, index=False):
+    """The same file write_bam_from_batch makes (fixed fields, CIGAR, SEQ, QUAL 0xff or - with qual_seed - random Phred values, SA tags from the
+    segment rows), for records [lo, hi) of a DeviceBatch whose arrays live on the GPU: the uncompressed stream is put together THERE slab by slab
+    (ragged gathers over torch tensors), compressed by the host's threads, and written as it comes - a million records (27 GB of stream) need neither
+    a per-record Python loop nor the whole stream in host memory.  index: also <path>.bai (records.write_bai).  Bench / test infrastructure.
+    Returns (n_records, uncompressed bytes)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    t = batch.t
+    dev = t["cigar"].device
+    hi = batch.n_rec if hi is None else hi
+    n = hi - lo
+    i64 = torch.int64
+    cig_off = t["cigar_off"][lo:hi + 1].to(i64)
+    seq_off = t["seq_off"][lo:hi + 1].to(i64)
+    lseq = t["lseq"][lo:hi].to(i64)
+    n_cig = cig_off[1:] - cig_off[:-1]
+    if n and int(n_cig.max().item()) > 65535:
+        raise ValueError("write_bam_from_device_batch: CIGARs beyond 65535 operations need the CG tag (svim_amd.records.write_bam handles them)")
+    # SA strings of the records that own segment rows (host loop over those records only)
+    seg_off = t["seg_off"][lo:hi + 1].cpu().numpy().astype(np.int64)
+    owners = np.nonzero(seg_off[1:] > seg_off[:-1])[0]
+    sa_len = np.zeros(n, dtype=np.int64)
+    sa_parts = []
+    if owners.size:
+        s0, s1 = int(seg_off[0]), int(seg_off[-1])
+        st, sp, sr, sm = (t[k][s0:s1].cpu().numpy() for k in ("seg_tid", "seg_pos", "seg_rev", "seg_mapq"))
+        sco = t["seg_cigar_off"][s0:s1 + 1].cpu().numpy().astype(np.int64)
+        scg = t["seg_cigar"][int(sco[0]):int(sco[-1])].cpu().numpy()
+        sco = sco - sco[0]
+        for i in owners.tolist():
+            parts = []
+            for r in range(int(seg_off[i]) - s0, int(seg_off[i + 1]) - s0):
+                words = scg[int(sco[r]):int(sco[r + 1])]
+                cg = "".join("%d%s" % (int(w) >> 4, _CIG[int(w) & 15]) for w in words)
+                parts.append("%s,%d,%s,%s,%d,0" % (references[int(st[r])], int(sp[r]) + 1, "-" if sr[r] else "+", cg, int(sm[r])))
+            b = ("SAZ" + ";".join(parts) + ";").encode("ascii") + b"\0"
+            sa_parts.append(b)
+            sa_len[i] = len(b)
+    sa_blob = torch.frombuffer(bytearray(b"".join(sa_parts) or b"\0"), dtype=torch.uint8).to(dev)
+    sa_len_t = torch.as_tensor(sa_len, device=dev)
+    sa_src = torch.cumsum(sa_len_t, 0) - sa_len_t
+    name_len = len(name_prefix) + name_digits + 1
+    nb = (lseq + 1) // 2
+    rec_len = 32 + name_len + 4 * n_cig + nb + lseq + sa_len_t
+    head_text = ("@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (r, l) for r, l in zip(references, lengths))).encode()
+    head = b"BAM\1" + len(head_text).to_bytes(4, "little") + head_text + len(references).to_bytes(4, "little")
+    for r, l in zip(references, lengths):
+        nm = r.encode() + b"\0"
+        head += len(nm).to_bytes(4, "little") + nm + int(l).to_bytes(4, "little")
+    cig_bytes = t["cigar"].view(torch.uint8)
+    seq_bytes = t["seq"]
+    flag = t["flag"][lo:hi].to(i64) & 0x0fff
+    gen = None
+    if qual_seed is not None:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(int(qual_seed))
+    prefix = torch.tensor(list(name_prefix.encode()), dtype=torch.uint8, device=dev)
+    pow10 = torch.tensor([10 ** k for k in range(name_digits - 1, -1, -1)], dtype=i64, device=dev)
+
+    def ragged(dst, dst_start, src, src_start, lens):
+        tot = int(lens.sum().item())
+        if tot == 0:
+            return
+        rep = torch.repeat_interleave(torch.arange(lens.numel(), device=dev), lens)
+        within = torch.arange(tot, device=dev) - (torch.cumsum(lens, 0) - lens)[rep]
+        dst[dst_start[rep] + within] = src[src_start[rep] + within]
+
+    # slabs of about slab_bytes of stream
+    rl_host = (rec_len + 4).cpu().numpy()
+    bounds = [0]
+    acc = 0
+    for i, l in enumerate(rl_host.tolist()):
+        acc += l
+        if acc >= slab_bytes:
+            bounds.append(i + 1)
+            acc = 0
+    if bounds[-1] != n:
+        bounds.append(n)
+    step = 65280
+    total_raw = len(head)
+    pending = head
+    pool = ThreadPoolExecutor(max_workers=threads or effective_cpus())
+    block_at = []                                                         # file offset of every BGZF block (for the index)
+    with open(path, "wb") as fh:
+        def flush(data, final):
+            k = len(data) if final else (len(data) // step) * step
+            chunks = [data[i:i + step] for i in range(0, k, step)]
+            for b in pool.map(lambda c: _bgzf_block(c, level), chunks):
+                block_at.append(fh.tell())
+                fh.write(b)
+            return data[k:]
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            m = b - a
+            rl = rec_len[a:b]
+            off = torch.cumsum(rl + 4, 0) - (rl + 4)
+            tot = int((rl + 4).sum().item())
+            if gen is None:
+                buf = torch.full((tot,), 0xff, dtype=torch.uint8, device=dev)
+            else:
+                buf = torch.normal(18.0, 8.0, (tot,), generator=gen, device=dev).round_().clamp_(1, 50).to(torch.uint8)
+            core = torch.zeros((m, 9), dtype=torch.int32, device=dev)
+            core[:, 0] = rl.to(torch.int32)
+            core[:, 1] = t["tid"][lo + a:lo + b]
+            core[:, 2] = t["pos"][lo + a:lo + b]
+            core[:, 3] = (name_len | (t["mapq"][lo + a:lo + b].to(i64) << 8) | (4680 << 16)).to(torch.int32)
+            core[:, 4] = (n_cig[a:b] | (flag[a:b] << 16)).to(torch.int32)
+            core[:, 5] = lseq[a:b].to(torch.int32)
+            core[:, 6] = -1
+            core[:, 7] = -1
+            ar36 = torch.arange(36, device=dev)
+            buf[(off[:, None] + ar36[None, :]).reshape(-1)] = core.view(torch.uint8).reshape(-1)
+            ids = t["read_id"][lo + a:lo + b].to(i64)
+            digits = ((ids[:, None] // pow10[None, :]) % 10 + 48).to(torch.uint8)
+            names = torch.cat([prefix[None, :].expand(m, -1), digits, torch.zeros((m, 1), dtype=torch.uint8, device=dev)], dim=1)
+            buf[((off + 36)[:, None] + torch.arange(name_len, device=dev)[None, :]).reshape(-1)] = names.reshape(-1)
+            at = off + 36 + name_len
+            ragged(buf, at, cig_bytes, 4 * cig_off[a:b], 4 * n_cig[a:b])
+            at = at + 4 * n_cig[a:b]
+            ragged(buf, at, seq_bytes, seq_off[a:b], nb[a:b])
+            at = at + nb[a:b] + lseq[a:b]
+            ragged(buf, at, sa_blob, sa_src[a:b], sa_len_t[a:b])
+            data = pending + buf.cpu().numpy().tobytes()
+            total_raw += tot
+            del buf
+            pending = flush(data, False)
+        flush(pending, True)
+        block_at.append(fh.tell())
+        fh.write(_bgzf_block(b""))                                        # EOF marker block
+    pool.shutdown()
+    if index:
+        from .records import write_bai
+        starts = len(head) + np.concatenate([[0], np.cumsum(rl_host)[:-1]]) if n else np.zeros(0, dtype=np.int64)
+        tids = t["tid"][lo:hi].cpu().numpy()
+        write_bai(path + ".bai", len(references), list(zip(tids.tolist(), starts.tolist())), total_raw, block_at, step)
+    return n, total_raw
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # measurements
 # ---------------------------------------------------------------------------------------------------------------------

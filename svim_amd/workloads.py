@@ -6,6 +6,9 @@
                     CIGAR DEL/INS plus split reads that make the reference emit DEL, INS (sequence taken from the primary:
                     the edlib path), INV, DUP_TAN, BND (other contig and > max_sv_size) and DUP_INT
                     (src/svim/SVIM_inter.py:58-300)
+    c3  configs[3]  whole-genome ONT profile: 47 contigs with hg38's names and length ratios (header order chr1..chr22, X, Y, M, then alt / random /
+                    unplaced scaffolds and HLA alleles - their str order, which the reference sorts partitions by, interleaves them), every SV type,
+                    split reads across contigs: what a contig-sharded multi-GPU run sees (tests: 8 ranks over one file, tests/mp_c3_ranks_one_gpu.py)
     c4  configs[4]  60x PacBio-CLR profile: shorter, noisier reads and DENSE sites, so that --partition_max_distance in
                     {1000, 5000, 20000, 100000} produces many partitions beyond 100 and beyond 1045 signatures
                     (random.sample pool / set paths, src/svim/SVIM_clustering.py:132-134)
@@ -44,6 +47,20 @@ PROFILES = {
     "c4": dict(contigs=(("chr1", 40_000_000),), reads_per_mb=5000, length="lognormal", n50=14000, m_lo=3, m_hi=14, ind_hi=3,
                sites_per_mb=650, size_lo=50, size_hi=2500, site_mix=(0.47, 0.47, 0.03, 0.0, 0.0, 0.03, 0.0, 0.0, 0.0), ins_err=0.08,
                max_sites_per_read=16, lowq=0.03),
+    # configs[3] stand-in: a whole genome's worth of contigs in header order chr1..chr22, X, Y, M followed by alt / random / unplaced scaffolds (hg38 names
+    # and length RATIOS; the str order of the names - the reference's partition key - interleaves them: chr1, chr10, chr11, .., chr1_KI270706v1_random,
+    # chr2, ..), ONT-like reads, every split-read layout: BND and DUP_INT rows cross contigs, i.e. ranks
+    "c3": dict(contigs=tuple([("chr%s" % n, l) for n, l in zip(list(range(1, 23)) + ["X", "Y", "M"],
+                              (248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
+                               133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468,
+                               156040895, 57227415, 16569))] +
+                             [(n, 1) for n in ("chr1_KI270706v1_random", "chr1_KI270707v1_random", "chr2_KI270715v1_random", "chr4_GL000008v2_random",
+                                               "chr9_KI270717v1_random", "chr11_KI270721v1_random", "chr14_GL000009v2_random", "chr14_GL000194v1_random",
+                                               "chr17_GL000205v2_random", "chr22_KI270731v1_random", "chrUn_KI270302v1", "chrUn_GL000195v1", "chrUn_KI270442v1",
+                                               "chrUn_GL000214v1", "chrUn_KI270744v1", "chrEBV", "chr1_KI270762v1_alt", "chr6_GL000250v2_alt",
+                                               "chr17_KI270857v1_alt", "chr19_KI270938v1_alt", "HLA-A*01:01:01:01", "HLA-DRB1*15:03:01:01")]),
+               reads_per_mb=1500, length="lognormal", n50=20000, m_lo=5, m_hi=30, ind_hi=3, sites_per_mb=120, size_lo=50, size_hi=5000,
+               site_mix=(0.33, 0.33, 0.08, 0.05, 0.05, 0.04, 0.06, 0.02, 0.04), ins_err=0.03, max_sites_per_read=6, lowq=0.03),
 }
 # site_mix: fractions of (CIGAR DEL, CIGAR INS, INV, split DEL, split INS, DUP_TAN, BND contig, BND far, DUP_INT)
 _SITE_KIND = (0, 0, 1, 2, 3, 4, 5, 6, 7)          # split-read layout a site of that class produces (0 = carried in the CIGAR)

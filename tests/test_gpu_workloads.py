@@ -176,3 +176,28 @@ def test_c1_full_bench_size_vs_oracle_and_properties(eng, oracle):
         eng.accumulate(False)
     assert sig3.first_difference(sig) is None
     assert ct3.first_difference(ct, rtol=0.0) is None
+
+
+@pytest.mark.parametrize("world", [8, 3])
+def test_c3_whole_genome_contig_sharded_ranks_on_one_gpu(tmp_path, world):
+    """BASELINE.json configs[3] (8 GPUs, whole genome, contig-sharded) as far as ONE GPU allows: `world` processes share cuda:0 over gloo, each reads its
+    own contig runs of one indexed 47-contig BAM with the device-resident reader, collects, clusters (svx_cluster's rank exchange over the process group)
+    and rank 0 gathers; the merged tables must be those of a single-rank run over the whole file AND of the oracle, read names included
+    (tests/mp_c3_ranks_one_gpu.py).  No scaling claim: one GPU is shared."""
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(repo, "tests", "mp_c3_ranks_one_gpu.py"), str(tmp_path / "wg.bam"), "0.003", "3"],
+                         capture_output=True, text=True, timeout=1500, cwd=repo)
+    assert out.returncode == 0, out.stderr[-3000:]
+    ok = [l for l in out.stdout.splitlines() if l.startswith("C3_RANKS_")]
+    assert ok and ok[0].startswith("C3_RANKS_OK"), (out.stdout[-2000:], out.stderr[-2000:])
+    _, n_clusters, n_cross, n_owners, dev_reader = ok[0].split()
+    assert int(n_clusters) > 500 and int(n_cross) > 50 and int(n_owners) == world and int(dev_reader) == 1
+    regions = [int(x) for x in [l for l in out.stdout.splitlines() if l.startswith("C3_REGIONS")][0].split()[1:]]
+    assert len(regions) == world and sum(regions) > world            # several ranks read more than one contig run of the file

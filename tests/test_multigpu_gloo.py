@@ -383,3 +383,32 @@ def test_a_failing_rank_takes_every_rank_out_of_the_step():
         mp.spawn(_worker_failing_rank, args=(3, port, ret, where), nprocs=3, join=True)
         ret = dict(ret)
         assert ret[1].startswith("own:") and ret[0] == "peer" and ret[2] == "peer", (where, ret)
+
+
+def test_eight_ranks_whole_genome_like_bam(tmp_path):
+    """configs[3] on CPU: the 47-contig whole-genome profile (svim_amd/workloads.py c3: header order chr1..chr22, X, Y, M, scaffolds, HLA alleles - the name
+    order interleaves them, so every rank reads SEVERAL non-adjacent regions of the file through the .bai) written by the device-side BAM writer with its
+    index, eight ranks, the oracle as engine: merged result = single process, read names resolved on rank 0."""
+    import torch
+    sys.path.insert(0, os.path.dirname(HERE))
+    from svim_amd import harness, synth, workloads
+    prof = workloads.profile("c3", 0.001)
+    prof["reads_per_mb"], prof["sites_per_mb"] = 260, 60
+    b, genome, g_off, meta = workloads.make_batch_full(prof, seed=7, device="cpu")
+    refs = [c[0] for c in prof["contigs"]]
+    lens = [int(x) for x in (g_off[1:] - g_off[:-1]).tolist()]
+    bam_path, fa = str(tmp_path / "wg.bam"), str(tmp_path / "wg.fa")
+    n, _ = harness.write_bam_from_device_batch(bam_path, b, refs, lens, index=True, slab_bytes=8 << 20, threads=4)
+    assert n == b.n_rec and os.path.exists(bam_path + ".bai")
+    code = "=ACMGRSVTWYHKDBN"
+    g = genome.numpy()
+    synth.write_fasta(fa, {r: "".join(code[c] for c in g[int(g_off[i]):int(g_off[i + 1])].tolist()) for i, r in enumerate(refs)})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_bam, args=(8, port, ret, bam_path, fa), nprocs=8, join=True)
+    ret = dict(ret)
+    assert [ret[r] for r in range(8)] == ["ok"] * 8, ret
+    assert sum(ret["regions%d" % r] for r in range(8)) >= 20          # the name order cuts the header order into many runs
