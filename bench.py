@@ -39,7 +39,25 @@ def options(pmd=1000):
                                  edit_distance_normalizer=1.0, cluster_max_distance=0.5, all_bnds=False)
 
 
-def cpu_baseline(batch, g_off, genome, params, eng=None, budget_s=20.0):
+def reference_python_figure():
+    """what the reference ITSELF (pure Python, src/svim/SVIM_COLLECT.py + SVIM_CLUSTER.py) needed for configs[0] at its stated size, recorded when
+    tests/golden/make_golden.py ran it in the build container (the reference cannot travel to the GPU box): reads/s over COLLECT + CLUSTER"""
+    try:
+        import gzip
+        with gzip.open(os.path.join(REPO, "tests", "golden", "g_c1_full.json.gz"), "rt") as fh:
+            g = json.load(fh)
+        t = g.get("reference_seconds") or {}
+        tc, tk = float(t.get("collect", 0)), float(t.get("cluster", 0))
+        if tc + tk <= 0:
+            return None
+        return {"reads_per_s": g["n_records"] / (tc + tk), "records": g["n_records"], "collect_s": tc, "cluster_s": tk,
+                "workload": "configs[0] at its stated size (10 000 records, 250 Mb contig, triangular(100, 20000, 15000) read lengths, DEL/INS only), CPython 3.10, "
+                            "1 core of the BUILD container, pysam / edlib stubbed (tests/golden/make_golden.py)"}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def cpu_baseline(batch, g_off, genome, params, eng=None, budget_s=20.0, parity_records=100_000):
     """The oracle (single-threaded C restatement of the reference algorithm, kind 'port') on a bounded, contiguous
     slice of the same batch (contiguous in coordinate order = full local coverage, so per-partition work is
     representative)."""
@@ -64,12 +82,25 @@ def cpu_baseline(batch, g_off, genome, params, eng=None, budget_s=20.0):
     t = best["t_collect"] + best["t_cluster"]
     parity = None
     if eng is not None:
-        # the same slice through the HIP path (host batch this time): the bench line carries its own parity evidence
+        # the bench line carries its own parity evidence: a slice of >= 100 k records through the HIP path (host batch this time) and through the oracle -
+        # the oracle's pair distances on every granted CPU here (svo_set_threads: the checker, not the timed baseline above, which stays on ONE core)
+        npar = min(batch.n_rec, max(parity_records, best["n_rec"]))
+        hb = batch.slice_records(0, npar)
+        t0 = time.perf_counter()
+        orc.set_threads(_granted_cpus())
+        try:
+            sig, _ = orc.collect(hb, params)
+            ct = orc.cluster(params, hb.contig_rank, source=0)
+        finally:
+            orc.set_threads(1)
+        t_or = time.perf_counter() - t0
         gs, _ = eng.collect(hb, params)
         gc = eng.cluster(params, hb.contig_rank, source=0)
-        parity = {"records": best["n_rec"], "signatures_identical": gs.first_difference(sig) is None,
-                  "clusters_identical": gc.first_difference(ct, rtol=1e-12) is None}
+        parity = {"records": npar, "signatures": int(sig.n), "clusters": int(ct.n), "signatures_identical": gs.first_difference(sig) is None,
+                  "clusters_identical": gc.first_difference(ct, rtol=1e-12) is None, "oracle_seconds_on_%d_threads" % _granted_cpus(): t_or}
+    ref_py = reference_python_figure()
     return {"parity_vs_gpu_on_sample": parity, "value": best["used"] / t, "unit": "reads/s", "cores": 1, "kind": "port",
+            "reference_python_reads_per_s": ref_py["reads_per_s"] if ref_py else None, "reference_python": ref_py,
             "what": "oracle/svx_oracle.c: single-threaded C restatement of the reference's algorithm (a STRONGER baseline than the "
                     "reference's Python loops: tests/golden/g_c1.json.gz records 1.99 s + 4.75 s of reference Python for 10 k records; "
                     "the reference itself cannot travel to the GPU box)",
@@ -114,6 +145,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--end-to-end-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--e2e-records-qual", type=int, default=300_000, help="end_to_end: records of the sample BAM with base qualities (the headline file)")
+    ap.add_argument("--e2e-records", type=int, default=180_000, help="end_to_end: records of the sample BAM without qualities (side figure)")
+    ap.add_argument("--e2e-chunk-mb", type=int, default=2048, help="end_to_end: inflated MB per chunk of the device reader on the headline file")
     ap.add_argument("--resident", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -146,7 +180,8 @@ def main():
         from svim_amd import devsynth, harness
         batch, genome, meta = devsynth.make_batch(n_reads=args.reads, n50=args.n50, contig_len=args.contig_len, n_sites=args.sites, seed=2, device=dev)
         g_off = torch.tensor([0, genome.numel()], dtype=torch.int64, device=dev)
-        emit(harness.end_to_end_sample(batch, g_off, genome, options(1000), device=local_rank, resident_reads_per_s=args.resident))
+        emit(harness.end_to_end_sample(batch, g_off, genome, options(1000), device=local_rank, resident_reads_per_s=args.resident, n_records=args.e2e_records,
+                                       n_records_qual=args.e2e_records_qual, chunk_mb=args.e2e_chunk_mb))
         return
     dist = None
     # SVX_BENCH_FORCE_DIST=1 exercises the multi-GPU code path (RCCL exchange + sharded clustering) with any world size
@@ -355,6 +390,9 @@ def main():
     out = {
         "metric": "aligned reads/sec through COLLECT+CLUSTER", "value": reads_per_s, "unit": "reads/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "scaling_note": "--gpus N is WEAK scaling: every rank generates its own batch of the same shape on its own contigs (seed = 2 + rank for c1, 3 + rank for "
+                        "c2 / c4), so value = N x per-rank records / max-over-ranks time and only rank 0's batch is the N=1 batch; the ranks meet in the rank "
+                        "exchange of svx_cluster and in the final gather (no hardware curve has been measured by the builder: one GPU per box)",
         "vs_baseline": None, "dtype": "u32/i32 CIGAR + u8 bases, int64 positions, f64 distances", "data": "synthetic",
         "config": cfg,
         "signatures_per_s": tot_sig * args.steps / elapsed,
@@ -382,7 +420,8 @@ def main():
         import subprocess
         try:
             cmd = [sys.executable, os.path.abspath(__file__), "--end-to-end-child", "--reads", str(args.reads), "--n50", str(args.n50),
-                   "--contig-len", str(args.contig_len), "--resident", repr(reads_per_s)] + (["--sites", str(args.sites)] if args.sites else [])
+                   "--contig-len", str(args.contig_len), "--resident", repr(reads_per_s), "--e2e-records", str(args.e2e_records), "--e2e-records-qual", str(args.e2e_records_qual),
+                   "--e2e-chunk-mb", str(args.e2e_chunk_mb)] + (["--sites", str(args.sites)] if args.sites else [])
             child = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
             lines = [l for l in child.stdout.splitlines() if l.startswith("{")]
             out["end_to_end"] = json.loads(lines[-1]) if child.returncode == 0 and lines else {"error": "exit %d: %s" % (child.returncode, child.stderr[-400:])}

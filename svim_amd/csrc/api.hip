@@ -29,9 +29,11 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
     {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        // SVX_EDIT_PRIO: which kind of edit-distance launch gets the high-priority streams - "band" (default), "full", "equal" (A/B switch)
+        // Which kind of edit-distance launch gets the high-priority streams.  The full-matrix launches hold the longest serial chains (a pair of 5000 x 5000
+        // symbols is 5000 dependent steps whatever the width) and, since the band windows narrow, most of the work: they go first, the band launches fill in
+        // (configs[1]: 16.9 ms against 17.9 the other way round, profiles/r04_edit_prio_ab.txt).  SVX_EDIT_PRIO=band / equal: A/B switch.
         const char* pe = getenv("SVX_EDIT_PRIO");
-        const int mode = pe && !strcmp(pe, "full") ? 1 : (pe && !strcmp(pe, "equal") ? 2 : 0);
+        const int mode = pe && !strcmp(pe, "band") ? 0 : (pe && !strcmp(pe, "equal") ? 2 : 1);
         for (int k = 0; k < SVX_N_AUX; k++) {
             const bool band_stream = k < 2 || k == 5;
             const int prio = mode == 2 ? least : ((band_stream == (mode == 0)) ? greatest : least);

@@ -436,6 +436,88 @@ __global__ void k_widen_u32(long long n, const uint32_t* in, uint64_t* out) {
     if (i < n) out[i] = in[i];
 }
 
+// ---- query-name-sorted input (src/svim/SVIM_COLLECT.py:8-41 bam_iterator, :96-129 analyze_alignment_file_querysorted; bamio.cpp svx_bam_read_batch mode 1) ----
+// Consecutive records with one read name are a group.  A group is analysed iff it holds exactly ONE record that is neither secondary nor supplementary and that
+// one is mapped with mapq >= min_mapq (:108); its good supplementary records (mapped, mapq >= min_mapq, :112) are analysed too, and THEY - not the SA tag - are the
+// segment rows of the primary.  Everything else carries SVX_FLAG_SKIP.  Emission slots per analysed read: primary, good supplementaries.., segments (:114-121).
+// Groups are small (a handful of records), so nothing here walks a group: group index and ranks inside a group come from scans over the batch.
+// first record index of the last group in [0, n) (the group the chunk may end in the middle of)
+__global__ void k_q_last_group(long long n, const int32_t* read_id, unsigned long long* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (i == 0 || read_id[i] != read_id[i - 1])) atomicMax(out, (unsigned long long)i);
+}
+// first group boundary at or behind `from` (n when the records from `from` on are one group with the record before)
+__global__ void k_q_next_boundary(long long from, long long n, const int32_t* read_id, unsigned long long* out) {
+    const long long i = from + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && i > 0 && read_id[i] != read_id[i - 1]) atomicMin(out, (unsigned long long)i);
+}
+// per record of the batch: group head?  good supplementary?  (0 / 1 as u32 for the scans)
+__global__ void k_q_marks(long long n, const uint16_t* flag, const uint8_t* mapq, const int32_t* read_id, int min_mapq, uint32_t* head, uint32_t* good) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { head[i] = 0u; good[i] = 0u; return; }
+    const unsigned f = flag[i];
+    head[i] = (i == 0 || read_id[i] != read_id[i - 1]) ? 1u : 0u;
+    good[i] = (!(f & 256u) && (f & 2048u) && !(f & 4u) && (int)mapq[i] >= min_mapq) ? 1u : 0u;
+}
+// group g starts at record gs[g]; primaries counted per group, the (last) primary's index kept
+__global__ void k_q_groups(long long n, const uint32_t* head, const uint32_t* gidx_ex, const uint16_t* flag, uint32_t* gs, uint32_t* n_prim, uint32_t* p_idx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = gidx_ex[i] + head[i] - 1u;                  // exclusive scan of head + own head - 1 = index of the record's group
+    if (head[i]) gs[g] = (uint32_t)i;
+    const unsigned f = flag[i];
+    if (!(f & 256u) && !(f & 2048u)) { atomicAdd(n_prim + g, 1u); atomicMax(p_idx + g, (uint32_t)i); }
+}
+// per group: analysed?  its slots and segment rows
+__global__ void k_q_verdict(long long n_groups, long long n, const uint32_t* gs, const uint32_t* n_prim, const uint32_t* p_idx, const uint16_t* flag, const uint8_t* mapq,
+                            int min_mapq, const uint32_t* good_ex, uint32_t* slots, uint32_t* rows) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_groups) return;
+    if (g == n_groups) { slots[g] = 0u; rows[g] = 0u; return; }
+    const uint32_t a = gs[g], b = g + 1 < n_groups ? gs[g + 1] : (uint32_t)n;
+    bool ok = n_prim[g] == 1u;
+    if (ok) { const uint32_t p = p_idx[g]; ok = !(flag[p] & 4u) && (int)mapq[p] >= min_mapq; }
+    const uint32_t n_good = ok ? good_ex[b] - good_ex[a] : 0u;
+    slots[g] = ok ? n_good + 2u : 0u;
+    rows[g] = n_good;
+}
+// per record: flag with SVX_FLAG_SKIP, emission slots, segment offsets; a good supplementary of an analysed read also fills its segment row
+__global__ void k_q_records(long long n, long long n_groups, const uint32_t* head, const uint32_t* gidx_ex, const uint32_t* gs, const uint32_t* p_idx, const uint32_t* good,
+                            const uint32_t* good_ex, const uint32_t* slots, const uint32_t* slot_ex, const uint32_t* row_ex, const uint16_t* flag, const int32_t* tid,
+                            const int32_t* pos, const uint8_t* mapq, const int32_t* lseq, const uint64_t* cigar_off, uint16_t* flag_out, uint32_t* order, uint32_t* seg_order,
+                            uint32_t* seg_off, int32_t* seg_tid, int32_t* seg_pos, uint8_t* seg_rev, uint8_t* seg_mapq, int32_t* seg_lseq, uint32_t* row_rec, uint32_t* row_ops) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { seg_off[i] = row_ex[n_groups]; return; }
+    const uint32_t g = gidx_ex[i] + head[i] - 1u;
+    const bool ok = slots[g] != 0u;
+    const uint32_t n_good = ok ? slots[g] - 2u : 0u;
+    const uint32_t p = p_idx[g];
+    uint16_t f = (uint16_t)((flag[i] & 0x0fffu) | SVX_FLAG_SKIP);
+    uint32_t o = 0u, so = 0u;
+    seg_off[i] = row_ex[g] + ((ok && (uint32_t)i > p) ? n_good : 0u);         // the rows belong to the primary: records behind it start past them
+    if (ok) {
+        if ((uint32_t)i == p) { f &= (uint16_t)~SVX_FLAG_SKIP; o = slot_ex[g]; so = slot_ex[g] + 1u + n_good; }
+        else if (good[i]) {
+            const uint32_t q = good_ex[i] - good_ex[gs[g]];
+            f &= (uint16_t)~SVX_FLAG_SKIP; o = slot_ex[g] + 1u + q;
+            const uint32_t r = row_ex[g] + q;
+            seg_tid[r] = tid[i]; seg_pos[r] = pos[i]; seg_rev[r] = (flag[i] & 16u) ? 1 : 0; seg_mapq[r] = mapq[i]; seg_lseq[r] = lseq[i];
+            row_rec[r] = (uint32_t)i; row_ops[r] = (uint32_t)(cigar_off[i + 1] - cigar_off[i]);
+        }
+    }
+    flag_out[i] = f; order[i] = o; seg_order[i] = so;
+}
+// CIGAR words of the segment rows: one wave per row
+__global__ __launch_bounds__(256) void k_q_seg_cigar(long long n_rows, const uint32_t* row_rec, const uint64_t* cigar_off, const uint32_t* cigar, const uint64_t* seg_cigar_off,
+                                                     uint32_t* seg_cigar) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const uint64_t src = cigar_off[row_rec[r]], dst = seg_cigar_off[r], cnt = seg_cigar_off[r + 1] - dst;
+    for (uint64_t k = threadIdx.x & 63; k < cnt; k += 64) seg_cigar[dst + k] = cigar[src + k];
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
 struct DevChunk {
     DevBuf stream; size_t data_begin = 0, data_end = 0, tail_start = 0;            // offsets into stream
@@ -445,12 +527,18 @@ struct DevChunk {
     DevBuf flag, tid, pos, mapq, lseq, read_id, cigar_off, cigar, seq_off, seg_off, segop_off, seg_tid, seg_pos, seg_rev, seg_mapq, seg_lseq, seg_cigar_off, seg_cigar;
     DevBuf slot_of, new_rec, name_len, name_at, name_blob;
     DevBuf order[2], seg_order[2]; int order_flip = 0;
+    // query-name mode: per handed-out batch (two alternating sets like order[]) the flags with SVX_FLAG_SKIP, the segment table made of the good supplementary records
+    DevBuf q_flag[2], q_seg_off[2], q_seg_tid[2], q_seg_pos[2], q_seg_rev[2], q_seg_mapq[2], q_seg_lseq[2], q_seg_cigar_off[2], q_seg_cigar[2];
+    DevBuf q_head, q_good, q_gidx, q_good_ex, q_gs, q_nprim, q_pidx, q_slots, q_rows, q_slot_ex, q_row_ex, q_row_rec, q_row_ops;
     int64_t n_rec = 0, tot_seg = 0, tot_ops = 0, tot_segops = 0;
     bool loaded = false;
     void release() {
         DevBuf* all[] = {&stream, &blk_off, &anchor, &cnt, &exit_at, &base, &rec_off, &desc, &n_cig, &n_seg, &n_segop, &scan_tmp, &crc_jobs, &flag, &tid, &pos, &mapq, &lseq, &read_id,
                          &cigar_off, &cigar, &seq_off, &seg_off, &segop_off, &seg_tid, &seg_pos, &seg_rev, &seg_mapq, &seg_lseq, &seg_cigar_off, &seg_cigar, &slot_of,
-                         &new_rec, &name_len, &name_at, &name_blob, &order[0], &order[1], &seg_order[0], &seg_order[1]};
+                         &new_rec, &name_len, &name_at, &name_blob, &order[0], &order[1], &seg_order[0], &seg_order[1],
+                         &q_flag[0], &q_flag[1], &q_seg_off[0], &q_seg_off[1], &q_seg_tid[0], &q_seg_tid[1], &q_seg_pos[0], &q_seg_pos[1], &q_seg_rev[0], &q_seg_rev[1],
+                         &q_seg_mapq[0], &q_seg_mapq[1], &q_seg_lseq[0], &q_seg_lseq[1], &q_seg_cigar_off[0], &q_seg_cigar_off[1], &q_seg_cigar[0], &q_seg_cigar[1],
+                         &q_head, &q_good, &q_gidx, &q_good_ex, &q_gs, &q_nprim, &q_pidx, &q_slots, &q_rows, &q_slot_ex, &q_row_ex, &q_row_rec, &q_row_ops};
         for (auto* b : all) b->release();
     }
 };
@@ -571,7 +659,8 @@ static int dd_check(svx_devdec* d, const char* where) {
 
 #define GRIDB(n, t) (unsigned)(((n) + (t) - 1) / (t))
 
-int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in, int carry_slot, uint64_t skip_bytes, bool final_chunk, int min_mapq) {
+int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in, int carry_slot, uint64_t skip_bytes, bool final_chunk, int min_mapq, int mode) {
+    if (mode == 1) min_mapq = 1000;            // query-name mode: the segment rows of a read are its supplementary RECORDS (devdec_batch), no SA tag is expanded
     if (!d || slot < 0 || slot > 2) return svx_fail(SVX_E_ARG, "bad slot", __FILE__, __LINE__, hipSuccess);
     HIPCHK(hipSetDevice(d->device));
     hipStream_t st = d->stream;
@@ -881,6 +970,18 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
         }
     }
     d->stats.t_names += dd_now() - t0;
+    if (mode == 1 && !final_chunk) {
+        // query-name mode: the chunk may end in the middle of a read's group - the last group goes to the next chunk whole (carried over like a partial record)
+        unsigned long long* lg = d->counters.as<unsigned long long>() + 16;
+        HIPCHK(hipMemsetAsync(lg, 0, 8, st));
+        k_q_last_group<<<GRIDB(n, 256), 256, 0, st>>>(n, c.read_id.as<int32_t>(), lg);
+        HIPCHK(hipMemcpyAsync(&d->h_cnt[16], lg, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const long long L = (long long)d->h_cnt[16];
+        HIPCHK(hipMemcpy(&d->h_cnt[17], c.rec_off.as<uint64_t>() + L, 8, hipMemcpyDeviceToHost));
+        c.tail_start = (size_t)d->h_cnt[17];
+        c.n_rec = L;
+    }
     d->stats.records += c.n_rec;
     c.loaded = true;
     return SVX_OK;
@@ -901,21 +1002,85 @@ int devdec_count(svx_devdec* d, int slot, int32_t tid_limit, int64_t* n_rec, int
     return SVX_OK;
 }
 
-int devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t count, svx_batch* out) {
+int devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t* count_io, int mode, int min_mapq, svx_batch* out) {
     DevChunk& c = d->chunk[slot];
+    int64_t count = *count_io;
     if (!c.loaded || first < 0 || count < 0 || first + count > c.n_rec) return svx_fail(SVX_E_ARG, "record range outside the chunk", __FILE__, __LINE__, hipSuccess);
     HIPCHK(hipSetDevice(d->device));
+    hipStream_t st = d->stream;
+    if (mode == 1 && count > 0 && first + count < c.n_rec) {
+        // a read's group is never split: the batch grows to the next group boundary (the chunk itself ends on one)
+        unsigned long long* nb = d->counters.as<unsigned long long>() + 18;
+        const unsigned long long big = (unsigned long long)c.n_rec;
+        d->h_cnt[18] = big;
+        HIPCHK(hipMemcpyAsync(nb, &d->h_cnt[18], 8, hipMemcpyHostToDevice, st));
+        k_q_next_boundary<<<GRIDB(c.n_rec - (first + count), 256), 256, 0, st>>>(first + count, c.n_rec, c.read_id.as<int32_t>(), nb);
+        HIPCHK(hipMemcpyAsync(&d->h_cnt[18], nb, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        count = (int64_t)d->h_cnt[18] - first;
+        *count_io = count;
+    }
     const int f = c.order_flip; c.order_flip ^= 1;
     SVXCHK(c.order[f].reserve((size_t)(count + 1) * 4)); SVXCHK(c.seg_order[f].reserve((size_t)(count + 1) * 4));
-    if (count) k_order_iota<<<GRIDB(count, 256), 256, 0, d->stream>>>(count, c.order[f].as<uint32_t>(), c.seg_order[f].as<uint32_t>());
-    HIPCHK(hipStreamSynchronize(d->stream));
     memset(out, 0, sizeof *out);
     out->on_device = 1; out->n_rec = count;
-    out->flag = c.flag.as<uint16_t>() + first; out->tid = c.tid.as<int32_t>() + first; out->pos = c.pos.as<int32_t>() + first; out->mapq = c.mapq.as<uint8_t>() + first;
+    out->tid = c.tid.as<int32_t>() + first; out->pos = c.pos.as<int32_t>() + first; out->mapq = c.mapq.as<uint8_t>() + first;
     out->lseq = c.lseq.as<int32_t>() + first; out->read_id = c.read_id.as<int32_t>() + first; out->order = c.order[f].as<uint32_t>(); out->seg_order = c.seg_order[f].as<uint32_t>();
     out->cigar_off = c.cigar_off.as<uint64_t>() + first; out->cigar = c.cigar.as<uint32_t>(); out->seq_off = c.seq_off.as<uint64_t>() + first; out->seq = c.stream.as<uint8_t>();
-    out->seg_off = c.seg_off.as<uint32_t>() + first; out->n_seg = c.tot_seg; out->seg_tid = c.seg_tid.as<int32_t>(); out->seg_pos = c.seg_pos.as<int32_t>();
-    out->seg_rev = c.seg_rev.as<uint8_t>(); out->seg_mapq = c.seg_mapq.as<uint8_t>(); out->seg_lseq = c.seg_lseq.as<int32_t>(); out->seg_cigar_off = c.seg_cigar_off.as<uint64_t>();
-    out->seg_cigar = c.seg_cigar.as<uint32_t>(); out->n_contig = d->n_ref; out->contig_rank = d->contig_rank.as<int32_t>();
+    out->n_contig = d->n_ref; out->contig_rank = d->contig_rank.as<int32_t>();
+    if (mode != 1) {
+        if (count) k_order_iota<<<GRIDB(count, 256), 256, 0, st>>>(count, c.order[f].as<uint32_t>(), c.seg_order[f].as<uint32_t>());
+        HIPCHK(hipStreamSynchronize(st));
+        out->flag = c.flag.as<uint16_t>() + first;
+        out->seg_off = c.seg_off.as<uint32_t>() + first; out->n_seg = c.tot_seg; out->seg_tid = c.seg_tid.as<int32_t>(); out->seg_pos = c.seg_pos.as<int32_t>();
+        out->seg_rev = c.seg_rev.as<uint8_t>(); out->seg_mapq = c.seg_mapq.as<uint8_t>(); out->seg_lseq = c.seg_lseq.as<int32_t>(); out->seg_cigar_off = c.seg_cigar_off.as<uint64_t>();
+        out->seg_cigar = c.seg_cigar.as<uint32_t>();
+        return SVX_OK;
+    }
+    // ---- query-name mode: groups, verdicts, emission slots and the segment table of this batch (kernels k_q_*) ------------------------------------------------
+    const long long n = count;
+    const size_t N1 = (size_t)n + 1;
+    const uint16_t* fl = c.flag.as<uint16_t>() + first; const uint8_t* mq = c.mapq.as<uint8_t>() + first; const int32_t* rid = c.read_id.as<int32_t>() + first;
+    SVXCHK(c.q_flag[f].reserve(N1 * 2)); SVXCHK(c.q_seg_off[f].reserve(N1 * 4));
+    SVXCHK(c.q_head.reserve(N1 * 4)); SVXCHK(c.q_good.reserve(N1 * 4)); SVXCHK(c.q_gidx.reserve(N1 * 4)); SVXCHK(c.q_good_ex.reserve(N1 * 4));
+    k_q_marks<<<GRIDB(n + 1, 256), 256, 0, st>>>(n, fl, mq, rid, min_mapq, c.q_head.as<uint32_t>(), c.q_good.as<uint32_t>());
+    SVXCHK(dd_scan<uint32_t>(d, c, c.q_head.as<uint32_t>(), c.q_gidx.as<uint32_t>(), N1));
+    SVXCHK(dd_scan<uint32_t>(d, c, c.q_good.as<uint32_t>(), c.q_good_ex.as<uint32_t>(), N1));
+    HIPCHK(hipMemcpyAsync(&d->h_cnt[20], c.q_gidx.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const long long G = (long long)(uint32_t)d->h_cnt[20];
+    const size_t G1 = (size_t)G + 1;
+    SVXCHK(c.q_gs.reserve(G1 * 4)); SVXCHK(c.q_nprim.reserve(G1 * 4)); SVXCHK(c.q_pidx.reserve(G1 * 4)); SVXCHK(c.q_slots.reserve(G1 * 4)); SVXCHK(c.q_rows.reserve(G1 * 4));
+    SVXCHK(c.q_slot_ex.reserve(G1 * 4)); SVXCHK(c.q_row_ex.reserve(G1 * 4));
+    HIPCHK(hipMemsetAsync(c.q_nprim.p, 0, G1 * 4, st)); HIPCHK(hipMemsetAsync(c.q_pidx.p, 0, G1 * 4, st));
+    if (n) k_q_groups<<<GRIDB(n, 256), 256, 0, st>>>(n, c.q_head.as<uint32_t>(), c.q_gidx.as<uint32_t>(), fl, c.q_gs.as<uint32_t>(), c.q_nprim.as<uint32_t>(), c.q_pidx.as<uint32_t>());
+    k_q_verdict<<<GRIDB(G + 1, 256), 256, 0, st>>>(G, n, c.q_gs.as<uint32_t>(), c.q_nprim.as<uint32_t>(), c.q_pidx.as<uint32_t>(), fl, mq, min_mapq, c.q_good_ex.as<uint32_t>(),
+                                                 c.q_slots.as<uint32_t>(), c.q_rows.as<uint32_t>());
+    SVXCHK(dd_scan<uint32_t>(d, c, c.q_slots.as<uint32_t>(), c.q_slot_ex.as<uint32_t>(), G1));
+    SVXCHK(dd_scan<uint32_t>(d, c, c.q_rows.as<uint32_t>(), c.q_row_ex.as<uint32_t>(), G1));
+    HIPCHK(hipMemcpyAsync(&d->h_cnt[21], c.q_row_ex.as<uint32_t>() + G, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const long long R = (long long)(uint32_t)d->h_cnt[21];
+    const size_t R1 = (size_t)R + 1;
+    SVXCHK(c.q_seg_tid[f].reserve(R1 * 4)); SVXCHK(c.q_seg_pos[f].reserve(R1 * 4)); SVXCHK(c.q_seg_rev[f].reserve(R1)); SVXCHK(c.q_seg_mapq[f].reserve(R1));
+    SVXCHK(c.q_seg_lseq[f].reserve(R1 * 4)); SVXCHK(c.q_seg_cigar_off[f].reserve(R1 * 8)); SVXCHK(c.q_row_rec.reserve(R1 * 4)); SVXCHK(c.q_row_ops.reserve(R1 * 4));
+    HIPCHK(hipMemsetAsync(c.q_row_ops.as<uint32_t>() + R, 0, 4, st));
+    k_q_records<<<GRIDB(n + 1, 256), 256, 0, st>>>(n, G, c.q_head.as<uint32_t>(), c.q_gidx.as<uint32_t>(), c.q_gs.as<uint32_t>(), c.q_pidx.as<uint32_t>(), c.q_good.as<uint32_t>(),
+                                                 c.q_good_ex.as<uint32_t>(), c.q_slots.as<uint32_t>(), c.q_slot_ex.as<uint32_t>(), c.q_row_ex.as<uint32_t>(), fl, out->tid, out->pos, mq,
+                                                 out->lseq, out->cigar_off, c.q_flag[f].as<uint16_t>(), c.order[f].as<uint32_t>(), c.seg_order[f].as<uint32_t>(),
+                                                 c.q_seg_off[f].as<uint32_t>(), c.q_seg_tid[f].as<int32_t>(), c.q_seg_pos[f].as<int32_t>(), c.q_seg_rev[f].as<uint8_t>(),
+                                                 c.q_seg_mapq[f].as<uint8_t>(), c.q_seg_lseq[f].as<int32_t>(), c.q_row_rec.as<uint32_t>(), c.q_row_ops.as<uint32_t>());
+    SVXCHK((svx_exclusive_scan<uint32_t, uint64_t>(c.q_row_ops.as<uint32_t>(), c.q_seg_cigar_off[f].as<uint64_t>(), (long long)R1, st, c.scan_tmp)));
+    HIPCHK(hipMemcpyAsync(&d->h_cnt[22], c.q_seg_cigar_off[f].as<uint64_t>() + R, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const size_t ops = (size_t)d->h_cnt[22];
+    SVXCHK(c.q_seg_cigar[f].reserve((ops + 16) * 4));
+    if (R) k_q_seg_cigar<<<GRIDB(R, 4), 256, 0, st>>>(R, c.q_row_rec.as<uint32_t>(), out->cigar_off, out->cigar, c.q_seg_cigar_off[f].as<uint64_t>(), c.q_seg_cigar[f].as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    out->flag = c.q_flag[f].as<uint16_t>();
+    out->seg_off = c.q_seg_off[f].as<uint32_t>(); out->n_seg = R; out->seg_tid = c.q_seg_tid[f].as<int32_t>(); out->seg_pos = c.q_seg_pos[f].as<int32_t>();
+    out->seg_rev = c.q_seg_rev[f].as<uint8_t>(); out->seg_mapq = c.q_seg_mapq[f].as<uint8_t>(); out->seg_lseq = c.q_seg_lseq[f].as<int32_t>();
+    out->seg_cigar_off = c.q_seg_cigar_off[f].as<uint64_t>(); out->seg_cigar = c.q_seg_cigar[f].as<uint32_t>();
     return SVX_OK;
 }

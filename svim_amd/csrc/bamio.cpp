@@ -216,6 +216,7 @@ struct svx_bam {
     // one before it) may still be read by the consumer's stream when the next region's first chunk is loaded (include/svx.h: arrays stay valid until the
     // third next chunk is loaded).  dev_last_slot = the slot that was loaded last.
     int dev_last_slot = -1, dev_handed_slot = -1;      // dev_handed_slot: the slot the last batch was handed out from
+    int dev_mode = 0;                         // 0 coordinate-sorted rules, 1 query-name-sorted rules: fixed by the first read after open / rewind / seek
     int dev_grow = 0;                         // a chunk without one complete record is loaded again, into the same slot, with 2^dev_grow times the budget
     size_t dev_region_bytes = 0;              // contig-range reading: budget of the next chunk (small after a seek, x4 per chunk: a range is not read 8 GB beyond its end)
     std::future<DevLoad> dev_future; bool dev_prefetching = false;
@@ -940,7 +941,7 @@ static void clear_batch(svx_bam* h) {
 // (src/svim/SVIM_COLLECT.py:132-167), 1 = query-name-sorted rules (:96-129).
 // one chunk of the device reader: whole BGZF blocks up to dev_chunk_bytes of inflated data -> slot `slot` (runs on a background thread while the
 // batches of the chunk before it are handed out; only this function advances dev_fpos)
-static svx_bam::DevLoad dev_load_chunk(svx_bam* h, int slot, int carry_slot, uint64_t skip, int min_mapq, size_t budget_bytes, size_t budget_blocks) {
+static svx_bam::DevLoad dev_load_chunk(svx_bam* h, int slot, int carry_slot, uint64_t skip, int min_mapq, int mode, size_t budget_bytes, size_t budget_blocks) {
     svx_bam::DevLoad r;
     r.slot = slot; r.carry_slot = carry_slot; r.skip = skip; r.fpos_start = h->dev_fpos;
     std::vector<DevDecBlock> blocks;
@@ -960,7 +961,7 @@ static svx_bam::DevLoad dev_load_chunk(svx_bam* h, int slot, int carry_slot, uin
     catch (const std::exception& e) { r.rc = SVX_E_ARG; r.err = e.what(); return r; }      // (this runs on a std::async thread: nothing may escape into future::get of a C entry point)
     if (blocks.empty() && carry_slot < 0) { r.file_done = true; r.empty = true; return r; }
     try {
-        r.rc = devdec_load(h->dev, slot, blocks.data(), blocks.size(), carry_slot, skip, r.file_done, min_mapq);
+        r.rc = devdec_load(h->dev, slot, blocks.data(), blocks.size(), carry_slot, skip, r.file_done, min_mapq, mode);
         if (r.rc == SVX_OK) r.rc = devdec_count(h->dev, slot, h->tid_limit, &r.n_rec, &r.n_valid);
         if (r.rc != SVX_OK) r.err = svx_last_error();
     } catch (const std::exception& e) { r.rc = SVX_E_ARG; r.err = e.what(); }
@@ -973,7 +974,7 @@ static void dev_start_prefetch(svx_bam* h, int slot, int carry_slot, uint64_t sk
     for (int g = 0; g < h->dev_grow; g++) { if (bytes < ((size_t)1 << 62)) bytes *= 2; if (blocks < ((size_t)1 << 62)) blocks *= 2; }
     if (h->dev_region_bytes && !h->dev_grow) h->dev_region_bytes = std::min(h->dev_region_bytes * 4, h->dev_chunk_bytes);
     h->dev_last_slot = slot;
-    h->dev_future = std::async(std::launch::async, dev_load_chunk, h, slot, carry_slot, skip, min_mapq, bytes, blocks);
+    h->dev_future = std::async(std::launch::async, dev_load_chunk, h, slot, carry_slot, skip, min_mapq, h->dev_mode, bytes, blocks);
     h->dev_prefetching = true;
 }
 // the slot after the one loaded last - never restarted at 0: see dev_last_slot
@@ -984,13 +985,15 @@ static void dev_drop_prefetch(svx_bam* h) {
 }
 
 // device decode: batches are views of the current chunk's arrays; the next chunk is inflated and decoded meanwhile
-static int read_batch_device(svx_bam* h, int64_t max_records, int min_mapq, svx_batch* out, int64_t* n_out) {
+static int read_batch_device(svx_bam* h, int64_t max_records, int mode, int min_mapq, svx_batch* out, int64_t* n_out) {
     *n_out = 0;
     memset(out, 0, sizeof *out);
+    if (h->dev_cur < 0 && !h->dev_prefetching) h->dev_mode = mode;           // a fresh start (open, rewind, seek): the mode of this pass
+    else if (mode != h->dev_mode) return bam_fail(SVX_E_ARG, "the sort mode of a pass over the file cannot change between batches (rewind first)");
     for (;;) {
         if (h->dev_cur >= 0 && h->dev_first < h->dev_valid) {
-            const int64_t count = std::min<int64_t>(max_records, h->dev_valid - h->dev_first);
-            const int rc = devdec_batch(h->dev, h->dev_cur, h->dev_first, count, out);
+            int64_t count = std::min<int64_t>(max_records, h->dev_valid - h->dev_first);
+            const int rc = devdec_batch(h->dev, h->dev_cur, h->dev_first, &count, mode, min_mapq, out);      // (query-name mode: grows to the end of the read's group)
             if (rc != SVX_OK) return rc;
             h->dev_first += count; h->total_records += count; *n_out = count;
             h->dev_handed_slot = h->dev_cur;
@@ -1038,10 +1041,7 @@ extern "C" int svx_bam_set_device_decode(svx_bam* h, int device) {
 }
 
 extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int min_mapq, svx_batch* out, int64_t* n_out) {
-    if (h->dev) {
-        if (mode != 0) return bam_fail(SVX_E_ARG, "the device BAM decode reads coordinate-sorted input only (query-name grouping stays on the host reader)");
-        return read_batch_device(h, max_records, min_mapq, out, n_out);
-    }
+    if (h->dev) return read_batch_device(h, max_records, mode == 1 ? 1 : 0, min_mapq, out, n_out);
     BatchArrays* const handed_out = h->b;                                                 // the set the previous call handed out: the caller may still upload from it
     try {
         h->b = &h->ba[h->b == &h->ba[0] ? 1 : 0];                                        // the previous batch stays valid during this read

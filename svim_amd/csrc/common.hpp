@@ -126,7 +126,7 @@ struct svx_ctx {
     int n_cu = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev[24];
-    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] high priority (band classes), [2..3] low (full-matrix classes); [4] low: linkage of the partitions that need no edit distances; [5] high: the widest band classes of round 0
+    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] band classes, [2..3] full-matrix classes (the high-priority ones: api.hip); [4] low: linkage of the partitions that need no edit distances; [5] high: the widest band classes of round 0
     // device copies of a host-resident batch
     std::vector<DevBuf> batch_bufs;
     // COLLECT results

@@ -19,11 +19,15 @@ void devdec_set_file(svx_devdec* d, const uint8_t* base, size_t bytes);
 // Inflate `n` blocks into chunk slot `slot` (0..2) behind the unconsumed tail of slot `carry_slot` (-1: none), skip `skip_bytes` at the start of the
 // stream (the BAM header, first chunk only), find every complete record and decode all of them.  final_chunk: nothing follows (a partial record at the
 // end is an error).  min_mapq: primaries below it get no segment rows (src/svim/SVIM_COLLECT.py:143-161).
-int  devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t n, int carry_slot, uint64_t skip_bytes, bool final_chunk, int min_mapq);
+// mode 1 = query-name-sorted input (src/svim/SVIM_COLLECT.py:96-129): no SA tag is expanded, and unless final_chunk the last read's group of the chunk is left to the
+// next load (groups never straddle loads).
+int  devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t n, int carry_slot, uint64_t skip_bytes, bool final_chunk, int min_mapq, int mode);
 // records decoded in the slot; n_valid: those before the first record whose reference id is negative or above tid_limit (tid_limit -2: all)
 int  devdec_count(svx_devdec* d, int slot, int32_t tid_limit, int64_t* n_rec, int64_t* n_valid);
 // device-resident svx_batch over records [first, first + count) of the slot (arrays stay valid until the slot is loaded again)
-int  devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t count, svx_batch* out);
+// mode 1: *count grows to the end of the read group it ends in; flags carry SVX_FLAG_SKIP, the segment table holds the good supplementary records of every analysed
+// read and the emission slots follow the reference's per-read order (bamio.cpp svx_bam_read_batch does the same on the host)
+int  devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t* count, int mode, int min_mapq, svx_batch* out);
 // read names interned so far, id order (host copy; grows with every load)
 const std::vector<std::string>& devdec_names(svx_devdec* d);
 // timing / accounting of the loads so far

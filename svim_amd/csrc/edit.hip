@@ -925,7 +925,7 @@ __device__ __forceinline__ void d_edit_stair(const int Q0, const bool narrow, lo
 
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
     // lane l receives lane l-1's value, lane 0 receives 0 (gfx9 DPP control wave_shr:1)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true);       // bound_ctrl: no `old` value to set up - one v_mov_b32_dpp
 }
 
 // ---- 3b. whole pattern in one lane (m <= 32*Q), full matrix: plain multi-word Myers, 64 pairs per wave ----------
@@ -1028,36 +1028,47 @@ __device__ __forceinline__ void d_edit_wide(long long blk, long long count, cons
         for (int b = 0; b < P; b++) pl[b][q] = e[b];
     }
     const bool is_last = gl == lanes_used - 1;               // this lane holds row m (in bit 31 of its last word)
-    int score = m;
+    int score = m;                                           // every lane keeps one; the last lane's is the result
     int steps = live ? n + lanes_used - 1 : 0, smax = steps;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(smax, o, 64); smax = v > smax ? v : smax; }
     const int txt_words = (n + 7) >> 3;
-    const bool feeder = live && gl == 0;
+    const bool first = gl == 0;                              // the group's first lane takes its inputs from the text, not from the lane above
+    const bool feeder = live && first;
+    const unsigned n_on = (live && gl < lanes_used) ? (unsigned)n : 0u;      // columns this lane works on (none: a lane beyond the pattern)
     uint32_t tw_next = (feeder && txt_words > 0) ? txt.word(0) : 0u;
-    uint32_t out = 0;
+    // What a lane hands to the lane below it for the same text column one step later: the symbol's plane masks, the (plus, minus) words whose bit 31
+    // is the horizontal delta leaving its last row, the adder's carry.  Each goes down by one DPP move; nothing is packed or unpacked.
+    uint32_t o_nk[P], o_ph = 0u, o_mh = 0u, o_cy = 0u;
+#pragma unroll
+    for (int b = 0; b < P; b++) o_nk[b] = 0u;
+    int col = -gl;                                           // text column of this lane at the current step
     for (int jb = 0; jb * 8 < smax; jb++) {
         const uint32_t tw = tw_next;
         tw_next = (feeder && jb + 1 < txt_words) ? txt.word(jb + 1) : 0u;
+        uint32_t tp[P];
+        planes8<P>(tw, tp);
+#pragma unroll
+        for (int b = 0; b < P; b++) tp[b] = ~tp[b];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int st = jb * 8 + k;                       // step; the group's first lane is at text column st
-            uint32_t in = dpp_wave_shr1(out);
-            if (gl == 0) in = (st < n) ? (sym<P>((tw >> (4 * k)) & 15u) | 0x20u | 0x80u) : 0u;      // top row: plus bit 1, no carry
-            if ((in & 0x80u) && gl < lanes_used) {
-                const uint32_t c = in & 15u;                 // already mapped by the feeder lane
-                uint32_t nk[P];
+            uint32_t nk[P];
 #pragma unroll
-                for (int b = 0; b < P; b++) nk[b] = ((c >> b) & 1u) - 1u;
-                unsigned carry = (in >> 4) & 1u;
-                uint32_t ph_prev = (in & 0x20u) << 26, mh_prev = (in & 0x40u) << 25;      // bit 31 = what the lane above pushed out
-                MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
-                const uint32_t po = ph_prev >> 31, mo = mh_prev >> 31;
-                if (is_last) score += (int)po - (int)mo;
-                out = c | (carry << 4) | (po << 5) | (mo << 6) | 0x80u;
-            } else {
-                out = 0;
+            for (int b = 0; b < P; b++) {
+                const uint32_t down = dpp_wave_shr1(o_nk[b]);
+                nk[b] = first ? (uint32_t)__builtin_amdgcn_sbfe((int)tp[b], k, 1) : down;       // bit set -> 0, clear -> all ones
             }
+            uint32_t ph_prev = dpp_wave_shr1(o_ph), mh_prev = dpp_wave_shr1(o_mh), cy = dpp_wave_shr1(o_cy);
+            if (first) { ph_prev = 0x80000000u; mh_prev = 0u; cy = 0u; }                        // top row: horizontal delta +1, no carry
+            if ((unsigned)col < n_on) {
+                unsigned carry = cy;
+                MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
+                score += (int)(ph_prev >> 31) - (int)(mh_prev >> 31);
+#pragma unroll
+                for (int b = 0; b < P; b++) o_nk[b] = nk[b];
+                o_ph = ph_prev; o_mh = mh_prev; o_cy = carry;
+            }
+            col += 1;
         }
     }
     wc_account(wc, (long long)smax * Q * 64, (live && gl == 0) ? (long long)n * ((m + 31) >> 5) : 0);

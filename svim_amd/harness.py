@@ -43,8 +43,8 @@ class BamPipeline(object):
         from .bamio import NativeBam
         self.bam = NativeBam(path, threads=threads)
         dev = getattr(engine, "device", None)
-        if device_decode is None:                                   # default for coordinate-sorted input on a GPU engine (SVX_BAM_DEVICE_DECODE=0: host reader)
-            device_decode = dev is not None and mode == "coordinate" and gpu_inflate is not False and os.environ.get("SVX_BAM_DEVICE_DECODE", "1") != "0"
+        if device_decode is None:                                   # default on a GPU engine, either sort order (SVX_BAM_DEVICE_DECODE=0: host reader)
+            device_decode = dev is not None and mode in ("coordinate", "queryname") and gpu_inflate is not False and os.environ.get("SVX_BAM_DEVICE_DECODE", "1") != "0"
         self.device_decode = bool(device_decode)
         self.options, self.eng, self.mode, self.batch_records = options, engine, mode, batch_records
         self.params = _abi.Params.from_options(options)
@@ -423,75 +423,122 @@ def _timed_bam_passes(path, opts, eng, genome, passes=1, threads=0, batch_record
     return out
 
 
-def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s=None, n_records=180_000, tmp_dir=None):
-    """bench.py's `end_to_end` block: the first n_records of the synthetic batch (coordinate order) written as a BAM file, then
-    (a) BAM file -> reader -> pipeline -> CLUSTER, wall clock including inflate, decode, H2D; (b) the same records handed over as host
-    arrays (H2D included, no file); next to (c) the resident rate of the headline.  One untimed pass warms allocations."""
+def _median_pass(runs):
+    """(cold pass, median of the warm passes) of _timed_bam_passes"""
+    warm = sorted(runs[1:], key=lambda r: r[1])
+    return runs[0], warm[len(warm) // 2]
+
+
+def _inflate_delta(runs, k):
+    """inflate counters of pass k alone (the reader's counters are cumulative over its passes)"""
+    cur = runs[k][2].get("inflate") or {}
+    prev = (runs[k - 1][2].get("inflate") or {}) if k else {}
+    return {key: cur.get(key, 0) - prev.get(key, 0) for key in ("gpu_blocks", "cpu_blocks", "gpu_kernel_ms")}
+
+
+def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s=None, n_records=180_000, n_records_qual=300_000, tmp_dir=None,
+                      chunk_mb=2048):
+    """bench.py's `end_to_end` block.  HEADLINE: the first n_records_qual records of the synthetic batch (coordinate order) written as a BAM file WITH base
+    qualities (what every real ONT / HiFi file carries; random Phred values, deflate ~1.5 : 1), read by the device-resident reader in chunks of chunk_mb of
+    inflated data (several chunks: the overlap of chunk i+1's inflate with chunk i's batches is inside the clock), COLLECT per batch, CLUSTER - wall clock
+    from before rewind() to the end of CLUSTER, median of three warm passes, the cold first pass beside it, and the cost of turning the result tables into
+    the reference's Python objects.  Side figures: the same records without qualities (QUAL 0xff, ~4 : 1: the round-3 headline), the host reader's routes
+    on that file, host arrays in, the resident rate."""
     import tempfile
     import torch
+    from . import lazy
     eng = _lib.Engine(device)
     n = min(int(n_records), batch.n_rec)
+    nq = min(int(n_records_qual), batch.n_rec)
     hb = batch.slice_records(0, n)
     refs = list(hb.references)
     lens = [int(x) for x in (g_off[1:] - g_off[:-1]).tolist()]
     d = tempfile.mkdtemp(prefix="svx_e2e_", dir=tmp_dir)
-    path = os.path.join(d, "sample.bam")
-    t0 = time.perf_counter()
-    _, raw_bytes = write_bam_from_batch(path, hb, refs, lens)
-    t_write = time.perf_counter() - t0
-    size = os.path.getsize(path)
+    path, qpath = os.path.join(d, "sample.bam"), os.path.join(d, "sample_q.bam")
     gen = (g_off, genome, True)
     p = _abi.Params.from_options(opts)
-    out = {"sample": "first %d records of the batch as a BAM file (%.0f MB, %.0f MB inflated; written in %.1f s, untimed)" % (n, size / 1e6, raw_bytes / 1e6, t_write),
-           "host_cores_visible": os.cpu_count(), "host_cpus_granted": effective_cpus()}
+    out = {"host_cores_visible": os.cpu_count(), "host_cpus_granted": effective_cpus()}
+    old_chunk = os.environ.get("SVX_BAM_DEV_CHUNK_MB")
     try:
-        per_batch = max(1000, n // 6)                                      # several batches: the reader runs ahead of the GPU thread
-        # product path: the device-resident reader (inflate + record discovery + decode on the GPU).  Every pass is timed from BEFORE rewind() to the
-        # end of CLUSTER; pass 0 also pays every first-touch allocation
+        # ---- headline: the file with base qualities ------------------------------------------------------------------------------------------------------
+        t0 = time.perf_counter()
+        _, q_raw = write_bam_from_device_batch(qpath, batch, refs, lens, 0, nq, qual_seed=7)
+        t_write_q = time.perf_counter() - t0
+        q_size = os.path.getsize(qpath)
+        os.environ["SVX_BAM_DEV_CHUNK_MB"] = str(int(chunk_mb))
+        per_batch = max(1000, nq // 16)
+        runs = _timed_bam_passes(qpath, opts, eng, gen, passes=4, batch_records=per_batch)
+        cold, med = _median_pass(runs)
+        k = runs.index(med)
+        inf = _inflate_delta(runs, k)
+        n_read, wall, ps, st, counts = med
+        gpu_share = inf["gpu_blocks"] / max(1, inf["gpu_blocks"] + inf["cpu_blocks"])
+        gpu_rate = gpu_share * q_raw / max(inf["gpu_kernel_ms"] * 1e-3, 1e-9) / 1e6                  # MB/s of inflated output while the kernels run
+        n_chunks = -(-q_raw // (int(chunk_mb) << 20))
+        out["sample"] = ("first %d records of the batch as a BAM file WITH base qualities (%.0f MB, %.0f MB inflated, deflate ratio %.2f; written in %.1f s, untimed); "
+                         "read in %d chunks of %d MB" % (nq, q_size / 1e6, q_raw / 1e6, q_raw / max(1, q_size), t_write_q, n_chunks, chunk_mb))
+        out["bam_file_reads_per_s"] = n_read / wall
+        out["bam_file_first_pass_reads_per_s"] = cold[0] / cold[1]          # cold: every host / device buffer is touched for the first time, the file is registered
+        blk = {"records": n_read, "reads_per_s": n_read / wall, "wall_s": wall, "passes": "1 cold + 3 warm; the figure is the MEDIAN warm pass",
+               "warm_pass_walls_s": sorted(r[1] for r in runs[1:]), "cold_pass_wall_s": cold[1], "chunks": int(n_chunks), "chunk_MB": int(chunk_mb),
+               "bam_MB": q_size / 1e6, "inflated_MB": q_raw / 1e6, "deflate_ratio": q_raw / max(1, q_size), "bam_MB_per_s": q_size / wall / 1e6,
+               "inflated_MB_per_s": q_raw / wall / 1e6, "batches": ps["batches"], "reader_busy_s": ps["t_reader_busy"], "gpu_collect_s": ps["t_gpu_collect"],
+               "gpu_waits_for_reader_s": ps["t_gpu_waits_for_reader"], "cluster_s": ps["t_cluster_wall"], "signatures": counts[0],
+               "qualities": "random Phred values, normal(18, 8) clipped to 1..50",
+               "reader": "device-resident: BGZF inflate, record discovery, field / CIGAR / SA / name decode on the GPU (csrc/bamdev.hip)",
+               "inflate_blocks_gpu": inf["gpu_blocks"], "inflate_blocks_host_cores": inf["cpu_blocks"], "inflate_kernel_ms": inf["gpu_kernel_ms"],
+               "inflate_kernel_MB_per_s": gpu_rate, "clock": "perf_counter from before rewind() to the end of CLUSTER (first chunk included)",
+               "bound_by": ("GPU (k_bgzf_inflate busy %.0f %% of the wall time; COLLECT + CLUSTER %.0f %%)" % (100 * inf["gpu_kernel_ms"] * 1e-3 / wall, 100 * (ps["t_gpu_collect"] + ps["t_cluster_wall"]) / wall))
+               if inf["gpu_kernel_ms"] * 1e-3 > 0.5 * wall else "host / PCIe (the GPU inflate is busy %.0f %% of the wall time)" % (100 * inf["gpu_kernel_ms"] * 1e-3 / wall)}
+        # what it costs to LOOK at the result: the signature table and the six cluster lists as the reference's Python objects (svim_amd/lazy.py builds them on
+        # first access; SVIM's own writers iterate them once)
+        pipe = BamPipeline(qpath, opts, eng, batch_records=per_batch)
+        try:
+            pipe.run()
+            pipe.cluster()
+            names = pipe.bam.read_names()
+            t0 = time.perf_counter()
+            sl = lazy.SignatureList(eng.fetch_signatures(0), refs, names)
+            bl = lazy.SignatureList(eng.fetch_signatures(1), refs, names)
+            sl.materialise(); bl.materialise()
+            lists = convert.cluster_objects(eng.fetch_clusters(), sl, refs)
+            n_obj = len(sl) + len(bl) + sum(len(l.materialise()) for l in lists)
+            t_obj = time.perf_counter() - t0
+        finally:
+            pipe.close()
+        blk["objects_materialised"] = {"objects": n_obj, "seconds": t_obj, "reads_per_s_including_them": n_read / (wall + t_obj)}
+        out["objects_materialised_reads_per_s"] = n_read / (wall + t_obj)
+        out["bam_file_with_base_qualities"] = blk
+        out["bam_file"] = blk
+        os.remove(qpath)
+        # ---- side figure: the same records without qualities (QUAL 0xff; one chunk) ---------------------------------------------------------------------------
+        if old_chunk is None:
+            os.environ.pop("SVX_BAM_DEV_CHUNK_MB", None)
+        else:
+            os.environ["SVX_BAM_DEV_CHUNK_MB"] = old_chunk
+        t0 = time.perf_counter()
+        _, raw_bytes = write_bam_from_device_batch(path, batch, refs, lens, 0, n)
+        size = os.path.getsize(path)
+        per_batch = max(1000, n // 6)
         runs = _timed_bam_passes(path, opts, eng, gen, passes=4, batch_records=per_batch)
-        out["bam_file_first_pass_reads_per_s"] = runs[0][0] / runs[0][1]   # cold: every host / device buffer is touched for the first time
-        best = min(runs[1:], key=lambda r: r[1])
-        n_read, wall, ps, st, counts = best
-        inf_all = [r[2].get("inflate") or {} for r in runs]
-        k = runs.index(best)
-        d_gpu = inf_all[k].get("gpu_blocks", 0) - inf_all[k - 1].get("gpu_blocks", 0)          # (the reader's counters are cumulative over its passes)
-        d_cpu = inf_all[k].get("cpu_blocks", 0) - inf_all[k - 1].get("cpu_blocks", 0)
-        d_ms = inf_all[k].get("gpu_kernel_ms", 0.0) - inf_all[k - 1].get("gpu_kernel_ms", 0.0)
-        gpu_share = d_gpu / max(1, d_gpu + d_cpu)
-        gpu_rate = gpu_share * raw_bytes / max(d_ms * 1e-3, 1e-9) / 1e6                            # MB/s of inflated output while the kernels run
-        out["bam_file_reads_per_s"] = st["n_rec_used"] and (n_read / wall)
-        out["bam_file"] = {"records": n_read, "wall_s": wall, "bam_MB_per_s": size / wall / 1e6, "inflated_MB_per_s": raw_bytes / wall / 1e6,
-                           "batches": ps["batches"], "reader_busy_s": ps["t_reader_busy"], "gpu_collect_s": ps["t_gpu_collect"],
-                           "gpu_waits_for_reader_s": ps["t_gpu_waits_for_reader"], "cluster_s": ps["t_cluster_wall"],
-                           "signatures": counts[0], "reader": "device-resident: BGZF inflate, record discovery, field / CIGAR / SA / name decode on the GPU (csrc/bamdev.hip)",
-                           "inflate_blocks_gpu": d_gpu, "inflate_blocks_host_cores": d_cpu, "inflate_kernel_ms": d_ms, "inflate_kernel_MB_per_s": gpu_rate,
-                           "clock": "perf_counter from before rewind() to the end of CLUSTER (first chunk included)",
-                           "bound_by": ("GPU (k_bgzf_inflate busy %.0f %% of the wall time; COLLECT + CLUSTER %.0f %%)" % (100 * d_ms * 1e-3 / wall, 100 * (ps["t_gpu_collect"] + ps["t_cluster_wall"]) / wall))
-                           if d_ms * 1e-3 > 0.5 * wall else "host (file slice -> pinned staging -> PCIe; the GPU inflate is busy %.0f %% of the wall time)" % (100 * d_ms * 1e-3 / wall)}
-        # the same with the host reader (inflate shared GPU / host cores, record decode on the host's cores) and with the host's cores alone
-        r = min(_timed_bam_passes(path, opts, eng, gen, passes=3, batch_records=per_batch, device_decode=False)[1:], key=lambda x: x[1])
+        cold0, med0 = _median_pass(runs)
+        inf0 = _inflate_delta(runs, runs.index(med0))
+        share0 = inf0["gpu_blocks"] / max(1, inf0["gpu_blocks"] + inf0["cpu_blocks"])
+        rate0 = share0 * raw_bytes / max(inf0["gpu_kernel_ms"] * 1e-3, 1e-9) / 1e6
+        out["bam_file_without_base_qualities"] = {"records": med0[0], "reads_per_s": med0[0] / med0[1], "first_pass_reads_per_s": cold0[0] / cold0[1], "bam_MB": size / 1e6,
+                                                  "inflated_MB": raw_bytes / 1e6, "deflate_ratio": raw_bytes / max(1, size), "inflated_MB_per_s": raw_bytes / med0[1] / 1e6,
+                                                  "inflate_kernel_MB_per_s": rate0, "note": "QUAL 0xff (absent): the round-3 headline file; one chunk"}
+        # the same file with the host reader (inflate shared GPU / host cores, record decode on the host's cores) and with the host's cores alone
+        r = _median_pass(_timed_bam_passes(path, opts, eng, gen, passes=3, batch_records=per_batch, device_decode=False))[1]
         out["bam_file_host_decode_reads_per_s"] = r[0] / r[1]
-        r = min(_timed_bam_passes(path, opts, eng, gen, passes=3, batch_records=per_batch, gpu_inflate=False, device_decode=False)[1:], key=lambda x: x[1])
+        r = _median_pass(_timed_bam_passes(path, opts, eng, gen, passes=3, batch_records=per_batch, gpu_inflate=False, device_decode=False))[1]
         out["bam_file_host_inflate_only_reads_per_s"] = r[0] / r[1]
         host_only_rate = raw_bytes / r[1] / 1e6
         # sanity of the clock (VERDICT r02): the end-to-end inflate rate cannot exceed what the GPU kernel and the host's cores deliver together
-        out["bam_file"]["sanity"] = {"inflated_MB_per_s": raw_bytes / wall / 1e6, "gpu_kernel_MB_per_s_while_running": gpu_rate, "host_only_reader_MB_per_s": host_only_rate,
-                                     "ok": raw_bytes / wall / 1e6 <= gpu_rate + host_only_rate}
-        assert out["bam_file"]["sanity"]["ok"], out["bam_file"]["sanity"]
-        # the same path on a file that carries base qualities (the sample above has QUAL 0xff = absent): a third of the records, random Phred values.
-        # Such a file deflates ~1.5 : 1 instead of ~4 : 1; the decoder's rate follows the compressed bits, so records/s drop accordingly
-        try:
-            nq = max(1000, n // 3)
-            qpath = os.path.join(d, "sample_q.bam")
-            _, q_raw = write_bam_from_batch(qpath, batch.slice_records(0, nq), refs, lens, qual_seed=7)
-            q_size = os.path.getsize(qpath)
-            rq = min(_timed_bam_passes(qpath, opts, eng, gen, passes=3, batch_records=max(1000, nq // 4))[1:], key=lambda x: x[1])
-            out["bam_file_with_base_qualities"] = {"records": rq[0], "reads_per_s": rq[0] / rq[1], "bam_MB": q_size / 1e6, "inflated_MB": q_raw / 1e6,
-                                                   "deflate_ratio": q_raw / max(1, q_size), "inflated_MB_per_s": q_raw / rq[1] / 1e6, "bam_MB_per_s": q_size / rq[1] / 1e6,
-                                                   "qualities": "random Phred values, normal(18, 8) clipped to 1..50"}
-            os.remove(qpath)
-        except OSError:
-            pass
+        sane = {"inflated_MB_per_s": raw_bytes / med0[1] / 1e6, "gpu_kernel_MB_per_s_while_running": rate0, "host_only_reader_MB_per_s": host_only_rate,
+                "ok": raw_bytes / med0[1] / 1e6 <= rate0 + host_only_rate, "file": "the one without qualities"}
+        out["bam_file_without_base_qualities"]["sanity"] = sane
+        assert sane["ok"], sane
         # (b) host arrays in, no file
         eng.accumulate(False)
         eng.set_genome(*gen)
@@ -506,8 +553,16 @@ def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s
         out["host_arrays_signatures"] = eng.collect_counts()[0]
         out["resident_reads_per_s"] = resident_reads_per_s
     finally:
+        if old_chunk is None:
+            os.environ.pop("SVX_BAM_DEV_CHUNK_MB", None)
+        else:
+            os.environ["SVX_BAM_DEV_CHUNK_MB"] = old_chunk
+        for f in (path, qpath):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
         try:
-            os.remove(path)
             os.rmdir(d)
         except OSError:
             pass

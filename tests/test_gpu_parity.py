@@ -1258,6 +1258,126 @@ def test_device_bam_decode_equals_host_reader(tmp_path, monkeypatch, chunk_block
         dev.close()
 
 
+def _expected_query_slots(A):
+    """emission slots of a query-name batch recomputed from its flags, read ids and segment offsets (src/svim/SVIM_COLLECT.py:114-121: per analysed read
+    primary, good supplementaries.., segments)"""
+    n = len(A["flag"])
+    order, seg_order = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+    slot, i = 0, 0
+    while i < n:
+        j = i
+        while j < n and A["read_id"][j] == A["read_id"][i]:
+            j += 1
+        live = [k for k in range(i, j) if not (int(A["flag"][k]) & 0x8000)]
+        if live:
+            prim = [k for k in live if not (int(A["flag"][k]) & 2048)]
+            assert len(prim) == 1
+            sups = [k for k in live if int(A["flag"][k]) & 2048]
+            order[prim[0]] = slot
+            for q, k in enumerate(sups):
+                order[k] = slot + 1 + q
+            seg_order[prim[0]] = slot + 1 + len(sups)
+            assert int(A["seg_off"][prim[0] + 1]) - int(A["seg_off"][prim[0]]) == len(sups)
+            slot += len(sups) + 2
+        i = j
+    return order, seg_order
+
+
+@pytest.mark.parametrize("chunk_blocks", [None, "1", "2"])
+def test_device_bam_decode_queryname_mode_equals_host_reader(tmp_path, monkeypatch, chunk_blocks):
+    """Query-name-sorted input on the device-resident reader (src/svim/SVIM_COLLECT.py:8-41 bam_iterator, :96-129): read groups, the "exactly one good primary"
+    rule, SVX_FLAG_SKIP, the segment table made of the good supplementary RECORDS and the per-read emission slots come out as the host reader makes them
+    (csrc/bamio.cpp) - on a fuzz file with every kind of group (no primary, two primaries, unmapped or low-mapq primary, secondary records, low-mapq
+    supplementaries), whole file in one chunk and in chunks of one or two BGZF blocks (groups and records straddle chunk boundaries), small batches
+    (groups are never split), two passes."""
+    from svim_amd.bamio import NativeBam
+    if chunk_blocks:
+        monkeypatch.setenv("SVX_BAM_DEV_CHUNK_BLOCKS", chunk_blocks)
+    refs, lens = ["chr1", "chr2", "chr10"], [180000, 60000, 60000]
+    ref = synth.make_reference(21, list(zip(refs, lens)))
+    recs = synth.fuzz_split_reads(24, 420, refs, lens) + synth.planted_reads(25, 260, ref, refs, lens, n_sites=20, types=("DEL", "INS", "INV"))
+    rng = random.Random(8)
+    groups = {}
+    for a in recs:
+        groups.setdefault(a.query_name, []).append(a)
+    names = list(groups)
+    rng.shuffle(names)
+    out = []
+    for k, nm in enumerate(names):
+        g = groups[nm]
+        rng.shuffle(g)                                                     # the primary is not always first
+        if k % 17 == 3 and len(g) > 1:                                     # a second primary: the read is not analysed (:108)
+            g[1].flag &= ~(256 | 2048)
+        if k % 19 == 5:
+            g[0].flag |= 4                                                 # an unmapped record
+        if k % 23 == 7:
+            for a in g:
+                a.mapping_quality = 3                                      # below min_mapq
+        out += g
+    path = str(tmp_path / "q.bam")
+    records.write_bam(path, refs, lens, out, sort_order="queryname")
+    host = NativeBam(path, threads=2)
+    want, want_names = [], []
+    while True:
+        b, n = host.read_batch(61, 20, "queryname")
+        if n == 0:
+            break
+        A = host.batch_arrays(b)
+        nm = host.read_names()
+        want_names += [nm[int(i)] for i in A["read_id"]]
+        want.append(A)
+    host.close()
+    n_live = sum(int(((A["flag"] & 0x8000) == 0).sum()) for A in want)
+    n_rows = sum(int(A["seg_off"][-1]) for A in want)
+    assert n_live > 300 and n_rows > 100 and sum(len(A["flag"]) for A in want) > n_live + 50
+    dev = NativeBam(path, threads=2)
+    dev.set_device_decode(0)
+    for rep in range(2):
+        got, got_names = [], []
+        while True:
+            b, n = dev.read_batch(61, 20, "queryname")
+            if n == 0:
+                break
+            A = dev.batch_arrays(b)
+            nm = dev.read_names()
+            got_names += [nm[int(i)] for i in A["read_id"]]
+            got.append(A)
+            exp_o, exp_s = _expected_query_slots(A)
+            assert np.array_equal(A["order"], exp_o) and np.array_equal(A["seg_order"], exp_s), (chunk_blocks, rep)
+        assert got_names == want_names
+        cuts = np.cumsum([len(x["flag"]) for x in got])[:-1]
+        assert all(got_names[int(c) - 1] != got_names[int(c)] for c in cuts)      # a read's group is whole inside its batch
+        a, b = H.concat_batch_rows(got), H.concat_batch_rows(want)
+        assert len(a) == len(b)
+        bad = [k for k, (x, y) in enumerate(zip(a, b)) if x != y]
+        assert not bad, (chunk_blocks, rep, bad[:5], a[bad[0]][:5], b[bad[0]][:5])
+        if chunk_blocks is None:                                           # one chunk: the batches themselves are the host reader's
+            assert [len(A["flag"]) for A in got] == [len(A["flag"]) for A in want]
+            for A, B in zip(got, want):
+                assert np.array_equal(A["order"], B["order"]) and np.array_equal(A["seg_order"], B["seg_order"]) and np.array_equal(A["seg_off"], B["seg_off"])
+        dev.rewind()
+    dev.close()
+
+
+@pytest.mark.parametrize("name", ["fuzzA", "fuzzB", "fuzzC", "layoutD"])
+def test_queryname_golden_cases_through_a_bam_file_on_the_device_reader(eng, tmp_path, name):
+    """the reference's own outputs for query-name-sorted input (tests/golden/g2_collect.json.gz, generated by running src/svim/SVIM_COLLECT.py:96-129) through a BAM file,
+    the device-resident reader and svx_collect, in small batches"""
+    from svim_amd import SVIM_COLLECT
+    g = H.load("g2_collect.json.gz")
+    cases = [c for c in g["cases"] if c["name"] == name and c["mode"] == "queryname"]
+    text = [c for c in cases if c.get("sam")][0]["sam"]
+    bam = records.AlignmentFile(text=text)
+    recs = list(bam.fetch(until_eof=True))
+    path = str(tmp_path / "q.bam")
+    records.write_bam(path, bam.references, bam.lengths, recs, sort_order="queryname")
+    for case in cases:
+        o = H.options(case["options"])
+        sigs, bnds = SVIM_COLLECT._run_native(path, o, "queryname", batch_records=23)
+        assert [H.sig_row(s) for s in sigs] == case["signatures"]
+        assert [H.sig_row(s) for s in bnds] == case["bnds"]
+
+
 def test_device_bam_decode_regions_and_pipeline(eng, tmp_path, monkeypatch):
     """contig-range reading (svx_bam_seek + reference id limit) in device mode == host mode, out of file order; and BamPipeline on the device reader
     accumulates the same signature list as on the host reader."""

@@ -11,10 +11,12 @@ from svim_amd import _lib                                 # noqa: E402
 from svim_amd._lib import Inflater, bgzf_blocks           # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
+qual = 7 if len(sys.argv) > 2 and sys.argv[2] == "qual" else None           # "qual": the sample carries base qualities (literal-heavy blocks)
 b, genome, meta = devsynth.make_batch(n_reads=max(n, 1000), n50=20000, contig_len=max(3_000_000, 250 * n), seed=2, device="cuda:0")
 hb = b.slice_records(0, min(n, b.n_rec))
 path = "/tmp/bgzf_prof.bam"
-nrec, raw = harness.write_bam_from_batch(path, hb, ["chr1"], [int(genome.numel())])
+nrec, raw = harness.write_bam_from_batch(path, hb, ["chr1"], [int(genome.numel())], qual_seed=qual)
+print("sample: %d records%s" % (nrec, ", WITH base qualities (random Phred values)" if qual else ", QUAL absent (0xff)"))
 blocks = bgzf_blocks(path)
 out_bytes = sum(s for _, s in blocks)
 lib = _lib.lib()
