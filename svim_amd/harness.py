@@ -511,11 +511,8 @@ def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s
         out["bam_file_with_base_qualities"] = blk
         out["bam_file"] = blk
         os.remove(qpath)
-        # ---- side figure: the same records without qualities (QUAL 0xff; one chunk) ---------------------------------------------------------------------------
-        if old_chunk is None:
-            os.environ.pop("SVX_BAM_DEV_CHUNK_MB", None)
-        else:
-            os.environ["SVX_BAM_DEV_CHUNK_MB"] = old_chunk
+        # ---- side figure: the same records without qualities (QUAL 0xff), read in chunks of the same size: the cold pass touches all three chunk slots of the
+        # reader, so that the warm passes are warm (the slots rotate across rewind, csrc/bamio.cpp dev_last_slot) -----------------------------------------------
         t0 = time.perf_counter()
         _, raw_bytes = write_bam_from_device_batch(path, batch, refs, lens, 0, n)
         size = os.path.getsize(path)
@@ -527,7 +524,7 @@ def end_to_end_sample(batch, g_off, genome, opts, device=0, resident_reads_per_s
         rate0 = share0 * raw_bytes / max(inf0["gpu_kernel_ms"] * 1e-3, 1e-9) / 1e6
         out["bam_file_without_base_qualities"] = {"records": med0[0], "reads_per_s": med0[0] / med0[1], "first_pass_reads_per_s": cold0[0] / cold0[1], "bam_MB": size / 1e6,
                                                   "inflated_MB": raw_bytes / 1e6, "deflate_ratio": raw_bytes / max(1, size), "inflated_MB_per_s": raw_bytes / med0[1] / 1e6,
-                                                  "inflate_kernel_MB_per_s": rate0, "note": "QUAL 0xff (absent): the round-3 headline file; one chunk"}
+                                                  "inflate_kernel_MB_per_s": rate0, "chunk_MB": int(chunk_mb), "note": "QUAL 0xff (absent): the round-3 headline file"}
         # the same file with the host reader (inflate shared GPU / host cores, record decode on the host's cores) and with the host's cores alone
         r = _median_pass(_timed_bam_passes(path, opts, eng, gen, passes=3, batch_records=per_batch, device_decode=False))[1]
         out["bam_file_host_decode_reads_per_s"] = r[0] / r[1]

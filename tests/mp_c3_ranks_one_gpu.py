@@ -103,8 +103,27 @@ def main():
         cross = np.isin(osig.type[:osig.n], (_abi.SVX_BND, _abi.SVX_DUP_INT)) & (osig.contig2[:osig.n] >= 0)
         n_foreign = int((owner[osig.contig[:osig.n][cross]] != owner[osig.contig2[:osig.n][cross]]).sum())          # signatures whose two contigs belong to different ranks
         print(("C3_RANKS_OK %d %d %d %d" % (full.n, n_foreign, len(set(owner.tolist())), int(device_reader))) if verdict == "ok" else "C3_RANKS_FAIL " + verdict, flush=True)
+    # diagnostics for a failure: what every rank collected (signatures by type, inserted bases) next to what the oracle's list says it should have
+    n_own, n_seq = ad.collect_counts()
+    by_type = [0] * 6
+    if n_own:
+        cols, _, _ = ad.fetch_signatures(with_seq=False)
+        by_type = torch.bincount(cols["type"].long(), minlength=6).tolist()
     stats = [None] * world
-    dist.all_gather_object(stats, (n_regions, device_reader))
+    dist.all_gather_object(stats, (n_regions, device_reader, by_type, int(n_seq)))
+    if rank == 0 and verdict != "ok":
+        hb_tid = hb.arrays["tid"]
+        rec_of_slot = {int(o) >> 1: i for i, o in enumerate(hb.arrays["order"].tolist())}
+        want = [[0] * 6 for _ in range(world)]
+        want_seq = [0] * world
+        for i in range(osig.n):
+            rec = rec_of_slot.get(int(osig.key[i] >> np.uint64(33)))
+            r = int(owner[hb_tid[rec]]) if rec is not None else -1
+            if r >= 0:
+                want[r][int(osig.type[i])] += 1
+                want_seq[r] += int(osig.seq_off[i + 1] - osig.seq_off[i])
+        for r in range(world):
+            print("C3_DIAG rank %d collected %r seq %d | oracle says %r seq %d" % (r, stats[r][2], stats[r][3], want[r], want_seq[r]), flush=True)
     if rank == 0:
         print("C3_REGIONS " + " ".join(str(s[0]) for s in stats), flush=True)
     dist.barrier()
