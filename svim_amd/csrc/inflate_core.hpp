@@ -154,6 +154,9 @@ __device__ unsigned long long g_inf_prof[16];
 #ifndef INF_STAT
 #define INF_STAT(path, len, dist)       // host-side token statistics (tools/inflate_host_test.cpp --stats)
 #endif
+#ifndef INF_WIDE_STAT
+#define INF_WIDE_STAT(taken)            // host-side: a two-window step was tried and taken (1) / given up for an ordinary one (0)
+#endif
 
 // ---- input ----------------------------------------------------------------------------------------------------------------------------------------
 // 1 KiB of input per refill, 16 bytes per lane, loaded when a step starts in the last words of the buffer.  No prefetch register: a register with a load
@@ -436,9 +439,87 @@ INF_FN int inf_emit_bytes(InfState& s, uint64_t MT, const VecT& T, const VecT& D
     return 0;
 }
 
+// the same for a step that decoded TWO windows (bit offsets 0..63 and 64..127 of the step: token lane l of window w is token 64 w + l; MT / T / DV / E / EX per
+// window, EX of the second window already continues the first one's): at most 64 output bytes in all, one per lane
+template <class VecT>
+INF_FN int inf_emit_bytes2(InfState& s, uint64_t MT0, uint64_t MT1, const VecT& T0, const VecT& DV0, const VecT& E0, const VecT& EX0, const VecT& T1, const VecT& DV1,
+                           const VecT& E1, const VecT& EX1, uint32_t acc) {
+    InfScratch& sc = *s.sc;
+    W_VEC(uint32_t, tk); W_VEC(uint32_t, PK0); W_VEC(uint32_t, PK1); W_VEC(uint32_t, pk); W_VEC(uint32_t, pa); W_VEC(uint32_t, pb); W_VEC(uint32_t, val); W_VEC(uint32_t, ref);
+    W_VEC(uint32_t, un); W_VEC(uint32_t, idx);
+    W_FOR { if (W_LANE < 16) reinterpret_cast<uint32_t*>(sc.tokmap)[W_LANE] = 0u; }
+    W_FOR { if ((MT0 >> W_LANE) & 1ull) sc.tokmap[V(EX0)] = (uint8_t)(W_LANE + 1); }
+    W_FOR { if ((MT1 >> W_LANE) & 1ull) sc.tokmap[V(EX1)] = (uint8_t)(W_LANE + 65); }
+    W_FOR { V(tk) = (uint32_t)W_LANE < acc ? (uint32_t)sc.tokmap[W_LANE] : 0u; }
+    W_INCL_MAX_SCAN(tk);
+    W_FOR {
+        V(PK0) = (V(DV0) & 0xffffu) | (V(EX0) << 16) | ((V(T0) & INF_T_MATCH) ? 1u << 22 : 0u) | ((V(T0) & INF_T_FAR) ? 1u << 23 : 0u) | ((V(E0) & 255u) << 24);
+        V(PK1) = (V(DV1) & 0xffffu) | (V(EX1) << 16) | ((V(T1) & INF_T_MATCH) ? 1u << 22 : 0u) | ((V(T1) & INF_T_FAR) ? 1u << 23 : 0u) | ((V(E1) & 255u) << 24);
+        V(idx) = (V(tk) - 1u) & 63u;
+    }
+    W_BPERMUTE(pa, PK0, idx);
+    W_BPERMUTE(pb, PK1, idx);
+    W_FOR { V(pk) = V(tk) > 64u ? V(pb) : V(pa); }
+    uint64_t bad, wait;
+    W_BALLOT(bad, (uint32_t)W_LANE < acc && ((V(pk) >> 22) & 1u) && (V(pk) & 0xffffu) > s.pos + ((V(pk) >> 16) & 63u));
+    if (bad) return INF_E_DIST;                                   // a distance reaching in front of the output
+    W_BALLOT(wait, (uint32_t)W_LANE < acc && ((V(pk) >> 23) & 1u) && s.pos + (uint32_t)W_LANE - (V(pk) & 0xffffu) >= s.clean);
+    if (wait) { W_FENCE(); s.clean = s.flushed; }
+    W_FOR {
+        const uint32_t dist = V(pk) & 0xffffu;
+        const bool m = (uint32_t)W_LANE < acc && ((V(pk) >> 22) & 1u);
+        V(val) = V(pk) >> 24;
+        V(un) = 0u; V(ref) = 0u;
+        if (m) {
+            if (dist > (uint32_t)W_LANE) {                                                                    // source in front of the step
+                if ((V(pk) >> 23) & 1u) V(val) = s.out[s.pos + (uint32_t)W_LANE - dist];
+                else V(val) = sc.ring[inf_ridx(s, s.pos + (uint32_t)W_LANE - dist)];
+            } else { V(un) = 1u; V(ref) = (uint32_t)W_LANE - dist; }                                          // source is a byte of this step
+        }
+    }
+    for (;;) {
+        uint64_t U;
+        W_BALLOT(U, V(un) != 0u);
+        if (!U) break;
+        W_VEC(uint32_t, vv); W_VEC(uint32_t, v2); W_VEC(uint32_t, r2);
+        W_FOR { V(vv) = V(val) | (V(un) << 8); }
+        W_BPERMUTE(v2, vv, ref);
+        W_BPERMUTE(r2, ref, ref);
+        W_FOR { if (V(un)) { if (!((V(v2) >> 8) & 1u)) { V(val) = V(v2) & 255u; V(un) = 0u; } else V(ref) = V(r2); } }
+    }
+    W_FOR { if ((uint32_t)W_LANE < acc) sc.ring[inf_ridx(s, s.pos + (uint32_t)W_LANE)] = (uint8_t)V(val); }
+    return 0;
+}
+
+// every lane: the WHOLE token that would start at its bit offset, from the 32 input bits x there and the literal/length entry ee of its first code (literal, or
+// length + extra bits + distance code + extra bits: base values and extra-bit counts come from two small LDS tables).  32-bit arithmetic: a token of more than
+// 32 bits (long distance codes with many extra bits) is left to the serial path (INF_T_STOP)
+#define INF_TOKEN(sc, x_, ee_, t_out, dv_out)                                                                               \
+    {                                                                                                                       \
+        const uint32_t x = (x_), ee = (ee_), cl = ee >> 10;                                                                 \
+        uint32_t t, dv = 0;                                                                                                 \
+        if (ee & INF_SIMPLE) t = cl | (1u << 8);                                                                            \
+        else {                                                                                                              \
+            const uint32_t i = (ee & 511u) - 257u;                                   /* 0..28 for a length symbol */         \
+            const uint32_t ll = (sc).len_lut[i & 31u];                                                                      \
+            const uint32_t xb = ll >> 9;                                                                                    \
+            const uint32_t len = (ll & 511u) + ((x >> cl) & ((1u << xb) - 1u));                                             \
+            const uint32_t p2 = cl + xb;                                             /* <= 15 */                            \
+            const uint32_t de = (sc).fast_d[(x >> p2) & ((1u << INF_FAST_D) - 1u)];                                         \
+            const uint32_t dl = (sc).dist_lut[de & 31u];                                                                    \
+            const uint32_t dxb = dl >> 16, p3 = p2 + (de >> 10);                       /* p3 <= 23 */                        \
+            dv = (dl & 0xffffu) + ((x >> p3) & ((1u << dxb) - 1u));                                                         \
+            const bool ok = ee != 0u && i <= 28u && de != 0u && (de & 511u) < 30u && p3 + dxb <= 32u;                       \
+            t = ok ? ((p3 + dxb) | (len << 8) | INF_T_MATCH | (dv + len + INF_STEP_CAP <= INF_RING ? 0u : INF_T_FAR)) : INF_T_STOP; \
+        }                                                                                                                   \
+        t_out = t; dv_out = dv;                                                                                             \
+    }
+
 INF_FN int inf_codes(InfState& s) {
     InfScratch& sc = *s.sc;
     bool match_mode = false;                                       // the step before produced matches: decode whole tokens right away
+    bool wide = false;                                             // ... and few bytes per input bit (short matches between literals: base qualities): the
+                                                                   // next step looks at TWO windows, 128 bits (see below)
     for (;;) {
         if (s.bp > 32u * s.in_words + 64u) return INF_E_INPUT;
         inf_sync_input(s);
@@ -483,28 +564,76 @@ INF_FN int inf_codes(InfState& s) {
             // phase B: every lane decodes the WHOLE token that would start at its offset (literal, or length + extra bits + distance code + extra bits: base
             // values and extra-bit counts come from two small LDS tables), then the chain runs on over literals and matches alike
             W_VEC(uint32_t, T); W_VEC(uint32_t, DV);
-            W_FOR {
-                // 32-bit arithmetic on the low word: a token of more than 32 bits (long distance codes with many extra bits) is left to the serial path
-                const uint32_t x = V(XL);
-                const uint32_t ee = V(E), cl = ee >> 10;
-                uint32_t t, dv = 0;
-                if (ee & INF_SIMPLE) t = cl | (1u << 8);
-                else {
-                    const uint32_t i = (ee & 511u) - 257u;                                   // 0..28 for a length symbol
-                    const uint32_t ll = sc.len_lut[i & 31u];
-                    const uint32_t xb = ll >> 9;
-                    const uint32_t len = (ll & 511u) + ((x >> cl) & ((1u << xb) - 1u));
-                    const uint32_t p2 = cl + xb;                                             // <= 15
-                    const uint32_t de = sc.fast_d[(x >> p2) & ((1u << INF_FAST_D) - 1u)];
-                    const uint32_t dl = sc.dist_lut[de & 31u];
-                    const uint32_t dxb = dl >> 16, p3 = p2 + (de >> 10);                       // p3 <= 23
-                    dv = (dl & 0xffffu) + ((x >> p3) & ((1u << dxb) - 1u));
-                    const bool ok = ee != 0u && i <= 28u && de != 0u && (de & 511u) < 30u && p3 + dxb <= 32u;
-                    t = ok ? ((p3 + dxb) | (len << 8) | INF_T_MATCH | (dv + len + INF_STEP_CAP <= INF_RING ? 0u : INF_T_FAR)) : INF_T_STOP;
-                }
-                V(T) = t; V(DV) = dv;
-            }
+            W_FOR { INF_TOKEN(sc, V(XL), V(E), V(T), V(DV)) }
             INF_PROF(s, 2) INF_COUNT(s, 10, 1)
+#ifndef INF_NO_WIDE
+            if (wide && o == 0u) {
+                // Two windows per step.  A step costs about the same whatever it emits: the gather, the flush test, the scans and LDS round trips of the
+                // emission.  Literal-heavy streams (base qualities: short matches between literals, ~13 bytes per 64 bits) use a fifth of the emission's 64 lanes,
+                // so the step takes the next 64 bit offsets as well - lane l decodes the tokens at offsets l AND 64 + l, the chain runs through both windows,
+                // one emission writes up to 64 bytes.  If that would be more than 64 bytes the second window is dropped and the step goes on as an ordinary one.
+                W_VEC(uint32_t, XL1); W_VEC(uint32_t, E1); W_VEC(uint32_t, T1); W_VEC(uint32_t, DV1);
+                {
+                    const uint32_t d2 = (s.bp >> 5) + 2u, sh = s.bp & 31u;
+                    uint32_t w0, w1, w2, w3;
+                    INF_WORDS4(s, d2, w0, w1, w2, w3)
+                    W_FOR {
+                        const uint32_t b = sh + (uint32_t)W_LANE, i = b >> 5, f = b & 31u;
+                        const uint32_t a0 = i == 0u ? w0 : (i == 1u ? w1 : w2), a1 = i == 0u ? w1 : (i == 1u ? w2 : w3);
+                        V(XL1) = (uint32_t)((((uint64_t)a1 << 32) | a0) >> f);
+                        V(E1) = sc.fast_l[V(XL1) & ((1u << INF_FAST_L) - 1u)];
+                    }
+                }
+                W_FOR { INF_TOKEN(sc, V(XL1), V(E1), V(T1), V(DV1)) }
+                uint64_t M0 = 0, M1 = 0;
+                uint32_t p0 = 0, p1 = 0, tt = 0;                   // chain position inside the first / second window
+                bool stopped = false;
+                for (;;) {
+                    tt = W_READLANE(T, p0);
+                    if (tt & INF_T_STOP) { stopped = true; break; }
+                    M0 |= 1ull << p0;
+                    p0 += tt & 63u;
+                    if (p0 >= 64u) break;
+                }
+                if (!stopped) {
+                    p1 = p0 - 64u;
+                    for (;;) {
+                        tt = W_READLANE(T1, p1);
+                        if (tt & INF_T_STOP) break;
+                        M1 |= 1ull << p1;
+                        p1 += tt & 63u;
+                        if (p1 >= 64u) break;
+                    }
+                }
+                if (M0 && M1) {
+                    W_VEC(uint32_t, OL0); W_VEC(uint32_t, EX0); W_VEC(uint32_t, OL1); W_VEC(uint32_t, EX1);
+                    W_FOR { V(OL0) = ((M0 >> W_LANE) & 1ull) ? (V(T) >> 8) & 511u : 0u; V(OL1) = ((M1 >> W_LANE) & 1ull) ? (V(T1) >> 8) & 511u : 0u; }
+                    uint32_t acc0, acc1;
+                    W_EXCL_SCAN(EX0, OL0, acc0);
+                    W_EXCL_SCAN(EX1, OL1, acc1);
+                    if (acc0 + acc1 <= 64u) {
+                        if (s.pos + acc0 + acc1 > s.out_cap) return INF_E_OUTPUT;
+                        W_FOR { V(EX1) += acc0; }
+                        const int rc = inf_emit_bytes2(s, M0, M1, T, DV, E, EX0, T1, DV1, E1, EX1, acc0 + acc1);
+                        if (rc) return rc;
+                        s.pos += acc0 + acc1;
+                        s.bp += 64u + p1;
+                        uint64_t MMa, MMb;
+                        W_BALLOT(MMa, ((M0 >> W_LANE) & 1ull) && (V(T) & INF_T_MATCH));
+                        W_BALLOT(MMb, ((M1 >> W_LANE) & 1ull) && (V(T1) & INF_T_MATCH));
+                        match_mode = (MMa | MMb) != 0ull;
+                        wide = match_mode && 2u * (acc0 + acc1) <= 64u + p1;          // still at most half a byte per input bit
+                        W_FOR { if ((M0 >> W_LANE) & 1ull) INF_STAT(0, (V(T) & INF_T_MATCH) ? (V(T) >> 8) & 511u : 0u, V(DV)); }
+                        W_FOR { if ((M1 >> W_LANE) & 1ull) INF_STAT(0, (V(T1) & INF_T_MATCH) ? (V(T1) >> 8) & 511u : 0u, V(DV1)); }
+                        INF_PROF(s, 4) INF_COUNT(s, 14, __builtin_popcountll(M0) + __builtin_popcountll(M1))
+                        INF_WIDE_STAT(1)
+                        continue;
+                    }
+                }
+                INF_WIDE_STAT(0)
+                wide = false;                                      // (the ordinary step below decodes the first window again from T / DV, which are untouched)
+            }
+#endif
             uint64_t MT = 0;
             uint32_t o2 = o, t = 0;
 #define INF_HOP_B                                                                                                           \
@@ -553,6 +682,7 @@ INF_FN int inf_codes(InfState& s) {
                 s.pos += acc;
                 s.bp += o2;
                 match_mode = MM != 0ull;
+                wide = match_mode && o2 >= 48u && 2u * acc <= o2;       // few bytes per input bit, and the window was used up: two windows next time
                 W_FOR { if ((MT >> W_LANE) & 1ull) INF_STAT(0, (V(T) & INF_T_MATCH) ? (V(T) >> 8) & 511u : 0u, V(DV)); }
                 INF_COUNT(s, 14, __builtin_popcountll(MT))
                 continue;                                               // (a token the chain stopped at starts the next step)
@@ -560,7 +690,7 @@ INF_FN int inf_codes(InfState& s) {
             // the very first token is not a plain near match: the serial path below decodes it
             e = W_READLANE(E, o);
         }
-        match_mode = false;
+        match_mode = false; wide = false;
         s.bp += o;
         int sym;
         if (e) { sym = (int)(e & 511u); s.bp += e >> 10; }

@@ -234,6 +234,9 @@ class SvxAdapter(object):
         for k in SIG_COLS:
             setattr(v, k, _abi.ptr(cols[k]))
         v.seq_off, v.seq = _abi.ptr(seq_off), (_abi.ptr(seq) if with_seq else None)
+        # torch fills the destination tensors on ITS stream, libsvx copies into them on its own: without this the zero-fill of `seq` can land on top of
+        # the copied bases (seen as INS clusters merging on a busy GPU: tests/mp_c3_ranks_one_gpu.py)
+        torch.cuda.current_stream().synchronize()
         _check(self.eng.L.svx_collect_fetch(self.eng.ctx, 0, C.byref(v)), "svx_collect_fetch")
         return {k: c[:n] for k, c in cols.items()}, seq_off, seq[:nseq]
 
@@ -280,6 +283,7 @@ class SvxAdapter(object):
         for k in CLU_DTYPES:
             setattr(cv, k, _abi.ptr(cols[k]))
         cv.member_off, cv.members = _abi.ptr(member_off), _abi.ptr(members)
+        torch.cuda.current_stream().synchronize()             # (the allocations above belong to torch's stream: see fetch_signatures)
         _check(eng.L.svx_cluster_fetch(eng.ctx, C.byref(cv)), "svx_cluster_fetch")
         return {k: v[:n] for k, v in cols.items()}, members[:nm]
 

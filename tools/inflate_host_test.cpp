@@ -13,6 +13,8 @@ static inline void stat_token(int path, unsigned len, unsigned dist) {
     g_len[path][lb]++; g_dist[path][db]++;
 }
 #define INF_STAT(path, len, dist) stat_token(path, len, dist)
+static unsigned long long g_wide[2];                                                   // two-window steps: [given up, taken]
+#define INF_WIDE_STAT(taken) g_wide[taken]++;
 #include "inflate_core.hpp"
 #include <zlib.h>
 #include <cstdio>
@@ -57,7 +59,7 @@ int main(int argc, char** argv) {
         for (int it = 0; it < n; it++) {
             const size_t len = (size_t)(rnd() % 65281);
             std::vector<uint8_t> src(len);
-            const int kind = (int)(rnd() % 6);
+            const int kind = (int)(rnd() % 8);
             for (size_t i = 0; i < len; i++) {
                 switch (kind) {
                     case 0: src[i] = (uint8_t)rnd(); break;                                       // incompressible
@@ -65,7 +67,10 @@ int main(int argc, char** argv) {
                     case 2: src[i] = (uint8_t)(i % 7 == 0 ? rnd() : 'I'); break;                  // long runs
                     case 3: src[i] = (uint8_t)(i >= 300 && (rnd() % 5) ? src[i - 1 - rnd() % 299] : rnd()); break;   // many short matches
                     case 4: src[i] = (uint8_t)(i & 1 ? 0 : rnd() % 3); break;
-                    default: src[i] = (uint8_t)(33 + rnd() % 40); break;                          // quality-like
+                    case 5: src[i] = (uint8_t)(33 + rnd() % 40); break;                           // quality-like
+                    case 6: { const unsigned q = 2 + (unsigned)((rnd() % 12) + (rnd() % 12) + (rnd() % 12));                  // Phred values with a bell-shaped law: literals
+                              src[i] = (uint8_t)(i >= 40 && rnd() % 9 == 0 ? src[i - 3 - rnd() % 37] : q); break; }          //   with short matches in between (two-window steps)
+                    default: src[i] = (uint8_t)((i / 700) & 1 ? 1 + rnd() % 45 : (rnd() % 11 == 0 ? rnd() : "\x11\x12\x14\x18\x21\x22\x24\x28\x41\x42\x44\x48\x81\x82\x84\x88"[rnd() & 15])); break;   // BAM-like: packed bases, then qualities
                 }
             }
             const int level = (int)(rnd() % 10);
@@ -76,6 +81,7 @@ int main(int argc, char** argv) {
             bad += check(comp.data(), comp.size(), src, what); done++;
         }
         printf("fuzz: %d buffers, %d mismatches\n", done, bad);
+        printf("two-window steps: %llu taken, %llu given up\n", g_wide[1], g_wide[0]);
         return bad ? 1 : 0;
     }
     if (argc < 2) { fprintf(stderr, "usage\n"); return 2; }
@@ -106,6 +112,7 @@ int main(int argc, char** argv) {
         at += blen; blocks++; total += isize;
     }
     printf("%s: %d BGZF blocks, %zu bytes inflated, %d mismatches\n", argv[1], blocks, total, bad);
+    printf("two-window steps: %llu taken, %llu given up\n", g_wide[1], g_wide[0]);
     for (int p = 0; p < 2; p++) {
         printf("%s: %llu literals, %llu matches, %llu bytes\n  match length (log2 bins from 2):", p ? "serial tokens" : "token chain", g_tok[p][0], g_tok[p][1], g_bytes[p]);
         for (int i = 1; i < 10; i++) printf(" %llu", g_len[p][i]);
