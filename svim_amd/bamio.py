@@ -124,9 +124,10 @@ class NativeBam(object):
         def arr(ptr, count, dt, skip=0):
             out = np.zeros(count, dtype=dt)
             if count:
-                src = C.c_void_p(C.cast(ptr, C.c_void_p).value + skip * np.dtype(dt).itemsize)
+                base = C.cast(ptr, C.c_void_p).value
+                src = C.c_void_p(base + skip * np.dtype(dt).itemsize)
                 if self.L.svx_memcpy_d2h(out.ctypes.data_as(C.c_void_p), src, C.c_uint64(out.nbytes)) != 0:
-                    raise SvxError("svx_memcpy_d2h failed: %s" % self.L.svx_last_error().decode())
+                    raise SvxError("svx_memcpy_d2h of %d x %s from %#x + %d elements failed: %s" % (count, np.dtype(dt).name, base or 0, skip, self.L.svx_last_error().decode()))
             return out
         A = {}
         for k in ("flag", "tid", "pos", "mapq", "lseq", "read_id", "order", "seg_order"):

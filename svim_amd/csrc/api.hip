@@ -74,6 +74,8 @@ extern "C" void svx_ctx_destroy(svx_ctx* c) {
 extern "C" void* svx_stream(svx_ctx* c) { return (void*)c->stream; }
 // test / inspection helper: device memory -> host (a device-resident svx_batch handed out by the BAM reader can be looked at without torch)
 extern "C" int svx_memcpy_d2h(void* host_dst, const void* device_src, uint64_t bytes) {
+    // (a fault of a kernel launched EARLIER, on any stream of the process, surfaces at the next synchronising call: told apart from a bad copy here)
+    { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) return svx_fail(SVX_E_HIP, "a kernel launched before this copy faulted (svx_memcpy_d2h only noticed it)", __FILE__, __LINE__, e); }
     if (bytes) HIPCHK(hipMemcpy(host_dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost));
     return SVX_OK;
 }

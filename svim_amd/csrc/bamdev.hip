@@ -548,7 +548,7 @@ struct svx_devdec {
     hipStream_t stream = nullptr;
     svx_inflater* inf = nullptr;
     int32_t n_ref = 0;
-    DevBuf ref_len, contig_rank, ct_key, ct_tid, ct_names, ct_name_off, err, counters, crc_shift;
+    DevBuf ref_len, contig_rank, ct_key, ct_tid, ct_names, ct_name_off, err, counters, crc_shift, batch_cnt;
     uint32_t ct_mask = 0;
     DevBuf nt_key, nt_check, nt_id; uint32_t nt_cap = 0;
     std::vector<std::string> names;
@@ -619,7 +619,7 @@ void devdec_destroy(svx_devdec* d) {
     (void)hipStreamSynchronize(d->stream);
     if (d->inf) svx_inflater_destroy(d->inf);
     for (auto& c : d->chunk) c.release();
-    DevBuf* all[] = {&d->ref_len, &d->contig_rank, &d->ct_key, &d->ct_tid, &d->ct_names, &d->ct_name_off, &d->err, &d->counters, &d->crc_shift, &d->nt_key, &d->nt_check, &d->nt_id};
+    DevBuf* all[] = {&d->ref_len, &d->contig_rank, &d->ct_key, &d->ct_tid, &d->ct_names, &d->ct_name_off, &d->err, &d->counters, &d->crc_shift, &d->batch_cnt, &d->nt_key, &d->nt_check, &d->nt_id};
     for (auto* b : all) b->release();
     if (d->h_err) (void)hipHostFree(d->h_err);
     if (d->hbuf) (void)hipHostFree(d->hbuf);
@@ -1010,7 +1010,9 @@ int devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t* count_io, int 
     hipStream_t st = d->stream;
     if (mode == 1 && count > 0 && first + count < c.n_rec) {
         // a read's group is never split: the batch grows to the next group boundary (the chunk itself ends on one)
-        unsigned long long* nb = d->counters.as<unsigned long long>() + 18;
+        // (a counter of its own: devdec_load - which may be running on the loader thread for the NEXT chunk - clears all of d->counters)
+        SVXCHK(d->batch_cnt.reserve(64));
+        unsigned long long* nb = d->batch_cnt.as<unsigned long long>();
         const unsigned long long big = (unsigned long long)c.n_rec;
         d->h_cnt[18] = big;
         HIPCHK(hipMemcpyAsync(nb, &d->h_cnt[18], 8, hipMemcpyHostToDevice, st));

@@ -223,6 +223,7 @@ struct svx_bam {
 };
 
 static void dev_drop_prefetch(svx_bam* h);
+extern "C" long long svx_inflater_unregister_failures();
 
 // ---- BGZF ------------------------------------------------------------------------------------------------------------------
 struct RawBlock { const uint8_t* comp; size_t clen; uint32_t isize; size_t out_at; uint32_t crc; };
@@ -587,7 +588,9 @@ extern "C" void svx_bam_close(svx_bam* h) {
                             "record discovery %.3f, decode %.3f, names %.3f; %lld serial fallbacks\n", (long long)ds.blocks, (long long)ds.gpu_blocks, (long long)ds.cpu_blocks, ds.bytes / 1e6, (long long)ds.records, ds.t_stage,
                     ds.t_inflate_wait, ds.inflate_kernel_ms, ds.t_discover, ds.t_decode, ds.t_names, (long long)ds.fallbacks);
         }
+        const long long before = svx_inflater_unregister_failures();
         devdec_destroy(h->dev); h->dev = nullptr;
+        if (svx_inflater_unregister_failures() != before) h->map = nullptr;      // the file's registration with the GPU could not be removed: the mapping stays (see bgzf.hip)
     }
     if (h->map) munmap((void*)h->map, h->map_len);
     if (h->fd >= 0) close(h->fd);

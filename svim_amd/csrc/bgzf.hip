@@ -4,6 +4,7 @@
 //
 // Replaces: zlib inflate() under htslib's bgzf_read_block (the reference reads BAM through pysam.AlignmentFile, SVIM_COLLECT.py:132-137).
 #include "common.hpp"
+#include <atomic>
 #include "inflate_core.hpp"
 #include <mutex>
 #include <cstdlib>
@@ -62,6 +63,19 @@ extern "C" int svx_inflater_create(int device, svx_inflater** out) {
     return SVX_OK;
 }
 
+// A registration that could NOT be removed must never meet other memory at its address: the runtime would go on treating that address range as page-locked with the old
+// physical pages (a later pageable copy into memory the allocator placed there faults).  The failures are counted; the owner of the memory (bamio.cpp: the file
+// mapping) keeps it mapped for the life of the process when the count moved.
+static std::atomic<long long> g_unregister_failures{0};
+extern "C" long long svx_inflater_unregister_failures() { return g_unregister_failures.load(); }
+static void inf_unregister(void* p) {
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (g_unregister_failures.fetch_add(1) == 0) fprintf(stderr, "libsvx: hipHostUnregister(%p) failed (%s): the memory stays mapped\n", p, hipGetErrorString(e));
+    }
+}
+
 extern "C" void svx_inflater_destroy(svx_inflater* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
@@ -72,7 +86,7 @@ extern "C" void svx_inflater_destroy(svx_inflater* f) {
         for (auto& e : sl.ev) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(sl.stream);
     }
-    for (auto& pr : f->pinned) (void)hipHostUnregister(pr.first);
+    for (auto& pr : f->pinned) inf_unregister(pr.first);
     delete f;
 }
 
@@ -105,7 +119,7 @@ extern "C" int svx_inflater_pin(svx_inflater* f, void* p, uint64_t bytes) {
         const char* a = (const char*)pr.first; const char* b = (const char*)p;
         if (b < a + pr.second && a < b + bytes) {                                   // overlaps an older registration: drop that one
             for (auto& sl : f->slot) if (sl.busy) { (void)hipStreamSynchronize(sl.stream); }
-            (void)hipHostUnregister(pr.first);
+            inf_unregister(pr.first);
             f->pinned.erase(f->pinned.begin() + (long)i); i--;
         }
     }
@@ -123,7 +137,7 @@ extern "C" int svx_inflater_unpin(svx_inflater* f, void* p) {
     for (size_t i = 0; i < f->pinned.size(); i++) {
         if (f->pinned[i].first != p) continue;
         for (auto& sl : f->slot) if (sl.busy) (void)hipStreamSynchronize(sl.stream);
-        if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+        inf_unregister(p);
         f->pinned.erase(f->pinned.begin() + (long)i);
         break;
     }

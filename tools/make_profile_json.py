@@ -40,7 +40,14 @@ with open(os.path.join(root, "traffic_k_cigar_scan.json"), "w") as fh:
 edit = {"measured_at_commit": commit, "bench_steps_in_run": steps, "workload_cigar_ops": n_ops,
         "source": "profiles/%s_pmc_SQ_INSTS_VALU_SQ_WAVE_CY.csv + profiles/%s_pmc_SQ_ACTIVE_INST_VALU_SQ_I.csv (rocprofv3 --kernel-trace --pmc ..., totals over the run "
                   "divided by its %d bench steps)" % (tag, tag, steps), "per_step": {}}
-for kern in ("void k_edit_bands<2>", "void k_edit_fulls<2>"):
+# every instantiation of the two fused launches (k_edit_bands<P, QM>: P bit planes, QM = widest window the kernel is built for; k_edit_fulls<P>)
+kerns = set()
+for name in ("%s_pmc_SQ_INSTS_VALU_SQ_WAVE_CY.csv" % tag, "%s_pmc_SQ_ACTIVE_INST_VALU_SQ_I.csv" % tag):
+    for r in rows(name):
+        k = r["Kernel"].strip('"')
+        if "k_edit_bands<" in k or "k_edit_fulls<" in k:
+            kerns.add(k)
+for kern in sorted(kerns):
     d = {}
     for name, ctrs in (("%s_pmc_SQ_INSTS_VALU_SQ_WAVE_CY.csv" % tag, ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")),
                        ("%s_pmc_SQ_ACTIVE_INST_VALU_SQ_I.csv" % tag, ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"))):
