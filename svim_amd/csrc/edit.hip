@@ -678,8 +678,8 @@ __device__ __forceinline__ void planes8(uint32_t w, uint32_t (&out)[P]) {       
     }
 }
 
-// bit-plane words of 32 rows given as 4 packed words.  Deliberately NOT inlined: unrolled into the Q-word set-up loops it drives the
-// kernels' register allocation up (155 -> fewer waves per SIMD) for code that runs once per pair / once per 32 columns.
+// bit-plane words of 32 rows given as 4 packed words.  Inlined: as a call it pins the callers' register arrays to the registers the calling
+// convention preserves (the staircase kernel went from 147 to 264 VGPRs with the call in its drop).
 template <int P>
 __device__ __forceinline__ void planes32(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t (&out)[P]) {
     uint32_t e0[P], e1[P], e2[P], e3[P];
