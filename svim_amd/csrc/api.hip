@@ -24,11 +24,15 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
     svx_ctx* c = new svx_ctx();
     c->device = device_ordinal;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount; }
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& ev : c->ev) HIPCHK(hipEventCreate(&ev));
     {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        {   // the main stream (SVX_MAIN_PRIO=high: A/B switch for the small kernels that run beside the early full matrices)
+            const char* pm = getenv("SVX_MAIN_PRIO");
+            if (pm && !strcmp(pm, "high")) HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+            else HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        }
         // Which kind of edit-distance launch gets the high-priority streams.  The full-matrix launches hold the longest serial chains (a pair of 5000 x 5000
         // symbols is 5000 dependent steps whatever the width) and, since the band windows narrow, most of the work: they go first, the band launches fill in
         // (configs[1]: 16.9 ms against 17.9 the other way round, profiles/r04_edit_prio_ab.txt).  SVX_EDIT_PRIO=band / equal: A/B switch.
@@ -36,7 +40,11 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
         const int mode = pe && !strcmp(pe, "band") ? 0 : (pe && !strcmp(pe, "equal") ? 2 : 1);
         for (int k = 0; k < SVX_N_AUX; k++) {
             const bool band_stream = k < 2 || k == 5;
-            const int prio = mode == 2 ? least : ((band_stream == (mode == 0)) ? greatest : least);
+            int prio = mode == 2 ? least : ((band_stream == (mode == 0)) ? greatest : least);
+            if (k == 6) {   // the early full matrices run beside the main stream's small kernels (sort passes of the other pairs): SVX_EDIT_EARLY_PRIO=high / normal / low
+                const char* pq = getenv("SVX_EDIT_EARLY_PRIO");
+                prio = pq && !strcmp(pq, "high") ? greatest : (pq && !strcmp(pq, "low") ? least : (least + greatest) / 2);
+            }
             HIPCHK(hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, prio));
         }
     }

@@ -1619,9 +1619,9 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         HIPCHK(hipMemsetAsync(c->e_hist.p, 0, 256 * 8, st));
         const long long stride = (n_rest + PILOT_MAX - 1) / PILOT_MAX, n_samp = (n_rest + stride - 1) / stride;
         k_edit_pilot<<<(unsigned)((n_samp + 255) / 256), 256, 0, st>>>(n_first, n_rest, stride, desc, scratch, c->e_hist.as<unsigned long long>());
+        SVXCHK(finish_early());                               // (before the copy: a copy into pageable memory holds the host until the stream gets there)
         unsigned long long h[256];
         HIPCHK(hipMemcpyAsync(h, c->e_hist.p, sizeof h, hipMemcpyDeviceToHost, st));
-        SVXCHK(finish_early());
         HIPCHK(hipStreamSynchronize(st));
         guess = guess_from_histogram(h, guess);
         c->edit_guess_last = guess;
