@@ -24,15 +24,11 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
     svx_ctx* c = new svx_ctx();
     c->device = device_ordinal;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount; }
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& ev : c->ev) HIPCHK(hipEventCreate(&ev));
     {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        {   // the main stream (SVX_MAIN_PRIO=high: A/B switch for the small kernels that run beside the early full matrices)
-            const char* pm = getenv("SVX_MAIN_PRIO");
-            if (pm && !strcmp(pm, "high")) HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
-            else HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        }
         // Which kind of edit-distance launch gets the high-priority streams.  The full-matrix launches hold the longest serial chains (a pair of 5000 x 5000
         // symbols is 5000 dependent steps whatever the width) and, since the band windows narrow, most of the work: they go first, the band launches fill in
         // (configs[1]: 16.9 ms against 17.9 the other way round, profiles/r04_edit_prio_ab.txt).  SVX_EDIT_PRIO=band / equal: A/B switch.
@@ -40,11 +36,7 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
         const int mode = pe && !strcmp(pe, "band") ? 0 : (pe && !strcmp(pe, "equal") ? 2 : 1);
         for (int k = 0; k < SVX_N_AUX; k++) {
             const bool band_stream = k < 2 || k == 5;
-            int prio = mode == 2 ? least : ((band_stream == (mode == 0)) ? greatest : least);
-            if (k == 6) {   // the early full matrices run beside the main stream's small kernels (sort passes of the other pairs): SVX_EDIT_EARLY_PRIO=high / normal / low
-                const char* pq = getenv("SVX_EDIT_EARLY_PRIO");
-                prio = pq && !strcmp(pq, "high") ? greatest : (pq && !strcmp(pq, "low") ? least : (least + greatest) / 2);
-            }
+            const int prio = mode == 2 ? least : ((band_stream == (mode == 0)) ? greatest : least);
             HIPCHK(hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, prio));
         }
     }
@@ -66,7 +58,7 @@ extern "C" void svx_ctx_destroy(svx_ctx* c) {
     c->sig.release(); c->bnd.release(); c->raw_sig.release(); c->raw_bnd.release();
     DevBuf* bufs[] = {&c->counters, &c->raw_indel, &c->shard_cnt, &c->rec_geom, &c->seg_geom, &c->seg_ws, &c->tmp0, &c->tmp1, &c->tmp2, &c->tmp3, &c->tmp4, &c->tmp5, &c->sort_tmp, &c->scan_tmp,
                       &c->g_off, &c->g_codes, &c->c_rank, &c->k_hi, &c->k_lo, &c->k_idx, &c->k_hi2, &c->k_lo2, &c->k_idx2, &c->part_flag, &c->part_id,
-                      &c->part_start, &c->part_meta, &c->samp_chain, &c->samp_idx, &c->large_list, &c->samp_stream, &c->cell_shards, &c->mt_words, &c->samp_meta, &c->samp_table, &c->samp_runs, &c->pair_off, &c->ed, &c->work, &c->stage, &c->stage_members, &c->labels, &c->e_words, &c->e_off, &c->e_scratch, &c->e_rec, &c->e_hist, &c->e_desc, &c->e_key, &c->e_val, &c->e_slot, &c->e_fail, &c->e_big_list, &c->e_big_state, &c->e_big_off, &c->e_work, &c->e_sort_tmp, &c->e_retry[0], &c->e_retry[1], &c->e_retry[2], &c->prepack_tmp,
+                      &c->part_start, &c->part_meta, &c->samp_chain, &c->samp_idx, &c->large_list, &c->samp_stream, &c->cell_shards, &c->mt_words, &c->samp_meta, &c->samp_table, &c->samp_runs, &c->pair_off, &c->ed, &c->work, &c->stage, &c->stage_members, &c->labels, &c->e_words, &c->e_off, &c->e_scratch, &c->e_rec, &c->e_hist, &c->e_desc, &c->e_key, &c->e_val, &c->e_slot, &c->e_fail, &c->e_big_list, &c->e_big_state, &c->e_big_off, &c->e_retry[0], &c->e_retry[1], &c->e_retry[2], &c->prepack_tmp,
                       &c->clu.type, &c->clu.contig, &c->clu.start, &c->clu.end, &c->clu.contig2, &c->clu.start2, &c->clu.end2, &c->clu.aux, &c->clu.score,
                       &c->clu.std_span, &c->clu.std_pos, &c->clu.size, &c->clu.member_off, &c->clu.members, &c->clu.part_index};
     for (auto* b : bufs) b->release();

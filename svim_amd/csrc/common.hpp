@@ -119,14 +119,14 @@ struct DevClusters {
     DevBuf type, contig, start, end, contig2, start2, end2, aux, score, std_span, std_pos, size, member_off, members, part_index;
 };
 
-#define SVX_N_AUX 7
+#define SVX_N_AUX 6
 
 struct svx_ctx {
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev[24];
-    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] band classes, [2..3] full-matrix classes (the high-priority ones: api.hip); [4] low: linkage of the partitions that need no edit distances; [5] with the band classes: the widest band classes of round 0; [6] with the full-matrix classes: the early full matrices (pairs whose length gap exceeds every band)
+    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] band classes, [2..3] full-matrix classes (the high-priority ones: api.hip); [4] low: linkage of the partitions that need no edit distances; [5] high: the widest band classes of round 0
     // device copies of a host-resident batch
     std::vector<DevBuf> batch_bufs;
     // COLLECT results
@@ -152,7 +152,7 @@ struct svx_ctx {
     long long stream_start[SVX_NTYPES] = {0, 0, 0, 0, 0, 0}, stream_end[SVX_NTYPES] = {0, 0, 0, 0, 0, 0};              // of the last svx_cluster
     DevBuf mt_words; long long mt_have = 0;      // tempered MT19937 words after seed(1524), kept across calls
     DevBuf pair_off, ed, work, stage, stage_members, labels;
-    DevBuf e_words, e_off, e_scratch, e_rec, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off, e_work, e_sort_tmp;
+    DevBuf e_words, e_off, e_scratch, e_rec, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off;
     DevBuf e_retry[3];              // per-class retry lists of the edit-distance rounds (rotating)     // edit-distance pipeline
     DevClusters clu;
     // Band speculation: a pair without a useful distance bound starts in the band sized for edit_guess * (core length) differences beyond
@@ -173,8 +173,6 @@ struct svx_ctx {
 // ---- primitives (prims.hip, scan.hpp: hand-written radix sort and scan) -------------------------------
 int svx_sort_pairs_u64(svx_ctx* c, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                        int64_t n, int begin_bit, int end_bit);
-int svx_sort_pairs_u64_on(svx_ctx* c, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                          int64_t n, int begin_bit, int end_bit, hipStream_t stream, DevBuf& tmp);
 int svx_exclusive_scan_i64(svx_ctx* c, const int64_t* in, int64_t* out, int64_t n);   // out[n] NOT written
 int svx_exclusive_scan_i64_on(svx_ctx* c, const int64_t* in, int64_t* out, int64_t n, hipStream_t stream, DevBuf& tmp);
 int svx_exclusive_scan_i32_to_i64(svx_ctx* c, const int32_t* in, int64_t* out, int64_t n);

@@ -322,16 +322,13 @@ __global__ __launch_bounds__(256) void k_hap_pack(long long n_rec, PairSource sr
 // G lanes per pair (64 / G pairs per wave): the kernel is bound by the latency of its dependent loads, so what counts is the number of
 // pairs in flight, not the symbols compared per step
 template <int G>
-__global__ __launch_bounds__(256) void k_edit_prep(long long w0, long long n_work, PairSource src, const uint32_t* packed, PairDesc* desc,
+__global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource src, const uint32_t* packed, PairDesc* desc,
                                                    uint64_t* sort_key, uint32_t* sort_val, int32_t* ed, unsigned long long* cells, int shift_bounds) {
-    // pairs w0 .. w0 + n_work - 1.  shift_bounds: 1 = bounds from the shift-justified and the left-justified alignment, 0 = the left-justified one only,
-    // -1 = none (pairs whose length gap alone sends them to a full matrix: nothing would look at the bound)
     const int wave_lane = lane_id();
     const int sg = wave_lane / G, lane = wave_lane % G;                   // sub-group of the wave / lane inside it
     const unsigned long long sg_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (sg * G);
-    const long long wl = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + sg;
-    if (wl >= n_work) return;
-    const long long w = w0 + wl;
+    const long long w = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + sg;
+    if (w >= n_work) return;
     HapView A, B;
     int sshift;
     src.views(w, A, B, sshift);
@@ -416,9 +413,9 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long w0, long long n_wor
     // the core of the EARLIER insertion is the one whose inserted sequence comes first: its symbols line up with the other core's `shift` further right
     const bool pat_earlier = (sshift > 0) == a_short;
     int ub = pd.n;                                                          // substitute the shorter core, insert the rest
-    if (shift_bounds > 0 && shift > 0 && shift < (pat_earlier ? pd.n : pd.m)) ub = pat_earlier ? bound_at(0, shift) : bound_at(shift, 0);
+    if (shift_bounds && shift > 0 && shift < (pat_earlier ? pd.n : pd.m)) ub = pat_earlier ? bound_at(0, shift) : bound_at(shift, 0);
     if (ub > pd.n) ub = pd.n;
-    if (shift_bounds >= 0 && 4 * ub > pd.n) { const int u = bound_at(0, 0); ub = u < ub ? u : ub; }         // (also the only one tried for insertions at the same position)
+    if (4 * ub > pd.n) { const int u = bound_at(0, 0); ub = u < ub ? u : ub; }         // (also the only one tried for insertions at the same position)
     const int zero = (A.flags | B.flags) & HAP_ZERO, other = (A.flags | B.flags) & HAP_OTHER;      // of the whole records: conservative
     if (lane == 0) {
         pd.ub = ub;
@@ -429,10 +426,9 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long w0, long long n_wor
 }
 
 // first class of every pair + its sort key (one thread per pair)
-__global__ void k_edit_classify(long long w0, long long n_work, PairDesc* desc, uint64_t* sort_key, uint32_t* sort_val, int force_full, float guess_frac, int few_pairs) {
-    const long long wl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wl >= n_work) return;
-    const long long w = w0 + wl;
+__global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort_key, uint32_t* sort_val, int force_full, float guess_frac, int few_pairs) {
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_work) return;
     const PairDesc pd = desc[w];
     if (pd.cls == -1) return;                               // empty core: answered by k_edit_prep, key already written
     int cls;
@@ -628,7 +624,7 @@ __device__ __forceinline__ void d_edit_band(long long blk, long long count, cons
 // length like the work it stands for.  No state is carried from one call to the next; routing only, results never depend on it.
 #define PILOT_MAX 16384
 #define PILOT_PREFIX 384
-__global__ __launch_bounds__(256) void k_edit_pilot(long long w0, long long n_work, long long stride, const PairDesc* desc, const uint32_t* scratch, unsigned long long* hist) {
+__global__ __launch_bounds__(256) void k_edit_pilot(long long n_work, long long stride, const PairDesc* desc, const uint32_t* scratch, unsigned long long* hist) {
     __shared__ unsigned long long h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -637,7 +633,7 @@ __global__ __launch_bounds__(256) void k_edit_pilot(long long w0, long long n_wo
     bool live = w < n_work;
     int full_m = 0;
     if (live) {
-        pd = desc[w0 + w];
+        pd = desc[w];
         full_m = pd.m;
         // '=' is the band kernel's filler symbol; short cores do not speculate; a large shift does not fit the pilot's band
         live = pd.cls != -1 && !(pd.cls & CLS_ZERO) && pd.m >= 128 && CLS_SHIFT(pd.cls) <= 12;
@@ -1331,29 +1327,6 @@ __global__ void k_slots(long long n_work, PairSource src, long long* slot_of) {
     if (w < n_work) slot_of[w] = src.slot(w);
 }
 
-// ---- early full matrices: the pairs whose LENGTH GAP alone exceeds every band -----------------------------------------------------------------
-// n - m = |len_a - len_b| does not change when the common prefix / suffix is trimmed, so it is known before k_edit_prep has read a symbol: a pair with
-// band_class_for(gap + 1) == CLS_FULL goes to a full-matrix class whatever its upper bound or the speculation say (k_edit_classify: need_window and the
-// speculated window are both >= gap + 1), and so does a pair with a '=' symbol.  These pairs are most of the full-matrix work.  The work list is
-// partitioned (stable: flags -> scan -> scatter) so that they come first; they are trimmed, classified, sorted and LAUNCHED while the bounds, the pilot and
-// the sort of the other pairs are still being computed - the full-matrix kernels no longer wait for the 2.5 ms the band classes need in front of them.
-__global__ void k_edit_gap_flags(long long n_work, PairSource src, int64_t* flag) {
-    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w > n_work) return;
-    if (w == n_work) { flag[w] = 0; return; }
-    HapView A, B;
-    int sshift;
-    src.views(w, A, B, sshift);
-    const int gap = A.len > B.len ? A.len - B.len : B.len - A.len;
-    flag[w] = (((A.flags | B.flags) & HAP_ZERO) || band_class_for(gap + 1) == CLS_FULL) ? 1 : 0;
-}
-__global__ void k_edit_gap_scatter(long long n_work, const EditWork* in, const int64_t* flag, const int64_t* pos, EditWork* out) {
-    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_work) return;
-    const long long n_first = pos[n_work];
-    out[flag[w] ? pos[w] : n_first + (w - pos[w])] = in[w];
-}
-
 // class boundaries in the sorted key array: first index whose sort class >= c, for c = 0..N_SORT_CLASSES
 __global__ void k_class_bounds(const uint64_t* keys, long long n, long long* bounds) {
     const int c = threadIdx.x;
@@ -1447,9 +1420,9 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     const int T = 256;
     PairSource src = src_in;
     src.n_pairs = n_work;
-    const size_t WC_OFF = 128 + MAX_ROUNDS * N_SORT_CLASSES, WC_PER_LAUNCH = 2 * WC_SHARDS, EARLY_OFF = WC_OFF + MAX_ROUNDS * 2 * WC_PER_LAUNCH, CNT_WORDS = EARLY_OFF + N_SORT_CLASSES + 8;
+    const size_t WC_OFF = 128 + MAX_ROUNDS * N_SORT_CLASSES, WC_PER_LAUNCH = 2 * WC_SHARDS, CNT_WORDS = WC_OFF + MAX_ROUNDS * 2 * WC_PER_LAUNCH;
     SVXCHK(c->e_fail.reserve(CNT_WORDS * 8));
-    unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..72] class bounds of round 0 (first [16..31] the span shards), [128 + 64 r ..] retry counters written by round r, [WC_OFF ..] word-column counters per (round, kind), [EARLY_OFF ..] class bounds of the early full matrices
+    unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..40] class bounds of round 0 (first [16..31] the span shards), [128 + 64 r ..] retry counters written by round r, [WC_OFF ..] word-column counters per (round, kind)
     HIPCHK(hipMemsetAsync(cnt, 0, CNT_WORDS * 8, st));
     // 1. packed store: one record per string / signature
     src.radius = 0;
@@ -1486,10 +1459,10 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         HIPCHK(hipGetLastError());
     }
     SVXCHK(c->e_desc.reserve((size_t)n_work * sizeof(PairDesc)));
-    SVXCHK(c->e_key.reserve((size_t)(n_work + 1) * 8 * 2)); SVXCHK(c->e_val.reserve((size_t)n_work * 4 * 2));
+    SVXCHK(c->e_key.reserve((size_t)n_work * 8 * 2)); SVXCHK(c->e_val.reserve((size_t)n_work * 4 * 2));
     SVXCHK(c->e_slot.reserve((size_t)n_work * 8));
     SVXCHK(c->e_big_list.reserve((size_t)n_work * 4 + 64));
-    uint64_t* key_a = c->e_key.as<uint64_t>(); uint64_t* key_b = key_a + n_work + 1;
+    uint64_t* key_a = c->e_key.as<uint64_t>(); uint64_t* key_b = key_a + n_work;
     uint32_t* val_a = c->e_val.as<uint32_t>(); uint32_t* val_b = val_a + n_work;
     long long* slot_of = c->e_slot.as<long long>();
     PairDesc* desc = c->e_desc.as<PairDesc>();
@@ -1498,128 +1471,18 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     // 2. trim + classify
     int shift_bounds = 1;                                   // SVX_EDIT_SHIFT_BOUNDS=0: upper bounds from the left-justified alignment only (A/B switch)
     if (const char* e = getenv("SVX_EDIT_SHIFT_BOUNDS")) shift_bounds = atoi(e) == 0 ? 0 : 1;
-    const bool profile = getenv("SVX_EDIT_PROFILE") != nullptr, serial = getenv("SVX_EDIT_SERIAL") != nullptr;
-    long long few_pairs = 2048;                             // SVX_EDIT_FEW_PAIRS: calls with at most this many pairs take the low-latency route (0 = never)
-    if (const char* e = getenv("SVX_EDIT_FEW_PAIRS")) few_pairs = atoll(e);
-    int narrow_windows = 1;                                 // SVX_EDIT_NARROW=0: static staircase windows (A/B switch; results are the same either way)
-    if (const char* e = getenv("SVX_EDIT_NARROW")) narrow_windows = atoi(e) == 0 ? 0 : 1;
-    hipStream_t band_st[2] = {c->aux[0], c->aux[1]};     // A/C/G/T-only pairs, generic pairs
-    hipStream_t full_st[2] = {c->aux[2], c->aux[3]};     // even / odd rounds
-    // full-matrix launch of one alphabet from per-class segments (lo / cn indexed by sort class) of `lst`
-    static const int order[14] = {CLS_FULL, CLS_WIDE0 + 3, CLS_WIDE12 + 3, CLS_WIDE0 + 2, CLS_WIDE12 + 2, CLS_WIDE0 + 1, CLS_WIDE12 + 1, CLS_WIDE0, CLS_WIDE12,
-                                  CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};     // longest serial chains first
-    auto launch_fulls = [&](int generic, const long long* lo, const long long* cn_of, const uint32_t* lst, hipStream_t fs, unsigned long long* wc, int label) -> int {
-        const int base = GENERIC_BASE * generic;
-        FusedTab tf; memset(&tf, 0, sizeof tf);
-        unsigned nblk = 0;
-        auto class_threads = [&](int cls, long long cn) -> long long {
-            if (cls == CLS_FULL) return cn * 64;
-            if (cls >= CLS_WIDE12) return cn * (2 << (cls - CLS_WIDE12));
-            if (cls >= CLS_WIDE0) return cn * (2 << (cls - CLS_WIDE0));
-            return cn;
-        };
-        // low-latency form of a long class: KIND_LL + words per lane (64 lanes), 0 = none
-        auto ll_kind = [](int cls) -> int {
-            if (cls == CLS_WIDE0 + 2 || cls == CLS_WIDE12 + 2) return KIND_LL + 2;       // <= 4096 rows
-            if (cls == CLS_WIDE12 + 3) return KIND_LL + 3;                              // <= 6144
-            if (cls == CLS_WIDE0 + 3) return KIND_LL + 4;                               // <= 8192
-            return 0;
-        };
-        long long waves_normal = 0, waves_ll = 0;
-        for (int k = 0; k < 14; k++) {
-            const long long cn = cn_of[base + order[k]];
-            if (cn <= 0) continue;
-            waves_normal += (class_threads(order[k], cn) + 63) / 64;
-            waves_ll += ll_kind(order[k]) ? cn : (class_threads(order[k], cn) + 63) / 64;
-        }
-        static long long ll_waves = 0;                                       // waves per SIMD below which the launch counts as latency-bound
-        if (!ll_waves) { const char* e = getenv("SVX_EDIT_LL_WAVES"); ll_waves = e && atoi(e) > 0 ? atoi(e) : 2; }
-        const bool low_latency = !getenv("SVX_EDIT_NO_LL") && waves_normal <= ll_waves * 4 * (long long)c->n_cu && waves_ll <= 8 * 4 * (long long)c->n_cu;
-        for (int k = 0; k < 14; k++) {
-            const int cls = order[k];
-            const long long cn = cn_of[base + cls];
-            if (cn <= 0) continue;
-            const int ll = low_latency ? ll_kind(cls) : 0;
-            const long long threads = ll ? cn * 64 : class_threads(cls, cn);
-            tf.kind[tf.n] = ll ? ll : cls; tf.lo[tf.n] = lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
-            nblk += (unsigned)((threads + T - 1) / T); tf.n++;
-        }
-        tf.first_block[tf.n] = nblk;
-        if (!tf.n) return SVX_OK;
-        if (serial) HIPCHK(hipEventRecord(c->ev[6], fs));
-        if (generic) k_edit_fulls<4><<<nblk, T, 0, fs>>>(tf, lst, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc);
-        else k_edit_fulls<2><<<nblk, T, 0, fs>>>(tf, lst, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc);
-        HIPCHK(hipGetLastError());
-        if (serial) {
-            HIPCHK(hipEventRecord(c->ev[7], fs));
-            HIPCHK(hipStreamSynchronize(fs));
-            float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
-            fprintf(stderr, "{\"edit_launch\": {\"round\": %d, \"kind\": \"fulls\", \"generic\": %d, \"blocks\": %u, \"ms\": %.4f}}\n", label, generic, nblk, ms);
-        }
-        return SVX_OK;
-    };
-    // 2a. early full matrices (k_edit_gap_flags): the pairs whose length gap alone exceeds every band come first in the work list and are launched right away
-    long long n_first = 0;
-    bool early_fulls = !src.plain && !c->edit_force_full && n_work > few_pairs && !serial;
-    if (const char* e = getenv("SVX_EDIT_EARLY_FULLS")) if (atoi(e) == 0) early_fulls = false;         // A/B switch (results are the same either way)
-    if (early_fulls) {
-        SVXCHK(c->e_work.reserve((size_t)n_work * sizeof(EditWork)));
-        int64_t* flag = reinterpret_cast<int64_t*>(key_a); int64_t* pos = reinterpret_cast<int64_t*>(key_b);
-        k_edit_gap_flags<<<(unsigned)((n_work + 1 + T - 1) / T), T, 0, st>>>(n_work, src, flag);
-        SVXCHK(svx_exclusive_scan_i64(c, flag, pos, n_work + 1));
-        k_edit_gap_scatter<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, src.work, flag, pos, c->e_work.as<EditWork>());
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&n_first, pos + n_work, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        src.work = c->e_work.as<EditWork>();
-    }
     k_slots<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, src, slot_of);
-    const unsigned prep_per_block = 4 * (64 / PREP_LANES);
-    // the early pairs are trimmed, classified and sorted on their own stream (c->aux[6], own sort scratch) beside the preparation of the others; the host
-    // comes back for their class bounds (finish_early) once it has queued that
-    hipStream_t es = c->aux[6];
-    bool early_pending = false;
-    if (n_first > 0) {
-        HIPCHK(hipEventRecord(c->ev[22], st));
-        HIPCHK(hipStreamWaitEvent(es, c->ev[22], 0));
-        k_edit_prep<PREP_LANES><<<(unsigned)((n_first + prep_per_block - 1) / prep_per_block), 256, 0, es>>>(0, n_first, src, scratch, desc, key_a, val_a, ed_dev, cells_dev, -1);
-        k_edit_classify<<<(unsigned)((n_first + T - 1) / T), T, 0, es>>>(0, n_first, desc, key_a, val_a, 0, c->edit_guess, 0);
-        HIPCHK(hipGetLastError());
-        SVXCHK(svx_sort_pairs_u64_on(c, key_a, key_b, val_a, val_b, n_first, 0, 40, es, c->e_sort_tmp));
-        k_class_bounds<<<1, 128, 0, es>>>(key_b, n_first, reinterpret_cast<long long*>(cnt + EARLY_OFF));
-        HIPCHK(hipMemcpyAsync(c->pinned + 64, cnt + EARLY_OFF, (N_SORT_CLASSES + 1) * 8, hipMemcpyDeviceToHost, es));
-        early_pending = true;
-    }
-    auto finish_early = [&]() -> int {
-        if (!early_pending) return SVX_OK;
-        early_pending = false;
-        HIPCHK(hipStreamSynchronize(es));
-        const long long* eb = reinterpret_cast<const long long*>(c->pinned + 64);
-        long long e_lo[N_SORT_CLASSES], e_cn[N_SORT_CLASSES];
-        for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
-            e_lo[sc] = eb[sc]; e_cn[sc] = eb[sc + 1] - eb[sc];
-            if (e_cn[sc] > 0 && (sc % GENERIC_BASE) < NBAND)          // cannot happen (k_edit_gap_flags / k_edit_classify): such a pair would never be computed
-                return svx_fail(SVX_E_STATE, "a pair of the early full-matrix list was given a band class", __FILE__, __LINE__, hipSuccess);
-        }
-        if (profile) profile_round(c, 0, e_lo, e_cn, val_b, desc, n_work);
-        unsigned long long* wc_full0 = cnt + WC_OFF + WC_PER_LAUNCH;
-        for (int generic = 0; generic <= 1; generic++) SVXCHK(launch_fulls(generic, e_lo, e_cn, val_b, es, wc_full0, 0));
-        return SVX_OK;
-    };
-    const long long n_rest = n_work - n_first;
-    if (n_rest > 0) {
-        k_edit_prep<PREP_LANES><<<(unsigned)((n_rest + prep_per_block - 1) / prep_per_block), 256, 0, st>>>(n_first, n_rest, src, scratch, desc, key_a, val_a, ed_dev, cells_dev, shift_bounds);
-        HIPCHK(hipGetLastError());
-    }
+    k_edit_prep<PREP_LANES><<<(unsigned)((n_work + 4 * (64 / PREP_LANES) - 1) / (4 * (64 / PREP_LANES))), 256, 0, st>>>(n_work, src, scratch, desc, key_a, val_a, ed_dev, cells_dev, shift_bounds);
+    HIPCHK(hipGetLastError());
+    const bool profile = getenv("SVX_EDIT_PROFILE") != nullptr, serial = getenv("SVX_EDIT_SERIAL") != nullptr;
     std::vector<PairDesc> first_desc;                       // SVX_EDIT_PROFILE: the descriptors as round 0 saw them (first class of every pair)
-    // 2b. band speculation of THIS call from a strided sample of its own pairs (k_edit_pilot); SVX_EDIT_GUESS pins it instead
+    // 2a. band speculation of THIS call from a strided sample of its own pairs (k_edit_pilot); SVX_EDIT_GUESS pins it instead
     float guess = c->edit_guess;
-    if (!c->edit_guess_pinned && !c->edit_force_full && n_work >= 4096 && n_rest > 0) {
+    if (!c->edit_guess_pinned && !c->edit_force_full && n_work >= 4096) {
         SVXCHK(c->e_hist.reserve(256 * 8));
         HIPCHK(hipMemsetAsync(c->e_hist.p, 0, 256 * 8, st));
-        const long long stride = (n_rest + PILOT_MAX - 1) / PILOT_MAX, n_samp = (n_rest + stride - 1) / stride;
-        k_edit_pilot<<<(unsigned)((n_samp + 255) / 256), 256, 0, st>>>(n_first, n_rest, stride, desc, scratch, c->e_hist.as<unsigned long long>());
-        SVXCHK(finish_early());                               // (before the copy: a copy into pageable memory holds the host until the stream gets there)
+        const long long stride = (n_work + PILOT_MAX - 1) / PILOT_MAX, n_samp = (n_work + stride - 1) / stride;
+        k_edit_pilot<<<(unsigned)((n_samp + 255) / 256), 256, 0, st>>>(n_work, stride, desc, scratch, c->e_hist.as<unsigned long long>());
         unsigned long long h[256];
         HIPCHK(hipMemcpyAsync(h, c->e_hist.p, sizeof h, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1627,27 +1490,33 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         c->edit_guess_last = guess;
         if (profile) fprintf(stderr, "{\"edit_guess_pilot\": %.4f, \"sampled_pairs\": %lld}\n", guess, n_samp);
     }
-    SVXCHK(finish_early());
+    int narrow_windows = 1;                                 // SVX_EDIT_NARROW=0: static staircase windows (A/B switch; results are the same either way)
+    if (const char* e = getenv("SVX_EDIT_NARROW")) narrow_windows = atoi(e) == 0 ? 0 : 1;
+    long long few_pairs = 2048;                             // SVX_EDIT_FEW_PAIRS: calls with at most this many pairs take the low-latency route (0 = never)
+    if (const char* e = getenv("SVX_EDIT_FEW_PAIRS")) few_pairs = atoll(e);
+    k_edit_classify<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, desc, key_a, val_a, c->edit_force_full ? 1 : 0, guess, n_work <= few_pairs ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
+    SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, 40));      // 32 bits of cost order + 6 bits of class (+2 spare)
+    k_class_bounds<<<1, 128, 0, st>>>(key_b, n_work, reinterpret_cast<long long*>(cnt + 8));
     long long bounds[N_SORT_CLASSES + 1];
-    for (int sc = 0; sc <= N_SORT_CLASSES; sc++) bounds[sc] = 0;
-    if (n_rest > 0) {
-        k_edit_classify<<<(unsigned)((n_rest + T - 1) / T), T, 0, st>>>(n_first, n_rest, desc, key_a, val_a, c->edit_force_full ? 1 : 0, guess, n_work <= few_pairs ? 1 : 0);
-        HIPCHK(hipGetLastError());
-        // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
-        SVXCHK(svx_sort_pairs_u64(c, key_a + n_first, key_b + n_first, val_a + n_first, val_b + n_first, n_rest, 0, 40));      // 32 bits of cost order + 6 bits of class (+2 spare)
-        k_class_bounds<<<1, 128, 0, st>>>(key_b + n_first, n_rest, reinterpret_cast<long long*>(cnt + 8));
-        HIPCHK(hipMemcpyAsync(bounds, cnt + 8, (N_SORT_CLASSES + 1) * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-    }
+    HIPCHK(hipMemcpyAsync(bounds, cnt + 8, (N_SORT_CLASSES + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
 
     // 4. rounds.  Full-matrix classes (never fail, most of the work and the longest serial chains) run on high-priority streams, band classes (may fail)
     // on low-priority ones (api.hip, SVX_EDIT_PRIO), each kind as ONE fused launch per round.  A failing pair is appended to the retry list of its next
     // class; a round only waits for its band launch, reads 64 counters and launches the next round straight from those lists - no sort, no small kernels
     // that would queue behind the long-running waves - so the retry rounds overlap the full-matrix work of the earlier ones.
+    // (Measured and taken out again, profiles/r04_edit_early_fulls_ab.txt: the pairs whose length gap alone exceeds every band - known before
+    // k_edit_prep has read a symbol, most of the full-matrix work - launched while bounds, pilot and sort of the other pairs are still computed.  The
+    // full-matrix waves leave k_edit_prep one or two waves per SIMD: it takes 6.4 ms instead of 1.6, the band launches start 5 ms later and the window
+    // ends where it ended before.)
+    hipStream_t band_st[2] = {c->aux[0], c->aux[1]};     // A/C/G/T-only pairs, generic pairs
+    hipStream_t full_st[2] = {c->aux[2], c->aux[3]};     // even / odd rounds
     long long seg_lo[N_SORT_CLASSES], seg_cn[N_SORT_CLASSES];
     long long pending = 0;
     for (int sc = 0; sc < N_SORT_CLASSES; sc++) { seg_lo[sc] = bounds[sc]; seg_cn[sc] = bounds[sc + 1] - bounds[sc]; pending += seg_cn[sc]; }
-    const uint32_t* list = val_b + n_first;
+    const uint32_t* list = val_b;
     for (int round = 0; pending > 0; round++) {
         if (round >= MAX_ROUNDS) return svx_fail(SVX_E_STATE, "edit-distance retry loop did not converge", __FILE__, __LINE__, hipSuccess);
         if (profile) profile_round(c, round, seg_lo, seg_cn, list, desc, n_work);
@@ -1665,6 +1534,59 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         unsigned long long* wc_band = cnt + WC_OFF + (size_t)(round * 2) * WC_PER_LAUNCH;
         unsigned long long* wc_full = wc_band + WC_PER_LAUNCH;
         bool band_used[2] = {false, false};
+        // full-matrix launch of one alphabet from per-class segments (lo / cn indexed by sort class) of `lst`
+        static const int order[14] = {CLS_FULL, CLS_WIDE0 + 3, CLS_WIDE12 + 3, CLS_WIDE0 + 2, CLS_WIDE12 + 2, CLS_WIDE0 + 1, CLS_WIDE12 + 1, CLS_WIDE0, CLS_WIDE12,
+                                      CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};     // longest serial chains first
+        auto launch_fulls = [&](int generic, const long long* lo, const long long* cn_of, const uint32_t* lst, hipStream_t fs, unsigned long long* wc, int label) -> int {
+            const int base = GENERIC_BASE * generic;
+            FusedTab tf; memset(&tf, 0, sizeof tf);
+            unsigned nblk = 0;
+            auto class_threads = [&](int cls, long long cn) -> long long {
+                if (cls == CLS_FULL) return cn * 64;
+                if (cls >= CLS_WIDE12) return cn * (2 << (cls - CLS_WIDE12));
+                if (cls >= CLS_WIDE0) return cn * (2 << (cls - CLS_WIDE0));
+                return cn;
+            };
+            // low-latency form of a long class: KIND_LL + words per lane (64 lanes), 0 = none
+            auto ll_kind = [](int cls) -> int {
+                if (cls == CLS_WIDE0 + 2 || cls == CLS_WIDE12 + 2) return KIND_LL + 2;       // <= 4096 rows
+                if (cls == CLS_WIDE12 + 3) return KIND_LL + 3;                              // <= 6144
+                if (cls == CLS_WIDE0 + 3) return KIND_LL + 4;                               // <= 8192
+                return 0;
+            };
+            long long waves_normal = 0, waves_ll = 0;
+            for (int k = 0; k < 14; k++) {
+                const long long cn = cn_of[base + order[k]];
+                if (cn <= 0) continue;
+                waves_normal += (class_threads(order[k], cn) + 63) / 64;
+                waves_ll += ll_kind(order[k]) ? cn : (class_threads(order[k], cn) + 63) / 64;
+            }
+            static long long ll_waves = 0;                                       // waves per SIMD below which the launch counts as latency-bound
+            if (!ll_waves) { const char* e = getenv("SVX_EDIT_LL_WAVES"); ll_waves = e && atoi(e) > 0 ? atoi(e) : 2; }
+            const bool low_latency = !getenv("SVX_EDIT_NO_LL") && waves_normal <= ll_waves * 4 * (long long)c->n_cu && waves_ll <= 8 * 4 * (long long)c->n_cu;
+            for (int k = 0; k < 14; k++) {
+                const int cls = order[k];
+                const long long cn = cn_of[base + cls];
+                if (cn <= 0) continue;
+                const int ll = low_latency ? ll_kind(cls) : 0;
+                const long long threads = ll ? cn * 64 : class_threads(cls, cn);
+                tf.kind[tf.n] = ll ? ll : cls; tf.lo[tf.n] = lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
+                nblk += (unsigned)((threads + T - 1) / T); tf.n++;
+            }
+            tf.first_block[tf.n] = nblk;
+            if (!tf.n) return SVX_OK;
+            if (serial) HIPCHK(hipEventRecord(c->ev[6], fs));
+            if (generic) k_edit_fulls<4><<<nblk, T, 0, fs>>>(tf, lst, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc);
+            else k_edit_fulls<2><<<nblk, T, 0, fs>>>(tf, lst, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc);
+            HIPCHK(hipGetLastError());
+            if (serial) {
+                HIPCHK(hipEventRecord(c->ev[7], fs));
+                HIPCHK(hipStreamSynchronize(fs));
+                float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
+                fprintf(stderr, "{\"edit_launch\": {\"round\": %d, \"kind\": \"fulls\", \"generic\": %d, \"blocks\": %u, \"ms\": %.4f}}\n", label, generic, nblk, ms);
+            }
+            return SVX_OK;
+        };
         // Round 0 launches its band classes in two parts, widest first: the pairs that fail the WIDEST bands are the long ones whose full matrices are
         // the serial tail of the next round, and they are known as soon as the first part is through - their full-matrix retries start right then,
         // beside the rest of the round (early_cn: what of every retry list has been launched already).
@@ -1749,7 +1671,6 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         list = fb.as<uint32_t>();
     }
     for (int k = 0; k < 2; k++) HIPCHK(hipStreamSynchronize(full_st[k]));
-    if (n_first > 0) HIPCHK(hipStreamSynchronize(c->aux[6]));
     if (profile && !first_desc.empty()) {
         // how much wider than necessary was the first band of every pair?  (needed = narrowest band class that certifies the distance found in the end)
         std::vector<long long> slot((size_t)n_work);

@@ -198,21 +198,16 @@ __global__ __launch_bounds__(RADIX_ONE_T) void k_radix_one(const uint64_t* keys_
 
 int svx_sort_pairs_u64(svx_ctx* c, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                        int64_t n, int begin_bit, int end_bit) {
-    return svx_sort_pairs_u64_on(c, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, c->stream, c->sort_tmp);
-}
-// the same on another stream with its own temporary storage (concurrent with the main stream's primitives)
-int svx_sort_pairs_u64_on(svx_ctx* c, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                          int64_t n, int begin_bit, int end_bit, hipStream_t st, DevBuf& tmp) {
-    (void)c;
     if (n <= 0) return SVX_OK;
     if (n >= (1ll << 32) || begin_bit < 0 || end_bit > 64 || begin_bit >= end_bit) return svx_fail(SVX_E_ARG, "svx_sort_pairs_u64: bad arguments", __FILE__, __LINE__, hipSuccess);
+    hipStream_t st = c->stream;
     const int passes = (end_bit - begin_bit + 7) / 8;
     const long long tiles = (n + RADIX_TILE - 1) / RADIX_TILE;
     // scratch: the second buffer of the ping-pong, and for the tiled path cnt / off [256][tiles] + the digit totals of every pass
     const size_t pair_bytes = ((size_t)n * 8 + 255) / 256 * 256, val_bytes = ((size_t)n * 4 + 255) / 256 * 256;
     const size_t table = ((size_t)256 * (size_t)tiles * 4 + 255) / 256 * 256, totals = (size_t)passes * 256 * 4;
-    SVXCHK(tmp.reserve(pair_bytes + val_bytes + 2 * table + totals + 256));
-    uint8_t* base = tmp.as<uint8_t>();
+    SVXCHK(c->sort_tmp.reserve(pair_bytes + val_bytes + 2 * table + totals + 256));
+    uint8_t* base = c->sort_tmp.as<uint8_t>();
     uint64_t* ktmp = reinterpret_cast<uint64_t*>(base);
     uint32_t* vtmp = reinterpret_cast<uint32_t*>(base + pair_bytes);
     if (n <= RADIX_ONE) {

@@ -768,16 +768,13 @@ def test_edit_distance_routes_do_not_change_results(oracle, monkeypatch):
     assert results[0][:400] == exp
 
 
-@pytest.mark.parametrize("env, normalizer", [({}, 900), ({"SVX_EDIT_NO_PREPACK": "1"}, 900), ({"SVX_EDIT_NO_EARLY": "1"}, 900), ({}, 40000), ({}, 5),
-                                             ({"SVX_EDIT_FEW_PAIRS": "0"}, 900), ({"SVX_EDIT_FEW_PAIRS": "0", "SVX_EDIT_EARLY_FULLS": "0"}, 900),
-                                             ({"SVX_EDIT_FEW_PAIRS": "0", "SVX_EDIT_NO_PREPACK": "1"}, 900)])
+@pytest.mark.parametrize("env, normalizer", [({}, 900), ({"SVX_EDIT_NO_PREPACK": "1"}, 900), ({"SVX_EDIT_NO_EARLY": "1"}, 900), ({}, 40000), ({}, 5)])
 def test_cluster_scheduling_switches_do_not_change_results(oracle, monkeypatch, env, normalizer):
     """The haplotype store packed ahead of the pair list (radius from the parameters; off when 2 * cluster_max_distance * normalizer is out of
-    range: normalizer 40000 -> the exact radius comes from the pair list), the early full-matrix retries and the early full matrices of the pairs
-    whose length gap exceeds every band (SVX_EDIT_EARLY_FULLS; SVX_EDIT_FEW_PAIRS=0 takes a small call through that path) are scheduling choices: the
-    tables stay those of the oracle."""
+    range: normalizer 40000 -> the exact radius comes from the pair list) and the early full-matrix retries are scheduling choices: the tables
+    stay those of the oracle."""
     from svim_amd._lib import Engine
-    for k in ("SVX_EDIT_NO_PREPACK", "SVX_EDIT_NO_EARLY", "SVX_EDIT_FEW_PAIRS", "SVX_EDIT_EARLY_FULLS"):
+    for k in ("SVX_EDIT_NO_PREPACK", "SVX_EDIT_NO_EARLY"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
