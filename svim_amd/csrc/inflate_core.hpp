@@ -48,7 +48,10 @@ struct InfScratch {
     alignas(16) uint8_t ring[INF_RING];
     uint16_t fast_l[1 << INF_FAST_L];
     uint16_t fast_d[1 << INF_FAST_D];
-    uint16_t fast_c[1 << INF_FAST_C];
+    union {
+        uint16_t fast_c[1 << INF_FAST_C];       // code-length code: while a header is read
+        uint32_t pk_list[64];                   // ... afterwards: the tokens of a multi-window step in output order (inf_emit_bytes_multi)
+    };
     uint16_t lsym[INF_MAXL];                 // symbols in canonical order (codes longer than the fast tables)
     uint16_t dsym[INF_MAXD];
     uint16_t csym[20];
@@ -58,7 +61,7 @@ struct InfScratch {
         struct {                                // ... and, once the tables are built, what the token decode of the block needs:
             uint32_t dist_lut[32];              // distance symbol -> base | extra bits << 16 (0: not a symbol)
             uint16_t len_lut[32];               // length symbol - 257 -> base | extra bits << 9 (0: not a symbol)
-            uint8_t tokmap[64];                 // output byte of a step -> lane of the token that produces it
+            uint8_t tokmap[64];                 // output byte of a step -> 1 + lane (rank, in a multi-window step) of the token that starts there, 0 elsewhere
         };
     };
 };
@@ -71,6 +74,7 @@ struct InfScratch {
 #define W_FOR for (int lane_ = 0; lane_ < 64; lane_++)
 #define V(name) name[lane_]
 #define V2(name, r) name[r][lane_]
+#define V2W(name, r) name[r]
 #define W_LANE lane_
 #define W_READLANE(name, idx) ((uint32_t)name[(idx)])
 #define W_BALLOT(dst, expr) do { dst = 0; for (int lane_ = 0; lane_ < 64; lane_++) if (expr) dst |= 1ull << lane_; } while (0)
@@ -85,6 +89,7 @@ static inline uint32_t inf_bitrev(uint32_t x) { uint32_t r = 0; for (int i = 0; 
 #define W_FOR
 #define V(name) name
 #define V2(name, r) name[r]
+#define V2W(name, r) name[r]
 #define W_LANE ((int)(threadIdx.x & 63))
 #define W_READLANE(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx)))
 #define W_BALLOT(dst, expr) dst = __ballot(expr)
@@ -154,8 +159,11 @@ __device__ unsigned long long g_inf_prof[16];
 #ifndef INF_STAT
 #define INF_STAT(path, len, dist)       // host-side token statistics (tools/inflate_host_test.cpp --stats)
 #endif
+#ifndef INF_STEP_STAT
+#define INF_STEP_STAT()                 // host-side: one decode step begins
+#endif
 #ifndef INF_WIDE_STAT
-#define INF_WIDE_STAT(taken)            // host-side: a two-window step was tried and taken (1) / given up for an ordinary one (0)
+#define INF_WIDE_STAT(taken)            // host-side: a multi-window step was tried and taken with `taken` windows / given up for an ordinary one (0)
 #endif
 
 // ---- input ----------------------------------------------------------------------------------------------------------------------------------------
@@ -439,27 +447,36 @@ INF_FN int inf_emit_bytes(InfState& s, uint64_t MT, const VecT& T, const VecT& D
     return 0;
 }
 
-// the same for a step that decoded TWO windows (bit offsets 0..63 and 64..127 of the step: token lane l of window w is token 64 w + l; MT / T / DV / E / EX per
-// window, EX of the second window already continues the first one's): at most 64 output bytes in all, one per lane
+// the same for a step that decoded SEVERAL windows (window w = bit offsets 64 w .. 64 w + 63 of the step; mask / T / DV / E / EX per window, EX already counted from
+// the start of the step): at most 64 output bytes in all, one per lane - and therefore at most 64 tokens: they are ranked in output order (window by window,
+// lane by lane), their parameters go to a list in LDS, and every output byte finds its token through the rank
+#ifndef INF_MAX_WIN
+#define INF_MAX_WIN 4
+#endif
 template <class VecT>
-INF_FN int inf_emit_bytes2(InfState& s, uint64_t MT0, uint64_t MT1, const VecT& T0, const VecT& DV0, const VecT& E0, const VecT& EX0, const VecT& T1, const VecT& DV1,
-                           const VecT& E1, const VecT& EX1, uint32_t acc) {
+INF_FN int inf_emit_bytes_multi(InfState& s, int nw, const uint64_t* MW, VecT* TW, VecT* DW, VecT* EW, VecT* XW, uint32_t acc) {
     InfScratch& sc = *s.sc;
-    W_VEC(uint32_t, tk); W_VEC(uint32_t, PK0); W_VEC(uint32_t, PK1); W_VEC(uint32_t, pk); W_VEC(uint32_t, pa); W_VEC(uint32_t, pb); W_VEC(uint32_t, val); W_VEC(uint32_t, ref);
-    W_VEC(uint32_t, un); W_VEC(uint32_t, idx);
+    W_VEC(uint32_t, tk); W_VEC(uint32_t, pk); W_VEC(uint32_t, val); W_VEC(uint32_t, ref); W_VEC(uint32_t, un);
     W_FOR { if (W_LANE < 16) reinterpret_cast<uint32_t*>(sc.tokmap)[W_LANE] = 0u; }
-    W_FOR { if ((MT0 >> W_LANE) & 1ull) sc.tokmap[V(EX0)] = (uint8_t)(W_LANE + 1); }
-    W_FOR { if ((MT1 >> W_LANE) & 1ull) sc.tokmap[V(EX1)] = (uint8_t)(W_LANE + 65); }
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < INF_MAX_WIN; w++) {
+        if (w < nw) {
+            const uint64_t M = MW[w];
+            W_FOR {
+                if ((M >> W_LANE) & 1ull) {
+                    const uint32_t r = base + W_RANK(M);
+                    sc.tokmap[V2(XW, w)] = (uint8_t)(r + 1u);
+                    sc.pk_list[r & 63u] = (V2(DW, w) & 0xffffu) | (V2(XW, w) << 16) | ((V2(TW, w) & INF_T_MATCH) ? 1u << 22 : 0u) | ((V2(TW, w) & INF_T_FAR) ? 1u << 23 : 0u) |
+                                          ((V2(EW, w) & 255u) << 24);
+                }
+            }
+            base += (uint32_t)__builtin_popcountll(M);
+        }
+    }
     W_FOR { V(tk) = (uint32_t)W_LANE < acc ? (uint32_t)sc.tokmap[W_LANE] : 0u; }
     W_INCL_MAX_SCAN(tk);
-    W_FOR {
-        V(PK0) = (V(DV0) & 0xffffu) | (V(EX0) << 16) | ((V(T0) & INF_T_MATCH) ? 1u << 22 : 0u) | ((V(T0) & INF_T_FAR) ? 1u << 23 : 0u) | ((V(E0) & 255u) << 24);
-        V(PK1) = (V(DV1) & 0xffffu) | (V(EX1) << 16) | ((V(T1) & INF_T_MATCH) ? 1u << 22 : 0u) | ((V(T1) & INF_T_FAR) ? 1u << 23 : 0u) | ((V(E1) & 255u) << 24);
-        V(idx) = (V(tk) - 1u) & 63u;
-    }
-    W_BPERMUTE(pa, PK0, idx);
-    W_BPERMUTE(pb, PK1, idx);
-    W_FOR { V(pk) = V(tk) > 64u ? V(pb) : V(pa); }
+    W_FOR { V(pk) = sc.pk_list[(V(tk) - 1u) & 63u]; }
     uint64_t bad, wait;
     W_BALLOT(bad, (uint32_t)W_LANE < acc && ((V(pk) >> 22) & 1u) && (V(pk) & 0xffffu) > s.pos + ((V(pk) >> 16) & 63u));
     if (bad) return INF_E_DIST;                                   // a distance reaching in front of the output
@@ -539,6 +556,7 @@ INF_FN int inf_codes(InfState& s) {
             }
         }
         INF_PROF(s, 0) INF_COUNT(s, 9, 1)
+        INF_STEP_STAT()
         uint32_t o = 0, e;
         if (!match_mode) {
             // phase A: follow the code starts through the 64 entries while they are literals
@@ -568,67 +586,75 @@ INF_FN int inf_codes(InfState& s) {
             INF_PROF(s, 2) INF_COUNT(s, 10, 1)
 #ifndef INF_NO_WIDE
             if (wide && o == 0u) {
-                // Two windows per step.  A step costs about the same whatever it emits: the gather, the flush test, the scans and LDS round trips of the
-                // emission.  Literal-heavy streams (base qualities: short matches between literals, ~13 bytes per 64 bits) use a fifth of the emission's 64 lanes,
-                // so the step takes the next 64 bit offsets as well - lane l decodes the tokens at offsets l AND 64 + l, the chain runs through both windows,
-                // one emission writes up to 64 bytes.  If that would be more than 64 bytes the second window is dropped and the step goes on as an ordinary one.
-                W_VEC(uint32_t, XL1); W_VEC(uint32_t, E1); W_VEC(uint32_t, T1); W_VEC(uint32_t, DV1);
-                {
-                    const uint32_t d2 = (s.bp >> 5) + 2u, sh = s.bp & 31u;
-                    uint32_t w0, w1, w2, w3;
-                    INF_WORDS4(s, d2, w0, w1, w2, w3)
-                    W_FOR {
-                        const uint32_t b = sh + (uint32_t)W_LANE, i = b >> 5, f = b & 31u;
-                        const uint32_t a0 = i == 0u ? w0 : (i == 1u ? w1 : w2), a1 = i == 0u ? w1 : (i == 1u ? w2 : w3);
-                        V(XL1) = (uint32_t)((((uint64_t)a1 << 32) | a0) >> f);
-                        V(E1) = sc.fast_l[V(XL1) & ((1u << INF_FAST_L) - 1u)];
+                // Several windows per step.  A step costs about the same whatever it emits: the flush test, the scans and LDS round trips of the emission.
+                // Literal-heavy streams (base qualities: short matches between literals, ~12 bytes per 64 bits) use a fifth of the emission's 64 lanes, so the
+                // step takes the next 64 bit offsets as well - lane l decodes the tokens at offsets l, 64 + l, 128 + l ... -, the chain runs on through
+                // the windows, and ONE emission writes up to 64 bytes.  Windows are added while their output fits (and is expected to fit) into the 64
+                // bytes; one that does not is dropped and the next step starts there.  With a single window left the step goes on as an ordinary one.
+                W_VEC2(uint32_t, TW, INF_MAX_WIN); W_VEC2(uint32_t, DW, INF_MAX_WIN); W_VEC2(uint32_t, EW, INF_MAX_WIN); W_VEC2(uint32_t, XW, INF_MAX_WIN);
+                uint64_t MW[INF_MAX_WIN];
+                W_FOR { V2(TW, 0) = V(T); V2(DW, 0) = V(DV); V2(EW, 0) = V(E); }
+                uint32_t p = 0, total = 0, bits = 0;               // chain position inside the current window; bytes / input bits of the windows taken so far
+                int nw = 0;
+                uint64_t any_match = 0;
+#pragma unroll
+                for (int w = 0; w < INF_MAX_WIN; w++) {
+                    if (w > 0) {
+                        const uint32_t dw = (s.bp >> 5) + 2u * (uint32_t)w, sh = s.bp & 31u;
+                        uint32_t w0, w1, w2, w3;
+                        INF_WORDS4(s, dw, w0, w1, w2, w3)
+                        W_FOR {
+                            const uint32_t b = sh + (uint32_t)W_LANE, i = b >> 5, f = b & 31u;
+                            const uint32_t a0 = i == 0u ? w0 : (i == 1u ? w1 : w2), a1 = i == 0u ? w1 : (i == 1u ? w2 : w3);
+                            const uint32_t xl = (uint32_t)((((uint64_t)a1 << 32) | a0) >> f);
+                            V2(EW, w) = sc.fast_l[xl & ((1u << INF_FAST_L) - 1u)];
+                            INF_TOKEN(sc, xl, V2(EW, w), V2(TW, w), V2(DW, w))
+                        }
                     }
-                }
-                W_FOR { INF_TOKEN(sc, V(XL1), V(E1), V(T1), V(DV1)) }
-                uint64_t M0 = 0, M1 = 0;
-                uint32_t p0 = 0, p1 = 0, tt = 0;                   // chain position inside the first / second window
-                bool stopped = false;
-                for (;;) {
-                    tt = W_READLANE(T, p0);
-                    if (tt & INF_T_STOP) { stopped = true; break; }
-                    M0 |= 1ull << p0;
-                    p0 += tt & 63u;
-                    if (p0 >= 64u) break;
-                }
-                if (!stopped) {
-                    p1 = p0 - 64u;
+                    uint64_t M = 0;
+                    uint32_t tt = 0;
+                    bool stopped = false;
                     for (;;) {
-                        tt = W_READLANE(T1, p1);
-                        if (tt & INF_T_STOP) break;
-                        M1 |= 1ull << p1;
-                        p1 += tt & 63u;
-                        if (p1 >= 64u) break;
+                        tt = W_READLANE(V2W(TW, w), p);
+                        if (tt & INF_T_STOP) { stopped = true; break; }
+                        M |= 1ull << p;
+                        p += tt & 63u;
+                        if (p >= 64u) break;
                     }
+                    if (!M) break;                                  // the window starts with a token the lanes do not decode: the serial path's
+                    W_VEC(uint32_t, OL);
+                    uint32_t acc;
+                    W_FOR { V(OL) = ((M >> W_LANE) & 1ull) ? (V2(TW, w) >> 8) & 511u : 0u; }
+                    W_EXCL_SCAN(V2W(XW, w), OL, acc);
+                    if (total + acc > 64u) break;                   // does not fit: dropped
+                    W_FOR { V2(XW, w) += total; }
+                    MW[w] = M;
+                    total += acc;
+                    bits = 64u * (uint32_t)w + p;                    // (a chain that stopped: p is where the next step starts)
+                    nw = w + 1;
+                    uint64_t MMw;
+                    W_BALLOT(MMw, ((M >> W_LANE) & 1ull) && (V2(TW, w) & INF_T_MATCH));
+                    any_match |= MMw;
+                    if (stopped) break;
+                    p -= 64u;
+                    if (total + total / (uint32_t)(w + 1) > 64u) break;         // the next window is not expected to fit
                 }
-                if (M0 && M1) {
-                    W_VEC(uint32_t, OL0); W_VEC(uint32_t, EX0); W_VEC(uint32_t, OL1); W_VEC(uint32_t, EX1);
-                    W_FOR { V(OL0) = ((M0 >> W_LANE) & 1ull) ? (V(T) >> 8) & 511u : 0u; V(OL1) = ((M1 >> W_LANE) & 1ull) ? (V(T1) >> 8) & 511u : 0u; }
-                    uint32_t acc0, acc1;
-                    W_EXCL_SCAN(EX0, OL0, acc0);
-                    W_EXCL_SCAN(EX1, OL1, acc1);
-                    if (acc0 + acc1 <= 64u) {
-                        if (s.pos + acc0 + acc1 > s.out_cap) return INF_E_OUTPUT;
-                        W_FOR { V(EX1) += acc0; }
-                        const int rc = inf_emit_bytes2(s, M0, M1, T, DV, E, EX0, T1, DV1, E1, EX1, acc0 + acc1);
-                        if (rc) return rc;
-                        s.pos += acc0 + acc1;
-                        s.bp += 64u + p1;
-                        uint64_t MMa, MMb;
-                        W_BALLOT(MMa, ((M0 >> W_LANE) & 1ull) && (V(T) & INF_T_MATCH));
-                        W_BALLOT(MMb, ((M1 >> W_LANE) & 1ull) && (V(T1) & INF_T_MATCH));
-                        match_mode = (MMa | MMb) != 0ull;
-                        wide = match_mode && 2u * (acc0 + acc1) <= 64u + p1;          // still at most half a byte per input bit
-                        W_FOR { if ((M0 >> W_LANE) & 1ull) INF_STAT(0, (V(T) & INF_T_MATCH) ? (V(T) >> 8) & 511u : 0u, V(DV)); }
-                        W_FOR { if ((M1 >> W_LANE) & 1ull) INF_STAT(0, (V(T1) & INF_T_MATCH) ? (V(T1) >> 8) & 511u : 0u, V(DV1)); }
-                        INF_PROF(s, 4) INF_COUNT(s, 14, __builtin_popcountll(M0) + __builtin_popcountll(M1))
-                        INF_WIDE_STAT(1)
-                        continue;
-                    }
+                if (nw >= 2) {
+                    if (s.pos + total > s.out_cap) return INF_E_OUTPUT;
+                    const int rc = inf_emit_bytes_multi(s, nw, MW, TW, DW, EW, XW, total);
+                    if (rc) return rc;
+                    s.pos += total;
+                    s.bp += bits;
+                    match_mode = any_match != 0ull;
+                    wide = match_mode && 2u * total <= bits;              // still at most half a byte per input bit
+#ifdef INF_HOST
+                    for (int w = 0; w < nw; w++) { W_FOR { if ((MW[w] >> W_LANE) & 1ull) INF_STAT(0, (V2(TW, w) & INF_T_MATCH) ? (V2(TW, w) >> 8) & 511u : 0u, V2(DW, w)); } }
+#endif
+#if defined(INF_PROFILE) && !defined(INF_HOST)
+                    { uint32_t ntok = 0; for (int w = 0; w < nw; w++) ntok += (uint32_t)__builtin_popcountll(MW[w]); INF_PROF(s, 4) INF_COUNT(s, 14, ntok) }
+#endif
+                    INF_WIDE_STAT(nw)
+                    continue;
                 }
                 INF_WIDE_STAT(0)
                 wide = false;                                      // (the ordinary step below decodes the first window again from T / DV, which are untouched)

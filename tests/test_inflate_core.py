@@ -22,9 +22,11 @@ def test_inflate_core_fuzz_vs_zlib(host_binary):
     out = subprocess.run([host_binary, "--fuzz", "1500"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "1500 buffers, 0 mismatches" in out.stdout
-    # the two-window steps of literal-heavy streams (base qualities) are part of what was checked
-    taken = int(out.stdout.split("two-window steps:")[1].split()[0])
-    assert taken > 100000, out.stdout[-300:]
+    # the multi-window steps of literal-heavy streams (base qualities) are part of what was checked, with 2, 3 and 4 windows
+    line = out.stdout.split("multi-window steps:")[1].splitlines()[0]
+    taken = int(line.split()[0])
+    by_width = [int(x) for x in line.split("windows:")[1].split(")")[0].replace("/", " ").split()]
+    assert taken > 100000 and all(n > 1000 for n in by_width), out.stdout[-300:]
 
 
 def test_inflate_core_bam_blocks_vs_zlib(host_binary, tmp_path):

@@ -13,8 +13,10 @@ static inline void stat_token(int path, unsigned len, unsigned dist) {
     g_len[path][lb]++; g_dist[path][db]++;
 }
 #define INF_STAT(path, len, dist) stat_token(path, len, dist)
-static unsigned long long g_wide[2];                                                   // two-window steps: [given up, taken]
+static unsigned long long g_wide[8];                                                   // multi-window steps: [given up, -, taken with 2, 3, 4 windows]
 #define INF_WIDE_STAT(taken) g_wide[taken]++;
+static unsigned long long g_steps;
+#define INF_STEP_STAT() g_steps++;
 #include "inflate_core.hpp"
 #include <zlib.h>
 #include <cstdio>
@@ -69,7 +71,7 @@ int main(int argc, char** argv) {
                     case 4: src[i] = (uint8_t)(i & 1 ? 0 : rnd() % 3); break;
                     case 5: src[i] = (uint8_t)(33 + rnd() % 40); break;                           // quality-like
                     case 6: { const unsigned q = 2 + (unsigned)((rnd() % 12) + (rnd() % 12) + (rnd() % 12));                  // Phred values with a bell-shaped law: literals
-                              src[i] = (uint8_t)(i >= 40 && rnd() % 9 == 0 ? src[i - 3 - rnd() % 37] : q); break; }          //   with short matches in between (two-window steps)
+                              src[i] = (uint8_t)(i >= 40 && rnd() % 9 == 0 ? src[i - 3 - rnd() % 37] : q); break; }          //   with short matches in between (multi-window steps)
                     default: src[i] = (uint8_t)((i / 700) & 1 ? 1 + rnd() % 45 : (rnd() % 11 == 0 ? rnd() : "\x11\x12\x14\x18\x21\x22\x24\x28\x41\x42\x44\x48\x81\x82\x84\x88"[rnd() & 15])); break;   // BAM-like: packed bases, then qualities
                 }
             }
@@ -81,7 +83,7 @@ int main(int argc, char** argv) {
             bad += check(comp.data(), comp.size(), src, what); done++;
         }
         printf("fuzz: %d buffers, %d mismatches\n", done, bad);
-        printf("two-window steps: %llu taken, %llu given up\n", g_wide[1], g_wide[0]);
+        printf("multi-window steps: %llu taken (2 / 3 / 4 windows: %llu / %llu / %llu), %llu given up\n", g_wide[2] + g_wide[3] + g_wide[4], g_wide[2], g_wide[3], g_wide[4], g_wide[0]);
         return bad ? 1 : 0;
     }
     if (argc < 2) { fprintf(stderr, "usage\n"); return 2; }
@@ -112,7 +114,8 @@ int main(int argc, char** argv) {
         at += blen; blocks++; total += isize;
     }
     printf("%s: %d BGZF blocks, %zu bytes inflated, %d mismatches\n", argv[1], blocks, total, bad);
-    printf("two-window steps: %llu taken, %llu given up\n", g_wide[1], g_wide[0]);
+    printf("decode steps: %llu (%.1f per block, %.1f bytes per step)\n", g_steps, (double)g_steps / (blocks ? blocks : 1), (double)total / (g_steps ? g_steps : 1));
+    printf("multi-window steps: %llu taken (2 / 3 / 4 windows: %llu / %llu / %llu), %llu given up\n", g_wide[2] + g_wide[3] + g_wide[4], g_wide[2], g_wide[3], g_wide[4], g_wide[0]);
     for (int p = 0; p < 2; p++) {
         printf("%s: %llu literals, %llu matches, %llu bytes\n  match length (log2 bins from 2):", p ? "serial tokens" : "token chain", g_tok[p][0], g_tok[p][1], g_bytes[p]);
         for (int i = 1; i < 10; i++) printf(" %llu", g_len[p][i]);
