@@ -1416,6 +1416,48 @@ def test_device_bam_decode_regions_and_pipeline(eng, tmp_path, monkeypatch):
     assert tabs[0] == tabs[1] and len(tabs[0]) > 100
 
 
+def test_device_batches_stay_valid_across_seek_and_rewind(tmp_path, monkeypatch):
+    """include/svx.h: the arrays of a batch stay valid until the third next chunk is loaded - also when a seek or a rewind comes in between (the reader
+    thread of BamPipeline runs one batch ahead of the GPU: a seek used to load the new region into the slot the last batch still lived in).  The batch
+    handed out last is only copied AFTER the next region's first batch has been read (which loads a chunk and prefetches another); regions of a few blocks,
+    chunks of two blocks."""
+    from svim_amd.bamio import NativeBam
+    refs, lens = ["chr1", "chr2", "chr10", "chr3"], [100000, 80000, 80000, 60000]
+    ref = synth.make_reference(71, list(zip(refs, lens)))
+    recs = synth.coordinate_sort(synth.fuzz_split_reads(72, 200, refs, lens, max_sv_size=20000) + synth.planted_reads(73, 260, ref, refs, lens, n_sites=20, types=("DEL", "INS")))
+    path = str(tmp_path / "m.bam")
+    records.write_bam(path, refs, lens, recs)
+    bai = records.read_bai(path + ".bai")
+    order = [t for t in (2, 0, 3, 1, 2, 0) if bai[t] is not None]
+    host = NativeBam(path, threads=2)
+    want = []
+    for t in order:
+        host.seek(bai[t][0], t)
+        b, n = host.read_batch(37, 20, "coordinate")
+        assert n > 0
+        want.append(_concat_batches([host.batch_arrays(b)]))
+    host.rewind()
+    b, n = host.read_batch(37, 20, "coordinate")
+    want_first = _concat_batches([host.batch_arrays(b)])
+    host.close()
+    monkeypatch.setenv("SVX_BAM_DEV_CHUNK_BLOCKS", "2")
+    dev = NativeBam(path, threads=2)
+    dev.set_device_decode(0)
+    held = None
+    for k, t in enumerate(order):
+        dev.seek(bai[t][0], t)
+        b, n = dev.read_batch(37, 20, "coordinate")
+        assert n > 0
+        if held is not None:
+            assert _concat_batches([dev.batch_arrays(held)]) == want[k - 1]           # the previous region's batch, copied only now
+        held = b
+    dev.rewind()
+    b, n = dev.read_batch(37, 20, "coordinate")
+    assert _concat_batches([dev.batch_arrays(held)]) == want[-1]
+    assert _concat_batches([dev.batch_arrays(b)]) == want_first
+    dev.close()
+
+
 def _bgzf_offsets(raw):
     """(offset, total size) of every BGZF block of a file image (SAM spec 4.1: BSIZE at byte 16 of a block with the standard 6-byte extra field)"""
     out, at = [], 0
