@@ -1449,13 +1449,20 @@ def test_device_batches_stay_valid_across_seek_and_rewind(tmp_path, monkeypatch)
         b, n = dev.read_batch(37, 20, "coordinate")
         assert n > 0
         if held is not None:
-            assert _concat_batches([dev.batch_arrays(held)]) == want[k - 1]           # the previous region's batch, copied only now
+            _same_leading_records(dev.batch_arrays(held), want[k - 1])              # the previous region's batch, copied only now
         held = b
     dev.rewind()
     b, n = dev.read_batch(37, 20, "coordinate")
-    assert _concat_batches([dev.batch_arrays(held)]) == want[-1]
-    assert _concat_batches([dev.batch_arrays(b)]) == want_first
+    _same_leading_records(dev.batch_arrays(held), want[-1])
+    _same_leading_records(dev.batch_arrays(b), want_first)
     dev.close()
+
+
+def _same_leading_records(A, want_rows):
+    """a device batch ends where its chunk ends, so it may hold fewer records than the host reader's batch of the same request: the records it holds are
+    the leading ones"""
+    got = _concat_batches([A])
+    assert 0 < len(got) <= len(want_rows) and got == want_rows[:len(got)]
 
 
 def _bgzf_offsets(raw):
