@@ -11,11 +11,12 @@
 //                               (a nibble offset + a length), so nothing is materialised per pair.
 //   2. k_edit_prep (wave/pair)  common prefix / suffix stripped on the packed words (8 symbols per lane and step), Hamming-style
 //                               upper bound, class choice.  A pair is described by 32 bytes (PairDesc).
-//   3. rounds.  Per round TWO fused launches: k_edit_bands (every band class, may fail) on a high-priority stream and
-//      k_edit_fulls (every full-matrix class, never fails) on a low-priority one; a block looks up its class segment.
-//        d_edit_band<Q>  (lane/pair, classes 0..2: 32/64/128 diagonals)  Ukkonen band in band-relative coordinates, the window
+//   3. rounds.  Per round TWO fused launches: k_edit_bands (every band class, may fail) on a low-priority stream and
+//      k_edit_fulls (every full-matrix class, never fails) on a high-priority one; a block looks up its class segment.
+//        d_edit_band<Q>  (lane/pair, classes 0..1: 32/64 diagonals)      Ukkonen band in band-relative coordinates, the window
 //                               slides one row per column
-//        d_edit_stair<Q> (lane/pair, classes 3..8: 192..512 diagonals)   window stands still for 32 columns, then drops a word
+//        d_edit_stair    (lane/pair, classes 2..8: 128..512 diagonals)   window stands still for 32 columns, then drops a word - or two, and
+//                               takes none in: it narrows by Ukkonen's cut-off against the largest distance the attempt certifies
 //        d_edit_lane<Q>  (lane/pair)  whole pattern (<= 512 rows) in one lane, full matrix
 //        d_edit_wide<G>  (G = 2..16 lanes/pair, 512 rows each)           full matrix up to 8192 rows, DPP hand-off between lanes
 //        d_edit_full     (wave/pair)  64-lane systolic full matrix; cores beyond 16384 rows keep block state in a scratch area
@@ -181,6 +182,11 @@ struct PairDesc {
 // Band classes 0..NBAND-1: window of 32 * BAND_WORDS diagonals (0..2 sliding window, 3.. staircase window), tried in rounds.
 #define NBAND 9
 __host__ __device__ __forceinline__ int band_words(int b) { return b <= 2 ? (1 << b) : 2 * b; }     // 1 2 4 | 6 8 10 12 14 16
+// classes below FIRST_STAIR_CLS: sliding window (d_edit_band), from it on: staircase window (d_edit_stair).  The 4-word class was a sliding window
+// until round 4: four v_alignbit per word and column make its word-column 54 issue cycles against 38, and it cannot narrow - as a staircase class
+// (46 diagonals of slack instead of 14, so the pairs with 82 < needed window <= 114 start with 6 words) the step went from 21.55 to 20.4 ms
+// (profiles/r04_edit_stair4_ab.txt)
+#define FIRST_STAIR_CLS 2
 #define CLS_FULL 9            /* systolic full matrix, one wave per pair */
 #define CLS_LANE0 10          /* 10..14: whole pattern (<= 32<<k rows) in one lane, full matrix, never fails */
 #define CLS_WIDE0 15          /* 15..18: full matrix, 2/4/8/16 lanes per pair with 512 rows each (m <= 1024 / 2048 / 4096 / 8192) */
@@ -209,10 +215,10 @@ __device__ __forceinline__ int full_class_for(int m);
 __device__ __forceinline__ int lane_class_for(int m) { return m <= 32 ? 0 : m <= 64 ? 1 : m <= 128 ? 2 : m <= 256 ? 3 : 4; }
 
 __device__ __forceinline__ int band_class_for(int need_w) {      // smallest class whose window keeps the needed margin
-    // classes 0..2 (sliding window, d_edit_band): 14 diagonals are lost to the alignment of dmax to 7 (mod 8);
-    // classes 3.. (staircase window, d_edit_stair): the window stands still for 32 columns, which costs 32 more diagonals
+    // classes 0..1 (sliding window, d_edit_band): 14 diagonals are lost to the alignment of dmax to 7 (mod 8);
+    // classes 2.. (staircase window, d_edit_stair): the window stands still for 32 columns, which costs 32 more diagonals
     for (int b = 0; b < NBAND; b++)
-        if (need_w + (b <= 2 ? 14 : 46) <= 32 * band_words(b)) return b;
+        if (need_w + (b < FIRST_STAIR_CLS ? 14 : 46) <= 32 * band_words(b)) return b;
     return CLS_FULL;
 }
 // first band class with at least `words` state words (CLS_FULL if none)
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(256) void k_edit_pilot(long long n_work, long long 
     if (h[threadIdx.x]) atomicAdd(hist + threadIdx.x, h[threadIdx.x]);
 }
 
-// ---- 3a. banded lane-per-pair kernel, staircase window (classes 3, 4) ------------------------------------------------------
+// ---- 3a. banded lane-per-pair kernel, staircase window (classes 2..8) ------------------------------------------------------
 // Sliding the window one row per column costs four v_alignbit per state word and column - and v_alignbit is a half-rate
 // instruction on gfx950 (4 cycles per wave64 against 2 for v_xor / v_bitop3; tools/micro/valu_ops.hip), 44 % of the sliding
 // kernel's cycles.  Here the window of W = 32*Q rows stands still for a block of 32 columns and then drops by one whole word:
@@ -701,7 +707,9 @@ __device__ __forceinline__ void planes32(uint32_t w0, uint32_t w1, uint32_t w2, 
 // selects the unrolled column code.  A pair is answered iff its result is <= kcap - exactly the acceptance rule of the static window
 // (d <= delta + 2 margin + 1), so narrowing changes what is computed, never what is accepted.  SVX_EDIT_NARROW=0 keeps the window static.
 #define STAIR_QMAX 16            /* widest class; a launch without the two widest classes runs the kernel built for 12 words (more waves per SIMD) */
+#ifndef STAIR_QMIN
 #define STAIR_QMIN 3
+#endif
 
 template <int Q, int P, bool PRED, int QM>
 __device__ __forceinline__ void stair_columns8(uint32_t (&pv)[QM], uint32_t (&mv)[QM], uint32_t (&pl)[P][QM], const uint32_t tword,
@@ -1276,7 +1284,6 @@ __global__ __launch_bounds__(256) void k_edit_bands(FusedTab tab, const uint32_t
     switch (tab.kind[s]) {
         case 0: d_edit_band<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
         case 1: d_edit_band<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
-        case 2: d_edit_band<4, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
                                                 default: d_edit_stair<P, QM>(band_words(tab.kind[s]), tab.narrow != 0, blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
     }
 }
@@ -1684,7 +1691,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         double used[N_CLASSES] = {0}, need[N_CLASSES] = {0}, failed[N_CLASSES] = {0}; long long cnt_c[N_CLASSES] = {0};
         double ratio_hist[8] = {0};
         auto h_need_class = [](int m, int n, int d) { int x = (d - (n - m)) / 2; if (x < 0) x = 0; const int nw = (n - m) + 2 * x + 1;
-            for (int b = 0; b < NBAND; b++) if (nw + (b <= 2 ? 14 : 46) <= 32 * band_words(b)) return b; return (int)CLS_FULL; };
+            for (int b = 0; b < NBAND; b++) if (nw + (b < FIRST_STAIR_CLS ? 14 : 46) <= 32 * band_words(b)) return b; return (int)CLS_FULL; };
         for (long long w = 0; w < n_work; w++) {
             const PairDesc& pd = first_desc[(size_t)w];
             if (pd.cls == -1) continue;
