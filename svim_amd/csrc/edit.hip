@@ -18,7 +18,7 @@
 //        d_edit_stair    (lane/pair, classes 2..8: 128..512 diagonals)   window stands still for 32 columns, then drops a word - or two, and
 //                               takes none in: it narrows by Ukkonen's cut-off against the largest distance the attempt certifies
 //        d_edit_lane<Q>  (lane/pair)  whole pattern (<= 512 rows) in one lane, full matrix
-//        d_edit_wide<G>  (G = 2..16 lanes/pair, 512 rows each)           full matrix up to 8192 rows, DPP hand-off between lanes
+//        d_edit_wide<G,Q>(G = 2..16 lanes/pair, Q = 10 / 12 / 14 / 16 words = 320..512 rows each)   full matrix up to 8192 rows, DPP hand-off between lanes
 //        d_edit_full     (wave/pair)  64-lane systolic full matrix; cores beyond 16384 rows keep block state in a scratch area
 //      All share one column update (MYERS_COLUMN: Myers/Hyyro bit-vector recurrence, add-with-carry chain, explicit v_bitop3),
 //      in a 2-bit-plane (A/C/G/T only) and a 4-bit-plane (any BAM code) instantiation.
@@ -191,7 +191,9 @@ __host__ __device__ __forceinline__ int band_words(int b) { return b <= 2 ? (1 <
 #define CLS_LANE0 10          /* 10..14: whole pattern (<= 32<<k rows) in one lane, full matrix, never fails */
 #define CLS_WIDE0 15          /* 15..18: full matrix, 2/4/8/16 lanes per pair with 512 rows each (m <= 1024 / 2048 / 4096 / 8192) */
 #define CLS_WIDE12 19         /* 19..22: the same with 384 rows (12 words) per lane (m <= 768 / 1536 / 3072 / 6144): halves the rows a pair pads up to */
-#define N_CLASSES 23
+#define CLS_WIDE14 23         /* 23..26: 14 words per lane (m <= 896 / 1792 / 3584 / 7168) */
+#define CLS_WIDE10 27         /* 27..30: 10 words per lane (m <= 640 / 1280 / 2560 / 5120): with the four widths a pair pads up to 1/8 of its rows at most */
+#define N_CLASSES 31
 #define MIN_MARGIN 16
 // A pair whose two cores hold only A/C/G/T (BAM codes 1,2,4,8) runs the 2-bit-plane kernels (P = 2); anything else (N, IUPAC codes,
 // the '=' filler) the generic 4-plane ones (P = 4).  PairDesc.cls bit 8 carries that flag; the sort class is flag*32 + class.
@@ -245,7 +247,13 @@ __device__ __forceinline__ int full_class_for(int m) {
     if (m <= 512) return CLS_LANE0 + lane_class_for(m);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+#ifndef SVX_NO_WIDE1014
+        if (m <= (640 << k)) return CLS_WIDE10 + k;
+#endif
         if (m <= (768 << k)) return CLS_WIDE12 + k;
+#ifndef SVX_NO_WIDE1014
+        if (m <= (896 << k)) return CLS_WIDE14 + k;
+#endif
         if (m <= (1024 << k)) return CLS_WIDE0 + k;
     }
     return CLS_FULL;
@@ -1259,7 +1267,7 @@ __device__ __forceinline__ void d_edit_full(long long blk, long long count, cons
 // small or its last waves drag on (and the runtime multiplexes streams onto a handful of hardware queues), so a round is TWO
 // launches: every band class in one grid, every full-matrix class in another.  Segments are laid out costliest first; a block
 // looks up its segment (uniform, scalar) and runs that class's routine.
-#define SEG_MAX 14
+#define SEG_MAX 22
 // A full-matrix pair is one serial chain of n steps, each as long as the words a lane holds.  When a round has only a few hundred long
 // pairs (HiFi-like data: related pairs need tiny bands, what is left are a few unrelated long ones) the launch lasts as long as its
 // slowest wave while most of the chip idles; the host then launches the classes beyond 2048 rows in their low-latency form - 64 lanes
@@ -1268,7 +1276,7 @@ __device__ __forceinline__ void d_edit_full(long long blk, long long count, cons
 struct FusedTab {
     int n;
     int narrow;                            // band launches: the staircase windows narrow as they run (d_edit_stair)
-    int kind[SEG_MAX];                     // class id (0..13)
+    int kind[SEG_MAX];                     // class id, or KIND_LL + words for a low-latency form
     unsigned first_block[SEG_MAX + 1];
     long long lo[SEG_MAX], cn[SEG_MAX];    // range of the class in the sorted list
 };
@@ -1310,6 +1318,14 @@ __global__ __launch_bounds__(256) void k_edit_fulls(FusedTab tab, const uint32_t
         case CLS_WIDE12 + 1: d_edit_wide<4, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
         case CLS_WIDE12 + 2: d_edit_wide<8, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
         case CLS_WIDE12 + 3: d_edit_wide<16, 12, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE14: d_edit_wide<2, 14, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE14 + 1: d_edit_wide<4, 14, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE14 + 2: d_edit_wide<8, 14, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE14 + 3: d_edit_wide<16, 14, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE10: d_edit_wide<2, 10, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE10 + 1: d_edit_wide<4, 10, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE10 + 2: d_edit_wide<8, 10, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case CLS_WIDE10 + 3: d_edit_wide<16, 10, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
         // low-latency forms of the long classes (KIND_LL + words per lane): one pair per wave, 64 lanes x 2 / 3 / 4 words
         case KIND_LL + 2: d_edit_wide<64, 2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
         case KIND_LL + 3: d_edit_wide<64, 3, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
@@ -1381,6 +1397,8 @@ static void profile_round(svx_ctx* c, int round, const long long* seg_lo, const 
         int words = 0, per_wave = 64;                       // 32-bit words of column state per pair; pairs per wave
         if (cls < NBAND) words = band_words(cls);
         else if (cls >= CLS_LANE0 && cls < CLS_WIDE0) words = 1 << (cls - CLS_LANE0);
+        else if (cls >= CLS_WIDE10) { words = 10 * (2 << (cls - CLS_WIDE10)); per_wave = 64 / (2 << (cls - CLS_WIDE10)); }
+        else if (cls >= CLS_WIDE14) { words = 14 * (2 << (cls - CLS_WIDE14)); per_wave = 64 / (2 << (cls - CLS_WIDE14)); }
         else if (cls >= CLS_WIDE12) { words = 12 * (2 << (cls - CLS_WIDE12)); per_wave = 64 / (2 << (cls - CLS_WIDE12)); }
         else if (cls >= CLS_WIDE0) { words = 16 * (2 << (cls - CLS_WIDE0)); per_wave = 64 / (2 << (cls - CLS_WIDE0)); }
         double useful = 0, issued = 0, sum_m = 0, sum_n = 0;
@@ -1542,27 +1560,27 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         unsigned long long* wc_full = wc_band + WC_PER_LAUNCH;
         bool band_used[2] = {false, false};
         // full-matrix launch of one alphabet from per-class segments (lo / cn indexed by sort class) of `lst`
-        static const int order[14] = {CLS_FULL, CLS_WIDE0 + 3, CLS_WIDE12 + 3, CLS_WIDE0 + 2, CLS_WIDE12 + 2, CLS_WIDE0 + 1, CLS_WIDE12 + 1, CLS_WIDE0, CLS_WIDE12,
-                                      CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};     // longest serial chains first
+        static const int order[SEG_MAX] = {CLS_FULL, CLS_WIDE0 + 3, CLS_WIDE14 + 3, CLS_WIDE12 + 3, CLS_WIDE10 + 3, CLS_WIDE0 + 2, CLS_WIDE14 + 2, CLS_WIDE12 + 2, CLS_WIDE10 + 2,
+                                           CLS_WIDE0 + 1, CLS_WIDE14 + 1, CLS_WIDE12 + 1, CLS_WIDE10 + 1, CLS_WIDE0, CLS_WIDE14, CLS_WIDE12, CLS_WIDE10,
+                                           CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};     // longest serial chains first
         auto launch_fulls = [&](int generic, const long long* lo, const long long* cn_of, const uint32_t* lst, hipStream_t fs, unsigned long long* wc, int label) -> int {
             const int base = GENERIC_BASE * generic;
             FusedTab tf; memset(&tf, 0, sizeof tf);
             unsigned nblk = 0;
             auto class_threads = [&](int cls, long long cn) -> long long {
                 if (cls == CLS_FULL) return cn * 64;
-                if (cls >= CLS_WIDE12) return cn * (2 << (cls - CLS_WIDE12));
-                if (cls >= CLS_WIDE0) return cn * (2 << (cls - CLS_WIDE0));
+                if (cls >= CLS_WIDE0) return cn * (2 << ((cls - CLS_WIDE0) & 3));        // the four wide families: 2 / 4 / 8 / 16 lanes per pair
                 return cn;
             };
             // low-latency form of a long class: KIND_LL + words per lane (64 lanes), 0 = none
             auto ll_kind = [](int cls) -> int {
-                if (cls == CLS_WIDE0 + 2 || cls == CLS_WIDE12 + 2) return KIND_LL + 2;       // <= 4096 rows
-                if (cls == CLS_WIDE12 + 3) return KIND_LL + 3;                              // <= 6144
-                if (cls == CLS_WIDE0 + 3) return KIND_LL + 4;                               // <= 8192
+                if (cls == CLS_WIDE0 + 2 || cls == CLS_WIDE12 + 2 || cls == CLS_WIDE14 + 2 || cls == CLS_WIDE10 + 2) return KIND_LL + 2;       // <= 4096 rows
+                if (cls == CLS_WIDE12 + 3 || cls == CLS_WIDE10 + 3) return KIND_LL + 3;     // <= 6144
+                if (cls == CLS_WIDE0 + 3 || cls == CLS_WIDE14 + 3) return KIND_LL + 4;      // <= 8192
                 return 0;
             };
             long long waves_normal = 0, waves_ll = 0;
-            for (int k = 0; k < 14; k++) {
+            for (int k = 0; k < SEG_MAX; k++) {
                 const long long cn = cn_of[base + order[k]];
                 if (cn <= 0) continue;
                 waves_normal += (class_threads(order[k], cn) + 63) / 64;
@@ -1571,7 +1589,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             static long long ll_waves = 0;                                       // waves per SIMD below which the launch counts as latency-bound
             if (!ll_waves) { const char* e = getenv("SVX_EDIT_LL_WAVES"); ll_waves = e && atoi(e) > 0 ? atoi(e) : 2; }
             const bool low_latency = !getenv("SVX_EDIT_NO_LL") && waves_normal <= ll_waves * 4 * (long long)c->n_cu && waves_ll <= 8 * 4 * (long long)c->n_cu;
-            for (int k = 0; k < 14; k++) {
+            for (int k = 0; k < SEG_MAX; k++) {
                 const int cls = order[k];
                 const long long cn = cn_of[base + cls];
                 if (cn <= 0) continue;

@@ -615,18 +615,29 @@ def test_partition_and_cluster_candidates_matches_reference(eng):
         assert H.close(a[7], b[7]) and H.close(a[8], b[8])
 
 
-def test_edit_distance_full_matrix_classes_vs_oracle(eng, oracle):
-    """Unrelated pairs at every row-count boundary of the full-matrix classes (one lane <= 512 rows; 2/4/8/16 lanes of 12 or 16
-    words; systolic beyond 8192), short and long texts."""
+@pytest.mark.parametrize("few_pairs", [None, "0"])
+def test_edit_distance_full_matrix_classes_vs_oracle(oracle, monkeypatch, few_pairs):
+    """Unrelated pairs at every row-count boundary of the full-matrix classes (one lane <= 512 rows; 2/4/8/16 lanes of 10, 12, 14 or 16
+    words; systolic beyond 8192), short and long texts.  A call this small takes the low-latency route (64-lane forms) by default;
+    SVX_EDIT_FEW_PAIRS=0 sends the same pairs through the classes a large call uses."""
+    from svim_amd._lib import Engine
+    if few_pairs is None:
+        monkeypatch.delenv("SVX_EDIT_FEW_PAIRS", raising=False)
+    else:
+        monkeypatch.setenv("SVX_EDIT_FEW_PAIRS", few_pairs)
     rng = random.Random(17)
     pairs = []
-    for m in (1, 31, 32, 33, 64, 65, 128, 129, 256, 257, 511, 512, 513, 700, 768, 769, 1000, 1024, 1025, 1500, 1536, 1537, 2048, 2049,
-              3000, 3072, 3073, 4096, 4097, 6000, 6144, 6145, 8192, 8193):
+    for m in (1, 31, 32, 33, 64, 65, 128, 129, 256, 257, 511, 512, 513, 640, 641, 700, 768, 769, 896, 897, 1000, 1024, 1025, 1280, 1281, 1500, 1536, 1537,
+              1792, 1793, 2048, 2049, 2560, 2561, 3000, 3072, 3073, 3584, 3585, 4096, 4097, 5120, 5121, 6000, 6144, 6145, 7168, 7169, 8192, 8193):
         for extra in (0, 3, 700):
             a = synth.random_seq(rng, m)
             b = synth.random_seq(rng, m + extra)
             pairs.append((a, b) if rng.random() < 0.5 else (b, a))
-    got = eng.edit_distances(pairs)
+    e = Engine()
+    try:
+        got = e.edit_distances(pairs)
+    finally:
+        e.close()
     exp = [oracle.edit_distance(a, b) for a, b in pairs]
     assert got == exp
 
