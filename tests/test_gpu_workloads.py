@@ -77,9 +77,14 @@ def test_c1_ont_quarter_scale_vs_oracle(eng, oracle):
     """configs[1] at 250 k reads / 62.5 Mb (same coverage and site density as the 1 M-read bench batch)."""
     import torch
     from svim_amd import devsynth
+    from helpers import granted_cpus
     batch, genome, meta = devsynth.make_batch(n_reads=250_000, contig_len=62_500_000, seed=2, device="cuda:0")
     g_off = torch.tensor([0, genome.numel()], dtype=torch.int64, device="cuda:0")
-    sig, ct, st = _both(eng, oracle, batch, g_off, genome, _options())
+    oracle.set_threads(granted_cpus())             # the oracle's partitions over the granted CPUs (results do not depend on the thread count)
+    try:
+        sig, ct, st = _both(eng, oracle, batch, g_off, genome, _options())
+    finally:
+        oracle.set_threads(1)
     assert sig.n > 150_000 and ct.n > 5_000 and st["n_large_partitions"] > 100
 
 
