@@ -149,15 +149,20 @@ class Engine(object):
 
     def set_ranks(self, rank, world, allgather=None):
         """Contig-sharded ranks (svx_cluster_set_ranks): this engine is rank `rank` of `world`; allgather(send: bytes) -> bytes of all ranks, rank-major
-        (len(send) * world) is the transport svx_cluster uses to find where its random.sample streams start.  allgather None / world 1: single rank."""
+        (len(send) * world) - or an object that also has gather_into(send_addr, recv_addr, nbytes) - is the transport svx_cluster uses to find where its random.sample streams start.  allgather None / world 1: single rank."""
         if allgather is None or world <= 1:
             self._ag_cb = None
             _check(self.L.svx_cluster_set_ranks(self.ctx, 0, 1, None, None), "svx_cluster_set_ranks")
             return
         proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 
+        into = getattr(allgather, "gather_into", None)      # a transport that works on the buffers themselves (multigpu.TorchAllGather)
+
         def tramp(user, send, recv, nbytes):
             try:
+                if into is not None and nbytes > 0:
+                    into(int(send), int(recv), int(nbytes))
+                    return 0
                 got = allgather(C.string_at(send, nbytes))
                 if len(got) != nbytes * world:
                     raise ValueError("all-gather callback returned %d bytes, expected %d" % (len(got), nbytes * world))

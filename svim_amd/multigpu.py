@@ -73,6 +73,23 @@ class TorchAllGather(object):
         self.bytes += n * self.world
         return out.cpu().numpy().tobytes()
 
+    def gather_into(self, send_addr, recv_addr, nbytes):
+        """the same on libsvx's own host buffers (Engine.set_ranks prefers this form): the collective reads `nbytes` at send_addr and writes
+        nbytes * world at recv_addr - over gloo with no copy at all, over RCCL through one staging tensor each way (the buffers are host memory)"""
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        src = torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(send_addr), dtype=torch.uint8)
+        dst = torch.frombuffer((ctypes.c_uint8 * (nbytes * self.world)).from_address(recv_addr), dtype=torch.uint8)
+        if dist.get_backend() == "nccl":
+            out = torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device)
+            dist.all_gather_into_tensor(out, src.to(self.device))
+            dst.copy_(out)
+        else:
+            dist.all_gather_into_tensor(dst, src)
+        self.calls += 1
+        self.bytes += nbytes * self.world
+
 
 class _CountingRandom(__import__("random").Random):
     """CPython's own generator (the one the reference uses) counting the 32-bit words it hands out: every getrandbits(k <= 32) is one word"""

@@ -412,3 +412,28 @@ def test_eight_ranks_whole_genome_like_bam(tmp_path):
     ret = dict(ret)
     assert [ret[r] for r in range(8)] == ["ok"] * 8, ret
     assert sum(ret["regions%d" % r] for r in range(8)) >= 20          # the name order cuts the header order into many runs
+
+
+def _worker_transport(rank, world, port, ret):
+    """multigpu.TorchAllGather on raw host buffers (gather_into: what Engine.set_ranks hands libsvx's rank exchange to) and as bytes -> bytes"""
+    import ctypes
+    _setup(rank, world, port)
+    from svim_amd import multigpu as MG
+    try:
+        ag = MG.TorchAllGather(world)
+        ok = True
+        for nbytes in (8, 128, 4099, 70001):
+            mine = bytes((rank * 37 + i * 11) & 255 for i in range(nbytes))
+            want = b"".join(bytes((r * 37 + i * 11) & 255 for i in range(nbytes)) for r in range(world))
+            send = (ctypes.c_uint8 * nbytes).from_buffer_copy(mine)
+            recv = (ctypes.c_uint8 * (nbytes * world))()
+            ag.gather_into(ctypes.addressof(send), ctypes.addressof(recv), nbytes)
+            ok = ok and bytes(recv) == want and ag(mine) == want
+        ret[rank] = "ok" if ok and ag.calls == 8 else "transport returned other bytes"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_transport_on_raw_buffers_and_bytes():
+    out = _run(_worker_transport, world=3)
+    assert out == {0: "ok", 1: "ok", 2: "ok"}
