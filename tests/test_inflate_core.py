@@ -38,3 +38,21 @@ def test_inflate_core_bam_blocks_vs_zlib(host_binary, tmp_path):
     out = subprocess.run([host_binary, path], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert " 0 mismatches" in out.stdout
+
+
+def test_inflate_core_damaged_streams_stay_inside_their_buffers(tmp_path):
+    """Bit flips, overwritten headers, truncation and a lying output size: the decoder ends in an error code or in some output, never in an access outside
+    its buffers (the host build under AddressSanitizer + UndefinedBehaviorSanitizer: array bounds of the LDS scratch members included) and never writes
+    behind the output capacity.  On the GPU such an access would take the whole process down (a damaged file must only fail its own read)."""
+    out = str(tmp_path / "inflate_host_asan")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-DINF_HOST", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                            "-I", os.path.join(REPO, "svim_amd", "csrc"), os.path.join(REPO, "tools", "inflate_host_test.cpp"), "-lz", "-o", out],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([out, "--damaged", "120"], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+    assert "720 streams, 0 wrote behind their output" in run.stdout
+    run = subprocess.run([out, "--fuzz", "60"], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0 and "60 buffers, 0 mismatches" in run.stdout, (run.stdout[-500:], run.stderr[-3000:])

@@ -52,7 +52,51 @@ static std::vector<uint8_t> deflate_raw(const std::vector<uint8_t>& src, int lev
     return out;
 }
 
+// a damaged stream must end in an error code or in some output - never in an access outside its buffers (build with -fsanitize=address,undefined) and
+// never in more than the output capacity written; returns 1 if the guard bytes behind the output were touched
+static int check_damaged(const std::vector<uint8_t>& comp, size_t out_cap) {
+    std::vector<uint32_t> in((comp.size() + 3) / 4 + 1, 0);
+    memcpy(in.data(), comp.data(), comp.size());
+    std::vector<uint8_t> out(out_cap + 8, 0xAA);
+    InfScratch sc;
+    (void)inflate_raw(reinterpret_cast<uint8_t*>(in.data()), (uint32_t)comp.size(), out.data(), (uint32_t)out_cap, sc);
+    for (size_t i = out_cap; i < out.size(); i++) if (out[i] != 0xAA) return 1;
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 3 && std::string(argv[1]) == "--damaged") {
+        // N valid streams, each damaged a few times: bit flips, overwritten bytes, truncation, a lying output capacity
+        const int n = atoi(argv[2]);
+        unsigned long long x = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        int bad = 0, done = 0;
+        for (int it = 0; it < n; it++) {
+            const size_t len = (size_t)(1 + rnd() % 40000);
+            std::vector<uint8_t> src(len);
+            const int kind = (int)(rnd() % 4);
+            for (size_t i = 0; i < len; i++)
+                src[i] = kind == 0 ? (uint8_t)rnd() : kind == 1 ? (uint8_t)("ACGT"[rnd() & 3]) : kind == 2 ? (uint8_t)(i >= 300 && (rnd() % 5) ? src[i - 1 - rnd() % 299] : rnd())
+                                                                                                          : (uint8_t)(33 + rnd() % 40);
+            const int strategies[4] = {Z_DEFAULT_STRATEGY, Z_FIXED, Z_HUFFMAN_ONLY, Z_RLE};
+            const std::vector<uint8_t> good = deflate_raw(src, (int)(rnd() % 10), strategies[rnd() % 4]);
+            for (int v = 0; v < 6; v++) {
+                std::vector<uint8_t> c = good;
+                size_t cap = len;
+                switch (v) {
+                    case 0: for (int k = 0; k < 1 + (int)(rnd() % 4); k++) c[rnd() % c.size()] ^= (uint8_t)(1u << (rnd() & 7)); break;          // bit flips anywhere
+                    case 1: for (int k = 0; k < 8 && k < (int)c.size(); k++) c[k] = (uint8_t)rnd(); break;                                   // a damaged block header
+                    case 2: c.resize(rnd() % c.size()); break;                                                                              // cut short
+                    case 3: cap = rnd() % (len + 1); break;                                                                                 // the ISIZE field lies (too small)
+                    case 4: { const size_t at = rnd() % c.size(); for (size_t k = at; k < c.size() && k < at + 64; k++) c[k] = (uint8_t)rnd(); break; }
+                    default: for (size_t k = 0; k < c.size(); k++) if (rnd() % 97 == 0) c[k] = (uint8_t)rnd(); break;
+                }
+                bad += check_damaged(c, cap); done++;
+            }
+        }
+        printf("damaged: %d streams, %d wrote behind their output\n", done, bad);
+        return bad ? 1 : 0;
+    }
     if (argc >= 3 && std::string(argv[1]) == "--fuzz") {
         const int n = atoi(argv[2]);
         unsigned long long x = 88172645463325252ull;
