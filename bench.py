@@ -365,8 +365,10 @@ def main():
         }
     if roofline_edit is not None and pj and pj.get("workload_cigar_ops") == meta["n_ops"]:
         # the same kernels under rocprofv3 --pmc (profiles/, measured at the commit named inside): instructions actually issued
+        wc_ref = pj.get("word_columns_executed_at_measurement") or wc_issued       # the counters belong to the commit they were measured at, and so does its word-column count
         roofline_edit["pmc"] = {"wave_valu_instr": pj["wave_valu_instr_per_step"], "source": pj["source"], "commit": pj["measured_at_commit"],
-                                "valu_instr_per_word_column": pj["wave_valu_instr_per_step"] / (wc_issued / 64.0),
+                                "word_columns_executed_at_that_commit": wc_ref,
+                                "valu_instr_per_word_column": pj["wave_valu_instr_per_step"] / (wc_ref / 64.0),
                                 "frac": pj["wave_valu_instr_per_step"] / edit_s / VALU_PEAK_WAVE_INSTR_PER_S}
     kernels = {
         "k_cigar_scan_ms": avg["t_cigar_scan_ms"], "k_segments_ms": avg["t_segments_ms"], "collect_order_ms": avg["t_sort_ms"],

@@ -2,13 +2,14 @@
 """Turns the PMC summaries of tools/gpu_profiles.sh (gpurun_out/<tag>_pmc_*.csv, copied to profiles/) into the two small JSON files bench.py reads:
    profiles/traffic_k_cigar_scan.json   HBM traffic of k_cigar_scan per launch (FETCH_SIZE + WRITE_SIZE passes, gfx950 correction)
    profiles/pmc_edit_kernels.json       SQ counters of k_edit_bands + k_edit_fulls per bench step
-Usage: python tools/make_profile_json.py <tag> <commit> <steps in the PMC runs> <cigar ops of the workload>"""
+Usage: python tools/make_profile_json.py <tag> <commit> <steps in the PMC runs> <cigar ops of the workload> [word-columns the edit kernels issued per step at that commit]"""
 import csv
 import json
 import os
 import sys
 
 tag, commit, steps, n_ops = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+wc_at_commit = int(float(sys.argv[5])) if len(sys.argv) > 5 else None        # roofline_edit.word_columns_executed of the bench line at that commit
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 
 
@@ -57,6 +58,8 @@ for kern in sorted(kerns):
     edit["per_step"][kern.replace("void ", "")] = d
 tot = sum(v.get("SQ_INSTS_VALU", 0) for v in edit["per_step"].values())
 edit["wave_valu_instr_per_step"] = tot
+if wc_at_commit:
+    edit["word_columns_executed_at_measurement"] = wc_at_commit
 edit["note"] = "GRBM_GUI_ACTIVE sums the 8 XCDs; band and full-matrix launches overlap in time, so their active cycles do not add up"
 with open(os.path.join(root, "pmc_edit_kernels.json"), "w") as fh:
     json.dump(edit, fh, indent=2)
