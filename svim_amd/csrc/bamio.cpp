@@ -410,7 +410,7 @@ static bool ensure(svx_bam* h, size_t need) {
         const size_t WIN_HEAD = h->win_head;
         const size_t keep = h->buf.size() - h->pos;
         if (keep <= WIN_HEAD) {
-            memcpy(h->next.data() + WIN_HEAD - keep, h->buf.data() + h->pos, keep);
+            if (keep) memcpy(h->next.data() + WIN_HEAD - keep, h->buf.data() + h->pos, keep);
             std::swap(h->buf.p, h->next.p); std::swap(h->buf.cap, h->next.cap);
             h->next.n = 0;                                   // the old window's content is dead: nothing to preserve when it grows
             h->buf.n = WIN_HEAD + h->next_len;

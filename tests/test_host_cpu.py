@@ -611,3 +611,29 @@ def test_sample_bam_with_base_qualities_is_the_same_file_but_for_qual(tmp_path):
     assert diff.any() and (np.frombuffer(r0, dtype=np.uint8)[diff] == 0xff).all() and q1.min() >= 1 and q1.max() <= 50
     import os
     assert os.path.getsize(p1) > 1.5 * os.path.getsize(p0)
+
+
+def test_host_reader_on_damaged_files_under_sanitizers(tmp_path):
+    """tools/bamio_fuzz.cpp: the host reader (csrc/bamio.cpp) built with AddressSanitizer + UndefinedBehaviorSanitizer reads damaged copies of a split-read BAM
+    file to the end - record streams with overwritten bytes and extreme header fields inside well-formed BGZF blocks (so that the damage reaches the record
+    decoder), cut streams, damaged compressed files; both sort modes, with and without the sparse-SEQ filter, 1-3 threads.  A read may be refused; it must
+    not touch memory outside its buffers."""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "bamio_fuzz")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                            os.path.join(repo, "svim_amd", "csrc", "bamio.cpp"), os.path.join(repo, "tools", "bamio_fuzz.cpp"), "-lz", "-lpthread", "-o", exe],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert build.returncode == 0, build.stderr[-2000:]
+    refs, lens = ["chr1", "chr2", "chr10"], [100000, 80000, 60000]
+    ref = synth.make_reference(61, list(zip(refs, lens)))
+    recs = synth.coordinate_sort(synth.fuzz_split_reads(62, 200, refs, lens, max_sv_size=20000) + synth.planted_reads(63, 250, ref, refs, lens, n_sites=20, types=("DEL", "INS", "INV")))
+    seed = str(tmp_path / "seed.bam")
+    records.write_bam(seed, refs, lens, recs)
+    run = subprocess.run([exe, seed, "160"], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+    assert "seed: %d records in the stream, %d read" % (len(recs), len(recs)) in run.stdout
+    tail = run.stdout.strip().splitlines()[-1]
+    assert tail.startswith("damaged files: 160,") and int(tail.split("refused")[1]) > 50, tail
