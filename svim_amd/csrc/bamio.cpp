@@ -1062,14 +1062,15 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
         if (mode == 1 && n == max_records) {
             // finish the current read group: keep reading while the name does not change (peek = parse, names are interned)
             for (;;) {
-                const size_t save_pos = h->pos;
                 if (!ensure(h, 4)) break;
                 const uint32_t bs = rd32(h->buf.data() + h->pos);
                 if (!ensure(h, 4 + (size_t)bs)) throw std::string("truncated BAM record");
                 const uint8_t* r = h->buf.data() + h->pos + 4;
                 const std::string name((const char*)r + 32, r[8] ? r[8] - 1 : 0);
                 const int32_t known = h->names.find(name.data(), name.size(), name_hash(name.data(), name.size()));
-                if (known < 0 || known != h->b->read_id[(size_t)n - 1]) { h->pos = save_pos; break; }
+                // a record of another read stays where it is: nothing has advanced h->pos (ensure() may have MOVED the window - the position from before it
+                // is stale then; restoring it, as this loop once did, sent the next batch into the middle of a record whenever the peek crossed a chunk end)
+                if (known < 0 || known != h->b->read_id[(size_t)n - 1]) break;
                 parse_record(h); n++;
             }
         }

@@ -637,3 +637,9 @@ def test_host_reader_on_damaged_files_under_sanitizers(tmp_path):
     assert "seed: %d records in the stream, %d read" % (len(recs), len(recs)) in run.stdout
     tail = run.stdout.strip().splitlines()[-1]
     assert tail.startswith("damaged files: 160,") and int(tail.split("refused")[1]) > 50, tail
+    # the undamaged file in windows of a few blocks, 1..6 threads, a rewind in the middle of a pass, the last pass in query-name mode: every pass returns
+    # every record (the query-name peek across a chunk end once restored a position from before the window moved)
+    for blocks in ("2", "3", "8"):
+        env = dict(os.environ, SVX_BAM_CHUNK_BLOCKS=blocks)
+        run = subprocess.run([exe, seed, "0"], capture_output=True, text=True, timeout=900, env=env)
+        assert run.returncode == 0 and "threads 1..6 with rewinds: 0 problems" in run.stdout, (blocks, run.stdout[-500:], run.stderr[-2000:])
