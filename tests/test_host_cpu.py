@@ -643,3 +643,4 @@ def test_host_reader_on_damaged_files_under_sanitizers(tmp_path):
         env = dict(os.environ, SVX_BAM_CHUNK_BLOCKS=blocks)
         run = subprocess.run([exe, seed, "0"], capture_output=True, text=True, timeout=900, env=env)
         assert run.returncode == 0 and "threads 1..6 with rewinds: 0 problems" in run.stdout, (blocks, run.stdout[-500:], run.stderr[-2000:])
+        assert "contig ranges out of file order: 0 problems" in run.stdout            # svx_bam_seek from every reference id's first record, twice, each range to its end

@@ -142,7 +142,31 @@ int main(int argc, char** argv) {
             svx_bam_close(h);
         }
         printf("threads 1..6 with rewinds: %lld problems\n", bad);
-        return bad ? 1 : 0;
+        // contig-range reading (svx_bam_seek): from the first record of every reference id, in an order that is not the file's, twice, each range read to
+        // its end - the count must be the number of records with that id; virtual offsets from the block layout of the file
+        std::vector<size_t> blk_file, blk_raw;                     // file offset / offset in the inflated stream of every BGZF block
+        { size_t at = 0, ro = 0; while (at + 18 <= file.size()) { const size_t blen = (size_t)(file[at + 16] | (file[at + 17] << 8)) + 1; if (at + blen > file.size()) break;
+              blk_file.push_back(at); blk_raw.push_back(ro); ro += file[at + blen - 4] | (file[at + blen - 3] << 8) | (file[at + blen - 2] << 16) | ((size_t)file[at + blen - 1] << 24); at += blen; } }
+        auto voff_of = [&](size_t raw_off) { size_t b = 0; while (b + 1 < blk_raw.size() && blk_raw[b + 1] <= raw_off) b++; return ((unsigned long long)blk_file[b] << 16) | (unsigned long long)(raw_off - blk_raw[b]); };
+        std::vector<int32_t> tids; std::vector<size_t> first_of; std::vector<long long> count_of;
+        for (size_t p : rec) { int32_t t; memcpy(&t, raw.data() + p + 4, 4); if (t < 0) continue;
+            if (tids.empty() || tids.back() != t) { tids.push_back(t); first_of.push_back(p); count_of.push_back(0); } count_of.back()++; }
+        long long rbad = 0;
+        for (int threads = 1; threads <= 3; threads++) {
+            svx_bam* h = nullptr;
+            if (svx_bam_open(argv[1], threads, &h) != SVX_OK) { rbad++; continue; }
+            for (int round = 0; round < 2; round++)
+                for (size_t k = 0; k < tids.size(); k++) {
+                    const size_t r = (k * 7 + 3 + (size_t)round) % tids.size();
+                    if (svx_bam_seek(h, voff_of(first_of[r]), tids[r]) != SVX_OK) { rbad++; continue; }
+                    long long got = 0;
+                    for (;;) { svx_batch b; int64_t n = 0; if (svx_bam_read_batch(h, 61, 0, 20, &b, &n) != SVX_OK) { rbad++; fprintf(stderr, "region tid %d: %s\n", tids[r], svx_last_error()); break; } if (n == 0) break; got += n; }
+                    if (got != count_of[r]) { rbad++; fprintf(stderr, "region tid %d: %lld records, %lld expected\n", tids[r], got, count_of[r]); }
+                }
+            svx_bam_close(h);
+        }
+        printf("contig ranges out of file order: %lld problems\n", rbad);
+        return bad || rbad ? 1 : 0;
     }
     long long ok = 0, failed = 0;
     for (int it = 0; it < iters; it++) {
