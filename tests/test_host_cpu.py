@@ -644,3 +644,6 @@ def test_host_reader_on_damaged_files_under_sanitizers(tmp_path):
         run = subprocess.run([exe, seed, "0"], capture_output=True, text=True, timeout=900, env=env)
         assert run.returncode == 0 and "threads 1..6 with rewinds: 0 problems" in run.stdout, (blocks, run.stdout[-500:], run.stderr[-2000:])
         assert "contig ranges out of file order: 0 problems" in run.stdout            # svx_bam_seek from every reference id's first record, twice, each range to its end
+        # the HOST side of the device-resident reader (chunk slots rotating across seek / rewind, grow-and-retry, carry, both modes) over a CPU stand-in of the
+        # decoder whose slot arrays are freed when a slot is loaded again: a batch read after its slot was reused would be a use-after-free
+        assert "device reader's host side over the stand-in decoder: 0 problems" in run.stdout
