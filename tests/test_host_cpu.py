@@ -647,3 +647,19 @@ def test_host_reader_on_damaged_files_under_sanitizers(tmp_path):
         # the HOST side of the device-resident reader (chunk slots rotating across seek / rewind, grow-and-retry, carry, both modes) over a CPU stand-in of the
         # decoder whose slot arrays are freed when a slot is loaded again: a batch read after its slot was reused would be a use-after-free
         assert "device reader's host side over the stand-in decoder: 0 problems" in run.stdout
+
+
+def test_narrowing_staircase_window_rules_against_the_plain_dynamic_programme(tmp_path):
+    """tools/stair_model.c: a cell-level model of d_edit_stair / stair_block (csrc/edit.hip) - the window's geometry, its boundary assumptions and the two cut-off
+    rules that let it drop two words at the top / take none in at the bottom - against the plain dynamic programme: every ACCEPTED result (d <= kcap, the kernel's
+    rule) is the edit distance, for any valid upper bound a pair may carry (exact, nearly exact, loose, useless), and narrowing never loses an answer the static
+    window gives.  Related pairs with noise everywhere / bunched at either end, a deletion early paid back by an insertion late, shifted cores, low-complexity
+    sequences, unequal lengths; windows of 4 .. 10 words.  (The GPU tests check the kernel itself against the oracle; this checks the RULES on far more cells.)"""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "stair_model")
+    subprocess.check_call(["gcc", "-O2", os.path.join(repo, "tools", "stair_model.c"), "-o", exe])
+    run = subprocess.run([exe, "2500", "11"], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0 and " 0 wrong" in run.stdout, (run.stdout[-500:], run.stderr[-2000:])
+    acc = int(run.stdout.split("settings:")[1].split("accepted")[0])
+    assert acc > 8000, run.stdout
