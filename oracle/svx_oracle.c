@@ -441,9 +441,11 @@ int svo_collect_count(svo_ctx* ctx, int64_t* n_sig, int64_t* n_seq, int64_t* n_b
 int svo_collect_fetch(svo_ctx* ctx, int which, svx_sig_view* o) {
     sigtab* t = which ? &ctx->bnd : &ctx->sig;
     size_t n = (size_t)t->n;
-    memcpy(o->key, t->key, n * 8); memcpy(o->type, t->type, n); memcpy(o->src, t->src, n); memcpy(o->aux, t->aux, n);
-    memcpy(o->contig, t->contig, n * 4); memcpy(o->start, t->start, n * 4); memcpy(o->end, t->end, n * 4);
-    memcpy(o->contig2, t->contig2, n * 4); memcpy(o->pos2, t->pos2, n * 4); memcpy(o->read_id, t->read_id, n * 4);
+    if (n) {                                               /* (an empty table has no arrays: nothing to copy from) */
+        memcpy(o->key, t->key, n * 8); memcpy(o->type, t->type, n); memcpy(o->src, t->src, n); memcpy(o->aux, t->aux, n);
+        memcpy(o->contig, t->contig, n * 4); memcpy(o->start, t->start, n * 4); memcpy(o->end, t->end, n * 4);
+        memcpy(o->contig2, t->contig2, n * 4); memcpy(o->pos2, t->pos2, n * 4); memcpy(o->read_id, t->read_id, n * 4);
+    }
     if (which == 0) {
         memcpy(o->seq_off, ctx->sig_seq_off, (n + 1) * 8);
         memcpy(o->seq, ctx->sig_seq, (size_t)ctx->sig_seq_off[n]);
