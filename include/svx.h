@@ -168,6 +168,10 @@ int  svx_version(void);
 int  svx_get_stats(svx_ctx* ctx, svx_stats* out);
 void* svx_stream(svx_ctx* ctx);                              /* hipStream_t the kernels run on */
 int  svx_memcpy_d2h(void* host_dst, const void* device_src, uint64_t bytes);   /* inspection of device-resident results (tests) */
+int  svx_memcpy_h2d(void* device_dst, const void* host_src, uint64_t bytes);
+void* svx_dev_alloc(uint64_t bytes);                                              /* library-owned device memory (tests, stress tools); NULL on failure */
+void svx_dev_free(void* p);
+int  svx_device_synchronize(void);                                               /* SVX_OK iff no kernel / copy of the process has faulted */
 /* self-test of the library's own radix sort (64-bit keys + 32-bit values, key bits [begin_bit, end_bit), stable) and exclusive scan on n pseudo-random
    elements, checked on the host against std::stable_sort / a serial sum: 0 = identical (tests) */
 int  svx_selftest_prims(svx_ctx* ctx, int64_t n, int32_t begin_bit, int32_t end_bit, uint64_t seed);

@@ -1,5 +1,6 @@
 // api.hip - the extern "C" boundary of libsvx.so (include/svx.h).
 #include "common.hpp"
+#include "hostcopy.hpp"
 #include <utility>
 #include <cstdlib>
 
@@ -10,6 +11,53 @@ int svx_fail(int code, const char* what, const char* file, int line, hipError_t 
     snprintf(buf, sizeof buf, "%s failed at %s:%d%s%s", what, file, line, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
     g_svx_err = buf;
     return code;
+}
+
+// ---- guard-mode allocator (common.hpp) --------------------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <unordered_map>
+bool svx_guard_mode() { static const bool on = []() { const char* e = getenv("SVX_ALLOC_GUARD"); return e && e[0] == '1'; }(); return on; }
+bool svx_guard_slack() { static const bool on = []() { const char* e = getenv("SVX_ALLOC_GUARD_SLACK"); return e && e[0] == '1'; }(); return on; }
+namespace {
+struct GuardRec { void* va; size_t va_len; void* map_at; size_t map_len; hipMemGenericAllocationHandle_t h; };
+std::mutex g_guard_mutex;
+std::unordered_map<void*, GuardRec> g_guard;
+}
+int svx_guard_alloc(void** out, size_t bytes) {
+    int dev = 0; HIPCHK(hipGetDevice(&dev));
+    hipMemAllocationProp prop; memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+    size_t gran = 0; HIPCHK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+    if (!gran) gran = 4096;
+    // the buffer's end sits on the end of the mapping up to the alignment (256 like hipMalloc; SVX_ALLOC_GUARD_ALIGN=16: strict - an overrun of one element faults)
+    static const size_t align = []() { const char* e = getenv("SVX_ALLOC_GUARD_ALIGN"); const long long v = e ? atoll(e) : 0; return (size_t)(v >= 16 && (v & (v - 1)) == 0 ? v : 256); }();
+    const size_t want = (bytes + align - 1) & ~(align - 1);
+    const size_t map_len = ((want ? want : 16) + gran - 1) / gran * gran;
+    // (the mapping starts at the start of the reservation: the runtime resolves a pointer inside a mapping against its RESERVATION when it copies or fills, so a
+    // mapping at an offset makes every hipMemcpy / hipMemset land one granule off; the unmapped granule is behind the buffer only)
+    GuardRec r; r.map_len = map_len; r.va_len = map_len + gran;
+    HIPCHK(hipMemAddressReserve(&r.va, r.va_len, gran, nullptr, 0));
+    r.map_at = r.va;
+    HIPCHK(hipMemCreate(&r.h, map_len, &prop, 0));
+    HIPCHK(hipMemMap(r.map_at, map_len, 0, r.h, 0));
+    hipMemAccessDesc acc; memset(&acc, 0, sizeof acc);
+    acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
+    HIPCHK(hipMemSetAccess(r.map_at, map_len, &acc, 1));
+    void* p = (char*)r.map_at + (map_len - want);
+    { std::lock_guard<std::mutex> g(g_guard_mutex); g_guard[p] = r; }
+    *out = p;
+    return SVX_OK;
+}
+void svx_guard_free(void* p) {
+    GuardRec r;
+    { std::lock_guard<std::mutex> g(g_guard_mutex); auto it = g_guard.find(p); if (it == g_guard.end()) { (void)hipFree(p); return; } r = it->second; g_guard.erase(it); }
+    (void)hipDeviceSynchronize();
+    (void)hipMemUnmap(r.map_at, r.map_len);
+    (void)hipMemRelease(r.h);
+    // the address range is NOT given back (SVX_ALLOC_GUARD_REUSE_VA=1 does): a later reservation at the same address is a different physical allocation, and a
+    // stale pointer into the old one should fault, not read the new one; 47 bits of address space outlast any test run
+    static const bool reuse = []() { const char* e = getenv("SVX_ALLOC_GUARD_REUSE_VA"); return e && e[0] == '1'; }();
+    if (reuse) (void)hipMemAddressFree(r.va, r.va_len);
 }
 
 extern "C" const char* svx_last_error(void) { return g_svx_err.c_str(); }
@@ -76,15 +124,27 @@ extern "C" void* svx_stream(svx_ctx* c) { return (void*)c->stream; }
 extern "C" int svx_memcpy_d2h(void* host_dst, const void* device_src, uint64_t bytes) {
     // (a fault of a kernel launched EARLIER, on any stream of the process, surfaces at the next synchronising call: told apart from a bad copy here)
     { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) return svx_fail(SVX_E_HIP, "a kernel launched before this copy faulted (svx_memcpy_d2h only noticed it)", __FILE__, __LINE__, e); }
-    if (bytes) HIPCHK(hipMemcpy(host_dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return svx_d2h(host_dst, device_src, (size_t)bytes, nullptr);         // through the library's page-locked buffers: the runtime never page-locks the caller's memory
+}
+// test / inspection helpers beside it: library-owned device memory, a host -> device copy, and "is the device clean" (any kernel fault of the process shows here)
+extern "C" void* svx_dev_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, (size_t)(bytes ? bytes : 1));
+    if (e != hipSuccess) { (void)svx_fail(SVX_E_HIP, "hipMalloc", __FILE__, __LINE__, e); return nullptr; }
+    return p;
+}
+extern "C" void svx_dev_free(void* p) { if (p) (void)hipFree(p); }
+extern "C" int svx_memcpy_h2d(void* device_dst, const void* host_src, uint64_t bytes) {
+    SVXCHK(svx_h2d(device_dst, host_src, (size_t)bytes, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
     return SVX_OK;
 }
+extern "C" int svx_device_synchronize(void) { HIPCHK(hipDeviceSynchronize()); return SVX_OK; }
 extern "C" int svx_get_stats(svx_ctx* c, svx_stats* out) { *out = c->stats; return SVX_OK; }
 
 static int upload(svx_ctx* c, DevBuf& d, const void* host, size_t bytes, size_t pad = 64) {
     SVXCHK(d.reserve(bytes + pad));
-    if (bytes) HIPCHK(hipMemcpyAsync(d.p, host, bytes, hipMemcpyHostToDevice, c->stream));
-    return SVX_OK;
+    return svx_h2d(d.p, host, bytes, c->stream);            // (hostcopy.hpp: `host` has been read when this returns)
 }
 
 // ---- COLLECT -----------------------------------------------------------------------------------------------
@@ -205,14 +265,16 @@ extern "C" int svx_collect_fetch(svx_ctx* c, int which, svx_sig_view* o) {
     const size_t n = (size_t)s.n;
     hipStream_t st = c->stream;
     // o->on_device: the caller's arrays live in HBM (e.g. torch tensors feeding an RCCL all-gather) -> device-to-device copies
-    const hipMemcpyKind kind = o->on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-#define CPY(dst, buf, bytes) do { if ((bytes) && (dst)) HIPCHK(hipMemcpyAsync((dst), (buf).p, (bytes), kind, st)); } while (0)
+    HostCopy hc(st);
+    const bool dev = o->on_device != 0;
+#define CPY(dst, buf, bytes) do { if ((bytes) && (dst)) { if (dev) HIPCHK(hipMemcpyAsync((dst), (buf).p, (bytes), hipMemcpyDeviceToDevice, st)); else SVXCHK(hc.d2h((dst), (buf).p, (bytes))); } } while (0)
     CPY(o->key, s.key, n * 8); CPY(o->type, s.type, n); CPY(o->src, s.src, n); CPY(o->aux, s.aux, n);
     CPY(o->contig, s.contig, n * 4); CPY(o->start, s.start, n * 4); CPY(o->end, s.end, n * 4); CPY(o->contig2, s.contig2, n * 4);
     CPY(o->pos2, s.pos2, n * 4); CPY(o->read_id, s.read_id, n * 4);
-    if (o->seq_off) HIPCHK(hipMemcpyAsync(o->seq_off, s.seq_off.p, (n + 1) * 8, kind, st));
+    CPY(o->seq_off, s.seq_off, (n + 1) * 8);
     CPY(o->seq, s.seq, (size_t)s.n_seq);
 #undef CPY
+    SVXCHK(hc.finish());
     HIPCHK(hipStreamSynchronize(st));
     o->n = s.n;
     return SVX_OK;
@@ -297,8 +359,8 @@ extern "C" int svx_pair_distances(svx_ctx* c, const svx_sig_view* sigs, int64_t 
     SVXCHK(upload(c, U[11], b_host, (size_t)n_pairs * 8));
     SVXCHK(c->tmp5.reserve((size_t)n_pairs * 8 + 8));
     SVXCHK(svx_pair_distances_impl(c, in, n_pairs, U[10].as<int64_t>(), U[11].as<int64_t>(), p, c->tmp5.as<double>()));
-    HIPCHK(hipMemcpy(out_host, c->tmp5.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost));
-    return SVX_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return svx_d2h(out_host, c->tmp5.p, (size_t)n_pairs * 8, c->stream);
 }
 
 // contig-sharded ranks: this context is rank `rank` of `world`; `fn` all-gathers small host buffers among them (NULL / world <= 1: single rank)
@@ -331,15 +393,20 @@ extern "C" int svx_cluster_fetch(svx_ctx* c, svx_cluster_view* o) {
     DevClusters& v = c->clu;
     const size_t n = (size_t)v.n;
     hipStream_t st = c->stream;
-    // hipMemcpyDefault: the destination arrays may be host or device memory (the multi-GPU exchange keeps them in HBM)
-#define D2H(dst, buf, bytes) do { if ((bytes) && (dst)) HIPCHK(hipMemcpyAsync((dst), (buf).p, (bytes), hipMemcpyDefault, st)); } while (0)
+    // the destination arrays may be host or device memory (the multi-GPU exchange keeps them in HBM): HostCopy::out looks each one up
+    HostCopy hc(st);
+#define D2H(dst, buf, bytes) do { if ((bytes) && (dst)) SVXCHK(hc.out((dst), (buf).p, (bytes))); } while (0)
     D2H(o->type, v.type, n); D2H(o->aux, v.aux, n); D2H(o->contig, v.contig, n * 4); D2H(o->start, v.start, n * 4); D2H(o->end, v.end, n * 4);
     D2H(o->contig2, v.contig2, n * 4); D2H(o->start2, v.start2, n * 4); D2H(o->end2, v.end2, n * 4); D2H(o->score, v.score, n * 8);
     D2H(o->std_span, v.std_span, n * 8); D2H(o->std_pos, v.std_pos, n * 8); D2H(o->size, v.size, n * 4);
-    static const int64_t zero_off = 0;
-    if (o->member_off) { if (n) HIPCHK(hipMemcpyAsync(o->member_off, v.member_off.p, (n + 1) * 8, hipMemcpyDefault, st)); else HIPCHK(hipMemcpyAsync(o->member_off, &zero_off, 8, hipMemcpyDefault, st)); }
+    if (o->member_off) {
+        if (n) D2H(o->member_off, v.member_off, (n + 1) * 8);
+        else if (svx_is_device_pointer(o->member_off)) HIPCHK(hipMemsetAsync(o->member_off, 0, 8, st));
+        else o->member_off[0] = 0;
+    }
     D2H(o->members, v.members, (size_t)v.n_members * 4);
 #undef D2H
+    SVXCHK(hc.finish());
     HIPCHK(hipStreamSynchronize(st));
     o->n = v.n; o->n_members = v.n_members;
     for (int t = 0; t < SVX_NTYPES; t++) o->type_count[t] = v.type_count[t];
@@ -372,10 +439,10 @@ extern "C" int svx_cigar_indel(svx_ctx* c, const uint32_t* cigar_host, int64_t n
     const int64_t n = c->sig.n;
     std::vector<int32_t> start((size_t)n + 1), qpos((size_t)n + 1), end((size_t)n + 1); std::vector<uint8_t> type((size_t)n + 1);
     if (n) {
-        HIPCHK(hipMemcpy(start.data(), c->sig.start.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(end.data(), c->sig.end.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(qpos.data(), c->sig.qpos.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(type.data(), c->sig.type.p, (size_t)n, hipMemcpyDeviceToHost));
+        HostCopy hc(c->stream);
+        SVXCHK(hc.d2h(start.data(), c->sig.start.p, (size_t)n * 4)); SVXCHK(hc.d2h(end.data(), c->sig.end.p, (size_t)n * 4));
+        SVXCHK(hc.d2h(qpos.data(), c->sig.qpos.p, (size_t)n * 4)); SVXCHK(hc.d2h(type.data(), c->sig.type.p, (size_t)n));
+        SVXCHK(hc.finish());
     }
     for (int64_t i = 0; i < n; i++) {
         out_pos_ref[i] = start[i]; out_len[i] = end[i] - start[i]; out_is_del[i] = type[i] == SVX_DEL;
@@ -395,8 +462,7 @@ extern "C" int svx_edit_distance(svx_ctx* c, int64_t n_pairs, const uint8_t* cod
     SVXCHK(upload(c, c->tmp2, b_off, (size_t)(n_pairs + 1) * 8));
     SVXCHK(c->tmp3.reserve((size_t)n_pairs * 4));
     SVXCHK(svx_edit_distance_pairs(c, n_pairs, c->tmp0.as<uint8_t>(), c->tmp1.as<int64_t>(), c->tmp2.as<int64_t>(), c->tmp3.as<int32_t>()));
-    HIPCHK(hipMemcpyAsync(out_dist, c->tmp3.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SVXCHK(svx_d2h(out_dist, c->tmp3.p, (size_t)n_pairs * 4, c->stream));
     return SVX_OK;
 }
 
@@ -414,9 +480,7 @@ extern "C" int svx_linkage_fcluster(svx_ctx* c, int64_t n_problems, const int32_
     SVXCHK(c->tmp4.reserve((size_t)nl * 4 + 16));
     SVXCHK(svx_linkage_batch(c, n_problems, c->tmp0.as<int32_t>(), c->tmp1.as<int64_t>(), c->tmp2.as<double>(), cutoff, c->tmp3.as<int64_t>(),
                              c->tmp4.as<int32_t>()));
-    HIPCHK(hipMemcpyAsync(labels_out, c->tmp4.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return SVX_OK;
+    return svx_d2h(labels_out, c->tmp4.p, (size_t)nl * 4, c->stream);
 }
 
 // ---- GENOTYPE ---------------------------------------------------------------------------------------------------------------

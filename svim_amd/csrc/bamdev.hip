@@ -7,6 +7,7 @@
 // Replaces, for coordinate-sorted BAM input: pysam.AlignmentFile(bam).fetch(until_eof=True) + the per-record accessors + the SA string handling of
 // src/svim/SVIM_COLLECT.py:44-93,132-167 (what bamio.cpp's decode_run / append_sa do on the host's cores).
 #include "common.hpp"
+#include "hostcopy.hpp"
 #include "devdec.hpp"
 #include "scan.hpp"
 #include <zlib.h>
@@ -556,9 +557,15 @@ struct svx_devdec {
     DevDecStats stats;
     const uint8_t* file_base = nullptr; size_t file_bytes = 0; const uint8_t* file_dev = nullptr;      // the memory-mapped BAM, registered with the GPU (or not)
     int n_threads = 8; hipStream_t copy_stream = nullptr; uint8_t* hbuf = nullptr; size_t hbuf_cap = 0;      // the host's share of the inflate
-    int* h_err = nullptr;                      // pinned
-    unsigned long long* h_cnt = nullptr;       // pinned, 16 values
+    int* h_err = nullptr;                      // pinned (DD_PINNED_BYTES: 64 bytes for h_err, then the DD_H_* values of h_cnt)
+    unsigned long long* h_cnt = nullptr;       // pinned: indexed by the DD_H_* slots below, each written by one copy and read after the synchronise that follows it
 };
+
+// slots of svx_devdec::h_cnt (pinned read-backs).  The loader thread (devdec_load / devdec_count) and the consumer (devdec_batch) use disjoint slots.
+enum { DD_H_OPS = 0, DD_H_WALK_TAIL = 1, DD_H_SEGOPS = 2, DD_H_SEG = 4, DD_H_SA_BAD = 6, DD_H_NEW = 8, DD_H_BLOB = 10, DD_H_FIRST_BEYOND = 12, DD_H_TAIL_BS = 13,
+       DD_H_LAST_GROUP = 16, DD_H_LAST_OFF = 17, DD_H_NEXT_BOUNDARY = 18, DD_H_GROUPS = 20, DD_H_ROWS = 21, DD_H_ROW_OPS = 22, DD_H_SLOTS = 24 };
+#define DD_PINNED_BYTES 320
+static_assert(64 + DD_H_SLOTS * sizeof(unsigned long long) <= DD_PINNED_BYTES, "the pinned block of svx_devdec holds h_err (64 bytes) and DD_H_SLOTS values of h_cnt");
 
 static int dd_alloc_names(svx_devdec* d, uint32_t cap) {
     SVXCHK(d->nt_key.reserve((size_t)cap * 8)); SVXCHK(d->nt_check.reserve((size_t)cap * 8)); SVXCHK(d->nt_id.reserve((size_t)cap * 4));
@@ -577,13 +584,13 @@ int devdec_create(int device, int n_threads, int32_t n_ref, const int32_t* ref_l
     HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     SVXCHK(svx_inflater_create(device, &d->inf));
-    { void* p = nullptr; HIPCHK(hipHostMalloc(&p, 256, hipHostMallocDefault)); d->h_err = (int*)p; d->h_cnt = (unsigned long long*)((char*)p + 64); }
+    { void* p = nullptr; HIPCHK(hipHostMalloc(&p, DD_PINNED_BYTES, hipHostMallocDefault)); memset(p, 0, DD_PINNED_BYTES); d->h_err = (int*)p; d->h_cnt = (unsigned long long*)((char*)p + 64); }
     SVXCHK(d->err.reserve(64)); SVXCHK(d->counters.reserve(256));
     const size_t nr = (size_t)(n_ref > 0 ? n_ref : 1);
     SVXCHK(d->ref_len.reserve(nr * 4)); SVXCHK(d->contig_rank.reserve(nr * 4));
     if (n_ref > 0) {
-        HIPCHK(hipMemcpyAsync(d->ref_len.p, ref_len, nr * 4, hipMemcpyHostToDevice, d->stream));
-        HIPCHK(hipMemcpyAsync(d->contig_rank.p, contig_rank, nr * 4, hipMemcpyHostToDevice, d->stream));
+        SVXCHK(svx_h2d(d->ref_len.p, ref_len, nr * 4, d->stream));
+        SVXCHK(svx_h2d(d->contig_rank.p, contig_rank, nr * 4, d->stream));
     }
     // reference names: hash table name -> id for the SA tags
     uint32_t cap = 16; while (cap < 4u * (uint32_t)nr) cap <<= 1;
@@ -602,10 +609,10 @@ int devdec_create(int device, int n_threads, int32_t n_ref, const int32_t* ref_l
     off[nr > (size_t)n_ref ? (size_t)n_ref : nr] = (uint32_t)blob.size();
     if (n_ref > 0) off[(size_t)n_ref] = (uint32_t)blob.size();
     SVXCHK(d->ct_key.reserve((size_t)cap * 8)); SVXCHK(d->ct_tid.reserve((size_t)cap * 4)); SVXCHK(d->ct_names.reserve(blob.size() + 16)); SVXCHK(d->ct_name_off.reserve((nr + 1) * 4));
-    HIPCHK(hipMemcpyAsync(d->ct_key.p, key.data(), (size_t)cap * 8, hipMemcpyHostToDevice, d->stream));
-    HIPCHK(hipMemcpyAsync(d->ct_tid.p, tid.data(), (size_t)cap * 4, hipMemcpyHostToDevice, d->stream));
-    if (!blob.empty()) HIPCHK(hipMemcpyAsync(d->ct_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice, d->stream));
-    HIPCHK(hipMemcpyAsync(d->ct_name_off.p, off.data(), (nr + 1) * 4, hipMemcpyHostToDevice, d->stream));
+    SVXCHK(svx_h2d(d->ct_key.p, key.data(), (size_t)cap * 8, d->stream));
+    SVXCHK(svx_h2d(d->ct_tid.p, tid.data(), (size_t)cap * 4, d->stream));
+    SVXCHK(svx_h2d(d->ct_names.p, blob.data(), blob.size(), d->stream));
+    SVXCHK(svx_h2d(d->ct_name_off.p, off.data(), (nr + 1) * 4, d->stream));
     d->ct_mask = cap - 1;
     SVXCHK(dd_alloc_names(d, 1u << 20));
     HIPCHK(hipStreamSynchronize(d->stream));
@@ -820,7 +827,7 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
     blk.push_back(c.data_end);
     SVXCHK(c.blk_off.reserve((size_t)(nb + 1) * 8)); SVXCHK(c.anchor.reserve((size_t)nb * 8)); SVXCHK(c.cnt.reserve((size_t)nb * 4));
     SVXCHK(c.exit_at.reserve((size_t)nb * 8)); SVXCHK(c.base.reserve((size_t)(nb + 1) * 8));
-    HIPCHK(hipMemcpyAsync(c.blk_off.p, blk.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, st));
+    SVXCHK(svx_h2d(c.blk_off.p, blk.data(), (size_t)(nb + 1) * 8, st));
     HIPCHK(hipMemsetAsync(d->err.p, 0, 64, st));
     static const bool verify_crc = []() { const char* e = getenv("SVX_BAM_VERIFY_CRC"); return !(e && e[0] == '0'); }();
     if (verify_crc && nb_in) {
@@ -828,12 +835,12 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
             uint32_t m[CRC_POW][32];
             crc_shift_matrices(m);
             SVXCHK(d->crc_shift.reserve(sizeof m));
-            HIPCHK(hipMemcpy(d->crc_shift.p, m, sizeof m, hipMemcpyHostToDevice));
+            SVXCHK(svx_h2d(d->crc_shift.p, m, sizeof m, st));
         }
         c.crc_host.resize(nb_in);
         for (size_t k = 0; k < nb_in; k++) c.crc_host[k] = CrcJob{(unsigned long long)(DD_HEAD + out_at[k]), blocks[k].isize, blocks[k].crc};
         SVXCHK(c.crc_jobs.reserve(nb_in * sizeof(CrcJob)));
-        HIPCHK(hipMemcpyAsync(c.crc_jobs.p, c.crc_host.data(), nb_in * sizeof(CrcJob), hipMemcpyHostToDevice, st));
+        SVXCHK(svx_h2d(c.crc_jobs.p, c.crc_host.data(), nb_in * sizeof(CrcJob), st));
         k_crc32<<<(unsigned)nb_in, 64, 0, st>>>(sp, c.crc_jobs.as<CrcJob>(), (long long)nb_in, d->crc_shift.as<uint32_t>(), d->err.as<int>() + 8);
     }
     k_anchor<<<(unsigned)nb, 64, 0, st>>>(sp, c.blk_off.as<uint64_t>(), nb, c.data_end, d->n_ref, d->ref_len.as<int32_t>(), c.anchor.as<uint64_t>());
@@ -841,12 +848,13 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> anchor((size_t)nb), exit_at((size_t)nb), base((size_t)nb + 1, 0);
     std::vector<uint32_t> cnt((size_t)nb);
-    HIPCHK(hipMemcpyAsync(anchor.data(), c.anchor.p, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(exit_at.data(), c.exit_at.p, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
     int crc_err[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(cnt.data(), c.cnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(crc_err, d->err.as<int>() + 8, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    {
+        HostCopy hc(st);
+        SVXCHK(hc.d2h(anchor.data(), c.anchor.p, (size_t)nb * 8)); SVXCHK(hc.d2h(exit_at.data(), c.exit_at.p, (size_t)nb * 8));
+        SVXCHK(hc.d2h(cnt.data(), c.cnt.p, (size_t)nb * 4)); SVXCHK(hc.d2h(crc_err, d->err.as<int>() + 8, 8));
+        SVXCHK(hc.finish());
+    }
     if (crc_err[0]) { char msg[96]; snprintf(msg, sizeof msg, "BGZF block %d of the chunk fails its CRC32", crc_err[1]); return svx_fail(SVX_E_ARG, msg, __FILE__, __LINE__, hipSuccess); }
     // the anchors are right iff they link up: the walk that leaves a block must arrive exactly at the next anchor, and the first anchor is the known start
     bool linked = anchor[0] == c.data_begin;
@@ -866,21 +874,22 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
     if (linked && tail + 4 <= c.data_end) {
         // the last walk left its block at `tail` and no block behind it produced an anchor: that is only right if the record at `tail` is the
         // incomplete one the chunk ends in (a complete record there means a record start the anchor search did not recognise)
-        uint32_t bs = 0;
-        HIPCHK(hipMemcpy(&bs, sp + tail, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_TAIL_BS], sp + tail, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const uint32_t bs = (uint32_t)d->h_cnt[DD_H_TAIL_BS];
         if (tail + 4ull + bs <= c.data_end) linked = false;
     }
     if (linked) {
         SVXCHK(c.rec_off.reserve((size_t)(n_rec + 1) * 8));
-        HIPCHK(hipMemcpyAsync(c.base.p, base.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, st));
+        SVXCHK(svx_h2d(c.base.p, base.data(), (size_t)(nb + 1) * 8, st));
         k_walk<<<GRIDB(nb, 64), 64, 0, st>>>(sp, c.blk_off.as<uint64_t>(), nb, c.data_end, c.anchor.as<uint64_t>(), nullptr, nullptr, c.base.as<uint64_t>(), c.rec_off.as<uint64_t>());
     } else {
         d->stats.fallbacks++;
         unsigned long long* cn = d->counters.as<unsigned long long>();
         k_walk_serial<<<1, 1, 0, st>>>(sp, c.data_begin, c.data_end, 0, nullptr, cn, reinterpret_cast<uint64_t*>(cn + 1));
-        HIPCHK(hipMemcpyAsync(d->h_cnt, cn, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_OPS], cn, 16, hipMemcpyDeviceToHost, st));      // (count, tail: slots DD_H_OPS and DD_H_WALK_TAIL, free at this point of the load)
         HIPCHK(hipStreamSynchronize(st));
-        n_rec = d->h_cnt[0]; tail = d->h_cnt[1];
+        n_rec = d->h_cnt[DD_H_OPS]; tail = d->h_cnt[DD_H_WALK_TAIL];
         SVXCHK(c.rec_off.reserve((size_t)(n_rec + 1) * 8));
         k_walk_serial<<<1, 1, 0, st>>>(sp, c.data_begin, c.data_end, n_rec, c.rec_off.as<uint64_t>(), cn, reinterpret_cast<uint64_t*>(cn + 1));
     }
@@ -905,11 +914,11 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
     SVXCHK(dd_scan<uint32_t>(d, c, c.n_seg.as<uint32_t>(), c.seg_off.as<uint32_t>(), N1));
     k_widen_u32<<<GRIDB(n + 1, 256), 256, 0, st>>>(n + 1, c.n_segop.as<uint32_t>(), c.name_at.as<uint64_t>());
     SVXCHK(dd_scan<uint64_t>(d, c, c.name_at.as<uint64_t>(), c.segop_off.as<uint64_t>(), N1));
-    HIPCHK(hipMemcpyAsync(&d->h_cnt[0], c.cigar_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&d->h_cnt[2], c.segop_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&d->h_cnt[4], c.seg_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_OPS], c.cigar_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_SEGOPS], c.segop_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_SEG], c.seg_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
     SVXCHK(dd_check(d, "records"));
-    c.tot_ops = (int64_t)d->h_cnt[0]; c.tot_segops = (int64_t)d->h_cnt[2]; c.tot_seg = (int64_t)(uint32_t)d->h_cnt[4];
+    c.tot_ops = (int64_t)d->h_cnt[DD_H_OPS]; c.tot_segops = (int64_t)d->h_cnt[DD_H_SEGOPS]; c.tot_seg = (int64_t)(uint32_t)d->h_cnt[DD_H_SEG];
     SVXCHK(c.flag.reserve(N1 * 2)); SVXCHK(c.tid.reserve(N1 * 4)); SVXCHK(c.pos.reserve(N1 * 4)); SVXCHK(c.mapq.reserve(N1)); SVXCHK(c.lseq.reserve(N1 * 4));
     SVXCHK(c.read_id.reserve(N1 * 4)); SVXCHK(c.seq_off.reserve(N1 * 8)); SVXCHK(c.cigar.reserve((size_t)(c.tot_ops + 16) * 4));
     const size_t S1 = (size_t)c.tot_seg + 1;
@@ -922,8 +931,8 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
                                            c.tid.as<int32_t>(), c.pos.as<int32_t>(), c.mapq.as<uint8_t>(), c.lseq.as<int32_t>(), c.seq_off.as<uint64_t>(), c.seg_tid.as<int32_t>(),
                                            c.seg_pos.as<int32_t>(), c.seg_rev.as<uint8_t>(), c.seg_mapq.as<uint8_t>(), c.seg_lseq.as<int32_t>(), c.seg_cigar_off.as<uint64_t>(),
                                            c.seg_cigar.as<uint32_t>(), d->err.as<int>(), d->counters.as<unsigned long long>() + 4);
-    c.seq_end_host = c.data_end;                                            // (the source of an asynchronous copy must outlive it: a member, not a local)
-    HIPCHK(hipMemcpyAsync(c.seq_off.as<uint64_t>() + n, &c.seq_end_host, 8, hipMemcpyHostToDevice, st));
+    c.seq_end_host = c.data_end;
+    SVXCHK(svx_h2d(c.seq_off.as<uint64_t>() + n, &c.seq_end_host, 8, st));
     k_cigar_copy<<<GRIDB(n, 4), 256, 0, st>>>(sp, n, c.desc.as<RecDesc>(), c.cigar_off.as<uint64_t>(), c.cigar.as<uint32_t>());
     HIPCHK(hipGetLastError());
     d->stats.t_decode += dd_now() - t0; t0 = dd_now();
@@ -945,25 +954,24 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
         unsigned int* n_new_dev = reinterpret_cast<unsigned int*>(d->counters.as<unsigned long long>() + 8);
         k_name_insert<<<GRIDB(n, 256), 256, 0, st>>>(n, c.desc.as<RecDesc>(), nt, (int32_t)have, c.slot_of.as<uint32_t>(), n_new_dev, c.new_rec.as<uint32_t>());
         k_name_ids<<<GRIDB(n, 256), 256, 0, st>>>(n, c.desc.as<RecDesc>(), nt, c.slot_of.as<uint32_t>(), c.read_id.as<int32_t>(), d->err.as<int>());
-        HIPCHK(hipMemcpyAsync(&d->h_cnt[8], n_new_dev, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&d->h_cnt[6], d->counters.as<unsigned long long>() + 4, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_NEW], n_new_dev, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_SA_BAD], d->counters.as<unsigned long long>() + 4, 8, hipMemcpyDeviceToHost, st));
         SVXCHK(dd_check(d, "fields / names"));
-        const long long n_new = (long long)(unsigned int)d->h_cnt[8];
-        if (d->h_cnt[6]) fprintf(stderr, "WARNING: %llu SA tag entries do not consist of 6 fields. This could be a sign of invalid characters (e.g. commas or semicolons) in a "
-                                          "chromosome name of the reference genome.\n", (unsigned long long)d->h_cnt[6]);
+        const long long n_new = (long long)(unsigned int)d->h_cnt[DD_H_NEW];
+        if (d->h_cnt[DD_H_SA_BAD]) fprintf(stderr, "WARNING: %llu SA tag entries do not consist of 6 fields. This could be a sign of invalid characters (e.g. commas or semicolons) in a "
+                                          "chromosome name of the reference genome.\n", (unsigned long long)d->h_cnt[DD_H_SA_BAD]);
         if (n_new) {
             HIPCHK(hipMemsetAsync(c.name_len.as<uint32_t>() + n_new, 0, 4, st));
             k_name_lens<<<GRIDB(n_new, 256), 256, 0, st>>>(n_new, c.new_rec.as<uint32_t>(), c.desc.as<RecDesc>(), c.name_len.as<uint32_t>());
             k_widen_u32<<<GRIDB(n_new + 1, 256), 256, 0, st>>>(n_new + 1, c.name_len.as<uint32_t>(), c.segop_off.as<uint64_t>());      // (segop_off is free again: scratch)
             SVXCHK(dd_scan<uint64_t>(d, c, c.segop_off.as<uint64_t>(), c.name_at.as<uint64_t>(), (size_t)n_new + 1));
-            HIPCHK(hipMemcpyAsync(&d->h_cnt[10], c.name_at.as<uint64_t>() + n_new, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_BLOB], c.name_at.as<uint64_t>() + n_new, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            const size_t blob_bytes = (size_t)d->h_cnt[10];
+            const size_t blob_bytes = (size_t)d->h_cnt[DD_H_BLOB];
             SVXCHK(c.name_blob.reserve(blob_bytes + 16));
             k_name_copy<<<GRIDB(n_new, 256), 256, 0, st>>>(sp, c.rec_off.as<uint64_t>(), n_new, c.new_rec.as<uint32_t>(), c.desc.as<RecDesc>(), c.name_at.as<uint64_t>(), c.name_blob.as<char>());
             std::vector<char> blob(blob_bytes + 1);
-            HIPCHK(hipMemcpyAsync(blob.data(), c.name_blob.p, blob_bytes, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            SVXCHK(svx_d2h(blob.data(), c.name_blob.p, blob_bytes, st));
             d->names.reserve(have + (size_t)n_new);
             const char* q = blob.data();
             for (long long k = 0; k < n_new; k++) { const size_t ln = strlen(q); d->names.emplace_back(q, ln); q += ln + 1; }
@@ -975,11 +983,12 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
         unsigned long long* lg = d->counters.as<unsigned long long>() + 16;
         HIPCHK(hipMemsetAsync(lg, 0, 8, st));
         k_q_last_group<<<GRIDB(n, 256), 256, 0, st>>>(n, c.read_id.as<int32_t>(), lg);
-        HIPCHK(hipMemcpyAsync(&d->h_cnt[16], lg, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_LAST_GROUP], lg, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        const long long L = (long long)d->h_cnt[16];
-        HIPCHK(hipMemcpy(&d->h_cnt[17], c.rec_off.as<uint64_t>() + L, 8, hipMemcpyDeviceToHost));
-        c.tail_start = (size_t)d->h_cnt[17];
+        const long long L = (long long)d->h_cnt[DD_H_LAST_GROUP];
+        HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_LAST_OFF], c.rec_off.as<uint64_t>() + L, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        c.tail_start = (size_t)d->h_cnt[DD_H_LAST_OFF];
         c.n_rec = L;
     }
     d->stats.records += c.n_rec;
@@ -993,12 +1002,12 @@ int devdec_count(svx_devdec* d, int slot, int32_t tid_limit, int64_t* n_rec, int
     if (tid_limit == -2 || c.n_rec == 0) return SVX_OK;
     HIPCHK(hipSetDevice(d->device));
     unsigned long long* first = d->counters.as<unsigned long long>() + 12;
-    const unsigned long long big = (unsigned long long)c.n_rec;
-    HIPCHK(hipMemcpyAsync(first, &big, 8, hipMemcpyHostToDevice, d->stream));
+    d->h_cnt[DD_H_FIRST_BEYOND] = (unsigned long long)c.n_rec;            // (pinned slot: the source of an asynchronous copy, not a stack local)
+    HIPCHK(hipMemcpyAsync(first, &d->h_cnt[DD_H_FIRST_BEYOND], 8, hipMemcpyHostToDevice, d->stream));
     k_first_beyond<<<GRIDB(c.n_rec, 256), 256, 0, d->stream>>>(c.n_rec, c.tid.as<int32_t>(), tid_limit, first);
-    HIPCHK(hipMemcpyAsync(&d->h_cnt[12], first, 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_FIRST_BEYOND], first, 8, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
-    *n_valid = (int64_t)d->h_cnt[12];
+    *n_valid = (int64_t)d->h_cnt[DD_H_FIRST_BEYOND];
     return SVX_OK;
 }
 
@@ -1014,12 +1023,12 @@ int devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t* count_io, int 
         SVXCHK(d->batch_cnt.reserve(64));
         unsigned long long* nb = d->batch_cnt.as<unsigned long long>();
         const unsigned long long big = (unsigned long long)c.n_rec;
-        d->h_cnt[18] = big;
-        HIPCHK(hipMemcpyAsync(nb, &d->h_cnt[18], 8, hipMemcpyHostToDevice, st));
+        d->h_cnt[DD_H_NEXT_BOUNDARY] = big;
+        HIPCHK(hipMemcpyAsync(nb, &d->h_cnt[DD_H_NEXT_BOUNDARY], 8, hipMemcpyHostToDevice, st));
         k_q_next_boundary<<<GRIDB(c.n_rec - (first + count), 256), 256, 0, st>>>(first + count, c.n_rec, c.read_id.as<int32_t>(), nb);
-        HIPCHK(hipMemcpyAsync(&d->h_cnt[18], nb, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_NEXT_BOUNDARY], nb, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        count = (int64_t)d->h_cnt[18] - first;
+        count = (int64_t)d->h_cnt[DD_H_NEXT_BOUNDARY] - first;
         *count_io = count;
     }
     const int f = c.order_flip; c.order_flip ^= 1;
@@ -1048,9 +1057,9 @@ int devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t* count_io, int 
     k_q_marks<<<GRIDB(n + 1, 256), 256, 0, st>>>(n, fl, mq, rid, min_mapq, c.q_head.as<uint32_t>(), c.q_good.as<uint32_t>());
     SVXCHK(dd_scan<uint32_t>(d, c, c.q_head.as<uint32_t>(), c.q_gidx.as<uint32_t>(), N1));
     SVXCHK(dd_scan<uint32_t>(d, c, c.q_good.as<uint32_t>(), c.q_good_ex.as<uint32_t>(), N1));
-    HIPCHK(hipMemcpyAsync(&d->h_cnt[20], c.q_gidx.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_GROUPS], c.q_gidx.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    const long long G = (long long)(uint32_t)d->h_cnt[20];
+    const long long G = (long long)(uint32_t)d->h_cnt[DD_H_GROUPS];
     const size_t G1 = (size_t)G + 1;
     SVXCHK(c.q_gs.reserve(G1 * 4)); SVXCHK(c.q_nprim.reserve(G1 * 4)); SVXCHK(c.q_pidx.reserve(G1 * 4)); SVXCHK(c.q_slots.reserve(G1 * 4)); SVXCHK(c.q_rows.reserve(G1 * 4));
     SVXCHK(c.q_slot_ex.reserve(G1 * 4)); SVXCHK(c.q_row_ex.reserve(G1 * 4));
@@ -1060,9 +1069,9 @@ int devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t* count_io, int 
                                                  c.q_slots.as<uint32_t>(), c.q_rows.as<uint32_t>());
     SVXCHK(dd_scan<uint32_t>(d, c, c.q_slots.as<uint32_t>(), c.q_slot_ex.as<uint32_t>(), G1));
     SVXCHK(dd_scan<uint32_t>(d, c, c.q_rows.as<uint32_t>(), c.q_row_ex.as<uint32_t>(), G1));
-    HIPCHK(hipMemcpyAsync(&d->h_cnt[21], c.q_row_ex.as<uint32_t>() + G, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_ROWS], c.q_row_ex.as<uint32_t>() + G, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    const long long R = (long long)(uint32_t)d->h_cnt[21];
+    const long long R = (long long)(uint32_t)d->h_cnt[DD_H_ROWS];
     const size_t R1 = (size_t)R + 1;
     SVXCHK(c.q_seg_tid[f].reserve(R1 * 4)); SVXCHK(c.q_seg_pos[f].reserve(R1 * 4)); SVXCHK(c.q_seg_rev[f].reserve(R1)); SVXCHK(c.q_seg_mapq[f].reserve(R1));
     SVXCHK(c.q_seg_lseq[f].reserve(R1 * 4)); SVXCHK(c.q_seg_cigar_off[f].reserve(R1 * 8)); SVXCHK(c.q_row_rec.reserve(R1 * 4)); SVXCHK(c.q_row_ops.reserve(R1 * 4));
@@ -1073,9 +1082,9 @@ int devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t* count_io, int 
                                                  c.q_seg_off[f].as<uint32_t>(), c.q_seg_tid[f].as<int32_t>(), c.q_seg_pos[f].as<int32_t>(), c.q_seg_rev[f].as<uint8_t>(),
                                                  c.q_seg_mapq[f].as<uint8_t>(), c.q_seg_lseq[f].as<int32_t>(), c.q_row_rec.as<uint32_t>(), c.q_row_ops.as<uint32_t>());
     SVXCHK((svx_exclusive_scan<uint32_t, uint64_t>(c.q_row_ops.as<uint32_t>(), c.q_seg_cigar_off[f].as<uint64_t>(), (long long)R1, st, c.scan_tmp)));
-    HIPCHK(hipMemcpyAsync(&d->h_cnt[22], c.q_seg_cigar_off[f].as<uint64_t>() + R, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_ROW_OPS], c.q_seg_cigar_off[f].as<uint64_t>() + R, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    const size_t ops = (size_t)d->h_cnt[22];
+    const size_t ops = (size_t)d->h_cnt[DD_H_ROW_OPS];
     SVXCHK(c.q_seg_cigar[f].reserve((ops + 16) * 4));
     if (R) k_q_seg_cigar<<<GRIDB(R, 4), 256, 0, st>>>(R, c.q_row_rec.as<uint32_t>(), out->cigar_off, out->cigar, c.q_seg_cigar_off[f].as<uint64_t>(), c.q_seg_cigar[f].as<uint32_t>());
     HIPCHK(hipGetLastError());

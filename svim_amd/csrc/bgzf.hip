@@ -4,9 +4,11 @@
 //
 // Replaces: zlib inflate() under htslib's bgzf_read_block (the reference reads BAM through pysam.AlignmentFile, SVIM_COLLECT.py:132-137).
 #include "common.hpp"
+#include "hostcopy.hpp"
 #include <atomic>
 #include "inflate_core.hpp"
 #include <mutex>
+#include <thread>
 #include <cstdlib>
 
 struct BgzfJob { unsigned long long in_off; unsigned long long out_off; uint32_t in_bytes; uint32_t out_bytes; };
@@ -37,15 +39,19 @@ struct InflaterSlot {
     hipEvent_t ev[2];
     DevBuf comp, out, jobs, status;
     void* staging = nullptr; size_t staging_cap = 0;      // pinned host memory the caller packs this slot's payloads into
-    int host_status[4] = {0, 0, 0, 0};
-    std::vector<BgzfJob> host_jobs;                       // alive until the slot's wait: its upload is asynchronous
+    int* host_status = nullptr;                           // 4 ints of the inflater's pinned block
+    std::vector<BgzfJob> host_jobs;
+    // inflated data on its way to a HOST window: device -> this slot's own page-locked buffer (a DMA), then a memcpy into the caller's window at the wait
+    // (the window itself is pageable memory of the reader: the runtime must not page-lock it in place - hostcopy.hpp)
+    void* out_stage = nullptr; size_t out_stage_cap = 0; uint8_t* out_host = nullptr; size_t out_host_bytes = 0;
     bool busy = false;
 };
 struct svx_inflater {
     int device = 0;
     InflaterSlot slot[INF_SLOTS];
-    std::vector<std::pair<void*, size_t>> pinned;         // caller buffers registered for direct DMA
+    std::vector<std::pair<void*, size_t>> pinned;         // caller buffers registered for direct DMA (only with SVX_READER_REGISTER=1 / SVX_BAM_DEV_MAPFILE=1)
     std::mutex pin_mutex;                                 // pin / unpin come from the reader's threads
+    int* status_block = nullptr;                          // pinned: 4 ints per slot
 };
 
 extern "C" int svx_inflater_create(int device, svx_inflater** out) {
@@ -55,7 +61,10 @@ extern "C" int svx_inflater_create(int device, svx_inflater** out) {
     HIPCHK(hipSetDevice(device));
     svx_inflater* f = new svx_inflater();
     f->device = device;
-    for (auto& sl : f->slot) {
+    { void* p = nullptr; HIPCHK(hipHostMalloc(&p, 256, hipHostMallocDefault)); f->status_block = (int*)p; memset(p, 0, 256); }
+    for (int k = 0; k < INF_SLOTS; k++) {
+        InflaterSlot& sl = f->slot[k];
+        sl.host_status = f->status_block + 4 * k;
         HIPCHK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         for (auto& e : sl.ev) HIPCHK(hipEventCreate(&e));
     }
@@ -63,6 +72,11 @@ extern "C" int svx_inflater_create(int device, svx_inflater** out) {
     return SVX_OK;
 }
 
+// Registering the reader's memory with the GPU (hipHostRegister: the inflate windows and batch arrays of the host reader, the memory-mapped BAM file of the device
+// reader) is OFF by default since round 5: a registration describes an address range the library later frees or unmaps, and any trace of it that the runtime keeps
+// beyond hipHostUnregister makes a later copy into whatever the allocator places there fault (hostcopy.hpp).  The data takes the library's own page-locked buffers
+// instead.  SVX_READER_REGISTER=1 (windows / arrays) and SVX_BAM_DEV_MAPFILE=1 (file mapping) switch the registrations back on for A/B runs.
+static bool reader_register() { static const bool on = []() { const char* e = getenv("SVX_READER_REGISTER"); return e && e[0] == '1'; }(); return on; }
 // A registration that could NOT be removed must never meet other memory at its address: the runtime would go on treating that address range as page-locked with the old
 // physical pages (a later pageable copy into memory the allocator placed there faults).  The failures are counted; the owner of the memory (bamio.cpp: the file
 // mapping) keeps it mapped for the life of the process when the count moved.
@@ -83,10 +97,12 @@ extern "C" void svx_inflater_destroy(svx_inflater* f) {
         (void)hipStreamSynchronize(sl.stream);
         sl.comp.release(); sl.out.release(); sl.jobs.release(); sl.status.release();
         if (sl.staging) (void)hipHostFree(sl.staging);
+        if (sl.out_stage) (void)hipHostFree(sl.out_stage);
         for (auto& e : sl.ev) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(sl.stream);
     }
     for (auto& pr : f->pinned) inf_unregister(pr.first);
+    if (f->status_block) (void)hipHostFree(f->status_block);
     delete f;
 }
 
@@ -110,7 +126,7 @@ extern "C" void* svx_inflater_staging(svx_inflater* f, int slot, uint64_t bytes)
 // page-lock a caller buffer that receives inflated data, so that the copy back is one DMA (without it the runtime stages through its own buffers);
 // a buffer that moved or grew is registered again.  Failure to register is not an error - the copies just take the slow path.
 extern "C" int svx_inflater_pin(svx_inflater* f, void* p, uint64_t bytes) {
-    if (!f || !p || !bytes) return SVX_OK;
+    if (!f || !p || !bytes || !reader_register()) return SVX_OK;
     std::lock_guard<std::mutex> guard(f->pin_mutex);
     (void)hipSetDevice(f->device);
     for (size_t i = 0; i < f->pinned.size(); i++) {
@@ -173,8 +189,21 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
     uint8_t* out_dev = out;
     if (!out_on_device) { SVXCHK(sl.out.reserve((size_t)out_bytes + 64)); out_dev = sl.out.as<uint8_t>(); }
     hipStream_t st = sl.stream;
+    // is the host window registered (SVX_READER_REGISTER=1: one DMA into place), or does the data come through the slot's page-locked buffer?
+    bool direct_out = false;
+    if (!out_on_device && reader_register()) {
+        std::lock_guard<std::mutex> guard(f->pin_mutex);
+        for (auto& pr : f->pinned) if ((const char*)out >= (const char*)pr.first && (const char*)out + out_bytes <= (const char*)pr.first + pr.second) direct_out = true;
+    }
+    if (!out_on_device && !direct_out && out_bytes > sl.out_stage_cap) {
+        if (sl.out_stage) (void)hipHostFree(sl.out_stage);
+        sl.out_stage = nullptr; sl.out_stage_cap = 0;
+        const size_t want = (size_t)out_bytes + (size_t)out_bytes / 4 + 4096;
+        HIPCHK(hipHostMalloc(&sl.out_stage, want, hipHostMallocDefault));
+        sl.out_stage_cap = want;
+    }
     if (!comp_dev) { HIPCHK(hipMemcpyAsync(sl.comp.p, sl.staging, (size_t)staged_bytes, hipMemcpyHostToDevice, st)); comp_dev = sl.comp.as<uint8_t>(); }
-    HIPCHK(hipMemcpyAsync(sl.jobs.p, jobs.data(), (size_t)n * sizeof(BgzfJob), hipMemcpyHostToDevice, st));
+    SVXCHK(svx_h2d(sl.jobs.p, jobs.data(), (size_t)n * sizeof(BgzfJob), st));
     HIPCHK(hipMemsetAsync(sl.status.p, 0, 16, st));
     HIPCHK(hipEventRecord(sl.ev[0], st));
     static const unsigned lds_pad = []() { const char* e = getenv("SVX_INFLATE_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();      // experiment: fewer resident waves per CU
@@ -182,7 +211,11 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.ev[1], st));
     HIPCHK(hipMemcpyAsync(sl.host_status, sl.status.p, 16, hipMemcpyDeviceToHost, st));
-    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, out_dev, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
+    sl.out_host = nullptr; sl.out_host_bytes = 0;
+    if (!out_on_device) {
+        if (direct_out) HIPCHK(hipMemcpyAsync(out, out_dev, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
+        else { HIPCHK(hipMemcpyAsync(sl.out_stage, out_dev, (size_t)out_bytes, hipMemcpyDeviceToHost, st)); sl.out_host = out; sl.out_host_bytes = (size_t)out_bytes; }
+    }
     sl.busy = true;
     return SVX_OK;
 }
@@ -205,9 +238,10 @@ extern "C" int svx_inflater_enqueue_mapped(svx_inflater* f, int slot, int64_t n,
     SVXCHK(sl.jobs.reserve((size_t)n * sizeof(BgzfJob)));
     SVXCHK(sl.status.reserve(16));
     hipStream_t st = sl.stream;
-    HIPCHK(hipMemcpyAsync(sl.jobs.p, jobs.data(), (size_t)n * sizeof(BgzfJob), hipMemcpyHostToDevice, st));
+    SVXCHK(svx_h2d(sl.jobs.p, jobs.data(), (size_t)n * sizeof(BgzfJob), st));
     HIPCHK(hipMemsetAsync(sl.status.p, 0, 16, st));
     HIPCHK(hipEventRecord(sl.ev[0], st));
+    sl.out_host = nullptr; sl.out_host_bytes = 0;
     k_bgzf_inflate<<<(unsigned)n, 64, 0, st>>>(comp_dev, sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.status.as<int>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.ev[1], st));
@@ -219,6 +253,7 @@ extern "C" int svx_inflater_enqueue_mapped(svx_inflater* f, int slot, int64_t n,
 // (the caller stages through pinned buffers instead)
 extern "C" int svx_inflater_map_file(svx_inflater* f, const void* base, uint64_t bytes, const uint8_t** dev_ptr) {
     if (!f || !base || !bytes || !dev_ptr) return svx_fail(SVX_E_ARG, "bad argument", __FILE__, __LINE__, hipSuccess);
+    { const char* e = getenv("SVX_BAM_DEV_MAPFILE"); if (!(e && e[0] == '1')) return svx_fail(SVX_E_HIP, "file mappings are not registered with the GPU (SVX_BAM_DEV_MAPFILE=1 switches it on)", __FILE__, __LINE__, hipSuccess); }
     (void)hipSetDevice(f->device);
     void* p = const_cast<void*>(base);
     hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterReadOnly);
@@ -239,6 +274,16 @@ extern "C" int svx_inflater_wait(svx_inflater* f, int slot, float* kernel_ms) {
     HIPCHK(hipSetDevice(f->device));
     HIPCHK(hipStreamSynchronize(sl.stream));
     sl.busy = false;
+    if (sl.out_host && sl.out_host_bytes) {                // the inflated data of a host window: out of the slot's page-locked buffer, a few threads for large pieces
+        const size_t nb = sl.out_host_bytes;
+        const int parts = nb > ((size_t)8 << 20) ? 4 : 1;
+        std::vector<std::thread> cp;
+        uint8_t* dst = sl.out_host; const uint8_t* src = (const uint8_t*)sl.out_stage;
+        for (int q = 1; q < parts; q++) { const size_t lo = nb * (size_t)q / parts, hi = nb * (size_t)(q + 1) / parts; cp.emplace_back([=]() { memcpy(dst + lo, src + lo, hi - lo); }); }
+        memcpy(dst, src, nb / parts);
+        for (auto& t : cp) t.join();
+        sl.out_host = nullptr; sl.out_host_bytes = 0;
+    }
     if (kernel_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1])); *kernel_ms = ms; }
     if (sl.host_status[0]) {
         char msg[128];

@@ -16,6 +16,7 @@
 // (<= 4950 doubles = 39.6 KB) and the whole dendrogram live in LDS; nothing is re-read from HBM.
 // FP64 throughout with the reference's operation order (-ffp-contract=off), so labels are bit-exact.
 #include "common.hpp"
+#include "hostcopy.hpp"
 #include <cstdlib>
 
 int svx_launch_edit_pairs(svx_ctx* c, int64_t n_work, const void* work_dev, const ClusterIn& in, int32_t* ed_dev,
@@ -1300,8 +1301,7 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
         int32_t* info_dev = c->samp_meta.as<int32_t>();
         k_large_info<<<GRID(n_large, T), T, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, info_dev);
         plan.info.resize((size_t)n_large * 2);
-        HIPCHK(hipMemcpyAsync(plan.info.data(), info_dev, (size_t)n_large * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        SVXCHK(svx_d2h(plan.info.data(), info_dev, (size_t)n_large * 8, st));
     }
     // consumption tables for windows around the given expected start of every type (mean0 / var0; least0 = lower bound), launched up to k_chase_runs
     auto build_tables = [&](const double* mean0, const double* var0, const long long* least0, long long reach) -> int {
@@ -1315,8 +1315,8 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
         plan.run_start_dev = reinterpret_cast<long long*>(plan.runs_dev + plan.n_runs);
         plan.trb_dev = plan.run_start_dev + plan.n_runs;
         plan.ends_dev = plan.trb_dev + (SVX_NTYPES + 1);
-        HIPCHK(hipMemcpyAsync(plan.meta_dev, plan.meta.data(), (size_t)n_large * sizeof(SampleMeta), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(plan.runs_dev, plan.runs.data(), (size_t)plan.n_runs * sizeof(ChaseRun), hipMemcpyHostToDevice, st));
+        SVXCHK(svx_h2d(plan.meta_dev, plan.meta.data(), (size_t)n_large * sizeof(SampleMeta), st));
+        SVXCHK(svx_h2d(plan.runs_dev, plan.runs.data(), (size_t)plan.n_runs * sizeof(ChaseRun), st));
         HIPCHK(hipMemcpyAsync(plan.trb_dev, plan.type_run_begin, sizeof plan.type_run_begin, hipMemcpyHostToDevice, st));
         k_sample_tables<<<dim3((unsigned)((plan.max_width + 255) / 256), (unsigned)n_large), 256, 0, st>>>(plan.meta_dev, c->mt_words.as<uint32_t>(), c->mt_have,
                                                                                                          c->samp_table.as<uint16_t>());
@@ -1401,8 +1401,7 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
             k_chase_span<<<dim3((unsigned)((wmax + 255) / 256), SVX_NTYPES), 256, 0, st>>>(plan.meta_dev, plan.runs_dev, plan.trb_dev, plan.ends_dev, foff_dev, f_dev);
             HIPCHK(hipGetLastError());
             f_host.resize((size_t)f_off[SVX_NTYPES] + 1);
-            HIPCHK(hipMemcpyAsync(f_host.data(), f_dev, (size_t)f_off[SVX_NTYPES] * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            SVXCHK(svx_d2h(f_host.data(), f_dev, (size_t)f_off[SVX_NTYPES] * 8, st));
             *f = f_host.data();
             return SVX_OK;
         };

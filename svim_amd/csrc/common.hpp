@@ -30,27 +30,35 @@ int svx_fail(int code, const char* what, const char* file, int line, hipError_t 
 inline double& svx_alloc_seconds() { static double v = 0; return v; }
 inline long long& svx_alloc_calls() { static long long v = 0; return v; }
 inline size_t& svx_alloc_bytes() { static size_t v = 0; return v; }
+// Guard mode (SVX_ALLOC_GUARD=1, debugging): every buffer is a mapping of its own whose LAST byte asked for (rounded up to 16) is the last mapped byte, with
+// unmapped address space on both sides - an access more than 15 bytes behind what reserve() was asked for is a GPU fault at once instead of a read of whatever
+// the allocator placed there (api.hip: svx_guard_alloc).  The 12.5 % growth slack is not added in this mode.
+bool svx_guard_mode();
+bool svx_guard_slack();          // SVX_ALLOC_GUARD_SLACK=1: the guard sits behind the growth slack (same reallocation pattern as without guard; only far overruns fault)
+int svx_guard_alloc(void** out, size_t bytes);
+void svx_guard_free(void* p);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     int reserve(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
         if (bytes <= cap) return SVX_OK;
-        size_t ncap = bytes + bytes / 8 + 256;
+        const bool guard = svx_guard_mode();
+        size_t ncap = guard && !svx_guard_slack() ? bytes : bytes + bytes / 8 + 256;
         void* np = nullptr;
         const auto t0_ = std::chrono::steady_clock::now();
-        HIPCHK(hipMalloc(&np, ncap));
+        if (guard) SVXCHK(svx_guard_alloc(&np, ncap)); else HIPCHK(hipMalloc(&np, ncap));
         svx_alloc_seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(); svx_alloc_calls()++; svx_alloc_bytes() += ncap;
         if (keep && p && cap) {
             HIPCHK(hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipStreamSynchronize(s));
         }
-        if (p) (void)hipFree(p);
+        release();
         p = np;
         cap = ncap;
         return SVX_OK;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) { if (svx_guard_mode()) svx_guard_free(p); else (void)hipFree(p); }
         p = nullptr;
         cap = 0;
     }

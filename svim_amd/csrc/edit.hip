@@ -30,6 +30,7 @@
 // measured by tools/micro/valu_ops.hip, valu_dep.hip and column_rate.hip (v_alignbit, v_addc_co and every instruction reading three
 // different VGPRs are half rate; the column update costs 38 issue cycles per word-column and runs at 42-44 stand-alone).
 #include "common.hpp"
+#include "hostcopy.hpp"
 #include <type_traits>
 
 struct EditWork { uint32_t a, b; long long slot; };
@@ -1385,15 +1386,13 @@ __global__ __launch_bounds__(256) void k_edit_hist(long long n_work, const PairD
 static void profile_round(svx_ctx* c, int round, const long long* seg_lo, const long long* seg_cn, const uint32_t* list_dev, const PairDesc* desc_dev, long long n_desc) {
     hipStream_t st = c->stream;
     std::vector<PairDesc> desc((size_t)n_desc);
-    if (hipMemcpyAsync(desc.data(), desc_dev, (size_t)n_desc * sizeof(PairDesc), hipMemcpyDeviceToHost, st) != hipSuccess) return;
-    (void)hipStreamSynchronize(st);
+    if (svx_d2h(desc.data(), desc_dev, (size_t)n_desc * sizeof(PairDesc), st) != SVX_OK) return;
     for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
         const int cls = sc & (GENERIC_BASE - 1), generic = sc / GENERIC_BASE;
         const long long cn = seg_cn[sc];
         if (cls >= N_CLASSES || cn <= 0) continue;
         std::vector<uint32_t> list((size_t)cn);
-        if (hipMemcpyAsync(list.data(), list_dev + seg_lo[sc], (size_t)cn * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return;
-        (void)hipStreamSynchronize(st);
+        if (svx_d2h(list.data(), list_dev + seg_lo[sc], (size_t)cn * 4, st) != SVX_OK) return;
         int words = 0, per_wave = 64;                       // 32-bit words of column state per pair; pairs per wave
         if (cls < NBAND) words = band_words(cls);
         else if (cls >= CLS_LANE0 && cls < CLS_WIDE0) words = 1 << (cls - CLS_LANE0);
@@ -1547,8 +1546,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         if (profile) profile_round(c, round, seg_lo, seg_cn, list, desc, n_work);
         if (profile && round == 0) {
             first_desc.resize((size_t)n_work);
-            HIPCHK(hipMemcpyAsync(first_desc.data(), desc, (size_t)n_work * sizeof(PairDesc), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            SVXCHK(svx_d2h(first_desc.data(), desc, (size_t)n_work * sizeof(PairDesc), st));
         }
         // retry lists this round's band launch appends to: one list of `pending` slots per sort class.  Three buffers rotate; the one reused now was
         // last read by round-2's launches
@@ -1701,11 +1699,11 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         std::vector<long long> slot((size_t)n_work);
         long long n_slot = n_work;
         if (slot_of) {
-            HIPCHK(hipMemcpy(slot.data(), slot_of, (size_t)n_work * 8, hipMemcpyDeviceToHost));
+            SVXCHK(svx_d2h(slot.data(), slot_of, (size_t)n_work * 8, st));
             for (long long w = 0; w < n_work; w++) if (slot[(size_t)w] + 1 > n_slot) n_slot = slot[(size_t)w] + 1;
         }
         std::vector<int32_t> ed((size_t)n_slot);
-        HIPCHK(hipMemcpy(ed.data(), ed_dev, (size_t)n_slot * 4, hipMemcpyDeviceToHost));
+        SVXCHK(svx_d2h(ed.data(), ed_dev, (size_t)n_slot * 4, st));
         double used[N_CLASSES] = {0}, need[N_CLASSES] = {0}, failed[N_CLASSES] = {0}; long long cnt_c[N_CLASSES] = {0};
         double ratio_hist[8] = {0};
         auto h_need_class = [](int m, int n, int d) { int x = (d - (n - m)) / 2; if (x < 0) x = 0; const int nw = (n - m) + 2 * x + 1;
@@ -1747,16 +1745,14 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             // rare: shorter core > 16384 symbols.  Size the block-state scratch exactly from the core lengths.
             const long long nbig = (long long)nb;
             std::vector<uint32_t> items((size_t)nbig);
-            HIPCHK(hipMemcpyAsync(items.data(), c->e_big_list.p, (size_t)nbig * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            SVXCHK(svx_d2h(items.data(), c->e_big_list.p, (size_t)nbig * 4, st));
             std::vector<PairDesc> pd((size_t)nbig);
-            for (long long i = 0; i < nbig; i++) HIPCHK(hipMemcpyAsync(&pd[(size_t)i], desc + items[(size_t)i], sizeof(PairDesc), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            { HostCopy hc(st); for (long long i = 0; i < nbig; i++) SVXCHK(hc.d2h(&pd[(size_t)i], desc + items[(size_t)i], sizeof(PairDesc))); SVXCHK(hc.finish()); }
             std::vector<long long> off((size_t)nbig + 1, 0);
             for (long long i = 0; i < nbig; i++) off[(size_t)i + 1] = off[(size_t)i] + (((long long)pd[(size_t)i].m + 31) / 32) * 7;
             SVXCHK(c->e_big_state.reserve((size_t)off[(size_t)nbig] * 4 + 16));
             SVXCHK(c->e_big_off.reserve((size_t)(nbig + 1) * 8));
-            HIPCHK(hipMemcpyAsync(c->e_big_off.p, off.data(), (size_t)(nbig + 1) * 8, hipMemcpyHostToDevice, st));
+            SVXCHK(svx_h2d(c->e_big_off.p, off.data(), (size_t)(nbig + 1) * 8, st));
             k_edit_full_big<<<(unsigned)nbig, 64, 0, st>>>(nbig, c->e_big_list.as<uint32_t>(), c->e_big_off.as<long long>(), scratch, desc, slot_of, ed_dev,
                                                           c->e_big_state.as<uint32_t>());
             HIPCHK(hipGetLastError());

@@ -6,6 +6,7 @@
 // alignment records are a structure-of-arrays in HBM in file order; one wavefront per candidate binary-searches its window and
 // walks it 64 records at a time.  HBM-bound (20 B per record visited), latency-dominated for the short walks of real data.
 #include "common.hpp"
+#include "hostcopy.hpp"
 
 struct AlnIndexDev {
     int64_t n; int32_t n_contig;
@@ -106,7 +107,7 @@ int svx_set_alignment_index_impl(svx_ctx* c, const svx_aln_index* h) {
         {&b[4], h->flag, n * 2}, {&b[5], h->mapq, n}, {&b[6], h->name_id, n * 4}};
     for (auto& u : ups) {
         SVXCHK(u.d->reserve(u.bytes + 64));
-        if (u.bytes) HIPCHK(hipMemcpyAsync(u.d->p, u.src, u.bytes, hipMemcpyHostToDevice, st));
+        SVXCHK(svx_h2d(u.d->p, u.src, u.bytes, st));
     }
     SVXCHK(b[7].reserve(n * 4 + 64));
     c->geno_n = h->n; c->geno_contigs = h->n_contig;
@@ -127,16 +128,13 @@ int svx_genotype_impl(svx_ctx* c, int32_t mode, int64_t n_cand, const int32_t* t
     DevBuf* b = c->geno;
     SVXCHK(b[8].reserve(n * 4 * 4 + 64)); SVXCHK(b[9].reserve((n + 1) * 8 + 64)); SVXCHK(b[10].reserve(nm * 4 + 64));
     int32_t* d_tid = b[8].as<int32_t>(); int32_t* d_start = d_tid + n; int32_t* d_end = d_start + n; int32_t* d_out = d_end + n;
-    HIPCHK(hipMemcpyAsync(d_tid, tid, n * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_start, start, n * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_end, end, n * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b[9].p, moff, (n + 1) * 8, hipMemcpyHostToDevice, st));
-    if (nm) HIPCHK(hipMemcpyAsync(b[10].p, mnames, nm * 4, hipMemcpyHostToDevice, st));
+    HostCopy hc(st);
+    SVXCHK(hc.h2d(d_tid, tid, n * 4)); SVXCHK(hc.h2d(d_start, start, n * 4)); SVXCHK(hc.h2d(d_end, end, n * 4));
+    SVXCHK(hc.h2d(b[9].p, moff, (n + 1) * 8)); SVXCHK(hc.h2d(b[10].p, mnames, nm * 4));
     AlnIndexDev ix{c->geno_n, c->geno_contigs, b[0].as<int64_t>(), b[1].as<int64_t>(), b[2].as<int32_t>(), b[3].as<int32_t>(), b[7].as<int32_t>(),
                    b[4].as<uint16_t>(), b[5].as<uint8_t>(), b[6].as<int32_t>()};
     k_genotype<<<(unsigned)n_cand, 64, 0, st>>>(ix, mode, n_cand, d_tid, d_start, d_end, b[9].as<int64_t>(), b[10].as<int32_t>(), min_mapq, d_out);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    return SVX_OK;
+    SVXCHK(hc.d2h(out, d_out, n * 4));
+    return hc.finish();
 }

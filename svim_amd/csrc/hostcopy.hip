@@ -1,0 +1,142 @@
+// hostcopy.hip - page-locked bounce buffers for every copy between pageable host memory and the device (hostcopy.hpp says why).
+//
+// The pool: per device, slots of two sizes - SMALL (64 KiB, for the many counters / offsets / short arrays of a call) and BIG (8 MiB, larger arrays go through
+// them in pieces, two in flight).  A slot carries an event: a host -> device copy leaves the slot "pending" until the event is over, and whoever takes the slot next
+// waits for it (or takes another slot whose event is already over).  Slots are allocated on demand with hipHostMalloc and live until the process ends - page-locked
+// memory that is never unmapped is the one kind of host memory whose registration with the GPU cannot go stale.
+#include "common.hpp"
+#include "hostcopy.hpp"
+#include <mutex>
+#include <cstdlib>
+
+struct BounceSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false, busy = false; int dev = 0; bool big = false; };
+
+namespace {
+const size_t SMALL_CAP = (size_t)64 << 10, BIG_CAP = (size_t)8 << 20;
+const int MAX_DEV = 16;
+struct Pool { std::mutex m; std::vector<BounceSlot*> small, big; };
+Pool g_pool[MAX_DEV];
+
+BounceSlot* acquire(size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) { (void)hipGetLastError(); return nullptr; }
+    Pool& P = g_pool[dev];
+    const bool big = bytes > SMALL_CAP;
+    BounceSlot* wait_for = nullptr;
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        std::vector<BounceSlot*>& v = big ? P.big : P.small;
+        for (BounceSlot* s : v) {
+            if (s->busy) continue;
+            if (s->pending) { if (hipEventQuery(s->ev) != hipSuccess) { (void)hipGetLastError(); if (!wait_for) wait_for = s; continue; } s->pending = false; }
+            s->busy = true;
+            return s;
+        }
+        // nothing free without waiting: a new slot while the pool is small (8 big = 64 MiB, 256 small = 16 MiB), else the oldest pending one
+        if (!wait_for || v.size() < (big ? 8u : 256u)) {
+            BounceSlot* s = new BounceSlot();
+            s->cap = big ? BIG_CAP : SMALL_CAP; s->dev = dev; s->big = big;
+            if (hipHostMalloc(&s->p, s->cap, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                if (s->p) (void)hipHostFree(s->p);
+                delete s;
+                if (!wait_for) return nullptr;
+            } else { s->busy = true; v.push_back(s); return s; }
+        }
+        wait_for->busy = true;
+    }
+    if (hipEventSynchronize(wait_for->ev) != hipSuccess) (void)hipGetLastError();      // (a sticky device error shows at the caller's next call)
+    wait_for->pending = false;
+    return wait_for;
+}
+void release(BounceSlot* s, bool pending) {
+    Pool& P = g_pool[s->dev];
+    std::lock_guard<std::mutex> g(P.m);
+    s->pending = pending; s->busy = false;
+}
+}  // namespace
+
+bool svx_copy_direct() { static const bool on = []() { const char* e = getenv("SVX_COPY_DIRECT"); return e && e[0] == '1'; }(); return on; }
+
+bool svx_is_device_pointer(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }     // memory the runtime does not know: pageable host memory
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray || a.type == hipMemoryTypeManaged;
+}
+
+HostCopy::~HostCopy() { for (auto& q : pend_) release(q.slot, false); }
+
+int HostCopy::h2d(void* dev_dst, const void* host_src, size_t bytes) {
+    if (!bytes) return SVX_OK;
+    if (svx_copy_direct()) { HIPCHK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st_)); return SVX_OK; }
+    const char* src = (const char*)host_src; char* dst = (char*)dev_dst;
+    while (bytes) {
+        const size_t n = bytes < BIG_CAP ? bytes : BIG_CAP;
+        BounceSlot* s = acquire(n);
+        if (!s) return svx_fail(SVX_E_HIP, "no page-locked bounce buffer (hipHostMalloc)", __FILE__, __LINE__, hipSuccess);
+        memcpy(s->p, src, n);
+        hipError_t e = hipMemcpyAsync(dst, s->p, n, hipMemcpyHostToDevice, st_);
+        if (e == hipSuccess) e = hipEventRecord(s->ev, st_);
+        release(s, e == hipSuccess);
+        if (e != hipSuccess) return svx_fail(SVX_E_HIP, "host -> device copy through a bounce buffer", __FILE__, __LINE__, e);
+        src += n; dst += n; bytes -= n;
+    }
+    return SVX_OK;
+}
+
+// hand out the oldest pending device -> host pieces until at most `keep_big` BIG ones and `keep_all` pieces altogether are left in flight
+int HostCopy::drain(size_t keep_big, size_t keep_all) {
+    size_t k = 0;
+    while (k < pend_.size() && (pend_big_ > keep_big || pend_.size() - k > keep_all)) {
+        Pending& q = pend_[k];
+        const hipError_t e = hipEventSynchronize(q.slot->ev);
+        if (e != hipSuccess) { pend_.erase(pend_.begin(), pend_.begin() + (long)k); return svx_fail(SVX_E_HIP, "device -> host copy through a bounce buffer", __FILE__, __LINE__, e); }
+        memcpy(q.dst, q.slot->p, q.bytes);
+        if (q.slot->big) pend_big_--;
+        release(q.slot, false);
+        k++;
+    }
+    pend_.erase(pend_.begin(), pend_.begin() + (long)k);
+    return SVX_OK;
+}
+
+int HostCopy::d2h(void* host_dst, const void* dev_src, size_t bytes) {
+    if (!bytes) return SVX_OK;
+    if (svx_copy_direct()) { HIPCHK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, st_)); return SVX_OK; }
+    char* dst = (char*)host_dst; const char* src = (const char*)dev_src;
+    while (bytes) {
+        const size_t n = bytes < BIG_CAP ? bytes : BIG_CAP;
+        if (n > SMALL_CAP && pend_big_ >= 2) SVXCHK(drain(1, (size_t)-1));              // two big pieces in flight: the copy of one overlaps the memcpy of the other
+        if (pend_.size() >= 192) SVXCHK(drain((size_t)-1, 96));                        // (a call with very many small arrays must not hold the whole pool)
+        BounceSlot* s = acquire(n);
+        if (!s) return svx_fail(SVX_E_HIP, "no page-locked bounce buffer (hipHostMalloc)", __FILE__, __LINE__, hipSuccess);
+        hipError_t e = hipMemcpyAsync(s->p, src, n, hipMemcpyDeviceToHost, st_);
+        if (e == hipSuccess) e = hipEventRecord(s->ev, st_);
+        if (e != hipSuccess) { release(s, false); return svx_fail(SVX_E_HIP, "device -> host copy through a bounce buffer", __FILE__, __LINE__, e); }
+        pend_.push_back(Pending{s, dst, n});
+        if (s->big) pend_big_++;
+        src += n; dst += n; bytes -= n;
+    }
+    return SVX_OK;
+}
+
+int HostCopy::out(void* dst, const void* dev_src, size_t bytes) {
+    if (!bytes) return SVX_OK;
+    if (svx_copy_direct()) { HIPCHK(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDefault, st_)); return SVX_OK; }
+    if (svx_is_device_pointer(dst)) { HIPCHK(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToDevice, st_)); return SVX_OK; }
+    return d2h(dst, dev_src, bytes);
+}
+
+int HostCopy::finish() {
+    if (svx_copy_direct()) { HIPCHK(hipStreamSynchronize(st_)); return SVX_OK; }
+    if (pend_.empty()) return SVX_OK;
+    const hipError_t e = hipStreamSynchronize(st_);
+    if (e != hipSuccess) return svx_fail(SVX_E_HIP, "device -> host copies through bounce buffers", __FILE__, __LINE__, e);
+    for (auto& q : pend_) { memcpy(q.dst, q.slot->p, q.bytes); release(q.slot, false); }
+    pend_.clear(); pend_big_ = 0;
+    return SVX_OK;
+}
+
+int svx_h2d(void* dev_dst, const void* host_src, size_t bytes, hipStream_t st) { HostCopy hc(st); return hc.h2d(dev_dst, host_src, bytes); }
+int svx_d2h(void* host_dst, const void* dev_src, size_t bytes, hipStream_t st) { HostCopy hc(st); SVXCHK(hc.d2h(host_dst, dev_src, bytes)); return hc.finish(); }
