@@ -198,6 +198,9 @@ int  svx_cluster(svx_ctx* ctx, int source, const svx_sig_view* sigs, int32_t n_c
                  const int32_t* contig_rank_host, const svx_params* p);
 int  svx_cluster_count(svx_ctx* ctx, int64_t* n_clusters, int64_t* n_members);
 int  svx_cluster_fetch(svx_ctx* ctx, svx_cluster_view* out);  /* destination arrays: host or device memory */
+/* partitions of the last svx_cluster as form_partitions (src/svim/SVIM_clustering.py:17-29) makes them: sorted_index[n_sig] = signature indices in partition
+ * order, part_start[n_part + 1] = where each partition begins in it.  Inspection hook (tests compare it with the reference's partitions); NULL arrays: counts only */
+int  svx_cluster_partitions_fetch(svx_ctx* c, int64_t* n_sig, int64_t* n_part, uint32_t* sorted_index, int64_t* part_start);
 
 /* multi-GPU, contig-sharded ranks: each rank clusters ONLY the signatures of the contigs it owns - every partition of
  * src/svim/SVIM_clustering.py:17-29 is local to one rank.  What still couples the ranks is the random.sample word stream, which a signature type's
@@ -309,11 +312,14 @@ int  svx_bam_seek(svx_bam* h, uint64_t voff, int32_t last_tid);
 int  svx_bam_set_gpu_inflate(svx_bam* h, int device);
 int  svx_bam_gpu_inflate_stats(svx_bam* h, int64_t* gpu_blocks, int64_t* cpu_blocks, double* gpu_kernel_ms);
 int  svx_bam_read_names(svx_bam* h, int64_t* n_names, const char** nul_separated, int64_t* blob_len);
-/* Device-resident front-end (coordinate mode): the compressed file slice is the only thing that crosses PCIe.  Every chunk of BGZF blocks (8 GB of inflated
+/* Device-resident front-end (either sort order): the compressed file slice is the only thing that crosses PCIe.  Every chunk of BGZF blocks (8 GB of inflated
  * data) is inflated by the GPU into HBM (one wavefront per block), the record boundaries are found there (BGZF blocks are the restart points of the
  * block_size chain: a speculative record start per block, verified by linking the chains), and fixed fields, CIGAR (CG tag included), the SA tag -> segment
  * table and the read names (interned by 2 x 64-bit hashes) are decoded by kernels.  svx_bam_read_batch then returns an svx_batch whose pointers are DEVICE
- * memory (on_device = 1; seq points into the inflated stream - no bases are copied); arrays stay valid until the THIRD next chunk is loaded.  Every
+ * memory (on_device = 1; seq points into the inflated stream - no bases are copied).  Lifetime: the arrays that are views of the chunk (tid, pos, mapq, lseq,
+ * read_id, cigar_off, cigar, seq_off, seq and - mode 0 - flag and the seg_* table) stay valid until the THIRD next chunk is loaded; the arrays made per batch
+ * (order, seg_order and - mode 1, query-name order - flag and the seg_* table built from the read's supplementary records) alternate between two sets per chunk
+ * and stay valid until the SECOND next svx_bam_read_batch, like the batches of the host reader.  Every
  * inflated block is checked against the CRC32 of its BGZF trailer on the device (as htslib's bgzf_read_block does; environment SVX_BAM_VERIFY_CRC=0: off);
  * a damaged block fails the svx_bam_read_batch that would have handed out its records.  device < 0: back to the host reader. */
 int  svx_bam_set_device_decode(svx_bam* h, int device);

@@ -17,7 +17,7 @@ _LIB_PATH = os.environ.get("SVX_LIB") or os.path.join(_HERE, "libsvx.so")      #
 _LIB = None
 _ENGINES = {}
 
-SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream", "svx_memcpy_d2h", "svx_memcpy_h2d", "svx_dev_alloc", "svx_dev_free", "svx_device_synchronize", "svx_selftest_prims", "svx_bam_set_device_decode",
+SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream", "svx_cluster_partitions_fetch", "svx_memcpy_d2h", "svx_memcpy_h2d", "svx_dev_alloc", "svx_dev_free", "svx_device_synchronize", "svx_selftest_prims", "svx_bam_set_device_decode",
            "svx_collect", "svx_collect_count", "svx_collect_fetch", "svx_collect_accumulate", "svx_collect_set_slot_base", "svx_set_genome", "svx_cluster",
            "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_ranks", "svx_cluster_abort_ranks", "svx_cluster_stream_positions",
            "svx_set_alignment_index", "svx_genotype",
@@ -122,6 +122,16 @@ class Engine(object):
         if not fetch:
             return None
         return self.fetch_clusters()
+
+    def partitions(self):
+        """partitions of the last cluster() call (svx_cluster_partitions_fetch): list of lists of signature indices, in the order they were formed"""
+        n, npart = C.c_int64(), C.c_int64()
+        _check(self.L.svx_cluster_partitions_fetch(self.ctx, C.byref(n), C.byref(npart), None, None), "svx_cluster_partitions_fetch")
+        if n.value <= 0:
+            return []
+        sidx, start = np.zeros(n.value, dtype=np.uint32), np.zeros(npart.value + 1, dtype=np.int64)
+        _check(self.L.svx_cluster_partitions_fetch(self.ctx, None, None, ptr(sidx), ptr(start)), "svx_cluster_partitions_fetch")
+        return [[int(i) for i in sidx[int(start[k]):int(start[k + 1])]] for k in range(npart.value)]
 
     def fetch_clusters(self):
         n, nm = C.c_int64(), C.c_int64()

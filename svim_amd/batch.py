@@ -93,7 +93,23 @@ def build_batch(bam, options, mode="coordinate", records=None):
     bam: object with fetch(until_eof=True), get_tid(name), references (our AlignmentFile or pysam's).
     """
     min_mapq = int(getattr(options, "min_mapq", 20))
-    recs = list(bam.fetch(until_eof=True)) if records is None else list(records)
+    if records is None:
+        # Ctrl-C while the file is read: stop there and go on with what has been read (src/svim/SVIM_COLLECT.py:126-128,164-166 break their loops the same
+        # way; the step after COLLECT runs on the signatures of the reads processed so far)
+        recs = []
+        try:
+            for a in bam.fetch(until_eof=True):
+                recs.append(a)
+        except KeyboardInterrupt:
+            logging.warning('Execution interrupted by user. Stop detection and continue with next step..')
+            if mode != "coordinate" and recs:
+                # query-name order: the reference only processes COMPLETE read groups (bam_iterator yields a group when the next name appears, :8-41) - the
+                # records of the group the interrupt fell into are dropped
+                last = recs[-1].query_name
+                while recs and recs[-1].query_name == last:
+                    recs.pop()
+    else:
+        recs = list(records)
     n = len(recs)
     hb = HostBatch()
     hb.n_rec = n

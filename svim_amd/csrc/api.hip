@@ -413,6 +413,23 @@ extern "C" int svx_cluster_fetch(svx_ctx* c, svx_cluster_view* o) {
     return SVX_OK;
 }
 
+// The partitions of the last svx_cluster (form_partitions, src/svim/SVIM_clustering.py:17-29): `sorted_index` = the signature indices in the order the
+// partitions were formed in (type, contig rank(s), coordinate; stable), `part_start[k]` = first position of partition k in it, part_start[n_part] = n_sig.
+// A test / inspection hook: the clustering itself never leaves the device.  NULL arrays: counts only.
+extern "C" int svx_cluster_partitions_fetch(svx_ctx* c, int64_t* n_sig, int64_t* n_part, uint32_t* sorted_index, int64_t* part_start) {
+    if (!c) return svx_fail(SVX_E_ARG, "null context", __FILE__, __LINE__, hipSuccess);
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t n = c->last_cluster_source_n, np = c->stats.n_partitions;
+    if (n_sig) *n_sig = n;
+    if (n_part) *n_part = np;
+    if (n <= 0 || (!sorted_index && !part_start)) return SVX_OK;
+    if (!c->k_idx.p || !c->part_start.p) return svx_fail(SVX_E_STATE, "no partitions: run svx_cluster first", __FILE__, __LINE__, hipSuccess);
+    HostCopy hc(c->stream);
+    if (sorted_index) SVXCHK(hc.d2h(sorted_index, c->k_idx.p, (size_t)n * 4));
+    if (part_start) SVXCHK(hc.d2h(part_start, c->part_start.p, (size_t)(np + 1) * 8));
+    return hc.finish();
+}
+
 // ---- single-function entry points ------------------------------------------------------------------------------
 extern "C" int svx_cigar_indel(svx_ctx* c, const uint32_t* cigar_host, int64_t n_ops, int32_t min_length, int64_t* out_pos_ref,
                                int64_t* out_pos_read, int32_t* out_len, uint8_t* out_is_del, int64_t* out_n) {

@@ -230,7 +230,7 @@ __global__ void k_measure(const uint8_t* st, const uint64_t* rec_off, long long 
     uint32_t segs = 0, ops = 0;
     if ((want_cg || primary_ok) && d.n_cig == ncf) {
         uint64_t q = d.seq_at + ((uint64_t)l_seq + 1) / 2 + l_seq;
-        uint64_t cg_at = 0; uint32_t cg_n = 0; bool have_cg = false;
+        uint64_t cg_at = 0; uint32_t cg_n = 0; bool have_cg = false, cg_seen = false;      // (bam_aux_get: the FIRST field named CG counts, whatever its type)
         while (q + 3 <= end) {
             const uint8_t t0 = st[q], t1 = st[q + 1], ty = st[q + 2];
             q += 3;
@@ -251,12 +251,13 @@ __global__ void k_measure(const uint8_t* st, const uint64_t* rec_off, long long 
                 const uint32_t c = ld32(st, q + 1);
                 const uint64_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
                 sz = 5 + es * (uint64_t)c;
-                if (sz <= left && t0 == 'C' && t1 == 'G' && (sub == 'I' || sub == 'i') && c > 0u) { cg_at = q + 5; cg_n = c; have_cg = true; }
+                if (sz <= left && t0 == 'C' && t1 == 'G' && !cg_seen && (sub == 'I' || sub == 'i') && c > 0u) { cg_at = q + 5; cg_n = c; have_cg = true; }
             } else { atomicExch(err, DD_E_AUX); break; }
+            if (t0 == 'C' && t1 == 'G') cg_seen = true;
             if (sz > left) { atomicExch(err, DD_E_AUX); break; }
             q += sz;
         }
-        if (want_cg && have_cg) { d.cig_at = cg_at; d.n_cig = cg_n; }      // long CIGARs (> 65535 operations) live in CG:B,I behind a <l_seq>S<ref_len>N placeholder
+        if (want_cg && have_cg && cg_n >= d.n_cig && cg_n < (1u << 29)) { d.cig_at = cg_at; d.n_cig = cg_n; }      // (only an array at least as long as the placeholder)      // long CIGARs (> 65535 operations) live in CG:B,I behind a <l_seq>S<ref_len>N placeholder
         if (primary_ok && d.sa_len) {
             // what the SA string expands to: entries with exactly 6 fields (src/svim/SVIM_COLLECT.py:55-62), operations of their CIGAR field
             d.flags = 1u;
@@ -546,7 +547,8 @@ struct DevChunk {
 
 struct svx_devdec {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;              // the chunk loader's (devdec_load / devdec_count: a background thread of the reader)
+    hipStream_t batch_stream = nullptr;        // the consumer's (devdec_batch): a chunk it hands out is complete, nothing of it waits behind the NEXT chunk's inflate
     svx_inflater* inf = nullptr;
     int32_t n_ref = 0;
     DevBuf ref_len, contig_rank, ct_key, ct_tid, ct_names, ct_name_off, err, counters, crc_shift, batch_cnt;
@@ -582,6 +584,7 @@ int devdec_create(int device, int n_threads, int32_t n_ref, const int32_t* ref_l
     d->device = device; d->n_ref = n_ref;
     d->n_threads = n_threads > 0 ? n_threads : 1;
     HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&d->batch_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     SVXCHK(svx_inflater_create(device, &d->inf));
     { void* p = nullptr; HIPCHK(hipHostMalloc(&p, DD_PINNED_BYTES, hipHostMallocDefault)); memset(p, 0, DD_PINNED_BYTES); d->h_err = (int*)p; d->h_cnt = (unsigned long long*)((char*)p + 64); }
@@ -624,6 +627,7 @@ void devdec_destroy(svx_devdec* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     (void)hipStreamSynchronize(d->stream);
+    (void)hipStreamSynchronize(d->batch_stream);
     if (d->inf) svx_inflater_destroy(d->inf);
     for (auto& c : d->chunk) c.release();
     DevBuf* all[] = {&d->ref_len, &d->contig_rank, &d->ct_key, &d->ct_tid, &d->ct_names, &d->ct_name_off, &d->err, &d->counters, &d->crc_shift, &d->batch_cnt, &d->nt_key, &d->nt_check, &d->nt_id};
@@ -631,6 +635,7 @@ void devdec_destroy(svx_devdec* d) {
     if (d->h_err) (void)hipHostFree(d->h_err);
     if (d->hbuf) (void)hipHostFree(d->hbuf);
     (void)hipStreamDestroy(d->copy_stream);
+    (void)hipStreamDestroy(d->batch_stream);
     (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -648,8 +653,8 @@ const std::vector<std::string>& devdec_names(svx_devdec* d) { return d->names; }
 void devdec_stats(svx_devdec* d, DevDecStats* out) { *out = d->stats; }
 void devdec_reset_names(svx_devdec* d) { (void)d; }
 
-template <class T> static int dd_scan(svx_devdec* d, DevChunk& c, const T* in, T* out, size_t n) {           // exclusive; out[n] NOT written
-    return svx_exclusive_scan<T, T>(in, out, (long long)n, d->stream, c.scan_tmp);
+template <class T> static int dd_scan(svx_devdec* d, DevChunk& c, const T* in, T* out, size_t n, hipStream_t st = nullptr) {           // exclusive; out[n] NOT written
+    return svx_exclusive_scan<T, T>(in, out, (long long)n, st ? st : d->stream, c.scan_tmp);
 }
 
 static int dd_check(svx_devdec* d, const char* where) {
@@ -1016,7 +1021,7 @@ int devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t* count_io, int 
     int64_t count = *count_io;
     if (!c.loaded || first < 0 || count < 0 || first + count > c.n_rec) return svx_fail(SVX_E_ARG, "record range outside the chunk", __FILE__, __LINE__, hipSuccess);
     HIPCHK(hipSetDevice(d->device));
-    hipStream_t st = d->stream;
+    hipStream_t st = d->batch_stream;
     if (mode == 1 && count > 0 && first + count < c.n_rec) {
         // a read's group is never split: the batch grows to the next group boundary (the chunk itself ends on one)
         // (a counter of its own: devdec_load - which may be running on the loader thread for the NEXT chunk - clears all of d->counters)
@@ -1055,8 +1060,8 @@ int devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t* count_io, int 
     SVXCHK(c.q_flag[f].reserve(N1 * 2)); SVXCHK(c.q_seg_off[f].reserve(N1 * 4));
     SVXCHK(c.q_head.reserve(N1 * 4)); SVXCHK(c.q_good.reserve(N1 * 4)); SVXCHK(c.q_gidx.reserve(N1 * 4)); SVXCHK(c.q_good_ex.reserve(N1 * 4));
     k_q_marks<<<GRIDB(n + 1, 256), 256, 0, st>>>(n, fl, mq, rid, min_mapq, c.q_head.as<uint32_t>(), c.q_good.as<uint32_t>());
-    SVXCHK(dd_scan<uint32_t>(d, c, c.q_head.as<uint32_t>(), c.q_gidx.as<uint32_t>(), N1));
-    SVXCHK(dd_scan<uint32_t>(d, c, c.q_good.as<uint32_t>(), c.q_good_ex.as<uint32_t>(), N1));
+    SVXCHK(dd_scan<uint32_t>(d, c, c.q_head.as<uint32_t>(), c.q_gidx.as<uint32_t>(), N1, st));
+    SVXCHK(dd_scan<uint32_t>(d, c, c.q_good.as<uint32_t>(), c.q_good_ex.as<uint32_t>(), N1, st));
     HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_GROUPS], c.q_gidx.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const long long G = (long long)(uint32_t)d->h_cnt[DD_H_GROUPS];
@@ -1067,8 +1072,8 @@ int devdec_batch(svx_devdec* d, int slot, int64_t first, int64_t* count_io, int 
     if (n) k_q_groups<<<GRIDB(n, 256), 256, 0, st>>>(n, c.q_head.as<uint32_t>(), c.q_gidx.as<uint32_t>(), fl, c.q_gs.as<uint32_t>(), c.q_nprim.as<uint32_t>(), c.q_pidx.as<uint32_t>());
     k_q_verdict<<<GRIDB(G + 1, 256), 256, 0, st>>>(G, n, c.q_gs.as<uint32_t>(), c.q_nprim.as<uint32_t>(), c.q_pidx.as<uint32_t>(), fl, mq, min_mapq, c.q_good_ex.as<uint32_t>(),
                                                  c.q_slots.as<uint32_t>(), c.q_rows.as<uint32_t>());
-    SVXCHK(dd_scan<uint32_t>(d, c, c.q_slots.as<uint32_t>(), c.q_slot_ex.as<uint32_t>(), G1));
-    SVXCHK(dd_scan<uint32_t>(d, c, c.q_rows.as<uint32_t>(), c.q_row_ex.as<uint32_t>(), G1));
+    SVXCHK(dd_scan<uint32_t>(d, c, c.q_slots.as<uint32_t>(), c.q_slot_ex.as<uint32_t>(), G1, st));
+    SVXCHK(dd_scan<uint32_t>(d, c, c.q_rows.as<uint32_t>(), c.q_row_ex.as<uint32_t>(), G1, st));
     HIPCHK(hipMemcpyAsync(&d->h_cnt[DD_H_ROWS], c.q_row_ex.as<uint32_t>() + G, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const long long R = (long long)(uint32_t)d->h_cnt[DD_H_ROWS];

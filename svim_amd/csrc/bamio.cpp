@@ -734,9 +734,11 @@ static inline bool cg_placeholder(const uint8_t* rec, const uint8_t* cig, uint32
     return n_cig >= 1 && (int32_t)rd32(rec) >= 0 && (int32_t)rd32(rec + 4) >= 0 && (rd32(cig) & 15) == 4 && (rd32(cig) >> 4) == l_seq;
 }
 
-// aux fields of one record: SA (Z) and CG (B,I)
+// aux fields of one record: SA (Z) and CG (B,I).  CG as htslib's bam_aux_get finds it: the FIRST field of that name, whatever its type - a first CG of
+// another type hides a later array (bam_tag2cigar then leaves the record alone)
 static void scan_aux(const uint8_t* q, const uint8_t* end, const char*& sa, size_t& sa_n, const uint8_t*& cg, uint32_t& cg_n) {
     sa = nullptr; sa_n = 0; cg = nullptr; cg_n = 0;
+    bool cg_seen = false;
     while (q + 3 <= end) {
         const char t0 = (char)q[0], t1 = (char)q[1], ty = (char)q[2]; q += 3;
         size_t sz = 0;
@@ -751,9 +753,10 @@ static void scan_aux(const uint8_t* q, const uint8_t* end, const char*& sa, size
                 const char sub = (char)q[0]; const uint32_t cnt = rd32(q + 1); const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
                 sz = 5 + es * (size_t)cnt;
                 if (sz > left) throw std::string("BAM aux array runs past the end of its record");
-                if (t0 == 'C' && t1 == 'G' && (sub == 'I' || sub == 'i') && cnt > 0) { cg = q + 5; cg_n = cnt; } break; }
+                if (t0 == 'C' && t1 == 'G' && !cg_seen && (sub == 'I' || sub == 'i') && cnt > 0) { cg = q + 5; cg_n = cnt; } break; }
             default: throw std::string("unknown BAM aux type");
         }
+        if (t0 == 'C' && t1 == 'G') cg_seen = true;
         if (sz > left) throw std::string("BAM aux field runs past the end of its record");
         q += sz;
     }
@@ -792,7 +795,8 @@ static int64_t decode_run(svx_bam* h, int64_t max_count, bool sparse) {
         if (cg_placeholder(rr.r, rr.cig, rr.n_cig, l_seq)) {
             const char* sa; size_t sa_n; const uint8_t* cg; uint32_t cg_n;
             scan_aux(rr.cig + 4 * (size_t)rr.n_cig + (l_seq + 1) / 2 + l_seq, rr.end, sa, sa_n, cg, cg_n);
-            if (cg) { if (cg + 4 * (size_t)cg_n > rr.end) throw std::string("corrupt CG tag"); rr.cig = cg; rr.n_cig = cg_n; }
+            // (bam_tag2cigar: only a CG array at least as long as the placeholder replaces it - "don't move if the real CIGAR length is shorter than the fake")
+            if (cg && cg_n >= rr.n_cig && cg_n < (1u << 29)) { if (cg + 4 * (size_t)cg_n > rr.end) throw std::string("corrupt CG tag"); rr.cig = cg; rr.n_cig = cg_n; }
         }
         cig_total += rr.n_cig;
         B.cigar_off.push_back(cig_total);
@@ -915,7 +919,7 @@ static int parse_record(svx_bam* h) {
     q += l_seq;
     const char* sa; size_t sa_n; const uint8_t* cg; uint32_t cg_n;
     scan_aux(q, end, sa, sa_n, cg, cg_n);
-    if (cg && cg_placeholder(r, cig, n_cig, l_seq)) { cig = cg; n_cig = cg_n; }          // long CIGARs (> 65535 ops): see decode_run
+    if (cg && cg_n >= n_cig && cg_n < (1u << 29) && cg_placeholder(r, cig, n_cig, l_seq)) { cig = cg; n_cig = cg_n; }          // long CIGARs (> 65535 ops): see decode_run
     const int32_t rid = h->names.intern(name.data(), name.size(), name_hash(name.data(), name.size()));
     h->b->flag.push_back((uint16_t)(flag & 0x0fff)); h->b->tid.push_back(tid); h->b->bpos.push_back(pos); h->b->mapq.push_back((uint8_t)mq);
     h->b->lseq.push_back((int32_t)l_seq); h->b->read_id.push_back(rid);

@@ -1200,6 +1200,7 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
     hipStream_t st = c->stream;
     const svx_params p = *pp;
     const int64_t n = in.n;
+    c->last_cluster_source_n = n;
     DevClusters& out = c->clu;
     out.n = 0; out.n_members = 0;
     for (int t = 0; t < SVX_NTYPES; t++) out.type_count[t] = 0;

@@ -12,6 +12,7 @@ bench.py uses run_bam() for `--bam/--fasta` (the real configs[2]-[4] inputs) and
 the default line: a BAM written from a slice of the synthetic batch (write_bam_from_batch - test / bench infrastructure, not on
 the product path).
 """
+import logging
 import os
 import threading
 import time
@@ -61,6 +62,7 @@ class BamPipeline(object):
         self.regions = regions            # [(virtual offset, last reference id)]: the contig runs this rank reads (None: the whole file)
         self.region_slots = []            # per region: (first local emission slot, records)
         self.stats = {}
+        self.interrupted = False          # run() was ended by Ctrl-C (KeyboardInterrupt): the results are those of the batches collected until then
 
     def run(self):
         bam, eng, p = self.bam, self.eng, self.params
@@ -129,6 +131,11 @@ class BamPipeline(object):
                 n_rec += n
                 n_batches += 1
                 free.release()
+        except KeyboardInterrupt:
+            # src/svim/SVIM_COLLECT.py:126-128,164-166: an interrupt ends the reading, the pipeline goes on with what was collected - here the batches whose
+            # svx_collect has completed (their signatures are in the accumulated lists on the device); the batch being read is dropped
+            logging.warning('Execution interrupted by user. Stop detection and continue with next step..')
+            self.interrupted = True
         finally:
             # whatever happened (a failing collect, an interrupt): the reader thread leaves libsvx BEFORE anyone may close the handle it reads from
             stop.set()

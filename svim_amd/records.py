@@ -272,10 +272,13 @@ def _read_bgzf(path):
 
 
 def _decode_bam_aux(buf, p, end, tags):
+    first = tags
     while p < end:
         name = buf[p:p + 2].decode("ascii")
         typ = chr(buf[p + 2])
         p += 3
+        # a tag that occurs twice: pysam's get_tag (htslib bam_aux_get) finds the FIRST occurrence - later ones are parsed (to step over them) and dropped
+        tags = {} if name in first else first
         if typ == "A":
             tags[name] = chr(buf[p]); p += 1
         elif typ == "c":
@@ -455,7 +458,8 @@ class AlignmentFile(object):
             _decode_bam_aux(data, q, end, tags)
             # long CIGARs (> 65535 ops) live in the CG:B,I tag with a placeholder kSmN CIGAR
             # (htslib's bam_tag2cigar rule: a mapped record whose first operation soft-clips the whole read; CG of type B,I or B,i)
-            if "CG" in tags and tags.get("__B_CG") in ("I", "i") and len(tags["CG"]) > 0 and n_cigar >= 1 and a._cigar[0] == (4, l_seq) and tid >= 0 and pos >= 0:
+            # ... and at least as long as the placeholder: "don't move if the real CIGAR length is shorter than the fake cigar length")
+            if "CG" in tags and tags.get("__B_CG") in ("I", "i") and n_cigar <= len(tags["CG"]) < (1 << 29) and n_cigar >= 1 and a._cigar[0] == (4, l_seq) and tid >= 0 and pos >= 0:
                 a._cigar = [(c & 0xF, c >> 4) for c in tags.pop("CG")]
                 tags.pop("__B_CG", None)
             a._tags = {k: v for k, v in tags.items() if not k.startswith("__B_")}

@@ -65,13 +65,32 @@ def foreign_case(seed, with_long=True):
         short2, long2, _ = H.long_cigar_records()
         long2.reference_id, long2.query_name = 2, "long_other_writer"
         tail.append((long2, [("CG", "B", ("i", [(l << 4) | o for o, l in long2._cigar])), ("NM", "i", 3)], None))
+        # htslib's bam_tag2cigar in full (what pysam hands the reference): the placeholder stays when the CG array is SHORTER than the placeholder CIGAR, and
+        # bam_aux_get finds the FIRST field named CG - of another type it hides a later array, of the right type it wins over a later one
+        def small(name, cigar):
+            a = records.AlignedSegment()
+            a.query_name, a.flag, a.reference_id, a.reference_start, a._mapq = name, 0, 2, 100, 60
+            a._cigar, a._seq, a._tags = list(cigar), "".join(rng.choice("ACGT") for _ in range(50)), {}
+            a.next_reference_id, a.next_reference_start, a.template_length = -1, -1, 0
+            return a
+        real_a, real_b = [(0, 30), (2, 60), (0, 20)], [(0, 10), (1, 45), (0, 5)]
+        pk = lambda cg: [(l << 4) | o for o, l in cg]                                   # noqa: E731
+        tail.append((small("cg_shorter_than_placeholder", [(4, 50), (3, 300), (3, 200)]), [("NM", "i", 1), ("CG", "B", ("I", pk([(0, 50), (2, 10)])))], None))
+        tail.append((small("cg_first_of_other_type", [(4, 50), (3, 500)]), [("CG", "Z", "not an array"), ("CG", "B", ("I", pk(real_a)))], None))
+        two = small("cg_two_arrays", real_a)                                             # (the truth list holds the CIGAR the FIRST array restores)
+        tail.append((two, [("tp", "A", "P"), ("CG", "B", ("I", pk(real_a))), ("CG", "B", ("I", pk(real_b)))], None))
         # keep the file coordinate-sorted: all go behind the last chr10 record
         last_pos = max([a.reference_start for a in recs if a.reference_id == 2] + [0])
         for k, (a, items, q) in enumerate(tail):
             a.reference_start = last_pos + 10
             last_pos += 10
             recs.append(a)
-            out.append(FB.record_bytes(a, items, q, placeholder_op=0 if k == 2 else 3))
+            if a.query_name == "cg_two_arrays":                                          # written behind a placeholder although it is short
+                ph = small(a.query_name, [(4, 50), (3, 110)])
+                ph._seq, ph.reference_start = a._seq, a.reference_start
+                out.append(FB.record_bytes(ph, items, q))
+            else:
+                out.append(FB.record_bytes(a, items, q, placeholder_op=0 if k == 2 else 3))
     return recs, out
 
 

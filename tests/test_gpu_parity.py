@@ -150,6 +150,35 @@ def test_cluster_golden_and_oracle(eng, oracle, idx):
     assert ct.first_difference(oc, rtol=1e-12) is None
 
 
+def test_form_partitions_on_the_gpu_match_reference_golden(eng):
+    """form_partitions (src/svim/SVIM_clustering.py:17-29) as the GPU makes it - key sort + boundary flags + scan - against g4_partitions, the reference's own
+    partitions of the g5 cases (so far only the oracle and a host helper saw this fixture; the GPU's partitions were pinned through the
+    member lists of g5 only)."""
+    g4 = H.load("g4_partitions.json.gz")
+    g5 = H.load("g5_cluster.json.gz")
+    cases = {c["name"]: c for c in g5["cases"]}
+    done = {}
+    checked = 0
+    for p in g4["partitions"]:
+        case = cases[p["case"]]
+        if p["case"] not in done:
+            o = H.options(case["options"])
+            sigs = [H.row_sig(r) for r in case["signatures"]]
+            tab, contigs, reads = convert.sigtable_from_objects(sigs, convert.Interner(H.REFS))
+            off, codes = convert.genome_arrays(o.genome, contigs.names)
+            eng.set_genome(off, codes)
+            eng.cluster(_abi.Params.from_options(o), batch.contig_ranks(contigs.names), table=tab, fetch=False)
+            done[p["case"]] = (tab, eng.partitions())
+        tab, parts = done[p["case"]]
+        code = _abi.TYPE_CODE[p["type"]]
+        got = [q for q in parts if tab.type[q[0]] == code]
+        assert all(len(set(int(tab.type[i]) for i in q)) == 1 for q in parts)
+        assert got == p["partitions"], (p["case"], p["type"])
+        checked += len(got)
+    assert checked > 50
+    assert sorted(i for q in done[p["case"]][1] for i in q) == list(range(len(done[p["case"]][0].type)))
+
+
 def test_sampling_many_partition_sizes_vs_oracle(eng, oracle):
     """random.sample replay: partitions of every size 101..190, around 256/512/1024 and the pool/set switch (1045/1046),
     several per type so that the RNG stream is carried across them."""
@@ -1252,6 +1281,7 @@ def test_device_bam_decode_equals_host_reader(tmp_path, monkeypatch, chunk_block
     p3 = str(tmp_path / "cg.bam")
     records.write_bam(p3, ["chr1"], [2000000], [short, long_rec, short])
     files.append((p3, 5))
+    truth = {p1: recs[:3000], p2: rr, p3: [short, long_rec, short]}
     for path, per_batch in files:
         host = NativeBam(path, threads=2)
         want, want_names = _read_all_batches(host, per_batch)
@@ -1263,6 +1293,16 @@ def test_device_bam_decode_equals_host_reader(tmp_path, monkeypatch, chunk_block
             assert got_names == want_names, path
             a, b = _concat_batches(got), _concat_batches(want)
             assert len(a) == len(b) and len(a) > 2, path
+            # not only "equal to the host reader": the records the file was written from (two product paths that agree on a wrong answer cannot pass)
+            src = truth[path]
+            assert len(a) == len(src) and got_names == [r.query_name for r in src], path
+            for k, (x, r) in enumerate(zip(a, src)):
+                cig = np.array([(ln << 4) | op for op, ln in (r.cigartuples or [])], dtype=np.uint32).tobytes()
+                seq = r.query_sequence or ""
+                assert (x[0] & 0x0fff) == r.flag and x[1] == r.reference_id and x[2] == r.reference_start and x[3] == r.mapping_quality and x[4] == len(seq) and x[5] == cig, (path, k)
+                codes = np.frombuffer(x[6], dtype=np.uint8)
+                nib = np.stack([codes >> 4, codes & 15], axis=1).reshape(-1)[:len(seq)]
+                assert bytes(b"=ACMGRSVTWYHKDBN"[int(v)] for v in nib).decode() == seq.upper(), (path, k)
             for k, (x, y) in enumerate(zip(a, b)):
                 assert x == y, (path, k, [i for i, (u, v) in enumerate(zip(x, y)) if u != v])
             dev.rewind()
@@ -1345,11 +1385,18 @@ def test_device_bam_decode_queryname_mode_equals_host_reader(tmp_path, monkeypat
     dev.set_device_decode(0)
     for rep in range(2):
         got, got_names = [], []
+        held = None
         while True:
             b, n = dev.read_batch(61, 20, "queryname")
             if n == 0:
                 break
             A = dev.batch_arrays(b)
+            if held is not None:
+                # include/svx.h: the per-batch arrays of query-name mode (flag, order, seg_order, the seg_* table) alternate between two sets - the batch handed
+                # out BEFORE this one is still intact (a consumer may stay one batch behind the reader, as harness.BamPipeline does)
+                again = dev.batch_arrays(held[0])
+                assert all(np.array_equal(again[k], held[1][k]) for k in held[1]), (chunk_blocks, rep, [k for k in held[1] if not np.array_equal(again[k], held[1][k])])
+            held = (b, A) if chunk_blocks is None else None                # (small chunks: a batch may be the last of its chunk - its slot rotates on)
             nm = dev.read_names()
             got_names += [nm[int(i)] for i in A["read_id"]]
             got.append(A)

@@ -663,3 +663,75 @@ def test_narrowing_staircase_window_rules_against_the_plain_dynamic_programme(tm
     assert run.returncode == 0 and " 0 wrong" in run.stdout, (run.stdout[-500:], run.stderr[-2000:])
     acc = int(run.stdout.split("settings:")[1].split("accepted")[0])
     assert acc > 8000, run.stdout
+
+
+def test_keyboard_interrupt_ends_the_reading_and_keeps_what_was_collected(tmp_path):
+    """src/svim/SVIM_COLLECT.py:126-128,164-166: Ctrl-C breaks the loop over the alignments and the function returns the signatures collected so far - the
+    pipeline goes on with them.  Here: (1) the Python batcher stops reading where the interrupt falls (query-name order: the incomplete last read group is
+    dropped - the reference only ever processes groups its iterator has completed, :8-41); (2) harness.BamPipeline ends its pass with the batches whose
+    COLLECT has completed, leaves libsvx's reader thread cleanly and reports the records of those batches."""
+    from svim_amd import harness
+    refs, lens = ["chr1", "chr2", "chr10"], [180000, 60000, 60000]
+    recs = synth.fuzz_split_reads(43, 60, refs, lens)                       # query-name order: the records of a read are adjacent
+
+    class Interrupting(object):
+        references = refs
+
+        def __init__(self, recs, after):
+            self.recs, self.after = recs, after
+
+        def fetch(self, until_eof=True):
+            for k, a in enumerate(self.recs):
+                if k == self.after:
+                    raise KeyboardInterrupt()
+                yield a
+
+        def get_tid(self, name):
+            return refs.index(name) if name in refs else -1
+
+    o = H.options({})
+    names = [a.query_name for a in recs]
+    cut = next(k for k in range(40, len(recs)) if names[k] == names[k - 1])          # inside a read group
+    hb = batch.build_batch(Interrupting(recs, cut), o, mode="queryname")
+    first_of_group = next(k for k in range(cut, -1, -1) if names[k] != names[cut - 1]) + 1
+    assert hb.n_rec == first_of_group < cut                                          # whole groups only
+    srt = synth.coordinate_sort(recs)
+    hb = batch.build_batch(Interrupting(srt, 37), o, mode="coordinate")
+    assert hb.n_rec == 37 and len(hb.read_names) > 5
+    whole = batch.build_batch(Interrupting(srt, 10 ** 9), o, mode="coordinate")
+    assert whole.n_rec == len(srt)
+
+    # (2) the native pipeline: a stand-in engine (no GPU here) whose second svx_collect is where the interrupt arrives
+    path = str(tmp_path / "ki.bam")
+    records.write_bam(path, refs, lens, srt)
+
+    class Eng(object):
+        device = None
+
+        def __init__(self):
+            self.calls, self.acc, self.sizes = 0, [], []
+
+        def accumulate(self, on):
+            self.acc.append(bool(on))
+
+        def set_slot_base(self, b):
+            pass
+
+        def collect(self, b, p, fetch=False):
+            self.calls += 1
+            if self.calls == 2:
+                raise KeyboardInterrupt()
+            self.sizes.append(int(b.n_rec))
+
+    eng = Eng()
+    pipe = harness.BamPipeline(path, o, eng, threads=2, batch_records=40, mode="coordinate", gpu_inflate=False, device_decode=False)
+    n = pipe.run()                                                                   # does not raise
+    assert pipe.interrupted and n == 40 and eng.sizes == [40] and pipe.stats["batches"] == 1
+    pipe.close()
+    assert eng.acc == [True, False]
+    # an uninterrupted pass over the same file for comparison
+    eng2 = Eng()
+    eng2.calls = 10
+    pipe = harness.BamPipeline(path, o, eng2, threads=2, batch_records=40, mode="coordinate", gpu_inflate=False, device_decode=False)
+    assert pipe.run() == len(srt) and not pipe.interrupted and sum(eng2.sizes) == len(srt)
+    pipe.close()
