@@ -57,6 +57,23 @@ def reference_python_figure():
         return None
 
 
+def reference_python_c1_shape():
+    """the reference itself on a configs[1]-SHAPED sample (tests/golden/g_c1_bench_sample.json.gz: 20 000 reads + their supplementary records at the bench workload's
+    densities, DEL / INS / INV), timed in the build container by tests/golden/make_golden.py c1_bench_sample"""
+    try:
+        import gzip
+        with gzip.open(os.path.join(REPO, "tests", "golden", "g_c1_bench_sample.json.gz"), "rt") as fh:
+            g = json.load(fh)
+        t = g["reference_seconds"]
+        return {"reads_per_s": g["n_reads"] / (t["collect"] + t["cluster"]), "reads": g["n_reads"], "records": g["n_records"], "collect_s": t["collect"], "cluster_s": t["cluster"],
+                "collect_only_reads_per_s": g["n_reads"] / t["collect"],
+                "workload": "configs[1]'s shape at a fiftieth of its size: 20 000 synthetic ONT reads (N50 20 kb) + 4 794 supplementary records on a 5 Mb contig, the bench "
+                            "workload's densities of DEL / INS / INV sites; CPython 3.10, 1 core of the BUILD container, pysam / edlib stubbed (the edlib stand-in is a "
+                            "pure-Python bit-vector Levenshtein: CLUSTER, 357 of the 367 s, is an upper bound - with the C edlib it would be a small fraction of that)"}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(batch, g_off, genome, params, eng=None, budget_s=20.0, parity_records=100_000):
     """The oracle (single-threaded C restatement of the reference algorithm, kind 'port') on a bounded, contiguous
     slice of the same batch (contiguous in coordinate order = full local coverage, so per-partition work is
@@ -101,6 +118,7 @@ def cpu_baseline(batch, g_off, genome, params, eng=None, budget_s=20.0, parity_r
     ref_py = reference_python_figure()
     return {"parity_vs_gpu_on_sample": parity, "value": best["used"] / t, "unit": "reads/s", "cores": 1, "kind": "port",
             "reference_python_reads_per_s": ref_py["reads_per_s"] if ref_py else None, "reference_python": ref_py,
+            "reference_python_on_configs1_shape": reference_python_c1_shape(),
             "what": "oracle/svx_oracle.c: single-threaded C restatement of the reference's algorithm (a STRONGER baseline than the "
                     "reference's Python loops: tests/golden/g_c1.json.gz records 1.99 s + 4.75 s of reference Python for 10 k records; "
                     "the reference itself cannot travel to the GPU box)",
@@ -126,12 +144,145 @@ def load_profile_json(name):
         return None
 
 
+def emit_strong(args, rank, world, local_rank, dev, use_dist, dist, opts, p, emit):
+    """--scaling strong: BASELINE.json configs[3]'s shape - one coordinate-sorted whole-genome batch (svim_amd/workloads.py, the same on every rank: same seed),
+    every rank collects the records of the contigs it owns (multigpu.assign_contigs: contiguous ranges in name order, balanced by length; the record runs of
+    those contigs are views of the resident batch) and the ranks cluster with svx_cluster's rank exchange; rank 0 gathers cluster rows + member lists
+    (signature columns stay on their ranks: gather_signatures=False).  Total work does not depend on N and N=1 is the plain single-GPU step over the whole
+    batch, so value(N) / value(1) IS the strong-scaling speedup.  The line carries what crossed the fabric in the last step (multigpu.WIRE)."""
+    import torch
+    from svim_amd import _lib, multigpu as MG, workloads
+    name = args.workload if args.workload != "c1" else "c3"
+    scale = args.scale if (args.scale != 1.0 or name != "c3") else 0.2      # c3 at full scale is a 30x human genome (4.6 M reads): the default is a fifth of it (~1 M reads)
+    t0 = time.perf_counter()
+    prof = workloads.profile(name, scale)
+    batch, genome, g_off, meta = workloads.make_batch_full(prof, seed=3, device=dev)            # NOT seed + rank: every rank holds the same batch
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    refs = [c[0] for c in prof["contigs"]]
+    lens = [int(x) for x in (g_off[1:] - g_off[:-1]).tolist()]
+    n_contig = len(refs)
+    owner = np.asarray(MG.assign_contigs(refs, lens, world), dtype=np.int32)
+    order = sorted(range(n_contig), key=lambda i: refs[i])
+    crank = np.zeros(n_contig, dtype=np.int32)
+    crank[order] = np.arange(n_contig, dtype=np.int32)
+    # this rank's record runs: maximal runs of consecutive reference ids it owns (the batch is sorted by reference id, position)
+    tid = batch.t["tid"][:batch.n_rec].to(torch.int64)
+    runs, t = [], 0
+    while t < n_contig:
+        if owner[t] == rank:
+            b = t
+            while b + 1 < n_contig and owner[b + 1] == rank:
+                b += 1
+            lo = int(torch.searchsorted(tid, torch.tensor([t], device=dev), right=False).item())
+            hi = int(torch.searchsorted(tid, torch.tensor([b], device=dev), right=True).item())
+            if hi > lo:
+                runs.append((lo, hi))
+            t = b + 1
+        else:
+            t += 1
+    views = [batch.view_records(lo, hi) for lo, hi in runs]
+    structs = [v.struct() for v in views]
+    eng = _lib.Engine(local_rank)
+    eng.set_genome(g_off, genome, on_device=True)
+    adapter = MG.SvxAdapter(eng, dev)
+    gid = np.arange(n_contig, dtype=np.int64)
+    last = {}
+
+    def step():
+        used = sigs = ops = 0
+        scan_ms = 0.0
+        eng.accumulate(True)
+        for b in structs:
+            eng.set_slot_base(0)                       # the views keep the batch's own emission slots (2 per record in file order): already global
+            eng.collect(b, p, fetch=False)
+            st = eng.stats()
+            used += st["n_rec_used"]; ops += st["n_ops"]; scan_ms += st["t_cigar_scan_ms"]
+        eng.accumulate(False)
+        sigs = eng.collect_counts()[0]
+        if use_dist:
+            MG.wire_reset()
+            last["res"] = MG.cluster_step(adapter, p, rank, world, gid, crank, owner, key_base=0, read_base=0, gather_signatures=False)
+        else:
+            eng.cluster(p, crank, source=0, fetch=False)
+        last.update(used=used, sigs=sigs, ops=ops, scan_ms=scan_ms, cluster_ms=eng.stats()["t_cluster_ms"], clusters=eng.stats()["n_clusters"])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            MG.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    f0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    first_step_ms = 1e3 * (time.perf_counter() - f0)
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = None
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        mine = torch.tensor([last["used"], last["sigs"], last["ops"], len(runs), sum(hi - lo for lo, hi in runs), int(1e3 * last["scan_ms"]), int(1e3 * last["cluster_ms"]),
+                             last["clusters"]], dtype=torch.int64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[int(x) for x in r.tolist()] for r in allr]
+        wire = dict(MG.WIRE)
+        backend = dist.get_backend()
+        world_seen = dist.get_world_size()
+        MG.barrier()
+        dist.destroy_process_group()
+    else:
+        per_rank = [[last["used"], last["sigs"], last["ops"], len(runs), sum(hi - lo for lo, hi in runs), int(1e3 * last["scan_ms"]), int(1e3 * last["cluster_ms"]), last["clusters"]]]
+        wire, backend, world_seen = None, None, 1
+    if rank != 0:
+        return
+    tot_used = sum(r[0] for r in per_rank)
+    res = last.get("res")
+    out = {
+        "metric": "aligned reads/sec through COLLECT+CLUSTER", "value": tot_used * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u32/i32 CIGAR + u8 bases, int64 positions, f64 distances", "data": "synthetic",
+        "config": {"workload": "configs[3] stand-in (%s profile, svim_amd/workloads.py): ONE whole-genome batch of %d records on %d contigs (%.0f Mb), the same on every rank, "
+                               "sharded by contig ownership; --scaling strong --scale %g (NOT the driver's default line: that one is configs[1], weak)" % (
+                                   name, meta["n_records"], n_contig, meta["genome_bases"] / 1e6, scale),
+                   "records_total": meta["n_records"], "cigar_ops_total": meta["n_ops"],
+                   "parallelism": "1 process/GPU; contigs sharded over ranks (contiguous ranges in name order, balanced by length), every partition local; over the fabric "
+                                  "per step: foreign BND / DUP_INT rows, the rank exchange of svx_cluster (all-gathers), cluster rows + member lists to rank 0"},
+        "first_step_ms": first_step_ms, "synth_seconds": t_gen,
+        "counts": {"reads_used": tot_used, "signatures": sum(r[1] for r in per_rank), "cigar_ops": sum(r[2] for r in per_rank),
+                   "clusters_gathered": (res.n if res is not None else last["clusters"])},
+        "per_rank": [dict(zip(("reads_used", "signatures", "cigar_ops", "contig_runs", "records", "k_cigar_scan_us", "cluster_us", "clusters"), r)) for r in per_rank],
+        "multi_gpu": None if not use_dist else {
+            "backend": backend + (" (= RCCL)" if backend == "nccl" else ""), "world_size_seen_by_the_process_group": world_seen,
+            "fabric_last_step_rank0": {"collectives": wire["collectives"], "payload_bytes": wire["bytes"],
+                                       "seconds_between_device_synchronises": wire["seconds"] if os.environ.get("SVX_WIRE_STATS") == "1" else None,
+                                       "by_kind": {k: {"calls": v[0], "bytes": v[1], "seconds": v[2] if os.environ.get("SVX_WIRE_STATS") == "1" else None}
+                                                   for k, v in wire["by_kind"].items()}},
+            "note": "payload bytes as the wire sees them (padded slots x world for all-gathers, all ranks' padded slots for the gathers to rank 0); SVX_WIRE_STATS=1 times "
+                    "every collective between two device synchronises (perturbs the step: off by default)"},
+    }
+    emit(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=("c1", "c2", "c4"), default="c1")
+    ap.add_argument("--workload", choices=("c1", "c2", "c3", "c4"), default="c1")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="strong: ONE whole-genome batch (c3 profile unless c2 / c4 is named), the same on every rank, sharded by contig ownership - total work "
+                         "is fixed and N=1 is the whole batch; weak (default, the driver's contract): every rank its own batch")
     ap.add_argument("--scale", type=float, default=1.0, help="c2 / c4: scale of the contig lengths (reads and sites follow)")
     ap.add_argument("--partition-max-distance", type=int, default=1000)
     ap.add_argument("--reads", type=int, default=1_000_000)
@@ -205,6 +356,9 @@ def main():
             dist.destroy_process_group()
         if rank == 0:
             emit(out)
+        return
+    if args.scaling == "strong" or args.workload == "c3":
+        emit_strong(args, rank, world, local_rank, dev, use_dist, dist, opts, p, emit)
         return
     t0 = time.perf_counter()
     if args.workload == "c1":

@@ -643,12 +643,13 @@ void devdec_destroy(svx_devdec* d) {
 void devdec_set_file(svx_devdec* d, const uint8_t* base, size_t bytes) {
     d->file_base = base; d->file_bytes = bytes; d->file_dev = nullptr;
     const char* e = getenv("SVX_BAM_DEV_MAPFILE");
-    if (e && e[0] == '0') return;
+    if (!(e && e[0] == '1')) return;                       // (off by default since round 5: bgzf.hip, "Registering the reader's memory")
     (void)hipSetDevice(d->device);
     const uint8_t* dp = nullptr;
     if (svx_inflater_map_file(d->inf, base, bytes, &dp) == SVX_OK) d->file_dev = dp;
     if (getenv("SVX_BAM_TIMING")) fprintf(stderr, "bamio device decode: the file mapping is %s\n", d->file_dev ? "registered with the GPU (no staging)" : "not registered (staging through pinned buffers)");
 }
+bool devdec_file_registered(const svx_devdec* d) { return d && d->file_dev != nullptr; }
 const std::vector<std::string>& devdec_names(svx_devdec* d) { return d->names; }
 void devdec_stats(svx_devdec* d, DevDecStats* out) { *out = d->stats; }
 void devdec_reset_names(svx_devdec* d) { (void)d; }

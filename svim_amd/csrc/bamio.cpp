@@ -205,6 +205,7 @@ struct svx_bam {
     int64_t gpu_blocks = 0, cpu_blocks = 0; double gpu_kernel_ms = 0;
     // svx_bam_set_device_decode: inflate, record discovery and decode on the GPU (bamdev.hip); batches come back with device pointers
     svx_devdec* dev = nullptr; int dev_device = -1;
+    bool map_registered_once = false;         // the file mapping has been registered with a GPU at some point (SVX_BAM_DEV_MAPFILE=1): its address range is quarantined at close
     size_t header_bytes = 0;                  // length of the BAM header in the inflated stream
     size_t dev_fpos = 0; uint64_t dev_skip = 0; bool dev_file_done = false, dev_region_done = false;
     int dev_cur = -1; int64_t dev_first = 0, dev_valid = 0; bool dev_have_carry = false;
@@ -591,6 +592,11 @@ extern "C" void svx_bam_close(svx_bam* h) {
         const long long before = svx_inflater_unregister_failures();
         devdec_destroy(h->dev); h->dev = nullptr;
         if (svx_inflater_unregister_failures() != before) h->map = nullptr;      // the file's registration with the GPU could not be removed: the mapping stays (see bgzf.hip)
+    }
+    if (h->map && h->map_registered_once) {
+        // (SVX_BAM_DEV_MAPFILE=1) an address range that WAS registered with the GPU is never handed back to the allocator: an inaccessible anonymous reservation
+        // takes the file mapping's place (the file itself is let go), so that nothing can be placed at an address the runtime may still remember
+        if (mmap((void*)h->map, h->map_len, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0) != MAP_FAILED) h->map = nullptr;
     }
     if (h->map) munmap((void*)h->map, h->map_len);
     if (h->fd >= 0) close(h->fd);
@@ -1038,7 +1044,7 @@ extern "C" int svx_bam_set_device_decode(svx_bam* h, int device) {
     const int rc = devdec_create(device, granted_cpus(), (int32_t)h->ref_names.size(), h->ref_len.data(), h->names_blob.c_str(), h->contig_rank.data(), &h->dev);
     if (rc != SVX_OK) { h->dev = nullptr; return rc; }
     h->dev_device = device;
-    if (h->map && h->map_len) devdec_set_file(h->dev, h->map, h->map_len);
+    if (h->map && h->map_len) { devdec_set_file(h->dev, h->map, h->map_len); if (devdec_file_registered(h->dev)) h->map_registered_once = true; }
     { const char* e = getenv("SVX_BAM_DEV_CHUNK_MB"); if (e && atoll(e) > 0) h->dev_chunk_bytes = (size_t)atoll(e) << 20; }
     { const char* e = getenv("SVX_BAM_DEV_CHUNK_BLOCKS"); if (e && atoll(e) > 0) h->dev_chunk_blocks = (size_t)atoll(e); }
     if (h->prefetch_active) { h->prefetch.wait(); h->prefetch_active = false; }

@@ -20,6 +20,9 @@ Signature columns of ordinary (non-foreign) signatures and inserted sequences ne
 
 The same code runs on CPU tensors over gloo with the oracle as stand-in engine (tests/test_multigpu_gloo.py).
 """
+import os
+import time
+
 import numpy as np
 
 from . import _abi
@@ -68,7 +71,8 @@ class TorchAllGather(object):
         dev = self.device if dist.get_backend() == "nccl" else "cpu"
         t = torch.frombuffer(bytearray(send), dtype=torch.uint8).to(dev)
         out = torch.empty(n * self.world, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(out, t)
+        with _Timed("all_gather(rank exchange of svx_cluster)", n * self.world):
+            dist.all_gather_into_tensor(out, t)
         self.calls += 1
         self.bytes += n * self.world
         return out.cpu().numpy().tobytes()
@@ -81,12 +85,13 @@ class TorchAllGather(object):
         import torch.distributed as dist
         src = torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(send_addr), dtype=torch.uint8)
         dst = torch.frombuffer((ctypes.c_uint8 * (nbytes * self.world)).from_address(recv_addr), dtype=torch.uint8)
-        if dist.get_backend() == "nccl":
-            out = torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device)
-            dist.all_gather_into_tensor(out, src.to(self.device))
-            dst.copy_(out)
-        else:
-            dist.all_gather_into_tensor(dst, src)
+        with _Timed("all_gather(rank exchange of svx_cluster)", nbytes * self.world):
+            if dist.get_backend() == "nccl":
+                out = torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device)
+                dist.all_gather_into_tensor(out, src.to(self.device))
+                dst.copy_(out)
+            else:
+                dist.all_gather_into_tensor(dst, src)
         self.calls += 1
         self.bytes += nbytes * self.world
 
@@ -106,6 +111,52 @@ def stream_words_after(sizes):
     for n in sizes:
         r.sample(range(int(n)), 100)
     return r.words
+
+
+# What crosses the fabric: every collective of this module is counted here (payload bytes as the wire sees them: all-gathers count world x the padded slot,
+# gathers to rank 0 the padded slots of all ranks).  SVX_WIRE_STATS=1 also times them (a device synchronise on both sides of every collective: the timed region
+# of a bench run is perturbed by it, so it is off by default).  bench.py prints the totals of the last step; DESIGN.md section 6 has the expected sizes.
+WIRE = {"collectives": 0, "bytes": 0, "seconds": 0.0, "by_kind": {}}
+
+
+def wire_reset():
+    WIRE.update(collectives=0, bytes=0, seconds=0.0, by_kind={})
+
+
+def _wire_count(kind, nbytes, seconds=0.0):
+    WIRE["collectives"] += 1
+    WIRE["bytes"] += int(nbytes)
+    WIRE["seconds"] += seconds
+    k = WIRE["by_kind"].setdefault(kind, [0, 0, 0.0])
+    k[0] += 1
+    k[1] += int(nbytes)
+    k[2] += seconds
+
+
+class _Timed(object):
+    """with _Timed(kind, bytes): <collective> - counts it; with SVX_WIRE_STATS=1 also its wall time between two device synchronises"""
+
+    def __init__(self, kind, nbytes):
+        self.kind, self.nbytes = kind, nbytes
+        self.on = os.environ.get("SVX_WIRE_STATS") == "1"
+
+    def __enter__(self):
+        if self.on:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        dt = 0.0
+        if self.on:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            dt = time.perf_counter() - self.t0
+        _wire_count(self.kind, self.nbytes, dt)
+        return False
 
 
 def barrier():
@@ -131,7 +182,8 @@ def _all_gather_counts(values, device):
     w = _wire(device)
     t = torch.tensor(values, dtype=torch.int64, device=w)
     out = torch.zeros(world * len(values), dtype=torch.int64, device=w)
-    dist.all_gather_into_tensor(out, t)
+    with _Timed("all_gather(counts)", out.numel() * 8):
+        dist.all_gather_into_tensor(out, t)
     return out.view(world, len(values)).tolist()
 
 
@@ -144,7 +196,8 @@ def _all_gather_rows(t, counts):
     pad = torch.zeros(mx, dtype=t.dtype, device=w)
     pad[:t.numel()] = t
     out = torch.empty(mx * len(counts), dtype=t.dtype, device=w)
-    dist.all_gather_into_tensor(out, pad)
+    with _Timed("all_gather(foreign rows)", out.numel() * out.element_size()):
+        dist.all_gather_into_tensor(out, pad)
     out = out.to(t.device)
     return [out[r * mx:r * mx + c] for r, c in enumerate(counts)]
 
@@ -157,12 +210,13 @@ def _gather_to_root(t, counts, rank):
     w = _wire(t.device)
     pad = torch.zeros(mx, dtype=t.dtype, device=w)
     pad[:t.numel()] = t
-    if rank == 0:
-        bufs = [torch.empty(mx, dtype=t.dtype, device=w) for _ in counts]
-        dist.gather(pad, bufs, dst=0)
-        return torch.cat([b[:c] for b, c in zip(bufs, counts)]).to(t.device)
-    dist.gather(pad, None, dst=0)
-    return None
+    with _Timed("gather(final, to rank 0)", mx * len(counts) * pad.element_size()):
+        if rank == 0:
+            bufs = [torch.empty(mx, dtype=t.dtype, device=w) for _ in counts]
+            dist.gather(pad, bufs, dst=0)
+            return torch.cat([b[:c] for b, c in zip(bufs, counts)]).to(t.device)
+        dist.gather(pad, None, dst=0)
+        return None
 
 
 def _gather_table_to_root(cols, names, counts, rank):

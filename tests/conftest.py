@@ -38,7 +38,7 @@ def oracle():
 # the rank-exchange protocol next, everything that reads BAM files (host reader, GPU inflate, device-resident reader, the life-cycle stress) last.
 _READER_WORDS = ("bam", "device_batches", "seek", "bgzf", "inflate", "foreign", "reader", "queryname", "long_cigar_cg", "c3_whole_genome", "bench_harness", "bench_under_torchrun",
                  "bench_two_ranks", "stress")
-_RANK_WORDS = ("rank_exchange", "two_ranks", "multigpu_step")
+_RANK_WORDS = ("rank_exchange", "two_ranks", "multigpu_step", "bench_strong")
 
 
 def gpu_tier(nodeid):

@@ -598,6 +598,59 @@ def gen_c1_full():
                                "source": "svim.SVIM_COLLECT.analyze_alignment_file_coordsorted + svim.SVIM_CLUSTER.cluster_sv_signatures"})
 
 
+def gen_c1_bench_sample():
+    """The reference ITSELF on a configs[1]-SHAPED sample (VERDICT r04 item 9 / SURVEY.md section 8d-i): 20 000 ONT-like reads (N50 20 kb) on a 5 Mb contig
+    with configs[1]'s densities - DEL / INS / INV sites, 12 % of the reads split across an inversion (supplementary records + SA tags) - written as a BAM
+    file (svim_amd.harness.write_bam_from_batch), read back as record objects and handed to the reference's COLLECT and CLUSTER, timed.  Stored: the
+    reference's signatures and clusters (a parity fixture at the bench workload's shape) and its seconds (bench.py's cpu_baseline.reference_python)."""
+    import time
+    import helpers as H
+    from svim_amd import harness
+    hb, genome, meta = H.c1_bench_sample_case()
+    bam = os.path.join(HERE, "_c1_bench_sample.bam")
+    harness.write_bam_from_batch(bam, hb, ["chr1"], [int(genome.shape[0])])
+    af = records.AlignmentFile(bam)
+    recs = list(af.fetch(until_eof=True))
+
+    class BamStub(object):
+        def __init__(self, recs):
+            self.recs, self.references = recs, ["chr1"]
+
+        def fetch(self, until_eof=True):
+            return iter(self.recs)
+
+        def getrname(self, tid):
+            return self.references[tid]
+
+        get_reference_name = getrname
+
+        def get_tid(self, name):
+            return self.references.index(name) if name in self.references else -1
+    fa = os.path.join(HERE, "_c1_bench_sample.fa")
+    H.write_fasta_from_codes(fa, "chr1", genome)
+    o = options(genome=fa)
+    t0 = time.perf_counter()
+    sigs, bnds = SVIM_COLLECT.analyze_alignment_file_coordsorted(BamStub(recs), o)
+    t1 = time.perf_counter()
+    print("C1 bench sample: COLLECT %.1f s, %d signatures" % (t1 - t0, len(sigs)), flush=True)
+    res = SVIM_CLUSTER.cluster_sv_signatures(sigs, o)
+    t2 = time.perf_counter()
+    os.remove(fa)
+    os.remove(bam)
+    n_reads = sum(1 for a in recs if not (a.flag & (256 | 2048)))
+    print("C1 bench sample: %d records (%d reads), %d ops, %d signatures, %d clusters, collect %.2fs cluster %.2fs" % (
+        len(recs), n_reads, meta["n_ops"], len(sigs), sum(len(x) for x in res), t1 - t0, t2 - t1))
+    dump("g_c1_bench_sample.json.gz", {
+        "note": "BASELINE.json configs[1] at a fiftieth of its size and the same densities (tests/helpers.py:c1_bench_sample_case) through the reference",
+        "generator": "tests/helpers.py:c1_bench_sample_case = svim_amd.devsynth.make_batch(device='cpu', **%r)" % (H.C1_BENCH_SAMPLE,),
+        "n_records": len(recs), "n_reads": n_reads, "n_ops": int(meta["n_ops"]), "options": opt_dict(options()),
+        "signatures": [sig_row(s) for s in sigs], "n_bnds": len(bnds), "clusters": cluster_rows(res, sigs),
+        "reference_seconds": {"collect": t1 - t0, "cluster": t2 - t1, "records_per_s": len(recs) / (t2 - t0), "reads_per_s": n_reads / (t2 - t0),
+                              "note": "the reference's Python functions in the build container, 1 core, pysam/edlib stubbed (records parsed before the clock starts; "
+                                      "edlib = pure-Python bit-vector Levenshtein: the cluster time is an upper bound)"},
+        "source": "svim.SVIM_COLLECT.analyze_alignment_file_coordsorted + svim.SVIM_CLUSTER.cluster_sv_signatures"})
+
+
 def gen_entrypoints(collect_cases):
     """Per-read entry points (analyze_alignment_indel, analyze_read_segments) and the COMBINE-side re-clustering
     (partition_and_cluster_candidates) as the reference computes them."""
@@ -907,6 +960,7 @@ def main():
     gen_edit()
     gen_c1()
     gen_c1_full()
+    gen_c1_bench_sample()
     gen_genotype()
     gen_writers()
     gen_combine()
@@ -921,5 +975,7 @@ if __name__ == "__main__":
         gen_c1_full()
     elif len(sys.argv) > 1 and sys.argv[1] == "combine":
         gen_combine()
+    elif len(sys.argv) > 1 and sys.argv[1] == "c1_bench_sample":
+        gen_c1_bench_sample()
     else:
         main()

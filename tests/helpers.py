@@ -153,6 +153,19 @@ def c1_full_case():
     return b.slice_records(0, b.n_rec), genome.numpy(), meta
 
 
+C1_BENCH_SAMPLE = dict(n_reads=20000, n50=20000, contig_len=5_000_000, n_sites=500, seed=2)
+
+
+def c1_bench_sample_case():
+    """BASELINE.json configs[1] at a fiftieth of its size and the SAME densities (bench.py's workload is devsynth.make_batch(n_reads=10^6, n50=20000,
+    contig_len=250 Mb, n_sites=25000): reads per Mb, planted DEL / INS / INV sites per Mb and the 12 % inversion-spanning split reads are those) - generated on
+    the CPU from its seed.  -> (HostBatch with the segment table, genome codes numpy uint8, meta)"""
+    from svim_amd import devsynth
+    b, genome, meta = devsynth.make_batch(device="cpu", **C1_BENCH_SAMPLE)
+    b.references = ["chr1"]
+    return b.slice_records(0, b.n_rec), genome.numpy(), meta
+
+
 def write_fasta_from_codes(path, name, codes, width=100):
     """one contig of 4-bit codes (1 2 4 8 15 = A C G T N) -> FASTA"""
     lut = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)

@@ -1221,6 +1221,59 @@ def test_bench_two_ranks_one_gpu_with_foreign_rows():
     assert d["multi_gpu"]["clusters_gathered"] > 100 and len(d["multi_gpu"]["signatures_per_rank"]) == 2
 
 
+def _run_bench(args, world, backend_env):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **backend_env)
+    if world == 1:
+        cmd = [sys.executable, os.path.join(repo, "bench.py")] + args
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(repo, "bench.py")] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_strong_scaling_two_ranks_equal_one_rank_on_one_gpu():
+    """bench.py --scaling strong: ONE whole-genome batch sharded by contig ownership - two ranks (both on cuda:0 over gloo here) process the
+    same records, signatures and clusters as one rank; the line names the process group's world size and what crossed the fabric in the last step.  No scaling
+    claim: the ranks share a GPU."""
+    common = ["--steps", "1", "--warmup", "1", "--scaling", "strong", "--scale", "0.01"]
+    one = _run_bench(["--gpus", "1"] + common, 1, {})
+    two = _run_bench(["--gpus", "2"] + common, 2, {"SVX_BENCH_BACKEND": "gloo", "SVX_BENCH_ONE_GPU": "1"})
+    assert one["scaling"] == two["scaling"] == "strong" and one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["counts"]["reads_used"] > 2000 and one["counts"]["clusters_gathered"] > 100
+    for k in ("reads_used", "signatures", "cigar_ops", "clusters_gathered"):
+        assert one["counts"][k] == two["counts"][k], (k, one["counts"], two["counts"])
+    assert len(two["per_rank"]) == 2 and all(r["records"] > 0 for r in two["per_rank"]) and sum(r["records"] for r in two["per_rank"]) == one["per_rank"][0]["records"]
+    mg = two["multi_gpu"]
+    assert mg["world_size_seen_by_the_process_group"] == 2 and mg["fabric_last_step_rank0"]["collectives"] >= 4 and mg["fabric_last_step_rank0"]["payload_bytes"] > 0
+    assert any("gather(final" in k for k in mg["fabric_last_step_rank0"]["by_kind"])
+
+
+def test_bench_strong_scaling_over_rccl_when_two_gpus_are_visible():
+    """the same over RCCL, one rank per GPU - only where the box has two GPUs (the builder's and the driver's test boxes have one: skipped there)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: RCCL refuses two ranks on one device")
+    common = ["--steps", "1", "--warmup", "1", "--scaling", "strong", "--scale", "0.01"]
+    one = _run_bench(["--gpus", "1"] + common, 1, {})
+    two = _run_bench(["--gpus", "2"] + common, 2, {})
+    for k in ("reads_used", "signatures", "cigar_ops", "clusters_gathered"):
+        assert one["counts"][k] == two["counts"][k], (k, one["counts"], two["counts"])
+    assert two["multi_gpu"]["backend"].startswith("nccl") and two["multi_gpu"]["world_size_seen_by_the_process_group"] == 2
+
+
 def _read_all_batches(nb, batch_records, regions=None):
     """every batch of a reader (host or device-resident) as host arrays + read names per record"""
     out, names_per_rec = [], []

@@ -164,3 +164,24 @@ def test_threaded_pair_distances_do_not_change_the_oracle():
     for ct, st in tables[1:]:
         assert tables[0][0].first_difference(ct, rtol=0.0) is None
         assert st["n_edit_pairs"] == tables[0][1]["n_edit_pairs"] and st["n_pairs"] == tables[0][1]["n_pairs"]
+
+
+def test_c1_bench_shape_sample_oracle_vs_reference(oracle):
+    """the oracle on the reference's outputs at the bench workload's shape (g_c1_bench_sample: configs[1]'s densities, 20 000 reads + supplementary records,
+    INV included) - the fixture the GPU is held to in tests/test_gpu_workloads.py"""
+    g = H.load("g_c1_bench_sample.json.gz")
+    hb, genome, meta = H.c1_bench_sample_case()
+    assert hb.n_rec == g["n_records"]
+    import types
+    o = types.SimpleNamespace(**g["options"])
+    p = _abi.Params.from_options(o)
+    oracle.set_genome(np.array([0, genome.shape[0]], dtype=np.int64), genome)
+    oracle.set_threads(H.granted_cpus())
+    try:
+        sig, bnd = oracle.collect(hb, p)
+        names = ["r%08d" % i for i in range(int(hb.arrays["read_id"].max()) + 1)]
+        assert H.table_rows(sig, ["chr1"], names) == g["signatures"] and bnd.n == g["n_bnds"]
+        ct = oracle.cluster(p, hb.contig_rank, source=0)
+    finally:
+        oracle.set_threads(1)
+    H.compare_cluster_rows(H.cluster_rows(ct, ["chr1"]), g["clusters"])
