@@ -20,6 +20,7 @@ for _i, _c in enumerate(NIBBLE):
     _ENC[ord(_c)] = _i
     _ENC[ord(_c.lower())] = _i
 _DEC = np.frombuffer(NIBBLE.encode("ascii"), dtype=np.uint8)
+_DEC_TABLE = bytes(NIBBLE.encode("ascii")[i & 15] for i in range(256))        # bytes.translate table: code -> symbol (codes are < 16)
 
 
 def encode_bases(s):
@@ -34,7 +35,8 @@ def encode_bases(s):
 
 
 def decode_bases(codes):
-    return _DEC[np.asarray(codes, dtype=np.uint8)].tobytes().decode("ascii")
+    # bytes.translate: one C loop over the codes (a numpy look-up of the same table costs 20 ms per 5 M bases - half of what building a table's objects took)
+    return np.ascontiguousarray(codes, dtype=np.uint8).tobytes().translate(_DEC_TABLE).decode("ascii")
 
 
 class Params(C.Structure):

@@ -45,6 +45,7 @@ int devdec_create(int, int, int32_t n_ref, const int32_t*, const char*, const in
 }
 void devdec_destroy(svx_devdec* d) { if (!d) return; for (auto& s : d->slot) s.release(); delete d; }
 void devdec_set_file(svx_devdec*, const uint8_t*, size_t) {}
+bool devdec_file_registered(const svx_devdec*) { return false; }
 int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t n, int carry_slot, uint64_t skip, bool final_chunk, int, int mode) {
     std::vector<uint8_t>* st = new std::vector<uint8_t>();
     if (carry_slot >= 0) { const MockSlot& c = d->slot[carry_slot]; if (!c.stream) { delete st; g_svx_err = "mock: carry from an empty slot"; return SVX_E_STATE; }
