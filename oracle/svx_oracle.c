@@ -446,9 +446,9 @@ int svo_collect_fetch(svo_ctx* ctx, int which, svx_sig_view* o) {
         memcpy(o->contig, t->contig, n * 4); memcpy(o->start, t->start, n * 4); memcpy(o->end, t->end, n * 4);
         memcpy(o->contig2, t->contig2, n * 4); memcpy(o->pos2, t->pos2, n * 4); memcpy(o->read_id, t->read_id, n * 4);
     }
-    if (which == 0) {
+    if (which == 0 && ctx->sig_seq_off) {
         memcpy(o->seq_off, ctx->sig_seq_off, (n + 1) * 8);
-        memcpy(o->seq, ctx->sig_seq, (size_t)ctx->sig_seq_off[n]);
+        if (ctx->sig_seq && ctx->sig_seq_off[n]) memcpy(o->seq, ctx->sig_seq, (size_t)ctx->sig_seq_off[n]);      /* (no inserted bases: no array, nothing to copy from) */
     } else { for (size_t i = 0; i <= n; i++) o->seq_off[i] = 0; }
     o->n = t->n;
     return 0;

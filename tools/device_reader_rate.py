@@ -42,7 +42,7 @@ def passes(nb, k=3):
     return tot, best
 
 
-variants = [("GPU + host cores (default)", {}), ("GPU + host cores, staged input (file not registered)", {"SVX_BAM_DEV_MAPFILE": "0"}), ("GPU only (default input path)", {"SVX_BAM_DEV_CPU": "0"}), ("GPU only, sub-batches of 12288", {"SVX_BAM_DEV_CPU": "0"}), ("GPU only, sub-batches of 4096", {"SVX_BAM_DEV_CPU": "0", "SVX_BAM_DEV_SUB": "4096"}),
+variants = [("GPU + host cores, staged input (default since round 5)", {}), ("file mapping registered with the GPU, one launch per chunk (SVX_BAM_DEV_MAPFILE=1)", {"SVX_BAM_DEV_MAPFILE": "1"}), ("GPU only (default input path)", {"SVX_BAM_DEV_CPU": "0"}), ("GPU only, sub-batches of 12288", {"SVX_BAM_DEV_CPU": "0"}), ("GPU only, sub-batches of 4096", {"SVX_BAM_DEV_CPU": "0", "SVX_BAM_DEV_SUB": "4096"}),
             ("GPU only, sub-batches of 40000", {"SVX_BAM_DEV_CPU": "0", "SVX_BAM_DEV_SUB": "40000"}), ("GPU + 8 host threads", {"SVX_BAM_DEV_CPU": "8"}),
             ("GPU + 6 host threads, sub-batches of 24576", {"SVX_BAM_DEV_CPU": "6", "SVX_BAM_DEV_SUB": "24576"})]
 if os.environ.get("SVX_READER_ONE"):                  # (profiling runs: the GPU-only reader with mid-size sub-batches, nothing else)
