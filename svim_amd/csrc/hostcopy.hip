@@ -7,6 +7,8 @@
 #include "common.hpp"
 #include "hostcopy.hpp"
 #include <mutex>
+#include <thread>
+#include <string>
 #include <cstdlib>
 
 struct BounceSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false, busy = false; int dev = 0; bool big = false; };
@@ -67,10 +69,43 @@ bool svx_is_device_pointer(const void* p) {
 
 HostCopy::~HostCopy() { for (auto& q : pend_) release(q.slot, false); }
 
+// one piece of a large upload: its own slot, its own copy, ordered on the caller's stream like every other piece
+static int h2d_piece(char* dst, const char* src, size_t n, hipStream_t st) {
+    BounceSlot* s = acquire(n);
+    if (!s) return svx_fail(SVX_E_HIP, "no page-locked bounce buffer (hipHostMalloc)", __FILE__, __LINE__, hipSuccess);
+    memcpy(s->p, src, n);
+    hipError_t e = hipMemcpyAsync(dst, s->p, n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(s->ev, st);
+    release(s, e == hipSuccess);
+    if (e != hipSuccess) return svx_fail(SVX_E_HIP, "host -> device copy through a bounce buffer", __FILE__, __LINE__, e);
+    return SVX_OK;
+}
+
 int HostCopy::h2d(void* dev_dst, const void* host_src, size_t bytes) {
     if (!bytes) return SVX_OK;
     if (svx_copy_direct()) { HIPCHK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st_)); return SVX_OK; }
     const char* src = (const char*)host_src; char* dst = (char*)dev_dst;
+    if (bytes >= ((size_t)64 << 20)) {
+        // a large array (the CIGAR words / packed bases of a host batch): one thread's memcpy into the bounce buffers (5-6 GB/s) would be the bottleneck of the
+        // upload, so four threads take the 8 MiB pieces in turn - each piece has a slot of its own, the device copies queue on the caller's stream
+        int dev = 0; HIPCHK(hipGetDevice(&dev));
+        const size_t pieces = (bytes + BIG_CAP - 1) / BIG_CAP;
+        const int T = pieces < 4 ? (int)pieces : 4;
+        std::vector<int> rc((size_t)T, SVX_OK); std::vector<std::string> msg((size_t)T);
+        std::vector<std::thread> th;
+        hipStream_t st = st_;
+        for (int t = 0; t < T; t++) th.emplace_back([=, &rc, &msg]() {
+            if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); rc[(size_t)t] = SVX_E_HIP; msg[(size_t)t] = "hipSetDevice in an upload thread"; return; }
+            for (size_t k = (size_t)t; k < pieces; k += (size_t)T) {
+                const size_t off = k * BIG_CAP, n = bytes - off < BIG_CAP ? bytes - off : BIG_CAP;
+                const int r = h2d_piece(dst + off, src + off, n, st);
+                if (r != SVX_OK) { rc[(size_t)t] = r; msg[(size_t)t] = g_svx_err; return; }
+            }
+        });
+        for (auto& x : th) x.join();
+        for (int t = 0; t < T; t++) if (rc[(size_t)t] != SVX_OK) { g_svx_err = msg[(size_t)t]; return rc[(size_t)t]; }
+        return SVX_OK;
+    }
     while (bytes) {
         const size_t n = bytes < BIG_CAP ? bytes : BIG_CAP;
         BounceSlot* s = acquire(n);
