@@ -63,7 +63,7 @@ def _workload_rank(nodeid):
 
 def pytest_collection_modifyitems(config, items):
     gpu = [it for it in items if it.get_closest_marker("gpu")]
-    if not gpu:
+    if not gpu or os.environ.get("SVX_TEST_ORDER") == "collection":      # (A/B runs of the DESIGN section 10 investigation: the order of round 4)
         return
     order = {id(it): k for k, it in enumerate(items)}
     gpu_sorted = sorted(gpu, key=lambda it: (gpu_tier(it.nodeid), _workload_rank(it.nodeid) if gpu_tier(it.nodeid) == 1 else 0, order[id(it)]))
