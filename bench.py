@@ -6,6 +6,8 @@ COLLECT+CLUSTER; SV signatures/sec clustered).
     python bench.py --workload c2                                          # configs[2] stand-in: HiFi profile, full SV-type set
     python bench.py --workload c4 --partition-max-distance 20000           # configs[4] stand-in: 60x CLR profile, large partitions
     python bench.py --bam reads.bam --fasta ref.fa                         # a real coordinate-sorted BAM (configs[2]-[4] proper)
+    python bench.py --scaling strong [--workload c3 --scale 0.2]           # ONE whole-genome batch sharded by contig ownership (configs[3]'s shape): total work fixed,
+                                                                           # N=1 is the whole batch; under torchrun with --gpus N: the strong-scaling line + fabric accounting
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
