@@ -67,7 +67,9 @@ bool svx_is_device_pointer(const void* p) {
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray || a.type == hipMemoryTypeManaged;
 }
 
-HostCopy::~HostCopy() { for (auto& q : pend_) release(q.slot, false); }
+// (a HostCopy dropped with device -> host pieces still in flight - an error return of its caller: the slots go back PENDING, their events were recorded behind the
+// copies, so whoever takes them next waits for the copy that still writes into them)
+HostCopy::~HostCopy() { for (auto& q : pend_) release(q.slot, true); }
 
 // one piece of a large upload: its own slot, its own copy, ordered on the caller's stream like every other piece
 static int h2d_piece(char* dst, const char* src, size_t n, hipStream_t st) {

@@ -735,3 +735,49 @@ def test_keyboard_interrupt_ends_the_reading_and_keeps_what_was_collected(tmp_pa
     pipe = harness.BamPipeline(path, o, eng2, threads=2, batch_records=40, mode="coordinate", gpu_inflate=False, device_decode=False)
     assert pipe.run() == len(srt) and not pipe.interrupted and sum(eng2.sizes) == len(srt)
     pipe.close()
+
+
+def test_gpu_suite_order_puts_hot_path_and_configs_in_front_of_the_readers():
+    """tests/conftest.py orders the `-m gpu` suite: hot-path parity, then the BASELINE configs at scale (configs[1] at its full size first), then the rank
+    exchange, then everything that reads BAM files - so that `pytest -x` can never again stop in a reader test before the configs have run."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(repo, "tests"), "-m", "gpu", "--collect-only", "-q"], capture_output=True, text=True, cwd=repo)
+    ids = [l.strip() for l in out.stdout.splitlines() if "::" in l]
+    assert len(ids) > 120
+    import conftest
+    tiers = [conftest.gpu_tier(i) for i in ids]
+    assert tiers == sorted(tiers), [(i, t) for i, t in zip(ids, tiers)][:5]
+    first_reader = tiers.index(3)
+    names = [i.split("::")[-1] for i in ids]
+    for must in ("test_c1_full_bench_size_vs_oracle_and_properties", "test_c2_hifi_full_sv_type_set_vs_oracle", "test_c4_clr_partition_max_distance_sweep_vs_oracle[1000]",
+                 "test_c1_bench_shape_sample_vs_reference_golden", "test_collect_golden_and_oracle[0]", "test_cluster_golden_and_oracle[0]", "test_edit_distance_golden"):
+        assert names.index(must) < first_reader, must
+    assert names.index("test_c1_full_bench_size_vs_oracle_and_properties") == tiers.index(1)          # configs[1] at the bench size opens the configs
+    for late in ("test_device_bam_decode_equals_host_reader[None]", "test_reader_life_cycle_stress_with_pageable_copies[1]", "test_c3_whole_genome_contig_sharded_ranks_on_one_gpu[8]"):
+        assert names.index(late) >= first_reader, late
+
+
+def test_bounce_buffer_copy_layer_over_an_asynchronous_model(tmp_path):
+    """svim_amd/csrc/hostcopy.hip - the page-locked bounce buffers EVERY host <-> device copy of the library goes through since round 5 - compiled
+    for the host over a model of the HIP calls it makes in which copies really are asynchronous (tools/hostcopy_model.cpp: bytes move only when a stream is drained, an
+    event is waited for or polled): uploads whose source is overwritten the moment h2d returns, fetches that must hold the uploaded bytes after finish(), sizes around
+    every boundary of the layer (64 KiB slots, 8 MiB pieces, the four-thread upload of >= 64 MB), a HostCopy dropped with copies in flight, several threads sharing the
+    slot pool.  A slot handed out again before the copy out of it has run, or a destination handed over early, is wrong data; under AddressSanitizer + UBSan, and under
+    ThreadSanitizer (two threads writing one slot)."""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
+        pytest.skip("no HIP headers")
+    for san, args, env in (("address,undefined", ["4", "30"], {"ASAN_OPTIONS": "detect_leaks=0"}),       # (the slot pool lives as long as the process, by design)
+                           ("thread", ["3", "8"], {})):
+        exe = str(tmp_path / ("hostcopy_model_" + san[:3]))
+        build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-x", "c++",
+                                os.path.join(repo, "svim_amd", "csrc", "hostcopy.hip"), os.path.join(repo, "tools", "hostcopy_model.cpp"), "-lpthread", "-o", exe],
+                               capture_output=True, text=True)
+        if build.returncode != 0 and "sanitize" in build.stderr and "cannot find" in build.stderr:
+            pytest.skip("no sanitizer runtime in this toolchain")
+        assert build.returncode == 0, build.stderr[-2000:]
+        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert run.returncode == 0 and "every byte arrived" in run.stdout and "runtime error" not in run.stderr and "WARNING: ThreadSanitizer" not in run.stderr, (san, run.stdout[-500:], run.stderr[-3000:])

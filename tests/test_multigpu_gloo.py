@@ -84,13 +84,29 @@ def _worker_signatures(rank, world, port, ret):
             pos += int(l)
         n_foreign = int((owner[multigpu.owner_contig(local.type, local.contig, local.contig2)] != rank).sum()) if local.n else 0
         ad = multigpu.HostAdapter(orc, local)
+        multigpu.wire_reset()
         res = multigpu.cluster_step(ad, p, rank, world, np.arange(len(contigs.names)), crank, owner)
+        wire_full = dict(multigpu.WIRE)
         ret["chain%d" % rank] = max(ad.stream_end()) if ad.stream_end() else -1
+        # the same step with the signature columns left on their ranks (bench.py --scaling strong: cluster rows + member lists only): identical clusters, one
+        # gather less on the wire and fewer bytes; every collective of the step is in multigpu.WIRE
+        ad2 = multigpu.HostAdapter(orc, local)
+        multigpu.wire_reset()
+        res2 = multigpu.cluster_step(ad2, p, rank, world, np.arange(len(contigs.names)), crank, owner, gather_signatures=False)
+        wire_lean = dict(multigpu.WIRE)
+        lean_ok = wire_lean["collectives"] == wire_full["collectives"] - 1 and 0 < wire_lean["bytes"] < wire_full["bytes"] and any("gather(final" in k for k in wire_lean["by_kind"])
         if rank == 0:
             verdict = _compare(res, full, tab.key[:n].astype(np.int64))
+            if verdict == "ok":
+                a, b = res.to_host(), res2.to_host()
+                same = a.n == b.n and list(a.type_count) == list(b.type_count) and np.array_equal(a.members, b.members) and np.array_equal(a.member_off, b.member_off) and \
+                    np.array_equal(a.start, b.start) and np.array_equal(a.score, b.score) and res2.sig_cols is None and list(res2.sig_counts) == list(res.sig_counts)
+                verdict = "ok" if same else "gather_signatures=False changes the clusters"
+            if verdict == "ok" and not lean_ok:
+                verdict = "fabric accounting: %r vs %r" % (wire_lean, wire_full)
             ret[0] = verdict if verdict != "ok" else ("ok" if sum(res.sig_counts) == n and orc.stats()["n_large_partitions"] >= 0 else "counts")
         else:
-            ret[rank] = "ok"
+            ret[rank] = "ok" if lean_ok else "fabric accounting: %r vs %r" % (wire_lean, wire_full)
         ret["foreign%d" % rank] = n_foreign
         ret["owned%d" % rank] = int((owner == rank).sum())
     finally:
