@@ -202,6 +202,28 @@ def _all_gather_rows(t, counts):
     return [out[r * mx:r * mx + c] for r, c in enumerate(counts)]
 
 
+def _all_gather_table(cols, names, counts):
+    """One all-gather for a whole table: the columns `names` of `cols` (1-D tensors of this rank's row count, any dtypes) travel as ONE byte buffer (column after
+    column, padded to the largest rank) instead of one collective per column -> {name: [per-rank tensors]}"""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    n = counts[rank]
+    sizes = [cols[k].element_size() for k in names]
+    dtypes = [cols[k].dtype for k in names]
+    row = sum(sizes)
+    dev = cols[names[0]].device
+    mine = torch.cat([cols[k].contiguous().view(torch.uint8) for k in names]) if n else torch.zeros(0, dtype=torch.uint8, device=dev)
+    got = _all_gather_rows(mine, [c * row for c in counts])
+    out = {k: [] for k in names}
+    for r, c in enumerate(counts):
+        off = 0
+        for k, sz, dt in zip(names, sizes, dtypes):
+            out[k].append(got[r][off:off + c * sz].clone().view(dt))          # clone: a fresh, aligned buffer for the typed view
+            off += c * sz
+    return out
+
+
 def _gather_to_root(t, counts, rank):
     """dist.gather of 1-D tensors with per-rank lengths `counts` to rank 0 -> concatenation (rank 0) / None"""
     import torch
@@ -611,8 +633,12 @@ def _cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, 
             g_names = [None] * world
             dist.all_gather_object(g_names, mine_names)
         rows = [c[0] for c in cnt2]
-        g_cols = {k: _all_gather_rows(f_cols[k], rows) for k in SIG_COLS}
-        g_len = _all_gather_rows(f_len, rows)
+        # two collectives: the fixed-width columns + the sequence lengths as ONE byte buffer (round 5; twelve all-gathers until then), the inserted bases
+        tab = dict(f_cols)
+        tab["__len"] = f_len
+        g_tab = _all_gather_table(tab, list(SIG_COLS) + ["__len"], rows)
+        g_len = g_tab.pop("__len")
+        g_cols = g_tab
         g_seq = _all_gather_rows(f_seq, [c[1] for c in cnt2])
         # ---- 2b. this rank's table: its own rows + the rows it received (local work), then all ranks enter svx_cluster together
         with _Phase() as ph:
