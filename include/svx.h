@@ -15,6 +15,10 @@
  *     member says which (device pointers let a caller keep everything resident in HBM)
  *   - results stay resident in the context (HBM) until fetched with svx_*_fetch into caller-allocated
  *     host arrays sized from svx_*_count
+ *   - HOST arrays handed to the library are pageable memory as far as it is concerned: it never registers them with the GPU (no
+ *     hipHostRegister, no copy call of the runtime ever sees their address) - every host <-> device copy goes through page-locked
+ *     buffers the library owns (csrc/hostcopy.hip).  An input array may be changed or freed as soon as the call returns; an output
+ *     array holds its data when the call returns
  *   - one context per GPU / per process; a context is not re-entrant
  */
 #ifndef SVX_H
