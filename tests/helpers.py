@@ -314,3 +314,17 @@ def concat_batch_rows(batches):
             rows.append((int(A["flag"][i]), int(A["tid"][i]), int(A["pos"][i]), int(A["mapq"][i]), int(A["lseq"][i]), A["cigar"][co[i]:co[i + 1]].tobytes(),
                          A["seq"][so[i]:so[i] + nbytes].tobytes(), tuple(segs)))
     return rows
+
+
+def assert_rows_are_the_written_records(rows, recs, what=""):
+    """rows of concat_batch_rows (or the same tuple layout) against the record objects a file was WRITTEN from - flag (12 bits), reference id, position, MAPQ, l_seq, the
+    packed CIGAR and the bases: an assertion that two readers cannot pass by agreeing on a wrong answer"""
+    assert len(rows) == len(recs), (what, len(rows), len(recs))
+    lut = b"=ACMGRSVTWYHKDBN"
+    for k, (x, r) in enumerate(zip(rows, recs)):
+        cig = np.array([(ln << 4) | op for op, ln in (r.cigartuples or [])], dtype=np.uint32).tobytes()
+        seq = r.query_sequence or ""
+        assert (x[0] & 0x0fff) == r.flag and x[1] == r.reference_id and x[2] == r.reference_start and x[3] == r.mapping_quality and x[4] == len(seq) and x[5] == cig, (what, k)
+        codes = np.frombuffer(x[6], dtype=np.uint8)
+        nib = np.stack([codes >> 4, codes & 15], axis=1).reshape(-1)[:len(seq)]
+        assert bytes(lut[int(v)] for v in nib).decode() == seq.upper(), (what, k)

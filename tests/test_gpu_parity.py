@@ -1347,15 +1347,8 @@ def test_device_bam_decode_equals_host_reader(tmp_path, monkeypatch, chunk_block
             a, b = _concat_batches(got), _concat_batches(want)
             assert len(a) == len(b) and len(a) > 2, path
             # not only "equal to the host reader": the records the file was written from (two product paths that agree on a wrong answer cannot pass)
-            src = truth[path]
-            assert len(a) == len(src) and got_names == [r.query_name for r in src], path
-            for k, (x, r) in enumerate(zip(a, src)):
-                cig = np.array([(ln << 4) | op for op, ln in (r.cigartuples or [])], dtype=np.uint32).tobytes()
-                seq = r.query_sequence or ""
-                assert (x[0] & 0x0fff) == r.flag and x[1] == r.reference_id and x[2] == r.reference_start and x[3] == r.mapping_quality and x[4] == len(seq) and x[5] == cig, (path, k)
-                codes = np.frombuffer(x[6], dtype=np.uint8)
-                nib = np.stack([codes >> 4, codes & 15], axis=1).reshape(-1)[:len(seq)]
-                assert bytes(b"=ACMGRSVTWYHKDBN"[int(v)] for v in nib).decode() == seq.upper(), (path, k)
+            assert got_names == [r.query_name for r in truth[path]], path
+            H.assert_rows_are_the_written_records(a, truth[path], path)
             for k, (x, y) in enumerate(zip(a, b)):
                 assert x == y, (path, k, [i for i, (u, v) in enumerate(zip(x, y)) if u != v])
             dev.rewind()
@@ -1460,6 +1453,8 @@ def test_device_bam_decode_queryname_mode_equals_host_reader(tmp_path, monkeypat
         assert all(got_names[int(c) - 1] != got_names[int(c)] for c in cuts)      # a read's group is whole inside its batch
         a, b = H.concat_batch_rows(got), H.concat_batch_rows(want)
         assert len(a) == len(b)
+        H.assert_rows_are_the_written_records(a, out, "query-name file")      # (not only the host reader's answer: the records the file was written from)
+        assert got_names == [r.query_name for r in out]
         bad = [k for k, (x, y) in enumerate(zip(a, b)) if x != y]
         assert not bad, (chunk_blocks, rep, bad[:5], a[bad[0]][:5], b[bad[0]][:5])
         if chunk_blocks is None:                                           # one chunk: the batches themselves are the host reader's
