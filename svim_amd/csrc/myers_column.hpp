@@ -3,16 +3,34 @@
 #include <stdint.h>
 
 // One column of the multi-word recurrence; leaves the (plus, minus) bits pushed out of the last word in bit 31 of ph_prev_ / mh_prev_.
-// Issue cost on gfx950 (tools/micro/valu_ops.hip, column_rate.hip): two-operand v_xor / v_and / v_or 2 cycles per wave64;
-// v_alignbit, v_addc_co and any instruction reading three different VGPRs (v_bitop3 included) 4.  v_bitop3 therefore pays where it
-// replaces THREE two-operand instructions (a | ~(b | c)); per word-column the update below costs 38 issue cycles and runs at 42-44.
+// Issue cost on gfx950, measured in real shader cycles per wave64 instruction and SIMD (tools/micro/gen_valu_banks.py -> profiles/r06_valu_banks.txt):
+//   2.3  v_xor / v_and / v_or / v_add_u32 / v_lshrrev / v_not / v_mov, and v_bitop3 / v_fma reading three VGPRs unless all three sit in one register bank
+//   4.4  v_addc_co / v_add_co / v_sub_co / v_cmp (everything that writes a carry or a lane mask), v_alignbit, v_lshlrev, v_bfe, v_bfi, v_perm, v_and_or,
+//        v_lshl_or, v_lshl_add, v_add3, v_xad, v_or3, v_mov_dpp, v_readlane, every instruction with an SGPR operand, v_bitop3 / v_fma with three same-bank VGPRs
+// but INSIDE the update a v_alignbit costs ~8.8 (tools/micro/column_parts.hip, column_shift.hip: profiles/r06_column_shift.txt), a v_addc_co its 4.4.  The shifts
+// phs = (ph << 1) | (bit 31 of the word below) therefore ride on two more carry chains - x + x + carry in, carry out = bit 31 of x - instead of two v_alignbit:
+// round 6, 42.2 -> 33.2 cycles per word-column at 16 words per lane, 43.1 -> 34.9 at 12, 44.6 -> 38.2 at 8 (the same twelve instructions per word:
+// 9 full rate + 3 v_addc_co = 33.9 by the table above).  -DSVX_MYERS_ALIGNBIT builds the round-5 form.
 // Left to itself the compiler emits each word's instructions almost back to back (a dependent chain mixing both rates stalls, see
 // valu_dep.hip), so the words are processed in groups of 4 with the recurrence cut into phases, every phase running over the 4
 // words before the next starts (sched_barrier keeps the phases apart).
 #define MYERS_GROUP(Q_) ((Q_) >= 4 ? 4 : (Q_))
 // v_bitop3_b32 (any function of three words): truth table = the function applied to 0xF0, 0xCC, 0xAA
 #define BITOP3(a_, b_, c_, tt_) ((uint32_t)__builtin_amdgcn_bitop3_b32((int)(a_), (int)(b_), (int)(c_), (tt_)))
-#define MYERS_COLUMN(Q_, P_, pl_, pv_, mv_, nk_, carry_, ph_prev_, mh_prev_)                                   \
+#ifdef SVX_MYERS_ALIGNBIT
+#define MYERS_SHIFT_DECL(ph_prev_, mh_prev_)
+#define MYERS_SHIFT(g_, ph_, mh_, phs_, mhs_, ph_prev_, mh_prev_) {                                                                       \
+            phs_[g_] = __builtin_amdgcn_alignbit(ph_[g_], g_ ? ph_[g_ - 1] : ph_prev_, 31);      /* (ph << 1) | top bit of the word below */ \
+            mhs_[g_] = __builtin_amdgcn_alignbit(mh_[g_], g_ ? mh_[g_ - 1] : mh_prev_, 31); }
+#else
+#define MYERS_SHIFT_DECL(ph_prev_, mh_prev_) unsigned cyp_ = (ph_prev_) >> 31, cym_ = (mh_prev_) >> 31;
+#define MYERS_SHIFT(g_, ph_, mh_, phs_, mhs_, ph_prev_, mh_prev_) {                                                                       \
+            unsigned co_;                                                                                                                  \
+            phs_[g_] = __builtin_addc(ph_[g_], ph_[g_], cyp_, &co_); cyp_ = co_;                 /* v_addc_co_u32: ph + ph + carry in; carry out = bit 31 of ph */ \
+            mhs_[g_] = __builtin_addc(mh_[g_], mh_[g_], cym_, &co_); cym_ = co_; }
+#endif
+#define MYERS_COLUMN(Q_, P_, pl_, pv_, mv_, nk_, carry_, ph_prev_, mh_prev_) {                                  \
+    MYERS_SHIFT_DECL(ph_prev_, mh_prev_)                                                                        \
     _Pragma("unroll") for (int q0 = 0; q0 < Q_; q0 += MYERS_GROUP(Q_)) {                                        \
         constexpr int GQ = MYERS_GROUP(Q_);                                                                     \
         const int gn = Q_ - q0 < GQ ? Q_ - q0 : GQ;                              /* words in this group (the last one may be short) */ \
@@ -25,7 +43,7 @@
         }                                                                                                       \
         _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
             xv_[g] = eq_[g] | mv_[q0 + g]; sum_[g] = eq_[g] & pv_[q0 + g];                                      \
-            asm("" : "+v"(xv_[g]));     /* opaque: keeps `phs & xv` a two-operand v_and (2 cycles) - the compiler would fold it into a three-operand v_bitop3 (4) */ \
+            asm("" : "+v"(xv_[g]));     /* opaque: keeps `phs & xv` a two-operand v_and */ \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
@@ -39,10 +57,7 @@
             mh_[g] = pv_[q0 + g] & sum_[g];                                                                     \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
-            phs_[g] = __builtin_amdgcn_alignbit(ph_[g], g ? ph_[g - 1] : ph_prev_, 31);      /* (ph << 1) | top bit of the word below */ \
-            mhs_[g] = __builtin_amdgcn_alignbit(mh_[g], g ? mh_[g - 1] : mh_prev_, 31);                         \
-        }                                                                                                       \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) MYERS_SHIFT(g, ph_, mh_, phs_, mhs_, ph_prev_, mh_prev_) \
         ph_prev_ = ph_[gn - 1]; mh_prev_ = mh_[gn - 1];                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
@@ -50,5 +65,5 @@
             mv_[q0 + g] = phs_[g] & xv_[g];                                                                     \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-    }
+    } }
 

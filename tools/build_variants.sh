@@ -20,7 +20,7 @@ for spec in "$@"; do
     cp "$ROOT"/svim_amd/csrc/*.hip "$ROOT"/svim_amd/csrc/*.hpp "$ROOT"/svim_amd/csrc/*.cpp "$ROOT"/svim_amd/csrc/Makefile "$bd"/
     mkdir -p "$bd/../../include_tmp"
     sed -i "s#\.\./\.\./include/svx\.h#$ROOT/include/svx.h#g" "$bd"/Makefile "$bd"/*.hip "$bd"/*.hpp "$bd"/*.cpp
-    make -s -j8 -C "$bd" EXTRA="$flags" OUT="$OUT/libsvx_$name.so" >/dev/null 2>&1
+    make -s -j8 -C "$bd" EXTRA="$flags" OUT="$OUT/libsvx_$name.so" > "$OUT/build_$name.log" 2>&1 || { echo "build of $name FAILED: $OUT/build_$name.log"; tail -5 "$OUT/build_$name.log"; }
     rm -rf "$bd"
   fi
   echo "built $OUT/libsvx_$name.so"
