@@ -734,9 +734,9 @@ __device__ __forceinline__ void stair_columns8(uint32_t (&pv)[QM], uint32_t (&mv
 #pragma unroll
             for (int b = 0; b < P; b++) nk[b] = (uint32_t)__builtin_amdgcn_sbfe((int)tp[b], k, 1);      // bit set -> 0, clear -> all ones: one v_bfe_i32
             top += 1;
-            unsigned carry = 0;
-            uint32_t ph_prev = 0x80000000u, mh_prev = 0u;          // the row above the window steps +1
-            MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
+            unsigned carry = 0, cyp = 1, cym = 0;                  // the row above the window steps +1
+            uint32_t ph_last, mh_last;
+            MYERS_COLUMN_C(Q, P, 1, pl, pv, mv, nk, carry, cyp, cym, ph_last, mh_last)
         }
     }
 }
@@ -1001,10 +1001,10 @@ __device__ __forceinline__ void d_edit_lane(long long blk, long long count, cons
                 uint32_t nk[P];
 #pragma unroll
                 for (int b = 0; b < P; b++) nk[b] = ((tp[b] >> k) & 1u) - 1u;
-                unsigned carry = 0;
-                uint32_t ph_prev = 0x80000000u, mh_prev = 0u;           // the row above the column steps +1
-                MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
-                score += (int)(ph_prev >> 31) - (int)(mh_prev >> 31);
+                unsigned carry = 0, cyp = 1, cym = 0;                   // the row above the column steps +1
+                uint32_t ph_last, mh_last;
+                MYERS_COLUMN_C(Q, P, 1, pl, pv, mv, nk, carry, cyp, cym, ph_last, mh_last)
+                score += (int)cyp - (int)cym;                            // the bits pushed out of the last word: the horizontal delta of row m
             }
         }
     }
@@ -1050,41 +1050,43 @@ __device__ __forceinline__ void d_edit_wide(long long blk, long long count, cons
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(smax, o, 64); smax = v > smax ? v : smax; }
     const int txt_words = (n + 7) >> 3;
-    const bool first = gl == 0;                              // the group's first lane takes its inputs from the text, not from the lane above
-    const bool feeder = live && first;
-    const unsigned n_on = (live && gl < lanes_used) ? (unsigned)n : 0u;      // columns this lane works on (none: a lane beyond the pattern)
-    uint32_t tw_next = (feeder && txt_words > 0) ? txt.word(0) : 0u;
-    // What a lane hands to the lane below it for the same text column one step later: the symbol's plane masks, the (plus, minus) words whose bit 31
-    // is the horizontal delta leaving its last row, the adder's carry.  Each goes down by one DPP move; nothing is packed or unpacked.
-    uint32_t o_nk[P], o_ph = 0u, o_mh = 0u, o_cy = 0u;
-#pragma unroll
-    for (int b = 0; b < P; b++) o_nk[b] = 0u;
+    const bool mine = live && gl < lanes_used;               // this lane holds pattern rows
+    const unsigned n_on = mine ? (unsigned)n : 0u;           // columns this lane works on (none: a lane beyond the pattern)
+    // Round 6.  Every lane reads the text of its OWN column (column 8 jb + k - gl at sub-step k of trip jb): it keeps the plane bits of two consecutive packed
+    // text words (16 columns) and shifts them so that sub-step k is bit k - the symbol masks no longer travel down the lanes (2 DPP moves + 2 selects per column
+    // before).  What does travel down - the (plus, minus) bits leaving a lane's last row and the adder's carry - are carries, one bit per lane: they travel as
+    // LANE MASKS in SGPR pairs, handed to the lane below by a scalar shift of the mask (3 DPP moves + 3 selects + 3 word-to-carry conversions before); the masks
+    // feed the three carry chains of the column update directly (inverse ballot).
+    const int wo = (gl + 7) >> 3, r8 = (8 - (gl & 7)) & 7;   // column of sub-step k = 8 (jb - wo) + r8 + k
+    auto text_word = [&](int idx) -> uint32_t { return (mine && idx >= 0 && idx < txt_words) ? txt.word(idx) : 0u; };
+    uint32_t tpa[P], tw_next = text_word(1 - wo);             // plane bits of word jb - wo; the packed word jb - wo + 1 (fetched a trip ahead)
+    planes8<P>(text_word(-wo), tpa);
+    const unsigned long long FIRST = __builtin_amdgcn_ballot_w64(gl == 0);      // lanes whose rows start at the top of a pattern: constant inputs
+    unsigned long long m_ph = 0, m_mh = 0, m_cy = 0;         // bit L: what lane L pushed out at its last column (plus, minus, adder carry)
+    uint32_t o_ph = 0u, o_mh = 0u;                           // a lane's last ph / mh words (bit 31 = the bits it hands down)
+    unsigned o_cy = 0u;
     int col = -gl;                                           // text column of this lane at the current step
     for (int jb = 0; jb * 8 < smax; jb++) {
-        const uint32_t tw = tw_next;
-        tw_next = (feeder && jb + 1 < txt_words) ? txt.word(jb + 1) : 0u;
-        uint32_t tp[P];
-        planes8<P>(tw, tp);
+        uint32_t tpb[P], tp[P];
+        planes8<P>(tw_next, tpb);
+        tw_next = text_word(jb + 2 - wo);
 #pragma unroll
-        for (int b = 0; b < P; b++) tp[b] = ~tp[b];
+        for (int b = 0; b < P; b++) { tp[b] = ~((tpa[b] | (tpb[b] << 8)) >> r8); tpa[b] = tpb[b]; }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             uint32_t nk[P];
 #pragma unroll
-            for (int b = 0; b < P; b++) {
-                const uint32_t down = dpp_wave_shr1(o_nk[b]);
-                nk[b] = first ? (uint32_t)__builtin_amdgcn_sbfe((int)tp[b], k, 1) : down;       // bit set -> 0, clear -> all ones
-            }
-            uint32_t ph_prev = dpp_wave_shr1(o_ph), mh_prev = dpp_wave_shr1(o_mh), cy = dpp_wave_shr1(o_cy);
-            if (first) { ph_prev = 0x80000000u; mh_prev = 0u; cy = 0u; }                        // top row: horizontal delta +1, no carry
+            for (int b = 0; b < P; b++) nk[b] = (uint32_t)__builtin_amdgcn_sbfe((int)tp[b], k, 1);       // bit set -> 0, clear -> all ones
+            // top row of a pattern: horizontal delta +1, no carry
+            unsigned cyp = __builtin_amdgcn_inverse_ballot_w64((m_ph << 1) | FIRST), cym = __builtin_amdgcn_inverse_ballot_w64((m_mh << 1) & ~FIRST);
+            unsigned carry = __builtin_amdgcn_inverse_ballot_w64((m_cy << 1) & ~FIRST);
             if ((unsigned)col < n_on) {
-                unsigned carry = cy;
-                MYERS_COLUMN(Q, P, pl, pv, mv, nk, carry, ph_prev, mh_prev)
-                score += (int)(ph_prev >> 31) - (int)(mh_prev >> 31);
-#pragma unroll
-                for (int b = 0; b < P; b++) o_nk[b] = nk[b];
-                o_ph = ph_prev; o_mh = mh_prev; o_cy = carry;
+                MYERS_COLUMN_C(Q, P, 0, pl, pv, mv, nk, carry, cyp, cym, o_ph, o_mh)
+                score += (int)(o_ph >> 31) - (int)(o_mh >> 31);
+                o_cy = carry;
             }
+            // (outside the branch: a mask assigned under divergent control flow would stop being a scalar)
+            m_ph = __builtin_amdgcn_ballot_w64((int)o_ph < 0); m_mh = __builtin_amdgcn_ballot_w64((int)o_mh < 0); m_cy = __builtin_amdgcn_ballot_w64(o_cy != 0u);
             col += 1;
         }
     }

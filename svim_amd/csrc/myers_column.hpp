@@ -10,27 +10,25 @@
 // but INSIDE the update a v_alignbit costs ~8.8 (tools/micro/column_parts.hip, column_shift.hip: profiles/r06_column_shift.txt), a v_addc_co its 4.4.  The shifts
 // phs = (ph << 1) | (bit 31 of the word below) therefore ride on two more carry chains - x + x + carry in, carry out = bit 31 of x - instead of two v_alignbit:
 // round 6, 42.2 -> 33.2 cycles per word-column at 16 words per lane, 43.1 -> 34.9 at 12, 44.6 -> 38.2 at 8 (the same twelve instructions per word:
-// 9 full rate + 3 v_addc_co = 33.9 by the table above).  -DSVX_MYERS_ALIGNBIT builds the round-5 form.
+// 9 full rate + 3 v_addc_co = 33.9 by the table above; A/B of the whole step at commit 993386d: profiles/r06_edit_carry_chain_shift_ab.txt).
 // Left to itself the compiler emits each word's instructions almost back to back (a dependent chain mixing both rates stalls, see
 // valu_dep.hip), so the words are processed in groups of 4 with the recurrence cut into phases, every phase running over the 4
 // words before the next starts (sched_barrier keeps the phases apart).
 #define MYERS_GROUP(Q_) ((Q_) >= 4 ? 4 : (Q_))
 // v_bitop3_b32 (any function of three words): truth table = the function applied to 0xF0, 0xCC, 0xAA
 #define BITOP3(a_, b_, c_, tt_) ((uint32_t)__builtin_amdgcn_bitop3_b32((int)(a_), (int)(b_), (int)(c_), (tt_)))
-#ifdef SVX_MYERS_ALIGNBIT
-#define MYERS_SHIFT_DECL(ph_prev_, mh_prev_)
-#define MYERS_SHIFT(g_, ph_, mh_, phs_, mhs_, ph_prev_, mh_prev_) {                                                                       \
-            phs_[g_] = __builtin_amdgcn_alignbit(ph_[g_], g_ ? ph_[g_ - 1] : ph_prev_, 31);      /* (ph << 1) | top bit of the word below */ \
-            mhs_[g_] = __builtin_amdgcn_alignbit(mh_[g_], g_ ? mh_[g_ - 1] : mh_prev_, 31); }
-#else
-#define MYERS_SHIFT_DECL(ph_prev_, mh_prev_) unsigned cyp_ = (ph_prev_) >> 31, cym_ = (mh_prev_) >> 31;
-#define MYERS_SHIFT(g_, ph_, mh_, phs_, mhs_, ph_prev_, mh_prev_) {                                                                       \
-            unsigned co_;                                                                                                                  \
-            phs_[g_] = __builtin_addc(ph_[g_], ph_[g_], cyp_, &co_); cyp_ = co_;                 /* v_addc_co_u32: ph + ph + carry in; carry out = bit 31 of ph */ \
-            mhs_[g_] = __builtin_addc(mh_[g_], mh_[g_], cym_, &co_); cym_ = co_; }
-#endif
-#define MYERS_COLUMN(Q_, P_, pl_, pv_, mv_, nk_, carry_, ph_prev_, mh_prev_) {                                  \
-    MYERS_SHIFT_DECL(ph_prev_, mh_prev_)                                                                        \
+// The core: one column over Q_ words.
+//   TOP_ = 1: the row above the column is the constant boundary (horizontal delta +1: the plus chain starts with carry 1, the minus chain with 0; cyp_ / cym_
+//             are not read); TOP_ = 0: cyp_ / cym_ hold the bits (0 / 1) the words above pushed out.
+//   carry_:   carry of the adder chain, in and out.
+//   Out: cyp_ / cym_ = the (plus, minus) bits pushed out of the last word (the horizontal delta of its last row), ph_last_ / mh_last_ = that word's ph / mh
+//   (bit 31 = the same bits) - a caller uses whichever it can hand on cheaply, the other is dead code.
+#define MYERS_SHIFT(w_, TOP_, ph_, mh_, phs_, mhs_, cyp_, cym_) {                                                                   \
+            unsigned co_;                                                                                                                      \
+            if (TOP_ && (w_) == 0) { phs_ = __builtin_addc(ph_, ph_, 0u, &co_) | 1u; cyp_ = co_; mhs_ = __builtin_addc(mh_, mh_, 0u, &co_); cym_ = co_; } \
+            else { phs_ = __builtin_addc(ph_, ph_, cyp_, &co_); cyp_ = co_;                      /* v_addc_co_u32: ph + ph + carry in; carry out = bit 31 of ph */ \
+                   mhs_ = __builtin_addc(mh_, mh_, cym_, &co_); cym_ = co_; } }
+#define MYERS_COLUMN_C(Q_, P_, TOP_, pl_, pv_, mv_, nk_, carry_, cyp_, cym_, ph_last_, mh_last_) {              \
     _Pragma("unroll") for (int q0 = 0; q0 < Q_; q0 += MYERS_GROUP(Q_)) {                                        \
         constexpr int GQ = MYERS_GROUP(Q_);                                                                     \
         const int gn = Q_ - q0 < GQ ? Q_ - q0 : GQ;                              /* words in this group (the last one may be short) */ \
@@ -43,7 +41,7 @@
         }                                                                                                       \
         _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
             xv_[g] = eq_[g] | mv_[q0 + g]; sum_[g] = eq_[g] & pv_[q0 + g];                                      \
-            asm("" : "+v"(xv_[g]));     /* opaque: keeps `phs & xv` a two-operand v_and */ \
+            asm("" : "+v"(xv_[g]));     /* opaque: keeps `phs & xv` a two-operand v_and */                       \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
@@ -57,8 +55,9 @@
             mh_[g] = pv_[q0 + g] & sum_[g];                                                                     \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) MYERS_SHIFT(g, ph_, mh_, phs_, mhs_, ph_prev_, mh_prev_) \
-        ph_prev_ = ph_[gn - 1]; mh_prev_ = mh_[gn - 1];                                                         \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn)                                              \
+            MYERS_SHIFT(q0 + g, TOP_, ph_[g], mh_[g], phs_[g], mhs_[g], cyp_, cym_)                              \
+        ph_last_ = ph_[gn - 1]; mh_last_ = mh_[gn - 1];                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
             pv_[q0 + g] = BITOP3(mhs_[g], xv_[g], phs_[g], 0xF1);                 /* mhs | ~(xv | phs) */         \
@@ -66,4 +65,9 @@
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     } }
+
+// Word interface (tools/micro): the bits coming in from above are bit 31 of ph_prev_ / mh_prev_, the bits pushed out are left there.
+#define MYERS_COLUMN(Q_, P_, pl_, pv_, mv_, nk_, carry_, ph_prev_, mh_prev_) {                                  \
+    unsigned cyp_w_ = (ph_prev_) >> 31, cym_w_ = (mh_prev_) >> 31;                                               \
+    MYERS_COLUMN_C(Q_, P_, 0, pl_, pv_, mv_, nk_, carry_, cyp_w_, cym_w_, ph_prev_, mh_prev_) }
 

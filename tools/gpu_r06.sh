@@ -22,5 +22,17 @@ ab)
   # interleaved A/B of library variants (tools/build_variants.sh):  VARIANTS="tree a b" WL="c1"
   bash tools/ab.sh "${WL:-c1}" ${VARIANTS:-tree} 2>&1 | tee $out/${tag}_ab.txt
   ;;
+serial)
+  # stand-alone duration of every edit launch (SVX_EDIT_SERIAL) and the per-class profile of the rounds (SVX_EDIT_PROFILE): stderr lines of one step
+  SVX_EDIT_SERIAL=1 SVX_EDIT_PROFILE=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --workload ${WL:-c1} 2>&1 >/dev/null | grep "^{" > $out/${tag}_edit_class_profile.jsonl
+  grep edit_launch $out/${tag}_edit_class_profile.jsonl | tail -8
+  ;;
+timeline)
+  rm -rf /tmp/kt && (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end --workload ${WL:-c1} > /dev/null 2> /tmp/kt.err)
+  db=$(find /tmp/kt -name "*.db" | head -1)
+  python tools/rocpd_stats.py $db $out/${tag}_kernel_stats.csv > /dev/null
+  python tools/rocpd_timeline.py $db > $out/${tag}_step_timeline.txt
+  grep "k_edit\|k_cigar\|k_cluster" $out/${tag}_step_timeline.txt
+  ;;
 *) echo "unknown step $step"; exit 2;;
 esac
