@@ -30,9 +30,12 @@ sys.path.insert(0, REPO)
 
 # VALU issue peak of the edit-distance kernels: 1024 SIMDs x 2.4 GHz, one wave64 instruction per 2 cycles (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2
-# the Myers/Hyyro column update: VALU instructions per 32-bit word-column (svim_amd/csrc/myers_column.hpp; 38 issue cycles)
-INSTR_PER_WORDCOL = 12.4
-CYCLES_PER_WORDCOL = 38.0
+# the Myers/Hyyro column update: VALU instructions per 32-bit word-column (svim_amd/csrc/myers_column.hpp): 9 full-rate instructions (2 issue cycles per
+# wave64) + 3 v_addc_co of the carry chains (4) = 30 issue cycles by the rates of the hardware; the same classes MEASURE 2.3 / 4.4 cycles
+# (profiles/r06_valu_banks.txt) = 33.9, and the update alone runs at 33.2 (profiles/r06_column_shift.txt).  Round 5: 12.4 instructions, 38 cycles (two v_alignbit).
+INSTR_PER_WORDCOL = 12.0
+CYCLES_PER_WORDCOL = 30.0
+CYCLES_PER_WORDCOL_MEASURED_RATES = 33.9
 
 
 def options(pmd=1000):
@@ -490,13 +493,13 @@ def main():
     tj = load_profile_json("traffic_k_cigar_scan.json")
     if tj and tj.get("workload_cigar_ops") == meta["n_ops"]:
         traffic = tj.get("traffic_bytes_per_launch")
-    roofline = {"kernel": "k_cigar_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+    roofline_scan = {"kernel": "k_cigar_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": (tj or {}).get("source"),
                 "algorithmic_bytes_per_launch": scan_bytes, "kernel_ms": avg["t_cigar_scan_ms"],
                 "whole_path": {"algorithmic_bytes_per_step": bytes_collect + bytes_cluster,
                                "achieved_GBps": (bytes_collect + bytes_cluster) / (ms_per_step * 1e-3) / 1e9,
                                "frac_of_hbm": (bytes_collect + bytes_cluster) / (ms_per_step * 1e-3) / 8e12,
-                               "note": "the path as a whole is integer-VALU bound in the edit-distance kernels: see roofline_edit"}}
+                               "note": "the path as a whole is integer-VALU bound in the edit-distance kernels: see roofline"}}
     # ---- roofline of the dominant kernels (k_edit_bands + k_edit_fulls): integer VALU issue ----
     edit_s = avg["t_edit_ms"] * 1e-3
     wc_issued, wc_useful = st.get("n_edit_wordcols_issued", 0), st.get("n_edit_wordcols_useful", 0)
@@ -505,7 +508,8 @@ def main():
     if edit_s > 0 and wc_issued:
         instr = wc_issued / 64.0 * INSTR_PER_WORDCOL
         roofline_edit = {
-            "kernels": "k_edit_bands<P> + k_edit_fulls<P> (all rounds; the window also holds pack/prep/sort/pilot)", "bound": "valu",
+            "kernel": "k_edit_bands<P> + k_edit_fulls<P> (all rounds; the window also holds pack/prep/sort/pilot): the dominant kernels of the step", "bound": "valu",
+            "share_of_step": avg["t_edit_ms"] / ms_per_step, "traffic": None,
             "seconds": edit_s, "word_columns_executed": wc_issued, "word_columns_useful": wc_useful,
             "word_columns_retry_rounds": st.get("n_edit_wordcols_retry"), "retry_fraction": st.get("n_edit_wordcols_retry", 0) / wc_issued,
             "cells_executed": wc_issued * 32, "cells_full_matrix": st["n_edit_cells"],
@@ -514,8 +518,11 @@ def main():
             "achieved": instr / edit_s, "frac": instr / edit_s / VALU_PEAK_WAVE_INSTR_PER_S,
             "frac_issue_cycles": (wc_issued / 64.0 * CYCLES_PER_WORDCOL) / (edit_s * 1024 * 2.4e9),
             "frac_useful_work_only": (wc_useful / 64.0 * CYCLES_PER_WORDCOL) / (edit_s * 1024 * 2.4e9),
-            "note": "frac counts 2 cycles per instruction; the update's instruction mix (v_bitop3 / v_alignbit / v_addc_co are half rate) "
-                    "needs 38 issue cycles per word-column: frac_issue_cycles prices exactly that",
+            "frac_issue_cycles_at_measured_rates": (wc_issued / 64.0 * CYCLES_PER_WORDCOL_MEASURED_RATES) / (edit_s * 1024 * 2.4e9),
+            "note": "frac counts 2 cycles per instruction for the 12 instructions of the update; 3 of them (v_addc_co of the three carry chains) are half rate: "
+                    "frac_issue_cycles prices the 30 issue cycles per word-column, frac_issue_cycles_at_measured_rates the 33.9 the instruction classes measure "
+                    "(2.3 / 4.4 cycles, profiles/r06_valu_banks.txt).  A step that skips word-columns (narrowing windows) lowers the time and the numerator alike: "
+                    "frac says how well the issued work runs, word_columns_executed against cells_full_matrix how much of it was avoided",
             "band_speculation_fraction": st.get("edit_guess"),
             "gcups_executed": wc_issued * 32 / edit_s / 1e9, "gcups_full_matrix_equivalent": st["n_edit_cells"] / edit_s / 1e9,
         }
@@ -560,7 +567,9 @@ def main():
                            "the band speculation is chosen inside each call from a sample of its own pairs",
         "counts": {"reads_used": tot_used, "signatures": tot_sig, "cigar_ops": tot_ops, "partitions": st["n_partitions"],
                    "large_partitions": st["n_large_partitions"], "clusters": st["n_clusters"], "ins_bases": n_ins},
-        "roofline": roofline, "roofline_edit": roofline_edit, "kernels": kernels, "synth_seconds": t_gen,
+        # `roofline` describes the dominant kernels of the step (edit distance: integer VALU); the HBM-bound streaming kernel of COLLECT is `roofline_scan`
+        "roofline": roofline_edit if roofline_edit is not None else roofline_scan, "roofline_scan": roofline_scan, "roofline_edit": roofline_edit,
+        "kernels": kernels, "synth_seconds": t_gen,
     }
     if use_dist:
         res = last.get("res")

@@ -278,16 +278,10 @@ void  svx_inflater_destroy(svx_inflater* f);
 /* three slots (0..2), each with its own stream, device buffers and pinned staging buffer: while one sub-batch is inflated and copied back, the
  * caller packs the next.  enqueue = H2D + inflate + copy of the inflated range to `out` (host, or device when out_on_device), asynchronous;
  * wait = its completion (error if a block was not a sound DEFLATE stream of ISIZE bytes).  run = enqueue + wait on slot 0. */
-void* svx_inflater_staging(svx_inflater* f, int slot, uint64_t bytes);
-int   svx_inflater_pin(svx_inflater* f, void* host_buffer, uint64_t bytes);      /* page-lock a destination buffer: the copy back becomes one DMA */
-int   svx_inflater_unpin(svx_inflater* f, void* host_buffer);                    /* MUST precede freeing / reallocating a pinned buffer */
+void* svx_inflater_staging(svx_inflater* f, int slot, uint64_t bytes);   /* NULL (SVX_E_STATE) while the slot is busy and the buffer would have to grow: wait first */
 int   svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const uint64_t* in_off, const uint32_t* clen, const uint32_t* isize,
                            const uint64_t* out_at, uint64_t staged_bytes, uint8_t* out, uint64_t out_bytes, int out_on_device);
 int   svx_inflater_wait(svx_inflater* f, int slot, float* kernel_ms /* may be NULL */);
-/* payloads already in device-visible memory (HBM, or the memory-mapped BAM file registered by svx_inflater_map_file): no staging, no copy */
-int   svx_inflater_map_file(svx_inflater* f, const void* base, uint64_t bytes, const uint8_t** dev_ptr);
-int   svx_inflater_enqueue_mapped(svx_inflater* f, int slot, int64_t n, const uint8_t* comp_dev, uint64_t comp_bytes, const uint64_t* in_off, const uint32_t* clen,
-                                  const uint32_t* isize, const uint64_t* out_at, uint8_t* out_dev, uint64_t out_bytes);
 int   svx_inflater_run(svx_inflater* f, int64_t n, const uint64_t* in_off, const uint32_t* clen, const uint32_t* isize, const uint64_t* out_at,
                        uint64_t staged_bytes, uint8_t* out, uint64_t out_bytes, int out_on_device, float* kernel_ms /* may be NULL */);
 

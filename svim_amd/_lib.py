@@ -23,8 +23,8 @@ SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version",
            "svx_set_alignment_index", "svx_genotype",
            "svx_cigar_indel", "svx_edit_distance", "svx_linkage_fcluster", "svx_pair_distances",
            "svx_bam_open", "svx_bam_close", "svx_bam_header", "svx_bam_read_batch", "svx_bam_read_names", "svx_bam_set_seq_filter", "svx_bam_rewind", "svx_bam_seek", "svx_bam_set_gpu_inflate", "svx_bam_gpu_inflate_stats",
-           "svx_inflater_create", "svx_inflater_destroy", "svx_inflater_staging", "svx_inflater_pin", "svx_inflater_unpin", "svx_inflater_enqueue", "svx_inflater_wait",
-           "svx_inflater_run", "svx_inflater_map_file", "svx_inflater_enqueue_mapped"]
+           "svx_inflater_create", "svx_inflater_destroy", "svx_inflater_staging", "svx_inflater_enqueue", "svx_inflater_wait",
+           "svx_inflater_run"]
 
 
 class SvxError(RuntimeError):

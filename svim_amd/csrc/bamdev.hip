@@ -230,7 +230,7 @@ __global__ void k_measure(const uint8_t* st, const uint64_t* rec_off, long long 
     uint32_t segs = 0, ops = 0;
     if ((want_cg || primary_ok) && d.n_cig == ncf) {
         uint64_t q = d.seq_at + ((uint64_t)l_seq + 1) / 2 + l_seq;
-        uint64_t cg_at = 0; uint32_t cg_n = 0; bool have_cg = false, cg_seen = false;      // (bam_aux_get: the FIRST field named CG counts, whatever its type)
+        uint64_t cg_at = 0; uint32_t cg_n = 0; bool have_cg = false, cg_seen = false, sa_seen = false;      // (bam_aux_get: the FIRST field named CG counts, whatever its type)
         while (q + 3 <= end) {
             const uint8_t t0 = st[q], t1 = st[q + 1], ty = st[q + 2];
             q += 3;
@@ -243,7 +243,7 @@ __global__ void k_measure(const uint8_t* st, const uint64_t* rec_off, long long 
                 uint64_t z = q;
                 while (z < end && st[z] != 0) z++;
                 if (z >= end) { atomicExch(err, DD_E_AUX); break; }
-                if (t0 == 'S' && t1 == 'A' && ty == 'Z') { d.sa_at = q; d.sa_len = (uint32_t)(z - q); }
+                if (t0 == 'S' && t1 == 'A' && ty == 'Z' && !sa_seen) { d.sa_at = q; d.sa_len = (uint32_t)(z - q); }
                 sz = z - q + 1;
             } else if (ty == 'B') {
                 if (left < 5) { atomicExch(err, DD_E_AUX); break; }
@@ -254,6 +254,7 @@ __global__ void k_measure(const uint8_t* st, const uint64_t* rec_off, long long 
                 if (sz <= left && t0 == 'C' && t1 == 'G' && !cg_seen && (sub == 'I' || sub == 'i') && c > 0u) { cg_at = q + 5; cg_n = c; have_cg = true; }
             } else { atomicExch(err, DD_E_AUX); break; }
             if (t0 == 'C' && t1 == 'G') cg_seen = true;
+            if (t0 == 'S' && t1 == 'A') sa_seen = true;
             if (sz > left) { atomicExch(err, DD_E_AUX); break; }
             q += sz;
         }
@@ -557,7 +558,6 @@ struct svx_devdec {
     std::vector<std::string> names;
     DevChunk chunk[3];
     DevDecStats stats;
-    const uint8_t* file_base = nullptr; size_t file_bytes = 0; const uint8_t* file_dev = nullptr;      // the memory-mapped BAM, registered with the GPU (or not)
     int n_threads = 8; hipStream_t copy_stream = nullptr; uint8_t* hbuf = nullptr; size_t hbuf_cap = 0;      // the host's share of the inflate
     int* h_err = nullptr;                      // pinned (DD_PINNED_BYTES: 64 bytes for h_err, then the DD_H_* values of h_cnt)
     unsigned long long* h_cnt = nullptr;       // pinned: indexed by the DD_H_* slots below, each written by one copy and read after the synchronise that follows it
@@ -640,16 +640,6 @@ void devdec_destroy(svx_devdec* d) {
     delete d;
 }
 
-void devdec_set_file(svx_devdec* d, const uint8_t* base, size_t bytes) {
-    d->file_base = base; d->file_bytes = bytes; d->file_dev = nullptr;
-    const char* e = getenv("SVX_BAM_DEV_MAPFILE");
-    if (!(e && e[0] == '1')) return;                       // (off by default since round 5: bgzf.hip, "Registering the reader's memory")
-    (void)hipSetDevice(d->device);
-    const uint8_t* dp = nullptr;
-    if (svx_inflater_map_file(d->inf, base, bytes, &dp) == SVX_OK) d->file_dev = dp;
-    if (getenv("SVX_BAM_TIMING")) fprintf(stderr, "bamio device decode: the file mapping is %s\n", d->file_dev ? "registered with the GPU (no staging)" : "not registered (staging through pinned buffers)");
-}
-bool devdec_file_registered(const svx_devdec* d) { return d && d->file_dev != nullptr; }
 const std::vector<std::string>& devdec_names(svx_devdec* d) { return d->names; }
 void devdec_stats(svx_devdec* d, DevDecStats* out) { *out = d->stats; }
 void devdec_reset_names(svx_devdec* d) { (void)d; }
@@ -704,8 +694,6 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
         const size_t SUB = sub_env ? sub_env : 32768;                  // a launch of >= ~25 k blocks runs at the kernel's best rate (a 12 k one at 0.8 of it: its tail)
         int n_cpu = cpu_env >= 0 ? cpu_env : (d->n_threads > 8 ? d->n_threads - 6 : (d->n_threads > 3 ? d->n_threads - 3 : 0));      // (the staging copies want cores, too)
         if (nb_in < 4 * SUB / 3) n_cpu = 0;                            // a small chunk: one launch does it
-        if (d->file_dev && cpu_env < 0) n_cpu = 0;                     // registered file: ONE launch over the whole chunk runs at the kernel's best rate, and nothing is staged -
-                                                                       // the host's share (zlib + upload) only adds launches with tails (measured: 39.3 vs 40.4 GB/s)
         std::mutex m;
         size_t lo = 0, hi = nb_in;
         size_t h_first_v = 0;                                              // (set below, before any worker runs)
@@ -763,20 +751,11 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
             int sl = 0;
             std::vector<uint64_t> in_off, o_at; std::vector<uint32_t> clen, isz;
             size_t a, b;
-            const bool mapped = d->file_dev != nullptr && nb_in > 0 && blocks[0].comp >= d->file_base && blocks[nb_in - 1].comp + blocks[nb_in - 1].clen <= d->file_base + d->file_bytes;
-            // sub-batch sizes.  Staged input: small first ones (the GPU starts after 4 k blocks are staged), then SUB.  Registered file: nothing to wait for, so the
-            // first launch takes most of what the GPU will end up with (one large launch runs at the kernel's best rate), later ones half of what is left
+            // sub-batch sizes: small first ones (the GPU starts after 4 k blocks are staged), then SUB
             size_t ramp = sub_env ? SUB : 4096;
-            bool first = true;
             for (;;) {
-                size_t want = ramp;
-                if (mapped && !sub_env) {
-                    size_t left; { std::lock_guard<std::mutex> g(m); left = hi > lo ? hi - lo : 0; }
-                    want = n_cpu > 0 ? (first ? left * 3 / 4 : (left + 1) / 2) : left;
-                    if (want < 2048) want = left;
-                }
+                const size_t want = ramp;
                 if (!(rc_gpu == SVX_OK && want > 0 && take(true, want, a, b))) break;
-                first = false;
                 if (ramp < SUB) ramp *= 2;
                 const size_t mm = b - a;
                 if (used[sl]) { float ms = 0; rc_gpu = svx_inflater_wait(d->inf, sl, &ms); d->stats.inflate_kernel_ms += ms; used[sl] = false; if (rc_gpu != SVX_OK) break; }
@@ -784,10 +763,7 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
                 const uint64_t staged = (uint64_t)(blocks[b - 1].comp + blocks[b - 1].clen - f0);
                 in_off.resize(mm); o_at.resize(mm); clen.resize(mm); isz.resize(mm);
                 for (size_t k = 0; k < mm; k++) { in_off[k] = (uint64_t)(blocks[a + k].comp - f0); clen[k] = blocks[a + k].clen; isz[k] = blocks[a + k].isize; o_at[k] = out_at[a + k] - out_at[a]; }
-                if (mapped) {
-                    rc_gpu = svx_inflater_enqueue_mapped(d->inf, sl, (int64_t)mm, d->file_dev + (f0 - d->file_base), staged, in_off.data(), clen.data(), isz.data(), o_at.data(),
-                                                         sp + DD_HEAD + out_at[a], out_at[b] - out_at[a]);
-                } else {
+                {
                     uint8_t* stage = (uint8_t*)svx_inflater_staging(d->inf, sl, staged + 8);
                     if (!stage) { rc_gpu = svx_fail(SVX_E_HIP, "no pinned staging memory", __FILE__, __LINE__, hipSuccess); break; }
                     {   // the slice of the file as it is, copied by a few threads (page cache -> pinned memory)
@@ -805,10 +781,6 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
                 if (rc_gpu != SVX_OK) break;
                 used[sl] = true; d->stats.gpu_blocks += (int64_t)mm;
                 sl = (sl + 1) % 3;
-                if (mapped && !sub_env) {                               // one launch at a time: what is left stays available to the host's cores until this one is through
-                    const int prev = (sl + 2) % 3;
-                    float ms = 0; rc_gpu = svx_inflater_wait(d->inf, prev, &ms); d->stats.inflate_kernel_ms += ms; used[prev] = false;
-                }
             }
             d->stats.t_stage += dd_now() - t0; t0 = dd_now();
             for (int k = 0; k < 3; k++) if (used[k]) { float ms = 0; const int rc = svx_inflater_wait(d->inf, k, &ms); d->stats.inflate_kernel_ms += ms; if (rc_gpu == SVX_OK) rc_gpu = rc; }

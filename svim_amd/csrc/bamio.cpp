@@ -38,11 +38,9 @@ static inline double now_s() { return std::chrono::duration<double>(std::chrono:
 // the decoder threads; std::vector::resize would first zero them (a memset of every batch)
 template <class T> struct RawVec {
     T* p = nullptr; size_t n = 0, cap = 0;
-    // a buffer that is page-locked for DMA (svx_inflater_pin) must lose its registration BEFORE its memory is freed or moved
-    void (*before_move)(void* user, void* old_ptr) = nullptr; void* bm_user = nullptr;
     RawVec() = default;
     RawVec(const RawVec&) = delete; RawVec& operator=(const RawVec&) = delete;
-    ~RawVec() { if (before_move && p) before_move(bm_user, p); free(p); }
+    ~RawVec() { free(p); }
     // Large buffers (inflate windows, CIGAR words, packed bases: hundreds of MB that 100+ threads write for the first time at once) are
     // 2 MB aligned and marked for transparent huge pages: first-touch page faults on 4 KB pages serialise the threads in the kernel.
     void reserve(size_t c) {
@@ -56,12 +54,10 @@ template <class T> struct RawVec {
             if (posix_memalign(&q, huge, rounded) != 0 || !q) throw std::string("out of host memory");
             (void)madvise(q, rounded, MADV_HUGEPAGE);
             if (p && n) memcpy(q, p, (n < cap ? n : cap) * sizeof(T));
-            if (before_move && p) before_move(bm_user, p);
             free(p);
             p = (T*)q; cap = rounded / sizeof(T);
             return;
         }
-        if (before_move && p) before_move(bm_user, p);
         T* q = (T*)realloc(p, bytes);
         if (!q) throw std::string("out of host memory");
         p = q; cap = nc;
@@ -205,7 +201,6 @@ struct svx_bam {
     int64_t gpu_blocks = 0, cpu_blocks = 0; double gpu_kernel_ms = 0;
     // svx_bam_set_device_decode: inflate, record discovery and decode on the GPU (bamdev.hip); batches come back with device pointers
     svx_devdec* dev = nullptr; int dev_device = -1;
-    bool map_registered_once = false;         // the file mapping has been registered with a GPU at some point (SVX_BAM_DEV_MAPFILE=1): its address range is quarantined at close
     size_t header_bytes = 0;                  // length of the BAM header in the inflated stream
     size_t dev_fpos = 0; uint64_t dev_skip = 0; bool dev_file_done = false, dev_region_done = false;
     int dev_cur = -1; int64_t dev_first = 0, dev_valid = 0; bool dev_have_carry = false;
@@ -224,7 +219,6 @@ struct svx_bam {
 };
 
 static void dev_drop_prefetch(svx_bam* h);
-extern "C" long long svx_inflater_unregister_failures();
 
 // ---- BGZF ------------------------------------------------------------------------------------------------------------------
 struct RawBlock { const uint8_t* comp; size_t clen; uint32_t isize; size_t out_at; uint32_t crc; };
@@ -293,15 +287,13 @@ static void inflate_next_chunk(svx_bam* h) {
             b.out_at = total; total += b.isize;
             blocks.push_back(b);
         }
-        if (h->gpu && WIN_HEAD + total > h->next.cap) (void)svx_inflater_unpin(h->gpu, h->next.data());      // the window is about to move
         h->next.resize_uninit(WIN_HEAD + total);
         h->next_len = total;
         if (h->gpu && !blocks.empty()) {
             // Both ends against the middle: a feeder thread hands sub-batches from the FRONT of the chunk to the GPU (payloads packed into pinned staging,
             // three sub-batches in flight: H2D, inflate and the copy back overlap), the worker threads inflate runs of 8 blocks from the BACK with zlib;
-            // whoever is faster takes more.  The window is page-locked so that the copy back is a DMA into place.
+            // whoever is faster takes more.  (The window is pageable memory of the reader: the inflated bytes reach it through the inflater's page-locked buffer.)
             uint8_t* out_base = h->next.data() + WIN_HEAD;
-            (void)svx_inflater_pin(h->gpu, h->next.data(), h->next.cap);
             std::mutex m;
             size_t lo = 0, hi = blocks.size();
             auto take = [&](bool front, size_t want, size_t& a, size_t& b) -> bool {
@@ -419,7 +411,6 @@ static bool ensure(svx_bam* h, size_t need) {
         } else {
             // a record longer than the headroom straddles the chunks: fall back to appending
             if (h->pos) { memmove(h->buf.data(), h->buf.data() + h->pos, keep); h->buf.n = keep; h->pos = 0; }
-            if (h->gpu && h->buf.n + h->next_len > h->buf.cap) (void)svx_inflater_unpin(h->gpu, h->buf.data());
             h->buf.append(h->next.data() + WIN_HEAD, h->next_len);
         }
         if (h->next_eof) h->file_eof = true;
@@ -461,17 +452,9 @@ static int default_threads() {
 
 // BGZF inflate shared between the GPU (svx_inflater, device >= 0) and the host's cores; device < 0 switches it off again.  Larger chunks then:
 // the GPU wants thousands of blocks in flight.
-// the buffers the GPU reads from / writes to by DMA: both inflate windows and the two big arrays of either batch set (CIGAR words, packed bases)
-static void unpin_hook(void* user, void* p) { svx_bam* h = (svx_bam*)user; if (h->gpu) (void)svx_inflater_unpin(h->gpu, p); }
-static void set_pin_hooks(svx_bam* h, bool on) {
-    auto set = [&](auto& v) { v.before_move = on ? unpin_hook : nullptr; v.bm_user = on ? h : nullptr; };
-    set(h->buf); set(h->next);
-    for (auto& b : h->ba) { set(b.cigar); set(b.seq); }
-}
 static void drop_gpu(svx_bam* h) {
     if (!h->gpu) return;
-    set_pin_hooks(h, false);
-    svx_inflater_destroy(h->gpu);                        // unregisters everything it page-locked
+    svx_inflater_destroy(h->gpu);
     h->gpu = nullptr;
 }
 
@@ -482,7 +465,6 @@ extern "C" int svx_bam_set_gpu_inflate(svx_bam* h, int device) {
     if (device < 0) return SVX_OK;
     const int rc = svx_inflater_create(device, &h->gpu);
     if (rc != SVX_OK) { h->gpu = nullptr; return rc; }
-    set_pin_hooks(h, true);
     if (!getenv("SVX_BAM_CHUNK_BLOCKS")) {                   // (the test hook keeps its small chunks)
         h->chunk_bytes = std::max<size_t>(h->chunk_bytes, (size_t)3072 << 20);
         h->chunk_blocks = std::max<size_t>(h->chunk_blocks, 65536);
@@ -589,14 +571,7 @@ extern "C" void svx_bam_close(svx_bam* h) {
                             "record discovery %.3f, decode %.3f, names %.3f; %lld serial fallbacks\n", (long long)ds.blocks, (long long)ds.gpu_blocks, (long long)ds.cpu_blocks, ds.bytes / 1e6, (long long)ds.records, ds.t_stage,
                     ds.t_inflate_wait, ds.inflate_kernel_ms, ds.t_discover, ds.t_decode, ds.t_names, (long long)ds.fallbacks);
         }
-        const long long before = svx_inflater_unregister_failures();
         devdec_destroy(h->dev); h->dev = nullptr;
-        if (svx_inflater_unregister_failures() != before) h->map = nullptr;      // the file's registration with the GPU could not be removed: the mapping stays (see bgzf.hip)
-    }
-    if (h->map && h->map_registered_once) {
-        // (SVX_BAM_DEV_MAPFILE=1) an address range that WAS registered with the GPU is never handed back to the allocator: an inaccessible anonymous reservation
-        // takes the file mapping's place (the file itself is let go), so that nothing can be placed at an address the runtime may still remember
-        if (mmap((void*)h->map, h->map_len, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0) != MAP_FAILED) h->map = nullptr;
     }
     if (h->map) munmap((void*)h->map, h->map_len);
     if (h->fd >= 0) close(h->fd);
@@ -744,7 +719,7 @@ static inline bool cg_placeholder(const uint8_t* rec, const uint8_t* cig, uint32
 // another type hides a later array (bam_tag2cigar then leaves the record alone)
 static void scan_aux(const uint8_t* q, const uint8_t* end, const char*& sa, size_t& sa_n, const uint8_t*& cg, uint32_t& cg_n) {
     sa = nullptr; sa_n = 0; cg = nullptr; cg_n = 0;
-    bool cg_seen = false;
+    bool cg_seen = false, sa_seen = false;      // bam_aux_get (pysam's get_tag, bam_tag2cigar): the FIRST field of a name counts, whatever its type
     while (q + 3 <= end) {
         const char t0 = (char)q[0], t1 = (char)q[1], ty = (char)q[2]; q += 3;
         size_t sz = 0;
@@ -754,7 +729,7 @@ static void scan_aux(const uint8_t* q, const uint8_t* end, const char*& sa, size
             case 's': case 'S': sz = 2; break;
             case 'i': case 'I': case 'f': sz = 4; break;
             case 'Z': case 'H': { const uint8_t* z = (const uint8_t*)memchr(q, 0, (size_t)(end - q)); if (!z) throw std::string("unterminated aux string");
-                if (t0 == 'S' && t1 == 'A' && ty == 'Z') { sa = (const char*)q; sa_n = (size_t)(z - q); } sz = (size_t)(z - q) + 1; break; }
+                if (t0 == 'S' && t1 == 'A' && ty == 'Z' && !sa_seen) { sa = (const char*)q; sa_n = (size_t)(z - q); } sz = (size_t)(z - q) + 1; break; }
             case 'B': { if (left < 5) throw std::string("truncated BAM aux array");
                 const char sub = (char)q[0]; const uint32_t cnt = rd32(q + 1); const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
                 sz = 5 + es * (size_t)cnt;
@@ -763,6 +738,7 @@ static void scan_aux(const uint8_t* q, const uint8_t* end, const char*& sa, size
             default: throw std::string("unknown BAM aux type");
         }
         if (t0 == 'C' && t1 == 'G') cg_seen = true;
+        if (t0 == 'S' && t1 == 'A') sa_seen = true;
         if (sz > left) throw std::string("BAM aux field runs past the end of its record");
         q += sz;
     }
@@ -1044,7 +1020,6 @@ extern "C" int svx_bam_set_device_decode(svx_bam* h, int device) {
     const int rc = devdec_create(device, granted_cpus(), (int32_t)h->ref_names.size(), h->ref_len.data(), h->names_blob.c_str(), h->contig_rank.data(), &h->dev);
     if (rc != SVX_OK) { h->dev = nullptr; return rc; }
     h->dev_device = device;
-    if (h->map && h->map_len) { devdec_set_file(h->dev, h->map, h->map_len); if (devdec_file_registered(h->dev)) h->map_registered_once = true; }
     { const char* e = getenv("SVX_BAM_DEV_CHUNK_MB"); if (e && atoll(e) > 0) h->dev_chunk_bytes = (size_t)atoll(e) << 20; }
     { const char* e = getenv("SVX_BAM_DEV_CHUNK_BLOCKS"); if (e && atoll(e) > 0) h->dev_chunk_blocks = (size_t)atoll(e); }
     if (h->prefetch_active) { h->prefetch.wait(); h->prefetch_active = false; }
@@ -1159,11 +1134,6 @@ extern "C" int svx_bam_read_batch(svx_bam* h, int64_t max_records, int mode, int
             out->seq_rng_byte = h->b->rng_byte.data(); out->n_seq_rng = (int64_t)h->b->rng_off[(size_t)n];
         }
         h->total_records += n;
-        // the consumer uploads these arrays to the GPU: page-locked, the upload is one DMA each (the registration lasts until the array moves)
-        if (h->gpu && n > 0) {
-            (void)svx_inflater_pin(h->gpu, h->b->cigar.data(), h->b->cigar.cap * sizeof(uint32_t));
-            (void)svx_inflater_pin(h->gpu, h->b->seq.data(), h->b->seq.cap);
-        }
     } catch (const std::string& e) { h->b = handed_out; return bam_fail(SVX_E_ARG, e); }
       catch (const std::exception& e) { h->b = handed_out; return bam_fail(SVX_E_ARG, std::string("reader: ") + e.what()); }
     return SVX_OK;

@@ -49,8 +49,6 @@ struct InflaterSlot {
 struct svx_inflater {
     int device = 0;
     InflaterSlot slot[INF_SLOTS];
-    std::vector<std::pair<void*, size_t>> pinned;         // caller buffers registered for direct DMA (only with SVX_READER_REGISTER=1 / SVX_BAM_DEV_MAPFILE=1)
-    std::mutex pin_mutex;                                 // pin / unpin come from the reader's threads
     int* status_block = nullptr;                          // pinned: 4 ints per slot
 };
 
@@ -72,24 +70,10 @@ extern "C" int svx_inflater_create(int device, svx_inflater** out) {
     return SVX_OK;
 }
 
-// Registering the reader's memory with the GPU (hipHostRegister: the inflate windows and batch arrays of the host reader, the memory-mapped BAM file of the device
-// reader) is OFF by default since round 5: a registration describes an address range the library later frees or unmaps, and any trace of it that the runtime keeps
-// beyond hipHostUnregister makes a later copy into whatever the allocator places there fault (hostcopy.hpp).  The data takes the library's own page-locked buffers
-// instead.  SVX_READER_REGISTER=1 (windows / arrays) and SVX_BAM_DEV_MAPFILE=1 (file mapping) switch the registrations back on for A/B runs.
-static bool reader_register() { static const bool on = []() { const char* e = getenv("SVX_READER_REGISTER"); return e && e[0] == '1'; }(); return on; }
-// A registration that could NOT be removed must never meet other memory at its address: the runtime would go on treating that address range as page-locked with the old
-// physical pages (a later pageable copy into memory the allocator placed there faults).  The failures are counted; the owner of the memory (bamio.cpp: the file
-// mapping) keeps it mapped for the life of the process when the count moved.
-static std::atomic<long long> g_unregister_failures{0};
-extern "C" long long svx_inflater_unregister_failures() { return g_unregister_failures.load(); }
-static void inf_unregister(void* p) {
-    const hipError_t e = hipHostUnregister(p);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        if (g_unregister_failures.fetch_add(1) == 0) fprintf(stderr, "libsvx: hipHostUnregister(%p) failed (%s): the memory stays mapped\n", p, hipGetErrorString(e));
-    }
-}
-
+// Nothing of the reader's memory is registered with the GPU (hipHostRegister): a registration describes an address range the library later frees or unmaps, and any
+// trace of it that the runtime keeps beyond hipHostUnregister makes a later copy into whatever the allocator places there fault (hostcopy.hpp).  All data takes the
+// library's own page-locked buffers.  (Round 5 kept the registrations of the reader's windows and of the memory-mapped file behind SVX_READER_REGISTER /
+// SVX_BAM_DEV_MAPFILE; nothing tested them and the registered file measured no faster than the staged input, profiles/r05_device_reader_rate*.txt: removed in round 6.)
 extern "C" void svx_inflater_destroy(svx_inflater* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
@@ -101,7 +85,6 @@ extern "C" void svx_inflater_destroy(svx_inflater* f) {
         for (auto& e : sl.ev) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(sl.stream);
     }
-    for (auto& pr : f->pinned) inf_unregister(pr.first);
     if (f->status_block) (void)hipHostFree(f->status_block);
     delete f;
 }
@@ -113,7 +96,7 @@ extern "C" void* svx_inflater_staging(svx_inflater* f, int slot, uint64_t bytes)
     InflaterSlot& sl = f->slot[slot];
     if (bytes > sl.staging_cap) {
         (void)hipSetDevice(f->device);
-        if (sl.busy) { (void)hipStreamSynchronize(sl.stream); sl.busy = false; }
+        if (sl.busy) { (void)svx_fail(SVX_E_STATE, "slot still busy: svx_inflater_wait before asking for a larger staging buffer", __FILE__, __LINE__, hipSuccess); return nullptr; }
         if (sl.staging) (void)hipHostFree(sl.staging);
         sl.staging = nullptr; sl.staging_cap = 0;
         const size_t want = (size_t)bytes + (size_t)bytes / 4 + 4096;
@@ -121,43 +104,6 @@ extern "C" void* svx_inflater_staging(svx_inflater* f, int slot, uint64_t bytes)
         sl.staging_cap = want;
     }
     return sl.staging;
-}
-
-// page-lock a caller buffer that receives inflated data, so that the copy back is one DMA (without it the runtime stages through its own buffers);
-// a buffer that moved or grew is registered again.  Failure to register is not an error - the copies just take the slow path.
-extern "C" int svx_inflater_pin(svx_inflater* f, void* p, uint64_t bytes) {
-    if (!f || !p || !bytes || !reader_register()) return SVX_OK;
-    std::lock_guard<std::mutex> guard(f->pin_mutex);
-    (void)hipSetDevice(f->device);
-    for (size_t i = 0; i < f->pinned.size(); i++) {
-        auto& pr = f->pinned[i];
-        if (pr.first == p && pr.second >= bytes) return SVX_OK;
-        const char* a = (const char*)pr.first; const char* b = (const char*)p;
-        if (b < a + pr.second && a < b + bytes) {                                   // overlaps an older registration: drop that one
-            for (auto& sl : f->slot) if (sl.busy) { (void)hipStreamSynchronize(sl.stream); }
-            inf_unregister(pr.first);
-            f->pinned.erase(f->pinned.begin() + (long)i); i--;
-        }
-    }
-    if (hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) == hipSuccess) f->pinned.emplace_back(p, (size_t)bytes);
-    else (void)hipGetLastError();
-    return SVX_OK;
-}
-
-// a page-locked destination is about to be freed or reallocated: its registration must go first (a stale one would make the runtime treat
-// whatever lives at that address later as page-locked memory with the OLD physical pages)
-extern "C" int svx_inflater_unpin(svx_inflater* f, void* p) {
-    if (!f || !p) return SVX_OK;
-    std::lock_guard<std::mutex> guard(f->pin_mutex);
-    (void)hipSetDevice(f->device);
-    for (size_t i = 0; i < f->pinned.size(); i++) {
-        if (f->pinned[i].first != p) continue;
-        for (auto& sl : f->slot) if (sl.busy) (void)hipStreamSynchronize(sl.stream);
-        inf_unregister(p);
-        f->pinned.erase(f->pinned.begin() + (long)i);
-        break;
-    }
-    return SVX_OK;
 }
 
 // n payloads in the slot's staging buffer (in_off[i], any alignment, clen[i] bytes of raw DEFLATE) -> out + out_at[i] (isize[i] bytes each),
@@ -189,13 +135,8 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
     uint8_t* out_dev = out;
     if (!out_on_device) { SVXCHK(sl.out.reserve((size_t)out_bytes + 64)); out_dev = sl.out.as<uint8_t>(); }
     hipStream_t st = sl.stream;
-    // is the host window registered (SVX_READER_REGISTER=1: one DMA into place), or does the data come through the slot's page-locked buffer?
-    bool direct_out = false;
-    if (!out_on_device && reader_register()) {
-        std::lock_guard<std::mutex> guard(f->pin_mutex);
-        for (auto& pr : f->pinned) if ((const char*)out >= (const char*)pr.first && (const char*)out + out_bytes <= (const char*)pr.first + pr.second) direct_out = true;
-    }
-    if (!out_on_device && !direct_out && out_bytes > sl.out_stage_cap) {
+    // a host window receives the data through the slot's page-locked buffer
+    if (!out_on_device && out_bytes > sl.out_stage_cap) {
         if (sl.out_stage) (void)hipHostFree(sl.out_stage);
         sl.out_stage = nullptr; sl.out_stage_cap = 0;
         const size_t want = (size_t)out_bytes + (size_t)out_bytes / 4 + 4096;
@@ -213,56 +154,9 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
     HIPCHK(hipMemcpyAsync(sl.host_status, sl.status.p, 16, hipMemcpyDeviceToHost, st));
     sl.out_host = nullptr; sl.out_host_bytes = 0;
     if (!out_on_device) {
-        if (direct_out) HIPCHK(hipMemcpyAsync(out, out_dev, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
-        else { HIPCHK(hipMemcpyAsync(sl.out_stage, out_dev, (size_t)out_bytes, hipMemcpyDeviceToHost, st)); sl.out_host = out; sl.out_host_bytes = (size_t)out_bytes; }
+        HIPCHK(hipMemcpyAsync(sl.out_stage, out_dev, (size_t)out_bytes, hipMemcpyDeviceToHost, st)); sl.out_host = out; sl.out_host_bytes = (size_t)out_bytes;
     }
     sl.busy = true;
-    return SVX_OK;
-}
-
-// the same with the payloads already in device-visible memory (`comp_dev` + in_off[i]: HBM, or host memory registered with the GPU - the memory-mapped BAM
-// file itself, svx_inflater_map_file): nothing is staged or copied, the launch follows at once.  Output to device memory only.
-extern "C" int svx_inflater_enqueue_mapped(svx_inflater* f, int slot, int64_t n, const uint8_t* comp_dev, uint64_t comp_bytes, const uint64_t* in_off, const uint32_t* clen,
-                                           const uint32_t* isize, const uint64_t* out_at, uint8_t* out_dev, uint64_t out_bytes) {
-    if (!f || slot < 0 || slot >= INF_SLOTS || n < 0 || (n && (!comp_dev || !in_off || !clen || !isize || !out_at || !out_dev))) return svx_fail(SVX_E_ARG, "bad argument", __FILE__, __LINE__, hipSuccess);
-    InflaterSlot& sl = f->slot[slot];
-    if (sl.busy) return svx_fail(SVX_E_STATE, "slot still busy: svx_inflater_wait first", __FILE__, __LINE__, hipSuccess);
-    if (n == 0) return SVX_OK;
-    HIPCHK(hipSetDevice(f->device));
-    std::vector<BgzfJob>& jobs = sl.host_jobs;
-    jobs.resize((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
-        if (in_off[i] + clen[i] > comp_bytes || out_at[i] + isize[i] > out_bytes) return svx_fail(SVX_E_ARG, "payload offset / size out of range", __FILE__, __LINE__, hipSuccess);
-        jobs[(size_t)i] = BgzfJob{in_off[i], out_at[i], clen[i], isize[i]};
-    }
-    SVXCHK(sl.jobs.reserve((size_t)n * sizeof(BgzfJob)));
-    SVXCHK(sl.status.reserve(16));
-    hipStream_t st = sl.stream;
-    SVXCHK(svx_h2d(sl.jobs.p, jobs.data(), (size_t)n * sizeof(BgzfJob), st));
-    HIPCHK(hipMemsetAsync(sl.status.p, 0, 16, st));
-    HIPCHK(hipEventRecord(sl.ev[0], st));
-    sl.out_host = nullptr; sl.out_host_bytes = 0;
-    k_bgzf_inflate<<<(unsigned)n, 64, 0, st>>>(comp_dev, sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.status.as<int>());
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(sl.ev[1], st));
-    HIPCHK(hipMemcpyAsync(sl.host_status, sl.status.p, 16, hipMemcpyDeviceToHost, st));
-    sl.busy = true;
-    return SVX_OK;
-}
-// register a read-only host mapping (the memory-mapped BAM file) with the GPU: *dev_ptr is its address for kernels.  Returns SVX_E_HIP when the runtime refuses
-// (the caller stages through pinned buffers instead)
-extern "C" int svx_inflater_map_file(svx_inflater* f, const void* base, uint64_t bytes, const uint8_t** dev_ptr) {
-    if (!f || !base || !bytes || !dev_ptr) return svx_fail(SVX_E_ARG, "bad argument", __FILE__, __LINE__, hipSuccess);
-    { const char* e = getenv("SVX_BAM_DEV_MAPFILE"); if (!(e && e[0] == '1')) return svx_fail(SVX_E_HIP, "file mappings are not registered with the GPU (SVX_BAM_DEV_MAPFILE=1 switches it on)", __FILE__, __LINE__, hipSuccess); }
-    (void)hipSetDevice(f->device);
-    void* p = const_cast<void*>(base);
-    hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterReadOnly);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostRegister(p, (size_t)bytes, hipHostRegisterMapped); }
-    if (e != hipSuccess) { (void)hipGetLastError(); return svx_fail(SVX_E_HIP, "the runtime does not register the file mapping", __FILE__, __LINE__, e); }
-    void* dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || !dp) { (void)hipGetLastError(); (void)hipHostUnregister(p); return svx_fail(SVX_E_HIP, "no device address for the file mapping", __FILE__, __LINE__, hipSuccess); }
-    { std::lock_guard<std::mutex> guard(f->pin_mutex); f->pinned.emplace_back(p, (size_t)bytes); }
-    *dev_ptr = (const uint8_t*)dp;
     return SVX_OK;
 }
 

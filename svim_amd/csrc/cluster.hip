@@ -1572,7 +1572,7 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
     S.n_partitions = n_part; S.n_large_partitions = n_large; S.n_pairs = (int64_t)h_cnt[10]; S.n_clusters = ncl;
     if (pair_total > 0 && c->cell_shards.p) {
         unsigned long long h_cells[1024];
-        HIPCHK(hipMemcpy(h_cells, c->cell_shards.p, sizeof h_cells, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h_cells, c->cell_shards.p, sizeof h_cells, hipMemcpyDeviceToHost));       // 8 KiB of stack: below the runtime's in-place pinning size (1 MiB; hostcopy.hpp), staged by the runtime
         unsigned long long tot = 0;
         for (int i = 0; i < 1024; i++) tot += h_cells[i];
         S.n_edit_cells = (int64_t)tot;

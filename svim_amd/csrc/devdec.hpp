@@ -13,10 +13,6 @@ struct svx_devdec;
 // names_blob: the reference names NUL-separated in header order (SA tags name contigs)
 int  devdec_create(int device, int n_threads /* CPUs the host's share of the inflate may use */, int32_t n_ref, const int32_t* ref_len, const char* names_blob, const int32_t* contig_rank, svx_devdec** out);
 void devdec_destroy(svx_devdec* d);
-// the memory-mapped file the blocks of devdec_load point into: registered with the GPU when the runtime allows it (the inflate kernel then reads the compressed
-// blocks straight from the page cache over PCIe; otherwise they are staged through pinned buffers)
-void devdec_set_file(svx_devdec* d, const uint8_t* base, size_t bytes);
-bool devdec_file_registered(const svx_devdec* d);      // the mapping was registered with the GPU (SVX_BAM_DEV_MAPFILE=1)
 // Inflate `n` blocks into chunk slot `slot` (0..2) behind the unconsumed tail of slot `carry_slot` (-1: none), skip `skip_bytes` at the start of the
 // stream (the BAM header, first chunk only), find every complete record and decode all of them.  final_chunk: nothing follows (a partial record at the
 // end is an error).  min_mapq: primaries below it get no segment rows (src/svim/SVIM_COLLECT.py:143-161).

@@ -1,12 +1,14 @@
 // hostcopy.hip - page-locked bounce buffers for every copy between pageable host memory and the device (hostcopy.hpp says why).
 //
-// The pool: per device, slots of two sizes - SMALL (64 KiB, for the many counters / offsets / short arrays of a call) and BIG (8 MiB, larger arrays go through
+// The pool: per device (the device of the stream a copy is ordered on), slots of two sizes - SMALL (64 KiB, for the many counters / offsets / short arrays of a call) and BIG (8 MiB, larger arrays go through
 // them in pieces, two in flight).  A slot carries an event: a host -> device copy leaves the slot "pending" until the event is over, and whoever takes the slot next
 // waits for it (or takes another slot whose event is already over).  Slots are allocated on demand with hipHostMalloc and live until the process ends - page-locked
 // memory that is never unmapped is the one kind of host memory whose registration with the GPU cannot go stale.
 #include "common.hpp"
 #include "hostcopy.hpp"
 #include <mutex>
+#include <condition_variable>
+#include <chrono>
 #include <thread>
 #include <string>
 #include <cstdlib>
@@ -15,35 +17,54 @@ struct BounceSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; 
 
 namespace {
 const size_t SMALL_CAP = (size_t)64 << 10, BIG_CAP = (size_t)8 << 20;
-const int MAX_DEV = 16;
-struct Pool { std::mutex m; std::vector<BounceSlot*> small, big; };
-Pool g_pool[MAX_DEV];
+const size_t MAX_BIG = 8, MAX_SMALL = 256;               // 64 MiB + 16 MiB of page-locked memory per device at most
+struct Pool { std::mutex m; std::condition_variable freed; std::vector<BounceSlot*> small, big; };
+// one pool per device of the node (sized once from hipGetDeviceCount: no fixed limit on the number of GPUs)
+Pool* pool_of(int dev) {
+    static std::vector<Pool>* pools = []() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; } return new std::vector<Pool>((size_t)n); }();
+    return dev >= 0 && (size_t)dev < pools->size() ? &(*pools)[(size_t)dev] : nullptr;
+}
+// the device a stream belongs to (the null stream: the calling thread's current device); slots, events and copies all live on that device
+int device_of(hipStream_t st) {
+    int dev = -1;
+    if (st && hipStreamGetDevice(st, &dev) == hipSuccess) return dev;
+    (void)hipGetLastError();
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return dev;
+}
 
-BounceSlot* acquire(size_t bytes) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) { (void)hipGetLastError(); return nullptr; }
-    Pool& P = g_pool[dev];
+BounceSlot* acquire(size_t bytes, int dev) {
+    Pool* pp = pool_of(dev);
+    if (!pp) return nullptr;
+    Pool& P = *pp;
     const bool big = bytes > SMALL_CAP;
     BounceSlot* wait_for = nullptr;
     {
-        std::lock_guard<std::mutex> g(P.m);
+        std::unique_lock<std::mutex> g(P.m);
         std::vector<BounceSlot*>& v = big ? P.big : P.small;
-        for (BounceSlot* s : v) {
-            if (s->busy) continue;
-            if (s->pending) { if (hipEventQuery(s->ev) != hipSuccess) { (void)hipGetLastError(); if (!wait_for) wait_for = s; continue; } s->pending = false; }
-            s->busy = true;
-            return s;
-        }
-        // nothing free without waiting: a new slot while the pool is small (8 big = 64 MiB, 256 small = 16 MiB), else the oldest pending one
-        if (!wait_for || v.size() < (big ? 8u : 256u)) {
-            BounceSlot* s = new BounceSlot();
-            s->cap = big ? BIG_CAP : SMALL_CAP; s->dev = dev; s->big = big;
-            if (hipHostMalloc(&s->p, s->cap, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) {
-                (void)hipGetLastError();
-                if (s->p) (void)hipHostFree(s->p);
-                delete s;
-                if (!wait_for) return nullptr;
-            } else { s->busy = true; v.push_back(s); return s; }
+        for (int attempt = 0; ; attempt++) {
+            wait_for = nullptr;
+            for (BounceSlot* s : v) {
+                if (s->busy) continue;
+                if (s->pending) { if (hipEventQuery(s->ev) != hipSuccess) { (void)hipGetLastError(); if (!wait_for) wait_for = s; continue; } s->pending = false; }
+                s->busy = true;
+                return s;
+            }
+            // nothing free without waiting: a new slot while the pool is below its cap, else the oldest pending one, else (every slot is in some thread's hands)
+            // wait for a release - the cap is a bound.  A thread that waited 2 s without anybody releasing gets a slot beyond the cap rather than a deadlock
+            // (several HostCopy objects of ONE thread holding the whole pool: not a pattern of the library, but not excluded by its interface either).
+            if (v.size() < (big ? MAX_BIG : MAX_SMALL) || (!wait_for && attempt > 0)) {
+                BounceSlot* s = new BounceSlot();
+                s->cap = big ? BIG_CAP : SMALL_CAP; s->dev = dev; s->big = big;
+                if (hipHostMalloc(&s->p, s->cap, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (s->p) (void)hipHostFree(s->p);
+                    delete s;
+                    if (!wait_for) return nullptr;
+                } else { s->busy = true; v.push_back(s); return s; }
+            }
+            if (wait_for) break;
+            P.freed.wait_for(g, std::chrono::seconds(2));
         }
         wait_for->busy = true;
     }
@@ -52,13 +73,11 @@ BounceSlot* acquire(size_t bytes) {
     return wait_for;
 }
 void release(BounceSlot* s, bool pending) {
-    Pool& P = g_pool[s->dev];
-    std::lock_guard<std::mutex> g(P.m);
-    s->pending = pending; s->busy = false;
+    Pool& P = *pool_of(s->dev);
+    { std::lock_guard<std::mutex> g(P.m); s->pending = pending; s->busy = false; }
+    P.freed.notify_one();
 }
 }  // namespace
-
-bool svx_copy_direct() { static const bool on = []() { const char* e = getenv("SVX_COPY_DIRECT"); return e && e[0] == '1'; }(); return on; }
 
 bool svx_is_device_pointer(const void* p) {
     if (!p) return false;
@@ -72,8 +91,8 @@ bool svx_is_device_pointer(const void* p) {
 HostCopy::~HostCopy() { for (auto& q : pend_) release(q.slot, true); }
 
 // one piece of a large upload: its own slot, its own copy, ordered on the caller's stream like every other piece
-static int h2d_piece(char* dst, const char* src, size_t n, hipStream_t st) {
-    BounceSlot* s = acquire(n);
+static int h2d_piece(char* dst, const char* src, size_t n, hipStream_t st, int dev) {
+    BounceSlot* s = acquire(n, dev);
     if (!s) return svx_fail(SVX_E_HIP, "no page-locked bounce buffer (hipHostMalloc)", __FILE__, __LINE__, hipSuccess);
     memcpy(s->p, src, n);
     hipError_t e = hipMemcpyAsync(dst, s->p, n, hipMemcpyHostToDevice, st);
@@ -85,12 +104,11 @@ static int h2d_piece(char* dst, const char* src, size_t n, hipStream_t st) {
 
 int HostCopy::h2d(void* dev_dst, const void* host_src, size_t bytes) {
     if (!bytes) return SVX_OK;
-    if (svx_copy_direct()) { HIPCHK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st_)); return SVX_OK; }
     const char* src = (const char*)host_src; char* dst = (char*)dev_dst;
-    if (bytes >= ((size_t)64 << 20)) {
+    const int dev = device_of(st_);
+    if (bytes >= ((size_t)16 << 20)) {
         // a large array (the CIGAR words / packed bases of a host batch): one thread's memcpy into the bounce buffers (5-6 GB/s) would be the bottleneck of the
         // upload, so four threads take the 8 MiB pieces in turn - each piece has a slot of its own, the device copies queue on the caller's stream
-        int dev = 0; HIPCHK(hipGetDevice(&dev));
         const size_t pieces = (bytes + BIG_CAP - 1) / BIG_CAP;
         const int T = pieces < 4 ? (int)pieces : 4;
         std::vector<int> rc((size_t)T, SVX_OK); std::vector<std::string> msg((size_t)T);
@@ -100,7 +118,7 @@ int HostCopy::h2d(void* dev_dst, const void* host_src, size_t bytes) {
             if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); rc[(size_t)t] = SVX_E_HIP; msg[(size_t)t] = "hipSetDevice in an upload thread"; return; }
             for (size_t k = (size_t)t; k < pieces; k += (size_t)T) {
                 const size_t off = k * BIG_CAP, n = bytes - off < BIG_CAP ? bytes - off : BIG_CAP;
-                const int r = h2d_piece(dst + off, src + off, n, st);
+                const int r = h2d_piece(dst + off, src + off, n, st, dev);
                 if (r != SVX_OK) { rc[(size_t)t] = r; msg[(size_t)t] = g_svx_err; return; }
             }
         });
@@ -110,7 +128,7 @@ int HostCopy::h2d(void* dev_dst, const void* host_src, size_t bytes) {
     }
     while (bytes) {
         const size_t n = bytes < BIG_CAP ? bytes : BIG_CAP;
-        BounceSlot* s = acquire(n);
+        BounceSlot* s = acquire(n, dev);
         if (!s) return svx_fail(SVX_E_HIP, "no page-locked bounce buffer (hipHostMalloc)", __FILE__, __LINE__, hipSuccess);
         memcpy(s->p, src, n);
         hipError_t e = hipMemcpyAsync(dst, s->p, n, hipMemcpyHostToDevice, st_);
@@ -140,13 +158,13 @@ int HostCopy::drain(size_t keep_big, size_t keep_all) {
 
 int HostCopy::d2h(void* host_dst, const void* dev_src, size_t bytes) {
     if (!bytes) return SVX_OK;
-    if (svx_copy_direct()) { HIPCHK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, st_)); return SVX_OK; }
     char* dst = (char*)host_dst; const char* src = (const char*)dev_src;
+    const int dev = device_of(st_);
     while (bytes) {
         const size_t n = bytes < BIG_CAP ? bytes : BIG_CAP;
         if (n > SMALL_CAP && pend_big_ >= 2) SVXCHK(drain(1, (size_t)-1));              // two big pieces in flight: the copy of one overlaps the memcpy of the other
         if (pend_.size() >= 192) SVXCHK(drain((size_t)-1, 96));                        // (a call with very many small arrays must not hold the whole pool)
-        BounceSlot* s = acquire(n);
+        BounceSlot* s = acquire(n, dev);
         if (!s) return svx_fail(SVX_E_HIP, "no page-locked bounce buffer (hipHostMalloc)", __FILE__, __LINE__, hipSuccess);
         hipError_t e = hipMemcpyAsync(s->p, src, n, hipMemcpyDeviceToHost, st_);
         if (e == hipSuccess) e = hipEventRecord(s->ev, st_);
@@ -160,13 +178,11 @@ int HostCopy::d2h(void* host_dst, const void* dev_src, size_t bytes) {
 
 int HostCopy::out(void* dst, const void* dev_src, size_t bytes) {
     if (!bytes) return SVX_OK;
-    if (svx_copy_direct()) { HIPCHK(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDefault, st_)); return SVX_OK; }
     if (svx_is_device_pointer(dst)) { HIPCHK(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToDevice, st_)); return SVX_OK; }
     return d2h(dst, dev_src, bytes);
 }
 
 int HostCopy::finish() {
-    if (svx_copy_direct()) { HIPCHK(hipStreamSynchronize(st_)); return SVX_OK; }
     if (pend_.empty()) return SVX_OK;
     const hipError_t e = hipStreamSynchronize(st_);
     if (e != hipSuccess) return svx_fail(SVX_E_HIP, "device -> host copies through bounce buffers", __FILE__, __LINE__, e);

@@ -6,7 +6,8 @@
 // on request.  A registration that outlives the memory it described - the array was freed, the address range unmapped and later handed out again by the allocator -
 // describes physical pages that are gone: the next copy the runtime resolves against it makes the GPU fault, in whatever innocent call happens to use that
 // address (a fresh numpy array in the failing test).  The library cannot see or flush those caches, so it never lets the runtime near memory it does not own:
-// the runtime only ever sees hipHostMalloc memory (allocated once, never unmapped) and device pointers.  SVX_COPY_DIRECT=1 restores the direct copies (A/B).
+// the runtime only ever sees hipHostMalloc memory (allocated once, never unmapped) and device pointers.  (Round 5 kept the direct copies behind SVX_COPY_DIRECT=1
+// for A/B runs; the one run with it hung and nothing ever tested it: removed in round 6.)
 //
 // A HostCopy object batches the copies of one call on one stream:
 //     HostCopy hc(stream);
@@ -35,7 +36,6 @@ private:
     std::vector<Pending> pend_;
     size_t pend_big_ = 0;
 };
-bool svx_copy_direct();
 bool svx_is_device_pointer(const void* p);
 // one-shot forms (a HostCopy of one copy + finish)
 int svx_h2d(void* dev_dst, const void* host_src, size_t bytes, hipStream_t st);

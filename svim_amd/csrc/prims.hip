@@ -15,6 +15,7 @@
 // svx_exclusive_scan_*: scan.hpp.
 #include "common.hpp"
 #include "scan.hpp"
+#include "hostcopy.hpp"
 #include <algorithm>
 #include <vector>
 
@@ -271,18 +272,20 @@ extern "C" int svx_selftest_prims(svx_ctx* c, int64_t n, int32_t begin_bit, int3
         SVXCHK(dk.reserve((size_t)n * 8 + 8)); SVXCHK(dk2.reserve((size_t)n * 8 + 8)); SVXCHK(dv.reserve((size_t)n * 4 + 8)); SVXCHK(dv2.reserve((size_t)n * 4 + 8));
         SVXCHK(ds.reserve((size_t)(n + 1) * 8)); SVXCHK(ds2.reserve((size_t)(n + 1) * 8));
         if (n) {
-            HIPCHK(hipMemcpy(dk.p, k.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(dv.p, v.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+            // std::vectors of up to 26 MB that die with this call: through the library's pinned bounce buffers like every other pageable array (hostcopy.hpp) -
+            // a direct hipMemcpy would page-lock them in place and leave a registration of freed memory behind
+            SVXCHK(svx_h2d(dk.p, k.data(), (size_t)n * 8, c->stream));
+            SVXCHK(svx_h2d(dv.p, v.data(), (size_t)n * 4, c->stream));
         }
-        HIPCHK(hipMemcpy(ds.p, s.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+        SVXCHK(svx_h2d(ds.p, s.data(), (size_t)(n + 1) * 8, c->stream));
         SVXCHK(svx_sort_pairs_u64(c, dk.as<uint64_t>(), dk2.as<uint64_t>(), dv.as<uint32_t>(), dv2.as<uint32_t>(), n, begin_bit, end_bit));
         SVXCHK(svx_exclusive_scan_i64(c, ds.as<int64_t>(), ds2.as<int64_t>(), n + 1));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (n) {
-            HIPCHK(hipMemcpy(k2.data(), dk2.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(v2.data(), dv2.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+            SVXCHK(svx_d2h(k2.data(), dk2.p, (size_t)n * 8, c->stream));
+            SVXCHK(svx_d2h(v2.data(), dv2.p, (size_t)n * 4, c->stream));
         }
-        HIPCHK(hipMemcpy(s2.data(), ds2.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+        SVXCHK(svx_d2h(s2.data(), ds2.p, (size_t)(n + 1) * 8, c->stream));
         return SVX_OK;
     };
     const int rc = on_device();

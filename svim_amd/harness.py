@@ -122,18 +122,27 @@ class BamPipeline(object):
                 if region is not cur_region:
                     cur_region = region
                     self.region_slots.append([slot_base, 0])
-                self.region_slots[-1][1] += n
                 t0 = time.perf_counter()
                 eng.set_slot_base(slot_base)
-                eng.collect(b, p, fetch=False)
-                t_gpu += time.perf_counter() - t0
-                slot_base += 2 * n + 2
-                n_rec += n
-                n_batches += 1
+                # A KeyboardInterrupt that arrives while the call is inside libsvx is raised when the call RETURNS (ctypes): the batch's signatures are in the
+                # accumulated lists by then, so it is counted before the interrupt goes on to the handler below.  (A collect that fails raises SvxError.)
+                def counted():
+                    nonlocal t_gpu, slot_base, n_rec, n_batches
+                    self.region_slots[-1][1] += n
+                    t_gpu += time.perf_counter() - t0
+                    slot_base += 2 * n + 2
+                    n_rec += n
+                    n_batches += 1
+                try:
+                    eng.collect(b, p, fetch=False)
+                except KeyboardInterrupt:
+                    counted()
+                    raise
+                counted()
                 free.release()
         except KeyboardInterrupt:
             # src/svim/SVIM_COLLECT.py:126-128,164-166: an interrupt ends the reading, the pipeline goes on with what was collected - here the batches whose
-            # svx_collect has completed (their signatures are in the accumulated lists on the device); the batch being read is dropped
+            # svx_collect has completed (their signatures are in the accumulated lists on the device, and the counters above say so); the batch being READ is dropped
             logging.warning('Execution interrupted by user. Stop detection and continue with next step..')
             self.interrupted = True
         finally:

@@ -79,6 +79,10 @@ def foreign_case(seed, with_long=True):
         tail.append((small("cg_first_of_other_type", [(4, 50), (3, 500)]), [("CG", "Z", "not an array"), ("CG", "B", ("I", pk(real_a)))], None))
         two = small("cg_two_arrays", real_a)                                             # (the truth list holds the CIGAR the FIRST array restores)
         tail.append((two, [("tp", "A", "P"), ("CG", "B", ("I", pk(real_a))), ("CG", "B", ("I", pk(real_b)))], None))
+        # the same rule for SA (pysam's get_tag is bam_aux_get too): of two SA fields only the FIRST is ever looked at (the native readers took the last)
+        twice = small("sa_twice", [(0, 30), (4, 20)])
+        twice._tags = {"SA": "%s,2001,+,30S20M,60,0;" % REFS[0]}
+        tail.append((twice, [("NM", "i", 0), ("SA", "Z", twice._tags["SA"]), ("SA", "Z", "%s,7001,-,25S25M,50,1;%s,9001,+,10M40S,33,2;" % (REFS[1], REFS[0]))], None))
         # keep the file coordinate-sorted: all go behind the last chr10 record
         last_pos = max([a.reference_start for a in recs if a.reference_id == 2] + [0])
         for k, (a, items, q) in enumerate(tail):

@@ -718,15 +718,19 @@ def test_keyboard_interrupt_ends_the_reading_and_keeps_what_was_collected(tmp_pa
             pass
 
         def collect(self, b, p, fetch=False):
+            # an interrupt that arrives while a thread is inside a foreign (ctypes) call is raised when the call RETURNS: the batch has been
+            # appended to the accumulated lists by then - the stand-in records it and raises
             self.calls += 1
+            self.sizes.append(int(b.n_rec))
             if self.calls == 2:
                 raise KeyboardInterrupt()
-            self.sizes.append(int(b.n_rec))
 
     eng = Eng()
     pipe = harness.BamPipeline(path, o, eng, threads=2, batch_records=40, mode="coordinate", gpu_inflate=False, device_decode=False)
     n = pipe.run()                                                                   # does not raise
-    assert pipe.interrupted and n == 40 and eng.sizes == [40] and pipe.stats["batches"] == 1
+    # the counters agree with what CLUSTER will see: both batches whose svx_collect returned, none of the batch that was being read
+    assert pipe.interrupted and n == 80 and eng.sizes == [40, 40] and pipe.stats["batches"] == 2
+    assert sum(c for _, c in pipe.region_slots) == 80
     pipe.close()
     assert eng.acc == [True, False]
     # an uninterrupted pass over the same file for comparison

@@ -21,11 +21,8 @@ extern "C" const char* svx_last_error(void) { return g_svx_err.c_str(); }
 extern "C" int svx_inflater_create(int, svx_inflater**) { return SVX_E_NODEVICE; }
 extern "C" void svx_inflater_destroy(svx_inflater*) {}
 extern "C" void* svx_inflater_staging(svx_inflater*, int, uint64_t) { return nullptr; }
-extern "C" int svx_inflater_pin(svx_inflater*, void*, uint64_t) { return SVX_E_NODEVICE; }
-extern "C" int svx_inflater_unpin(svx_inflater*, void*) { return SVX_E_NODEVICE; }
 extern "C" int svx_inflater_enqueue(svx_inflater*, int, int64_t, const uint64_t*, const uint32_t*, const uint32_t*, const uint64_t*, uint64_t, uint8_t*, uint64_t, int) { return SVX_E_NODEVICE; }
 extern "C" int svx_inflater_wait(svx_inflater*, int, float*) { return SVX_E_NODEVICE; }
-extern "C" long long svx_inflater_unregister_failures() { return 0; }
 // ---- a CPU stand-in for the device decoder (bamdev.hip) with the same contract towards bamio.cpp: chunk slots, the unconsumed tail of one slot carried into the
 // next load, query-name mode holding the last read group back, batches as views of a slot's arrays.  What it is for: the HOST side of the device reader (slot
 // rotation across seek / rewind, grow-and-retry of chunks without a complete record, the chunk budget of contig ranges) under the sanitizers - every array of a slot
@@ -44,8 +41,6 @@ int devdec_create(int, int, int32_t n_ref, const int32_t*, const char*, const in
     svx_devdec* d = new svx_devdec(); d->rank.assign(contig_rank, contig_rank + n_ref); *out = d; return SVX_OK;
 }
 void devdec_destroy(svx_devdec* d) { if (!d) return; for (auto& s : d->slot) s.release(); delete d; }
-void devdec_set_file(svx_devdec*, const uint8_t*, size_t) {}
-bool devdec_file_registered(const svx_devdec*) { return false; }
 int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t n, int carry_slot, uint64_t skip, bool final_chunk, int, int mode) {
     std::vector<uint8_t>* st = new std::vector<uint8_t>();
     if (carry_slot >= 0) { const MockSlot& c = d->slot[carry_slot]; if (!c.stream) { delete st; g_svx_err = "mock: carry from an empty slot"; return SVX_E_STATE; }

@@ -42,7 +42,7 @@ def passes(nb, k=3):
     return tot, best
 
 
-variants = [("GPU + host cores, staged input (default since round 5)", {}), ("file mapping registered with the GPU, one launch per chunk (SVX_BAM_DEV_MAPFILE=1)", {"SVX_BAM_DEV_MAPFILE": "1"}), ("GPU only (default input path)", {"SVX_BAM_DEV_CPU": "0"}), ("GPU only, sub-batches of 12288", {"SVX_BAM_DEV_CPU": "0"}), ("GPU only, sub-batches of 4096", {"SVX_BAM_DEV_CPU": "0", "SVX_BAM_DEV_SUB": "4096"}),
+variants = [("GPU + host cores, staged input", {}), ("GPU only (default input path)", {"SVX_BAM_DEV_CPU": "0"}), ("GPU only, sub-batches of 12288", {"SVX_BAM_DEV_CPU": "0"}), ("GPU only, sub-batches of 4096", {"SVX_BAM_DEV_CPU": "0", "SVX_BAM_DEV_SUB": "4096"}),
             ("GPU only, sub-batches of 40000", {"SVX_BAM_DEV_CPU": "0", "SVX_BAM_DEV_SUB": "40000"}), ("GPU + 8 host threads", {"SVX_BAM_DEV_CPU": "8"}),
             ("GPU + 6 host threads, sub-batches of 24576", {"SVX_BAM_DEV_CPU": "6", "SVX_BAM_DEV_SUB": "24576"})]
 if os.environ.get("SVX_READER_ONE"):                  # (profiling runs: the GPU-only reader with mid-size sub-batches, nothing else)
@@ -50,7 +50,7 @@ if os.environ.get("SVX_READER_ONE"):                  # (profiling runs: the GPU
 for mb in chunks:
     for label, env in variants if mb == chunks[0] else variants[:1]:
         os.environ["SVX_BAM_DEV_CHUNK_MB"] = str(mb)
-        for k in ("SVX_BAM_DEV_CPU", "SVX_BAM_DEV_SUB", "SVX_BAM_DEV_MAPFILE"):
+        for k in ("SVX_BAM_DEV_CPU", "SVX_BAM_DEV_SUB"):
             os.environ.pop(k, None)
         os.environ.update(env)
         nb = NativeBam(path)
@@ -59,7 +59,7 @@ for mb in chunks:
         print("device reader, %4d MB chunks, %s: %.3f s  %.2f M records/s  %.1f GB/s inflated  %.1f GB/s of BAM  %r" % (
             mb, label, t, tot / t / 1e6, raw / t / 1e9, size / t / 1e9, nb.gpu_inflate_stats()), flush=True)
         nb.close()                                        # (prints the stage times of all passes to stderr)
-for k in ("SVX_BAM_DEV_CPU", "SVX_BAM_DEV_SUB", "SVX_BAM_DEV_MAPFILE"):
+for k in ("SVX_BAM_DEV_CPU", "SVX_BAM_DEV_SUB"):
     os.environ.pop(k, None)
 if os.environ.get("SVX_READER_ONE"):
     sys.exit(0)

@@ -54,6 +54,8 @@ void drain(Stream* st, Event* until, long long until_id, int budget = 1 << 30) {
 
 extern "C" {
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipStreamGetDevice(hipStream_t, hipDevice_t* d) { *d = 0; return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "model"; }
