@@ -150,15 +150,27 @@ def load_profile_json(name):
 
 
 def emit_strong(args, rank, world, local_rank, dev, use_dist, dist, opts, p, emit):
+    out = measure_strong(args, rank, world, local_rank, dev, use_dist, dist, opts, p, args.steps, args.warmup)
+    if use_dist:
+        from svim_amd import multigpu as MG
+        MG.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        emit(out)
+
+
+def measure_strong(args, rank, world, local_rank, dev, use_dist, dist, opts, p, steps, warmup, scale_default=0.2):
     """--scaling strong: BASELINE.json configs[3]'s shape - one coordinate-sorted whole-genome batch (svim_amd/workloads.py, the same on every rank: same seed),
-    every rank collects the records of the contigs it owns (multigpu.assign_contigs: contiguous ranges in name order, balanced by length; the record runs of
-    those contigs are views of the resident batch) and the ranks cluster with svx_cluster's rank exchange; rank 0 gathers cluster rows + member lists
-    (signature columns stay on their ranks: gather_signatures=False).  Total work does not depend on N and N=1 is the plain single-GPU step over the whole
-    batch, so value(N) / value(1) IS the strong-scaling speedup.  The line carries what crossed the fabric in the last step (multigpu.WIRE)."""
+    every rank collects the records of the coordinate WINDOWS it owns (multigpu.assign_windows, round 6: world - 1 cuts in (contig name, coordinate) order that
+    balance the records - a histogram of their start coordinates per Mb, what a BAM index gives - and cut long contigs; the step moves every cut into a corridor
+    no partition can straddle; the record runs are views of the resident batch) and the ranks cluster with svx_cluster's rank exchange; rank 0 gathers cluster
+    rows + member lists (signature columns stay on their ranks: gather_signatures=False).  Total work does not depend on N and N=1 is the plain single-GPU step
+    over the whole batch, so value(N) / value(1) IS the strong-scaling speedup.  The line carries what crossed the fabric in the last step (multigpu.WIRE).
+    Returns the line (rank 0) / None; the process group stays up."""
     import torch
     from svim_amd import _lib, multigpu as MG, workloads
     name = args.workload if args.workload != "c1" else "c3"
-    scale = args.scale if (args.scale != 1.0 or name != "c3") else 0.2      # c3 at full scale is a 30x human genome (4.6 M reads): the default is a fifth of it (~1 M reads)
+    scale = args.scale if (args.scale != 1.0 or name != "c3") else scale_default      # c3 at full scale is a 30x human genome (4.6 M reads): the default is a fifth of it (~1 M reads)
     t0 = time.perf_counter()
     prof = workloads.profile(name, scale)
     batch, genome, g_off, meta = workloads.make_batch_full(prof, seed=3, device=dev)            # NOT seed + rank: every rank holds the same batch
@@ -167,25 +179,24 @@ def emit_strong(args, rank, world, local_rank, dev, use_dist, dist, opts, p, emi
     refs = [c[0] for c in prof["contigs"]]
     lens = [int(x) for x in (g_off[1:] - g_off[:-1]).tolist()]
     n_contig = len(refs)
-    owner = np.asarray(MG.assign_contigs(refs, lens, world), dtype=np.int32)
     order = sorted(range(n_contig), key=lambda i: refs[i])
     crank = np.zeros(n_contig, dtype=np.int32)
     crank[order] = np.arange(n_contig, dtype=np.int32)
-    # this rank's record runs: maximal runs of consecutive reference ids it owns (the batch is sorted by reference id, position)
+    # proposed windows: equal numbers of RECORDS per rank, from the records' start coordinates per Mb (the batch is sorted by reference id, position)
     tid = batch.t["tid"][:batch.n_rec].to(torch.int64)
-    runs, t = [], 0
-    while t < n_contig:
-        if owner[t] == rank:
-            b = t
-            while b + 1 < n_contig and owner[b + 1] == rank:
-                b += 1
-            lo = int(torch.searchsorted(tid, torch.tensor([t], device=dev), right=False).item())
-            hi = int(torch.searchsorted(tid, torch.tensor([b], device=dev), right=True).item())
-            if hi > lo:
-                runs.append((lo, hi))
-            t = b + 1
-        else:
-            t += 1
+    pos = batch.t["pos"][:batch.n_rec].to(torch.int64)
+    BIN = 1 << 20
+    dens = []
+    for k in range(n_contig):
+        sel = pos[tid == k]
+        nb = max(1, -(-lens[k] // BIN))
+        dens.append(torch.bincount(sel // BIN, minlength=nb)[:nb].cpu().numpy().astype(np.float64) if sel.numel() else np.zeros(nb))
+    windows = MG.assign_windows(refs, lens, world, weights=dens, bin_size=BIN)
+    # this rank's record runs: maximal runs of consecutive records whose start lies in one of its windows
+    mine = windows.owner_of_positions(tid.clamp_min(0), pos) == rank
+    edge = torch.nonzero(mine[1:] != mine[:-1]).flatten() + 1
+    bounds = [0] + [int(x) for x in edge.tolist()] + [batch.n_rec]
+    runs = [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a and bool(mine[a].item())]
     views = [batch.view_records(lo, hi) for lo, hi in runs]
     structs = [v.struct() for v in views]
     eng = _lib.Engine(local_rank)
@@ -207,7 +218,7 @@ def emit_strong(args, rank, world, local_rank, dev, use_dist, dist, opts, p, emi
         sigs = eng.collect_counts()[0]
         if use_dist:
             MG.wire_reset()
-            last["res"] = MG.cluster_step(adapter, p, rank, world, gid, crank, owner, key_base=0, read_base=0, gather_signatures=False)
+            last["res"] = MG.cluster_step(adapter, p, rank, world, gid, crank, windows, key_base=0, read_base=0, gather_signatures=False)
         else:
             eng.cluster(p, crank, source=0, fetch=False)
         last.update(used=used, sigs=sigs, ops=ops, scan_ms=scan_ms, cluster_ms=eng.stats()["t_cluster_ms"], clusters=eng.stats()["n_clusters"])
@@ -223,11 +234,11 @@ def emit_strong(args, rank, world, local_rank, dev, use_dist, dist, opts, p, emi
     step()
     torch.cuda.synchronize()
     first_step_ms = 1e3 * (time.perf_counter() - f0)
-    for _ in range(max(0, args.warmup - 1)):
+    for _ in range(max(0, warmup - 1)):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -244,25 +255,32 @@ def emit_strong(args, rank, world, local_rank, dev, use_dist, dist, opts, p, emi
         wire = dict(MG.WIRE)
         backend = dist.get_backend()
         world_seen = dist.get_world_size()
-        MG.barrier()
-        dist.destroy_process_group()
     else:
         per_rank = [[last["used"], last["sigs"], last["ops"], len(runs), sum(hi - lo for lo, hi in runs), int(1e3 * last["scan_ms"]), int(1e3 * last["cluster_ms"]), last["clusters"]]]
         wire, backend, world_seen = None, None, 1
+    eng.close()
     if rank != 0:
-        return
+        return None
     tot_used = sum(r[0] for r in per_rank)
     res = last.get("res")
+    cuts_used = getattr(res, "windows", None) or windows
+    sig_rows = [r[1] for r in per_rank]
     out = {
-        "metric": "aligned reads/sec through COLLECT+CLUSTER", "value": tot_used * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "metric": "aligned reads/sec through COLLECT+CLUSTER", "value": tot_used * steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u32/i32 CIGAR + u8 bases, int64 positions, f64 distances", "data": "synthetic",
         "config": {"workload": "configs[3] stand-in (%s profile, svim_amd/workloads.py): ONE whole-genome batch of %d records on %d contigs (%.0f Mb), the same on every rank, "
-                               "sharded by contig ownership; --scaling strong --scale %g (NOT the driver's default line: that one is configs[1], weak)" % (
+                               "sharded by coordinate-window ownership; --scaling strong --scale %g (the driver's default line is configs[1], weak; with --gpus N > 1 it "
+                               "carries this measurement as its strong_scaling block)" % (
                                    name, meta["n_records"], n_contig, meta["genome_bases"] / 1e6, scale),
                    "records_total": meta["n_records"], "cigar_ops_total": meta["n_ops"],
-                   "parallelism": "1 process/GPU; contigs sharded over ranks (contiguous ranges in name order, balanced by length), every partition local; over the fabric "
-                                  "per step: foreign BND / DUP_INT rows, the rank exchange of svx_cluster (all-gathers), cluster rows + member lists to rank 0"},
+                   "parallelism": "1 process/GPU; coordinate windows sharded over ranks (consecutive ranges of the (contig name, coordinate) order, balanced by records, cuts "
+                                  "inside contigs moved into corridors no partition straddles), every partition local; over the fabric per step: the merged signature stretches "
+                                  "around the cuts, foreign rows (reads across a cut, BND / DUP_INT), the rank exchange of svx_cluster (all-gathers), cluster rows + member lists to rank 0"},
+        "ownership": {"cuts": [[refs[int(c)], int(x)] for c, x in zip(cuts_used.cut_contig, cuts_used.cut_pos)],
+                      "signatures_collected_per_rank": sig_rows,
+                      "max_over_mean_signatures": (max(sig_rows) / (sum(sig_rows) / float(len(sig_rows)))) if sum(sig_rows) else None,
+                      "max_over_mean_records": max(r[4] for r in per_rank) / (sum(r[4] for r in per_rank) / float(len(per_rank)))},
         "first_step_ms": first_step_ms, "synth_seconds": t_gen,
         "counts": {"reads_used": tot_used, "signatures": sum(r[1] for r in per_rank), "cigar_ops": sum(r[2] for r in per_rank),
                    "clusters_gathered": (res.n if res is not None else last["clusters"])},
@@ -276,7 +294,7 @@ def emit_strong(args, rank, world, local_rank, dev, use_dist, dist, opts, p, emi
             "note": "payload bytes as the wire sees them (padded slots x world for all-gathers, all ranks' padded slots for the gathers to rank 0); SVX_WIRE_STATS=1 times "
                     "every collective between two device synchronises (perturbs the step: off by default)"},
     }
-    emit(out)
+    return out
 
 
 def main():
@@ -472,9 +490,20 @@ def main():
         cnt = torch.tensor([st["n_rec_used"], st["n_sig"], st["n_ops"]], dtype=torch.int64, device=dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         tot_used, tot_sig, tot_ops = (int(x) for x in cnt.tolist())
+        # With more than one rank the weak-scaling value is linear by construction; the line therefore also carries a STRONG-scaling measurement (one whole-genome
+        # batch, configs[3]'s shape at a tenth of its size, sharded by coordinate windows) - measure_strong at N ranks; the same block at N=1 is the reference point
+        strong_block = None
+        try:
+            sb = measure_strong(args, rank, world, local_rank, dev, True, dist, opts, p, max(2, min(args.steps, 3)), 1, scale_default=0.1)
+            if rank == 0:
+                strong_block = {k: sb[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "config", "counts", "ownership", "multi_gpu")}
+                strong_block["how_to_read"] = "value(N) / value(1) of THIS block is the strong-scaling speedup (same total work at every N); python bench.py --scaling strong --scale 0.1 gives value(1)"
+        except Exception as e:                                        # the headline line stands whatever happens here
+            strong_block = {"error": repr(e)}
         MG.barrier()
         dist.destroy_process_group()                                  # all ranks together, before rank 0 goes on alone
     else:
+        strong_block = None
         tot_used, tot_sig, tot_ops = st["n_rec_used"], st["n_sig"], st["n_ops"]
     if rank != 0:
         return
@@ -572,6 +601,7 @@ def main():
         "kernels": kernels, "synth_seconds": t_gen,
     }
     if use_dist:
+        out["strong_scaling"] = strong_block
         res = last.get("res")
         out["multi_gpu"] = {"foreign_segments_planted_rank0": n_foreign_planted, "signatures_per_rank": list(res.sig_counts) if res is not None else None,
                             "clusters_gathered": res.n if res is not None else None, "stream_end_rank0": res.chain_end if res is not None else None,

@@ -1,10 +1,15 @@
 """Contig-sharded multi-GPU COLLECT+CLUSTER: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on the GPU box,
 "gloo" in the CPU tests).  SURVEY.md section 8(e), DESIGN.md section 6.
 
-Ownership.  Every contig belongs to one rank; ranks own CONSECUTIVE ranges of the NAME-SORTED contig list (assign_contigs).
-A signature belongs to the owner of the contig its partition key starts with (`contig`, for DUP_INT the destination `contig2`:
-src/svim/SVSignature.py get_key, SVIM_clustering.py:17-29) - so every partition is local to one rank, and the global sorted
-order of all partitions of a type is rank-major.
+Ownership (round 6: coordinate WINDOWS).  The partition keys of a type are sorted by (contig name, key coordinate) - `end`, for INS `start`, for BND `pos1`
+(src/svim/SVSignature.py get_key) - and ranks own CONSECUTIVE ranges of that order: world - 1 cuts (contig, coordinate), class Windows.  A cut inside a
+contig is only legal where no partition can straddle it: form_partitions (src/svim/SVIM_clustering.py:17-29) cuts where the gap to the previous element
+exceeds partition_max_distance, so a cut goes into a CORRIDOR - a stretch wider than partition_max_distance that no signature's [start, end] of any type
+touches.  assign_windows proposes cuts that balance a weight (contig length, or a density histogram); Windows.refine moves every proposal into the nearest
+corridor from the signatures the ranks actually collected (one small all-gather of merged intervals per step) or, where there is none, to the contig's
+edge.  Whole-contig ownership (assign_contigs, rounds 2-5) is the special case of cuts at contig starts.  DUP_INT rows - keyed (destination contig,
+SOURCE contig, destination start), i.e. not in coordinate order inside a contig - stay whole-contig: they belong to the rank that owns the destination
+contig's first base.  Every partition is local to one rank, and the global sorted order of all partitions of a type is rank-major.
 
 What crosses the fabric per step
   1. foreign signatures: a read's record is collected by the rank that owns the record's contig, but a split read can emit a
@@ -54,6 +59,197 @@ def owner_contig(typ, contig, contig2):
         return np.where(is_dup_int, contig2, contig)
     import torch
     return torch.where(is_dup_int, contig2, contig)
+
+
+def _is_np(x):
+    return isinstance(x, np.ndarray)
+
+
+class Windows(object):
+    """Coordinate-window ownership: rank r owns the keys (contig name rank, coordinate) in [cut[r-1], cut[r]) (cut[-1] = -inf, cut[world-1] = +inf).
+
+    crank        int32 [n_global]: rank of every contig NAME in str order (batch.contig_ranks)
+    cut_contig   int   [world - 1]: global contig id of every cut
+    cut_pos      int64 [world - 1]: coordinate of the cut on that contig; -1 = the contig's first base belongs to the rank above the cut (whole contigs)
+    A key is the pair packed into one int64: crank << 33 | (coordinate + 1) - coordinates are < 2^31."""
+
+    def __init__(self, world, crank, cut_contig, cut_pos, refined=False):
+        self.world = int(world)
+        self.crank = np.asarray(crank, dtype=np.int64)
+        self.cut_contig = np.asarray(cut_contig, dtype=np.int64).reshape(-1)
+        self.cut_pos = np.asarray(cut_pos, dtype=np.int64).reshape(-1)
+        assert self.cut_contig.size == self.world - 1 and self.cut_pos.size == self.world - 1
+        self.refined = refined or bool((self.cut_pos < 0).all())
+        keys = self._cut_keys()
+        assert (np.diff(keys) >= 0).all(), "cuts must be monotone in (contig name, coordinate) order"
+
+    def _cut_keys(self):
+        return (self.crank[self.cut_contig] << 33) | (self.cut_pos + 1).clip(0)
+
+    @classmethod
+    def from_contig_owner(cls, owner, crank):
+        """whole-contig ownership (assign_contigs) as cuts: the cut below rank r sits at the start of the first contig (name order) of a rank >= r"""
+        owner = np.asarray(owner)
+        crank = np.asarray(crank, dtype=np.int64)
+        world = int(owner.max()) + 1 if owner.size else 1
+        return cls._whole(owner, crank, world)
+
+    @classmethod
+    def _whole(cls, owner, crank, world):
+        order = np.argsort(crank, kind="stable")                    # contig ids in name order
+        cut_contig, cut_pos = [], []
+        for r in range(1, world):
+            later = [int(i) for i in order if owner[i] >= r]
+            if later:
+                cut_contig.append(later[0]); cut_pos.append(-1)
+            else:                                                    # nothing at or above r: the cut sits behind everything
+                cut_contig.append(int(order[-1])); cut_pos.append((1 << 32) - 2)
+        return cls(world, crank, cut_contig, cut_pos, refined=True)
+
+    def with_world(self, world):
+        return self
+
+    # ---- who owns a key ---------------------------------------------------------------------------------------------------
+    def _rank_of_keys(self, key):
+        cuts = self._cut_keys()
+        if _is_np(key):
+            return np.searchsorted(cuts, key, side="right").astype(np.int64)
+        import torch
+        return torch.searchsorted(torch.as_tensor(cuts, device=key.device), key, right=True)
+
+    def owner_of_positions(self, contig_gid, pos):
+        """owner of (global contig id, coordinate) pairs: numpy arrays or torch tensors"""
+        if _is_np(contig_gid):
+            key = (self.crank[np.asarray(contig_gid, dtype=np.int64)] << 33) | (np.asarray(pos, dtype=np.int64) + 1).clip(0)
+            return self._rank_of_keys(key)
+        import torch
+        cr = torch.as_tensor(self.crank, device=contig_gid.device)
+        key = (cr[contig_gid.long()] << 33) | (pos.long() + 1).clamp_min(0)
+        return self._rank_of_keys(key)
+
+    def owner_of_signatures(self, typ, contig_gid, contig2_gid, start, end, pos2):
+        """owner of signature rows (columns of a signature table with GLOBAL contig ids): the coordinate is the one the partition key uses
+        (csrc/cluster.hip k_make_keys); DUP_INT rows go with the first base of their destination contig"""
+        if _is_np(typ):
+            t = typ.astype(np.int64)
+            is_di = t == _abi.SVX_DUP_INT
+            c = np.where(is_di, contig2_gid, contig_gid).astype(np.int64)
+            coord = np.where(t == _abi.SVX_INS, start, np.where(t == _abi.SVX_BND, start, end)).astype(np.int64)
+            coord = np.where(is_di, -1, coord)
+            return self.owner_of_positions(c.clip(0), coord)
+        import torch
+        t = typ.long()
+        is_di = t == _abi.SVX_DUP_INT
+        c = torch.where(is_di, contig2_gid.long(), contig_gid.long()).clamp_min(0)
+        coord = torch.where((t == _abi.SVX_INS) | (t == _abi.SVX_BND), start.long(), end.long())
+        coord = torch.where(is_di, torch.full_like(coord, -1), coord)
+        return self.owner_of_positions(c, coord)
+
+    # ---- moving proposed cuts into corridors ------------------------------------------------------------------------------
+    def needs_refine(self):
+        return not self.refined
+
+    def local_intervals(self, typ, contig_gid, start, end, radius):
+        """per cut that lies inside a contig: this rank's signature intervals [start, end] (DUP_INT excluded) within `radius` of the proposal, MERGED -
+        a flat int64 array [cut index, lo, hi]* (numpy).  What the ranks all-gather before refine_from."""
+        out = []
+        typ = np.asarray(typ); contig_gid = np.asarray(contig_gid); start = np.asarray(start, dtype=np.int64); end = np.asarray(end, dtype=np.int64)
+        for k in range(self.world - 1):
+            x = int(self.cut_pos[k])
+            if x < 0:
+                continue
+            sel = (contig_gid == self.cut_contig[k]) & (typ != _abi.SVX_DUP_INT) & (np.maximum(start, end) >= x - radius) & (np.minimum(start, end) <= x + radius)
+            if not sel.any():
+                continue
+            lo, hi = np.minimum(start[sel], end[sel]), np.maximum(start[sel], end[sel])
+            o = np.argsort(lo, kind="stable")
+            lo, hi = lo[o], hi[o]
+            run_hi = np.maximum.accumulate(hi)
+            new = np.concatenate([[True], lo[1:] > run_hi[:-1]])                      # an interval that starts beyond everything before it opens a merged one
+            first = np.nonzero(new)[0]
+            last = np.concatenate([first[1:] - 1, [lo.size - 1]])
+            for a, b in zip(lo[first], run_hi[last]):
+                out += [k, int(a), int(b)]
+        return np.asarray(out, dtype=np.int64)
+
+    def refine_from(self, gathered, max_distance, radius, lengths=None):
+        """gathered: concatenation of every rank's local_intervals.  Every proposal inside a contig moves to the START of the nearest corridor's right edge -
+        the first covered coordinate behind a gap wider than max_distance that lies within `radius` - or, where the neighbourhood holds no such gap, down to the
+        contig's first base (the contig then belongs whole to the rank above the cut; monotonicity is restored by pushing later cuts of the same contig along).
+        Deterministic: all ranks compute the same cuts from the same gathered bytes."""
+        g = np.asarray(gathered, dtype=np.int64).reshape(-1, 3)
+        new_pos = self.cut_pos.copy()
+        for k in range(self.world - 1):
+            x = int(self.cut_pos[k])
+            if x < 0:
+                continue
+            iv = g[g[:, 0] == k][:, 1:]
+            if iv.shape[0] == 0:
+                continue                                                              # nobody has a signature near the proposal: it is in a corridor already
+            o = np.argsort(iv[:, 0], kind="stable")
+            lo, hi = iv[o, 0], np.maximum.accumulate(iv[o, 1])
+            # gaps between consecutive merged stretches (and the open ends of the neighbourhood, as far as it was looked at)
+            edges_l = np.concatenate([[x - radius - max_distance - 2], hi])             # left edge of every gap = right end of what lies before it
+            edges_r = np.concatenate([lo, [x + radius + max_distance + 2]])             # right edge = first covered coordinate behind it
+            ok = (edges_r - edges_l) > max_distance
+            # a gap is usable if its left neighbour really ends before its right neighbour starts (overlapping stretches produce negative gaps)
+            if not ok.any():
+                new_pos[k] = -1
+                continue
+            cand = np.nonzero(ok)[0]
+            # the cut goes to the right edge R of the gap (left rows end <= L < R <= right rows' start); distance of the proposal to the gap
+            dist = np.where(edges_r[cand] < x, x - edges_r[cand], np.where(edges_l[cand] > x, edges_l[cand] - x, 0))
+            j = cand[int(np.argmin(dist))]
+            r_edge = int(edges_r[j])
+            if j == edges_r.size - 1:                                                 # the open gap behind the last stretch: anywhere behind it, keep the proposal if it is inside
+                r_edge = max(x, int(edges_l[j]) + 1)
+            elif j == 0 and x <= int(edges_r[0]):
+                r_edge = min(max(x, 0), int(edges_r[0]))                              # the open gap in front of the first stretch
+            new_pos[k] = max(r_edge, 0)
+        # monotone again inside every contig (a cut that fell back to -1 takes the cuts before it on the same contig with it)
+        for k in range(self.world - 2, -1, -1):
+            if k + 1 < self.world - 1 and self.cut_contig[k] == self.cut_contig[k + 1] and new_pos[k] > new_pos[k + 1]:
+                new_pos[k] = new_pos[k + 1]
+        return Windows(self.world, self.crank, self.cut_contig, new_pos, refined=True)
+
+
+def assign_windows(names, lengths, world, weights=None, bin_size=1 << 20):
+    """Proposed cuts that give every rank about the same WEIGHT of the (name-sorted contig, coordinate) order: weights None -> bases (contig lengths); else
+    weights[i] = array of per-bin weights of contig i (bins of bin_size bases: records or signatures per bin from a first look at the input).  Returns Windows
+    (not refined: cluster_step moves the cuts into corridors)."""
+    n = len(names)
+    order = sorted(range(n), key=lambda i: names[i])
+    crank = np.zeros(n, dtype=np.int64)
+    crank[order] = np.arange(n)
+    if weights is None:
+        weights = [np.full(max(1, -(-int(lengths[i]) // bin_size)), float(bin_size)) for i in range(n)]
+        for i in range(n):
+            if lengths[i] % bin_size:
+                weights[i][-1] = float(lengths[i] % bin_size)
+    cum = []                       # (contig, bin, cumulative weight before the bin, weight)
+    total = 0.0
+    for i in order:
+        w = np.asarray(weights[i], dtype=np.float64)
+        cum.append((i, total + np.concatenate([[0.0], np.cumsum(w)[:-1]]), w))
+        total += float(w.sum())
+    cut_contig, cut_pos = [], []
+    for r in range(1, world):
+        target = total * r / world
+        done = False
+        for i, before, w in cum:
+            end = before[-1] + w[-1] if w.size else before[0] if before.size else 0.0
+            if w.size and target < end:
+                b = int(np.searchsorted(before, target, side="right") - 1)
+                frac = (target - before[b]) / w[b] if w[b] > 0 else 0.0
+                bin_len = min(bin_size, int(lengths[i]) - b * bin_size)                  # (the last bin of a contig is shorter)
+                pos = b * bin_size + int(frac * bin_len)
+                pos = min(pos, int(lengths[i]) - 1)
+                cut_contig.append(i); cut_pos.append(pos if pos > 0 else -1)
+                done = True
+                break
+        if not done:
+            cut_contig.append(order[-1]); cut_pos.append((1 << 32) - 2)
+    return Windows(world, crank, cut_contig, cut_pos, refined=False)
 
 
 class TorchAllGather(object):
@@ -536,7 +732,8 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
 
     contig_gid          int64 [n_local_contig]: global id of every LOCAL contig id the COLLECT tables use
     contig_rank_global  int32 [n_global]: rank of every contig NAME in str order
-    owner_of_contig     int32 [n_global]: assign_contigs
+    owner_of_contig     int32 [n_global] (assign_contigs: whole contigs) or a Windows object (assign_windows: coordinate windows; cuts that are not refined
+                        yet are moved into corridors of the collected signatures at the start of the step - one small all-gather)
     key_base            added to the slot half of the emission keys: 2 x (records in file order before this rank's first record)
     read_base           added to the read ids (unique across ranks when reads never span ranks: the synthetic bench layout)
     key_runs            (local_slot_starts, global_slot_starts): a rank that collected several file regions (contig runs of a BAM) numbered
@@ -551,7 +748,7 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
     import torch.distributed as dist
     dev = adapter.device
     gid = torch.as_tensor(np.asarray(contig_gid), dtype=torch.int64, device=dev)
-    owner_t = torch.as_tensor(np.asarray(owner_of_contig), dtype=torch.int64, device=dev)
+    windows = owner_of_contig if isinstance(owner_of_contig, Windows) else Windows._whole(np.asarray(owner_of_contig), np.asarray(contig_rank_global, dtype=np.int64), world)
     if key_runs is not None:
         kr_local = torch.as_tensor(np.asarray(key_runs[0], dtype=np.int64), device=dev)
         kr_delta = torch.as_tensor(np.asarray(key_runs[1], dtype=np.int64) - np.asarray(key_runs[0], dtype=np.int64), device=dev)
@@ -566,8 +763,8 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
 
     adapter.begin_step(rank, world)
     try:
-        return _cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, owner_of_contig, gather_signatures, names_of, ids_of,
-                             read_base, gid, owner_t, global_keys, dev)
+        return _cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, windows, gather_signatures, names_of, ids_of,
+                             read_base, gid, global_keys, dev)
     except BaseException:
         adapter.abort()               # (only does something between the last agreement of the ranks and svx_cluster: see SvxAdapter.abort)
         raise
@@ -575,19 +772,47 @@ def cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, o
         adapter.end_step()
 
 
-def _cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, owner_of_contig, gather_signatures, names_of, ids_of, read_base, gid,
-                  owner_t, global_keys, dev):
+def _owner_rows(windows, cols, gid=None):
+    """owner rank of every row of a signature table (torch columns; gid: local -> global contig ids, None when the columns are global already)"""
+    import torch
+    c1 = cols["contig"].long()
+    c2 = cols["contig2"].long()
+    if gid is not None:
+        c1 = gid[c1]
+        c2 = torch.where(c2 >= 0, gid[c2.clamp_min(0)], c2)
+    return windows.owner_of_signatures(cols["type"], c1, c2, cols["start"], cols["end"], cols["pos2"])
+
+
+def _cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, windows, gather_signatures, names_of, ids_of, read_base, gid,
+                  global_keys, dev):
     import torch
     import torch.distributed as dist
-    # ---- 1. foreign signatures --------------------------------------------------------------------------------------------
     cols = seq_off = seq = None
-    n_foreign = n_own = 0
+    n_own = 0
+    # ---- 0. proposed cuts -> corridors ------------------------------------------------------------------------------------
+    # (only with assign_windows: every rank publishes the merged [start, end] stretches of its signatures around every cut that lies inside a contig, and all
+    # ranks move the cuts into the same corridors - Windows.refine_from)
+    if world > 1 and windows.needs_refine():
+        max_d = int(params.partition_max_distance)
+        radius = max(64 * max_d, 100000)
+        mine = np.zeros(0, dtype=np.int64)
+        with _Phase() as ph:
+            n_own, _ = adapter.collect_counts()
+            if n_own:
+                cols, seq_off, seq = adapter.fetch_signatures(with_seq=False)
+                mine = windows.local_intervals(cols["type"].cpu().numpy(), gid[cols["contig"].long()].cpu().numpy(), cols["start"].cpu().numpy(),
+                                               cols["end"].cpu().numpy(), radius)
+        cnt0 = _agree(ph, [mine.size], dev, world)
+        got = _all_gather_rows(torch.as_tensor(mine, device=dev), [c[0] for c in cnt0])
+        windows = windows.refine_from(torch.cat(got).cpu().numpy() if got else mine, max_d, radius)
+    # ---- 1. foreign signatures --------------------------------------------------------------------------------------------
+    n_foreign = 0
     with _Phase() as ph:
         n_own, _ = adapter.collect_counts()
         if world > 1 and n_own:
-            cols, seq_off, seq = adapter.fetch_signatures(with_seq=False)        # the columns decide who owns a row; sequences only travel with foreign rows
-            own_c = owner_contig(cols["type"], gid[cols["contig"].long()], torch.where(cols["contig2"] >= 0, gid[cols["contig2"].clamp_min(0).long()], cols["contig2"].long()))
-            foreign = owner_t[own_c] != rank
+            if cols is None:
+                cols, seq_off, seq = adapter.fetch_signatures(with_seq=False)    # the columns decide who owns a row; sequences only travel with foreign rows
+            foreign = _owner_rows(windows, cols, gid) != rank
             n_foreign = int(foreign.sum().item())
     counts = _agree(ph, [n_foreign], dev, world)
     any_foreign = any(c[0] for c in counts)
@@ -654,8 +879,7 @@ def _cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, 
             for r in range(world):
                 if r == rank or rows[r] == 0:
                     continue
-                oc = owner_contig(g_cols["type"][r], g_cols["contig"][r].long(), g_cols["contig2"][r].long())
-                take = owner_t[oc] == rank
+                take = _owner_rows(windows, {k: g_cols[k][r] for k in ("type", "contig", "contig2", "start", "end", "pos2")}) == rank
                 if not bool(take.any()):
                     continue
                 tidx = torch.nonzero(take).flatten()
@@ -740,4 +964,6 @@ def _cluster_step(adapter, params, rank, world, contig_gid, contig_rank_global, 
     torch.cumsum(out_sizes, 0, out=member_off[1:])
     nm = int(g_mem.numel())
     src_idx = torch.repeat_interleave(src_off[order] - member_off[:-1], out_sizes) + torch.arange(nm, dtype=torch.int64, device=dev)
-    return StepResult(out_cols, member_off, g_mem[src_idx], g_sig, sig_counts, chain_end)
+    res = StepResult(out_cols, member_off, g_mem[src_idx], g_sig, sig_counts, chain_end)
+    res.windows = windows                                                  # the (refined) ownership every rank used
+    return res

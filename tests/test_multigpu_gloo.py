@@ -48,7 +48,7 @@ def _compare(res, full, full_keys):
     return "ok"
 
 
-def _worker_signatures(rank, world, port, ret):
+def _worker_signatures(rank, world, port, ret, windows=False):
     """Signature-level: g5's 'stress31' list (3 contigs, 35 partitions beyond 100 members, all six types) dealt out to 4 ranks by
     contig owner; BND / DUP_INT rows are 'collected' by the owner of their OTHER contig, i.e. arrive as foreign rows.  With 3 contigs
     one rank owns nothing and only relays the stream positions."""
@@ -68,10 +68,16 @@ def _worker_signatures(rank, world, port, ret):
         p = _abi.Params.from_options(o)
         crank = batch.contig_ranks(contigs.names)
         full = orc.cluster(p, crank, table=tab)
-        owner = multigpu.assign_contigs(contigs.names, g5["lengths"], world)
         n = tab.n
         other = np.where(tab.type[:n] == _abi.SVX_DUP_INT, tab.contig[:n], np.where(tab.contig2[:n] >= 0, tab.contig2[:n], tab.contig[:n]))
-        collector = owner[other]                                           # who "collected" the row
+        if windows:
+            # coordinate windows (round 6): cuts proposed by length, i.e. INSIDE the contigs; a row is "collected" by the rank whose proposed window holds its START
+            # (as a read near a cut would be) - once the cuts have moved into corridors some of those rows are foreign
+            owner = multigpu.assign_windows(contigs.names, g5["lengths"], world)
+            collector = owner.owner_of_positions(np.where(tab.contig2[:n] >= 0, other, tab.contig[:n]).astype(np.int64), tab.start[:n].astype(np.int64))
+        else:
+            owner = multigpu.assign_contigs(contigs.names, g5["lengths"], world)
+            collector = owner[other]                                           # who "collected" the row
         idx = np.nonzero(collector == rank)[0]
         local = _abi.SigTable(len(idx), int((tab.seq_off[idx + 1] - tab.seq_off[idx]).sum()))
         for k in _abi.SIG_DTYPES:
@@ -82,7 +88,10 @@ def _worker_signatures(rank, world, port, ret):
         for i, l in zip(idx, ln):
             local.seq[pos:pos + l] = tab.seq[tab.seq_off[i]:tab.seq_off[i] + l]
             pos += int(l)
-        n_foreign = int((owner[multigpu.owner_contig(local.type, local.contig, local.contig2)] != rank).sum()) if local.n else 0
+        if windows:
+            n_foreign = -1                                                     # (known once the cuts are refined: rank 0 reports it from the result)
+        else:
+            n_foreign = int((owner[multigpu.owner_contig(local.type, local.contig, local.contig2)] != rank).sum()) if local.n else 0
         ad = multigpu.HostAdapter(orc, local)
         multigpu.wire_reset()
         res = multigpu.cluster_step(ad, p, rank, world, np.arange(len(contigs.names)), crank, owner)
@@ -108,12 +117,24 @@ def _worker_signatures(rank, world, port, ret):
         else:
             ret[rank] = "ok" if lean_ok else "fabric accounting: %r vs %r" % (wire_lean, wire_full)
         ret["foreign%d" % rank] = n_foreign
-        ret["owned%d" % rank] = int((owner == rank).sum())
+        if windows:
+            if rank == 0:
+                W = res.windows                                                 # the refined cuts every rank used
+                own = W.owner_of_signatures(tab.type[:n], tab.contig[:n], tab.contig2[:n], tab.start[:n], tab.end[:n], tab.pos2[:n])
+                ret["rows_per_rank"] = [int((own == r).sum()) for r in range(world)]
+                ret["cuts"] = [(contigs.names[int(c)], int(x)) for c, x in zip(W.cut_contig, W.cut_pos)]
+                ret["foreign_total"] = int((own != collector).sum())
+                # no partition straddles a cut: single-process partitions of the whole list, owner of every member
+                sidx, pid = orc.form_partitions(tab, crank, int(p.partition_max_distance))
+                po = own[sidx]
+                ret["straddling_partitions"] = int(sum(1 for a, b in zip(*_runs(pid)) if po[a:b].min() != po[a:b].max()))
+        else:
+            ret["owned%d" % rank] = int((owner == rank).sum())
     finally:
         dist.destroy_process_group()
 
 
-def _worker_records(rank, world, port, ret):
+def _worker_records(rank, world, port, ret, windows=False):
     """Record-level: g2's split-read fuzz set (3 contigs, BNDs and DUP_INTs across contigs, secondary / low-mapq records) collected
     per rank from the records of its contigs with GLOBAL emission slots; read ids are rank-local and foreign rows travel with their
     read names."""
@@ -125,7 +146,17 @@ def _worker_records(rank, world, port, ret):
         g = H.load("g2_collect.json.gz")
         case = [c for c in g["cases"] if c["name"] == "fuzzA" and c["mode"] == "coordinate" and c.get("sam")][0]
         o = H.options(case["options"])
-        bam = records.AlignmentFile(text=case["sam"])
+        if windows:
+            # coordinate windows: a sparser, longer input than the fuzz set (planted sites every ~8 kb + split reads: corridors are plentiful, as on a genome)
+            from svim_amd import synth
+            refs, lens = ["chr1", "chr2", "chr10"], [420000, 160000, 150000]
+            ref = synth.make_reference(11, list(zip(refs, lens)))
+            rr = synth.planted_reads(12, 900, ref, refs, lens, n_sites=90, types=("DEL", "INS", "INV")) + synth.fuzz_split_reads(13, 80, refs, lens)
+            bam = records.AlignmentFile(text=synth.sam_text(refs, lens, synth.coordinate_sort(rr)))
+            o.genome = ref
+            o.max_sv_size = 3000           # (a 90 kb deletion between two fuzz segments spans a fifth of chr1: no cut may fall inside a signature, and the balance this test asserts would be its doing)
+        else:
+            bam = records.AlignmentFile(text=case["sam"])
         recs = list(bam.fetch(until_eof=True))
         refs, lens = list(bam.references), list(bam.lengths)
         p = _abi.Params.from_options(o)
@@ -135,9 +166,17 @@ def _worker_records(rank, world, port, ret):
         hb_all = batch.build_batch(bam, o, mode="coordinate")
         sig_all, _ = orc.collect(hb_all, p)
         full = orc.cluster(p, hb_all.contig_rank, table=sig_all)
-        owner = multigpu.assign_contigs(refs, lens, world)
-        # with 3 contigs and 4 ranks one rank stays empty; unplaced records (tid -1) go to the last rank like the file tail
-        mine = [i for i, a in enumerate(recs) if (owner[a.reference_id] if a.reference_id >= 0 else world - 1) == rank]
+        if windows:
+            # proposed cuts balance the RECORDS (what a driver knows before COLLECT: the index of a BAM file, here a histogram of the record starts per 10 kb)
+            bins = 10000
+            dens = [np.bincount([a.reference_start // bins for a in recs if a.reference_id == k], minlength=-(-lens[k] // bins)).astype(np.float64) for k in range(len(refs))]
+            owner = multigpu.assign_windows(refs, lens, world, weights=dens, bin_size=bins)
+            rec_owner = owner.owner_of_positions(np.asarray([max(a.reference_id, 0) for a in recs], dtype=np.int64), np.asarray([a.reference_start for a in recs], dtype=np.int64))
+            mine = [i for i, a in enumerate(recs) if (rec_owner[i] if a.reference_id >= 0 else world - 1) == rank]
+        else:
+            owner = multigpu.assign_contigs(refs, lens, world)
+            # with 3 contigs and 4 ranks one rank stays empty; unplaced records (tid -1) go to the last rank like the file tail
+            mine = [i for i, a in enumerate(recs) if (owner[a.reference_id] if a.reference_id >= 0 else world - 1) == rank]
         hb = batch.build_batch(bam, o, mode="coordinate", records=[recs[i] for i in mine])
         gi = np.asarray(mine, dtype=np.int64)
         hb.arrays["order"] = (2 * gi).astype(np.uint32)                    # emission slots in FILE order, not in local order
@@ -159,7 +198,18 @@ def _worker_records(rank, world, port, ret):
             return out
         ad = multigpu.HostAdapter(orc, sig)
         res = multigpu.cluster_step(ad, p, rank, world, np.arange(len(refs)), hb_all.contig_rank, owner, names_of=names_of, ids_of=ids_of)
-        n_foreign = int((owner[multigpu.owner_contig(sig.type[:sig.n], sig.contig[:sig.n], sig.contig2[:sig.n])] != rank).sum()) if sig.n else 0
+        if windows:
+            n_foreign = -1
+            if rank == 0:
+                W, t, n = res.windows, sig_all, sig_all.n
+                own = W.owner_of_signatures(t.type[:n], t.contig[:n], t.contig2[:n], t.start[:n], t.end[:n], t.pos2[:n])
+                ret["rows_per_rank"] = [int((own == r).sum()) for r in range(world)]
+                ret["cuts"] = [(refs[int(c)], int(x)) for c, x in zip(W.cut_contig, W.cut_pos)]
+                sidx, pid = orc.form_partitions(t, hb_all.contig_rank, int(p.partition_max_distance))
+                po = own[sidx]
+                ret["straddling_partitions"] = int(sum(1 for a, b in zip(*_runs(pid)) if po[a:b].min() != po[a:b].max()))
+        else:
+            n_foreign = int((owner[multigpu.owner_contig(sig.type[:sig.n], sig.contig[:sig.n], sig.contig2[:sig.n])] != rank).sum()) if sig.n else 0
         ret["foreign%d" % rank] = n_foreign
         if rank == 0:
             verdict = _compare(res, full, sig_all.key[:sig_all.n].astype(np.int64))
@@ -181,14 +231,49 @@ def _worker_records(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def _run(worker, world=4):
+def _runs(pid):
+    """(starts, ends) of the runs of equal values in pid"""
+    cut = np.nonzero(np.diff(pid))[0] + 1
+    return np.concatenate([[0], cut]), np.concatenate([cut, [len(pid)]])
+
+
+def _run(worker, world=4, extra=()):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, port, ret) + tuple(extra), nprocs=world, join=True)
     return dict(ret)
+
+
+def test_eight_ranks_coordinate_windows_split_contigs():
+    """Round 6: ranks own coordinate WINDOWS - cuts inside contigs, moved into corridors wider than partition_max_distance that no
+    signature touches.  g5's stress31 list (3 contigs of 180 / 60 / 60 kb, 12.5 k signatures, 35 partitions beyond 100 members) on 8 ranks: every contig is
+    split, the merged result equals the single-process oracle's (clusters, members, order, the random.sample streams relayed from rank to rank)."""
+    ret = _run(_worker_signatures, world=8, extra=(True,))
+    assert [ret[r] for r in range(8)] == ["ok"] * 8, ret
+    cuts = ret["cuts"]
+    assert sum(1 for c, x in cuts if x > 0) >= 5, cuts                      # cuts inside contigs ...
+    assert len({c for c, x in cuts if x > 0}) == 3, cuts                    # ... of all three of them
+    assert ret["straddling_partitions"] == 0
+    rows = ret["rows_per_rank"]
+    assert sum(1 for x in rows if x > 0) >= 2 and sum(rows) == 12525, rows  # (12.5 k rows in 300 kb: hardly a corridor - cuts that found none fell to an edge, the balance is what the list allows)
+    assert ret["foreign_total"] > 0                                         # rows collected on one side of a moved cut and owned on the other
+    ends = [ret["chain%d" % r] for r in range(8)]
+    assert ends == sorted(ends) and ends[-1] > 1500
+
+
+def test_eight_ranks_coordinate_windows_from_records_balanced():
+    """The same on records: 980 reads on 3 contigs (420 / 160 / 150 kb) dealt out by the proposed windows of their start coordinate, every rank collects its
+    own records (oracle), reads that span a cut leave rows on both sides (foreign rows with read names).  Merged == single process, and the rows every rank ends
+    up clustering are balanced (the proposal balances the records per window from a histogram of their start coordinates)."""
+    ret = _run(_worker_records, world=8, extra=(True,))
+    assert [ret[r] for r in range(8)] == ["ok"] * 8, ret
+    cuts, rows = ret["cuts"], ret["rows_per_rank"]
+    assert sum(1 for c, x in cuts if x > 0) >= 6, cuts
+    assert ret["straddling_partitions"] == 0
+    assert min(rows) > 0 and max(rows) / (sum(rows) / 8.0) < 1.4, rows
 
 
 def test_four_ranks_signature_lists_with_foreign_rows_and_stream_relay():
