@@ -13,9 +13,9 @@
 //                               upper bound, class choice.  A pair is described by 32 bytes (PairDesc).
 //   3. rounds.  Per round TWO fused launches: k_edit_bands (every band class, may fail) on a low-priority stream and
 //      k_edit_fulls (every full-matrix class, never fails) on a high-priority one; a block looks up its class segment.
-//        d_edit_band<Q>  (lane/pair, classes 0..1: 32/64 diagonals)      Ukkonen band in band-relative coordinates, the window
+//        d_edit_band<Q>  (lane/pair, class 0: 32 diagonals; the pilot)   Ukkonen band in band-relative coordinates, the window
 //                               slides one row per column
-//        d_edit_stair    (lane/pair, classes 2..8: 128..512 diagonals)   window stands still for 32 columns, then drops a word - or two, and
+//        d_edit_stair    (lane/pair, classes 1..8: 96..512 diagonals)    window stands still for 32 columns, then drops a word - or two, and
 //                               takes none in: it narrows by Ukkonen's cut-off against the largest distance the attempt certifies
 //        d_edit_lane<Q>  (lane/pair)  whole pattern (<= 512 rows) in one lane, full matrix
 //        d_edit_wide<G,Q>(G = 2..16 lanes/pair, Q = 10 / 12 / 14 / 16 words = 320..512 rows each)   full matrix up to 8192 rows, DPP hand-off between lanes
@@ -182,12 +182,15 @@ struct PairDesc {
 
 // Band classes 0..NBAND-1: window of 32 * BAND_WORDS diagonals (0..2 sliding window, 3.. staircase window), tried in rounds.
 #define NBAND 9
-__host__ __device__ __forceinline__ int band_words(int b) { return b <= 2 ? (1 << b) : 2 * b; }     // 1 2 4 | 6 8 10 12 14 16
+__host__ __device__ __forceinline__ int band_words(int b) { return b == 0 ? 1 : (b == 1 ? 3 : (b == 2 ? 4 : 2 * b)); }     // 1 | 3 4 6 8 10 12 14 16
 // classes below FIRST_STAIR_CLS: sliding window (d_edit_band), from it on: staircase window (d_edit_stair).  The 4-word class was a sliding window
 // until round 4: four v_alignbit per word and column make its word-column 54 issue cycles against 38, and it cannot narrow - as a staircase class
 // (46 diagonals of slack instead of 14, so the pairs with 82 < needed window <= 114 start with 6 words) the step went from 21.55 to 20.4 ms
 // (profiles/r04_edit_stair4_ab.txt)
-#define FIRST_STAIR_CLS 2
+// Round 6: the 2-word sliding class too - a v_alignbit costs ~8.8 cycles inside the update (myers_column.hpp), four of them per word and column make the sliding
+// word-column ~2.3 x the staircase one; as a 3-word staircase window (96 rows: the same 50 diagonals of need, 46 of slack) the class pays 3 x 34 instead of 2 x ~90
+// cycles per column.  Only the 1-word class (32 diagonals, patterns of a few dozen rows) still slides.
+#define FIRST_STAIR_CLS 1
 #define CLS_FULL 9            /* systolic full matrix, one wave per pair */
 #define CLS_LANE0 10          /* 10..14: whole pattern (<= 32<<k rows) in one lane, full matrix, never fails */
 #define CLS_WIDE0 15          /* 15..18: full matrix, 2/4/8/16 lanes per pair with 512 rows each (m <= 1024 / 2048 / 4096 / 8192) */
@@ -218,8 +221,8 @@ __device__ __forceinline__ int full_class_for(int m);
 __device__ __forceinline__ int lane_class_for(int m) { return m <= 32 ? 0 : m <= 64 ? 1 : m <= 128 ? 2 : m <= 256 ? 3 : 4; }
 
 __device__ __forceinline__ int band_class_for(int need_w) {      // smallest class whose window keeps the needed margin
-    // classes 0..1 (sliding window, d_edit_band): 14 diagonals are lost to the alignment of dmax to 7 (mod 8);
-    // classes 2.. (staircase window, d_edit_stair): the window stands still for 32 columns, which costs 32 more diagonals
+    // class 0 (sliding window, d_edit_band): 14 diagonals are lost to the alignment of dmax to 7 (mod 8);
+    // classes 1.. (staircase window, d_edit_stair): the window stands still for 32 columns, which costs 32 more diagonals
     for (int b = 0; b < NBAND; b++)
         if (need_w + (b < FIRST_STAIR_CLS ? 14 : 46) <= 32 * band_words(b)) return b;
     return CLS_FULL;
@@ -342,6 +345,8 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     const int wave_lane = lane_id();
     const int sg = wave_lane / G, lane = wave_lane % G;                   // sub-group of the wave / lane inside it
     const unsigned long long sg_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (sg * G);
+    // (Round 6, measured and dropped: an XCD-aware block order - every XCD takes a contiguous eighth of the work list, so that the pairs of a partition, which share
+    // their packed haplotypes, meet in ONE L2 instead of all eight - 1.70 ms either way, the step 0.15 ms slower: profiles/r06_edit_class1_stair_prep_xcd_ab.txt)
     const long long w = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + sg;
     if (w >= n_work) return;
     HapView A, B;
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(256) void k_edit_pilot(long long n_work, long long 
     if (h[threadIdx.x]) atomicAdd(hist + threadIdx.x, h[threadIdx.x]);
 }
 
-// ---- 3a. banded lane-per-pair kernel, staircase window (classes 2..8) ------------------------------------------------------
+// ---- 3a. banded lane-per-pair kernel, staircase window (classes 1..8) ------------------------------------------------------
 // Sliding the window one row per column costs four v_alignbit per state word and column - and v_alignbit is a half-rate
 // instruction on gfx950 (4 cycles per wave64 against 2 for v_xor / v_bitop3; tools/micro/valu_ops.hip), 44 % of the sliding
 // kernel's cycles.  Here the window of W = 32*Q rows stands still for a block of 32 columns and then drops by one whole word:
@@ -903,7 +908,11 @@ __device__ __forceinline__ void d_edit_stair(const int Q0, const bool narrow, lo
         const uint32_t mlow = nvirt >= 32 ? 0xffffffffu : (nvirt <= 0 ? 0u : ((1u << nvirt) - 1u));
         mv[q] = mlow; pv[q] = ~mlow;
         uint32_t acc[P];
-        planes32<P>(pat_word(w0 + 4 * q), pat_word(w0 + 4 * q + 1), pat_word(w0 + 4 * q + 2), pat_word(w0 + 4 * q + 3), acc);
+#pragma unroll
+        for (int b = 0; b < P; b++) acc[b] = 0u;
+        // (the value of a word beyond Q0 is never looked at - it only has to be SOME value in its register: a wave-uniform branch skips its four loads and ~60
+        // instructions; the 3-word class spends 12 % less on its set-up)
+        if (q < Q0) planes32<P>(pat_word(w0 + 4 * q), pat_word(w0 + 4 * q + 1), pat_word(w0 + 4 * q + 2), pat_word(w0 + 4 * q + 3), acc);
 #pragma unroll
         for (int b = 0; b < P; b++) pl[b][q] = acc[b];
     }
@@ -1296,7 +1305,6 @@ __global__ __launch_bounds__(256) void k_edit_bands(FusedTab tab, const uint32_t
     const uint32_t* l = list + tab.lo[s];
     switch (tab.kind[s]) {
         case 0: d_edit_band<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
-        case 1: d_edit_band<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
                                                 default: d_edit_stair<P, QM>(band_words(tab.kind[s]), tab.narrow != 0, blk, tab.cn[s], l, scratch, desc, slot_of, ed, fail_cnt, fail_lists, fail_cap, wc); break;
     }
 }

@@ -34,5 +34,24 @@ timeline)
   python tools/rocpd_timeline.py $db > $out/${tag}_step_timeline.txt
   grep "k_edit\|k_cigar\|k_cluster" $out/${tag}_step_timeline.txt
   ;;
+strong)
+  # the strong-scaling line on one rank and on 2 / 4 ranks that share this box's one GPU (gloo transport), and the driver's default (weak) line on 2 ranks with its strong_scaling block
+  python bench.py --scaling strong --steps 5 --warmup 2 > $out/${tag}_bench_strong_1rank.json 2> $out/${tag}_bench_strong_1rank.err; echo "strong 1 rank rc=$?"
+  for n in ${RANKS:-2 4}; do
+    SVX_BENCH_BACKEND=gloo SVX_BENCH_ONE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2957$n bench.py --gpus $n --scaling strong --steps 5 --warmup 2 > $out/${tag}_bench_strong_${n}ranks_one_gpu.json 2> $out/${tag}_bench_strong_${n}ranks_one_gpu.err; echo "strong $n ranks rc=$?"
+  done
+  SVX_BENCH_BACKEND=gloo SVX_BENCH_ONE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29588 bench.py --gpus 2 --steps 3 --warmup 1 --reads 200000 --contig-len 50000000 > $out/${tag}_bench_default_2ranks_one_gpu.json 2> $out/${tag}_bench_default_2ranks_one_gpu.err; echo "default line, 2 ranks rc=$?"
+  python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/%s_bench_strong_*.json" % "'$tag'".strip("'"))) + sorted(glob.glob("gpurun_out/%s_bench_default_2ranks*.json" % "'$tag'".strip("'"))):
+    try:
+        j = json.loads([l for l in open(f) if l.startswith("{")][-1])
+    except Exception as e:
+        print(f, "no line:", e); continue
+    sb = j.get("strong_scaling")
+    print(f.split("/")[-1], "value %.3g reads/s, %.2f ms/step, clusters %s" % (j["value"], j["ms_per_step"], j["counts"].get("clusters_gathered", j["counts"].get("clusters"))), (j.get("ownership") or {}).get("max_over_mean_signatures"), (j.get("ownership") or {}).get("cuts"))
+    if sb: print("   strong_scaling block:", {k: sb.get(k) for k in ("value", "ms_per_step", "n_gpus", "error")}, (sb.get("ownership") or {}).get("max_over_mean_signatures"))
+PY
+  ;;
 *) echo "unknown step $step"; exit 2;;
 esac
