@@ -405,8 +405,10 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     // mismatch from the first symbols on).  A tight bound does two things: the pair starts in the narrowest band that certifies it, and the
     // staircase window narrows against the bound instead of against the window's own capacity (d_edit_stair).
     const uint32_t* wp = packed + P.word_off; const uint32_t* wt = packed + T.word_off;
-    // (Round 6, measured and dropped: four chunks per lane and trip with all eight loads issued up front - 1.72 -> 1.94-2.04 ms, with conditional as with clamped
-    // unconditional loads: the kernel is bound by the bytes it pulls through L2, not by the latency of one chain, and the lanes of a last trip then load for nothing.)
+    // (Round 6, measured and dropped - none of them moves the kernel's 1.7 ms: four chunks per lane and trip with all eight loads issued up front (1.94-2.04 ms: the
+    // lanes of a last trip load for nothing); 32 symbols per lane and trip - five words of either string, four funnel shifts, ~45 instructions per 32 symbols instead
+    // of ~25 per 8 (1.76 ms); an XCD-aware block order (1.70 ms).  The bound pass is not what the kernel waits for; the chain of dependent loads in front of it -
+    // work item -> signature columns -> contig offsets -> record headers -> first words - is the suspect, not followed up.)
     auto bound_at = [&](const int a, const int b) -> int {                  // every lane of the sub-group returns the same value; m + n = useless
         const int L = (pd.m - a) < (pd.n - b) ? (pd.m - a) : (pd.n - b);
         if (L <= 0) return pd.m + pd.n;
