@@ -7,20 +7,49 @@
 #include "hostcopy.hpp"
 #include <atomic>
 #include "inflate_core.hpp"
+#include "inflate_lanes.hpp"
 #include <mutex>
 #include <thread>
 #include <cstdlib>
 
 struct BgzfJob { unsigned long long in_off; unsigned long long out_off; uint32_t in_bytes; uint32_t out_bytes; };
 
-// one wavefront = one workgroup = one BGZF block (the waves share nothing, so they are scheduled one by one; ~8 KB of LDS each: 20 per CU)
-__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* comp, const BgzfJob* jobs, long long n_jobs, uint8_t* out, int* status) {
+// one wavefront = one workgroup = one BGZF block (the waves share nothing, so they are scheduled one by one; ~8 KB of LDS each: 20 per CU).
+// only_if != nullptr: just the blocks the lane-per-block decoder below has given up (stored blocks, code tables beyond its LDS budget, damaged streams)
+__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* comp, const BgzfJob* jobs, long long n_jobs, uint8_t* out, int* status, const uint8_t* only_if) {
     __shared__ InfScratch scratch;
     const long long j = (long long)blockIdx.x;
     if (j >= n_jobs) return;
+    if (only_if) { if (!only_if[j]) return; if (lane_id() == 0) atomicAdd(&status[3], 1); }
     const BgzfJob job = jobs[j];
     const int rc = inflate_raw(comp + job.in_off, job.in_bytes, out + job.out_off, job.out_bytes, scratch);
     if (lane_id() == 0 && rc != (int)job.out_bytes) { status[0] = 1; status[1] = (int)j; status[2] = rc; }
+}
+
+// one LANE = one BGZF block (inflate_lanes.hpp): 64 blocks per wavefront, the lane's code tables in its own INFL_STRIDE bytes of LDS (two workgroups per CU).
+// A lane that reaches a block header parks until INFL_HDR_BATCH lanes of the wave wait at one (or nobody is decoding): the serial header code then runs for all of
+// them at once.  redo[j] = 1: the block is left to k_bgzf_inflate.  The trip bound ends a wave whatever its input is (a sound block of 64 KiB takes ~45 k trips)
+#define INFL_TRIP_BOUND 600000u
+__global__ __launch_bounds__(64) void k_bgzf_inflate_lanes(const uint8_t* comp, const BgzfJob* jobs, long long n_jobs, uint8_t* out, uint8_t* redo) {
+    __shared__ uint32_t lds[64 * INFL_STRIDE / 4];
+    const int lane = (int)threadIdx.x;
+    const long long j = (long long)blockIdx.x * 64 + lane;
+    InflLane L;
+    BgzfJob job{0ull, 0ull, 0u, 0u};
+    if (j < n_jobs) job = jobs[j];
+    infl_init(L, comp + job.in_off, job.in_bytes, out + job.out_off, job.out_bytes, reinterpret_cast<uint8_t*>(lds) + lane * INFL_STRIDE);
+    if (j >= n_jobs) L.state = INFL_ST_DONE;
+    uint32_t trips = 0;
+    for (;;) {
+        const uint64_t hm = __ballot(L.state == INFL_ST_HEADER);
+        if (hm && (__popcll(hm) >= INFL_HDR_BATCH || __ballot(L.state == INFL_ST_DECODE) == 0ull)) {
+            if (L.state == INFL_ST_HEADER) infl_header(L);
+        }
+        infl_step(L);
+        if (__ballot(infl_running(L)) == 0ull) break;
+        if (++trips > INFL_TRIP_BOUND) { if (L.state != INFL_ST_DONE) L.state = INFL_ST_FAIL; break; }
+    }
+    if (j < n_jobs) redo[j] = L.state == INFL_ST_DONE ? (uint8_t)0 : (uint8_t)1;
 }
 
 #ifdef INF_PROFILE
@@ -37,7 +66,7 @@ extern "C" int svx_inflate_profile(unsigned long long* out16, int reset) {
 struct InflaterSlot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[2];
-    DevBuf comp, out, jobs, status;
+    DevBuf comp, out, jobs, status, redo;
     void* staging = nullptr; size_t staging_cap = 0;      // pinned host memory the caller packs this slot's payloads into
     int* host_status = nullptr;                           // 4 ints of the inflater's pinned block
     std::vector<BgzfJob> host_jobs;
@@ -79,7 +108,7 @@ extern "C" void svx_inflater_destroy(svx_inflater* f) {
     (void)hipSetDevice(f->device);
     for (auto& sl : f->slot) {
         (void)hipStreamSynchronize(sl.stream);
-        sl.comp.release(); sl.out.release(); sl.jobs.release(); sl.status.release();
+        sl.comp.release(); sl.out.release(); sl.jobs.release(); sl.status.release(); sl.redo.release();
         if (sl.staging) (void)hipHostFree(sl.staging);
         if (sl.out_stage) (void)hipHostFree(sl.out_stage);
         for (auto& e : sl.ev) (void)hipEventDestroy(e);
@@ -126,7 +155,13 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
     // the compressed payloads: read by the kernel straight from the pinned staging buffer over PCIe (each byte is read once, 256 B at a time per wave and far
     // ahead of its use - and the copy engine's H2D would not overlap the kernel of the sub-batch before: it starts when that kernel ends), or copied to HBM first
     // (SVX_INFLATE_ZEROCOPY=0)
-    static const bool zero_copy = []() { const char* e = getenv("SVX_INFLATE_ZEROCOPY"); return !(e && e[0] == '0'); }();
+    // SVX_INFLATE_LANES=1: lane per block (round 6), the blocks it gives up redone by the wave-per-block decoder.  Measured and NOT the default: a lane's code tables
+    // take 1276 bytes of LDS, so a CU holds two such waves - one wave on a SIMD issues a dependent instruction every ~4 cycles, a trip of ~365 instructions takes 1500
+    // cycles before any memory wait and 2900 with the copy engine's far loads: 29 GB/s on the file with base qualities against 31-35 (profiles/r06_inflate_lanes_probe.txt)
+    const bool lanes = []() { const char* e = getenv("SVX_INFLATE_LANES"); return e && e[0] == '1'; }();      // (read per call: the GPU tests run both decoders in one process)
+    // the lane decoder reads 8 bytes per lane and load: its input has to be in HBM (a lane's loads over PCIe would fetch a line for every 8 bytes)
+    static const bool zero_copy_env = []() { const char* e = getenv("SVX_INFLATE_ZEROCOPY"); return !(e && e[0] == '0'); }();
+    const bool zero_copy = zero_copy_env && !lanes;
     const uint8_t* comp_dev = nullptr;
     if (zero_copy) { void* dp = nullptr; if (hipHostGetDevicePointer(&dp, sl.staging, 0) == hipSuccess) comp_dev = (const uint8_t*)dp; else (void)hipGetLastError(); }
     if (!comp_dev) SVXCHK(sl.comp.reserve((size_t)staged_bytes + 64));
@@ -148,7 +183,12 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
     HIPCHK(hipMemsetAsync(sl.status.p, 0, 16, st));
     HIPCHK(hipEventRecord(sl.ev[0], st));
     static const unsigned lds_pad = []() { const char* e = getenv("SVX_INFLATE_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();      // experiment: fewer resident waves per CU
-    k_bgzf_inflate<<<(unsigned)n, 64, lds_pad, st>>>(comp_dev, sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.status.as<int>());
+    if (lanes) {
+        SVXCHK(sl.redo.reserve((size_t)n + 64));
+        k_bgzf_inflate_lanes<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(comp_dev, sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.redo.as<uint8_t>());
+        HIPCHK(hipGetLastError());
+    }
+    k_bgzf_inflate<<<(unsigned)n, 64, lds_pad, st>>>(comp_dev, sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.status.as<int>(), lanes ? sl.redo.as<uint8_t>() : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(sl.ev[1], st));
     HIPCHK(hipMemcpyAsync(sl.host_status, sl.status.p, 16, hipMemcpyDeviceToHost, st));

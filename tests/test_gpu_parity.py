@@ -893,9 +893,12 @@ def test_bench_under_torchrun_multi_gpu_code_path_single_rank():
     assert d["counts"]["signatures"] > 10000 and d["counts"]["clusters"] > 1000
 
 
-def test_bgzf_inflate_on_the_gpu_equals_zlib(tmp_path):
-    """svx_inflater (one wavefront per BGZF block, svim_amd/csrc/inflate_core.hpp) returns zlib's bytes: the blocks of a BAM the writer made at its
-    usual level, the same records at level 9 and level 1, stored blocks (level 0), an empty block (the EOF marker) and incompressible data."""
+@pytest.mark.parametrize("decoder", ["wave_per_block", "lane_per_block"])
+def test_bgzf_inflate_on_the_gpu_equals_zlib(tmp_path, monkeypatch, decoder):
+    """svx_inflater returns zlib's bytes: the blocks of a BAM the writer made at its usual level, the same records at level 9 and level 1, stored blocks
+    (level 0), an empty block (the EOF marker) and incompressible data - with the default decoder (one wavefront per BGZF block, svim_amd/csrc/inflate_core.hpp)
+    and with the opt-in one (SVX_INFLATE_LANES=1: one LANE per block, inflate_lanes.hpp; the blocks a lane gives up - stored ones, code tables beyond its
+    share of LDS - are redone by the first, so the result must be the same bytes; a damaged block must still be reported)."""
     import gzip
     import zlib
     from svim_amd._lib import Inflater, bgzf_blocks
@@ -918,13 +921,23 @@ def test_bgzf_inflate_on_the_gpu_equals_zlib(tmp_path):
             blocks.append((co.compress(raw) + co.flush(), len(raw)))
         co = zlib.compressobj(level, zlib.DEFLATED, -15)
         blocks.append((co.compress(noise) + co.flush(), len(noise)))
+    if decoder == "lane_per_block":
+        monkeypatch.setenv("SVX_INFLATE_LANES", "1")
+    else:
+        monkeypatch.delenv("SVX_INFLATE_LANES", raising=False)
     f = Inflater(0)
     try:
         got = f.inflate(blocks)
+        expect = b"".join(zlib.decompress(b, -15) if s else b"" for b, s in blocks)
+        assert len(got) == len(expect) and got.tobytes() == expect
+        # a block with a damaged payload among sound ones: refused by either decoder (the lane gives it up, the wave-per-block decoder reports it)
+        bad = blocks[3][0][:len(blocks[3][0]) // 2]                                # cut in the middle: it cannot produce its ISIZE
+        with pytest.raises(Exception):
+            f.inflate(blocks[:3] + [(bytes(bad), blocks[3][1])] + blocks[4:8])
+        got = f.inflate(blocks[:8])                                              # and the inflater still works afterwards
+        assert got.tobytes() == b"".join(zlib.decompress(b, -15) if s else b"" for b, s in blocks[:8])
     finally:
         f.close()
-    expect = b"".join(zlib.decompress(b, -15) if s else b"" for b, s in blocks)
-    assert len(got) == len(expect) and got.tobytes() == expect
 
 
 @pytest.mark.parametrize("sub", ["16", "40", None])

@@ -53,5 +53,13 @@ for f in sorted(glob.glob("gpurun_out/%s_bench_strong_*.json" % "'$tag'".strip("
     if sb: print("   strong_scaling block:", {k: sb.get(k) for k in ("value", "ms_per_step", "n_gpus", "error")}, (sb.get("ownership") or {}).get("max_over_mean_signatures"))
 PY
   ;;
+inflate)
+  # the two BGZF inflaters on the sample files of tools/bgzf_inflate_rate.py: lane per block (default) against wave per block (SVX_INFLATE_LANES=0)
+  for m in 1 0; do SVX_INFLATE_LANES=$m timeout 900 python tools/bgzf_inflate_rate.py ${NREC:-60000} > $out/${tag}_bgzf_inflate_rate_lanes$m.txt 2>&1; echo "lanes=$m rc=$?"; grep "GPU\|identical\|Error\|error\|assert" $out/${tag}_bgzf_inflate_rate_lanes$m.txt; done
+  ;;
+readers)
+  timeout 1500 python -m pytest tests/ -x -q -m gpu -k "bam or reader or inflate or bgzf" --durations=5 > $out/${tag}_pytest_readers.txt 2>&1
+  echo "readers: rc=$? $(tail -1 $out/${tag}_pytest_readers.txt)"
+  ;;
 *) echo "unknown step $step"; exit 2;;
 esac
