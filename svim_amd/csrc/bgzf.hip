@@ -26,18 +26,19 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* comp, const 
     if (lane_id() == 0 && rc != (int)job.out_bytes) { status[0] = 1; status[1] = (int)j; status[2] = rc; }
 }
 
-// one LANE = one BGZF block (inflate_lanes.hpp): 64 blocks per wavefront, the lane's code tables in its own INFL_STRIDE bytes of LDS (two workgroups per CU).
+// one LANE = one BGZF block (inflate_lanes.hpp): 64 blocks per wavefront, the lane's code tables in its own INFL_STRIDE bytes of LDS (636: four workgroups per CU, one per SIMD).
 // A lane that reaches a block header parks until INFL_HDR_BATCH lanes of the wave wait at one (or nobody is decoding): the serial header code then runs for all of
 // them at once.  redo[j] = 1: the block is left to k_bgzf_inflate.  The trip bound ends a wave whatever its input is (a sound block of 64 KiB takes ~45 k trips)
 #define INFL_TRIP_BOUND 600000u
-__global__ __launch_bounds__(64) void k_bgzf_inflate_lanes(const uint8_t* comp, const BgzfJob* jobs, long long n_jobs, uint8_t* out, uint8_t* redo) {
+__global__ __launch_bounds__(64) void k_bgzf_inflate_lanes(const uint8_t* comp, const BgzfJob* jobs, long long n_jobs, uint8_t* out, uint8_t* redo, uint32_t* lens_scratch) {
     __shared__ uint32_t lds[64 * INFL_STRIDE / 4];
     const int lane = (int)threadIdx.x;
     const long long j = (long long)blockIdx.x * 64 + lane;
     InflLane L;
     BgzfJob job{0ull, 0ull, 0u, 0u};
     if (j < n_jobs) job = jobs[j];
-    infl_init(L, comp + job.in_off, job.in_bytes, out + job.out_off, job.out_bytes, reinterpret_cast<uint8_t*>(lds) + lane * INFL_STRIDE);
+    infl_init(L, comp + job.in_off, job.in_bytes, out + job.out_off, job.out_bytes, reinterpret_cast<uint8_t*>(lds) + lane * INFL_STRIDE,
+              lens_scratch + (size_t)blockIdx.x * (64 * INFL_LENS_WORDS) + lane, 64u);       // word k of the wave's lanes side by side
     if (j >= n_jobs) L.state = INFL_ST_DONE;
     uint32_t trips = 0;
     for (;;) {
@@ -66,7 +67,7 @@ extern "C" int svx_inflate_profile(unsigned long long* out16, int reset) {
 struct InflaterSlot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[2];
-    DevBuf comp, out, jobs, status, redo;
+    DevBuf comp, out, jobs, status, redo, lens;
     void* staging = nullptr; size_t staging_cap = 0;      // pinned host memory the caller packs this slot's payloads into
     int* host_status = nullptr;                           // 4 ints of the inflater's pinned block
     std::vector<BgzfJob> host_jobs;
@@ -108,7 +109,7 @@ extern "C" void svx_inflater_destroy(svx_inflater* f) {
     (void)hipSetDevice(f->device);
     for (auto& sl : f->slot) {
         (void)hipStreamSynchronize(sl.stream);
-        sl.comp.release(); sl.out.release(); sl.jobs.release(); sl.status.release(); sl.redo.release();
+        sl.comp.release(); sl.out.release(); sl.jobs.release(); sl.status.release(); sl.redo.release(); sl.lens.release();
         if (sl.staging) (void)hipHostFree(sl.staging);
         if (sl.out_stage) (void)hipHostFree(sl.out_stage);
         for (auto& e : sl.ev) (void)hipEventDestroy(e);
@@ -185,7 +186,8 @@ extern "C" int svx_inflater_enqueue(svx_inflater* f, int slot, int64_t n, const 
     static const unsigned lds_pad = []() { const char* e = getenv("SVX_INFLATE_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();      // experiment: fewer resident waves per CU
     if (lanes) {
         SVXCHK(sl.redo.reserve((size_t)n + 64));
-        k_bgzf_inflate_lanes<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(comp_dev, sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.redo.as<uint8_t>());
+        SVXCHK(sl.lens.reserve((size_t)((n + 63) / 64) * 64 * INFL_LENS_WORDS * 4));
+        k_bgzf_inflate_lanes<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(comp_dev, sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.redo.as<uint8_t>(), sl.lens.as<uint32_t>());
         HIPCHK(hipGetLastError());
     }
     k_bgzf_inflate<<<(unsigned)n, 64, lds_pad, st>>>(comp_dev, sl.jobs.as<BgzfJob>(), (long long)n, out_dev, sl.status.as<int>(), lanes ? sl.redo.as<uint8_t>() : nullptr);

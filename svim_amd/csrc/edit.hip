@@ -1734,6 +1734,37 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             if (nc <= cls) { need[cls] += nd; int r = band_words(cls) * 4 / band_words(nc) - 4; if (r > 7) r = 7; ratio_hist[r] += u; }
             else failed[cls] += u;
         }
+        // The full matrices of round 0 (pairs whose length gap exceeds every band): how many of their word-columns (32 rows x 1 column) lie outside the diagonals
+        // [-x, (n - m) + x] a tile decomposition could skip?  x from the upper bound the pair came with (what such a kernel would know beforehand) and from the
+        // distance found in the end (perfect foresight).  A word of rows [32 w, 32 w + 31] is needed in the columns 32 w - x .. 32 w + 31 + (n - m) + x
+        for (int grp = 0; grp < 2; grp++) {                                          // 0: whole pattern in one lane (<= 512 rows), 1: the multi-lane forms
+            double all = 0, by_ub = 0, by_d = 0; long long pairs = 0;
+            for (long long w = 0; w < n_work; w++) {
+                const PairDesc& pd = first_desc[(size_t)w];
+                if (pd.cls == -1) continue;
+                const int cls = pd.cls & 0xff;
+                if (cls < NBAND || (cls >= (int)CLS_LANE0 && cls < (int)CLS_WIDE0) != (grp == 0)) continue;
+                const int d = ed[(size_t)(slot_of ? slot[(size_t)w] : w)], m = pd.m, n = pd.n, gap = n - m;
+                if (gap < 0) continue;
+                pairs++;
+                for (int which = 0; which < 2; which++) {
+                    const int bound = which == 0 ? (pd.ub < m + n ? pd.ub : m + n) : d;
+                    const int x = bound > gap ? (bound - gap + 1) / 2 : 0;
+                    double cols = 0;
+                    for (int r0 = 0; r0 < m; r0 += 32) {
+                        int lo = r0 - x, hi = r0 + 31 + gap + x;
+                        if (lo < 0) lo = 0;
+                        if (hi > n - 1) hi = n - 1;
+                        cols += hi >= lo ? hi - lo + 1 : 0;
+                    }
+                    (which == 0 ? by_ub : by_d) += cols;
+                }
+                all += (double)n * ((m + 31) / 32);
+            }
+            fprintf(stderr, "{\"edit_full_matrix_corners\": {\"form\": \"%s\", \"pairs\": %lld, \"word_cols\": %.4g, \"inside_band_of_upper_bound\": %.4g, \"inside_band_of_final_distance\": %.4g, "
+                            "\"skippable_fraction_known_beforehand\": %.4f, \"skippable_fraction_perfect_foresight\": %.4f}}\n",
+                    grp == 0 ? "one lane per pair" : "multi-lane", pairs, all, by_ub, by_d, all > 0 ? 1.0 - by_ub / all : 0.0, all > 0 ? 1.0 - by_d / all : 0.0);
+        }
         for (int b = 0; b < NBAND; b++) if (cnt_c[b])
             fprintf(stderr, "{\"edit_band_fit\": {\"first_cls\": %d, \"words\": %d, \"pairs\": %lld, \"word_cols_first_band\": %.4g, \"of_which_failed\": %.4g, \"word_cols_narrowest_sufficient\": %.4g}}\n",
                     b, band_words(b), cnt_c[b], used[b], failed[b], need[b]);

@@ -17,7 +17,7 @@ struct BounceSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; 
 
 namespace {
 const size_t SMALL_CAP = (size_t)64 << 10, BIG_CAP = (size_t)8 << 20;
-const size_t MAX_BIG = 8, MAX_SMALL = 256;               // 64 MiB + 16 MiB of page-locked memory per device at most
+const size_t MAX_BIG = 16, MAX_SMALL = 256;              // 128 MiB + 16 MiB of page-locked memory per device at most
 struct Pool { std::mutex m; std::condition_variable freed; std::vector<BounceSlot*> small, big; };
 // one pool per device of the node (sized once from hipGetDeviceCount: no fixed limit on the number of GPUs)
 Pool* pool_of(int dev) {
@@ -108,9 +108,11 @@ int HostCopy::h2d(void* dev_dst, const void* host_src, size_t bytes) {
     const int dev = device_of(st_);
     if (bytes >= ((size_t)16 << 20)) {
         // a large array (the CIGAR words / packed bases of a host batch): one thread's memcpy into the bounce buffers (5-6 GB/s) would be the bottleneck of the
-        // upload, so four threads take the 8 MiB pieces in turn - each piece has a slot of its own, the device copies queue on the caller's stream
+        // upload, so several threads take the 8 MiB pieces in turn - each piece has a slot of its own, the device copies queue on the caller's stream
         const size_t pieces = (bytes + BIG_CAP - 1) / BIG_CAP;
-        const int T = pieces < 4 ? (int)pieces : 4;
+        // (round 6: up to eight threads and sixteen slots - with four, the memcpy side (4 x 5-6 GB/s) was what the 6 GB of CIGAR words of a configs[1] batch waited for)
+        static const int max_t = []() { const char* e = getenv("SVX_UPLOAD_THREADS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+        const int T = pieces < (size_t)max_t ? (int)pieces : max_t;
         std::vector<int> rc((size_t)T, SVX_OK); std::vector<std::string> msg((size_t)T);
         std::vector<std::thread> th;
         hipStream_t st = st_;

@@ -16,16 +16,16 @@
 #include <string.h>
 
 #ifndef INFL_LR
-#define INFL_LR 8              /* root bits of the literal/length table */
+#define INFL_LR 6              /* root bits of the literal/length table */
 #endif
 #ifndef INFL_LSUB
-#define INFL_LSUB 158          /* entries for its second-level tables */
+#define INFL_LSUB 132          /* entries for its second- and third-level tables */
 #endif
 #ifndef INFL_DR
-#define INFL_DR 6
+#define INFL_DR 5
 #endif
 #ifndef INFL_DSUB
-#define INFL_DSUB 48
+#define INFL_DSUB 56
 #endif
 #ifndef INFL_HDR_BATCH
 #define INFL_HDR_BATCH 8
@@ -36,12 +36,15 @@
 #define INFL_DT_N ((1 << INFL_DR) + INFL_DSUB)
 #define INFL_OFF_LT 0
 #define INFL_OFF_DT (2 * INFL_LT_N)
-#define INFL_OFF_LENS (INFL_OFF_DT + 2 * INFL_DT_N)      /* 320 code lengths, 4 bits each */
-#define INFL_OFF_CNT (INFL_OFF_LENS + 160)               /* u16 count[16], u16 next[16] */
+#define INFL_OFF_CNT (INFL_OFF_DT + 2 * INFL_DT_N)       /* u16 count[16], u16 next[16] */
 #define INFL_BYTES (INFL_OFF_CNT + 64)
-#define INFL_OFF_CL INFL_OFF_DT                          /* the 7-bit table of the code-length code lives where the distance table is built afterwards */
-static_assert(2 * INFL_DT_N >= 128, "the code-length table needs 128 bytes");
-static_assert(INFL_LSUB <= 256 && INFL_DSUB <= 256, "second-level offsets are 8 bits");
+// while a header is read the literal/length region (built last) holds the 320 code lengths, 4 bits each, and the 7-bit table of the code-length code; before the
+// literal/length table is built over them the lengths move to the lane's 160 bytes of GLOBAL scratch (read back 8 lengths per load, three sequential passes)
+#define INFL_OFF_LENS INFL_OFF_LT
+#define INFL_OFF_CL (INFL_OFF_LT + 160)
+#define INFL_LENS_WORDS 40                                 /* dwords of global scratch per lane */
+static_assert(2 * INFL_LT_N >= 288, "the header needs 288 bytes of the literal/length region");
+static_assert(15 - INFL_LR - 4 <= 7 && 15 - INFL_DR - 4 <= 7, "third-level index bits are a 3-bit field");
 static_assert((INFL_BYTES & 3) == 0, "scratch is a whole number of dwords");
 #define INFL_STRIDE (INFL_BYTES + (((INFL_BYTES >> 2) & 1) ? 0 : 4))   /* distance of two lanes' scratch in LDS: an odd number of dwords, so that the lanes of a wave
                                                                           that touch the same entry of their tables (the table builds) use 64 different banks */
@@ -53,10 +56,12 @@ static_assert((INFL_BYTES & 3) == 0, "scratch is a whole number of dwords");
 
 #ifdef INFL_HOST
 #define INFL_FN static inline
+#define INFL_MFN inline
 static inline uint32_t infl_bitrev(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (x & 1u); x >>= 1; } return r; }
 static inline uint32_t infl_alignbit(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u)); }
 #else
 #define INFL_FN __device__ __forceinline__
+#define INFL_MFN __device__ __forceinline__
 static __device__ __forceinline__ uint32_t infl_bitrev(uint32_t x) { return __builtin_bitreverse32(x); }
 static __device__ __forceinline__ uint32_t infl_alignbit(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
 #endif
@@ -85,6 +90,7 @@ struct InflLane {
     uint32_t c_rem, c_dst, c_dist, c_pend, c_data, c_pdst;
     uint32_t state, fin;
     uint8_t* S;                        // this lane's scratch (LDS)
+    uint32_t* G; uint32_t g_stride;    // this lane's INFL_LENS_WORDS dwords of global scratch: word k at G[k * g_stride]
 };
 
 INFL_FN uint32_t infl_peek(const InflLane& L, uint32_t b) {              // 32 bits from bit b (< 64) of w0:w1
@@ -110,7 +116,7 @@ INFL_FN void infl_seek(InflLane& L, uint32_t bit) {
 }
 INFL_FN uint32_t infl_bitpos(const InflLane& L) { return 8u * (L.in_at - 32u) + L.bo; }
 
-INFL_FN void infl_init(InflLane& L, const uint8_t* payload, uint32_t in_bytes, uint8_t* out, uint32_t cap, uint8_t* S) {
+INFL_FN void infl_init(InflLane& L, const uint8_t* payload, uint32_t in_bytes, uint8_t* out, uint32_t cap, uint8_t* S, uint32_t* G, uint32_t g_stride) {
     const uint32_t skip = (uint32_t)(reinterpret_cast<uintptr_t>(payload) & 7u);
     L.in0 = payload - skip;
     L.in_bits = 8u * (skip + in_bytes);
@@ -118,7 +124,7 @@ INFL_FN void infl_init(InflLane& L, const uint8_t* payload, uint32_t in_bytes, u
     L.out = out; L.pos = 0; L.cap = cap;
     L.c_rem = L.c_pend = 0; L.c_dst = L.c_dist = L.c_data = L.c_pdst = 0;
     L.state = INFL_ST_HEADER; L.fin = 0;
-    L.S = S;
+    L.S = S; L.G = G; L.g_stride = g_stride;
     infl_seek(L, 8u * skip);
 }
 
@@ -151,12 +157,23 @@ INFL_FN uint32_t infl_entry_dist(uint32_t sym, uint32_t len) { return ((sym < 30
 #ifndef INFL_L2
 #define INFL_L2 4
 #endif
-template <bool LIT>
-INFL_FN int infl_build(uint8_t* S, uint32_t first, uint32_t n, uint16_t* tab, const uint32_t R, const uint32_t sub_cap) {
+struct InflLensLds {                       // the lengths where the header left them
+    const uint8_t* S; uint32_t first;
+    INFL_MFN void rewind() {}
+    INFL_MFN uint32_t next(uint32_t i) { return infl_len_get(S, first + i); }
+};
+struct InflLensGlobal {                    // the lane's global copy: symbols 0, 1, 2 ... in order, one load per 8 of them
+    const uint32_t* G; uint32_t stride, w;
+    INFL_MFN void rewind() { w = 0; }
+    INFL_MFN uint32_t next(uint32_t i) { if ((i & 7u) == 0u) w = G[(i >> 3) * stride]; const uint32_t l = w & 15u; w >>= 4; return l; }
+};
+template <bool LIT, class Lens>
+INFL_FN int infl_build(uint8_t* S, Lens lens, uint32_t n, uint16_t* tab, const uint32_t R, const uint32_t sub_cap) {
     uint16_t* cnt = reinterpret_cast<uint16_t*>(S + INFL_OFF_CNT);
     uint16_t* nxt = cnt + 16;
     for (uint32_t l = 0; l < 16u; l++) cnt[l] = 0;
-    for (uint32_t i = 0; i < n; i++) cnt[infl_len_get(S, first + i)]++;
+    lens.rewind();
+    for (uint32_t i = 0; i < n; i++) cnt[lens.next(i)]++;
     cnt[0] = 0;
     int left = 1;
     uint32_t code = 0, longs = 0, deep = 0;
@@ -172,8 +189,9 @@ INFL_FN int infl_build(uint8_t* S, uint32_t first, uint32_t n, uint16_t* tab, co
     uint16_t* sub = tab + root_n;
     for (uint32_t k = 0; k < root_n; k++) tab[k] = 0;
     // pass 1: the short codes fill the root, a longer code leaves its length in its root slot
+    lens.rewind();
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t l = infl_len_get(S, first + i);
+        const uint32_t l = lens.next(i);
         if (!l) continue;
         const uint32_t c = nxt[l]++;
         const uint32_t rev = infl_bitrev(c) >> (32u - l);
@@ -199,8 +217,9 @@ INFL_FN int infl_build(uint8_t* S, uint32_t first, uint32_t n, uint16_t* tab, co
     // pass 2: the codes of up to R + INFL_L2 bits into the second level; a longer one leaves its length in its second-level slot
     code = 0;
     for (uint32_t l = 1; l < 16u; l++) { code = (code + cnt[l - 1u]) << 1; nxt[l] = (uint16_t)code; }
+    lens.rewind();
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t l = infl_len_get(S, first + i);
+        const uint32_t l = lens.next(i);
         if (!l) continue;
         const uint32_t c = nxt[l]++;
         if (l <= R) continue;
@@ -227,8 +246,9 @@ INFL_FN int infl_build(uint8_t* S, uint32_t first, uint32_t n, uint16_t* tab, co
         }
         code = 0;
         for (uint32_t l = 1; l < 16u; l++) { code = (code + cnt[l - 1u]) << 1; nxt[l] = (uint16_t)code; }
+        lens.rewind();
         for (uint32_t i = 0; i < n; i++) {
-            const uint32_t l = infl_len_get(S, first + i);
+            const uint32_t l = lens.next(i);
             if (!l) continue;
             const uint32_t c = nxt[l]++;
             if (l <= R + INFL_L2) continue;
@@ -330,8 +350,12 @@ INFL_FN void infl_header(InflLane& L) {
         }
         if (infl_len_get(S, 256u) == 0u) { INFL_FAIL(L, 6); return; }
     } else { INFL_FAIL(L, 7); return; }                           // stored blocks (and the reserved type): the other decoder
-    if (infl_build<false>(S, nlen, ndist, reinterpret_cast<uint16_t*>(S + INFL_OFF_DT), INFL_DR, INFL_DSUB) ||
-        infl_build<true>(S, 0u, nlen, reinterpret_cast<uint16_t*>(S + INFL_OFF_LT), INFL_LR, INFL_LSUB)) { INFL_FAIL(L, 8); return; }
+    if (infl_build<false>(S, InflLensLds{S, nlen}, ndist, reinterpret_cast<uint16_t*>(S + INFL_OFF_DT), INFL_DR, INFL_DSUB)) { INFL_FAIL(L, 8); return; }
+    {
+        const uint32_t* ls = reinterpret_cast<const uint32_t*>(S + INFL_OFF_LENS);
+        for (uint32_t k = 0; k < (nlen + 7u) / 8u; k++) L.G[k * L.g_stride] = ls[k];
+    }
+    if (infl_build<true>(S, InflLensGlobal{L.G, L.g_stride, 0u}, nlen, reinterpret_cast<uint16_t*>(S + INFL_OFF_LT), INFL_LR, INFL_LSUB)) { INFL_FAIL(L, 8); return; }
     if (hb.bit > L.in_bits) { INFL_FAIL(L, 9); return; }
     infl_seek(L, hb.bit);
     L.state = INFL_ST_DECODE;

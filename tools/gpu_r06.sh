@@ -61,5 +61,23 @@ readers)
   timeout 1500 python -m pytest tests/ -x -q -m gpu -k "bam or reader or inflate or bgzf" --durations=5 > $out/${tag}_pytest_readers.txt 2>&1
   echo "readers: rc=$? $(tail -1 $out/${tag}_pytest_readers.txt)"
   ;;
+e2e)
+  # the end_to_end block of bench.py alone (its child process), under the settings given:  E2E="name:ENV=V,ENV=V[:extra bench flags] ..."
+  for spec in ${E2E:-default:}; do
+    name=${spec%%:*}; rest=${spec#*:}; envs=${rest%%:*}; flags=""; [ "$rest" != "$envs" ] && flags=${rest#*:}
+    env $(echo $envs | tr ',' ' ') python bench.py --end-to-end-child --resident 6.5e7 $(echo $flags | tr ',' ' ') > $out/${tag}_e2e_$name.json 2> $out/${tag}_e2e_$name.err; echo "e2e $name rc=$?"
+    python - $out/${tag}_e2e_$name.json $name <<'PY'
+import json, sys
+try:
+    j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    b = j["bam_file_with_base_qualities"]
+    print("  %-12s warm %.3f M/s (%.3f s) cold %.3f M/s objects %.3f M/s | blocks gpu %d host %d kernel %.0f ms | no-qual %.2f M/s | host arrays %.2f M/s" % (sys.argv[2], b["reads_per_s"] / 1e6, b["wall_s"],
+          j["bam_file_first_pass_reads_per_s"] / 1e6, j["objects_materialised_reads_per_s"] / 1e6, b["inflate_blocks_gpu"], b["inflate_blocks_host_cores"], b["inflate_kernel_ms"],
+          j["bam_file_without_base_qualities"]["reads_per_s"] / 1e6, j.get("host_arrays_reads_per_s", 0) / 1e6))
+except Exception as e:
+    print("  no line:", e)
+PY
+  done
+  ;;
 *) echo "unknown step $step"; exit 2;;
 esac

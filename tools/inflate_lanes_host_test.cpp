@@ -28,8 +28,9 @@ static int run_lane(const uint8_t* comp, size_t clen, const std::vector<uint8_t>
     memcpy(payload, comp, clen);
     std::vector<uint8_t> out(cap + 16, 0xAA);
     std::vector<uint32_t> scratch(INFL_BYTES / 4 + 1, 0xDEADBEEF);
+    std::vector<uint32_t> gscratch(3 * INFL_LENS_WORDS + 1, 0xDEADBEEF);        // the lane's global scratch, at a stride of 3 words
     InflLane L;
-    infl_init(L, payload, (uint32_t)clen, out.data(), (uint32_t)cap, reinterpret_cast<uint8_t*>(scratch.data()));
+    infl_init(L, payload, (uint32_t)clen, out.data(), (uint32_t)cap, reinterpret_cast<uint8_t*>(scratch.data()), gscratch.data(), 3u);
     unsigned long long trips = 0;
     const unsigned long long bound = 4ull * cap + 4096ull;
     while (infl_running(L)) {
@@ -38,7 +39,7 @@ static int run_lane(const uint8_t* comp, size_t clen, const std::vector<uint8_t>
         if (++trips > bound) { fprintf(stderr, "trip bound exceeded\n"); return -1; }
     }
     g_trips += trips;
-    if (scratch[INFL_BYTES / 4] != 0xDEADBEEF) { fprintf(stderr, "scratch overrun\n"); return -1; }
+    if (scratch[INFL_BYTES / 4] != 0xDEADBEEF || gscratch[3 * INFL_LENS_WORDS] != 0xDEADBEEF) { fprintf(stderr, "scratch overrun\n"); return -1; }
     for (size_t i = cap; i < out.size(); i++) if (out[i] != 0xAA) { fprintf(stderr, "wrote behind the output\n"); return -1; }
     if (L.state != INFL_ST_DONE) return 0;
     if (expect && (L.pos != expect->size() || memcmp(out.data(), expect->data(), expect->size()) != 0)) {

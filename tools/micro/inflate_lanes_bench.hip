@@ -14,14 +14,15 @@
 struct Job { unsigned long long in_off, out_off; uint32_t in_bytes, out_bytes; };
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
-__global__ __launch_bounds__(64) void k_lanes(const uint8_t* comp, const Job* jobs, long long n_jobs, uint8_t* out, uint8_t* redo, unsigned long long* prof) {
+__global__ __launch_bounds__(64) void k_lanes(const uint8_t* comp, const Job* jobs, long long n_jobs, uint8_t* out, uint8_t* redo, unsigned long long* prof, uint32_t* lens_scratch) {
     __shared__ uint32_t lds[64 * INFL_STRIDE / 4];
     const int lane = (int)threadIdx.x;
     const long long j = (long long)blockIdx.x * 64 + lane;
     InflLane L;
     Job job{0ull, 0ull, 0u, 0u};
     if (j < n_jobs) job = jobs[j];
-    infl_init(L, comp + job.in_off, job.in_bytes, out + job.out_off, job.out_bytes, reinterpret_cast<uint8_t*>(lds) + lane * INFL_STRIDE);
+    infl_init(L, comp + job.in_off, job.in_bytes, out + job.out_off, job.out_bytes, reinterpret_cast<uint8_t*>(lds) + lane * INFL_STRIDE,
+              lens_scratch + (size_t)blockIdx.x * (64 * INFL_LENS_WORDS) + lane, 64u);
     if (j >= n_jobs) L.state = INFL_ST_DONE;
     uint32_t trips = 0, hdr_events = 0;
     unsigned long long t_hdr = 0;
@@ -75,6 +76,7 @@ int main(int argc, char** argv) {
     const size_t nwaves = (n + 63) / 64;
     CHK(hipMalloc(&d_comp, copies * file.size() + 256)); CHK(hipMalloc(&d_out, out_bytes + 256)); CHK(hipMalloc(&d_redo, n + 64)); CHK(hipMalloc(&d_jobs, n * sizeof(Job)));
     CHK(hipMalloc(&d_prof, nwaves * 32));
+    uint32_t* d_lens; CHK(hipMalloc(&d_lens, nwaves * 64 * INFL_LENS_WORDS * 4));
     for (size_t c = 0; c < copies; c++) CHK(hipMemcpy(d_comp + c * file.size(), file.data(), file.size(), hipMemcpyHostToDevice));
     CHK(hipMemcpy(d_jobs, jobs.data(), n * sizeof(Job), hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
@@ -82,7 +84,7 @@ int main(int argc, char** argv) {
     for (int r = 0; r < reps; r++) {
         CHK(hipMemset(d_out, 0, out_bytes));
         CHK(hipEventRecord(e0));
-        k_lanes<<<(unsigned)nwaves, 64>>>(d_comp, d_jobs, (long long)n, d_out, d_redo, d_prof);
+        k_lanes<<<(unsigned)nwaves, 64>>>(d_comp, d_jobs, (long long)n, d_out, d_redo, d_prof, d_lens);
         CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
         float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
