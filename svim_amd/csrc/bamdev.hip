@@ -691,7 +691,12 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
     {
         const size_t sub_env = []() { const char* e = getenv("SVX_BAM_DEV_SUB"); return e && atoll(e) > 0 ? (size_t)atoll(e) : (size_t)0; }();       // (experiments)
         const int cpu_env = []() { const char* e = getenv("SVX_BAM_DEV_CPU"); return e ? atoi(e) : -1; }();
-        const size_t SUB = sub_env ? sub_env : 32768;                  // a launch of >= ~25 k blocks runs at the kernel's best rate (a 12 k one at 0.8 of it: its tail)
+        // the lane-per-block decoder (SVX_INFLATE_LANES=1) wants ~64 k blocks in flight whatever the launch sizes are (a launch takes ~80 ms from 1 to 64 k blocks):
+        // three sub-batches of a third of that, no ramp.  (Six rolling sub-batches of 11 k blocks measured worse - 0.82 against 0.96 M records/s on the 8 GB chunk,
+        // profiles/r06_end_to_end_lane_decoder.txt: more streams than hardware queues.)
+        const bool lanes = []() { const char* e = getenv("SVX_INFLATE_LANES"); return e && e[0] == '1'; }();
+        const int NS = 3;
+        const size_t SUB = sub_env ? sub_env : (lanes ? 21845 : 32768);   // wave-per-block: a launch of >= ~25 k blocks runs at the kernel's best rate (a 12 k one at 0.8 of it: its tail)
         int n_cpu = cpu_env >= 0 ? cpu_env : (d->n_threads > 8 ? d->n_threads - 6 : (d->n_threads > 3 ? d->n_threads - 3 : 0));      // (the staging copies want cores, too)
         if (nb_in < 4 * SUB / 3) n_cpu = 0;                            // a small chunk: one launch does it
         std::mutex m;
@@ -747,12 +752,12 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
         });
         int rc_gpu = SVX_OK;
         {
-            bool used[3] = {false, false, false};
+            bool used[8] = {false, false, false, false, false, false, false, false};
             int sl = 0;
             std::vector<uint64_t> in_off, o_at; std::vector<uint32_t> clen, isz;
             size_t a, b;
             // sub-batch sizes: small first ones (the GPU starts after 4 k blocks are staged), then SUB
-            size_t ramp = sub_env ? SUB : 4096;
+            size_t ramp = (sub_env || lanes) ? SUB : 4096;
             for (;;) {
                 const size_t want = ramp;
                 if (!(rc_gpu == SVX_OK && want > 0 && take(true, want, a, b))) break;
@@ -780,10 +785,10 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
                 }
                 if (rc_gpu != SVX_OK) break;
                 used[sl] = true; d->stats.gpu_blocks += (int64_t)mm;
-                sl = (sl + 1) % 3;
+                sl = (sl + 1) % NS;
             }
             d->stats.t_stage += dd_now() - t0; t0 = dd_now();
-            for (int k = 0; k < 3; k++) if (used[k]) { float ms = 0; const int rc = svx_inflater_wait(d->inf, k, &ms); d->stats.inflate_kernel_ms += ms; if (rc_gpu == SVX_OK) rc_gpu = rc; }
+            for (int k = 0; k < NS; k++) if (used[k]) { float ms = 0; const int rc = svx_inflater_wait(d->inf, k, &ms); d->stats.inflate_kernel_ms += ms; if (rc_gpu == SVX_OK) rc_gpu = rc; }
         }
         if (rc_gpu != SVX_OK) { std::lock_guard<std::mutex> g(m); lo = hi; }        // let the workers run out
         for (auto& t : workers) t.join();

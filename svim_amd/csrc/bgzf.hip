@@ -30,6 +30,10 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* comp, const 
 // A lane that reaches a block header parks until INFL_HDR_BATCH lanes of the wave wait at one (or nobody is decoding): the serial header code then runs for all of
 // them at once.  redo[j] = 1: the block is left to k_bgzf_inflate.  The trip bound ends a wave whatever its input is (a sound block of 64 KiB takes ~45 k trips)
 #define INFL_TRIP_BOUND 600000u
+#define HDR_T0
+#define HDR_T1
+#define INFL_TRIP_LIMIT INFL_TRIP_BOUND
+static_assert(6 % INFL_DEPTH == 0, "the loop body holds six trips");
 __global__ __launch_bounds__(64) void k_bgzf_inflate_lanes(const uint8_t* comp, const BgzfJob* jobs, long long n_jobs, uint8_t* out, uint8_t* redo, uint32_t* lens_scratch) {
     __shared__ uint32_t lds[64 * INFL_STRIDE / 4];
     const int lane = (int)threadIdx.x;
@@ -41,14 +45,20 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_lanes(const uint8_t* comp, 
               lens_scratch + (size_t)blockIdx.x * (64 * INFL_LENS_WORDS) + lane, 64u);       // word k of the wave's lanes side by side
     if (j >= n_jobs) L.state = INFL_ST_DONE;
     uint32_t trips = 0;
+    // the loop, unrolled INFL_DEPTH times (inflate_lanes.hpp: the chunk slot a trip stores from and loads into is a constant of the trip's position in the body)
+#define INFL_TRIP(PAR_) \
+        {                                                                                                   \
+            infl_step<(PAR_) % INFL_DEPTH>(L);                                                              \
+            if (__ballot(infl_running(L)) == 0ull) break;                                                   \
+            if (++trips > INFL_TRIP_LIMIT) { if (L.state != INFL_ST_DONE) L.state = INFL_ST_FAIL; break; }  \
+        }
     for (;;) {
+        // block headers: once per six trips (ONE copy of the header code in the kernel), for the lanes that wait at one - when enough of them do, or nobody decodes
         const uint64_t hm = __ballot(L.state == INFL_ST_HEADER);
         if (hm && (__popcll(hm) >= INFL_HDR_BATCH || __ballot(L.state == INFL_ST_DECODE) == 0ull)) {
-            if (L.state == INFL_ST_HEADER) infl_header(L);
+            HDR_T0 if (L.state == INFL_ST_HEADER) infl_header(L); HDR_T1
         }
-        infl_step(L);
-        if (__ballot(infl_running(L)) == 0ull) break;
-        if (++trips > INFL_TRIP_BOUND) { if (L.state != INFL_ST_DONE) L.state = INFL_ST_FAIL; break; }
+        INFL_TRIP(0) INFL_TRIP(1) INFL_TRIP(2) INFL_TRIP(3) INFL_TRIP(4) INFL_TRIP(5)
     }
     if (j < n_jobs) redo[j] = L.state == INFL_ST_DONE ? (uint8_t)0 : (uint8_t)1;
 }
@@ -63,7 +73,7 @@ extern "C" int svx_inflate_profile(unsigned long long* out16, int reset) {
 }
 #endif
 
-#define INF_SLOTS 3
+#define INF_SLOTS 8            /* sub-batches in flight (the readers use three with the wave-per-block decoder, six with the lane-per-block one) */
 struct InflaterSlot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[2];

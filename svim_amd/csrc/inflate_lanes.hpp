@@ -76,21 +76,27 @@ INFL_FN uint64_t infl_ld64(const uint8_t* p) { uint64_t v; memcpy(&v, __builtin_
 typedef uint32_t __attribute__((aligned(1), may_alias)) infl_u32u;
 INFL_FN uint32_t infl_ld32u(const uint8_t* p) { return *reinterpret_cast<const infl_u32u*>(p); }
 
+#ifndef INFL_DEPTH
+#define INFL_DEPTH 3           /* trips between the load of a match chunk and its store */
+#endif
 struct InflLane {
-    // input: 64-bit words of the stream from the 8-byte boundary in front of the payload; w0:w1 hold the bits being decoded, w2 and w3 are the words after them.
-    // A trip moves the window by one word at most (48 bits per token) and has ONE load, at its end, into w3 - which nothing reads before the next move
-    uint64_t w0, w1, w2, w3;
+    // input: 64-bit words of the stream from the 8-byte boundary in front of the payload; w0:w1 hold the bits being decoded, w2, w3 and pw are the words after
+    // them.  A trip moves the window by one word at most (48 bits per token); pw is loaded at the END of EVERY trip (the word behind w3, whether the window moved
+    // or not: an unconditional load is one the compiler can count - see infl_step), and nothing reads it before the window moves in a later trip
+    uint64_t w0, w1, w2, w3, pw;
     uint32_t bo;                       // bit offset of the next code in w0:w1; < 64 when a trip begins
-    uint32_t moved;                    // the window has moved in this trip: w3 is to be loaded
     const uint8_t* in0;                // aligned start
-    uint32_t in_at, in_lim, in_bits;   // byte offset of the word behind w3; loads stop at in_lim; last valid bit of the payload (from in0)
+    uint32_t in_at, in_lim, in_bits;   // byte offset of pw; loads stop at in_lim; last valid bit of the payload (from in0)
     // output
     uint8_t* out; uint32_t pos, cap;
-    // copy engine: c_rem bytes of the current match still to load for out[c_dst ...], c_pend bytes in c_data waiting for their store at out[c_pdst ...]
-    uint32_t c_rem, c_dst, c_dist, c_pend, c_data, c_pdst;
+    // copy engine (infl_step): the match being loaded (c_rem bytes still to request for out[c_dst ...]), the match decoded behind it (m_len != 0: waiting for the
+    // engine), and INFL_DEPTH chunk slots: s_data[k] was requested in a trip of parity k and is stored INFL_DEPTH trips later, s_n[k] = bytes | (distance < 4 ? distance << 4 : 0)
+    uint32_t c_rem, c_dst, c_dist;
+    uint32_t m_len, m_dst, m_dist;
+    uint32_t s_data[INFL_DEPTH], s_dst[INFL_DEPTH], s_n[INFL_DEPTH], n_pend, p_min;     // p_min: no pending chunk lies below this output position
     uint32_t state, fin;
     uint8_t* S;                        // this lane's scratch (LDS)
-    uint32_t* G; uint32_t g_stride;    // this lane's INFL_LENS_WORDS dwords of global scratch: word k at G[k * g_stride]
+    uint32_t* G; uint32_t g_stride;    // this lane's INFL_LENS_WORDS dwords of global scratch: word k at G[k * g_stride]; the last word is where idle stores / loads go
 };
 
 INFL_FN uint32_t infl_peek(const InflLane& L, uint32_t b) {              // 32 bits from bit b (< 64) of w0:w1
@@ -102,16 +108,13 @@ INFL_FN uint64_t infl_word_at(const InflLane& L, uint32_t at) {          // a lo
     return infl_ld64(L.in0 + (at < L.in_lim ? at : L.in_lim));
 }
 INFL_FN void infl_shift(InflLane& L) {
-    if (L.bo >= 64u) { L.w0 = L.w1; L.w1 = L.w2; L.w2 = L.w3; L.bo -= 64u; L.moved = 1u; }
-}
-INFL_FN void infl_refill(InflLane& L) {
-    if (L.moved) { L.w3 = infl_word_at(L, L.in_at); L.in_at += 8u; L.moved = 0u; }
+    if (L.bo >= 64u) { L.w0 = L.w1; L.w1 = L.w2; L.w2 = L.w3; L.w3 = L.pw; L.bo -= 64u; L.in_at += 8u; }
 }
 // position the window on absolute bit `bit` of the stream (from in0)
 INFL_FN void infl_seek(InflLane& L, uint32_t bit) {
     const uint32_t at = (bit >> 6) << 3;
-    L.bo = bit & 63u; L.moved = 0u;
-    L.w0 = infl_word_at(L, at); L.w1 = infl_word_at(L, at + 8u); L.w2 = infl_word_at(L, at + 16u); L.w3 = infl_word_at(L, at + 24u);
+    L.bo = bit & 63u;
+    L.w0 = infl_word_at(L, at); L.w1 = infl_word_at(L, at + 8u); L.w2 = infl_word_at(L, at + 16u); L.w3 = infl_word_at(L, at + 24u); L.pw = infl_word_at(L, at + 32u);
     L.in_at = at + 32u;
 }
 INFL_FN uint32_t infl_bitpos(const InflLane& L) { return 8u * (L.in_at - 32u) + L.bo; }
@@ -122,7 +125,8 @@ INFL_FN void infl_init(InflLane& L, const uint8_t* payload, uint32_t in_bytes, u
     L.in_bits = 8u * (skip + in_bytes);
     L.in_lim = (skip + in_bytes + 7u) & ~7u;                   // loads behind the payload all read this word: 8 bytes behind the last word of a payload must exist
     L.out = out; L.pos = 0; L.cap = cap;
-    L.c_rem = L.c_pend = 0; L.c_dst = L.c_dist = L.c_data = L.c_pdst = 0;
+    L.c_rem = L.c_dst = L.c_dist = 0; L.m_len = L.m_dst = L.m_dist = 0; L.n_pend = 0; L.p_min = 0;
+    for (int k = 0; k < INFL_DEPTH; k++) { L.s_data[k] = 0; L.s_dst[k] = 0; L.s_n[k] = 0; }
     L.state = INFL_ST_HEADER; L.fin = 0;
     L.S = S; L.G = G; L.g_stride = g_stride;
     infl_seek(L, 8u * skip);
@@ -362,27 +366,36 @@ INFL_FN void infl_header(InflLane& L) {
 }
 
 // ---- one trip -------------------------------------------------------------------------------------------------------------------------------------
-INFL_FN void infl_store(uint8_t* p, uint32_t v, uint32_t n) {
-    if (n == 4u) { memcpy(p, &v, 4); return; }
-    if (n & 2u) { const uint16_t h = (uint16_t)v; memcpy(p, &h, 2); p += 2; v >>= 16; }
-    if (n & 1u) *p = (uint8_t)v;
+// What a trip costs is decided by what it WAITS for.  The vector memory counter of gfx9 is one in-order counter for loads and stores: "wait until at most N of my
+// memory operations are outstanding".  The compiler can only use N > 0 where it can count the operations between a load and its use - a load or store inside a
+// branch that the wave may skip makes that count zero, and every wait a wait for everything, i.e. for the slowest lane's HBM miss of the newest load.  So every
+// memory operation of a trip is issued in EVERY trip by EVERY lane - a lane with nothing to store stores to its own idle word of global scratch, one with nothing
+// to load loads from there - and a chunk of a match is stored INFL_DEPTH trips after it was requested (the loop is unrolled INFL_DEPTH times so that the slot a
+// trip works on is a constant): its load has INFL_DEPTH trips to come back, with 6 memory operations issued per trip in between.
+//
+// Order of the bytes.  Literals are stored at once.  A match is parked when decoded (the output position moves on at once), becomes the active match when the one
+// before it has requested all its chunks, and requests 4 bytes per trip.  A request reads out[c_dst - dist, +4): the chunks requested in the last INFL_DEPTH - 1
+// trips are not stored yet, so a match with a distance below 4 INFL_DEPTH requests a chunk only when no chunk is pending (one chunk per INFL_DEPTH trips), and a
+// match becomes active while chunks of its predecessors are pending only if everything it reads lies in front of all of them (a pending chunk can be far behind
+// the output position: a short-distance match waits for empty slots while the literals behind it are decoded and stored).
+INFL_FN uint32_t infl_fix_short_distance(uint32_t w, uint32_t dist) {   // the first `dist` (1..3) bytes of w repeated over the four
+    return dist == 1u ? (w & 0xffu) * 0x01010101u : (dist == 2u ? (w & 0xffffu) * 0x00010001u : (w & 0xffffffu) | (w << 24));
 }
-
+typedef uint16_t __attribute__((aligned(1), may_alias)) infl_u16u;
+template <int PAR>
 INFL_FN void infl_step(InflLane& L) {
+    uint8_t* const idle = reinterpret_cast<uint8_t*>(L.G + (INFL_LENS_WORDS - 1) * L.g_stride);
+    uint8_t* lit_at = idle; uint32_t lit = 0;
     if (L.state == INFL_ST_DECODE) {
         const uint16_t* lt = reinterpret_cast<const uint16_t*>(L.S + INFL_OFF_LT);
         const uint32_t x = infl_peek(L, L.bo);
         const uint32_t e = infl_lookup(lt, INFL_LR, x);
         const uint32_t len = e & 15u, pay = e >> 4;
         if (pay < 256u && len != 0u) {                                    // literal
-#ifdef INFL_PROBE_NOLIT                                                   /* probe builds of tools/micro/inflate_lanes_bench.hip: a trip without its literal store */
-            if (L.pos < L.cap) { L.pos++; L.bo += len; }
-#else
-            if (L.pos < L.cap) { L.out[L.pos] = (uint8_t)pay; L.pos++; L.bo += len; }
-#endif
+            if (L.pos < L.cap) { lit_at = L.out + L.pos; lit = pay; L.pos++; L.bo += len; }
             else INFL_FAIL(L, 10);
-        } else if (pay & 0x800u) {                                        // length + distance: only when the copy engine is free
-            if (L.c_rem == 0u && L.c_pend == 0u) {
+        } else if (pay & 0x800u) {                                        // length + distance: parked behind the active match, if that place is free
+            if (L.m_len == 0u) {
                 const uint32_t xb = (pay >> 8) & 7u;
                 const uint32_t mlen = 3u + (pay & 255u) + ((x >> len) & ((1u << xb) - 1u));
                 L.bo += len + xb;
@@ -396,7 +409,7 @@ INFL_FN void infl_step(InflLane& L) {
                 const uint32_t dist = (dsv < 4u ? 1u + dsv : 1u + ((2u + (dsv & 1u)) << dxb)) + ((y >> dl) & ((1u << dxb) - 1u));
                 L.bo += dl + dxb;
                 if (dl == 0u || ds >= 30u || dist > L.pos || L.pos + mlen > L.cap) INFL_FAIL(L, 11);
-                else { L.c_dist = dist; L.c_dst = L.pos; L.c_rem = mlen; L.pos += mlen; }
+                else { L.m_dist = dist; L.m_dst = L.pos; L.m_len = mlen; L.pos += mlen; }
             } else { INFL_STAT(2, 1); }
         } else if (pay == 256u && len != 0u) {                            // end of block
             L.bo += len;
@@ -404,26 +417,42 @@ INFL_FN void infl_step(InflLane& L) {
             if (L.fin && (L.pos != L.cap || infl_bitpos(L) > L.in_bits)) INFL_FAIL(L, 12);
         } else INFL_FAIL(L, 13);                                    // no such code / a symbol that must not occur
     }
+#ifndef INFL_PROBE_NOLIT                                                  /* (probe builds of tools/micro/inflate_lanes_bench.hip switch parts of a trip off) */
+    *lit_at = (uint8_t)lit;
+#endif
     infl_shift(L);
-    infl_refill(L);
-    // the copy engine
-    // (a source closer than 4 bytes repeats itself inside the chunk: the pattern is laid out when the chunk is stored - a trip after its load, which nothing
-    // waits for until then; c_dist stays what it is until the engine is idle)
-#ifdef INFL_PROBE_NOCOPY                                                  /* probe: matches advance the output position, nothing is loaded or stored for them */
-    L.c_rem = 0;
+    L.pw = infl_word_at(L, L.in_at);
+    // ---- the copy engine
+#ifdef INFL_PROBE_NOCOPY
+    L.c_rem = 0; L.m_len = 0;
 #else
-    if (L.c_pend) {
-        uint32_t w = L.c_data;
-        if (L.c_dist < 4u) w = L.c_dist == 1u ? (w & 0xffu) * 0x01010101u : (L.c_dist == 2u ? (w & 0xffffu) * 0x00010001u : (w & 0xffffffu) | (w << 24));
-        infl_store(L.out + L.c_pdst, w, L.c_pend);
-        L.c_pend = 0;
+    {   // the chunk requested INFL_DEPTH trips ago
+        const uint32_t sn = L.s_n[PAR], n = sn & 15u, fd = sn >> 4;
+        uint32_t w = L.s_data[PAR];
+        if (fd) w = infl_fix_short_distance(w, fd);
+        uint8_t* const a = L.out + L.s_dst[PAR];
+        *reinterpret_cast<infl_u32u*>(n == 4u ? a : idle) = w;
+        const bool two = (n & 2u) != 0u && n != 4u, one = (n & 1u) != 0u;
+        *reinterpret_cast<infl_u16u*>(two ? a : idle) = (uint16_t)w;
+        *((one ? a + (two ? 2 : 0) : idle)) = (uint8_t)(two ? w >> 16 : w);
+        L.n_pend -= n ? 1u : 0u;
+        L.s_n[PAR] = 0;
     }
-    if (L.c_rem) {
-        const uint32_t n = L.c_rem < 4u ? L.c_rem : 4u;
-        L.c_data = infl_ld32u(L.out + (L.c_dst - L.c_dist));
-        L.c_pdst = L.c_dst; L.c_pend = n;
-        L.c_dst += n; L.c_rem -= n;
+    // (the bytes the parked match reads in front of its own output end at m_dst - m_dist + min(m_len, m_dist): it may start beside pending chunks if all of them
+    // lie behind that - p_min is the destination of the oldest chunk requested since the slots were last empty, and destinations only grow)
+    if (L.c_rem == 0u && L.m_len != 0u && (L.n_pend == 0u || L.m_dst - L.m_dist + (L.m_len < L.m_dist ? L.m_len : L.m_dist) <= L.p_min)) {
+        L.c_rem = L.m_len; L.c_dst = L.m_dst; L.c_dist = L.m_dist; L.m_len = 0;
+    }
+    {
+        const bool req = L.c_rem != 0u && (L.c_dist >= 4u * INFL_DEPTH || L.n_pend == 0u);
+        L.s_data[PAR] = infl_ld32u(req ? L.out + (L.c_dst - L.c_dist) : idle);
+        if (req) {
+            const uint32_t n = L.c_rem < 4u ? L.c_rem : 4u;
+            if (L.n_pend == 0u) L.p_min = L.c_dst;
+            L.s_dst[PAR] = L.c_dst; L.s_n[PAR] = n | (L.c_dist < 4u ? L.c_dist << 4 : 0u); L.n_pend++;
+            L.c_dst += n; L.c_rem -= n;
+        }
     }
 #endif
 }
-INFL_FN bool infl_running(const InflLane& L) { return L.state <= INFL_ST_HEADER || L.c_rem != 0u || L.c_pend != 0u; }
+INFL_FN bool infl_running(const InflLane& L) { return L.state <= INFL_ST_HEADER || L.c_rem != 0u || L.m_len != 0u || L.n_pend != 0u; }

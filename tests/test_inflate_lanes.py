@@ -22,6 +22,21 @@ def host_binary(tmp_path_factory):
     return out
 
 
+@pytest.mark.parametrize("depth", [2, 6])
+def test_lane_decoder_at_other_pipeline_depths(tmp_path, depth):
+    """INFL_DEPTH = trips between the request of a match chunk and its store (3 in the shipped build).  The rules that keep a request from reading bytes whose
+    store is still pending depend on it; depth 6 is where a wrong rule shows within a few hundred BAM blocks (it found one: a pending chunk can lie far behind
+    the output position when a short-distance match waited for empty slots)."""
+    out = str(tmp_path / "inflate_lanes_depth")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DINFL_DEPTH=%d" % depth, *INC, *SRC, "-lz", "-o", out])
+    path = str(tmp_path / "t.bam")
+    _bam_with_qualities(path, False)
+    run = subprocess.run([out, path], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and " 0 mismatches" in run.stdout.splitlines()[0], (run.stdout[-400:], run.stderr[-1000:])
+    run = subprocess.run([out, "--fuzz", "600"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "600 buffers, 0 mismatches" in run.stdout, (run.stdout[-400:], run.stderr[-1000:])
+
+
 def test_lane_decoder_fuzz_vs_zlib(host_binary):
     out = subprocess.run([host_binary, "--fuzz", "1500"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -20,6 +20,7 @@ static unsigned long long g_fail_site[16];
 #include <cstring>
 #include <string>
 #include <vector>
+static_assert(INFL_DEPTH <= 6, "the switch below");
 
 // 1 = decoded and identical, 0 = given up (block goes to the other decoder), -1 = WRONG (a result that differs, or a write outside the output)
 static int run_lane(const uint8_t* comp, size_t clen, const std::vector<uint8_t>* expect, size_t cap, unsigned shift) {
@@ -35,7 +36,14 @@ static int run_lane(const uint8_t* comp, size_t clen, const std::vector<uint8_t>
     const unsigned long long bound = 4ull * cap + 4096ull;
     while (infl_running(L)) {
         if (L.state == INFL_ST_HEADER) { infl_header(L); g_hdrs++; }
-        infl_step(L);
+        switch (trips % INFL_DEPTH) {                                        // (the GPU unrolls its loop: the slot of a trip is a constant)
+            case 0: infl_step<0>(L); break;
+            case 1: infl_step<1 % INFL_DEPTH>(L); break;
+            case 2: infl_step<2 % INFL_DEPTH>(L); break;
+            case 3: infl_step<3 % INFL_DEPTH>(L); break;
+            case 4: infl_step<4 % INFL_DEPTH>(L); break;
+            default: infl_step<5 % INFL_DEPTH>(L); break;
+        }
         if (++trips > bound) { fprintf(stderr, "trip bound exceeded\n"); return -1; }
     }
     g_trips += trips;

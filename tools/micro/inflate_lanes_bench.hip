@@ -14,6 +14,10 @@
 struct Job { unsigned long long in_off, out_off; uint32_t in_bytes, out_bytes; };
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
+#define HDR_T0 const unsigned long long h0 = __builtin_readcyclecounter();
+#define HDR_T1 t_hdr += __builtin_readcyclecounter() - h0; hdr_events++;
+#define INFL_TRIP_LIMIT 600000u
+static_assert(6 % INFL_DEPTH == 0, "the loop body holds six trips");
 __global__ __launch_bounds__(64) void k_lanes(const uint8_t* comp, const Job* jobs, long long n_jobs, uint8_t* out, uint8_t* redo, unsigned long long* prof, uint32_t* lens_scratch) {
     __shared__ uint32_t lds[64 * INFL_STRIDE / 4];
     const int lane = (int)threadIdx.x;
@@ -27,16 +31,20 @@ __global__ __launch_bounds__(64) void k_lanes(const uint8_t* comp, const Job* jo
     uint32_t trips = 0, hdr_events = 0;
     unsigned long long t_hdr = 0;
     const unsigned long long t0 = __builtin_readcyclecounter();
+    // the loop, unrolled INFL_DEPTH times (inflate_lanes.hpp: the chunk slot a trip stores from and loads into is a constant of the trip's position in the body)
+#define INFL_TRIP(PAR_) \
+        {                                                                                                   \
+            infl_step<(PAR_) % INFL_DEPTH>(L);                                                              \
+            if (__ballot(infl_running(L)) == 0ull) break;                                                   \
+            if (++trips > INFL_TRIP_LIMIT) { if (L.state != INFL_ST_DONE) L.state = INFL_ST_FAIL; break; }  \
+        }
     for (;;) {
+        // block headers: once per six trips (ONE copy of the header code in the kernel), for the lanes that wait at one - when enough of them do, or nobody decodes
         const uint64_t hm = __ballot(L.state == INFL_ST_HEADER);
         if (hm && (__popcll(hm) >= INFL_HDR_BATCH || __ballot(L.state == INFL_ST_DECODE) == 0ull)) {
-            const unsigned long long h0 = __builtin_readcyclecounter();
-            if (L.state == INFL_ST_HEADER) infl_header(L);
-            t_hdr += __builtin_readcyclecounter() - h0; hdr_events++;
+            HDR_T0 if (L.state == INFL_ST_HEADER) infl_header(L); HDR_T1
         }
-        infl_step(L);
-        if (__ballot(infl_running(L)) == 0ull) break;
-        if (++trips > 600000u) { if (L.state != INFL_ST_DONE) L.state = INFL_ST_FAIL; break; }
+        INFL_TRIP(0) INFL_TRIP(1) INFL_TRIP(2) INFL_TRIP(3) INFL_TRIP(4) INFL_TRIP(5)
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (j < n_jobs) redo[j] = L.state == INFL_ST_DONE ? (uint8_t)0 : (uint8_t)1;
