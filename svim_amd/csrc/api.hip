@@ -89,6 +89,14 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
         }
     }
     { void* hp = nullptr; HIPCHK(hipHostMalloc(&hp, 4096, hipHostMallocDefault)); c->pinned = (int64_t*)hp; }
+    {
+        void* hp = nullptr;
+        HIPCHK(hipHostMalloc(&hp, (size_t)SVX_MAIL_SLOTS * SVX_MAIL_WORDS * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(hp, 0, (size_t)SVX_MAIL_SLOTS * SVX_MAIL_WORDS * 8);
+        c->mail = (unsigned long long*)hp;
+        const char* e = getenv("SVX_MAILBOX");
+        c->mail_mode = e && e[0] == '0' ? 0 : 1;
+    }
     memset(&c->stats, 0, sizeof c->stats);
     svx_preload_collect(); svx_preload_cluster(); svx_preload_edit(); svx_preload_prims();       // code objects now, not inside the first call
     { const char* e = getenv("SVX_EDIT_FORCE_FULL"); c->edit_force_full = e && e[0] == '1'; }
@@ -114,9 +122,65 @@ extern "C" void svx_ctx_destroy(svx_ctx* c) {
     for (auto& b : c->geno) b.release();
     for (auto& ev : c->ev) (void)hipEventDestroy(ev);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->mail) (void)hipHostFree(c->mail);
     for (auto& a : c->aux) (void)hipStreamDestroy(a);
     (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+// ---- mailbox (common.hpp) -----------------------------------------------------------------------------------------------------------------------------
+// One wave copies the words and, after a system-scope fence, the sequence number of the post into word 0 of the slot; the host spins on that word.  Sequence
+// numbers only grow, so a slot that is reused can never show an older post as the new one.  The wait keeps an eye on the stream: a kernel that faulted
+// never posts, and hipStreamQuery says so.
+__global__ __launch_bounds__(64) void k_mail(MailSrc src, unsigned long long* slot, unsigned long long seq) {
+    int at = 1;
+    for (int j = 0; j < src.k; j++) {
+        const unsigned long long* p = (const unsigned long long*)src.p[j];
+        for (int i = (int)threadIdx.x; i < src.n[j]; i += 64) __hip_atomic_store(slot + at + i, p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        at += src.n[j];
+    }
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0) __hip_atomic_store(slot, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int svx_mail_post(svx_ctx* c, hipStream_t st, const MailSrc& src, unsigned long long* ticket) {
+    int total = 0;
+    if (src.k < 0 || src.k > 4) return svx_fail(SVX_E_ARG, "svx_mail_post: bad source count", __FILE__, __LINE__, hipSuccess);
+    for (int j = 0; j < src.k; j++) { if (src.n[j] < 0) return svx_fail(SVX_E_ARG, "svx_mail_post: negative length", __FILE__, __LINE__, hipSuccess); total += src.n[j]; }
+    if (total >= SVX_MAIL_WORDS) return svx_fail(SVX_E_ARG, "svx_mail_post: too many words", __FILE__, __LINE__, hipSuccess);
+    const unsigned long long seq = ++c->mail_seq;
+    unsigned long long* slot = c->mail + (size_t)(seq % SVX_MAIL_SLOTS) * SVX_MAIL_WORDS;
+    if (c->mail_mode) {
+        k_mail<<<1, 64, 0, st>>>(src, slot, seq);
+        HIPCHK(hipGetLastError());
+    } else {
+        int at = 1;
+        for (int j = 0; j < src.k; j++) {
+            if (src.n[j]) HIPCHK(hipMemcpyAsync(slot + at, src.p[j], (size_t)src.n[j] * 8, hipMemcpyDeviceToHost, st));
+            at += src.n[j];
+        }
+    }
+    *ticket = seq;
+    return SVX_OK;
+}
+
+int svx_mail_wait(svx_ctx* c, hipStream_t st, unsigned long long ticket, const unsigned long long** payload) {
+    unsigned long long* slot = c->mail + (size_t)(ticket % SVX_MAIL_SLOTS) * SVX_MAIL_WORDS;
+    *payload = slot + 1;
+    if (!c->mail_mode) { HIPCHK(hipStreamSynchronize(st)); return SVX_OK; }
+    for (long long spin = 0;; spin++) {
+        if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == ticket) return SVX_OK;
+        __builtin_ia32_pause();
+        if ((spin & 0xffff) == 0xffff) {                      // every few hundred microseconds: is the stream still alive?
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == ticket) return SVX_OK;
+                return svx_fail(SVX_E_STATE, "mailbox: the stream ran dry without the post", __FILE__, __LINE__, hipSuccess);
+            }
+            if (q != hipErrorNotReady) return svx_fail(SVX_E_HIP, "mailbox: stream failed while a post was awaited", __FILE__, __LINE__, q);
+        }
+    }
 }
 
 extern "C" void* svx_stream(svx_ctx* c) { return (void*)c->stream; }

@@ -695,7 +695,7 @@ int devdec_load(svx_devdec* d, int slot, const DevDecBlock* blocks, size_t nb_in
         // three sub-batches of a third of that, no ramp.  (Six rolling sub-batches of 11 k blocks measured worse - 0.82 against 0.96 M records/s on the 8 GB chunk,
         // profiles/r06_end_to_end_lane_decoder.txt: more streams than hardware queues.)
         const bool lanes = []() { const char* e = getenv("SVX_INFLATE_LANES"); return e && e[0] == '1'; }();
-        const int NS = 3;
+        const int NS = []() { const char* e = getenv("SVX_BAM_DEV_SLOTS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 3; }();      // sub-batches in flight
         const size_t SUB = sub_env ? sub_env : (lanes ? 21845 : 32768);   // wave-per-block: a launch of >= ~25 k blocks runs at the kernel's best rate (a 12 k one at 0.8 of it: its tail)
         int n_cpu = cpu_env >= 0 ? cpu_env : (d->n_threads > 8 ? d->n_threads - 6 : (d->n_threads > 3 ? d->n_threads - 3 : 0));      // (the staging copies want cores, too)
         if (nb_in < 4 * SUB / 3) n_cpu = 0;                            // a small chunk: one launch does it

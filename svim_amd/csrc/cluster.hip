@@ -551,8 +551,7 @@ int svx_pair_distances_impl(svx_ctx* c, const ClusterIn& in, int64_t n_pairs, co
     HIPCHK(hipMemsetAsync(c->ed.p, 0, (size_t)(n_pairs + 1) * 4, st));
     k_pairs_need_edit<<<(unsigned)((n_pairs + 255) / 256), 256, 0, st>>>(n_pairs, ia_dev, ib_dev, in, *pp, c->work.as<EditWork>(), cnt + 8);
     unsigned long long n_work = 0;
-    HIPCHK(hipMemcpyAsync(&n_work, cnt + 8, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    SVXCHK(svx_mail_read(c, st, cnt + 8, 1, &n_work));
     if (n_work) {
         if (!c->g_off_p) return svx_fail(SVX_E_STATE, "svx_set_genome must precede insertion distances", __FILE__, __LINE__, hipSuccess);
         SVXCHK(svx_launch_edit_pairs(c, (int64_t)n_work, c->work.p, in, c->ed.as<int32_t>(), nullptr));
@@ -1242,8 +1241,7 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
     k_part_flags<<<GRID(n + 1, T), T, 0, st>>>(in, hi_sorted, sidx, p.partition_max_distance, c->part_flag.as<int64_t>());
     SVXCHK(svx_exclusive_scan_i64(c, c->part_flag.as<int64_t>(), c->part_id.as<int64_t>(), n + 1));
     int64_t n_part = 0;
-    HIPCHK(hipMemcpyAsync(&n_part, c->part_id.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    SVXCHK(svx_mail_read(c, st, c->part_id.as<int64_t>() + n, 1, &n_part));
     SVXCHK(svx_edit_prepack_pack(c, in));
     SVXCHK(c->part_start.reserve((size_t)(n_part + 1) * 8));
     k_part_starts<<<GRID(n + 1, T), T, 0, st>>>(c->part_flag.as<int64_t>(), c->part_id.as<int64_t>(), n, c->part_start.as<int64_t>(), n_part);
@@ -1258,10 +1256,7 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
     SVXCHK(svx_exclusive_scan_i64(c, large_a, large_excl, n_part + 1));
     SVXCHK(svx_exclusive_scan_i64(c, pairs_a, pair_off, n_part + 1));
     int64_t totals[3];
-    HIPCHK(hipMemcpyAsync(&totals[0], samp_base + n_part, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&totals[1], large_excl + n_part, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&totals[2], pair_off + n_part, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    SVXCHK(svx_mail_read3(c, st, samp_base + n_part, 1, &totals[0], large_excl + n_part, 1, &totals[1], pair_off + n_part, 1, &totals[2]));
     const int64_t samp_total = totals[0], n_large = totals[1], pair_total = totals[2];
     SVXCHK(c->counters.reserve(16 * 8));
     unsigned long long* cnt = c->counters.as<unsigned long long>();
@@ -1334,10 +1329,9 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
         k_sample_apply<<<(unsigned)n_large, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
                                                         c->mt_words.as<uint32_t>(), c->mt_have, samp_start, c->samp_idx.as<int32_t>());
         HIPCHK(hipGetLastError());
-        int h_err = 0;
-        HIPCHK(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(chain, chain_dev, sizeof chain, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));       // also covers the plan's host vectors
+        unsigned long long err_word = 0;              // err is the low half of cnt[15]
+        SVXCHK(svx_mail_read2(c, st, cnt + 15, 1, &err_word, chain_dev, (int)(sizeof chain / 8), chain));       // the wait also covers the plan's host vectors
+        const int h_err = (int)(uint32_t)err_word;
         *done = !h_err;
         return SVX_OK;
     };
@@ -1365,10 +1359,9 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
             k_sample_apply<<<(unsigned)n_large, 64, 0, st>>>(c->large_list.as<int32_t>(), n_large, c->part_start.as<int64_t>(), sidx, in.type, large_excl,
                                                             stream, c->mt_have, samp_start, c->samp_idx.as<int32_t>());
             HIPCHK(hipGetLastError());
-            int h_err = 0;
-            HIPCHK(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(chain + SVX_NTYPES, chain_dev + SVX_NTYPES, SVX_NTYPES * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            unsigned long long err_word = 0;
+            SVXCHK(svx_mail_read2(c, st, cnt + 15, 1, &err_word, chain_dev + SVX_NTYPES, SVX_NTYPES, chain + SVX_NTYPES));
+            const int h_err = (int)(uint32_t)err_word;
             if (!h_err) break;
             if (attempt == 5) return svx_fail(SVX_E_CAPACITY, "random word stream", __FILE__, __LINE__, hipSuccess);
             cap = c->mt_have * 4;
@@ -1491,8 +1484,7 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
         k_ins_pairs<<<(unsigned)n_part, 64, 0, st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl, pairs_a, pair_off, in, p,
                                                     c->work.as<EditWork>(), cnt + 8, pair_total);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h_cnt, cnt, 16 * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        SVXCHK(svx_mail_read(c, st, cnt, 16, h_cnt));
         const int64_t n_work = (int64_t)h_cnt[8];
         SVXCHK(c->cell_shards.reserve(1024 * 8));
         HIPCHK(hipMemsetAsync(c->cell_shards.p, 0, 1024 * 8, st));
@@ -1509,10 +1501,7 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
     SVXCHK(svx_exclusive_scan_i32_to_i64(c, ncl_a, clu_off, n_part + 1));
     SVXCHK(svx_exclusive_scan_i32_to_i64(c, nmem_a, mem_off, n_part + 1));
     int64_t tot2[2];
-    HIPCHK(hipMemcpyAsync(&tot2[0], clu_off + n_part, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&tot2[1], mem_off + n_part, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h_cnt, cnt, 16 * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    SVXCHK(svx_mail_read3(c, st, clu_off + n_part, 1, &tot2[0], mem_off + n_part, 1, &tot2[1], cnt, 16, h_cnt));
     const int64_t ncl = tot2[0], nmem = tot2[1];
     const size_t CN = (size_t)(ncl + 1);
     // unsorted dense copy lives in tmp buffers, final tables in c->clu
@@ -1555,8 +1544,7 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
         HIPCHK(hipMemsetAsync(tc, 0, 6 * 8, st));
         k_type_counts<<<1, 64, 0, st>>>(ncl, out.type.as<uint8_t>(), tc);
         unsigned long long h_tc[6];
-        HIPCHK(hipMemcpyAsync(h_tc, tc, 6 * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        SVXCHK(svx_mail_read(c, st, tc, 6, h_tc));
         for (int t = 0; t < SVX_NTYPES; t++) out.type_count[t] = (int64_t)h_tc[t];
     } else {
         HIPCHK(hipMemsetAsync(out.member_off.p, 0, 16, st));

@@ -73,76 +73,38 @@ struct ScanArgs {
     int min_mapq, min_sv_size;
 };
 
-struct ItemMeta { unsigned long long off0, off1; int lseq; unsigned flag; int mapq; int has_seg; };
+// One work item as the streaming loop sees it (round 6).  k_scan_prepare writes one 16-byte entry per item; the scan kernel reads an entry with ONE scalar
+// load and keeps 32-bit positions relative to the 16-byte-aligned word the item's first operation lies in - the absolute 64-bit offsets of the item, of the
+// item after it and of the array ends, and the nine column pointers behind the metadata, were ~45 scalar registers that had to live across the streaming
+// loop; with the table the kernel fits the 80 SGPRs / 64 VGPRs of eight waves per SIMD (it is bound by the bytes it keeps in flight).
+//   x = low word of a0 = off0 & ~3 (operations);  y = bits 0..23 high bits of a0, bit 24 skip (filtered-out record / short segment row), bit 25 the item
+//   needs its geometry record, bits 28..29 lead = off0 & 3;  z = len = off1 - a0;  w = lim = operations of the array from a0 on (clamped): a 16-byte load
+//   at position k is legal iff k + 4 <= lim.
+#define ITEM_SKIP (1u << 24)
+#define ITEM_GEOM (1u << 25)
+struct ItemMeta { const uint32_t* base; uint32_t lead, len, lim, flags; };
 
-__device__ __forceinline__ ItemMeta load_meta(const ScanArgs& b, long long w) {
-    ItemMeta m;
-    if (w < b.n_rec) {
-        m.off0 = b.cigar_off[w]; m.off1 = b.cigar_off[w + 1]; m.lseq = b.lseq[w]; m.flag = b.flag[w]; m.mapq = b.mapq[w];
-        m.has_seg = b.seg_off[w + 1] > b.seg_off[w];
-    } else {
-        const long long s = w - b.n_rec;
-        m.off0 = b.seg_cigar_off[s]; m.off1 = b.seg_cigar_off[s + 1]; m.lseq = b.seg_lseq[s]; m.flag = 0; m.mapq = 255; m.has_seg = 1;
-    }
-    return m;
-}
+// Segment rows come from SA tags and most aligners abbreviate their CIGARs to a handful of operations: a wave per row would spend its time on
+// latency (one trip, one serial epilogue), so rows of at most SEG_SMALL operations are done one per LANE here and k_cigar_scan skips them.
+#define SEG_SMALL 32
 
-__device__ __forceinline__ uint4 load_chunk(const uint32_t* cig, unsigned long long k, unsigned long long off1, unsigned long long tot) {
+// the four operations at position k of an item (k a multiple of 4).  One load instruction whatever the position: where the 16 bytes would run off the end of
+// the ARRAY (its last three words) the load is moved back to the array's last four words and the elements are shifted down; what slides in from behind is at a
+// position >= len, which the caller masks.  A lane at or behind the item's end does not load (those bytes are the neighbours', fetched by their own waves).
+// (lim >= 4: svx_collect_impl pads an array of fewer than four operations.)
+__device__ __forceinline__ uint4 load_chunk(const uint32_t* base, uint32_t k, uint32_t len, uint32_t lim) {
     uint4 q = make_uint4(15u, 15u, 15u, 15u);            // op 15 / len 0 = no-op
-    if (k < off1) {
-        if (k + 4 <= tot) q = *reinterpret_cast<const uint4*>(cig + k);
-        else {
-            if (k < tot) q.x = cig[k];
-            if (k + 1 < tot) q.y = cig[k + 1];
-            if (k + 2 < tot) q.z = cig[k + 2];
+    if (k < len) {
+        const int kk = k + 4 <= lim ? (int)k : (int)lim - 4;            // (signed: the item may start inside the array's last four words)
+        q = *reinterpret_cast<const uint4*>(base + kk);
+        const uint32_t d = k - (uint32_t)kk;
+        if (d) {
+            q.x = d == 1 ? q.y : (d == 2 ? q.z : q.w);
+            q.y = d == 1 ? q.z : q.w;
+            q.z = q.w;
         }
     }
     return q;
-}
-
-// cursors of the operations [from, to) of a record that starts at off0 (lane partial sums): the chunks were streamed moments ago (L2)
-#ifndef SVX_CATCHUP_G
-#define SVX_CATCHUP_G 1        /* chunks loaded per step of the catch-up walk: more in flight costs registers, and occupancy is worth more (measured) */
-#endif
-// SVX_SCAN_RING > 0: the last SVX_SCAN_RING streamed 1 KiB chunks of the current item stay in a per-wave LDS ring, so that the catch-up walk re-reads
-// LDS instead of L2 / HBM (the streamed chunks have partly left the L2 by the time an indel turns up: 1.23 x the algorithmic traffic without it)
-#ifndef SVX_SCAN_RING
-#define SVX_SCAN_RING 4
-#endif
-__device__ __forceinline__ void catch_up(const uint32_t* cig, unsigned long long from, unsigned long long to, unsigned long long off0, unsigned long long limit,
-                                         unsigned long long tot, int lane, int& acc_ref, int& acc_read, const uint4* ring) {
-    for (unsigned long long kk = from; kk < to; kk += 256ull * SVX_CATCHUP_G) {
-        uint4 r[SVX_CATCHUP_G];
-#pragma unroll
-        for (int g = 0; g < SVX_CATCHUP_G; g++) {
-            const unsigned long long kq = kk + 256ull * g;
-            r[g] = make_uint4(15u, 15u, 15u, 15u);
-            if (kq < to) {
-#if SVX_SCAN_RING > 0
-                if (to - kq < 256ull * SVX_SCAN_RING) r[g] = ring[((kq >> 8) % SVX_SCAN_RING) * 64 + lane];       // still in the ring (masked like load_chunk did)
-                else
-#endif
-                r[g] = load_chunk(cig, kq + (unsigned long long)lane * 4, limit < to ? limit : to, tot);
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < SVX_CATCHUP_G; g++) {
-            const unsigned long long kq = kk + 256ull * g, kc = kq + (unsigned long long)lane * 4;
-            if (kq < off0) {
-                if (kc < off0) r[g].x = 15u;
-                if (kc + 1 < off0) r[g].y = 15u;
-                if (kc + 2 < off0) r[g].z = 15u;
-                if (kc + 3 < off0) r[g].w = 15u;
-            }
-            const uint32_t rv[4] = {r[g].x, r[g].y, r[g].z, r[g].w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int op = (int)(rv[j] & 15u), l = (int)(rv[j] >> 4);
-                acc_ref += op_sel(MASK_REF, op, l);
-                acc_read += op_sel(MASK_READ, op, l);
-            }
-        }
-    }
 }
 
 // geometry record of one alignment from the sums over its CIGAR: {reference length, query_alignment_start, query_alignment_end, infer_read_length,
@@ -179,103 +141,104 @@ __device__ __forceinline__ void finish_geom(const uint32_t* c, long long n, int 
     geom_out[3] = (n > 0) ? (int)(sum_read + sum_h) : 0; geom_out[4] = (int)sum_h;
 }
 
-// Segment rows come from SA tags and most aligners abbreviate their CIGARs to a handful of operations: a wave per row would spend its time on
-// latency (one trip, one serial epilogue), so rows of at most SEG_SMALL operations are done one per LANE here and k_cigar_scan skips them.
-#define SEG_SMALL 32
-__global__ __launch_bounds__(256) void k_seg_geom_small(ScanArgs b, int* seg_geom) {
-    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= b.n_seg) return;
-    const unsigned long long off0 = b.seg_cigar_off[s], off1 = b.seg_cigar_off[s + 1];
-    const long long n = (long long)(off1 - off0);
-    if (n > SEG_SMALL) return;
-    const uint32_t* c = b.seg_cigar + off0;
-    int sum_ref = 0, sum_read = 0, sum_n = 0, sum_h = 0, sum_s = 0;
-    for (long long i = 0; i < n; i++) {
-        const int op = (int)(c[i] & 15u), l = (int)(c[i] >> 4);
-        sum_ref += op_sel(MASK_REF, op, l);
-        sum_read += op_sel(MASK_READ, op, l);
-        sum_n += (op == 3) ? l : 0;
-        sum_h += (op == 5) ? l : 0;
-        sum_s += (op == 4) ? l : 0;
+// One thread per item: the table entry of the scan (above); the geometry of a short segment row; and, for an item whose geometry the scan computes, the
+// stored sequence length in word 0 of its geometry record, where the scan's epilogue picks it up (finish_geom reads it before it writes the record).
+__global__ __launch_bounds__(256) void k_scan_prepare(ScanArgs b, unsigned long long total_ops, unsigned long long total_seg_ops, uint4* items, int* geom) {
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= b.n_rec + b.n_seg) return;
+    const bool is_rec = w < b.n_rec;
+    const long long s = w - b.n_rec;
+    const unsigned long long off0 = is_rec ? b.cigar_off[w] : b.seg_cigar_off[s], off1 = is_rec ? b.cigar_off[w + 1] : b.seg_cigar_off[s + 1];
+    const unsigned long long tot = is_rec ? total_ops : total_seg_ops;
+    const int lseq = is_rec ? b.lseq[w] : b.seg_lseq[s];
+    bool skip, geom_needed;
+    if (is_rec) {
+        const unsigned flag = b.flag[w];
+        skip = (flag & SVX_FLAG_USED_MASK) || (int)b.mapq[w] < b.min_mapq;
+        geom_needed = !(flag & 2048u) && b.seg_off[w + 1] > b.seg_off[w];
+    } else {
+        skip = off1 - off0 <= SEG_SMALL;
+        geom_needed = true;
     }
-    finish_geom(c, n, b.seg_lseq[s], sum_ref, sum_read, sum_n, sum_h, sum_s, seg_geom + 5 * s);
+    const unsigned long long a0 = off0 & ~3ull, room = tot - a0;
+    uint4 e;
+    e.x = (uint32_t)a0;
+    e.y = (uint32_t)(a0 >> 32) | (skip ? ITEM_SKIP : 0u) | (geom_needed ? ITEM_GEOM : 0u) | ((uint32_t)(off0 - a0) << 28);
+    e.z = (uint32_t)(off1 - a0);
+    e.w = room > 0xffffffffull ? 0xffffffffu : (uint32_t)room;
+    items[w] = e;
+    if (!is_rec && skip) {
+        const uint32_t* c = b.seg_cigar + off0;
+        const long long n = (long long)(off1 - off0);
+        int sum_ref = 0, sum_read = 0, sum_n = 0, sum_h = 0, sum_s = 0;
+        for (long long i = 0; i < n; i++) {
+            const int op = (int)(c[i] & 15u), l = (int)(c[i] >> 4);
+            sum_ref += op_sel(MASK_REF, op, l);
+            sum_read += op_sel(MASK_READ, op, l);
+            sum_n += (op == 3) ? l : 0;
+            sum_h += (op == 5) ? l : 0;
+            sum_s += (op == 4) ? l : 0;
+        }
+        finish_geom(c, n, lseq, sum_ref, sum_read, sum_n, sum_h, sum_s, geom + 5 * w);
+    } else if (!skip && geom_needed) geom[5 * w] = lseq;
 }
 
-template <bool GEOM>
-__device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& out, long long w,
-                                          const ItemMeta& mt, bool need_indel, int* geom_out, unsigned long long total_ops,
-                                          unsigned long long total_seg_ops, int shard, int& n_out, uint4 (&nx)[SVX_SCAN_NU], bool has_next,
-                                          long long wn, const ItemMeta& mtn, uint4* ring) {
+// One item, streamed.  The two cursors are lane-local running sums kept in EVERY chunk (until round 5 the records without segment rows only asked "is any
+// of these operations a long I / D" and re-decoded the chunks since the last report when one turned up: 17 % of the bytes were fetched twice, much of it
+// from HBM - 768 waves per XCD stream the 4 MB of its L2 between the first read of a chunk and the walk back).  GEOM adds the three sums the geometry
+// record needs and its serial epilogue.
+__device__ __forceinline__ void scan_item(const bool GEOM, RawIndel* out_raw, int shard_cap, uint32_t w, const ItemMeta& mt, bool need_indel, int* geom_out,
+                                          int min_len, int& n_out, uint4 (&nx)[SVX_SCAN_NU], const ItemMeta& mtn) {
     const int lane = lane_id();
-    const bool is_rec = w < b.n_rec;
-    const uint32_t* cig = is_rec ? b.cigar : b.seg_cigar;
-    const unsigned long long tot = is_rec ? total_ops : total_seg_ops;
-    const unsigned long long off0 = mt.off0, off1 = mt.off1;
-    // the item after this one: its first trip is requested while this item's last trip is decoded
-    const bool n_is_rec = wn < b.n_rec;
-    const uint32_t* cig_n = n_is_rec ? b.cigar : b.seg_cigar;
-    const unsigned long long tot_n = n_is_rec ? total_ops : total_seg_ops;
-    const unsigned long long a0_n = mtn.off0 & ~3ull, off1_n = has_next ? mtn.off1 : 0ull;
-    const int min_len = b.min_sv_size;
+    const uint32_t* base = mt.base;
+    const uint32_t lead = mt.lead, len = mt.len, lim = mt.lim;
+    // the item after this one (len 0 when there is none): its first trip is requested while this item's last trip is decoded
+    const uint32_t* base_n = mtn.base;
+    const uint32_t len_n = mtn.len, lim_n = mtn.lim;
     int acc_ref = 0, acc_read = 0, acc_n = 0, acc_h = 0, acc_s = 0;
-    const unsigned long long a0 = off0 & ~3ull;
-    unsigned long long done_k = a0;                          // !GEOM: operations before done_k are in acc_ref / acc_read
-    // packed word of the shortest reportable indel (any op code); a filter only - the exact test follows in the emission branch
-    const uint32_t emit_floor = min_len > 0x0fffffff ? 0xffffffffu : ((uint32_t)(min_len > 0 ? min_len : 0) << 4);
     // NU consecutive 1 KiB chunks per trip: the loads of the next trip are all issued before the current one is decoded,
     // so a wave keeps NU KiB in flight (memory-level parallelism is what this kernel lives on)
     constexpr int NU = SVX_SCAN_NU;
-    if (off1 <= a0) {                                  // empty CIGAR: nothing to decode, just keep the pipeline primed
-#pragma unroll
-        for (int u = 0; u < NU; u++) nx[u] = load_chunk(cig_n, a0_n + 256ull * u + (unsigned long long)lane * 4, off1_n, tot_n);
-    }
-    for (unsigned long long kb = a0; kb < off1; kb += 256ull * NU) {
+    uint32_t kb = 0;
+    do {                                               // (an empty CIGAR makes one trip too: nothing to decode, but the pipeline stays primed)
         uint4 cu[NU];
 #pragma unroll
         for (int u = 0; u < NU; u++) cu[u] = nx[u];
-        if (kb + 256ull * NU < off1) {
+        {
+            // one load site: the next trip of this item, or the first trip of the item after it (scalar selects)
+            const bool more = len > kb && len - kb > 256u * NU;
+            const uint32_t* lb = more ? base : base_n;
+            const uint32_t lk = more ? kb + 256u * NU : 0u, ll = more ? len : len_n, lm = more ? lim : lim_n;
 #pragma unroll
-            for (int u = 0; u < NU; u++) nx[u] = load_chunk(cig, kb + 256ull * (NU + u) + (unsigned long long)lane * 4, off1, tot);
-        } else {
-#pragma unroll
-            for (int u = 0; u < NU; u++) nx[u] = load_chunk(cig_n, a0_n + 256ull * u + (unsigned long long)lane * 4, off1_n, tot_n);
+            for (int u = 0; u < NU; u++) nx[u] = load_chunk(lb, lk + 256u * u + (uint32_t)lane * 4, ll, lm);
         }
 #pragma unroll
         for (int u = 0; u < NU; u++) {
-        const unsigned long long k0 = kb + 256ull * u;
-        if (k0 >= off1) break;
-        const unsigned long long k = k0 + (unsigned long long)lane * 4;
+        const uint32_t k0 = kb + 256u * u;
+        if (k0 >= len) break;
+        const uint32_t k = k0 + (uint32_t)lane * 4;
         uint4 q = cu[u];
-#if SVX_SCAN_RING > 0
-        if (!GEOM) ring[((k0 >> 8) % SVX_SCAN_RING) * 64 + lane] = q;         // (as loaded: elements beyond off1 are no-ops already, those before off0 are masked by the walk)
-#endif
-        // mask the elements outside [off0, off1) (only the first and the last chunk of an item can have any)
-        if (k0 < off0 || k0 + 256 > off1) {
-            if (k < off0 || k >= off1) q.x = 15u;
-            if (k + 1 < off0 || k + 1 >= off1) q.y = 15u;
-            if (k + 2 < off0 || k + 2 >= off1) q.z = 15u;
-            if (k + 3 < off0 || k + 3 >= off1) q.w = 15u;
+        // mask the elements outside [lead, len) (only the first and the last chunk of an item can have any)
+        if (k0 == 0 || len - k0 < 256u) {
+            if (k < lead || k >= len) q.x = 15u;
+            if (k + 1 < lead || k + 1 >= len) q.y = 15u;
+            if (k + 2 < lead || k + 2 >= len) q.z = 15u;
+            if (k + 3 < lead || k + 3 >= len) q.w = 15u;
         }
         const uint32_t v[4] = {q.x, q.y, q.z, q.w};
         int t_ref = 0, t_read = 0;
         bool any_emit = false;
-        if (!GEOM) {
-            // A record without segment rows needs its cursors only where it reports an indel: the streaming path just asks "is any of
-            // these operations a long I / D" (two compares per operation on the packed word) and leaves the running sums alone ...
-#pragma unroll
-            for (int j = 0; j < 4; j++) any_emit |= (v[j] >= emit_floor) && (((v[j] - 1u) & 15u) < 2u);
-            if (!__any(any_emit)) continue;
-            // ... and catches up when one turns up: the operations of [done_k, k0) are decoded now (they were streamed moments ago: L2)
-            catch_up(cig, done_k, k0, off0, off1, tot, lane, acc_ref, acc_read, ring);
-            done_k = k0 + 256ull;
-        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int op = (int)(v[j] & 15u), l = (int)(v[j] >> 4);
             t_ref += op_sel(MASK_REF, op, l);
             t_read += op_sel(MASK_READ, op, l);
-            if (GEOM) {
-                any_emit |= ((unsigned)(op - 1) < 2u) && l >= min_len;
+            any_emit |= ((unsigned)(op - 1) < 2u) && l >= min_len;
+        }
+        if (GEOM) {                                        // (uniform: one copy of the loop serves both kinds of item)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int op = (int)(v[j] & 15u), l = (int)(v[j] >> 4);
                 acc_n += (op == 3) ? l : 0;
                 acc_h += (op == 5) ? l : 0;
                 acc_s += (op == 4) ? l : 0;
@@ -292,12 +255,12 @@ __device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& ou
                 const bool e = ((unsigned)(op - 1) < 2u) && l >= min_len;
                 const unsigned long long m = __ballot(e);
                 if (m) {
-                    const long long slot = (long long)n_out + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (e && slot < out.shard_cap) {
+                    const int slot = n_out + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (e && slot < shard_cap) {
                         RawIndel ri;
-                        ri.item = (uint32_t)w; ri.opidx = (uint32_t)((k + j) - off0);
+                        ri.item = w; ri.opidx = (k + j) - lead;
                         ri.pos_ref = base_ref + ex_ref + pr; ri.pos_read = base_read + ex_read + pq; ri.len_op = (l << 1) | (op == 2);
-                        out.raw[(long long)shard * out.shard_cap + slot] = ri;
+                        out_raw[slot] = ri;
                     }
                     n_out += __popcll(m);
                 }
@@ -306,80 +269,77 @@ __device__ __forceinline__ void scan_item(const ScanArgs& b, const RawTarget& ou
         }
         acc_ref += t_ref; acc_read += t_read;
         }
-    }
+        kb += 256u * NU;
+    } while (kb < len);
     if (!GEOM) return;
     const long long sum_ref = wave_sum_i32(acc_ref), sum_read = wave_sum_i32(acc_read);
     const long long sum_n = wave_sum_i32(acc_n), sum_h = wave_sum_i32(acc_h), sum_s = wave_sum_i32(acc_s);
-    if (lane == 0) finish_geom(cig + off0, (long long)(off1 - off0), mt.lseq, sum_ref, sum_read, sum_n, sum_h, sum_s, geom_out);
+    if (lane == 0) finish_geom(base + lead, len > lead ? (long long)(len - lead) : 0ll, geom_out[0] /* the stored sequence length: k_scan_prepare */, sum_ref, sum_read, sum_n, sum_h,
+                               sum_s, geom_out);
 }
 
-// an item this kernel leaves alone: a filtered-out record, or a short segment row (k_seg_geom_small has those)
-__device__ __forceinline__ bool scan_skips(const ScanArgs& b, long long w, const ItemMeta& m) {
-    if (w >= b.n_rec) return m.off1 - m.off0 <= SEG_SMALL;
-    return (m.flag & SVX_FLAG_USED_MASK) || m.mapq < b.min_mapq;
+__device__ __forceinline__ ItemMeta load_meta(const uint4* items, uint32_t w, uint32_t n_rec, const uint32_t* cigar, const uint32_t* seg_cigar) {
+    const uint4 e = items[w];                               // uniform address: one scalar load
+    // (select on integers: a pointer chosen in the two arms of a branch becomes a two-entry table in scratch memory, indexed through a VGPR - and with it
+    // everything derived from the base pointer leaves the scalar registers)
+    const unsigned long long cigp = w < n_rec ? (unsigned long long)cigar : (unsigned long long)seg_cigar;
+    ItemMeta m;
+    m.base = reinterpret_cast<const uint32_t*>(cigp) + (((unsigned long long)(e.y & 0xffffffu) << 32) | e.x);
+    m.lead = e.y >> 28; m.len = e.z; m.lim = e.w; m.flags = e.y;
+    return m;
 }
 
-__device__ __forceinline__ void scan_items(const ScanArgs& b, const RawTarget& out, int* rec_geom, int* seg_geom,
-                                           unsigned long long total_ops, unsigned long long total_seg_ops, int map_mode, long long block, long long n_blocks) {
-    const long long n_items = b.n_rec + b.n_seg;
-    const long long n_waves = n_blocks * 4;
+__device__ __forceinline__ void scan_items(const uint4* items, uint32_t n_rec, uint32_t n_items, const uint32_t* cigar, const uint32_t* seg_cigar, int min_len,
+                                           const RawTarget& out, int* geom, uint32_t block, uint32_t n_blocks) {
+    // items, waves and raw slots are 32-bit counts (a batch holds fewer than 2^31 records + segment rows: svx_collect_impl checks)
+    const uint32_t n_waves = n_blocks * 4;
     // the wave index is uniform: keep it (and everything derived from it: metadata, base pointers) in scalar registers
-    const long long wave = block * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int shard = (int)wave;                   // grid is capped at RAW_SHARDS waves
-    int n_out = 0;                                 // records this wave has emitted (uniform)
-    // map_mode 0: wave walks items wave, wave+W, ... ; 1: wave owns a contiguous run of items (sequential DRAM stream per wave)
-    long long w, w_end, w_step;
-    if (map_mode == 0) { w = wave; w_end = n_items; w_step = n_waves; }
-    else { const long long per = (n_items + n_waves - 1) / n_waves; w = wave * per; w_end = w + per < n_items ? w + per : n_items; w_step = 1; }
-    // first used item of this wave
+    const uint32_t wave = block * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int n_out = 0;                                 // records this wave has emitted (uniform); its private raw region is shard `wave` (the grid is capped at RAW_SHARDS waves)
+    // wave walks items wave, wave + W, ...; first used item of this wave
+    uint32_t w = wave;
     ItemMeta mt;
-    for (;; w += w_step) {
-        if (w >= w_end) return;
-        mt = load_meta(b, w);
-        if (!scan_skips(b, w, mt)) break;
+    for (;; w += n_waves) {
+        if (w >= n_items) return;
+        mt = load_meta(items, w, n_rec, cigar, seg_cigar);
+        if (!(mt.flags & ITEM_SKIP)) break;
     }
-#if SVX_SCAN_RING > 0
-    __shared__ uint4 ring_all[4][SVX_SCAN_RING * 64];
-    uint4* ring = ring_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
-#else
-    uint4* ring = nullptr;
-#endif
+    RawIndel* out_raw = out.raw + (long long)wave * out.shard_cap;
+    const int shard_cap = (int)(out.shard_cap > 0x7fffffffll ? 0x7fffffffll : out.shard_cap);
     uint4 nx[SVX_SCAN_NU];
-    {
-        const bool is_rec = w < b.n_rec;
-        const uint32_t* cig = is_rec ? b.cigar : b.seg_cigar;
-        const unsigned long long tot = is_rec ? total_ops : total_seg_ops;
 #pragma unroll
-        for (int u = 0; u < SVX_SCAN_NU; u++) nx[u] = load_chunk(cig, (mt.off0 & ~3ull) + 256ull * u + (unsigned long long)lane_id() * 4, mt.off1, tot);
-    }
+    for (int u = 0; u < SVX_SCAN_NU; u++) nx[u] = load_chunk(mt.base, 256u * u + (uint32_t)lane_id() * 4, mt.len, mt.lim);
     for (;;) {
-        // next used item (its metadata comes through the scalar cache)
-        long long wn = w + w_step;
+        // next used item (its table entry comes through the scalar cache)
+        uint32_t wn = w;
         ItemMeta mtn = mt;
         bool has_next = false;
-        for (; wn < w_end; wn += w_step) {
-            mtn = load_meta(b, wn);
-            if (!scan_skips(b, wn, mtn)) { has_next = true; break; }
+        while (n_items - wn > n_waves) {
+            wn += n_waves;
+            mtn = load_meta(items, wn, n_rec, cigar, seg_cigar);
+            if (!(mtn.flags & ITEM_SKIP)) { has_next = true; break; }
         }
-        const bool is_rec = w < b.n_rec;
-        const bool need_geom = is_rec ? (!(mt.flag & 2048u) && mt.has_seg) : true;
-        int* geom_out = is_rec ? rec_geom + 5 * w : seg_geom + 5 * (w - b.n_rec);
-        if (need_geom) scan_item<true>(b, out, w, mt, is_rec, geom_out, total_ops, total_seg_ops, shard, n_out, nx, has_next, wn, mtn, ring);
-        else scan_item<false>(b, out, w, mt, is_rec, geom_out, total_ops, total_seg_ops, shard, n_out, nx, has_next, wn, mtn, ring);
+        if (!has_next) mtn.len = 0;
+        int* geom_out = geom + 5ll * w;
+        scan_item((mt.flags & ITEM_GEOM) != 0u, out_raw, shard_cap, w, mt, w < n_rec, geom_out, min_len, n_out, nx, mtn);
         if (!has_next) break;
         w = wn; mt = mtn;
     }
-    if (lane_id() == 0) out.shard_counter[shard] = (unsigned long long)n_out;
+    if (lane_id() == 0) out.shard_counter[wave] = (unsigned long long)n_out;
 }
 
-#ifdef SVX_SCAN_WAVES
+// built for eight waves per SIMD (<= 64 VGPRs, <= 80 SGPRs on gfx950; SVX_SCAN_WAVES=0: the compiler's own choice)
+#ifndef SVX_SCAN_WAVES
+#define SVX_SCAN_WAVES 8
+#endif
+#if SVX_SCAN_WAVES > 0
 #define SVX_SCAN_ATTR __attribute__((amdgpu_waves_per_eu(SVX_SCAN_WAVES, SVX_SCAN_WAVES)))
 #else
 #define SVX_SCAN_ATTR
 #endif
-__global__ __launch_bounds__(256) SVX_SCAN_ATTR void k_cigar_scan(ScanArgs b, RawTarget out, int* rec_geom, int* seg_geom, unsigned long long total_ops,
-                                                    unsigned long long total_seg_ops, int map_mode) {
-    scan_items(b, out, rec_geom, seg_geom, total_ops, total_seg_ops, map_mode, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(256) SVX_SCAN_ATTR void k_cigar_scan(const uint4* items, uint32_t n_rec, uint32_t n_items, const uint32_t* cigar, const uint32_t* seg_cigar,
+                                                                  int min_len, RawTarget out, int* geom) {
+    scan_items(items, n_rec, n_items, cigar, seg_cigar, min_len, out, geom, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(1024) void k_shard_prefix(const unsigned long long* shard_counter, long long shard_cap, long long* prefix,
@@ -727,8 +687,10 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
     hipStream_t st = c->stream;
     const svx_batch& b = *bd;
     SVXCHK(c->counters.reserve(16 * 8));
-    SVXCHK(c->rec_geom.reserve((size_t)(b.n_rec + 1) * 5 * 4));
-    SVXCHK(c->seg_geom.reserve((size_t)(b.n_seg + 1) * 5 * 4));
+    // geometry records of the records and, behind them, of the segment rows (one array: the scan addresses it by item); seg_geom holds the scan's item table
+    SVXCHK(c->rec_geom.reserve((size_t)(b.n_rec + b.n_seg + 2) * 5 * 4));
+    SVXCHK(c->seg_geom.reserve((size_t)(b.n_rec + b.n_seg + 1) * sizeof(uint4)));
+    int* const rec_geom_p = c->rec_geom.as<int>(); int* const seg_geom_p = rec_geom_p + 5 * b.n_rec;
     const size_t ws_n = (size_t)(b.n_seg + b.n_rec + 1);
     SVXCHK(c->seg_ws.reserve(ws_n * (sizeof(ASeg) + sizeof(TDup) + sizeof(Trn))));
     ASeg* ws_al = c->seg_ws.as<ASeg>();
@@ -736,9 +698,8 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
     Trn* ws_tr = reinterpret_cast<Trn*>(ws_td + ws_n);
     // total op counts (needed to bound the 16-byte loads at the very end of the arrays)
     uint64_t tot_ops = 0, tot_seg_ops = 0;
-    HIPCHK(hipMemcpyAsync(&tot_ops, b.cigar_off + b.n_rec, 8, hipMemcpyDeviceToHost, st));
-    if (b.n_seg > 0) HIPCHK(hipMemcpyAsync(&tot_seg_ops, b.seg_cigar_off + b.n_seg, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (b.n_seg > 0) SVXCHK(svx_mail_read2(c, st, b.cigar_off + b.n_rec, 1, &tot_ops, b.seg_cigar_off + b.n_seg, 1, &tot_seg_ops));
+    else SVXCHK(svx_mail_read(c, st, b.cigar_off + b.n_rec, 1, &tot_ops));
     int64_t cap_sig = c->raw_sig.cap > 0 ? c->raw_sig.cap : 0, cap_bnd = c->raw_bnd.cap > 0 ? c->raw_bnd.cap : 0;
     int64_t want_sig = (int64_t)(tot_ops / 256) + 4 * b.n_seg + 16 * (int64_t)RAW_SHARDS;      // >= 16 raw slots per wave-private region
     if (cap_sig < want_sig) cap_sig = want_sig;
@@ -755,12 +716,13 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
         const long long items = b.n_rec + b.n_seg;
         if (items > 0) {
             long long blocks = (items + 3) / 4;
-            static int per_cu = 0, scan_map = 0;                           // resident 256-thread blocks per CU for this kernel
-            { const char* e = getenv("SVX_SCAN_MAP"); if (e) scan_map = atoi(e); const char* f = getenv("SVX_SCAN_BLOCKS"); if (f) per_cu = atoi(f); }
+            if (items >= (1ll << 31)) return svx_fail(SVX_E_ARG, "more than 2^31 records + segment rows in one batch", __FILE__, __LINE__, hipSuccess);
+            static int per_cu = 0;                                         // resident 256-thread blocks per CU for this kernel
+            { const char* f = getenv("SVX_SCAN_BLOCKS"); if (f) per_cu = atoi(f); }
             if (!per_cu) {
                 int occ = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_cigar_scan, 256, 0) != hipSuccess || occ < 1) occ = 4;
-                per_cu = occ > 6 ? 6 : occ;                                // > 96 SGPRs: the hardware admits one block fewer than the API says
+                per_cu = occ > 8 ? 8 : occ;                                // 8 blocks = 8 waves per SIMD: the kernel is built for <= 64 VGPRs / <= 80 SGPRs (Makefile check)
             }
             long long max_blocks = (long long)c->n_cu * per_cu;
             if (max_blocks > RAW_SHARDS / 4) max_blocks = RAW_SHARDS / 4;
@@ -772,9 +734,17 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
             long long* shard_prefix = reinterpret_cast<long long*>(shard_counter + RAW_SHARDS);
             HIPCHK(hipMemsetAsync(shard_counter, 0, RAW_SHARDS * 8, st));
             RawTarget rt{c->raw_indel.as<RawIndel>(), shard_cap, shard_counter};
-            ScanArgs sa{b.n_rec, b.n_seg, b.flag, b.mapq, b.lseq, b.seg_off, b.cigar_off, b.cigar, b.seg_lseq, b.seg_cigar_off, b.seg_cigar, p->min_mapq, p->min_sv_size};
-            if (b.n_seg > 0) k_seg_geom_small<<<(unsigned)((b.n_seg + 255) / 256), 256, 0, st>>>(sa, c->seg_geom.as<int>());
-            k_cigar_scan<<<(unsigned)blocks, 256, 0, st>>>(sa, rt, c->rec_geom.as<int>(), c->seg_geom.as<int>(), tot_ops, tot_seg_ops, scan_map);
+            // the scan's 16-byte loads need an array of at least four operations (load_chunk): a smaller one is copied in front of no-op padding
+            const uint32_t* cigar_p = b.cigar; uint64_t tot_scan = tot_ops;
+            if (tot_ops < 4 && b.n_rec > 0) {
+                SVXCHK(c->tmp5.reserve(64));
+                HIPCHK(hipMemsetAsync(c->tmp5.p, 0x0f, 16, st));                      // op 15: advances nothing, reports nothing
+                if (tot_ops) HIPCHK(hipMemcpyAsync(c->tmp5.p, b.cigar, (size_t)tot_ops * 4, hipMemcpyDeviceToDevice, st));
+                cigar_p = c->tmp5.as<uint32_t>(); tot_scan = 4;
+            }
+            ScanArgs sa{b.n_rec, b.n_seg, b.flag, b.mapq, b.lseq, b.seg_off, b.cigar_off, cigar_p, b.seg_lseq, b.seg_cigar_off, b.seg_cigar, p->min_mapq, p->min_sv_size};
+            k_scan_prepare<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(sa, tot_scan, tot_seg_ops, c->seg_geom.as<uint4>(), rec_geom_p);
+            k_cigar_scan<<<(unsigned)blocks, 256, 0, st>>>(c->seg_geom.as<uint4>(), (uint32_t)b.n_rec, (uint32_t)items, cigar_p, b.seg_cigar, p->min_sv_size, rt, rec_geom_p);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev[5], st));
             // dense slots for the raw records; the total becomes the start of the segment kernel's allocations
@@ -785,13 +755,12 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
         }
         HIPCHK(hipEventRecord(c->ev[1], st));
         if (b.n_rec > 0 && b.n_seg > 0) {
-            k_segments<<<(unsigned)((b.n_rec + 255) / 256), 256, 0, st>>>(b, *p, ts, tb, c->rec_geom.as<int>(), c->seg_geom.as<int>(), ws_al, ws_td, ws_tr);
+            k_segments<<<(unsigned)((b.n_rec + 255) / 256), 256, 0, st>>>(b, *p, ts, tb, rec_geom_p, seg_geom_p, ws_al, ws_td, ws_tr);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(c->ev[2], st));
         if (b.n_rec > 0) k_count_used<<<(unsigned)std::min<long long>((b.n_rec + 255) / 256, 1024), 256, 0, st>>>(b, *p, c->counters.as<unsigned long long>());
-        HIPCHK(hipMemcpyAsync(h_cnt, c->counters.p, 16 * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        SVXCHK(svx_mail_read(c, st, c->counters.p, 16, h_cnt));
         if ((int64_t)h_cnt[CNT_SIG] <= c->raw_sig.cap && (int64_t)h_cnt[CNT_BND] <= c->raw_bnd.cap && h_cnt[CNT_OVERFLOW] == 0) break;
         if (attempt == 2) return svx_fail(SVX_E_CAPACITY, "signature buffers", __FILE__, __LINE__, hipSuccess);
         cap_sig = 2 * ((int64_t)h_cnt[CNT_SIG] + (int64_t)h_cnt[CNT_OVERFLOW]) + 64 * (int64_t)RAW_SHARDS; cap_bnd = (int64_t)h_cnt[CNT_BND] + 1024;
@@ -806,8 +775,7 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
     int64_t n_seq = 0;
     if (n_sig > 0 && !c->no_seq_gather) {
         SVXCHK(svx_exclusive_scan_i32_to_i64(c, c->sig.qlen.as<int32_t>(), c->sig.seq_off.as<int64_t>(), n_sig + 1));
-        HIPCHK(hipMemcpyAsync(&n_seq, c->sig.seq_off.as<int64_t>() + n_sig, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        SVXCHK(svx_mail_read(c, st, c->sig.seq_off.as<int64_t>() + n_sig, 1, &n_seq));
         SVXCHK(c->sig.seq.reserve((size_t)n_seq + 16));
         k_gather_seq<<<(unsigned)((n_sig + 3) / 4), 256, 0, st>>>(sig_ptrs(c->sig), n_sig, c->sig.seq_off.as<int64_t>(), c->sig.seq.as<uint8_t>(),
                                                                  b.seq_off, b.seq, b.seq_rng_off, b.seq_rng_q0, b.seq_rng_len, b.seq_rng_byte,
@@ -815,8 +783,7 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
         HIPCHK(hipGetLastError());
         if (b.seq_rng_off) {
             unsigned long long miss = 0;
-            HIPCHK(hipMemcpyAsync(&miss, c->counters.as<unsigned long long>() + CNT_SEQ_MISSING, 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            SVXCHK(svx_mail_read(c, st, c->counters.as<unsigned long long>() + CNT_SEQ_MISSING, 1, &miss));
             if (miss) return svx_fail(SVX_E_ARG, "sparse SEQ: the bases of a reported insertion are not in the batch (svx_bam_set_seq_filter larger than params.min_sv_size?)",
                                       __FILE__, __LINE__, hipSuccess);
         }

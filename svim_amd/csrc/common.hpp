@@ -171,6 +171,10 @@ struct svx_ctx {
     // 0 = none, 1 = word counts + offsets enqueued, 2 = packed (ev[18] marks the end)
     int prepack_state = 0; long long prepack_radius = 0, prepack_n = 0; DevBuf prepack_tmp;
     int64_t* pinned = nullptr;       // 4 KB of pinned host memory for small asynchronous read-backs
+    // Mailbox (api.hip, svx_mail_post / svx_mail_wait): the few words a host decision waits for in the middle of a call (list sizes, class bounds, retry
+    // counters) are written INTO page-locked host memory by a one-wave kernel at the end of the producing stream, behind a sequence word the host spins on -
+    // no copy command, no interrupt-driven wake-up.  SVX_MAILBOX=0: hipMemcpyAsync + hipStreamSynchronize (A/B switch).
+    unsigned long long* mail = nullptr; unsigned long long mail_seq = 0; int mail_mode = 1;
     DevBuf e_hist;
     bool edit_force_full = false;  // debugging aid (env SVX_EDIT_FORCE_FULL=1): every pair through the full-matrix kernel
     bool no_seq_gather = false;   // svx_cigar_indel hook: positions only
@@ -184,6 +188,36 @@ int svx_sort_pairs_u64(svx_ctx* c, const uint64_t* keys_in, uint64_t* keys_out, 
 int svx_exclusive_scan_i64(svx_ctx* c, const int64_t* in, int64_t* out, int64_t n);   // out[n] NOT written
 int svx_exclusive_scan_i64_on(svx_ctx* c, const int64_t* in, int64_t* out, int64_t n, hipStream_t stream, DevBuf& tmp);
 int svx_exclusive_scan_i32_to_i64(svx_ctx* c, const int32_t* in, int64_t* out, int64_t n);
+
+#define SVX_MAIL_SLOTS 16
+#define SVX_MAIL_WORDS 512           /* per slot, word 0 = sequence flag: up to 511 payload words (8 bytes each) */
+// post: after everything enqueued on `st` so far, the 64-bit words of up to four device arrays travel to the host, one after the other; wait: blocks until
+// they are there (payload = the words).  read / gather: post + wait + copy out.
+struct MailSrc { const void* p[4]; int n[4]; int k; };
+int svx_mail_post(svx_ctx* c, hipStream_t st, const MailSrc& src, unsigned long long* ticket);
+int svx_mail_wait(svx_ctx* c, hipStream_t st, unsigned long long ticket, const unsigned long long** payload);
+inline int svx_mail_gather(svx_ctx* c, hipStream_t st, int k, const void* const* srcs, const int* n_words, void* const* dsts) {
+    MailSrc m; memset(&m, 0, sizeof m);
+    m.k = k;
+    for (int j = 0; j < k; j++) { m.p[j] = srcs[j]; m.n[j] = n_words[j]; }
+    unsigned long long t = 0; const unsigned long long* w = nullptr;
+    SVXCHK(svx_mail_post(c, st, m, &t));
+    SVXCHK(svx_mail_wait(c, st, t, &w));
+    for (int j = 0; j < k; j++) { memcpy(dsts[j], w, (size_t)n_words[j] * 8); w += n_words[j]; }
+    return SVX_OK;
+}
+inline int svx_mail_read(svx_ctx* c, hipStream_t st, const void* dev_src, int n_words, void* host_dst) {
+    const void* srcs[1] = {dev_src}; const int n[1] = {n_words}; void* dsts[1] = {host_dst};
+    return svx_mail_gather(c, st, 1, srcs, n, dsts);
+}
+inline int svx_mail_read2(svx_ctx* c, hipStream_t st, const void* a, int na, void* da, const void* b, int nb, void* db) {
+    const void* srcs[2] = {a, b}; const int n[2] = {na, nb}; void* dsts[2] = {da, db};
+    return svx_mail_gather(c, st, 2, srcs, n, dsts);
+}
+inline int svx_mail_read3(svx_ctx* c, hipStream_t st, const void* a, int na, void* da, const void* b, int nb, void* db, const void* e, int ne, void* de) {
+    const void* srcs[3] = {a, b, e}; const int n[3] = {na, nb, ne}; void* dsts[3] = {da, db, de};
+    return svx_mail_gather(c, st, 3, srcs, n, dsts);
+}
 
 void svx_preload_collect(); void svx_preload_cluster(); void svx_preload_edit(); void svx_preload_prims();      // code objects loaded at context creation
 

@@ -109,7 +109,9 @@ __device__ __forceinline__ Hap plain_hap(const uint8_t* s, int n) {
 // pair the signature takes part in is a substring of its record; for the plain entry point a record is the string itself.
 #define HAP_ZERO 1            /* the record holds code 0 ('=') */
 #define HAP_OTHER 2           /* the record holds a symbol that is not exactly one of A, C, G, T */
-struct HapRec { unsigned long long word_off; int left, len, right, flags; };
+// start / clen (round 6): the signature's start and the length of its contig, so that a pair's views come from its two records alone - k_edit_prep is bound by
+// its chain of dependent loads, and work item -> start / contig columns -> contig offsets -> records was three links of it (now: work item -> records)
+struct HapRec { unsigned long long word_off; int left, len, right, flags; int start, clen; };
 // a haplotype as the pair kernels see it: `len` symbols starting `off` symbols into record words w[]
 struct HapView { unsigned long long word_off; int off, len, flags; };
 
@@ -152,12 +154,11 @@ struct PairSource {
             B.word_off = rb.word_off; B.off = 0; B.len = rb.len; B.flags = rb.flags;
         } else {
             const EditWork wk = work[w];
-            const long long s1 = in.start[wk.a], s2 = in.start[wk.b];
+            const HapRec ra = rec[wk.a], rb = rec[wk.b];
+            const long long s1 = ra.start, s2 = rb.start;
             const long long ws = (s1 < s2 ? s1 : s2) - 100, we = (s1 > s2 ? s1 : s2) + 100;
             shift = (int)(s2 - s1);
-            const int c1 = in.contig[wk.a], c2 = in.contig[wk.b];
-            const long long l1 = g_off[c1 + 1] - g_off[c1], l2 = g_off[c2 + 1] - g_off[c2];
-            const HapRec ra = rec[wk.a], rb = rec[wk.b];
+            const long long l1 = ra.clen, l2 = rb.clen;
             const int la = fetch_len(l1, ws, s1), ra_ = fetch_len(l1, s1, we);
             const int lb = fetch_len(l2, ws, s2), rb_ = fetch_len(l2, s2, we);
             A.word_off = ra.word_off; A.off = ra.left - la; A.len = la + ra.len + ra_; A.flags = ra.flags;
@@ -239,13 +240,21 @@ __device__ __forceinline__ int need_window(int m, int n, int ub) {
     return (n - m) + 2 * x + 1;
 }
 
+// The sort key of the work list is 24 bits = three radix passes (round 6; 40 bits = five passes before: 0.11 ms of the window): 7 bits of sort class
+// (SORT_ANSWERED = behind every class) over 17 bits of cost order.  The order inside a class only decides which pairs share a wave - results are written by slot.
+#define SORT_COST_BITS 17
+#define SORT_ANSWERED 127ull
 __device__ __forceinline__ unsigned long long work_key(int cls, int m, int n) {
     // descending cost inside a class: the longest-running waves are dispatched first, the short ones fill the tail
-    const unsigned long long nn = (unsigned long long)(n > 0x3ffff ? 0x3ffff : n);
-    unsigned long long k = nn;
-    if (cls == CLS_FULL) k = ((unsigned long long)(m > 0x3fff ? 0x3fff : m) << 18) | nn;          // systolic: rows decide the lane count
-    return 0xffffffffull - k;
+    const unsigned long long top = (1ull << SORT_COST_BITS) - 1;
+    unsigned long long k = (unsigned long long)n > top ? top : (unsigned long long)n;
+    if (cls == CLS_FULL) {                                   // systolic: rows decide the lane count - 9 bits of rows (units of 64) over 8 bits of text length (units of 256)
+        const unsigned long long mm = (unsigned long long)(m >> 6) > 511 ? 511 : (unsigned long long)(m >> 6), nn = (unsigned long long)(n >> 8) > 255 ? 255 : (unsigned long long)(n >> 8);
+        k = (mm << 8) | nn;
+    }
+    return top - k;
 }
+__device__ __forceinline__ unsigned long long sort_key_of(unsigned long long sort_cls, unsigned long long cost_key) { return (sort_cls << SORT_COST_BITS) | cost_key; }
 
 __device__ __forceinline__ int full_class_for(int m) {
     if (m <= 512) return CLS_LANE0 + lane_class_for(m);
@@ -328,7 +337,13 @@ __global__ __launch_bounds__(256) void k_hap_pack(long long n_rec, PairSource sr
     zero = __any(zero); other = __any(other);
     if (lane == 0) {
         HapRec hr; hr.word_off = base; hr.left = h.n0; hr.len = h.n1; hr.right = h.n2; hr.flags = (zero ? HAP_ZERO : 0) | (other ? HAP_OTHER : 0);
+        hr.start = 0; hr.clen = 0;
         if (src.plain) { hr.left = 0; hr.len = h.len; hr.right = 0; }
+        else {
+            const int ctg = src.in.contig[r];
+            const long long cl = src.g_off[ctg + 1] - src.g_off[ctg];
+            hr.start = src.in.start[r]; hr.clen = cl > 0x7fffffffll ? 0x7fffffff : (int)cl;      // (BAM positions are 32-bit: no contig is longer)
+        }
         rec[r] = hr;
     }
 }
@@ -356,13 +371,21 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     const uint32_t* wa = packed + A.word_off; const uint32_t* wb = packed + B.word_off;
     const int la = A.len, lb = B.len;
     const int mn = la < lb ? la : lb;
-    // common prefix / suffix, 8 symbols per lane and step
+    // common prefix / suffix, 8 symbols per lane and step.  The first trips of the two walks are loaded together (round 6: the suffix walk's addresses do
+    // not depend on the prefix, only its symbol count does - one round trip less in the chain of dependent loads)
+    uint32_t xp0 = 0, xs0 = 0;
+    if (mn - lane * 8 > 0) {
+        const uint32_t pa = fetch8(wa, A.off + lane * 8), pb = fetch8(wb, B.off + lane * 8);
+        const uint32_t sa = fetch8(wa, A.off + la - lane * 8 - 8), sb = fetch8(wb, B.off + lb - lane * 8 - 8);
+        xp0 = pa ^ pb; xs0 = sa ^ sb;
+    }
     int pre = mn;
     for (int base = 0; base < mn; base += 8 * G) {
         const int i0 = base + lane * 8;
         const int cnt = mn - i0 >= 8 ? 8 : (mn - i0 < 0 ? 0 : mn - i0);
         uint32_t x = 0;
-        if (cnt > 0) x = fetch8(wa, A.off + i0) ^ fetch8(wb, B.off + i0);
+        if (base == 0) x = cnt > 0 ? xp0 : 0u;
+        else if (cnt > 0) x = fetch8(wa, A.off + i0) ^ fetch8(wb, B.off + i0);
         const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
         int k = nz ? (__ffs((int)nz) - 1) >> 2 : 8;                       // first differing symbol of the chunk
         if (k > cnt) k = cnt;
@@ -375,7 +398,8 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
         const int i0 = base + lane * 8;
         const int cnt = lim - i0 >= 8 ? 8 : (lim - i0 < 0 ? 0 : lim - i0);
         uint32_t x = 0;
-        if (cnt > 0) x = fetch8(wa, A.off + la - i0 - 8) ^ fetch8(wb, B.off + lb - i0 - 8);
+        if (base == 0) x = cnt > 0 ? xs0 : 0u;
+        else if (cnt > 0) x = fetch8(wa, A.off + la - i0 - 8) ^ fetch8(wb, B.off + lb - i0 - 8);
         const uint32_t nz = (x | (x << 1) | (x << 2) | (x << 3)) & 0x88888888u;
         int k = nz ? __clz((int)nz) >> 2 : 8;                              // matching symbols counted from the end of the chunk
         if (k > cnt) k = cnt;
@@ -393,7 +417,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
     pd.txt = T.word_off + (unsigned long long)(t0 >> 3);
     const int sh_bits = ((p0 & 7) << 12) | ((t0 & 7) << 16) | ((shift > 2047 ? 2047 : shift) << 20);
     if (pd.m == 0) {                                   // one core is empty: the distance is the other's length
-        if (lane == 0) { ed[src.slot(w)] = pd.n; pd.ub = pd.n; pd.cls = -1; desc[w] = pd; sort_key[w] = 0xffull << 32; sort_val[w] = (uint32_t)w; }
+        if (lane == 0) { ed[src.slot(w)] = pd.n; pd.ub = pd.n; pd.cls = -1; desc[w] = pd; sort_key[w] = sort_key_of(SORT_ANSWERED, 0); sort_val[w] = (uint32_t)w; }
         return;
     }
     // Upper bounds from trivial alignments: substitutions only, the pattern pushed `a` and the text `b` symbols to the right
@@ -450,7 +474,7 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
 }
 
 // first class of every pair + its sort key (one thread per pair)
-__global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort_key, uint32_t* sort_val, int force_full, float guess_frac, int few_pairs) {
+__global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort_key, uint32_t* sort_val, int force_full, const unsigned long long* guess_word, int few_pairs) {
     const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_work) return;
     const PairDesc pd = desc[w];
@@ -463,6 +487,7 @@ __global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort
         // shifts the two cores against each other) start from a band sized for guess_frac * m differences and widen on failure.
         const int guaranteed = band_class_for(need_window(pd.m, pd.n, pd.ub));
         int guess = 2 * MIN_MARGIN;
+        const float guess_frac = __uint_as_float((uint32_t)guess_word[0]);          // k_edit_guess / the host's fallback (cnt[2])
         const int by_frac = (int)ceilf(guess_frac * (float)pd.m);
         if (by_frac > guess) guess = by_frac;
         guess += 2 * CLS_SHIFT(pd.cls);                 // what the position shift alone costs (see PairSource::views)
@@ -483,7 +508,7 @@ __global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort
         cls = pd.m <= 4096 ? CLS_WIDE0 + 2 : (pd.m <= 6144 ? CLS_WIDE12 + 3 : (pd.m <= 8192 ? CLS_WIDE0 + 3 : CLS_FULL));
     const int flagged = cls | (pd.cls & ~0xff);
     desc[w].cls = flagged;
-    sort_key[w] = (sort_class(flagged) << 32) | work_key(cls, pd.m, pd.n);
+    sort_key[w] = sort_key_of(sort_class(flagged), work_key(cls, pd.m, pd.n));
     sort_val[w] = (uint32_t)w;
 }
 
@@ -674,6 +699,59 @@ __global__ __launch_bounds__(256) void k_edit_pilot(long long n_work, long long 
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(hist + threadIdx.x, h[threadIdx.x]);
+}
+
+// The speculation fraction from the pilot's histogram, on the device (round 6: the host used to fetch the 256 bins and wait for them - one stream
+// synchronisation less in front of the rounds).  Same rule as guess_from_histogram below (kept for the profile output): the g with the least expected
+// cost; thread b prices g = (b + 1) / 256, the first of the cheapest wins.  out[0] = the fraction (float bits), unchanged when the histogram is empty.
+__global__ __launch_bounds__(128) void k_edit_guess(const unsigned long long* hist, unsigned long long* out) {
+    __shared__ double cum[257];
+    __shared__ double cost_of[128];
+    if (threadIdx.x == 0) {
+        double total = 0;
+        cum[0] = 0;
+        for (int b = 0; b < 256; b++) { total += (double)hist[b]; cum[b + 1] = total; }
+    }
+    __syncthreads();
+    const double total = cum[256];
+    const int b = (int)threadIdx.x;
+    double cost = 1e300;
+    if (b >= 3 && b < 128 && total > 0) {
+        const double g = (b + 1) / 256.0;
+        cost = g;
+        for (double w = g; w < 1.0; w *= 2) {
+            int q = (int)(w * 256.0); if (q > 256) q = 256;
+            cost += (2 * w <= 0.5 ? 2 * w : 0.75) * (1.0 - cum[q] / total);
+        }
+    }
+    cost_of[b] = cost;
+    __syncthreads();
+    if (threadIdx.x == 0 && total > 0) {
+        int best = 31; double best_cost = 1e300;
+        for (int k = 3; k < 128; k++) if (cost_of[k] < best_cost) { best_cost = cost_of[k]; best = k; }
+        out[0] = (unsigned long long)__float_as_uint((float)((best + 2) / 256.0));
+    }
+}
+
+// What the host wants to know when the rounds are over, in one post (svx_mail_*): [0] pairs too long for the register forms, [1] the speculation fraction
+// (float bits), [2..5] word-columns issued / useful / of retry rounds / of band launches, summed over the shards of every (round, kind) counter block.
+__global__ __launch_bounds__(256) void k_edit_tail(const unsigned long long* cnt, const unsigned long long* wc, int rounds, unsigned long long* out) {
+    __shared__ unsigned long long acc[4];
+    if (threadIdx.x < 4) acc[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long iss = 0, use = 0, retry = 0, band = 0;
+    const int per = 2 * WC_SHARDS;
+    for (int i = (int)threadIdx.x; i < rounds * 2 * WC_SHARDS; i += 256) {
+        const int blockno = i / WC_SHARDS, sh = i % WC_SHARDS, r = blockno >> 1, k = blockno & 1;
+        const unsigned long long a = wc[(size_t)blockno * per + 2 * sh], u = wc[(size_t)blockno * per + 2 * sh + 1];
+        iss += a; use += u;
+        if (r > 0) retry += a;
+        if (k == 0) band += a;
+    }
+    atomicAdd(&acc[0], iss); atomicAdd(&acc[1], use); atomicAdd(&acc[2], retry); atomicAdd(&acc[3], band);
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] = cnt[1]; out[1] = cnt[2]; }
+    if (threadIdx.x < 4) out[2 + threadIdx.x] = acc[threadIdx.x];
 }
 
 // ---- 3a. banded lane-per-pair kernel, staircase window (classes 1..8) ------------------------------------------------------
@@ -1370,7 +1448,7 @@ __global__ void k_class_bounds(const uint64_t* keys, long long n, long long* bou
     const int c = threadIdx.x;
     if (c > N_SORT_CLASSES) return;
     long long lo = 0, hi = n;
-    while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)(keys[mid] >> 32) < c) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)(keys[mid] >> SORT_COST_BITS) < c) lo = mid + 1; else hi = mid; }
     bounds[c] = lo;
 }
 
@@ -1462,6 +1540,8 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     SVXCHK(c->e_fail.reserve(CNT_WORDS * 8));
     unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..40] class bounds of round 0 (first [16..31] the span shards), [128 + 64 r ..] retry counters written by round r, [WC_OFF ..] word-column counters per (round, kind)
     HIPCHK(hipMemsetAsync(cnt, 0, CNT_WORDS * 8, st));
+    // cnt[2]: the speculation fraction k_edit_classify reads (float bits) - the fallback here, overwritten by k_edit_guess when the call is sampled
+    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cnt + 2), (int)__builtin_bit_cast(uint32_t, c->edit_guess), 1, st));
     // 1. packed store: one record per string / signature
     src.radius = 0;
     const bool prepacked = !src.plain && c->prepack_state == 2 && c->prepack_n == src.in.n;
@@ -1472,8 +1552,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     } else if (!src.plain) {
         k_pair_span<<<(unsigned)(c->n_cu * 4), T, 0, st>>>(n_work, src, cnt);
         unsigned long long shard[16], span = 0;
-        HIPCHK(hipMemcpyAsync(shard, cnt + 16, sizeof shard, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        SVXCHK(svx_mail_read(c, st, cnt + 16, 16, shard));
         for (unsigned long long v : shard) span = v > span ? v : span;
         src.radius = (long long)span + 100;
     }
@@ -1489,8 +1568,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         src.rec = c->e_rec.as<HapRec>();
         k_hap_words<<<(unsigned)((n_rec + 1 + T - 1) / T), T, 0, st>>>(n_rec, src, c->e_words.as<int64_t>());
         SVXCHK(svx_exclusive_scan_i64(c, c->e_words.as<int64_t>(), c->e_off.as<int64_t>(), n_rec + 1));
-        HIPCHK(hipMemcpyAsync(&total_words, c->e_off.as<int64_t>() + n_rec, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        SVXCHK(svx_mail_read(c, st, c->e_off.as<int64_t>() + n_rec, 1, &total_words));
         SVXCHK(c->e_scratch.reserve((size_t)(total_words + 64) * 4));
         HIPCHK(hipMemsetAsync(c->e_scratch.p, 0, 4, st));                    // the leading pad word
         k_hap_pack<<<(unsigned)((n_rec + 3) / 4), 256, 0, st>>>(n_rec, src, c->e_off.as<int64_t>(), c->e_scratch.as<uint32_t>(), c->e_rec.as<HapRec>());
@@ -1521,25 +1599,32 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         HIPCHK(hipMemsetAsync(c->e_hist.p, 0, 256 * 8, st));
         const long long stride = (n_work + PILOT_MAX - 1) / PILOT_MAX, n_samp = (n_work + stride - 1) / stride;
         k_edit_pilot<<<(unsigned)((n_samp + 255) / 256), 256, 0, st>>>(n_work, stride, desc, scratch, c->e_hist.as<unsigned long long>());
-        unsigned long long h[256];
-        HIPCHK(hipMemcpyAsync(h, c->e_hist.p, sizeof h, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        guess = guess_from_histogram(h, guess);
-        c->edit_guess_last = guess;
-        if (profile) fprintf(stderr, "{\"edit_guess_pilot\": %.4f, \"sampled_pairs\": %lld}\n", guess, n_samp);
+        k_edit_guess<<<1, 128, 0, st>>>(c->e_hist.as<unsigned long long>(), cnt + 2);        // the host learns the value with the last post of the call (k_edit_tail)
+        HIPCHK(hipGetLastError());
+        if (profile) {
+            unsigned long long gw = 0;
+            SVXCHK(svx_mail_read(c, st, cnt + 2, 1, &gw));
+            guess = __builtin_bit_cast(float, (uint32_t)gw);
+            fprintf(stderr, "{\"edit_guess_pilot\": %.4f, \"sampled_pairs\": %lld}\n", guess, n_samp);
+        }
     }
     int narrow_windows = 1;                                 // SVX_EDIT_NARROW=0: static staircase windows (A/B switch; results are the same either way)
     if (const char* e = getenv("SVX_EDIT_NARROW")) narrow_windows = atoi(e) == 0 ? 0 : 1;
     long long few_pairs = 2048;                             // SVX_EDIT_FEW_PAIRS: calls with at most this many pairs take the low-latency route (0 = never)
     if (const char* e = getenv("SVX_EDIT_FEW_PAIRS")) few_pairs = atoll(e);
-    k_edit_classify<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, desc, key_a, val_a, c->edit_force_full ? 1 : 0, guess, n_work <= few_pairs ? 1 : 0);
+    k_edit_classify<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, desc, key_a, val_a, c->edit_force_full ? 1 : 0, cnt + 2, n_work <= few_pairs ? 1 : 0);
     HIPCHK(hipGetLastError());
     // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
-    SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, 40));      // 32 bits of cost order + 6 bits of class (+2 spare)
+    SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, SORT_COST_BITS + 7));      // 17 bits of cost order + 7 bits of class: three passes
     k_class_bounds<<<1, 128, 0, st>>>(key_b, n_work, reinterpret_cast<long long*>(cnt + 8));
     long long bounds[N_SORT_CLASSES + 1];
-    HIPCHK(hipMemcpyAsync(bounds, cnt + 8, (N_SORT_CLASSES + 1) * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    SVXCHK(svx_mail_read(c, st, cnt + 8, N_SORT_CLASSES + 1, bounds));
+    // A retry round with only a few band pairs is bound by the LATENCY of its slowest pair: a band retry walks its columns in one lane with 6-16 state words
+    // (configs[1], round 1: 196 pairs, one wave of 16-word windows = 0.31 ms at the very end of the window), the systolic full matrix spreads the rows of the
+    // same pair over 64 lanes and never fails, so the round is also the last.  Up to this many band pairs of a retry round go there
+    // (SVX_EDIT_RETRY_FULL, 0 = never; the distances are exact either way).
+    long long retry_full = 4096;
+    if (const char* e = getenv("SVX_EDIT_RETRY_FULL")) retry_full = atoll(e);
 
     // 4. rounds.  Full-matrix classes (never fail, most of the work and the longest serial chains) run on high-priority streams, band classes (may fail)
     // on low-priority ones (api.hip, SVX_EDIT_PRIO), each kind as ONE fused launch per round.  A failing pair is appended to the retry list of its next
@@ -1629,8 +1714,31 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         // beside the rest of the round (early_cn: what of every retry list has been launched already).
         const int SPLIT_CLS = 7;                              // classes 7, 8 (14 / 16 words): the first part, and the only ones that need the 16-word kernel
         bool split_used[2] = {false, false};
+        long long band_pending = 0;
+        for (int generic = 0; generic <= 1; generic++) for (int cls = 0; cls < NBAND; cls++) band_pending += seg_cn[GENERIC_BASE * generic + cls];
+        const bool bands_as_fulls = round >= 1 && band_pending > 0 && band_pending <= retry_full && !c->edit_force_full;
         for (int generic = 0; generic <= 1; generic++) {
             const int base = GENERIC_BASE * generic;
+            if (bands_as_fulls) {
+                // the band lists of this alphabet as systolic full matrices, one launch beside the round's full-matrix launch
+                FusedTab tf; memset(&tf, 0, sizeof tf);
+                unsigned nblk = 0;
+                for (int cls = NBAND - 1; cls >= 0; cls--) {
+                    const long long cn = seg_cn[base + cls];
+                    if (cn <= 0) continue;
+                    tf.kind[tf.n] = CLS_FULL; tf.lo[tf.n] = seg_lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
+                    nblk += (unsigned)((cn * 64 + T - 1) / T); tf.n++;
+                }
+                tf.first_block[tf.n] = nblk;
+                if (tf.n) {
+                    hipStream_t fs = full_st[round & 1];
+                    if (generic) k_edit_fulls<4><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc_full);
+                    else k_edit_fulls<2><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc_full);
+                    HIPCHK(hipGetLastError());
+                }
+                SVXCHK(launch_fulls(generic, seg_lo, seg_cn, list, full_st[round & 1], wc_full, round));
+                continue;
+            }
             bool any_wide = false, any_narrow = false;
             for (int cls = 0; cls < NBAND; cls++) if (seg_cn[base + cls] > 0) { if (cls >= SPLIT_CLS) any_wide = true; else any_narrow = true; }
             const bool split = round == 0 && !serial && any_wide && any_narrow && !getenv("SVX_EDIT_NO_EARLY");
@@ -1662,7 +1770,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                     else k_edit_bands<2, 12><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
                 }
                 HIPCHK(hipGetLastError());
-                if (split && part == 0) { HIPCHK(hipEventRecord(c->ev[20 + generic], bs)); split_used[generic] = true; }
+                if (split && part == 0) split_used[generic] = true;
                 if (serial) {                                                        // SVX_EDIT_SERIAL=1: stand-alone kernel durations for profiling
                     HIPCHK(hipEventRecord(c->ev[7], band_st[generic]));
                     HIPCHK(hipStreamSynchronize(band_st[generic]));
@@ -1675,10 +1783,8 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         long long early_cn[N_SORT_CLASSES];
         for (int sc = 0; sc < N_SORT_CLASSES; sc++) early_cn[sc] = 0;
         if (split_used[0] || split_used[1]) {
-            for (int g = 0; g <= 1; g++) if (split_used[g]) HIPCHK(hipEventSynchronize(c->ev[20 + g]));
             unsigned long long h[N_SORT_CLASSES];
-            HIPCHK(hipMemcpyAsync(h, fail_cnt, sizeof h, hipMemcpyDeviceToHost, st));         // the main stream is idle during the rounds
-            HIPCHK(hipStreamSynchronize(st));
+            SVXCHK(svx_mail_read(c, c->aux[5], fail_cnt, N_SORT_CLASSES, h));              // posted behind the first part(s) on their (high-priority) stream
             long long e_lo[N_SORT_CLASSES];
             for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
                 e_lo[sc] = (long long)sc * pending;
@@ -1694,11 +1800,11 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         pending = 0;
         for (int sc = 0; sc < N_SORT_CLASSES; sc++) { seg_lo[sc] = (long long)sc * cap; seg_cn[sc] = 0; }
         if (band_used[0] || band_used[1]) {
-            for (int g = 0; g <= 1; g++) if (band_used[g]) HIPCHK(hipStreamSynchronize(band_st[g]));
-            if (split_used[0] || split_used[1]) HIPCHK(hipStreamSynchronize(c->aux[5]));
+            // one post for the round: the main stream (idle during the rounds, not a low-priority one) waits for every band stream and sends the counters
+            for (int g = 0; g <= 1; g++) if (band_used[g]) { HIPCHK(hipEventRecord(c->ev[22 + g], band_st[g])); HIPCHK(hipStreamWaitEvent(st, c->ev[22 + g], 0)); }
+            if (split_used[0] || split_used[1]) { HIPCHK(hipEventRecord(c->ev[19], c->aux[5])); HIPCHK(hipStreamWaitEvent(st, c->ev[19], 0)); }
             unsigned long long h[N_SORT_CLASSES];
-            HIPCHK(hipMemcpyAsync(h, fail_cnt, sizeof h, hipMemcpyDeviceToHost, band_st[0]));
-            HIPCHK(hipStreamSynchronize(band_st[0]));
+            SVXCHK(svx_mail_read(c, st, fail_cnt, N_SORT_CLASSES, h));
             for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
                 seg_lo[sc] += early_cn[sc];                                       // that part of the list is running already
                 seg_cn[sc] = (long long)h[sc] - early_cn[sc];
@@ -1707,7 +1813,14 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         }
         list = fb.as<uint32_t>();
     }
-    for (int k = 0; k < 2; k++) HIPCHK(hipStreamSynchronize(full_st[k]));
+    // the end of the rounds: the main stream waits for both full-matrix streams, sums the counters (k_edit_tail) and posts them - one wait for the host
+    unsigned long long tail[6];
+    for (int k = 0; k < 2; k++) { HIPCHK(hipEventRecord(c->ev[22 + k], full_st[k])); HIPCHK(hipStreamWaitEvent(st, c->ev[22 + k], 0)); }
+    k_edit_tail<<<1, 256, 0, st>>>(cnt, cnt + WC_OFF, MAX_ROUNDS, cnt + 8);             // (the class bounds at cnt[8..] are history by now)
+    HIPCHK(hipGetLastError());
+    SVXCHK(svx_mail_read(c, st, cnt + 8, 6, tail));
+    guess = __builtin_bit_cast(float, (uint32_t)tail[1]);
+    c->edit_guess_last = guess;
     if (profile && !first_desc.empty()) {
         // how much wider than necessary was the first band of every pair?  (needed = narrowest band class that certifies the distance found in the end)
         std::vector<long long> slot((size_t)n_work);
@@ -1772,19 +1885,9 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                 ratio_hist[0], ratio_hist[1], ratio_hist[2], ratio_hist[3], ratio_hist[4], ratio_hist[5], ratio_hist[6], ratio_hist[7]);
     }
     {
-        std::vector<unsigned long long> wch((size_t)MAX_ROUNDS * 2 * WC_PER_LAUNCH);
-        unsigned long long nb = 0;
-        HIPCHK(hipMemcpyAsync(&nb, cnt + 1, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(wch.data(), cnt + WC_OFF, wch.size() * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        for (int r = 0; r < MAX_ROUNDS; r++)
-            for (int k = 0; k < 2; k++)
-                for (int sh = 0; sh < WC_SHARDS; sh++) {
-                    const unsigned long long iss = wch[((size_t)(r * 2 + k)) * WC_PER_LAUNCH + 2 * sh], use = wch[((size_t)(r * 2 + k)) * WC_PER_LAUNCH + 2 * sh + 1];
-                    c->stats.n_edit_wordcols_issued += (int64_t)iss; c->stats.n_edit_wordcols_useful += (int64_t)use;
-                    if (r > 0) c->stats.n_edit_wordcols_retry += (int64_t)iss;
-                    if (k == 0) c->stats.n_edit_wordcols_band += (int64_t)iss;
-                }
+        const unsigned long long nb = tail[0];
+        c->stats.n_edit_wordcols_issued += (int64_t)tail[2]; c->stats.n_edit_wordcols_useful += (int64_t)tail[3];
+        c->stats.n_edit_wordcols_retry += (int64_t)tail[4]; c->stats.n_edit_wordcols_band += (int64_t)tail[5];
         c->stats.edit_guess = guess;
         if (nb) {
             // rare: shorter core > 16384 symbols.  Size the block-state scratch exactly from the core lengths.

@@ -765,7 +765,8 @@ def test_edit_distance_narrowing_windows_vs_oracle(oracle, monkeypatch, guess):
 
 def test_edit_distance_routes_do_not_change_results(oracle, monkeypatch):
     """The band speculation (SVX_EDIT_GUESS pinned tiny / huge, or chosen by the per-call pilot from a sample of the call's own
-    pairs) and the forced full-matrix route are performance choices only: every route must return the oracle's distances."""
+    pairs), the forced full-matrix route and the route of a small retry round are performance choices only: every route must return the
+    oracle's distances."""
     from svim_amd._lib import Engine
     rng = random.Random(5)
     pairs = []
@@ -791,8 +792,12 @@ def test_edit_distance_routes_do_not_change_results(oracle, monkeypatch):
     exp = [oracle.edit_distance(a, b) for a, b in pairs[:400]]
     results = []
     for env in ({"SVX_EDIT_GUESS": "0.004"}, {"SVX_EDIT_GUESS": "0.45"}, {"SVX_EDIT_FORCE_FULL": "1"}, {"SVX_EDIT_NARROW": "0"},
-                {"SVX_EDIT_NARROW": "0", "SVX_EDIT_GUESS": "0.2"}, {"SVX_EDIT_GUESS": "0.2"}, {}):
-        for k in ("SVX_EDIT_GUESS", "SVX_EDIT_FORCE_FULL", "SVX_EDIT_NARROW"):
+                {"SVX_EDIT_NARROW": "0", "SVX_EDIT_GUESS": "0.2"}, {"SVX_EDIT_GUESS": "0.2"},
+                # retry rounds: band pairs of a small retry round as systolic full matrices (round 6) - never / always / default (<= 4096 pairs);
+                # the host's waits through the mailbox or through copy + stream synchronisation
+                {"SVX_EDIT_GUESS": "0.004", "SVX_EDIT_RETRY_FULL": "0"}, {"SVX_EDIT_GUESS": "0.004", "SVX_EDIT_RETRY_FULL": "1000000"},
+                {"SVX_EDIT_RETRY_FULL": "0"}, {"SVX_MAILBOX": "0"}, {}):
+        for k in ("SVX_EDIT_GUESS", "SVX_EDIT_FORCE_FULL", "SVX_EDIT_NARROW", "SVX_EDIT_RETRY_FULL", "SVX_MAILBOX"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -11,6 +11,13 @@ micro)
   for b in ${BINS:-valu_banks}; do timeout 300 tools/micro/$b.bin > $out/${tag}_$b.txt 2>&1; echo "$b rc=$?"; done
   cat $out/${tag}_valu_banks.txt 2>/dev/null | head -80
   ;;
+quick)
+  # the hot-path parity tests named by K (pytest -k), then an A/B:  K="edit_distance or c1_full" VARIANTS="tree tree@SVX_MAILBOX=0"
+  timeout 1200 python -m pytest tests/ -x -q -m gpu -k "${K:-edit_distance}" --durations=5 > $out/${tag}_pytest_quick.txt 2>&1
+  echo "quick: rc=$? $(tail -1 $out/${tag}_pytest_quick.txt)"
+  [ -n "${VARIANTS:-}" ] && bash tools/ab.sh "${WL:-c1}" $VARIANTS 2>&1 | tee $out/${tag}_ab.txt
+  [ -n "${E2E:-}" ] && bash tools/gpu_r06.sh e2e $tag
+  ;;
 suite)
   timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=8 > $out/${tag}_pytest.txt 2>&1
   echo "suite: rc=$? $(tail -1 $out/${tag}_pytest.txt)"
