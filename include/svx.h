@@ -19,6 +19,8 @@
  *     hipHostRegister, no copy call of the runtime ever sees their address) - every host <-> device copy goes through page-locked
  *     buffers the library owns (csrc/hostcopy.hip).  An input array may be changed or freed as soon as the call returns; an output
  *     array holds its data when the call returns
+ *   - the exception a caller can ask for: an input array that lies in memory from svx_host_alloc (page-locked, owned by the library, mapped
+ *     until the process ends) is read by the copy engine in place - no bounce pass (what a numpy array costs: one memcpy of its bytes)
  *   - one context per GPU / per process; a context is not re-entrant
  */
 #ifndef SVX_H
@@ -175,6 +177,11 @@ int  svx_memcpy_d2h(void* host_dst, const void* device_src, uint64_t bytes);   /
 int  svx_memcpy_h2d(void* device_dst, const void* host_src, uint64_t bytes);
 void* svx_dev_alloc(uint64_t bytes);                                              /* library-owned device memory (tests, stress tools); NULL on failure */
 void svx_dev_free(void* p);
+/* page-locked host memory for the caller's batch arrays (svx_batch with on_device = 0): arrays built here are uploaded without the bounce pass.  The reference
+   builds its per-read Python objects from pysam (src/svim/SVIM_COLLECT.py:133-167); the batcher that replaces that loop (svim_amd/batch.py) fills these arrays.
+   svx_host_free hands the block back to the library (it is reused by a later svx_host_alloc, never unmapped); NULL on failure */
+void* svx_host_alloc(uint64_t bytes);
+void svx_host_free(void* p);
 int  svx_device_synchronize(void);                                               /* SVX_OK iff no kernel / copy of the process has faulted */
 /* self-test of the library's own radix sort (64-bit keys + 32-bit values, key bits [begin_bit, end_bit), stable) and exclusive scan on n pseudo-random
    elements, checked on the host against std::stable_sort / a serial sum: 0 = identical (tests) */

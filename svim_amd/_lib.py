@@ -17,7 +17,7 @@ _LIB_PATH = os.environ.get("SVX_LIB") or os.path.join(_HERE, "libsvx.so")      #
 _LIB = None
 _ENGINES = {}
 
-SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream", "svx_cluster_partitions_fetch", "svx_memcpy_d2h", "svx_memcpy_h2d", "svx_dev_alloc", "svx_dev_free", "svx_device_synchronize", "svx_selftest_prims", "svx_bam_set_device_decode",
+SYMBOLS = ["svx_ctx_create", "svx_ctx_destroy", "svx_last_error", "svx_version", "svx_get_stats", "svx_stream", "svx_cluster_partitions_fetch", "svx_memcpy_d2h", "svx_memcpy_h2d", "svx_dev_alloc", "svx_dev_free", "svx_host_alloc", "svx_host_free", "svx_device_synchronize", "svx_selftest_prims", "svx_bam_set_device_decode",
            "svx_collect", "svx_collect_count", "svx_collect_fetch", "svx_collect_accumulate", "svx_collect_set_slot_base", "svx_set_genome", "svx_cluster",
            "svx_cluster_count", "svx_cluster_fetch", "svx_cluster_set_ranks", "svx_cluster_abort_ranks", "svx_cluster_stream_positions",
            "svx_set_alignment_index", "svx_genotype",
@@ -50,6 +50,25 @@ def lib():
         L.svx_stream.restype = C.c_void_p
         _LIB = L
     return _LIB
+
+
+def host_empty(n, dtype):
+    """numpy array of n elements in page-locked memory the LIBRARY owns (svx_host_alloc, include/svx.h): svx_collect uploads such an array without the bounce
+    pass a pageable numpy array costs.  The block goes back to the library when the array (and every view of it) is gone.  Raises SvxError when the memory
+    cannot be had (no GPU): callers that only want the speed-up fall back to numpy themselves."""
+    import weakref
+    L = lib()
+    L.svx_host_alloc.restype = C.c_void_p
+    L.svx_host_alloc.argtypes = [C.c_uint64]
+    L.svx_host_free.argtypes = [C.c_void_p]
+    dt = np.dtype(dtype)
+    nbytes = max(1, int(n) * dt.itemsize)
+    p = L.svx_host_alloc(C.c_uint64(nbytes))
+    if not p:
+        raise SvxError("svx_host_alloc(%d) failed: %s" % (nbytes, L.svx_last_error().decode("utf-8", "replace")))
+    buf = (C.c_uint8 * nbytes).from_address(p)
+    weakref.finalize(buf, L.svx_host_free, C.c_void_p(p))
+    return np.frombuffer(buf, dtype=dt, count=int(n))
 
 
 def _check(rc, what):

@@ -62,6 +62,20 @@ class HostBatch(object):
     def nbytes(self):
         return sum(a.nbytes for a in self.arrays.values())
 
+    def pinned(self):
+        """The same batch with its arrays in page-locked memory the library owns (svim_amd._lib.host_empty): svx_collect then uploads them in place, without the
+        bounce pass through the library's own buffers that pageable numpy memory takes (include/svx.h).  A batcher that fills the arrays it got from host_empty
+        in the first place spares this copy too."""
+        from ._lib import host_empty
+        out = HostBatch()
+        out.n_rec, out.n_seg, out.read_names, out.references = self.n_rec, self.n_seg, self.read_names, self.references
+        for k, a in self.arrays.items():
+            a = np.ascontiguousarray(a)
+            b = host_empty(a.size, a.dtype)
+            b[...] = a.reshape(-1)
+            out.arrays[k] = b
+        return out
+
 
 def _parse_sa(sa_value, bam):
     """SA tag string -> list of (tid, pos0, reverse, mapq, cigar_tuples); follows

@@ -84,7 +84,8 @@ extern "C" int svx_ctx_create(int device_ordinal, svx_ctx** out) {
         const int mode = pe && !strcmp(pe, "band") ? 0 : (pe && !strcmp(pe, "equal") ? 2 : 1);
         for (int k = 0; k < SVX_N_AUX; k++) {
             const bool band_stream = k < 2 || k == 5;
-            const int prio = mode == 2 ? least : ((band_stream == (mode == 0)) ? greatest : least);
+            int prio = mode == 2 ? least : ((band_stream == (mode == 0)) ? greatest : least);
+            if (k == 6) prio = (least + greatest) / 2;                 // the main stream's own priority
             HIPCHK(hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, prio));
         }
     }
@@ -210,6 +211,12 @@ static int upload(svx_ctx* c, DevBuf& d, const void* host, size_t bytes, size_t 
     SVXCHK(d.reserve(bytes + pad));
     return svx_h2d(d.p, host, bytes, c->stream);            // (hostcopy.hpp: `host` has been read when this returns)
 }
+// the same inside a batch of copies: `host` has been read after hc.finish() (arrays in the library's own page-locked memory are copied in place, hostcopy.hpp)
+static int upload(svx_ctx* c, HostCopy& hc, DevBuf& d, const void* host, size_t bytes, size_t pad = 64) {
+    (void)c;
+    SVXCHK(d.reserve(bytes + pad));
+    return hc.h2d(d.p, host, bytes);
+}
 
 // ---- COLLECT -----------------------------------------------------------------------------------------------
 __global__ void k_acc_fix(long long n, uint64_t* key, uint64_t key_add, int64_t* seq_off_dst, const int64_t* seq_off_src, int64_t seq_add) {
@@ -246,34 +253,36 @@ extern "C" int svx_collect(svx_ctx* c, const svx_batch* b, const svx_params* p) 
         const size_t n_sops = ns ? (size_t)b->seg_cigar_off[ns] : 0;
         if (c->batch_bufs.size() < 25) c->batch_bufs.resize(25);
         auto& B = c->batch_bufs;
-        SVXCHK(upload(c, B[0], b->flag, n * 2)); d.flag = B[0].as<uint16_t>();
-        SVXCHK(upload(c, B[1], b->tid, n * 4)); d.tid = B[1].as<int32_t>();
-        SVXCHK(upload(c, B[2], b->pos, n * 4)); d.pos = B[2].as<int32_t>();
-        SVXCHK(upload(c, B[3], b->mapq, n)); d.mapq = B[3].as<uint8_t>();
-        SVXCHK(upload(c, B[4], b->lseq, n * 4)); d.lseq = B[4].as<int32_t>();
-        SVXCHK(upload(c, B[5], b->read_id, n * 4)); d.read_id = B[5].as<int32_t>();
-        SVXCHK(upload(c, B[6], b->order, n * 4)); d.order = B[6].as<uint32_t>();
-        SVXCHK(upload(c, B[7], b->seg_order, n * 4)); d.seg_order = B[7].as<uint32_t>();
-        SVXCHK(upload(c, B[8], b->cigar_off, (n + 1) * 8)); d.cigar_off = B[8].as<uint64_t>();
-        SVXCHK(upload(c, B[9], b->cigar, n_ops * 4)); d.cigar = B[9].as<uint32_t>();
-        SVXCHK(upload(c, B[10], b->seq_off, (n + 1) * 8)); d.seq_off = B[10].as<uint64_t>();
-        SVXCHK(upload(c, B[11], b->seq, n_seq)); d.seq = B[11].as<uint8_t>();
-        SVXCHK(upload(c, B[12], b->seg_off, (n + 1) * 4)); d.seg_off = B[12].as<uint32_t>();
-        SVXCHK(upload(c, B[13], b->seg_tid, ns * 4)); d.seg_tid = B[13].as<int32_t>();
-        SVXCHK(upload(c, B[14], b->seg_pos, ns * 4)); d.seg_pos = B[14].as<int32_t>();
-        SVXCHK(upload(c, B[15], b->seg_rev, ns)); d.seg_rev = B[15].as<uint8_t>();
-        SVXCHK(upload(c, B[16], b->seg_mapq, ns)); d.seg_mapq = B[16].as<uint8_t>();
-        SVXCHK(upload(c, B[17], b->seg_lseq, ns * 4)); d.seg_lseq = B[17].as<int32_t>();
-        SVXCHK(upload(c, B[18], b->seg_cigar_off, (ns + 1) * 8)); d.seg_cigar_off = B[18].as<uint64_t>();
-        SVXCHK(upload(c, B[19], b->seg_cigar, n_sops * 4)); d.seg_cigar = B[19].as<uint32_t>();
-        SVXCHK(upload(c, B[20], b->contig_rank, (size_t)b->n_contig * 4)); d.contig_rank = B[20].as<int32_t>();
+        HostCopy hc(c->stream);
+        SVXCHK(upload(c, hc, B[0], b->flag, n * 2)); d.flag = B[0].as<uint16_t>();
+        SVXCHK(upload(c, hc, B[1], b->tid, n * 4)); d.tid = B[1].as<int32_t>();
+        SVXCHK(upload(c, hc, B[2], b->pos, n * 4)); d.pos = B[2].as<int32_t>();
+        SVXCHK(upload(c, hc, B[3], b->mapq, n)); d.mapq = B[3].as<uint8_t>();
+        SVXCHK(upload(c, hc, B[4], b->lseq, n * 4)); d.lseq = B[4].as<int32_t>();
+        SVXCHK(upload(c, hc, B[5], b->read_id, n * 4)); d.read_id = B[5].as<int32_t>();
+        SVXCHK(upload(c, hc, B[6], b->order, n * 4)); d.order = B[6].as<uint32_t>();
+        SVXCHK(upload(c, hc, B[7], b->seg_order, n * 4)); d.seg_order = B[7].as<uint32_t>();
+        SVXCHK(upload(c, hc, B[8], b->cigar_off, (n + 1) * 8)); d.cigar_off = B[8].as<uint64_t>();
+        SVXCHK(upload(c, hc, B[9], b->cigar, n_ops * 4)); d.cigar = B[9].as<uint32_t>();
+        SVXCHK(upload(c, hc, B[10], b->seq_off, (n + 1) * 8)); d.seq_off = B[10].as<uint64_t>();
+        SVXCHK(upload(c, hc, B[11], b->seq, n_seq)); d.seq = B[11].as<uint8_t>();
+        SVXCHK(upload(c, hc, B[12], b->seg_off, (n + 1) * 4)); d.seg_off = B[12].as<uint32_t>();
+        SVXCHK(upload(c, hc, B[13], b->seg_tid, ns * 4)); d.seg_tid = B[13].as<int32_t>();
+        SVXCHK(upload(c, hc, B[14], b->seg_pos, ns * 4)); d.seg_pos = B[14].as<int32_t>();
+        SVXCHK(upload(c, hc, B[15], b->seg_rev, ns)); d.seg_rev = B[15].as<uint8_t>();
+        SVXCHK(upload(c, hc, B[16], b->seg_mapq, ns)); d.seg_mapq = B[16].as<uint8_t>();
+        SVXCHK(upload(c, hc, B[17], b->seg_lseq, ns * 4)); d.seg_lseq = B[17].as<int32_t>();
+        SVXCHK(upload(c, hc, B[18], b->seg_cigar_off, (ns + 1) * 8)); d.seg_cigar_off = B[18].as<uint64_t>();
+        SVXCHK(upload(c, hc, B[19], b->seg_cigar, n_sops * 4)); d.seg_cigar = B[19].as<uint32_t>();
+        SVXCHK(upload(c, hc, B[20], b->contig_rank, (size_t)b->n_contig * 4)); d.contig_rank = B[20].as<int32_t>();
         if (b->seq_rng_off) {
             const size_t nr = (size_t)b->n_seq_rng;
-            SVXCHK(upload(c, B[21], b->seq_rng_off, (n + 1) * 4)); d.seq_rng_off = B[21].as<uint32_t>();
-            SVXCHK(upload(c, B[22], b->seq_rng_q0, nr * 4)); d.seq_rng_q0 = B[22].as<int32_t>();
-            SVXCHK(upload(c, B[23], b->seq_rng_len, nr * 4)); d.seq_rng_len = B[23].as<int32_t>();
-            SVXCHK(upload(c, B[24], b->seq_rng_byte, nr * 8)); d.seq_rng_byte = B[24].as<uint64_t>();
+            SVXCHK(upload(c, hc, B[21], b->seq_rng_off, (n + 1) * 4)); d.seq_rng_off = B[21].as<uint32_t>();
+            SVXCHK(upload(c, hc, B[22], b->seq_rng_q0, nr * 4)); d.seq_rng_q0 = B[22].as<int32_t>();
+            SVXCHK(upload(c, hc, B[23], b->seq_rng_len, nr * 4)); d.seq_rng_len = B[23].as<int32_t>();
+            SVXCHK(upload(c, hc, B[24], b->seq_rng_byte, nr * 8)); d.seq_rng_byte = B[24].as<uint64_t>();
         }
+        SVXCHK(hc.finish());
         d.on_device = 1;
     }
     SVXCHK(svx_collect_impl(c, &d, p));

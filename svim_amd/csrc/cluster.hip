@@ -1469,13 +1469,6 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
     SVXCHK(c->ed.reserve((size_t)(pair_total + 1) * 4));
     // partitions without insertions need nothing from the edit-distance rounds: their linkage runs beside them on a side stream
     const bool split = pair_total > 0;
-    if (split) {
-        HIPCHK(hipEventRecord(c->ev[13], st));
-        HIPCHK(hipStreamWaitEvent(c->aux[4], c->ev[13], 0));
-        SVXCHK(launch_cluster(c->aux[4], 1));
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(c->ev[14], c->aux[4]));
-    }
     // ---- INS haplotype edit distances -----------------------------------------------------------------------------
     unsigned long long h_cnt[16] = {0};
     if (pair_total > 0) {
@@ -1484,7 +1477,18 @@ static int svx_cluster_body(svx_ctx* c, const ClusterIn& in, int32_t n_contig, c
         k_ins_pairs<<<(unsigned)n_part, 64, 0, st>>>(n_part, c->part_start.as<int64_t>(), sidx, c->samp_idx.as<int32_t>(), large_excl, pairs_a, pair_off, in, p,
                                                     c->work.as<EditWork>(), cnt + 8, pair_total);
         HIPCHK(hipGetLastError());
-        SVXCHK(svx_mail_read(c, st, cnt, 16, h_cnt));
+        // (the pair list is on the critical path, the side stream's linkage is not: its three launches are enqueued while k_ins_pairs runs)
+        HIPCHK(hipEventRecord(c->ev[13], st));
+        unsigned long long ticket = 0; const unsigned long long* words = nullptr;
+        { MailSrc ms; memset(&ms, 0, sizeof ms); ms.k = 1; ms.p[0] = cnt; ms.n[0] = 16; SVXCHK(svx_mail_post(c, st, ms, &ticket)); }
+        {
+            HIPCHK(hipStreamWaitEvent(c->aux[4], c->ev[13], 0));
+            SVXCHK(launch_cluster(c->aux[4], 1));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev[14], c->aux[4]));
+        }
+        SVXCHK(svx_mail_wait(c, st, ticket, &words));
+        memcpy(h_cnt, words, 16 * 8);
         const int64_t n_work = (int64_t)h_cnt[8];
         SVXCHK(c->cell_shards.reserve(1024 * 8));
         HIPCHK(hipMemsetAsync(c->cell_shards.p, 0, 1024 * 8, st));

@@ -64,6 +64,10 @@ __device__ __forceinline__ void py_slice(long long a, long long b, long long len
 #define MASK_READ 0x193     /* M I S = X advance the read cursor */
 
 __device__ __forceinline__ int op_sel(int mask, int op, int l) { return l & -((mask >> op) & 1); }
+// the same on the packed word in ONE instruction per mask: v_bfe_i32 takes its bit offset from the low five bits of a register, i.e. from the operation code and
+// the lowest length bit - with the 16-entry table repeated in both halves of the word the length bit does not matter.  -1 for the operations of the table, else 0.
+#define TAB32(m) ((int)(((uint32_t)(m) & 0xffffu) | ((uint32_t)(m) << 16)))
+__device__ __forceinline__ int op_in(int table32, uint32_t packed) { return __builtin_amdgcn_sbfe(table32, packed, 1u); }
 
 // only what the scan touches: fewer live SGPRs -> more resident blocks per CU (MI355X admits 8 blocks only up to 80 SGPRs)
 struct ScanArgs {
@@ -196,6 +200,7 @@ __device__ __forceinline__ void scan_item(const bool GEOM, RawIndel* out_raw, in
     const uint32_t* base_n = mtn.base;
     const uint32_t len_n = mtn.len, lim_n = mtn.lim;
     int acc_ref = 0, acc_read = 0, acc_n = 0, acc_h = 0, acc_s = 0;
+    const int emit_thr = (min_len > 0 ? (min_len > 0x10000000 ? 0x10000000 : min_len) : 0) + 1;       // lengths are 28 bits: (length + 1) >= emit_thr <=> length >= min_len
     // NU consecutive 1 KiB chunks per trip: the loads of the next trip are all issued before the current one is decoded,
     // so a wave keeps NU KiB in flight (memory-level parallelism is what this kernel lives on)
     constexpr int NU = SVX_SCAN_NU;
@@ -227,21 +232,24 @@ __device__ __forceinline__ void scan_item(const bool GEOM, RawIndel* out_raw, in
         }
         const uint32_t v[4] = {q.x, q.y, q.z, q.w};
         int t_ref = 0, t_read = 0;
-        bool any_emit = false;
+        // "is any of these a reportable I / D": the largest (length + 1) over the I / D operations against emit_thr (one compare per chunk)
+        int id_max = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int op = (int)(v[j] & 15u), l = (int)(v[j] >> 4);
-            t_ref += op_sel(MASK_REF, op, l);
-            t_read += op_sel(MASK_READ, op, l);
-            any_emit |= ((unsigned)(op - 1) < 2u) && l >= min_len;
+            const int l = (int)(v[j] >> 4);
+            t_ref += l & op_in(TAB32(MASK_REF), v[j]);
+            t_read += l & op_in(TAB32(MASK_READ), v[j]);
+            const int sc = (l + 1) & op_in(TAB32(0x6), v[j]);
+            id_max = sc > id_max ? sc : id_max;
         }
+        const bool any_emit = id_max >= emit_thr;
         if (GEOM) {                                        // (uniform: one copy of the loop serves both kinds of item)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int op = (int)(v[j] & 15u), l = (int)(v[j] >> 4);
-                acc_n += (op == 3) ? l : 0;
-                acc_h += (op == 5) ? l : 0;
-                acc_s += (op == 4) ? l : 0;
+                const int l = (int)(v[j] >> 4);
+                acc_n += l & op_in(TAB32(1 << 3), v[j]);
+                acc_h += l & op_in(TAB32(1 << 5), v[j]);
+                acc_s += l & op_in(TAB32(1 << 4), v[j]);
             }
         }
         if (need_indel && __any(any_emit)) {

@@ -127,14 +127,14 @@ struct DevClusters {
     DevBuf type, contig, start, end, contig2, start2, end2, aux, score, std_span, std_pos, size, member_off, members, part_index;
 };
 
-#define SVX_N_AUX 6
+#define SVX_N_AUX 7
 
 struct svx_ctx {
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev[24];
-    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] band classes, [2..3] full-matrix classes (the high-priority ones: api.hip); [4] low: linkage of the partitions that need no edit distances; [5] high: the widest band classes of round 0
+    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] band classes, [2..3] full-matrix classes (the high-priority ones: api.hip); [4] low: linkage of the partitions that need no edit distances; [5] high: the widest band classes of round 0; [6] normal priority (like the main stream): the packed haplotype store built ahead of the pair list
     // device copies of a host-resident batch
     std::vector<DevBuf> batch_bufs;
     // COLLECT results

@@ -1367,6 +1367,9 @@ __device__ __forceinline__ void d_edit_full(long long blk, long long count, cons
 // slowest wave while most of the chip idles; the host then launches the classes beyond 2048 rows in their low-latency form - 64 lanes
 // with 2-4 words each instead of 8-16 lanes with 12-16 words: ~3x shorter chains for ~1.4x the instructions.
 #define KIND_LL 32
+// the band pairs of a small retry round (run_edit_pipeline): one wave per pair, the form chosen by the pair's own rows - the 64-lane low-latency forms up to
+// 8192 rows (a 631 x 725 pair: 0.06 ms against 0.21 as a systolic matrix and 0.31 as a 16-word band in one lane), the systolic kernel beyond
+#define KIND_RETRY 40
 struct FusedTab {
     int n;
     int narrow;                            // band launches: the staircase windows narrow as they run (d_edit_stair)
@@ -1396,7 +1399,13 @@ __global__ __launch_bounds__(256) void k_edit_fulls(FusedTab tab, const uint32_t
     while (s + 1 < tab.n && blockIdx.x >= tab.first_block[s + 1]) s++;
     const long long blk = (long long)(blockIdx.x - tab.first_block[s]);
     const uint32_t* l = list + tab.lo[s];
-    switch (tab.kind[s]) {
+    int kind = tab.kind[s];
+    if (kind == KIND_RETRY) {                               // (uniform per wave: every wave of the segment has one pair)
+        const long long t = blk * 4 + (long long)(threadIdx.x >> 6);
+        const int m = __builtin_amdgcn_readfirstlane(t < tab.cn[s] ? desc[l[t]].m : 0);
+        kind = m <= 4096 ? KIND_LL + 2 : (m <= 6144 ? KIND_LL + 3 : (m <= 8192 ? KIND_LL + 4 : (int)CLS_FULL));
+    }
+    switch (kind) {
         case CLS_FULL: d_edit_full<P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, n_big, big_list, wc); break;
         case CLS_LANE0: d_edit_lane<1, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
         case CLS_LANE0 + 1: d_edit_lane<2, P>(blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
@@ -1620,8 +1629,8 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     long long bounds[N_SORT_CLASSES + 1];
     SVXCHK(svx_mail_read(c, st, cnt + 8, N_SORT_CLASSES + 1, bounds));
     // A retry round with only a few band pairs is bound by the LATENCY of its slowest pair: a band retry walks its columns in one lane with 6-16 state words
-    // (configs[1], round 1: 196 pairs, one wave of 16-word windows = 0.31 ms at the very end of the window), the systolic full matrix spreads the rows of the
-    // same pair over 64 lanes and never fails, so the round is also the last.  Up to this many band pairs of a retry round go there
+    // (configs[1], round 1: 196 pairs, one wave of 16-word windows = 0.31 ms at the very end of the window), a full matrix spread over the 64 lanes of a wave
+    // (KIND_RETRY) finishes the same pair in a fifth of that and never fails, so the round is also the last.  Up to this many band pairs of a retry round go there
     // (SVX_EDIT_RETRY_FULL, 0 = never; the distances are exact either way).
     long long retry_full = 4096;
     if (const char* e = getenv("SVX_EDIT_RETRY_FULL")) retry_full = atoll(e);
@@ -1720,18 +1729,18 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         for (int generic = 0; generic <= 1; generic++) {
             const int base = GENERIC_BASE * generic;
             if (bands_as_fulls) {
-                // the band lists of this alphabet as systolic full matrices, one launch beside the round's full-matrix launch
+                // the band lists of this alphabet as full matrices, one wave per pair (KIND_RETRY), one launch beside the round's full-matrix launch
                 FusedTab tf; memset(&tf, 0, sizeof tf);
                 unsigned nblk = 0;
                 for (int cls = NBAND - 1; cls >= 0; cls--) {
                     const long long cn = seg_cn[base + cls];
                     if (cn <= 0) continue;
-                    tf.kind[tf.n] = CLS_FULL; tf.lo[tf.n] = seg_lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
+                    tf.kind[tf.n] = KIND_RETRY; tf.lo[tf.n] = seg_lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
                     nblk += (unsigned)((cn * 64 + T - 1) / T); tf.n++;
                 }
                 tf.first_block[tf.n] = nblk;
                 if (tf.n) {
-                    hipStream_t fs = full_st[round & 1];
+                    hipStream_t fs = full_st[(round + 1) & 1];        // (beside the round's own full-matrix launch, not behind it)
                     if (generic) k_edit_fulls<4><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc_full);
                     else k_edit_fulls<2><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc_full);
                     HIPCHK(hipGetLastError());
@@ -1935,6 +1944,15 @@ int svx_edit_distance_pairs(svx_ctx* c, int64_t n_pairs, const uint8_t* codes_de
 // distance has |start_a - start_b| <= 2 * cluster_max_distance * position_distance_normalizer (ins_needs_edit in cluster.hip): with that bound as
 // radius the store is built on a side stream while the main stream sorts, partitions and samples.  begin: word counts + offsets (enqueue only);
 // pack: called after the caller's next host synchronisation - reads the total, reserves, packs, records ev[18].
+// The store is built on the high-priority stream of the full-matrix rounds (idle at that time): on the HiFi-like stand-in k_edit_prep waits for it, and at the
+// main stream's priority or below it arrives 0.6-0.9 ms later (profiles/r06_prepack_priority_ab.txt).  What the high priority cost configs[1] - the main stream's
+// one-workgroup scans of the partition sizes waited 0.04-0.4 ms each for a CU with sixteen free wave slots while the store's blocks were being dispatched - is
+// taken care of in scan.hpp (256-thread workgroups for small scans).  SVX_PREPACK_PRIO=normal / low: A/B.
+static hipStream_t prepack_stream(svx_ctx* c) {
+    static const int which = []() { const char* e = getenv("SVX_PREPACK_PRIO"); return e && !strcmp(e, "normal") ? 6 : (e && !strcmp(e, "low") ? 0 : 2); }();
+    return c->aux[which];
+}
+
 static PairSource prepack_source(svx_ctx* c, const ClusterIn& in) {
     PairSource src; memset(&src, 0, sizeof src);
     src.plain = 0; src.in = in; src.g_off = c->g_off_p; src.g_codes = c->g_codes_p; src.radius = c->prepack_radius; src.rec = c->e_rec.as<HapRec>();
@@ -1948,7 +1966,7 @@ int svx_edit_prepack_begin(svx_ctx* c, const ClusterIn& in, const svx_params& p,
     if (!(bound >= 0) || !(bound < 16000.0)) return SVX_OK;                       // unusual parameters: the exact radius is found from the pair list
     c->prepack_radius = (long long)(bound * (1.0 + 1e-9)) + 2 + 100;
     c->prepack_n = in.n;
-    hipStream_t ps = c->aux[2];
+    hipStream_t ps = prepack_stream(c);
     const long long n_rec = in.n;
     SVXCHK(c->e_words.reserve((size_t)(n_rec + 1) * 8));
     SVXCHK(c->e_off.reserve((size_t)(n_rec + 1) * 8));
@@ -1964,7 +1982,7 @@ int svx_edit_prepack_begin(svx_ctx* c, const ClusterIn& in, const svx_params& p,
 
 int svx_edit_prepack_pack(svx_ctx* c, const ClusterIn& in) {
     if (c->prepack_state != 1) return SVX_OK;
-    hipStream_t ps = c->aux[2];
+    hipStream_t ps = prepack_stream(c);
     HIPCHK(hipStreamSynchronize(ps));
     const int64_t total_words = c->pinned[0];
     SVXCHK(c->e_scratch.reserve((size_t)(total_words + 64) * 4));

@@ -79,6 +79,47 @@ void release(BounceSlot* s, bool pending) {
 }
 }  // namespace
 
+// ---- library-owned page-locked arrays (svx_host_alloc / svx_host_free, include/svx.h) ---------------------------------------------------------------------------
+// A caller that builds its batch arrays in memory obtained here spares the bounce pass: the copy engine reads the array itself.  The memory is hipHostMalloc memory
+// and stays mapped for the life of the process - svx_host_free puts a block on a free list, a later svx_host_alloc of at most that size takes it again - so the one
+// kind of registration the runtime ever holds for it never goes stale (hostcopy.hpp).
+#include <map>
+namespace {
+struct HostBlock { size_t cap; bool in_use; };
+std::mutex g_host_m;
+std::map<uintptr_t, HostBlock> g_host_blocks;          // by start address
+}
+extern "C" void* svx_host_alloc(uint64_t bytes) {
+    const size_t want = bytes ? (size_t)bytes : 1;
+    {
+        std::lock_guard<std::mutex> g(g_host_m);
+        uintptr_t best = 0; size_t best_cap = ~(size_t)0;
+        for (auto& kv : g_host_blocks) if (!kv.second.in_use && kv.second.cap >= want && kv.second.cap < best_cap && kv.second.cap <= 2 * want + (1u << 20)) { best = kv.first; best_cap = kv.second.cap; }
+        if (best) { g_host_blocks[best].in_use = true; return (void*)best; }
+    }
+    void* p = nullptr;
+    const size_t cap = (want + 4095) & ~(size_t)4095;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); (void)svx_fail(SVX_E_HIP, "svx_host_alloc: hipHostMalloc", __FILE__, __LINE__, hipSuccess); return nullptr; }
+    std::lock_guard<std::mutex> g(g_host_m);
+    g_host_blocks[(uintptr_t)p] = HostBlock{cap, true};
+    return p;
+}
+extern "C" void svx_host_free(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(g_host_m);
+    auto it = g_host_blocks.find((uintptr_t)p);
+    if (it != g_host_blocks.end()) it->second.in_use = false;          // (kept mapped: see above)
+}
+// [p, p + bytes) lies inside one block handed out by svx_host_alloc
+bool svx_host_owned(const void* p, size_t bytes) {
+    std::lock_guard<std::mutex> g(g_host_m);
+    if (g_host_blocks.empty()) return false;
+    auto it = g_host_blocks.upper_bound((uintptr_t)p);
+    if (it == g_host_blocks.begin()) return false;
+    --it;
+    return it->second.in_use && (uintptr_t)p >= it->first && (uintptr_t)p + bytes <= it->first + it->second.cap;
+}
+
 bool svx_is_device_pointer(const void* p) {
     if (!p) return false;
     hipPointerAttribute_t a;
@@ -88,7 +129,10 @@ bool svx_is_device_pointer(const void* p) {
 
 // (a HostCopy dropped with device -> host pieces still in flight - an error return of its caller: the slots go back PENDING, their events were recorded behind the
 // copies, so whoever takes them next waits for the copy that still writes into them)
-HostCopy::~HostCopy() { for (auto& q : pend_) release(q.slot, true); }
+HostCopy::~HostCopy() {
+    for (auto& q : pend_) release(q.slot, true);
+    if (direct_pending_) (void)hipStreamSynchronize(st_);            // the copy engine may still be reading the caller's page-locked array
+}
 
 // one piece of a large upload: its own slot, its own copy, ordered on the caller's stream like every other piece
 static int h2d_piece(char* dst, const char* src, size_t n, hipStream_t st, int dev) {
@@ -105,6 +149,12 @@ static int h2d_piece(char* dst, const char* src, size_t n, hipStream_t st, int d
 int HostCopy::h2d(void* dev_dst, const void* host_src, size_t bytes) {
     if (!bytes) return SVX_OK;
     const char* src = (const char*)host_src; char* dst = (char*)dev_dst;
+    if (svx_host_owned(host_src, bytes)) {
+        // the library's own page-locked memory: the copy engine reads it in place; finish() (or the destructor) waits for the stream before the caller may touch it
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st_));
+        direct_pending_ = true;
+        return SVX_OK;
+    }
     const int dev = device_of(st_);
     if (bytes >= ((size_t)16 << 20)) {
         // a large array (the CIGAR words / packed bases of a host batch): one thread's memcpy into the bounce buffers (5-6 GB/s) would be the bottleneck of the
@@ -185,13 +235,14 @@ int HostCopy::out(void* dst, const void* dev_src, size_t bytes) {
 }
 
 int HostCopy::finish() {
-    if (pend_.empty()) return SVX_OK;
+    if (pend_.empty() && !direct_pending_) return SVX_OK;
     const hipError_t e = hipStreamSynchronize(st_);
+    direct_pending_ = false;
     if (e != hipSuccess) return svx_fail(SVX_E_HIP, "device -> host copies through bounce buffers", __FILE__, __LINE__, e);
     for (auto& q : pend_) { memcpy(q.dst, q.slot->p, q.bytes); release(q.slot, false); }
     pend_.clear(); pend_big_ = 0;
     return SVX_OK;
 }
 
-int svx_h2d(void* dev_dst, const void* host_src, size_t bytes, hipStream_t st) { HostCopy hc(st); return hc.h2d(dev_dst, host_src, bytes); }
+int svx_h2d(void* dev_dst, const void* host_src, size_t bytes, hipStream_t st) { HostCopy hc(st); SVXCHK(hc.h2d(dev_dst, host_src, bytes)); return hc.finish(); }
 int svx_d2h(void* host_dst, const void* dev_src, size_t bytes, hipStream_t st) { HostCopy hc(st); SVXCHK(hc.d2h(host_dst, dev_src, bytes)); return hc.finish(); }

@@ -11,7 +11,8 @@
 //
 // A HostCopy object batches the copies of one call on one stream:
 //     HostCopy hc(stream);
-//     SVXCHK(hc.h2d(dev, host, bytes));     // returns when `host` has been read (it may be reused / freed); the device copy is ordered on the stream
+//     SVXCHK(hc.h2d(dev, host, bytes));     // returns when `host` has been read (it may be reused / freed); the device copy is ordered on the stream.
+//                                           // `host` inside memory from svx_host_alloc: no bounce, the copy engine reads it in place - `host` has been read after finish()
 //     SVXCHK(hc.d2h(host, dev, bytes));     // enqueued; `host` holds the data after finish()
 //     SVXCHK(hc.out(dst, dev, bytes));      // dst may be host OR device memory (the hipMemcpyDefault of before): looked up once
 //     SVXCHK(hc.finish());                  // waits for the stream where device -> host copies are pending, then hands the bytes out
@@ -35,7 +36,9 @@ private:
     hipStream_t st_;
     std::vector<Pending> pend_;
     size_t pend_big_ = 0;
+    bool direct_pending_ = false;          // a copy straight out of the library's own page-locked memory (svx_host_alloc) is in flight
 };
+bool svx_host_owned(const void* p, size_t bytes);
 bool svx_is_device_pointer(const void* p);
 // one-shot forms (a HostCopy of one copy + finish)
 int svx_h2d(void* dev_dst, const void* host_src, size_t bytes, hipStream_t st);

@@ -54,15 +54,17 @@ template <class T> __device__ __forceinline__ void scan_tile_store(T* out, long 
     }
 }
 
-// (1024 threads: 8192 elements per trip)
+// (1024 threads: 8192 elements per trip.  Up to 2048 elements - the tile sums of a scan over four million, every small scan of a CLUSTER call - the workgroup has
+// 256 threads (round 6): a workgroup of sixteen waves needs a CU with four free wave slots on EVERY SIMD and waits for one while a full-chip kernel of a side
+// stream is being dispatched (the packed haplotype store beside the partition phase: 0.04-0.4 ms per scan, profiles/r06_step_timeline_all_kernels.txt))
 #define SCAN_ONE_T 1024
-template <class Tin, class T> __global__ __launch_bounds__(SCAN_ONE_T) void k_scan_one(const Tin* in, T* out, long long n) {
-    __shared__ T sh[SCAN_ONE_T / 64 + 1];
+template <class Tin, class T, int NT> __global__ __launch_bounds__(NT) void k_scan_one(const Tin* in, T* out, long long n) {
+    __shared__ T sh[NT / 64 + 1];
     T carry = 0;
-    for (long long lo = 0; lo < n; lo += SCAN_ONE_T * SCAN_ITEMS) {
+    for (long long lo = 0; lo < n; lo += NT * SCAN_ITEMS) {
         T x[SCAN_ITEMS], total;
         const T mine = scan_tile_load<Tin, T>(in, lo, n, x);
-        const T ex = scan_block_excl<T, SCAN_ONE_T>(mine, sh, &total);
+        const T ex = scan_block_excl<T, NT>(mine, sh, &total);
         scan_tile_store<T>(out, lo, n, x, carry + ex);
         carry += total;
     }
@@ -87,7 +89,8 @@ template <class Tin, class T> __global__ __launch_bounds__(SCAN_T) void k_scan_t
 template <class Tin, class T> static int svx_exclusive_scan(const Tin* in, T* out, long long n, hipStream_t stream, DevBuf& tmp) {
     if (n <= 0) return SVX_OK;
     if (n <= SCAN_ONE) {
-        k_scan_one<Tin, T><<<1, SCAN_ONE_T, 0, stream>>>(in, out, n);
+        if (n <= SCAN_TILE) k_scan_one<Tin, T, SCAN_T><<<1, SCAN_T, 0, stream>>>(in, out, n);
+        else k_scan_one<Tin, T, SCAN_ONE_T><<<1, SCAN_ONE_T, 0, stream>>>(in, out, n);
         HIPCHK(hipGetLastError());
         return SVX_OK;
     }
@@ -95,7 +98,8 @@ template <class Tin, class T> static int svx_exclusive_scan(const Tin* in, T* ou
     SVXCHK(tmp.reserve((size_t)tiles * sizeof(T) + 64));
     T* sums = tmp.as<T>();
     k_scan_tile_sums<Tin, T><<<(unsigned)tiles, SCAN_T, 0, stream>>>(in, n, sums);
-    k_scan_one<T, T><<<1, SCAN_ONE_T, 0, stream>>>(sums, sums, tiles);
+    if (tiles <= SCAN_TILE) k_scan_one<T, T, SCAN_T><<<1, SCAN_T, 0, stream>>>(sums, sums, tiles);
+    else k_scan_one<T, T, SCAN_ONE_T><<<1, SCAN_ONE_T, 0, stream>>>(sums, sums, tiles);
     k_scan_tiles<Tin, T><<<(unsigned)tiles, SCAN_T, 0, stream>>>(in, out, n, sums);
     HIPCHK(hipGetLastError());
     return SVX_OK;

@@ -240,6 +240,19 @@ def test_collect_then_cluster_resident_vs_oracle(eng, oracle):
     osig, obnd = oracle.collect(hb, p)
     assert sig.n > 1000
     assert sig.first_difference(osig) is None and bnd.first_difference(obnd) is None
+    # the same batch with its arrays in page-locked memory of the library (svx_host_alloc: uploaded in place, no bounce pass): same tables;
+    # the blocks go back to the library with the arrays and are handed out again
+    hp = hb.pinned()
+    psig, pbnd = eng.collect(hp, p)
+    assert psig.first_difference(osig) is None and pbnd.first_difference(obnd) is None
+    first = hp.arrays["cigar"].ctypes.data
+    del hp, psig, pbnd
+    import gc
+    gc.collect()
+    hp = hb.pinned()
+    assert hp.arrays["cigar"].ctypes.data == first or any(a.ctypes.data == first for a in hp.arrays.values())
+    sig, bnd = eng.collect(hp, p)
+    assert sig.first_difference(osig) is None and bnd.first_difference(obnd) is None
     for source in (0, 1):
         ct = eng.cluster(p, hb.contig_rank, source=source)
         oc = oracle.cluster(p, hb.contig_rank, source=source)

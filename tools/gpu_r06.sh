@@ -39,6 +39,7 @@ timeline)
   db=$(find /tmp/kt -name "*.db" | head -1)
   python tools/rocpd_stats.py $db $out/${tag}_kernel_stats.csv > /dev/null
   python tools/rocpd_timeline.py $db > $out/${tag}_step_timeline.txt
+  ALL=1 python tools/rocpd_timeline.py $db > $out/${tag}_step_timeline_all_kernels.txt
   grep "k_edit\|k_cigar\|k_cluster" $out/${tag}_step_timeline.txt
   ;;
 strong)
@@ -78,9 +79,9 @@ import json, sys
 try:
     j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
     b = j["bam_file_with_base_qualities"]
-    print("  %-12s warm %.3f M/s (%.3f s) cold %.3f M/s objects %.3f M/s | blocks gpu %d host %d kernel %.0f ms | no-qual %.2f M/s | host arrays %.2f M/s" % (sys.argv[2], b["reads_per_s"] / 1e6, b["wall_s"],
+    print("  %-12s warm %.3f M/s (%.3f s) cold %.3f M/s objects %.3f M/s | blocks gpu %d host %d kernel %.0f ms | no-qual %.2f M/s | host arrays %.2f M/s, library-pinned %.2f M/s" % (sys.argv[2], b["reads_per_s"] / 1e6, b["wall_s"],
           j["bam_file_first_pass_reads_per_s"] / 1e6, j["objects_materialised_reads_per_s"] / 1e6, b["inflate_blocks_gpu"], b["inflate_blocks_host_cores"], b["inflate_kernel_ms"],
-          j["bam_file_without_base_qualities"]["reads_per_s"] / 1e6, j.get("host_arrays_reads_per_s", 0) / 1e6))
+          j["bam_file_without_base_qualities"]["reads_per_s"] / 1e6, j.get("host_arrays_reads_per_s", 0) / 1e6, j.get("host_arrays_library_pinned_reads_per_s", 0) / 1e6))
 except Exception as e:
     print("  no line:", e)
 PY

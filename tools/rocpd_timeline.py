@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the libsvx kernels of the LAST bench step in a rocprofv3 (rocpd SQLite) kernel trace: name, start offset (ms),
 duration (ms), one line per launch, so that overlap between the side streams can be read off."""
+import os
 import sqlite3
 import sys
 
@@ -16,7 +17,7 @@ def main(db_path, marker="k_cigar_scan"):
         return
     t0 = starts[-1]
     for n, s, e in rows:
-        if s >= t0 and (n.startswith("k_") or "k_edit" in n or "k_cluster" in n or "k_linkage" in n):
+        if s >= t0 and (os.environ.get("ALL") or n.startswith("k_") or "k_edit" in n or "k_cluster" in n or "k_linkage" in n):
             print("%-28s %9.3f %9.3f" % (n.split("(")[0].replace("void ", "")[:28], (s - t0) / 1e6, (e - s) / 1e6))
 
 
