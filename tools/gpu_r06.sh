@@ -35,8 +35,8 @@ serial)
   grep edit_launch $out/${tag}_edit_class_profile.jsonl | tail -8
   ;;
 timeline)
-  rm -rf /tmp/kt && (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end --workload ${WL:-c1} > /dev/null 2> /tmp/kt.err)
-  db=$(find /tmp/kt -name "*.db" | head -1)
+  KT=/tmp/kt_$$; rm -rf $KT; (cd /tmp && rocprofv3 --kernel-trace --stats -d $KT -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end --workload ${WL:-c1} > /dev/null 2> $KT.err)
+  db=$(find $KT -name "*.db" | head -1)
   python tools/rocpd_stats.py $db $out/${tag}_kernel_stats.csv > /dev/null
   python tools/rocpd_timeline.py $db > $out/${tag}_step_timeline.txt
   ALL=1 python tools/rocpd_timeline.py $db > $out/${tag}_step_timeline_all_kernels.txt
@@ -86,6 +86,29 @@ except Exception as e:
     print("  no line:", e)
 PY
   done
+  ;;
+evidence)
+  # what profiles/ holds at the end of the round, all at the SAME code: the default bench line, kernel stats + step timelines (rocprofv3 --kernel-trace --stats),
+  # the four PMC passes (separate runs, no trace domains beside --kernel-trace), the stand-in workloads, small-batch latency, strong-scaling lines (one GPU, gloo)
+  python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_c1.json 2> $out/${tag}_bench_c1.err; echo "bench c1 rc=$?"
+  B="--steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end"
+  KT=/tmp/kt_$$; rm -rf $KT; (cd /tmp && rocprofv3 --kernel-trace --stats -d $KT -o p -- python $R/bench.py $B > /dev/null 2> $KT.err)
+  db=$(find $KT -name "*.db" | head -1)
+  python tools/rocpd_stats.py $db $out/${tag}_kernel_stats.csv > /dev/null
+  python tools/rocpd_timeline.py $db > $out/${tag}_step_timeline.txt
+  ALL=1 python tools/rocpd_timeline.py $db > $out/${tag}_step_timeline_all_kernels.txt
+  for pass in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+    t=$(echo $pass | tr ' ' '_' | cut -c1-24)
+    P=/tmp/pmc_${t}_$$; rm -rf $P
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass -d $P -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2> $P.err)
+    db=$(find $P -name "*.db" | head -1)
+    [ -n "$db" ] && python tools/pmc_summary.py $db $out/${tag}_pmc_$t.csv > /dev/null
+  done
+  python bench.py --steps 10 --warmup 3 --workload c2 --no-cpu-baseline > $out/${tag}_bench_c2.json 2>/dev/null
+  python bench.py --steps 5 --warmup 2 --workload c4 --no-cpu-baseline > $out/${tag}_bench_c4.json 2>/dev/null
+  python tools/small_batch_latency.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_small_batch_latency.txt
+  git rev-parse HEAD > $out/${tag}_evidence_commit.txt 2>/dev/null || true
+  ls -la $out/${tag}_* | head -40
   ;;
 *) echo "unknown step $step"; exit 2;;
 esac
