@@ -147,8 +147,10 @@ __device__ __forceinline__ void finish_geom(const uint32_t* c, long long n, int 
 
 // One thread per item: the table entry of the scan (above); the geometry of a short segment row; and, for an item whose geometry the scan computes, the
 // stored sequence length in word 0 of its geometry record, where the scan's epilogue picks it up (finish_geom reads it before it writes the record).
-__global__ __launch_bounds__(256) void k_scan_prepare(ScanArgs b, unsigned long long total_ops, unsigned long long total_seg_ops, uint4* items, int* geom) {
+__global__ __launch_bounds__(256) void k_scan_prepare(ScanArgs b, unsigned long long total_ops, unsigned long long total_seg_ops, uint4* items, int* geom,
+                                                      unsigned long long* shard_counter) {
     const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (shard_counter && w < RAW_SHARDS) shard_counter[w] = 0ull;          // the scan's per-wave emission counters (a launch of its own before: one gap less in front of the scan)
     if (w >= b.n_rec + b.n_seg) return;
     const bool is_rec = w < b.n_rec;
     const long long s = w - b.n_rec;
@@ -740,7 +742,8 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
             SVXCHK(c->shard_cnt.reserve((size_t)RAW_SHARDS * 8 + (size_t)(RAW_SHARDS + 1) * 8));
             unsigned long long* shard_counter = c->shard_cnt.as<unsigned long long>();
             long long* shard_prefix = reinterpret_cast<long long*>(shard_counter + RAW_SHARDS);
-            HIPCHK(hipMemsetAsync(shard_counter, 0, RAW_SHARDS * 8, st));
+            const bool zero_in_prepare = items >= RAW_SHARDS;                 // (a grid of at least RAW_SHARDS threads)
+            if (!zero_in_prepare) HIPCHK(hipMemsetAsync(shard_counter, 0, RAW_SHARDS * 8, st));
             RawTarget rt{c->raw_indel.as<RawIndel>(), shard_cap, shard_counter};
             // the scan's 16-byte loads need an array of at least four operations (load_chunk): a smaller one is copied in front of no-op padding
             const uint32_t* cigar_p = b.cigar; uint64_t tot_scan = tot_ops;
@@ -751,7 +754,7 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
                 cigar_p = c->tmp5.as<uint32_t>(); tot_scan = 4;
             }
             ScanArgs sa{b.n_rec, b.n_seg, b.flag, b.mapq, b.lseq, b.seg_off, b.cigar_off, cigar_p, b.seg_lseq, b.seg_cigar_off, b.seg_cigar, p->min_mapq, p->min_sv_size};
-            k_scan_prepare<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(sa, tot_scan, tot_seg_ops, c->seg_geom.as<uint4>(), rec_geom_p);
+            k_scan_prepare<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(sa, tot_scan, tot_seg_ops, c->seg_geom.as<uint4>(), rec_geom_p, zero_in_prepare ? shard_counter : nullptr);
             k_cigar_scan<<<(unsigned)blocks, 256, 0, st>>>(c->seg_geom.as<uint4>(), (uint32_t)b.n_rec, (uint32_t)items, cigar_p, b.seg_cigar, p->min_sv_size, rt, rec_geom_p);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev[5], st));
