@@ -34,6 +34,12 @@ traffic = {"kernel": "k_cigar_scan", "measured_at_commit": commit,
            "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled for wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section); "
                          "WRITE_SIZE uncalibrated, taken as is (KB = 1024 B)",
            "traffic_bytes_per_launch": int(2 * fetch_kb * 1024 + (write_kb or 0) * 1024)}
+# round 6: k_scan_prepare (the item table of the scan; it sits inside the HIP-event bracket of the bench line's k_cigar_scan_ms) - its own, smaller traffic beside the scan's
+pf, _ = per_dispatch("%s_pmc_FETCH_SIZE.csv" % tag, "k_scan_prepare", "FETCH_SIZE")
+pw, _ = per_dispatch("%s_pmc_WRITE_SIZE.csv" % tag, "k_scan_prepare", "WRITE_SIZE")
+if pf is not None:
+    traffic["k_scan_prepare"] = {"fetch_size_kb": pf, "write_size_kb": pw, "traffic_bytes_per_launch": int(2 * pf * 1024 + (pw or 0) * 1024),
+                                 "note": "FETCH_SIZE doubled like the scan's (an upper bound for its narrower loads)"}
 with open(os.path.join(root, "traffic_k_cigar_scan.json"), "w") as fh:
     json.dump(traffic, fh, indent=2)
     fh.write("\n")
