@@ -115,7 +115,7 @@ extern "C" void svx_ctx_destroy(svx_ctx* c) {
     c->sig.release(); c->bnd.release(); c->raw_sig.release(); c->raw_bnd.release();
     DevBuf* bufs[] = {&c->counters, &c->raw_indel, &c->shard_cnt, &c->rec_geom, &c->seg_geom, &c->seg_ws, &c->tmp0, &c->tmp1, &c->tmp2, &c->tmp3, &c->tmp4, &c->tmp5, &c->sort_tmp, &c->scan_tmp,
                       &c->g_off, &c->g_codes, &c->c_rank, &c->k_hi, &c->k_lo, &c->k_idx, &c->k_hi2, &c->k_lo2, &c->k_idx2, &c->part_flag, &c->part_id,
-                      &c->part_start, &c->part_meta, &c->samp_chain, &c->samp_idx, &c->large_list, &c->samp_stream, &c->cell_shards, &c->mt_words, &c->samp_meta, &c->samp_table, &c->samp_runs, &c->pair_off, &c->ed, &c->work, &c->stage, &c->stage_members, &c->labels, &c->e_words, &c->e_off, &c->e_scratch, &c->e_rec, &c->e_hist, &c->e_desc, &c->e_key, &c->e_val, &c->e_slot, &c->e_fail, &c->e_big_list, &c->e_big_state, &c->e_big_off, &c->e_retry[0], &c->e_retry[1], &c->e_retry[2], &c->prepack_tmp,
+                      &c->part_start, &c->part_meta, &c->samp_chain, &c->samp_idx, &c->large_list, &c->samp_stream, &c->cell_shards, &c->mt_words, &c->samp_meta, &c->samp_table, &c->samp_runs, &c->pair_off, &c->ed, &c->work, &c->stage, &c->stage_members, &c->labels, &c->e_words, &c->e_off, &c->e_scratch, &c->e_rec, &c->e_hist, &c->e_desc, &c->e_key, &c->e_val, &c->e_slot, &c->e_fail, &c->e_big_list, &c->e_big_state, &c->e_big_off, &c->e_retry[0], &c->e_retry[1], &c->e_retry[2], &c->e_blk[0], &c->e_blk[1], &c->prepack_tmp,
                       &c->clu.type, &c->clu.contig, &c->clu.start, &c->clu.end, &c->clu.contig2, &c->clu.start2, &c->clu.end2, &c->clu.aux, &c->clu.score,
                       &c->clu.std_span, &c->clu.std_pos, &c->clu.size, &c->clu.member_off, &c->clu.members, &c->clu.part_index};
     for (auto* b : bufs) b->release();

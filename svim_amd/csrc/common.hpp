@@ -127,14 +127,14 @@ struct DevClusters {
     DevBuf type, contig, start, end, contig2, start2, end2, aux, score, std_span, std_pos, size, member_off, members, part_index;
 };
 
-#define SVX_N_AUX 7
+#define SVX_N_AUX 8
 
 struct svx_ctx {
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev[24];
-    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] band classes, [2..3] full-matrix classes (the high-priority ones: api.hip); [4] low: linkage of the partitions that need no edit distances; [5] high: the widest band classes of round 0; [6] normal priority (like the main stream): the packed haplotype store built ahead of the pair list
+    hipStream_t aux[SVX_N_AUX];     // side streams of the edit-distance pipeline: [0..1] band classes, [2..3] full-matrix classes (the high-priority ones: api.hip); [4] low: linkage of the partitions that need no edit distances; [5] high: the widest band classes of round 0; [6] normal priority (like the main stream): the packed haplotype store built ahead of the pair list (A/B); [7] high: the row-block launches (SVX_EDIT_BLOCKED)
     // device copies of a host-resident batch
     std::vector<DevBuf> batch_bufs;
     // COLLECT results
@@ -161,6 +161,7 @@ struct svx_ctx {
     DevBuf mt_words; long long mt_have = 0;      // tempered MT19937 words after seed(1524), kept across calls
     DevBuf pair_off, ed, work, stage, stage_members, labels;
     DevBuf e_words, e_off, e_scratch, e_rec, e_desc, e_key, e_val, e_slot, e_fail, e_big_list, e_big_state, e_big_off;
+    DevBuf e_blk[2];                // boundary words + hand-over values of the row-block route (SVX_EDIT_BLOCKED), per alphabet
     DevBuf e_retry[3];              // per-class retry lists of the edit-distance rounds (rotating)     // edit-distance pipeline
     DevClusters clu;
     // Band speculation: a pair without a useful distance bound starts in the band sized for edit_guess * (core length) differences beyond

@@ -474,8 +474,17 @@ __global__ __launch_bounds__(256) void k_edit_prep(long long n_work, PairSource 
 }
 
 // first class of every pair + its sort key (one thread per pair)
-__global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort_key, uint32_t* sort_val, int force_full, const unsigned long long* guess_word, int few_pairs) {
+// classes whose round-0 pairs run in row blocks (SVX_EDIT_BLOCKED): the 2- and 4-lane families (<= 4 blocks: the blocks of a pair are serial launches); words per block
+__host__ __device__ __forceinline__ int blocked_words(int cls, int kmax) {
+    if (cls >= CLS_WIDE0 && cls <= CLS_WIDE0 + kmax) return 16;
+    if (cls >= CLS_WIDE12 && cls <= CLS_WIDE12 + kmax) return 12;
+    if (cls >= CLS_WIDE14 && cls <= CLS_WIDE14 + kmax) return 14;
+    if (cls >= CLS_WIDE10 && cls <= CLS_WIDE10 + kmax) return 10;
+    return 0;
+}
+__global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort_key, uint32_t* sort_val, int force_full, unsigned long long* guess_word, int few_pairs_flags) {
     const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int few_pairs = few_pairs_flags & 1, blocked_kmax = (few_pairs_flags >> 1) - 1;          // -1: no blocked route
     if (w >= n_work) return;
     const PairDesc pd = desc[w];
     if (pd.cls == -1) return;                               // empty core: answered by k_edit_prep, key already written
@@ -508,7 +517,17 @@ __global__ void k_edit_classify(long long n_work, PairDesc* desc, uint64_t* sort
         cls = pd.m <= 4096 ? CLS_WIDE0 + 2 : (pd.m <= 6144 ? CLS_WIDE12 + 3 : (pd.m <= 8192 ? CLS_WIDE0 + 3 : CLS_FULL));
     const int flagged = cls | (pd.cls & ~0xff);
     desc[w].cls = flagged;
-    sort_key[w] = sort_key_of(sort_class(flagged), work_key(cls, pd.m, pd.n));
+    int cost_n = pd.n;
+    const int bq = blocked_kmax >= 0 ? blocked_words(cls, blocked_kmax) : 0;
+    if (bq) {
+        // a row block walks 32 Q + (length gap) + 2 x columns (d_edit_blocked): pairs that share a wave should agree on THAT; and the longest text of the
+        // blocked pairs sizes their boundary words (guess_word[1], read by the host with the class bounds)
+        int ub = pd.ub; if (ub > pd.m + pd.n) ub = pd.m + pd.n; if (ub < pd.n - pd.m) ub = pd.n - pd.m;
+        const long long walk = 32ll * bq + (pd.n - pd.m) + 2ll * ((ub - (pd.n - pd.m)) / 2 + 1);
+        cost_n = walk < pd.n ? (int)walk : pd.n;
+        if ((unsigned long long)pd.n > __hip_atomic_load(guess_word + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(guess_word + 1, (unsigned long long)pd.n);
+    }
+    sort_key[w] = sort_key_of(sort_class(flagged), work_key(cls, pd.m, cost_n));
     sort_val[w] = (uint32_t)w;
 }
 
@@ -1103,6 +1122,103 @@ __device__ __forceinline__ void d_edit_lane(long long blk, long long count, cons
     if (live) ed[slot_of ? slot_of[widx] : (long long)widx] = score;
 }
 
+// ---- 3d. full matrix in ROW BLOCKS: one lane per (pair, block of 32 Q rows), the blocks of a pair in successive launches (round 6, SVX_EDIT_BLOCKED=1) --------
+// The multi-lane forms below sweep the text in lock step: a lane whose rows lie outside the band the pair's upper bound allows - the two corner triangles of a
+// pair whose length gap exceeds every band - idles while its wave still pays for the column.  Here block r of a pair (rows r * 32 Q - pad + 1 .. of the
+// bottom-aligned pattern, pad in block 0) is a task of its own: it walks only the columns jlo .. jhi its rows can meet on diagonals -x .. delta + x
+// (x = floor((ub - delta) / 2) + 1: a path of cost <= ub leaves the corridor 0 .. delta by no more), 64 pairs per wave like d_edit_lane, no hand-off between
+// lanes.  What it needs from the block above - the horizontal delta of that block's last row, two bits per column - comes through memory (written by the launch
+// of rank r - 1; columns behind that block's range step +1), together with the value of its last row in front of this block's first column; the column in
+// front of the block's range steps +1 per row.  Both assumptions are upper bounds of cells no path of cost <= ub visits (the cut-off argument of the staircase
+// window), so the last block's last row ends at the distance.  Deltas stay in {-1, 0, +1}: the boundaries are.
+struct BlkArgs { int rank; uint32_t* bnd_in; uint32_t* bnd_out; int* e_in; int* e_out; long long wmax; };
+__device__ __forceinline__ long long blk_word_at(long long slot, long long wmax, int wi, int plane) { return (((slot >> 6) * wmax + wi) * 2 + plane) * 64 + (slot & 63); }
+
+template <int Q, int P>
+__device__ __forceinline__ void d_edit_blocked(const BlkArgs& A, long long slot_base, long long blk, long long count, const uint32_t* list, const uint32_t* scratch,
+                                               const PairDesc* desc, const long long* slot_of, int32_t* ed, unsigned long long* wc) {
+    constexpr int RL = 32 * Q;
+    const long long t = blk * 256 + threadIdx.x;
+    bool live = t < count;
+    uint32_t widx = 0;
+    PairDesc pd; pd.m = 1; pd.n = 1; pd.pat = 0; pd.txt = 0; pd.ub = 2; pd.cls = 0;
+    if (live) { widx = list[t]; pd = desc[widx]; }
+    const long long slot = slot_base + t;
+    const int m = pd.m, n = pd.n, r = A.rank;
+    const int B = (m + RL - 1) / RL;
+    if (r >= B) live = false;
+    const int pad = B * RL - m, delta = n - m;
+    int ub = pd.ub; if (ub > m + n) ub = m + n; if (ub < delta) ub = delta;
+    const int x = (ub - delta) / 2 + 1;
+    const int ihi = (r + 1) * RL - pad, ilo = r * RL - pad + 1 > 1 ? r * RL - pad + 1 : 1;
+    const int jlo = ilo - x > 1 ? ilo - x : 1;
+    const long long jhi_l = (long long)ihi + delta + x;
+    const int jhi = jhi_l > n ? n : (int)jhi_l;
+    const long long jhp_l = (long long)(r * RL - pad) + delta + x;                       // last column of the block above
+    const int jhi_prev = jhp_l > n ? n : (int)jhp_l;
+    const int jlo_next = ihi + 1 - x > 1 ? ihi + 1 - x : 1;                              // first column of the block below
+    const int len = live && jhi >= jlo ? jhi - jlo + 1 : 0;
+    const Packed pat{scratch + pd.pat, CLS_PAT_SH(pd.cls)};
+    const int ts = (CLS_TXT_SH(pd.cls) >> 2) + jlo - 1;                                 // text symbol of column jlo, counted from the record word pd.txt
+    const Packed txt{scratch + pd.txt + (ts >> 3), (ts & 7) << 2};
+    uint32_t pv[Q], mv[Q], pl[P][Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int nvirt = r == 0 ? pad - 32 * q : 0;                                    // virtual rows above row 1 (block 0 only): vertical delta -1
+        const uint32_t mlow = nvirt >= 32 ? 0xffffffffu : (nvirt <= 0 ? 0u : ((1u << nvirt) - 1u));
+        mv[q] = mlow; pv[q] = ~mlow;
+        uint32_t e[P];
+        planes32_at<P>(pat, r * RL + 32 * q - pad, live, e);
+#pragma unroll
+        for (int b = 0; b < P; b++) pl[b][q] = e[b];
+    }
+    // value of the block's last row in front of its first column: column 0 (D[i][0] = i), or what the block above handed over + one per row
+    int cur = jlo == 1 ? ihi : (live ? A.e_in[slot] : 0) + RL;
+    int lenmax = len;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(lenmax, o, 64); lenmax = v > lenmax ? v : lenmax; }
+    const int txt_words = (len + 7) >> 3;
+    uint32_t tw_next = txt_words > 0 ? txt.word(0) : 0u;
+    uint32_t in_p = 0u, in_m = 0u, out_p = 0u, out_m = 0u;
+    const bool has_above = r > 0, has_below = r + 1 < B;
+    for (int cb = 0; cb * 8 < lenmax; cb++) {
+        const uint32_t tw = tw_next;
+        tw_next = (cb + 1 < txt_words) ? txt.word(cb + 1) : 0u;
+        uint32_t tp[P];
+        planes8<P>(tw, tp);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = cb * 8 + k;
+            if (c < len) {
+                const int a = jlo - 1 + c, sh = a & 31;                                 // column j = a + 1; its bit in the boundary words
+                unsigned cyp = 1, cym = 0;
+                if (has_above) {
+                    if (c == 0 || sh == 0) { in_p = A.bnd_in[blk_word_at(slot, A.wmax, a >> 5, 0)]; in_m = A.bnd_in[blk_word_at(slot, A.wmax, a >> 5, 1)]; }
+                    if (a < jhi_prev) { cyp = (in_p >> sh) & 1u; cym = (in_m >> sh) & 1u; }
+                }
+                uint32_t nk[P];
+#pragma unroll
+                for (int b = 0; b < P; b++) nk[b] = ((tp[b] >> k) & 1u) - 1u;
+                unsigned carry = 0;
+                const uint32_t hin_m = cym;
+                uint32_t ph_last, mh_last;
+                MYERS_COLUMN_B(Q, P, pl, pv, mv, nk, hin_m, carry, cyp, cym, ph_last, mh_last)
+                cur += (int)cyp - (int)cym;                                             // the bits pushed out of the last word: the horizontal delta of the block's last row
+                if (has_below) {
+                    out_p |= cyp << sh; out_m |= cym << sh;
+                    if (sh == 31 || c == len - 1) {
+                        A.bnd_out[blk_word_at(slot, A.wmax, a >> 5, 0)] = out_p; A.bnd_out[blk_word_at(slot, A.wmax, a >> 5, 1)] = out_m;
+                        out_p = 0u; out_m = 0u;
+                    }
+                    if (a + 1 == jlo_next - 1) A.e_out[slot] = cur;
+                }
+            }
+        }
+    }
+    wc_account(wc, (long long)lenmax * Q * 64, (long long)len * Q);
+    if (live && !has_below) ed[slot_of ? slot_of[widx] : (long long)widx] = cur;
+}
+
 // ---- 3c. full matrix, G lanes per pair, 32 Q rows (Q = 16 or 12 words) per lane ------------------------------------------------
 // The column is ONE wide bit-vector spread over the first L = ceil(m / (32 Q)) lanes of a group, bottom-aligned like above (row m is
 // bit 31 of lane L-1's last word); lane g of a group works on text column t-g at step t and hands (symbol, adder carry,
@@ -1435,6 +1551,24 @@ __global__ __launch_bounds__(256) void k_edit_fulls(FusedTab tab, const uint32_t
     }
 }
 
+// the row-block launches of the classes below (SVX_EDIT_BLOCKED): one launch per block rank, segments as in k_edit_fulls; slot_base[s] = position of the
+// segment's first pair among the blocked pairs of the round (the index of its boundary words)
+struct BlkTab { long long slot_base[SEG_MAX]; };
+template <int P>
+__global__ __launch_bounds__(256) void k_edit_blocked(FusedTab tab, BlkTab bt, BlkArgs A, const uint32_t* list, const uint32_t* scratch, const PairDesc* desc,
+                                                      const long long* slot_of, int32_t* ed, unsigned long long* wc) {
+    int s = 0;
+    while (s + 1 < tab.n && blockIdx.x >= tab.first_block[s + 1]) s++;
+    const long long blk = (long long)(blockIdx.x - tab.first_block[s]);
+    const uint32_t* l = list + tab.lo[s];
+    switch (tab.kind[s]) {
+        case 10: d_edit_blocked<10, P>(A, bt.slot_base[s], blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case 12: d_edit_blocked<12, P>(A, bt.slot_base[s], blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        case 14: d_edit_blocked<14, P>(A, bt.slot_base[s], blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+        default: d_edit_blocked<16, P>(A, bt.slot_base[s], blk, tab.cn[s], l, scratch, desc, slot_of, ed, wc); break;
+    }
+}
+
 
 __global__ __launch_bounds__(64) void k_edit_full_big(long long count, const uint32_t* big_list, const long long* state_off, const uint32_t* scratch,
                                                       const PairDesc* desc, const long long* slot_of, int32_t* ed, uint32_t* state) {
@@ -1453,8 +1587,16 @@ __global__ void k_slots(long long n_work, PairSource src, long long* slot_of) {
 }
 
 // class boundaries in the sorted key array: first index whose sort class >= c, for c = 0..N_SORT_CLASSES
-__global__ void k_class_bounds(const uint64_t* keys, long long n, long long* bounds) {
+// threads 128 .. 191 (row-block route): split[c] = first index of class c whose cost order is at most `limit` (the pairs of a class are sorted by descending cost)
+__global__ void k_class_bounds(const uint64_t* keys, long long n, long long* bounds, long long* split, long long limit) {
     const int c = threadIdx.x;
+    if (c >= 128 && c < 128 + N_SORT_CLASSES && split) {
+        const unsigned long long top = (1ull << SORT_COST_BITS) - 1, want = sort_key_of((unsigned long long)(c - 128), top - (unsigned long long)(limit < 0 ? 0 : ((unsigned long long)limit > top ? top : limit)));
+        long long lo = 0, hi = n;
+        while (lo < hi) { const long long mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+        split[c - 128] = lo;
+        return;
+    }
     if (c > N_SORT_CLASSES) return;
     long long lo = 0, hi = n;
     while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)(keys[mid] >> SORT_COST_BITS) < c) lo = mid + 1; else hi = mid; }
@@ -1621,13 +1763,24 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     if (const char* e = getenv("SVX_EDIT_NARROW")) narrow_windows = atoi(e) == 0 ? 0 : 1;
     long long few_pairs = 2048;                             // SVX_EDIT_FEW_PAIRS: calls with at most this many pairs take the low-latency route (0 = never)
     if (const char* e = getenv("SVX_EDIT_FEW_PAIRS")) few_pairs = atoll(e);
-    k_edit_classify<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, desc, key_a, val_a, c->edit_force_full ? 1 : 0, cnt + 2, n_work <= few_pairs ? 1 : 0);
+    // SVX_EDIT_BLOCKED=1 (round 6, opt-in): the round-0 pairs of the 2- and 4-lane full-matrix families run in row blocks that skip the corners outside the band of
+    // the pair's upper bound (d_edit_blocked); SVX_EDIT_BLOCKED_K: up to which family (0: 2 lanes, 1: 4 lanes [default], 2: 8 lanes)
+    int blocked_kmax = -1;
+    if (const char* e = getenv("SVX_EDIT_BLOCKED")) if (e[0] == '1' && !c->edit_force_full && n_work > few_pairs) { blocked_kmax = 1; if (const char* k = getenv("SVX_EDIT_BLOCKED_K")) blocked_kmax = atoi(k) < 0 ? 0 : (atoi(k) > 2 ? 2 : atoi(k)); }
+    k_edit_classify<<<(unsigned)((n_work + T - 1) / T), T, 0, st>>>(n_work, desc, key_a, val_a, c->edit_force_full ? 1 : 0, cnt + 2, (n_work <= few_pairs ? 1 : 0) | ((blocked_kmax + 1) << 1));
     HIPCHK(hipGetLastError());
     // 3. group by class (and by descending text length inside a class, so that the 64 pairs of a wave finish together)
     SVXCHK(svx_sort_pairs_u64(c, key_a, key_b, val_a, val_b, n_work, 0, SORT_COST_BITS + 7));      // 17 bits of cost order + 7 bits of class: three passes
-    k_class_bounds<<<1, 128, 0, st>>>(key_b, n_work, reinterpret_cast<long long*>(cnt + 8));
-    long long bounds[N_SORT_CLASSES + 1];
-    SVXCHK(svx_mail_read(c, st, cnt + 8, N_SORT_CLASSES + 1, bounds));
+    // the row-block route takes the pairs of its classes that walk at most this many columns per block (the blocks of a pair are serial launches: the longest
+    // texts would make the chain of launches the tail of the window) - the others stay in the multi-lane forms (SVX_EDIT_BLOCKED_WALK)
+    long long blocked_walk = 2500;
+    if (const char* e = getenv("SVX_EDIT_BLOCKED_WALK")) blocked_walk = atoll(e);
+    SVXCHK(c->e_hist.reserve(256 * 8));
+    k_class_bounds<<<1, 256, 0, st>>>(key_b, n_work, reinterpret_cast<long long*>(cnt + 8), blocked_kmax >= 0 ? c->e_hist.as<long long>() : nullptr, blocked_walk);
+    long long bounds[N_SORT_CLASSES + 1], blocked_split[N_SORT_CLASSES];
+    unsigned long long blocked_nmax = 0;
+    if (blocked_kmax >= 0) SVXCHK(svx_mail_read3(c, st, cnt + 8, N_SORT_CLASSES + 1, bounds, cnt + 3, 1, &blocked_nmax, c->e_hist.p, N_SORT_CLASSES, blocked_split));
+    else SVXCHK(svx_mail_read(c, st, cnt + 8, N_SORT_CLASSES + 1, bounds));
     // A retry round with only a few band pairs is bound by the LATENCY of its slowest pair: a band retry walks its columns in one lane with 6-16 state words
     // (configs[1], round 1: 196 pairs, one wave of 16-word windows = 0.31 ms at the very end of the window), a full matrix spread over the 64 lanes of a wave
     // (KIND_RETRY) finishes the same pair in a fifth of that and never fails, so the round is also the last.  Up to this many band pairs of a retry round go there
@@ -1649,6 +1802,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     long long pending = 0;
     for (int sc = 0; sc < N_SORT_CLASSES; sc++) { seg_lo[sc] = bounds[sc]; seg_cn[sc] = bounds[sc + 1] - bounds[sc]; pending += seg_cn[sc]; }
     const uint32_t* list = val_b;
+    bool blocked_used = false;
     for (int round = 0; pending > 0; round++) {
         if (round >= MAX_ROUNDS) return svx_fail(SVX_E_STATE, "edit-distance retry loop did not converge", __FILE__, __LINE__, hipSuccess);
         if (profile) profile_round(c, round, seg_lo, seg_cn, list, desc, n_work);
@@ -1669,8 +1823,15 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         static const int order[SEG_MAX] = {CLS_FULL, CLS_WIDE0 + 3, CLS_WIDE14 + 3, CLS_WIDE12 + 3, CLS_WIDE10 + 3, CLS_WIDE0 + 2, CLS_WIDE14 + 2, CLS_WIDE12 + 2, CLS_WIDE10 + 2,
                                            CLS_WIDE0 + 1, CLS_WIDE14 + 1, CLS_WIDE12 + 1, CLS_WIDE10 + 1, CLS_WIDE0, CLS_WIDE14, CLS_WIDE12, CLS_WIDE10,
                                            CLS_LANE0 + 4, CLS_LANE0 + 3, CLS_LANE0 + 2, CLS_LANE0 + 1, CLS_LANE0};     // longest serial chains first
-        auto launch_fulls = [&](int generic, const long long* lo, const long long* cn_of, const uint32_t* lst, hipStream_t fs, unsigned long long* wc, int label) -> int {
+        auto launch_fulls = [&](int generic, const long long* lo, const long long* cn_of_in, const uint32_t* lst, hipStream_t fs, unsigned long long* wc, int label, bool skip_blocked = false) -> int {
             const int base = GENERIC_BASE * generic;
+            long long cn_local[N_SORT_CLASSES];
+            for (int sc = 0; sc < N_SORT_CLASSES; sc++) cn_local[sc] = cn_of_in[sc];
+            if (skip_blocked) for (int cls = CLS_WIDE0; cls < N_CLASSES; cls++) if (blocked_words(cls, blocked_kmax)) {      // the pairs behind the split run in row blocks
+                long long sp = blocked_split[base + cls]; if (sp < lo[base + cls]) sp = lo[base + cls]; if (sp > lo[base + cls] + cn_local[base + cls]) sp = lo[base + cls] + cn_local[base + cls];
+                cn_local[base + cls] = sp - lo[base + cls];
+            }
+            const long long* cn_of = cn_local;
             FusedTab tf; memset(&tf, 0, sizeof tf);
             unsigned nblk = 0;
             auto class_threads = [&](int cls, long long cn) -> long long {
@@ -1787,7 +1948,42 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                     fprintf(stderr, "{\"edit_launch\": {\"round\": %d, \"kind\": \"bands\", \"generic\": %d, \"blocks\": %u, \"ms\": %.4f}}\n", round, generic, nblk, ms);
                 }
             }
-            SVXCHK(launch_fulls(generic, seg_lo, seg_cn, list, full_st[round & 1], wc_full, round));
+            SVXCHK(launch_fulls(generic, seg_lo, seg_cn, list, full_st[round & 1], wc_full, round, round == 0 && blocked_kmax >= 0));
+            if (round == 0 && blocked_kmax >= 0) {
+                // the row-block route: one launch per block rank on a high-priority stream of its own; boundary words and hand-over values ping-pong between ranks
+                FusedTab tb; memset(&tb, 0, sizeof tb);
+                BlkTab bt; memset(&bt, 0, sizeof bt);
+                unsigned nblk = 0;
+                long long slots = 0;
+                for (int cls = N_CLASSES - 1; cls >= (int)CLS_WIDE0; cls--) {
+                    const int bq = blocked_words(cls, blocked_kmax);
+                    if (!bq || seg_cn[base + cls] <= 0) continue;
+                    long long sp = blocked_split[base + cls]; if (sp < seg_lo[base + cls]) sp = seg_lo[base + cls]; if (sp > seg_lo[base + cls] + seg_cn[base + cls]) sp = seg_lo[base + cls] + seg_cn[base + cls];
+                    const long long cn = seg_lo[base + cls] + seg_cn[base + cls] - sp;
+                    if (cn <= 0) continue;
+                    tb.kind[tb.n] = bq; tb.lo[tb.n] = sp; tb.cn[tb.n] = cn; tb.first_block[tb.n] = nblk; bt.slot_base[tb.n] = slots;
+                    nblk += (unsigned)((cn + T - 1) / T); slots += (cn + 63) / 64 * 64; tb.n++;
+                }
+                tb.first_block[tb.n] = nblk;
+                if (tb.n) {
+                    const long long wmax = (long long)((blocked_nmax + 31) / 32) + 1;
+                    const size_t bnd_words = (size_t)(slots / 64) * (size_t)wmax * 2 * 64;
+                    DevBuf& bb = generic ? c->e_blk[1] : c->e_blk[0];
+                    SVXCHK(bb.reserve((bnd_words * 2 + (size_t)slots * 2) * 4 + 256));
+                    uint32_t* bnd0 = bb.as<uint32_t>(); uint32_t* bnd1 = bnd0 + bnd_words;
+                    int* e0 = reinterpret_cast<int*>(bnd1 + bnd_words); int* e1 = e0 + slots;
+                    hipStream_t bs = c->aux[7];
+                    const int ranks = 2 << blocked_kmax;
+                    for (int r = 0; r < ranks; r++) {
+                        BlkArgs A; A.rank = r; A.wmax = wmax;
+                        A.bnd_in = (r & 1) ? bnd0 : bnd1; A.bnd_out = (r & 1) ? bnd1 : bnd0; A.e_in = (r & 1) ? e0 : e1; A.e_out = (r & 1) ? e1 : e0;
+                        if (generic) k_edit_blocked<4><<<nblk, T, 0, bs>>>(tb, bt, A, list, scratch, desc, slot_of, ed_dev, wc_full);
+                        else k_edit_blocked<2><<<nblk, T, 0, bs>>>(tb, bt, A, list, scratch, desc, slot_of, ed_dev, wc_full);
+                    }
+                    HIPCHK(hipGetLastError());
+                    blocked_used = true;
+                }
+            }
         }
         long long early_cn[N_SORT_CLASSES];
         for (int sc = 0; sc < N_SORT_CLASSES; sc++) early_cn[sc] = 0;
@@ -1825,6 +2021,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     // the end of the rounds: the main stream waits for both full-matrix streams, sums the counters (k_edit_tail) and posts them - one wait for the host
     unsigned long long tail[6];
     for (int k = 0; k < 2; k++) { HIPCHK(hipEventRecord(c->ev[22 + k], full_st[k])); HIPCHK(hipStreamWaitEvent(st, c->ev[22 + k], 0)); }
+    if (blocked_used) { HIPCHK(hipEventRecord(c->ev[19], c->aux[7])); HIPCHK(hipStreamWaitEvent(st, c->ev[19], 0)); }
     k_edit_tail<<<1, 256, 0, st>>>(cnt, cnt + WC_OFF, MAX_ROUNDS, cnt + 8);             // (the class bounds at cnt[8..] are history by now)
     HIPCHK(hipGetLastError());
     SVXCHK(svx_mail_read(c, st, cnt + 8, 6, tail));

@@ -66,6 +66,50 @@
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     } }
 
+// The same column for a ROW BLOCK that receives its top boundary from memory (d_edit_blocked, edit.hip): cyp_ / cym_ hold the (plus, minus) horizontal delta of the
+// row above the block, hin_m_ = the minus bit again (0 / 1) - ORed into the match vector's first bit AFTER xv was taken, as in Myers' block formulation (the
+// adder's carry does not cross a block boundary: carry_ comes in as 0).
+#define MYERS_COLUMN_B(Q_, P_, pl_, pv_, mv_, nk_, hin_m_, carry_, cyp_, cym_, ph_last_, mh_last_) {              \
+    _Pragma("unroll") for (int q0 = 0; q0 < Q_; q0 += MYERS_GROUP(Q_)) {                                        \
+        constexpr int GQ = MYERS_GROUP(Q_);                                                                     \
+        const int gn = Q_ - q0 < GQ ? Q_ - q0 : GQ;                              /* words in this group (the last one may be short) */ \
+        uint32_t eq_[GQ], xv_[GQ], sum_[GQ], ph_[GQ], mh_[GQ], phs_[GQ], mhs_[GQ];                              \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
+            uint32_t e = pl_[0][q0 + g] ^ nk_[0];                                                               \
+            if (P_ == 2) e = BITOP3(e, pl_[1][q0 + g], nk_[1], 0x60);             /* e & (p1 ^ n1) */              \
+            else { _Pragma("unroll") for (int b = 1; b < P_; b++) e &= pl_[b][q0 + g] ^ nk_[b]; }               \
+            eq_[g] = e;                                                                                         \
+        }                                                                                                       \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
+            xv_[g] = eq_[g] | mv_[q0 + g];                                                                      \
+            if (q0 == 0 && g == 0) eq_[g] |= (hin_m_);                 /* Myers' block rule: a -1 coming in from above is a match in row 1 */ \
+            sum_[g] = eq_[g] & pv_[q0 + g];                                                                     \
+            asm("" : "+v"(xv_[g]));     /* opaque: keeps `phs & xv` a two-operand v_and */                       \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
+            unsigned carry_out;                                                                                 \
+            sum_[g] = __builtin_addc(sum_[g], pv_[q0 + g], carry_, &carry_out);    /* v_addc_co_u32: the carry stays in an SGPR pair */ \
+            carry_ = carry_out;                                                                                 \
+        }                                                                                                       \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) sum_[g] = BITOP3(sum_[g], pv_[q0 + g], eq_[g], 0xBE);     /* xh = (sum ^ pv) | eq */ \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
+            ph_[g] = BITOP3(mv_[q0 + g], sum_[g], pv_[q0 + g], 0xF1);             /* mv | ~(xh | pv) */           \
+            mh_[g] = pv_[q0 + g] & sum_[g];                                                                     \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn)                                              \
+            MYERS_SHIFT(q0 + g, 0, ph_[g], mh_[g], phs_[g], mhs_[g], cyp_, cym_)                              \
+        ph_last_ = ph_[gn - 1]; mh_last_ = mh_[gn - 1];                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int g = 0; g < GQ; g++) if (g < gn) {                                            \
+            pv_[q0 + g] = BITOP3(mhs_[g], xv_[g], phs_[g], 0xF1);                 /* mhs | ~(xv | phs) */         \
+            mv_[q0 + g] = phs_[g] & xv_[g];                                                                     \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } }
+
+
 // Word interface (tools/micro): the bits coming in from above are bit 31 of ph_prev_ / mh_prev_, the bits pushed out are left there.
 #define MYERS_COLUMN(Q_, P_, pl_, pv_, mv_, nk_, carry_, ph_prev_, mh_prev_) {                                  \
     unsigned cyp_w_ = (ph_prev_) >> 31, cym_w_ = (mh_prev_) >> 31;                                               \

@@ -657,6 +657,60 @@ def test_partition_and_cluster_candidates_matches_reference(eng):
         assert H.close(a[7], b[7]) and H.close(a[8], b[8])
 
 
+@pytest.mark.parametrize("kmax", ["0", "1", "2"])
+def test_edit_distance_row_blocks_vs_oracle(oracle, monkeypatch, kmax):
+    """SVX_EDIT_BLOCKED=1 (round 6): the round-0 pairs of the 2-, 4- (and 8-) lane full-matrix families run as row blocks that only walk the columns inside the
+    band of the pair's own upper bound, the blocks of a pair in successive launches with their boundary rows handed over through memory.  Pairs at every block-count
+    boundary of the four word widths, with a large length gap (what sends a pair to a full matrix in the first place): related ones (one long deletion + a few edits:
+    tight upper bound, narrow band, big corners), loosely related and unrelated ones (upper bound = the trivial one: nothing is spared).  Equal to the default route
+    on every pair and to the oracle on a sample."""
+    from svim_amd._lib import Engine
+    rng = random.Random(29)
+    pairs = []
+    for m in (330, 512, 513, 639, 640, 641, 700, 767, 768, 769, 895, 896, 897, 1000, 1023, 1024, 1025, 1279, 1280, 1281, 1400, 1535, 1536, 1537, 1700, 1791, 1792, 1793,
+              1900, 2047, 2048, 2049, 2300, 2559, 2560, 2561, 3000, 3071, 3072, 3073, 3500, 3583, 3584, 3585, 4000, 4095, 4096):
+        for gap in (650, 1100, 2500):
+            for kind in range(6):
+                b = synth.random_seq(rng, m + gap)
+                if kind == 3:
+                    a = synth.random_seq(rng, m)                                    # unrelated
+                elif kind >= 4:
+                    # the shorter string is the longer one's head (kind 4: the left-justified alignment bounds the distance tightly - a narrow band, the largest
+                    # corners) or its tail (kind 5), with a few substitutions spread over it
+                    a = list(b[:m] if kind == 4 else b[gap:])
+                    for q in range(7, m, max(1, m // 9)):
+                        a[q] = "ACGT"[("ACGT".index(a[q]) + 1) % 4]
+                    a = "".join(a)
+                else:
+                    cut = rng.randrange(0, m)
+                    a = list(b[:cut] + b[cut + gap:])                                # one long deletion ...
+                    for _ in range((0, 6, m // 12)[kind]):                           # ... and none / a few / many point edits
+                        q = rng.randrange(len(a))
+                        a[q] = rng.choice("ACGT")
+                    a = "".join(a)
+                pairs.append((a, b) if rng.random() < 0.5 else (b, a))
+    # (a call of at most SVX_EDIT_FEW_PAIRS pairs takes the low-latency route: short filler pairs make this one a large call)
+    filler = [(synth.random_seq(rng, 40), synth.random_seq(rng, 44)) for _ in range(2100)]
+    idx = rng.sample(range(len(pairs)), 120)
+    exp = {i: oracle.edit_distance(*pairs[i]) for i in idx}
+    results = []
+    # (SVX_EDIT_BLOCKED_WALK: pairs that walk more columns per block stay in the multi-lane forms - the default split in one variant, everything in row blocks in the others)
+    walk = {} if kmax == "2" else {"SVX_EDIT_BLOCKED_WALK": "1000000"}
+    for env in ({}, dict({"SVX_EDIT_BLOCKED": "1", "SVX_EDIT_BLOCKED_K": kmax}, **walk)):
+        for k in ("SVX_EDIT_BLOCKED", "SVX_EDIT_BLOCKED_K", "SVX_EDIT_BLOCKED_WALK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = Engine()
+        try:
+            results.append(e.edit_distances(pairs + filler))
+        finally:
+            e.close()
+    assert results[0] == results[1]
+    for i in idx:
+        assert results[1][i] == exp[i], (i, len(pairs[i][0]), len(pairs[i][1]))
+
+
 @pytest.mark.parametrize("few_pairs", [None, "0"])
 def test_edit_distance_full_matrix_classes_vs_oracle(oracle, monkeypatch, few_pairs):
     """Unrelated pairs at every row-count boundary of the full-matrix classes (one lane <= 512 rows; 2/4/8/16 lanes of 10, 12, 14 or 16
