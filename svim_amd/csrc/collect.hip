@@ -638,7 +638,11 @@ __global__ void k_permute_sigs(SigPtrs in, SigPtrs out, const uint32_t* idx, lon
 __global__ __launch_bounds__(256) void k_gather_seq(SigPtrs s, long long n, const int64_t* seq_off, uint8_t* seq_out,
                                                     const uint64_t* rec_seq_off, const uint8_t* rec_seq, const uint32_t* rng_off, const int32_t* rng_q0,
                                                     const int32_t* rng_len, const uint64_t* rng_byte, unsigned long long* missing) {
-    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // 16 lanes per signature, four signatures per wave (round 6: a wave per signature - most of them deletions without bases, the insertions ~ 370 bases - spent its
+    // time on its chain of dependent loads, signature -> record -> bytes; four chains per wave: 0.33 -> 0.1x ms on configs[1])
+    constexpr int GS = 16;
+    const int lane = lane_id() & (GS - 1);
+    const long long i = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / GS) + (lane_id() / GS);
     if (i >= n) return;
     const int len = s.qlen[i];
     if (len <= 0) return;
@@ -652,11 +656,11 @@ __global__ __launch_bounds__(256) void k_gather_seq(SigPtrs s, long long n, cons
             const int a = rng_q0[r];
             if (a <= q0 && q0 + len <= a + rng_len[r]) { src = rec_seq + rng_byte[r]; q0 -= a; break; }      // a is even: nibble parity is kept
         }
-        if (!src) { if (lane_id() == 0) atomicAdd(missing, 1ull); return; }
+        if (!src) { if (lane == 0) atomicAdd(missing, 1ull); return; }
     } else src = rec_seq + rec_seq_off[s.rec[i]];
     // 8 bases per lane and step: one 8-byte load + one 8-byte store while 16 more bases of THIS slice remain (the load then stays inside
     // the record's own bytes), byte accesses for the last chunks
-    for (int k0 = lane_id() * 8; k0 < len; k0 += 512) {
+    for (int k0 = lane * 8; k0 < len; k0 += 8 * GS) {
         const int q = q0 + k0;
         if (k0 + 16 <= len) {
             unsigned long long x;
@@ -788,7 +792,7 @@ int svx_collect_impl(svx_ctx* c, const svx_batch* bd, const svx_params* p) {
         SVXCHK(svx_exclusive_scan_i32_to_i64(c, c->sig.qlen.as<int32_t>(), c->sig.seq_off.as<int64_t>(), n_sig + 1));
         SVXCHK(svx_mail_read(c, st, c->sig.seq_off.as<int64_t>() + n_sig, 1, &n_seq));
         SVXCHK(c->sig.seq.reserve((size_t)n_seq + 16));
-        k_gather_seq<<<(unsigned)((n_sig + 3) / 4), 256, 0, st>>>(sig_ptrs(c->sig), n_sig, c->sig.seq_off.as<int64_t>(), c->sig.seq.as<uint8_t>(),
+        k_gather_seq<<<(unsigned)((n_sig + 15) / 16), 256, 0, st>>>(sig_ptrs(c->sig), n_sig, c->sig.seq_off.as<int64_t>(), c->sig.seq.as<uint8_t>(),
                                                                  b.seq_off, b.seq, b.seq_rng_off, b.seq_rng_q0, b.seq_rng_len, b.seq_rng_byte,
                                                                  c->counters.as<unsigned long long>() + CNT_SEQ_MISSING);
         HIPCHK(hipGetLastError());

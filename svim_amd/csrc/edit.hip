@@ -1687,7 +1687,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     const int T = 256;
     PairSource src = src_in;
     src.n_pairs = n_work;
-    const size_t WC_OFF = 128 + MAX_ROUNDS * N_SORT_CLASSES, WC_PER_LAUNCH = 2 * WC_SHARDS, CNT_WORDS = WC_OFF + MAX_ROUNDS * 2 * WC_PER_LAUNCH;
+    const size_t WC_OFF = 128 + MAX_ROUNDS * N_SORT_CLASSES, WC_PER_LAUNCH = 2 * WC_SHARDS, EARLY_OFF = WC_OFF + MAX_ROUNDS * 2 * WC_PER_LAUNCH, CNT_WORDS = EARLY_OFF + N_SORT_CLASSES;
     SVXCHK(c->e_fail.reserve(CNT_WORDS * 8));
     unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..40] class bounds of round 0 (first [16..31] the span shards), [128 + 64 r ..] retry counters written by round r, [WC_OFF ..] word-column counters per (round, kind)
     HIPCHK(hipMemsetAsync(cnt, 0, CNT_WORDS * 8, st));
@@ -1814,7 +1814,13 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         // last read by round-2's launches
         DevBuf& fb = c->e_retry[round % 3];
         if (round >= 2) HIPCHK(hipStreamSynchronize(full_st[round & 1]));
-        SVXCHK(fb.reserve((size_t)N_SORT_CLASSES * (size_t)pending * 4 + 64));
+        // (two sets of lists: the second one and the counters at EARLY_OFF belong to the FIRST PART of round 0 alone.  Its failures are launched as soon as that
+        // part's kernels have ended - their list entries are then visible - while the second part is still appending to the round's own lists: a counter of those
+        // says how many entries have been CLAIMED, not how many have been written, and a store of a running kernel need not have left its XCD's L2.  Until round 6
+        // both parts shared lists and the early launch took "what the counters say now": entries of the second part in flight among them.)
+        SVXCHK(fb.reserve((size_t)2 * N_SORT_CLASSES * (size_t)pending * 4 + 64));
+        uint32_t* const fb_early = fb.as<uint32_t>() + (size_t)N_SORT_CLASSES * (size_t)pending;
+        unsigned long long* const fail_cnt_early = cnt + EARLY_OFF;
         unsigned long long* fail_cnt = cnt + 128 + (size_t)round * N_SORT_CLASSES;
         unsigned long long* wc_band = cnt + WC_OFF + (size_t)(round * 2) * WC_PER_LAUNCH;
         unsigned long long* wc_full = wc_band + WC_PER_LAUNCH;
@@ -1932,12 +1938,14 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                 // the kernel built for 12 state words keeps more waves per SIMD: every launch without the two widest classes takes it
                 bool wide16 = false;
                 for (int k = 0; k < tb.n; k++) if (band_words(tb.kind[k]) > 12) wide16 = true;
+                unsigned long long* const fc = (split && part == 0) ? fail_cnt_early : fail_cnt;
+                uint32_t* const fl = (split && part == 0) ? fb_early : fb.as<uint32_t>();
                 if (generic) {
-                    if (wide16) k_edit_bands<4, 16><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
-                    else k_edit_bands<4, 12><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
+                    if (wide16) k_edit_bands<4, 16><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fc, fl, pending, wc_band);
+                    else k_edit_bands<4, 12><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fc, fl, pending, wc_band);
                 } else {
-                    if (wide16) k_edit_bands<2, 16><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
-                    else k_edit_bands<2, 12><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fail_cnt, fb.as<uint32_t>(), pending, wc_band);
+                    if (wide16) k_edit_bands<2, 16><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fc, fl, pending, wc_band);
+                    else k_edit_bands<2, 12><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fc, fl, pending, wc_band);
                 }
                 HIPCHK(hipGetLastError());
                 if (split && part == 0) split_used[generic] = true;
@@ -1989,16 +1997,17 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         for (int sc = 0; sc < N_SORT_CLASSES; sc++) early_cn[sc] = 0;
         if (split_used[0] || split_used[1]) {
             unsigned long long h[N_SORT_CLASSES];
-            SVXCHK(svx_mail_read(c, c->aux[5], fail_cnt, N_SORT_CLASSES, h));              // posted behind the first part(s) on their (high-priority) stream
+            SVXCHK(svx_mail_read(c, c->aux[5], fail_cnt_early, N_SORT_CLASSES, h));        // posted behind the first part(s) on their (high-priority) stream: their kernels have ended
             long long e_lo[N_SORT_CLASSES];
             for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
                 e_lo[sc] = (long long)sc * pending;
                 const int cls = sc % GENERIC_BASE;
-                early_cn[sc] = (cls >= NBAND && split_used[sc / GENERIC_BASE]) ? (long long)h[sc] : 0;      // full-matrix classes only; band retries wait for the round
+                early_cn[sc] = split_used[sc / GENERIC_BASE] ? (long long)h[sc] : 0;       // (a pair that fails the widest bands goes to a full-matrix class: band_retry)
+                if (cls < NBAND && early_cn[sc]) return svx_fail(SVX_E_STATE, "a pair of the widest band classes retried in a band class", __FILE__, __LINE__, hipSuccess);
             }
             hipStream_t fs = full_st[(round + 1) & 1];
             unsigned long long* wc_next = cnt + WC_OFF + (size_t)((round + 1) * 2 + 1) * WC_PER_LAUNCH;
-            for (int generic = 0; generic <= 1; generic++) SVXCHK(launch_fulls(generic, e_lo, early_cn, fb.as<uint32_t>(), fs, wc_next, round + 1));
+            for (int generic = 0; generic <= 1; generic++) SVXCHK(launch_fulls(generic, e_lo, early_cn, fb_early, fs, wc_next, round + 1));
         }
         // only the band launches can hand pairs to the next round
         const long long cap = pending;
@@ -2011,8 +2020,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
             unsigned long long h[N_SORT_CLASSES];
             SVXCHK(svx_mail_read(c, st, fail_cnt, N_SORT_CLASSES, h));
             for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
-                seg_lo[sc] += early_cn[sc];                                       // that part of the list is running already
-                seg_cn[sc] = (long long)h[sc] - early_cn[sc];
+                seg_cn[sc] = (long long)h[sc];                                    // (the first part's failures have lists of their own and are running already)
                 pending += seg_cn[sc];
             }
         }

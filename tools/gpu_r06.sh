@@ -110,5 +110,18 @@ evidence)
   git rev-parse HEAD > $out/${tag}_evidence_commit.txt 2>/dev/null || true
   ls -la $out/${tag}_* | head -40
   ;;
+rccl20)
+  # the review's item: the single-rank RCCL test 20 x in fresh processes under NCCL_DEBUG=INFO with a 120 s watchdog - does process-group creation ever stall?
+  ok=0; bad=0
+  for k in $(seq 1 ${REPEAT:-20}); do
+    t0=$(date +%s.%N)
+    NCCL_DEBUG=INFO timeout 120 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "test_multigpu_step_single_rank_device_path or test_bench_under_torchrun_multi_gpu_code_path_single_rank" > $out/${tag}_rccl_run.log 2>&1
+    rc=$?; t1=$(date +%s.%N)
+    echo "run $k: rc=$rc $(python -c "print('%.1f s' % ($t1 - $t0))") $(tail -1 $out/${tag}_rccl_run.log) | NCCL lines: $(grep -c NCCL $out/${tag}_rccl_run.log)" | tee -a $out/${tag}_rccl_20_runs.txt
+    if [ $rc -eq 0 ]; then ok=$((ok+1)); else bad=$((bad+1)); cp $out/${tag}_rccl_run.log $out/${tag}_rccl_run_FAILED_$k.log; fi
+  done
+  echo "ok=$ok bad=$bad" | tee -a $out/${tag}_rccl_20_runs.txt
+  grep "NCCL INFO" $out/${tag}_rccl_run.log | head -40 >> $out/${tag}_rccl_20_runs.txt
+  ;;
 *) echo "unknown step $step"; exit 2;;
 esac
