@@ -1687,7 +1687,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
     const int T = 256;
     PairSource src = src_in;
     src.n_pairs = n_work;
-    const size_t WC_OFF = 128 + MAX_ROUNDS * N_SORT_CLASSES, WC_PER_LAUNCH = 2 * WC_SHARDS, EARLY_OFF = WC_OFF + MAX_ROUNDS * 2 * WC_PER_LAUNCH, CNT_WORDS = EARLY_OFF + N_SORT_CLASSES;
+    const size_t WC_OFF = 128 + MAX_ROUNDS * N_SORT_CLASSES, WC_PER_LAUNCH = 2 * WC_SHARDS, EARLY_OFF = WC_OFF + MAX_ROUNDS * 2 * WC_PER_LAUNCH, CNT_WORDS = EARLY_OFF + 2 * N_SORT_CLASSES;
     SVXCHK(c->e_fail.reserve(CNT_WORDS * 8));
     unsigned long long* cnt = c->e_fail.as<unsigned long long>();        // [1] big pairs, [8..40] class bounds of round 0 (first [16..31] the span shards), [128 + 64 r ..] retry counters written by round r, [WC_OFF ..] word-column counters per (round, kind)
     HIPCHK(hipMemsetAsync(cnt, 0, CNT_WORDS * 8, st));
@@ -1818,9 +1818,12 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         // part's kernels have ended - their list entries are then visible - while the second part is still appending to the round's own lists: a counter of those
         // says how many entries have been CLAIMED, not how many have been written, and a store of a running kernel need not have left its XCD's L2.  Until round 6
         // both parts shared lists and the early launch took "what the counters say now": entries of the second part in flight among them.)
-        SVXCHK(fb.reserve((size_t)2 * N_SORT_CLASSES * (size_t)pending * 4 + 64));
-        uint32_t* const fb_early = fb.as<uint32_t>() + (size_t)N_SORT_CLASSES * (size_t)pending;
-        unsigned long long* const fail_cnt_early = cnt + EARLY_OFF;
+        SVXCHK(fb.reserve((size_t)3 * N_SORT_CLASSES * (size_t)pending * 4 + 64));
+        uint32_t* const fb_early[2] = {fb.as<uint32_t>() + (size_t)N_SORT_CLASSES * (size_t)pending, fb.as<uint32_t>() + (size_t)2 * N_SORT_CLASSES * (size_t)pending};
+        unsigned long long* const fail_cnt_early[2] = {cnt + EARLY_OFF, cnt + EARLY_OFF + N_SORT_CLASSES};
+        hipStream_t const early_st[2] = {c->aux[5], c->aux[7]};          // the early parts of the two alphabets, each a chain of its own (both high priority)
+        struct EarlyPost { unsigned long long ticket; int generic, set; };
+        std::vector<EarlyPost> early_posts;
         unsigned long long* fail_cnt = cnt + 128 + (size_t)round * N_SORT_CLASSES;
         unsigned long long* wc_band = cnt + WC_OFF + (size_t)(round * 2) * WC_PER_LAUNCH;
         unsigned long long* wc_full = wc_band + WC_PER_LAUNCH;
@@ -1888,7 +1891,39 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         // Round 0 launches its band classes in two parts, widest first: the pairs that fail the WIDEST bands are the long ones whose full matrices are
         // the serial tail of the next round, and they are known as soon as the first part is through - their full-matrix retries start right then,
         // beside the rest of the round (early_cn: what of every retry list has been launched already).
-        const int SPLIT_CLS = 7;                              // classes 7, 8 (14 / 16 words): the first part, and the only ones that need the 16-word kernel
+        // the band lists (lo / cn by sort class) of one alphabet as full matrices, one wave per pair (KIND_RETRY)
+        auto launch_retry_as_fulls = [&](int generic, const long long* lo, const long long* cn_of, const uint32_t* lst, hipStream_t fs, unsigned long long* wc) -> int {
+            const int base = GENERIC_BASE * generic;
+            FusedTab tf; memset(&tf, 0, sizeof tf);
+            unsigned nblk = 0;
+            for (int cls = NBAND - 1; cls >= 0; cls--) {
+                const long long cn = cn_of[base + cls];
+                if (cn <= 0) continue;
+                tf.kind[tf.n] = KIND_RETRY; tf.lo[tf.n] = lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
+                nblk += (unsigned)((cn * 64 + T - 1) / T); tf.n++;
+            }
+            tf.first_block[tf.n] = nblk;
+            if (!tf.n) return SVX_OK;
+            if (generic) k_edit_fulls<4><<<nblk, T, 0, fs>>>(tf, lst, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc);
+            else k_edit_fulls<2><<<nblk, T, 0, fs>>>(tf, lst, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc);
+            HIPCHK(hipGetLastError());
+            return SVX_OK;
+        };
+        // First class of the early part.  Classes 7, 8 (14 / 16 words) are always in it (the longest pairs; the only ones that need the 16-word kernel).  When classes
+        // 5 and 6 hold a real share of the band work (configs[1]: 27 %, the long related pairs; >= 8 % by the proxy pairs x words^2) they join it as a second launch
+        // on the early stream (12-word kernel): their failures - full matrices of 3000-5000 rows - then start in the middle of the round instead of at its end
+        // (12.7 -> 12.4 ms on configs[1]).  Where they hold next to nothing (the HiFi-like stand-in: 2 %) the extra launch only delays that stream (5.0 -> 6.2 ms there):
+        // profiles/r06_edit_split_class_ab.txt.  SVX_EDIT_SPLIT_CLS pins it (7 = classes 7, 8 alone).
+        int SPLIT_CLS = 7;
+        if (round == 0) {
+            double early56 = 0, all = 0;
+            for (int generic = 0; generic <= 1; generic++) for (int cls = 0; cls < NBAND; cls++) {
+                const double wgt = (double)seg_cn[GENERIC_BASE * generic + cls] * band_words(cls) * band_words(cls);
+                all += wgt; if (cls == 5 || cls == 6) early56 += wgt;
+            }
+            if (all > 0 && early56 >= 0.08 * all) SPLIT_CLS = 5;
+            if (const char* e = getenv("SVX_EDIT_SPLIT_CLS")) { const int v = atoi(e); if (v >= 1 && v <= 7) SPLIT_CLS = v; }
+        }
         bool split_used[2] = {false, false};
         long long band_pending = 0;
         for (int generic = 0; generic <= 1; generic++) for (int cls = 0; cls < NBAND; cls++) band_pending += seg_cn[GENERIC_BASE * generic + cls];
@@ -1896,36 +1931,24 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         for (int generic = 0; generic <= 1; generic++) {
             const int base = GENERIC_BASE * generic;
             if (bands_as_fulls) {
-                // the band lists of this alphabet as full matrices, one wave per pair (KIND_RETRY), one launch beside the round's full-matrix launch
-                FusedTab tf; memset(&tf, 0, sizeof tf);
-                unsigned nblk = 0;
-                for (int cls = NBAND - 1; cls >= 0; cls--) {
-                    const long long cn = seg_cn[base + cls];
-                    if (cn <= 0) continue;
-                    tf.kind[tf.n] = KIND_RETRY; tf.lo[tf.n] = seg_lo[base + cls]; tf.cn[tf.n] = cn; tf.first_block[tf.n] = nblk;
-                    nblk += (unsigned)((cn * 64 + T - 1) / T); tf.n++;
-                }
-                tf.first_block[tf.n] = nblk;
-                if (tf.n) {
-                    hipStream_t fs = full_st[(round + 1) & 1];        // (beside the round's own full-matrix launch, not behind it)
-                    if (generic) k_edit_fulls<4><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc_full);
-                    else k_edit_fulls<2><<<nblk, T, 0, fs>>>(tf, list, scratch, desc, slot_of, ed_dev, cnt + 1, c->e_big_list.as<uint32_t>(), wc_full);
-                    HIPCHK(hipGetLastError());
-                }
+                // the band lists of this alphabet as full matrices, beside the round's full-matrix launch (not behind it)
+                SVXCHK(launch_retry_as_fulls(generic, seg_lo, seg_cn, list, full_st[(round + 1) & 1], wc_full));
                 SVXCHK(launch_fulls(generic, seg_lo, seg_cn, list, full_st[round & 1], wc_full, round));
                 continue;
             }
             bool any_wide = false, any_narrow = false;
             for (int cls = 0; cls < NBAND; cls++) if (seg_cn[base + cls] > 0) { if (cls >= SPLIT_CLS) any_wide = true; else any_narrow = true; }
             const bool split = round == 0 && !serial && any_wide && any_narrow && !getenv("SVX_EDIT_NO_EARLY");
-            for (int part = 0; part < (split ? 2 : 1); part++) {
+            for (int part3 = 0; part3 < (split ? 3 : 1); part3++) {
+                // (split: part3 0 = classes 7, 8; 1 = SPLIT_CLS .. 6, both "part 0" = the early part on its own stream; 2 = the rest)
+                const int part = split ? (part3 < 2 ? 0 : 1) : 0;
                 FusedTab tb; memset(&tb, 0, sizeof tb);
                 tb.narrow = narrow_windows;
                 unsigned nblk = 0;
                 for (int cls = NBAND - 1; cls >= 0; cls--) {                          // widest band first
                     const long long cn = seg_cn[base + cls];
                     if (cn <= 0) continue;
-                    if (split && (part == 0) != (cls >= SPLIT_CLS)) continue;
+                    if (split && (part3 == 0 ? cls < 7 : (part3 == 1 ? (cls >= 7 || cls < SPLIT_CLS) : cls >= SPLIT_CLS))) continue;
                     tb.kind[tb.n] = cls; tb.lo[tb.n] = seg_lo[base + cls]; tb.cn[tb.n] = cn; tb.first_block[tb.n] = nblk;
                     nblk += (unsigned)((cn + T - 1) / T); tb.n++;
                 }
@@ -1934,12 +1957,13 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                 band_used[generic] = true;
                 if (serial) HIPCHK(hipEventRecord(c->ev[6], band_st[generic]));
                 // the first part (few, long pairs: latency) on a stream of its own, so that the second does not wait for it
-                hipStream_t bs = (split && part == 0) ? c->aux[5] : band_st[generic];
+                hipStream_t bs = (split && part == 0) ? early_st[generic] : band_st[generic];
                 // the kernel built for 12 state words keeps more waves per SIMD: every launch without the two widest classes takes it
                 bool wide16 = false;
                 for (int k = 0; k < tb.n; k++) if (band_words(tb.kind[k]) > 12) wide16 = true;
-                unsigned long long* const fc = (split && part == 0) ? fail_cnt_early : fail_cnt;
-                uint32_t* const fl = (split && part == 0) ? fb_early : fb.as<uint32_t>();
+                // (each launch of the early part has lists of its own: everything it failed is launched when IT has ended)
+                unsigned long long* const fc = (split && part == 0) ? fail_cnt_early[part3] : fail_cnt;
+                uint32_t* const fl = (split && part == 0) ? fb_early[part3] : fb.as<uint32_t>();
                 if (generic) {
                     if (wide16) k_edit_bands<4, 16><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fc, fl, pending, wc_band);
                     else k_edit_bands<4, 12><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fc, fl, pending, wc_band);
@@ -1948,7 +1972,13 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                     else k_edit_bands<2, 12><<<nblk, T, 0, bs>>>(tb, list, scratch, desc, slot_of, ed_dev, fc, fl, pending, wc_band);
                 }
                 HIPCHK(hipGetLastError());
-                if (split && part == 0) split_used[generic] = true;
+                if (split && part == 0) {
+                    split_used[generic] = true;
+                    MailSrc ms; memset(&ms, 0, sizeof ms); ms.k = 1; ms.p[0] = fail_cnt_early[part3] + base; ms.n[0] = GENERIC_BASE;
+                    EarlyPost ep; ep.generic = generic; ep.set = part3;
+                    SVXCHK(svx_mail_post(c, bs, ms, &ep.ticket));                     // behind this launch on its stream
+                    early_posts.push_back(ep);
+                }
                 if (serial) {                                                        // SVX_EDIT_SERIAL=1: stand-alone kernel durations for profiling
                     HIPCHK(hipEventRecord(c->ev[7], band_st[generic]));
                     HIPCHK(hipStreamSynchronize(band_st[generic]));
@@ -1993,21 +2023,19 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
                 }
             }
         }
-        long long early_cn[N_SORT_CLASSES];
-        for (int sc = 0; sc < N_SORT_CLASSES; sc++) early_cn[sc] = 0;
-        if (split_used[0] || split_used[1]) {
-            unsigned long long h[N_SORT_CLASSES];
-            SVXCHK(svx_mail_read(c, c->aux[5], fail_cnt_early, N_SORT_CLASSES, h));        // posted behind the first part(s) on their (high-priority) stream: their kernels have ended
-            long long e_lo[N_SORT_CLASSES];
-            for (int sc = 0; sc < N_SORT_CLASSES; sc++) {
-                e_lo[sc] = (long long)sc * pending;
-                const int cls = sc % GENERIC_BASE;
-                early_cn[sc] = split_used[sc / GENERIC_BASE] ? (long long)h[sc] : 0;       // (a pair that fails the widest bands goes to a full-matrix class: band_retry)
-                if (cls < NBAND && early_cn[sc]) return svx_fail(SVX_E_STATE, "a pair of the widest band classes retried in a band class", __FILE__, __LINE__, hipSuccess);
-            }
+        // the early parts, in the order they end: everything such a launch failed - full-matrix classes in their forms, band classes (class 4..6 can fail into class 8)
+        // as one-wave-per-pair full matrices - starts now, beside the rest of the round
+        for (int set = 0; set < 2; set++) for (const EarlyPost& ep : early_posts) {
+            if (ep.set != set) continue;
+            const unsigned long long* w = nullptr;
+            SVXCHK(svx_mail_wait(c, early_st[ep.generic], ep.ticket, &w));
+            long long e_lo[N_SORT_CLASSES], e_cn[N_SORT_CLASSES];
+            for (int sc = 0; sc < N_SORT_CLASSES; sc++) { e_lo[sc] = (long long)sc * pending; e_cn[sc] = 0; }
+            for (int k = 0; k < GENERIC_BASE; k++) e_cn[GENERIC_BASE * ep.generic + k] = (long long)w[k];
             hipStream_t fs = full_st[(round + 1) & 1];
             unsigned long long* wc_next = cnt + WC_OFF + (size_t)((round + 1) * 2 + 1) * WC_PER_LAUNCH;
-            for (int generic = 0; generic <= 1; generic++) SVXCHK(launch_fulls(generic, e_lo, early_cn, fb_early, fs, wc_next, round + 1));
+            SVXCHK(launch_fulls(ep.generic, e_lo, e_cn, fb_early[ep.set], fs, wc_next, round + 1));
+            SVXCHK(launch_retry_as_fulls(ep.generic, e_lo, e_cn, fb_early[ep.set], fs, wc_next));
         }
         // only the band launches can hand pairs to the next round
         const long long cap = pending;
@@ -2016,7 +2044,7 @@ static int run_edit_pipeline(svx_ctx* c, long long n_work, const PairSource& src
         if (band_used[0] || band_used[1]) {
             // one post for the round: the main stream (idle during the rounds, not a low-priority one) waits for every band stream and sends the counters
             for (int g = 0; g <= 1; g++) if (band_used[g]) { HIPCHK(hipEventRecord(c->ev[22 + g], band_st[g])); HIPCHK(hipStreamWaitEvent(st, c->ev[22 + g], 0)); }
-            if (split_used[0] || split_used[1]) { HIPCHK(hipEventRecord(c->ev[19], c->aux[5])); HIPCHK(hipStreamWaitEvent(st, c->ev[19], 0)); }
+            for (int g = 0; g <= 1; g++) if (split_used[g]) { HIPCHK(hipEventRecord(c->ev[20 + g], early_st[g])); HIPCHK(hipStreamWaitEvent(st, c->ev[20 + g], 0)); }
             unsigned long long h[N_SORT_CLASSES];
             SVXCHK(svx_mail_read(c, st, fail_cnt, N_SORT_CLASSES, h));
             for (int sc = 0; sc < N_SORT_CLASSES; sc++) {

@@ -1,4 +1,3 @@
-echo "=== C: the edit tests of test_gpu_parity in file order (3 x)"
-for k in 1 2 3; do timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "edit_distance" 2>&1 | grep -v "^$" | tail -2; done
-bash tools/gpu_r06.sh suite r06P
-grep -n "FAILED\|ERROR" gpurun_out/r06P_pytest.txt | head
+export K="routes_do_not_change"
+export VARIANTS="tree tree@SVX_EDIT_SPLIT_CLS=7 tree@SVX_EDIT_SPLIT_CLS=5" WL="c1 c2 c4"
+bash tools/gpu_r06.sh quick r06W
