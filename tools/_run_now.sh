@@ -1,3 +1,4 @@
-export K="routes_do_not_change"
-export VARIANTS="tree tree@SVX_EDIT_SPLIT_CLS=7 tree@SVX_EDIT_SPLIT_CLS=5" WL="c1 c2 c4"
-bash tools/gpu_r06.sh quick r06W
+bash tools/gpu_r06.sh suite r06X
+grep -n "FAILED\|ERROR" gpurun_out/r06X_pytest.txt | head -5
+bash tools/gpu_r06.sh evidence r06
+echo 6371535 > gpurun_out/r06_evidence_commit.txt
