@@ -1591,6 +1591,10 @@ def test_device_bam_decode_regions_and_pipeline(eng, tmp_path, monkeypatch):
     dev.close()
     assert got_names == want_names
     assert _concat_batches(got) == _concat_batches(want)
+    # not only "equal to the host reader": the regions, in the order asked for, are the records the file was WRITTEN from (a region = every record of its contig)
+    truth = [r for t in (2, 0, 3, 1) if bai[t] is not None for r in recs if r.reference_id == t]
+    assert got_names == [r.query_name for r in truth]
+    H.assert_rows_are_the_written_records(_concat_batches(got), truth, "regions")
     o = H.options({"min_mapq": 20, "min_sv_size": 40, "max_sv_size": 20000, "segment_gap_tolerance": 10, "segment_overlap_tolerance": 5, "partition_max_distance": 1000,
                    "position_distance_normalizer": 900, "edit_distance_normalizer": 1.0, "cluster_max_distance": 0.5, "all_bnds": False})
     tabs = []
@@ -1631,6 +1635,10 @@ def test_device_batches_stay_valid_across_seek_and_rewind(tmp_path, monkeypatch)
     b, n = host.read_batch(37, 20, "coordinate")
     want_first = _concat_batches([host.batch_arrays(b)])
     host.close()
+    # the expectation itself is held to the records the file was written from: the first records of every contig asked for, and of the file after the rewind
+    for k, t in enumerate(order):
+        H.assert_rows_are_the_written_records(want[k], [r for r in recs if r.reference_id == t][:len(want[k])], "region of contig %d" % t)
+    H.assert_rows_are_the_written_records(want_first, recs[:len(want_first)], "after rewind")
     monkeypatch.setenv("SVX_BAM_DEV_CHUNK_BLOCKS", "2")
     dev = NativeBam(path, threads=2)
     dev.set_device_decode(0)
